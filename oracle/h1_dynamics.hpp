@@ -1,0 +1,305 @@
+// TEST INFRASTRUCTURE (oracle) -- CPU restatement of the reference's dynamics path; not shipped.
+//
+// Restates RobotUtils::rolloutOneStep (/root/reference/src/common/robot_utils.cpp:106-117), i.e. one
+// MuJoCo mj_step of the Unitree H1 (h1.xml) in the constraint-free regime (no contact, no joint-limit
+// constraint) with MuJoCo's semantics:
+//   * qpos = [p(3), quat wxyz(4), hinge(19)], qvel = [v_lin WORLD(3), omega BODY(3), hinge rate(19)]
+//   * quaternion normalised at the start of kinematics
+//   * ctrl clamped to ctrlrange, motor gear 1, passive hinge damping -d*qvel
+//   * semi-implicit Euler with implicit joint damping: (M + arm + h*D) qacc = tau - D v - bias
+//   * qvel += h*qacc; p += h*v_lin; quat <- normalize(quat (x) exp(h*omega)); hinge += h*rate
+// MuJoCo itself is not in /root/reference and not installed here => "parity unpinned" for this part;
+// it is pinned instead by physics identities and an independent Kane-method residual (tests/).
+// Everything is templated on the scalar so the same restatement yields exact Jacobians through
+// forward-mode AD (ad.hpp) -- the analytic counterpart of linearizeDynamicsFD (robot_utils.cpp:120-160),
+// which is also restated verbatim as a forward finite difference in ilqr_oracle.cpp.
+#pragma once
+#include <cmath>
+
+#include "ad.hpp"
+#include "h1_model_data.h"
+
+namespace orc {
+using std::cos;
+using std::sin;
+using std::sqrt;
+
+struct DynParams {
+  double h;     // timestep
+  double g[3];  // world gravity vector
+};
+
+// ---------- small dense helpers (row-major) ----------
+template <class T> inline void mat3_mul(const T* A, const T* B, T* C) {
+  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) { T s = A[3 * i] * B[j]; s += A[3 * i + 1] * B[3 + j]; s += A[3 * i + 2] * B[6 + j]; C[3 * i + j] = s; }
+}
+template <class T, class U> inline void mat3_vec(const T* A, const U* x, T* y) { for (int i = 0; i < 3; ++i) y[i] = A[3 * i] * x[0] + A[3 * i + 1] * x[1] + A[3 * i + 2] * x[2]; }
+template <class T, class U> inline void mat3T_vec(const T* A, const U* x, T* y) { for (int i = 0; i < 3; ++i) y[i] = A[i] * x[0] + A[3 + i] * x[1] + A[6 + i] * x[2]; }
+template <class T, class U> inline void cross3(const T* a, const U* b, T* c) { T c0 = a[1] * b[2] - a[2] * b[1]; T c1 = a[2] * b[0] - a[0] * b[2]; T c2 = a[0] * b[1] - a[1] * b[0]; c[0] = c0; c[1] = c1; c[2] = c2; }
+
+// unit quaternion (w,x,y,z) -> rotation matrix (body->world)
+template <class T> inline void quat_wxyz_to_R(const T& w, const T& x, const T& y, const T& z, T* R) {
+  R[0] = 1.0 - 2.0 * (y * y + z * z); R[1] = 2.0 * (x * y - w * z); R[2] = 2.0 * (x * z + w * y);
+  R[3] = 2.0 * (x * y + w * z); R[4] = 1.0 - 2.0 * (x * x + z * z); R[5] = 2.0 * (y * z - w * x);
+  R[6] = 2.0 * (x * z - w * y); R[7] = 2.0 * (y * z + w * x); R[8] = 1.0 - 2.0 * (x * x + y * y);
+}
+
+// rotation about principal axis a by angle th
+template <class T> inline void rot_axis(int a, const T& th, T* R) {
+  T c = cos(th), s = sin(th);
+  for (int i = 0; i < 9; ++i) R[i] = T(0.0);
+  if (a == 0) { R[0] = T(1.0); R[4] = c; R[5] = -s; R[7] = s; R[8] = c; }
+  else if (a == 1) { R[4] = T(1.0); R[0] = c; R[2] = s; R[6] = -s; R[8] = c; }
+  else { R[8] = T(1.0); R[0] = c; R[1] = -s; R[3] = s; R[4] = c; }
+}
+
+// joint placement of body i (>=1) in its parent: Rj = Rfix * Rot(axis, theta) (child->parent coords)
+template <class T> inline void joint_rot(int i, const T& th, const double (*rfix)[3][3], T* Rj) {
+  T Ra[9]; rot_axis(H1_AXIS[i], th, Ra);
+  for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) { T s = rfix[i][r][0] * Ra[c]; s += rfix[i][r][1] * Ra[3 + c]; s += rfix[i][r][2] * Ra[6 + c]; Rj[3 * r + c] = s; }
+}
+
+// ---------- spatial algebra, 6-vectors ordered [angular; linear] ----------
+// motion transform parent->child coordinates; E = Rj^T, r = child origin in parent coordinates
+template <class T> inline void xf_motion(const T* Rj, const double* r, const T* vp, T* vc) {
+  T t[3]; cross3(vp, r, t);  // omega_p x r
+  T lin[3] = {vp[3] + t[0], vp[4] + t[1], vp[5] + t[2]};
+  mat3T_vec(Rj, vp, vc); mat3T_vec(Rj, lin, vc + 3);
+}
+// force transform child->parent coordinates, accumulating
+template <class T> inline void xf_force_acc(const T* Rj, const double* r, const T* fc, T* fp) {
+  T n[3], f[3]; mat3_vec(Rj, fc, n); mat3_vec(Rj, fc + 3, f);
+  T rf[3]; T rr[3] = {T(r[0]), T(r[1]), T(r[2])}; cross3(rr, f, rf);
+  for (int k = 0; k < 3; ++k) { fp[k] += n[k] + rf[k]; fp[3 + k] += f[k]; }
+}
+// dense Plucker motion matrix X (6x6) parent->child
+template <class T> inline void plucker(const T* Rj, const double* r, T* X) {
+  T E[9]; for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) E[3 * i + j] = Rj[3 * j + i];
+  double rx[9] = {0, -r[2], r[1], r[2], 0, -r[0], -r[1], r[0], 0};
+  for (int i = 0; i < 36; ++i) X[i] = T(0.0);
+  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) {
+    X[6 * i + j] = E[3 * i + j]; X[6 * (i + 3) + (j + 3)] = E[3 * i + j];
+    T s = E[3 * i] * rx[j]; s += E[3 * i + 1] * rx[3 + j]; s += E[3 * i + 2] * rx[6 + j];
+    X[6 * (i + 3) + j] = -s;
+  }
+}
+template <class T> inline void crm(const T* v, const T* m, T* out) {  // v x m (motion)
+  T a[3], b[3], c[3]; cross3(v, m, a); cross3(v + 3, m, b); cross3(v, m + 3, c);
+  for (int k = 0; k < 3; ++k) { out[k] = a[k]; out[3 + k] = b[k] + c[k]; }
+}
+template <class T> inline void crf(const T* v, const T* f, T* out) {  // v x* f (force)
+  T a[3], b[3], c[3]; cross3(v, f, a); cross3(v + 3, f + 3, b); cross3(v, f + 3, c);
+  for (int k = 0; k < 3; ++k) { out[k] = a[k] + b[k]; out[3 + k] = c[k]; }
+}
+// spatial inertia about the body origin from (mass, com, inertia about com)
+inline void spatial_inertia(double m, const double* c, const double (*Ic)[3], double* I) {
+  double cx[9] = {0, -c[2], c[1], c[2], 0, -c[0], -c[1], c[0], 0};
+  for (int i = 0; i < 36; ++i) I[i] = 0.0;
+  double cc = c[0] * c[0] + c[1] * c[1] + c[2] * c[2];
+  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) {
+    I[6 * i + j] = Ic[i][j] + m * ((i == j ? cc : 0.0) - c[i] * c[j]);
+    I[6 * i + (3 + j)] = m * cx[3 * i + j];
+    I[6 * (3 + i) + j] = m * cx[3 * j + i];
+    I[6 * (3 + i) + (3 + j)] = (i == j) ? m : 0.0;
+  }
+}
+template <class T, class U> inline void mat6_vec(const U* A, const T* x, T* y) {
+  for (int i = 0; i < 6; ++i) { T s = x[0] * A[6 * i]; for (int j = 1; j < 6; ++j) s += x[j] * A[6 * i + j]; y[i] = s; }
+}
+// solve SPD 6x6 system A y = b (LDL^T without pivoting)
+template <class T> inline void solve6_spd(const T* A, const T* b, T* y) {
+  T L[36], d[6];
+  for (int j = 0; j < 6; ++j) {
+    T s = A[6 * j + j]; for (int k = 0; k < j; ++k) s -= L[6 * j + k] * L[6 * j + k] * d[k]; d[j] = s;
+    for (int i = j + 1; i < 6; ++i) { T t = A[6 * i + j]; for (int k = 0; k < j; ++k) t -= L[6 * i + k] * L[6 * j + k] * d[k]; L[6 * i + j] = t / d[j]; }
+  }
+  T z[6];
+  for (int i = 0; i < 6; ++i) { T s = b[i]; for (int k = 0; k < i; ++k) s -= L[6 * i + k] * z[k]; z[i] = s; }
+  for (int i = 0; i < 6; ++i) z[i] = z[i] / d[i];
+  for (int i = 5; i >= 0; --i) { T s = z[i]; for (int k = i + 1; k < 6; ++k) s -= L[6 * k + i] * y[k]; y[i] = s; }
+}
+
+// ---------- forward dynamics (articulated-body algorithm) in MuJoCo coordinates ----------
+// Input : quat_hat (unit, wxyz), theta[19], v (MuJoCo qvel, 25), tau[19] (hinge generalized forces),
+//         arm_eff (effective armature on hinges), gravity.
+// Output: qacc (MuJoCo convention, 25)
+template <class T>
+inline void forward_dynamics_mj(const T* quat_hat, const T* theta, const T* v, const T* tau, double arm_eff,
+                                const double* grav, T* qacc) {
+  double Isp[H1_NB][36];
+  for (int i = 0; i < H1_NB; ++i) spatial_inertia(H1_MASS[i], H1_COM[i], H1_INERTIA[i], Isp[i]);
+
+  T R0[9]; quat_wxyz_to_R(quat_hat[0], quat_hat[1], quat_hat[2], quat_hat[3], R0);
+  T Rj[H1_NB][9], vel[H1_NB][6], cb[H1_NB][6], IA[H1_NB][36], pA[H1_NB][6];
+  // base spatial velocity in body coordinates: (omega_body, R0^T v_lin_world)
+  for (int k = 0; k < 3; ++k) vel[0][k] = v[3 + k];
+  mat3T_vec(R0, v, vel[0] + 3);
+  for (int k = 0; k < 6; ++k) cb[0][k] = T(0.0);
+  for (int i = 0; i < H1_NB; ++i) {
+    if (i > 0) {
+      joint_rot(i, theta[i - 1], H1_RFIX, Rj[i]);
+      xf_motion(Rj[i], H1_POS[i], vel[H1_PARENT[i]], vel[i]);
+      T vJ[6]; for (int k = 0; k < 6; ++k) vJ[k] = T(0.0);
+      vJ[H1_AXIS[i]] = v[6 + i - 1];
+      vel[i][H1_AXIS[i]] += v[6 + i - 1];
+      crm(vel[i], vJ, cb[i]);
+    }
+    for (int k = 0; k < 36; ++k) IA[i][k] = T(Isp[i][k]);
+    T Iv[6]; mat6_vec(Isp[i], vel[i], Iv);
+    crf(vel[i], Iv, pA[i]);
+  }
+  T U[H1_NB][6], D[H1_NB], uu[H1_NB];
+  for (int i = H1_NB - 1; i >= 1; --i) {
+    const int a = H1_AXIS[i];
+    for (int k = 0; k < 6; ++k) U[i][k] = IA[i][6 * k + a];
+    D[i] = U[i][a] + arm_eff;
+    uu[i] = tau[i - 1] - pA[i][a];
+    T Ia[36], pa[6];
+    for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c) Ia[6 * r + c] = IA[i][6 * r + c] - U[i][r] * U[i][c] / D[i];
+    T Iac[6]; mat6_vec(Ia, cb[i], Iac);
+    for (int k = 0; k < 6; ++k) pa[k] = pA[i][k] + Iac[k] + U[i][k] * (uu[i] / D[i]);
+    // propagate to parent: IA_p += X^T Ia X ; pA_p += X^T pa
+    T X[36]; plucker(Rj[i], H1_POS[i], X);
+    T tmp[36];
+    for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c) { T s = Ia[6 * r] * X[c]; for (int k = 1; k < 6; ++k) s += Ia[6 * r + k] * X[6 * k + c]; tmp[6 * r + c] = s; }
+    const int p = H1_PARENT[i];
+    for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c) { T s = X[r] * tmp[c]; for (int k = 1; k < 6; ++k) s += X[6 * k + r] * tmp[6 * k + c]; IA[p][6 * r + c] += s; }
+    xf_force_acc(Rj[i], H1_POS[i], pa, pA[p]);
+  }
+  // base: a0' = X0 * (0, -g) = (0, -R0^T g); coordinate acceleration nu_dot = -IA^-1 pA - a0'
+  T a0p[6]; for (int k = 0; k < 3; ++k) a0p[k] = T(0.0);
+  T mg[3] = {T(-grav[0]), T(-grav[1]), T(-grav[2])};
+  mat3T_vec(R0, mg, a0p + 3);
+  T acc[H1_NB][6];
+  T rhs[6]; for (int k = 0; k < 6; ++k) rhs[k] = -pA[0][k];
+  solve6_spd(IA[0], rhs, acc[0]);  // gravity-offset spatial acceleration of the base
+  T nudot[6]; for (int k = 0; k < 6; ++k) nudot[k] = acc[0][k] - a0p[k];
+  for (int i = 1; i < H1_NB; ++i) {
+    const int a = H1_AXIS[i];
+    T ap[6]; xf_motion(Rj[i], H1_POS[i], acc[H1_PARENT[i]], ap);
+    for (int k = 0; k < 6; ++k) ap[k] += cb[i][k];
+    T s = uu[i]; for (int k = 0; k < 6; ++k) s -= U[i][k] * ap[k];
+    T qdd = s / D[i];
+    for (int k = 0; k < 6; ++k) acc[i][k] = ap[k];
+    acc[i][a] += qdd;
+    qacc[6 + i - 1] = qdd;
+  }
+  // MuJoCo convention: linear = world acceleration of the base origin = R0 (vdot_O + omega x v_O)
+  T wxv[3]; cross3(vel[0], vel[0] + 3, wxv);
+  T lin[3] = {nudot[3] + wxv[0], nudot[4] + wxv[1], nudot[5] + wxv[2]};
+  mat3_vec(R0, lin, qacc);
+  for (int k = 0; k < 3; ++k) qacc[3 + k] = nudot[k];
+}
+
+// ---------- inverse dynamics (RNEA) in MuJoCo coordinates: tau = M(q) qacc + bias(q,v) ----------
+// armature enters as arm * qacc on hinge rows. Used for qfrc_bias (gravity compensation,
+// robot_utils.cpp:844-866) and for the ABA o RNEA = id identity test.
+template <class T>
+inline void inverse_dynamics_mj(const T* quat_hat, const T* theta, const T* v, const T* qacc, double arm,
+                                const double* grav, T* tau) {
+  double Isp[H1_NB][36];
+  for (int i = 0; i < H1_NB; ++i) spatial_inertia(H1_MASS[i], H1_COM[i], H1_INERTIA[i], Isp[i]);
+  T R0[9]; quat_wxyz_to_R(quat_hat[0], quat_hat[1], quat_hat[2], quat_hat[3], R0);
+  T Rj[H1_NB][9], vel[H1_NB][6], acc[H1_NB][6], f[H1_NB][6];
+  for (int k = 0; k < 3; ++k) vel[0][k] = v[3 + k];
+  mat3T_vec(R0, v, vel[0] + 3);
+  // nu_dot: angular = qacc_ang ; linear = R0^T qacc_lin - omega x v_O ; plus gravity offset (0, -R0^T g)
+  T wxv[3]; cross3(vel[0], vel[0] + 3, wxv);
+  T t3[3]; mat3T_vec(R0, qacc, t3);
+  T mg[3] = {T(-grav[0]), T(-grav[1]), T(-grav[2])}; T g3[3]; mat3T_vec(R0, mg, g3);
+  for (int k = 0; k < 3; ++k) { acc[0][k] = qacc[3 + k]; acc[0][3 + k] = t3[k] - wxv[k] + g3[k]; }
+  for (int i = 0; i < H1_NB; ++i) {
+    if (i > 0) {
+      joint_rot(i, theta[i - 1], H1_RFIX, Rj[i]);
+      const int a = H1_AXIS[i], p = H1_PARENT[i];
+      xf_motion(Rj[i], H1_POS[i], vel[p], vel[i]);
+      T vJ[6]; for (int k = 0; k < 6; ++k) vJ[k] = T(0.0);
+      vJ[a] = v[6 + i - 1];
+      vel[i][a] += v[6 + i - 1];
+      T c[6]; crm(vel[i], vJ, c);
+      xf_motion(Rj[i], H1_POS[i], acc[p], acc[i]);
+      for (int k = 0; k < 6; ++k) acc[i][k] += c[k];
+      acc[i][a] += qacc[6 + i - 1];
+    }
+    T Iv[6], Ia[6], vIv[6]; mat6_vec(Isp[i], vel[i], Iv); mat6_vec(Isp[i], acc[i], Ia); crf(vel[i], Iv, vIv);
+    for (int k = 0; k < 6; ++k) f[i][k] = Ia[k] + vIv[k];
+  }
+  for (int i = H1_NB - 1; i >= 1; --i) {
+    tau[6 + i - 1] = f[i][H1_AXIS[i]] + arm * qacc[6 + i - 1];
+    xf_force_acc(Rj[i], H1_POS[i], f[i], f[H1_PARENT[i]]);
+  }
+  mat3_vec(R0, f[0] + 3, tau);  // force conjugate to world linear velocity
+  for (int k = 0; k < 3; ++k) tau[3 + k] = f[0][k];
+}
+
+// smooth cos(a/2), sin(a/2)/a as functions of s = a^2 (AD-safe at a = 0)
+template <class T> inline void half_angle_cs(const T& s, T& c, T& sn_over_a) {
+  if (val(s) < 1e-6) {
+    c = 1.0 - s / 8.0 + s * s / 384.0 - s * s * s / 46080.0;
+    sn_over_a = 0.5 - s / 48.0 + s * s / 3840.0 - s * s * s / 645120.0;
+  } else {
+    T a = sqrt(s); c = cos(a * 0.5); sn_over_a = sin(a * 0.5) / a;
+  }
+}
+
+// One dynamics step x_next = f(x, u): restates rolloutOneStep (robot_utils.cpp:106-117).
+template <class T>
+inline void h1_step(const T* x, const T* u, const DynParams& P, T* xn) {
+  const double h = P.h;
+  T qn = sqrt(x[3] * x[3] + x[4] * x[4] + x[5] * x[5] + x[6] * x[6]);
+  T qh[4] = {x[3] / qn, x[4] / qn, x[5] / qn, x[6] / qn};
+  T tau[H1_NU];
+  for (int i = 0; i < H1_NU; ++i) {
+    T ui = u[i];
+    if (val(ui) < H1_CTRLRANGE[i][0]) ui = T(H1_CTRLRANGE[i][0]);
+    if (val(ui) > H1_CTRLRANGE[i][1]) ui = T(H1_CTRLRANGE[i][1]);
+    tau[i] = ui - H1_DAMPING * x[H1_NQ + 6 + i];
+  }
+  T qacc[H1_NV];
+  forward_dynamics_mj(qh, x + 7, x + H1_NQ, tau, H1_ARMATURE + h * H1_DAMPING, P.g, qacc);
+  T vn[H1_NV];
+  for (int i = 0; i < H1_NV; ++i) { vn[i] = x[H1_NQ + i] + h * qacc[i]; xn[H1_NQ + i] = vn[i]; }
+  for (int k = 0; k < 3; ++k) xn[k] = x[k] + h * vn[k];
+  for (int i = 0; i < H1_NJ; ++i) xn[7 + i] = x[7 + i] + h * vn[6 + i];
+  // quat <- normalize(qh (x) exp(h * omega_body))
+  T s = (vn[3] * vn[3] + vn[4] * vn[4] + vn[5] * vn[5]) * (h * h);
+  T c, so; half_angle_cs(s, c, so);
+  T ew = c, ex = so * h * vn[3], ey = so * h * vn[4], ez = so * h * vn[5];
+  T rw = qh[0] * ew - qh[1] * ex - qh[2] * ey - qh[3] * ez;
+  T rx = qh[0] * ex + qh[1] * ew + qh[2] * ez - qh[3] * ey;
+  T ry = qh[0] * ey - qh[1] * ez + qh[2] * ew + qh[3] * ex;
+  T rz = qh[0] * ez + qh[1] * ey - qh[2] * ex + qh[3] * ew;
+  T rn = sqrt(rw * rw + rx * rx + ry * ry + rz * rz);
+  xn[3] = rw / rn; xn[4] = rx / rn; xn[5] = ry / rn; xn[6] = rz / rn;
+}
+
+// MuJoCo-side forward kinematics (MJCF constants): world rotation/position of every body frame.
+template <class T>
+inline void fk_mj(const T* x, T (*Rw)[9], T (*pw)[3]) {
+  T qn = sqrt(x[3] * x[3] + x[4] * x[4] + x[5] * x[5] + x[6] * x[6]);
+  quat_wxyz_to_R(x[3] / qn, x[4] / qn, x[5] / qn, x[6] / qn, Rw[0]);
+  for (int k = 0; k < 3; ++k) pw[0][k] = x[k];
+  for (int i = 1; i < H1_NB; ++i) {
+    const int p = H1_PARENT[i];
+    T Rj[9]; joint_rot(i, x[7 + i - 1], H1_RFIX, Rj);
+    mat3_mul(Rw[p], Rj, Rw[i]);
+    T t[3]; mat3_vec(Rw[p], H1_POS[i], t);
+    for (int k = 0; k < 3; ++k) pw[i][k] = pw[p][k] + t[k];
+  }
+}
+
+// RobotUtils::computeCoM (robot_utils.cpp:810-833): mass-weighted mean of MuJoCo xipos (MJCF masses)
+template <class T>
+inline void com_mj(const T* x, T* com) {
+  T Rw[H1_NB][9], pw[H1_NB][3];
+  fk_mj(x, Rw, pw);
+  double mtot = 0.0; for (int k = 0; k < 3; ++k) com[k] = T(0.0);
+  for (int i = 0; i < H1_NB; ++i) {
+    T c[3]; mat3_vec(Rw[i], H1_COM[i], c);
+    for (int k = 0; k < 3; ++k) com[k] += H1_MASS[i] * (pw[i][k] + c[k]);
+    mtot += H1_MASS[i];
+  }
+  for (int k = 0; k < 3; ++k) com[k] = com[k] / mtot;
+}
+
+}  // namespace orc

@@ -1,0 +1,375 @@
+#!/usr/bin/env python3
+"""Generate the committed golden fixtures under tests/golden/ (run in the BUILD container only).
+
+The reference (/root/reference) has no tests/golden outputs for this path and cannot be built or
+imported here (MuJoCo/Pinocchio/CasADi/Eigen absent) => these goldens are INDEPENDENT restatements
+written differently from oracle/ (which they pin), plus excerpts of the reference's own data files:
+
+  dynamics_golden.npz : one MuJoCo-semantics step computed by a world-frame Kane (virtual power)
+                        formulation in NumPy with constants parsed straight from h1.xml
+                        (oracle uses a body-frame articulated-body algorithm).
+  cost_golden.npz     : per-term gradient/Hessian of the six task terms via torch autograd (fp64) of
+                        an independently written torch FK with constants parsed from h1.urdf, the
+                        line-search cost (computeTotalCost) and the soft-limit penalties.
+  riccati_golden.npz  : NumPy restatement of iLQR::backwardPass (ilqr.cpp:250-309) on synthetic inputs
+                        incl. the LLT-failure branch.
+  refdata_golden.npz  : rows of data/q_ref2_mj.csv, data/v_ref2.csv (reference data files) used as a
+                        known-answer test of the state conventions.
+"""
+import math
+import os
+import xml.etree.ElementTree as ET
+
+import numpy as np
+import torch
+
+REF = "/root/reference"
+HERE = os.path.dirname(os.path.abspath(__file__))
+torch.set_default_dtype(torch.float64)
+
+
+# ----------------------------------------------------------------------------- model parsing
+def fl(s):
+    return np.array([float(t) for t in s.split()])
+
+
+def q2R(q):
+    w, x, y, z = np.asarray(q, dtype=float) / np.linalg.norm(q)
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
+                     [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                     [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+
+
+def load_mjcf():
+    root = ET.parse(os.path.join(REF, "robots/h1_description/mjcf/h1.xml")).getroot()
+    bodies = []
+
+    def rec(e, parent):
+        for b in e.findall("body"):
+            i = len(bodies)
+            ine = b.find("inertial")
+            j = b.find("joint")
+            Rq = q2R(fl(ine.get("quat", "1 0 0 0")))
+            bodies.append(dict(name=b.get("name"), parent=parent, pos=fl(b.get("pos", "0 0 0")), R=q2R(fl(b.get("quat", "1 0 0 0"))),
+                               m=float(ine.get("mass")), c=fl(ine.get("pos")), I=Rq @ np.diag(fl(ine.get("diaginertia"))) @ Rq.T,
+                               axis=None if j is None else fl(j.get("axis")), rng=None if j is None else fl(j.get("range"))))
+            rec(b, i)
+
+    rec(root.find("worldbody"), -1)
+    ctrl = [fl(m.get("ctrlrange")) for m in root.find("actuator").findall("motor")]
+    return bodies, np.array(ctrl)
+
+
+def load_urdf():
+    root = ET.parse(os.path.join(REF, "robots/h1_description/urdf/h1.urdf")).getroot()
+    links = {l.get("name"): l for l in root.findall("link")}
+    joints = [j for j in root.findall("joint") if j.get("type") == "revolute"]
+    order = ["pelvis"] + [j.find("child").get("link") for j in joints]
+    out = []
+    for name in order:
+        ine = links[name].find("inertial")
+        d = dict(name=name, m=float(ine.find("mass").get("value")), c=fl(ine.find("origin").get("xyz")))
+        if name == "pelvis":
+            d.update(parent=-1, pos=np.zeros(3), rpy=np.zeros(3), axis=None)
+        else:
+            j = [jj for jj in joints if jj.find("child").get("link") == name][0]
+            d.update(parent=order.index(j.find("parent").get("link")), pos=fl(j.find("origin").get("xyz")),
+                     rpy=fl(j.find("origin").get("rpy", "0 0 0")), axis=fl(j.find("axis").get("xyz")))
+        out.append(d)
+    return out
+
+
+# ----------------------------------------------------------------------------- Kane dynamics (numpy)
+def skew(a):
+    return np.array([[0, -a[2], a[1]], [a[2], 0, -a[0]], [-a[1], a[0], 0]])
+
+
+def axis_rot(axis, th):
+    K = skew(axis)
+    return np.eye(3) + math.sin(th) * K + (1 - math.cos(th)) * (K @ K)
+
+
+def kane_residual(bodies, q, v, qacc, grav, armature):
+    """Generalized inertia+bias forces F(qacc) = M qacc + bias in MuJoCo coordinates (world-frame Kane)."""
+    nb = len(bodies)
+    quat = q[3:7] / np.linalg.norm(q[3:7])
+    R = [None] * nb; p = [None] * nb; om = [None] * nb; al = [None] * nb; acc = [None] * nb; z = [None] * nb
+    R[0] = q2R(quat); p[0] = q[0:3].copy()
+    om[0] = R[0] @ v[3:6]; al[0] = R[0] @ qacc[3:6]; acc[0] = qacc[0:3].copy()
+    for i in range(1, nb):
+        b = bodies[i]; pa = b["parent"]
+        Rj = b["R"] @ axis_rot(b["axis"], q[7 + i - 1])
+        R[i] = R[pa] @ Rj
+        d = R[pa] @ b["pos"]
+        p[i] = p[pa] + d
+        z[i] = R[i] @ b["axis"]
+        qd, qdd = v[6 + i - 1], qacc[6 + i - 1]
+        om[i] = om[pa] + z[i] * qd
+        al[i] = al[pa] + np.cross(om[pa], z[i]) * qd + z[i] * qdd
+        acc[i] = acc[pa] + np.cross(al[pa], d) + np.cross(om[pa], np.cross(om[pa], d))
+    F = np.zeros(25)
+    for i in range(nb):
+        b = bodies[i]
+        e = R[i] @ b["c"]
+        ci = p[i] + e
+        ac = acc[i] + np.cross(al[i], e) + np.cross(om[i], np.cross(om[i], e))
+        Iw = R[i] @ b["I"] @ R[i].T
+        fl_ = b["m"] * (ac - grav)
+        tq = Iw @ al[i] + np.cross(om[i], Iw @ om[i])
+        # partial velocities of body i w.r.t. the generalized speeds
+        F[0:3] += fl_
+        F[3:6] += R[0].T @ (np.cross(ci - p[0], fl_) + tq)
+        a = i
+        while a > 0:
+            F[6 + a - 1] += z[a] @ (np.cross(ci - p[a], fl_) + tq)
+            a = bodies[a]["parent"]
+    F[6:] += armature * qacc[6:]
+    return F
+
+
+def kane_step(bodies, ctrlrange, x, u, h, grav, damping=1.0, armature=0.1):
+    q, v = x[:26].copy(), x[26:].copy()
+    bias = kane_residual(bodies, q, v, np.zeros(25), grav, armature)
+    M = np.stack([kane_residual(bodies, q, v, np.eye(25)[k], grav, armature) - bias for k in range(25)], axis=1)
+    D = np.concatenate([np.zeros(6), damping * np.ones(19)])
+    tau = np.concatenate([np.zeros(6), np.clip(u, ctrlrange[:, 0], ctrlrange[:, 1])])
+    qacc = np.linalg.solve(M + h * np.diag(D), tau - D * v - bias)
+    vn = v + h * qacc
+    qn = q.copy()
+    qn[0:3] += h * vn[0:3]
+    qn[7:] += h * vn[6:]
+    quat = q[3:7] / np.linalg.norm(q[3:7])
+    w = vn[3:6]; ang = np.linalg.norm(w) * h
+    e = np.array([1.0, 0, 0, 0]) if ang < 1e-15 else np.concatenate([[math.cos(ang / 2)], math.sin(ang / 2) * w / np.linalg.norm(w)])
+    a, b = quat, e
+    r = np.array([a[0] * b[0] - a[1:] @ b[1:], *(a[0] * b[1:] + b[0] * a[1:] + np.cross(a[1:], b[1:]))])
+    qn[3:7] = r / np.linalg.norm(r)
+    return np.concatenate([qn, vn]), qacc, M, bias
+
+
+def gen_dynamics():
+    bodies, ctrl = load_mjcf()
+    rng = np.random.default_rng(123)
+    xs, us, gs, xn, qa = [], [], [], [], []
+    for k in range(6):
+        x = np.zeros(51); x[2] = 1.0432; x[3] = 1.0
+        if k > 0:
+            x[0:3] += rng.uniform(-0.1, 0.1, 3)
+            qq = rng.normal(size=4); x[3:7] = qq / np.linalg.norm(qq) if k > 2 else x[3:7]
+            x[7:26] = rng.uniform(-0.4, 0.4, 19)
+            x[26:] = rng.uniform(-1.0, 1.0, 25) * (0.0 if k == 1 else 1.0)
+        u = rng.uniform(-30, 30, 19)
+        if k == 4:
+            u[3] = 500.0; u[13] = -100.0  # exercise ctrl clamping
+        g = np.array([0, 0, -9.81]) if k % 2 == 0 else np.array([0.0, 0.0, -1.0])
+        if k == 5:
+            x[3:7] *= 1.3  # un-normalised quaternion input (normalised inside kinematics)
+        xnext, qacc, M, bias = kane_step(bodies, ctrl, x, u, 0.02, g)
+        xs.append(x); us.append(u); gs.append(g); xn.append(xnext); qa.append(qacc)
+    np.savez(os.path.join(HERE, "dynamics_golden.npz"), x=np.array(xs), u=np.array(us), gravity=np.array(gs), x_next=np.array(xn), qacc=np.array(qa), h=0.02)
+    print("dynamics golden: M cond", np.linalg.cond(M))
+
+
+# ----------------------------------------------------------------------------- torch cost terms
+def t_axis_rot(k, th):
+    c, s = torch.cos(th), torch.sin(th)
+    o, z = torch.ones(()), torch.zeros(())
+    if k == 0:
+        rows = [[o, z, z], [z, c, -s], [z, s, c]]
+    elif k == 1:
+        rows = [[c, z, s], [z, o, z], [-s, z, c]]
+    else:
+        rows = [[c, -s, z], [s, c, z], [z, z, o]]
+    return torch.stack([torch.stack(r) for r in rows])
+
+
+def rpy_R(rpy):
+    r, p, y = rpy
+    Rx = np.array([[1, 0, 0], [0, math.cos(r), -math.sin(r)], [0, math.sin(r), math.cos(r)]])
+    Ry = np.array([[math.cos(p), 0, math.sin(p)], [0, 1, 0], [-math.sin(p), 0, math.cos(p)]])
+    Rz = np.array([[math.cos(y), -math.sin(y), 0], [math.sin(y), math.cos(y), 0], [0, 0, 1]])
+    return Rz @ Ry @ Rx
+
+
+class PinTorch:
+    """Pinocchio-convention FK (free-flyer + revolute), spatial velocities propagated body-frame
+    the way pinocchio::forwardKinematics does, written directly in torch."""
+
+    def __init__(self):
+        self.L = load_urdf()
+
+    def fk(self, xp):
+        L = self.L
+        qx, qy, qz, qw = xp[3], xp[4], xp[5], xp[6]
+        R0 = torch.stack([
+            torch.stack([1 - 2 * (qy * qy + qz * qz), 2 * (qx * qy - qw * qz), 2 * (qx * qz + qw * qy)]),
+            torch.stack([2 * (qx * qy + qw * qz), 1 - 2 * (qx * qx + qz * qz), 2 * (qy * qz - qw * qx)]),
+            torch.stack([2 * (qx * qz - qw * qy), 2 * (qy * qz + qw * qx), 1 - 2 * (qx * qx + qy * qy)])])
+        oR = [R0]; op = [xp[0:3]]
+        vl = [xp[26:29]]; va = [xp[29:32]]  # body-frame spatial velocity (linear, angular)
+        for i in range(1, len(L)):
+            b = L[i]; pa = b["parent"]
+            k = int(np.argmax(np.abs(b["axis"])))
+            Rj = torch.tensor(rpy_R(b["rpy"])) @ t_axis_rot(k, xp[7 + i - 1])
+            pj = torch.tensor(b["pos"])
+            oR.append(oR[pa] @ Rj)
+            op.append(op[pa] + oR[pa] @ pj)
+            # v_i = liMi.actInv(v_parent) + S qd
+            w_p, v_p = va[pa], vl[pa]
+            lin = Rj.T @ (v_p + torch.linalg.cross(w_p, pj))
+            ang = Rj.T @ w_p + torch.tensor(np.eye(3)[k]) * xp[26 + 6 + i - 1]
+            vl.append(lin); va.append(ang)
+        return oR, op, vl, va
+
+    def com(self, xp, with_vel=False):
+        L = self.L
+        oR, op, vl, va = self.fk(xp)
+        M = sum(b["m"] for b in L)
+        c = sum(b["m"] * (op[i] + oR[i] @ torch.tensor(b["c"])) for i, b in enumerate(L)) / M
+        if not with_vel:
+            return c
+        vc = sum(b["m"] * (oR[i] @ (vl[i] + torch.linalg.cross(va[i], torch.tensor(b["c"])))) for i, b in enumerate(L)) / M
+        return c, vc
+
+    def frame(self, xp, idx):
+        oR, op, vl, va = self.fk(xp)
+        return op[idx], oR[idx] @ vl[idx]  # position; LOCAL_WORLD_ALIGNED linear velocity
+
+
+def gen_costs():
+    pin = PinTorch()
+    rng = np.random.default_rng(7)
+    out = {}
+    xs = []
+    for k in range(3):
+        x = np.zeros(51); x[2] = 1.0432; x[3] = 1.0
+        x[0:3] += rng.uniform(-0.05, 0.05, 3)
+        qq = np.array([1.0, 0, 0, 0]) + rng.uniform(-0.2, 0.2, 4) * (k > 0); x[3:7] = qq / np.linalg.norm(qq)
+        x[7:26] = rng.uniform(-0.3, 0.3, 19)
+        x[26:] = rng.uniform(-0.5, 0.5, 25)
+        xs.append(x)
+    xs = np.array(xs)
+    refs = dict(com=np.array([0.01, -0.02, 0.95]), comvel=np.array([0.1, 0.0, -0.05]), ee=np.array([0.03, 0.21, 0.08]),
+                ps=np.array([0.02, 0.01]))
+    w = dict(com=100.0, comvel=7.0, eepos=400.0, eevel=400.0, upright=20.0, balance=30.0)
+
+    def perm(x):
+        xp = x.clone(); xp[3], xp[4], xp[5], xp[6] = x[4], x[5], x[6], x[3]
+        return xp
+
+    terms = {
+        "com": lambda xp: w["com"] * ((pin.com(xp) - torch.tensor(refs["com"])) ** 2).sum(),
+        "comvel": lambda xp: w["comvel"] * ((pin.com(xp, True)[1] - torch.tensor(refs["comvel"])) ** 2).sum(),
+        "eepos_L": lambda xp: w["eepos"] * ((pin.frame(xp, 5)[0] - torch.tensor(refs["ee"])) ** 2).sum(),
+        "eepos_R": lambda xp: w["eepos"] * ((pin.frame(xp, 10)[0] - torch.tensor(refs["ee"] * np.array([1, -1, 1]))) ** 2).sum(),
+        "eevel_L": lambda xp: w["eevel"] * (pin.frame(xp, 5)[1] ** 2).sum(),
+        "eevel_R": lambda xp: w["eevel"] * (pin.frame(xp, 10)[1] ** 2).sum(),
+    }
+
+    def upright(xp):  # derivatives.cpp:646-666 (slot labelling quirk kept)
+        qw, qx, qy, qz = xp[3], xp[4], xp[5], xp[6]
+        r = torch.stack([2 * (qx * qz + qw * qy), 2 * (qy * qz - qw * qx), (1 - 2 * (qx * qx + qy * qy)) - 1.0])
+        return 0.5 * w["upright"] * (r ** 2).sum()
+
+    def balance(xp):  # derivatives.cpp:668-707
+        c, vc = pin.com(xp, True)
+        om = torch.sqrt(c[2] / 9.81)
+        r = c[0:2] + vc[0:2] * om - torch.tensor(refs["ps"])
+        return 0.5 * w["balance"] * (r ** 2).sum()
+
+    terms["upright"] = upright
+    terms["balance"] = balance
+    for name, f in terms.items():
+        G, H = [], []
+        for x in xs:
+            xp = perm(torch.tensor(x)).requires_grad_(True)
+            g = torch.autograd.grad(f(xp), xp)[0]
+            Hm = torch.autograd.functional.hessian(f, perm(torch.tensor(x)))
+            G.append(g.numpy()); H.append(Hm.numpy())
+        out["grad_" + name] = np.array(G); out["hess_" + name] = np.array(H)
+    out["x"] = xs
+    for k, v in refs.items():
+        out["ref_" + k] = v
+    for k, v in w.items():
+        out["w_" + k] = v
+
+    # MuJoCo-side quantities for computeTotalCost: CoM with MJCF masses, true-quaternion upright
+    bodies, ctrl = load_mjcf()
+    coms, ees = [], []
+    for x in xs:
+        nb = len(bodies); R = [None] * nb; p = [None] * nb
+        R[0] = q2R(x[3:7]); p[0] = x[0:3]
+        for i in range(1, nb):
+            b = bodies[i]; pa = b["parent"]
+            R[i] = R[pa] @ b["R"] @ axis_rot(b["axis"], x[7 + i - 1]); p[i] = p[pa] + R[pa] @ b["pos"]
+        M = sum(b["m"] for b in bodies)
+        coms.append(sum(b["m"] * (p[i] + R[i] @ b["c"]) for i, b in enumerate(bodies)) / M)
+        ees.append(np.stack([p[5], p[10]]))
+    out["com_mj"] = np.array(coms); out["ee_mj"] = np.array(ees)
+    out["jrange"] = np.array([b["rng"] for b in bodies[1:]]); out["ctrlrange"] = ctrl
+    np.savez(os.path.join(HERE, "cost_golden.npz"), **out)
+    print("cost golden written:", sorted(k for k in out if k.startswith("hess_")))
+
+
+# ----------------------------------------------------------------------------- Riccati (numpy)
+def riccati_numpy(A, B, lx, lu, lxx, luu, lam):
+    """ilqr.cpp:250-309 with NumPy (np.linalg.cholesky for the LLT check, np.linalg.solve for ldlt().solve)."""
+    N = A.shape[0]; n, m = B.shape[1], B.shape[2]
+    Vx, Vxx = lx[N].copy(), lxx[N].copy()
+    K = np.zeros((N, m, n)); k = np.zeros((N, m)); bumped = []
+    for t in range(N - 1, -1, -1):
+        Qx = lx[t] + A[t].T @ Vx
+        Qu = lu[t] + B[t].T @ Vx
+        Qxx = lxx[t] + A[t].T @ Vxx @ A[t]
+        Quu = np.diag(luu[t]) + B[t].T @ Vxx @ B[t]
+        Qxu = A[t].T @ Vxx @ B[t]
+        Quu = Quu + lam * np.eye(m)
+        try:
+            np.linalg.cholesky(Quu)
+        except np.linalg.LinAlgError:
+            Quu = Quu + 1e-4 * np.eye(m); bumped.append(t)
+        K[t] = -np.linalg.solve(Quu, Qxu.T)
+        k[t] = -np.linalg.solve(Quu, Qu)
+        Vx = Qx + K[t].T @ Quu @ k[t] + K[t].T @ Qu + Qxu @ k[t]
+        Vxx = Qxx + K[t].T @ Quu @ K[t] + K[t].T @ Qxu.T + Qxu @ K[t]
+        Vxx = 0.5 * (Vxx + Vxx.T)
+    return K, k, Vx, Vxx, bumped
+
+
+def gen_riccati():
+    rng = np.random.default_rng(99)
+    N, n, m = 6, 51, 19
+    cases = {}
+    for name in ("spd", "bump"):
+        A = np.eye(n)[None] + 0.05 * rng.normal(size=(N, n, n))
+        B = 0.1 * rng.normal(size=(N, n, m))
+        lx = rng.normal(size=(N + 1, n)); lu = rng.normal(size=(N, m))
+        lxx = np.zeros((N + 1, n, n))
+        for t in range(N + 1):
+            G = rng.normal(size=(n, n)); lxx[t] = G @ G.T / n + np.diag(rng.uniform(1, 100, n))
+        luu = rng.uniform(1e-3, 1e-2, size=(N, m))
+        if name == "bump":  # indefinite terminal Hessian + tiny R -> Quu not PD at some knots
+            lxx[N] = lxx[N] - 2.0 * np.diag(np.diag(lxx[N])); luu[:] = 1e-9
+        K, k, Vx, Vxx, bumped = riccati_numpy(A, B, lx, lu, lxx, luu, 1e-6)
+        cases[name] = dict(A=A, B=B, lx=lx, lu=lu, lxx=lxx, luu=luu, K=K, k=k, Vx=Vx, Vxx=Vxx, bumped=np.array(bumped, dtype=np.int64))
+        print("riccati", name, "bumped knots", bumped, "|K|max", np.abs(K).max())
+    flat = {f"{c}_{k}": v for c, d in cases.items() for k, v in d.items()}
+    np.savez_compressed(os.path.join(HERE, "riccati_golden.npz"), lam=1e-6, **flat)
+
+
+# ----------------------------------------------------------------------------- reference data excerpt
+def gen_refdata():
+    q = np.loadtxt(os.path.join(REF, "data/q_ref2_mj.csv"), delimiter=",")
+    v = np.loadtxt(os.path.join(REF, "data/v_ref2.csv"), delimiter=",")
+    qp = np.loadtxt(os.path.join(REF, "data/q_ref2_pin.csv"), delimiter=",")
+    cw = np.loadtxt(os.path.join(REF, "data/contact_walking.csv"), delimiter=",", skiprows=1).astype(np.int32)
+    rows = slice(0, 80)
+    np.savez_compressed(os.path.join(HERE, "refdata_golden.npz"), q_ref2_mj=q[rows], v_ref2=v[rows], q_ref2_pin=qp[rows], contact_walking=cw[rows], dt=0.02)
+    print("refdata rows", q[rows].shape, v[rows].shape)
+
+
+if __name__ == "__main__":
+    gen_dynamics()
+    gen_costs()
+    gen_riccati()
+    gen_refdata()

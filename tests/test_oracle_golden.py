@@ -1,0 +1,263 @@
+"""Pin the CPU oracle (oracle/) against the committed independent goldens (tests/golden/).
+No GPU needed.  See tests/golden/gen_golden.py for how each fixture was produced."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+from conftest import load_package
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+sc = load_package().scenario
+
+
+def test_dynamics_step_vs_kane_golden():
+    d = np.load(os.path.join(G, "dynamics_golden.npz"))
+    o = ol.Oracle(25, float(d["h"]))
+    for x, u, g, xn in zip(d["x"], d["u"], d["gravity"], d["x_next"]):
+        prob = sc.make_problem(ol.reference_kinematics, gravity=g)
+        o.set_problem(prob)
+        got = o.step(x, u)
+        assert np.allclose(got, xn, rtol=0, atol=1e-10), np.abs(got - xn).max()
+
+
+def test_aba_rnea_identity_and_mass_matrix():
+    rng = np.random.default_rng(0)
+    g = np.array([0, 0, -9.81])
+    for _ in range(5):
+        x = sc.standing_state()
+        x[7:26] = rng.uniform(-0.5, 0.5, 19)
+        q = rng.normal(size=4)
+        x[3:7] = q / np.linalg.norm(q)
+        x[26:] = rng.uniform(-2, 2, 25)
+        tau = rng.uniform(-30, 30, 19)
+        qacc = ol.forward_dynamics(x, tau, 0.12, g)
+        back = ol.inverse_dynamics(x, qacc, 0.12, g)
+        assert np.abs(back[:6]).max() < 1e-9
+        assert np.abs(back[6:] - tau).max() < 1e-9
+    x0 = x.copy()
+    x0[26:] = 0
+    bias = ol.inverse_dynamics(x0, np.zeros(25), 0.0, g)
+    M = np.array([ol.inverse_dynamics(x0, np.eye(25)[i], 0.0, g) - bias for i in range(25)]).T
+    assert np.abs(M - M.T).max() < 1e-10
+    assert np.linalg.eigvalsh(0.5 * (M + M.T)).min() > 0
+    assert abs(M[0, 0] - 51.649896) < 1e-6 and abs(M[2, 2] - 51.649896) < 1e-6  # total MJCF mass
+
+
+def test_energy_conservation_without_damping_and_gravity_momentum():
+    # free flight, zero gravity, zero torque: v'_lin of the CoM stays constant (momentum conservation)
+    o = ol.Oracle(25, 0.002)
+    prob = sc.make_problem(ol.reference_kinematics, gravity=(0.0, 0.0, 0.0))
+    o.set_problem(prob)
+    rng = np.random.default_rng(1)
+    x = sc.standing_state()
+    x[26:] = rng.uniform(-0.5, 0.5, 25)
+    # damping torque is internal -> linear momentum of the whole robot is conserved exactly in continuous time
+    com0, _ = ol.reference_kinematics(x)
+    xs = [x]
+    for _ in range(50):
+        xs.append(o.step(xs[-1], np.zeros(19)))
+    coms = np.array([ol.reference_kinematics(s)[0] for s in xs])
+    vel = np.diff(coms, axis=0) / 0.002
+    assert np.abs(vel - vel[0]).max() < 5e-3 * max(1.0, np.abs(vel[0]).max())
+
+
+def test_state_conventions_against_reference_data_files():
+    """Known-answer test on the reference's own data files:
+    data/v_ref2.csv == differentiatePos(data/q_ref2_mj.csv, 0.02) with world-frame linear velocity,
+    BODY-frame angular velocity (log of q_t^-1 (x) q_{t+1}) and plain joint differences; and
+    q_ref2_mj is q_ref2_pin with the quaternion reordered xyzw -> wxyz."""
+    d = np.load(os.path.join(G, "refdata_golden.npz"))
+    q, v, dt = d["q_ref2_mj"], d["v_ref2"], float(d["dt"])
+    assert np.array_equal(d["q_ref2_pin"][:, [6, 3, 4, 5]], q[:, 3:7])
+    for t in range(q.shape[0] - 1):
+        qa, qb = q[t, 3:7], q[t + 1, 3:7]
+        ca = qa * np.array([1, -1, -1, -1])
+        dq = np.concatenate([[ca[0] * qb[0] - ca[1:] @ qb[1:]], ca[0] * qb[1:] + qb[0] * ca[1:] + np.cross(ca[1:], qb[1:])])
+        s = np.linalg.norm(dq[1:])
+        speed = 2 * np.arctan2(s, dq[0])
+        if speed > np.pi:
+            speed -= 2 * np.pi
+        w = (dq[1:] / s if s > 1e-15 else np.zeros(3)) * speed / dt
+        assert np.abs((q[t + 1, :3] - q[t, :3]) / dt - v[t, :3]).max() < 1e-9
+        assert np.abs((q[t + 1, 7:] - q[t, 7:]) / dt - v[t, 6:]).max() < 1e-9
+        assert np.abs(w - v[t, 3:6]).max() < 1e-9
+        # and the oracle's integrator inverts it: quat_t (x) exp(dt * w) == quat_{t+1} (up to the CSV's 6 digits)
+        x = np.zeros(51); x[:26] = q[t]; x[26:] = v[t]
+        ang = np.linalg.norm(w) * dt
+        e = np.array([1.0, 0, 0, 0]) if ang < 1e-14 else np.concatenate([[np.cos(ang / 2)], np.sin(ang / 2) * w / np.linalg.norm(w)])
+        a = qa / np.linalg.norm(qa)
+        r = np.concatenate([[a[0] * e[0] - a[1:] @ e[1:]], a[0] * e[1:] + e[0] * a[1:] + np.cross(a[1:], e[1:])])
+        assert np.abs(r - qb / np.linalg.norm(qb)).max() < 1e-9
+
+
+def _golden_problem(c, **weights):
+    cfg = dict(sc.SHIPPED_CONFIG)
+    cfg.update(W_com_pos=0.0, W_com_vel=0.0, W_foot=0.0, W_foot_vel=0.0, W_upright=0.0, w_balance=0.0)
+    cfg.update(weights)
+    prob = sc.make_problem(ol.reference_kinematics, cfg=cfg)
+    # zero out tracking so only the task term remains
+    prob["Q"] = np.zeros(51); prob["Qf"] = np.zeros(51); prob["R"] = np.zeros(19)
+    prob["w_joint"] = 0.0; prob["w_ctrl"] = 0.0
+    return prob
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_cost_terms_vs_torch_autograd_golden(mode):
+    c = np.load(os.path.join(G, "cost_golden.npz"))
+    o = ol.Oracle(25, 0.02)
+    t = 3
+
+    def check(prob, names):
+        o.set_problem(prob)
+        for i, x in enumerate(c["x"]):
+            lx, lu, lxx, luu = o.knot_quadratics(t, x, np.zeros(19), mode)
+            g = sum(c["grad_" + n][i] for n in names)
+            H = sum(c["hess_" + n][i] for n in names)
+            assert np.abs(lx - g).max() <= 1e-9 * max(1.0, np.abs(g).max()), (names, np.abs(lx - g).max())
+            assert np.abs(lxx - H).max() <= 1e-9 * max(1.0, np.abs(H).max()), (names, np.abs(lxx - H).max())
+
+    p = _golden_problem(c, W_com_pos=float(c["w_com"]))
+    p["com_ref"][:] = c["ref_com"]
+    check(p, ["com"])
+    p = _golden_problem(c, W_com_vel=float(c["w_comvel"]))
+    p["com_vel_ref"][:] = c["ref_comvel"]
+    check(p, ["comvel"])
+    p = _golden_problem(c, W_foot=float(c["w_eepos"]))
+    p["stance"][:] = 0
+    p["ee_ref"][0, :, 0] = c["ref_ee"]
+    p["ee_ref"][0, :, 1] = c["ref_ee"] * np.array([1, -1, 1])
+    check(p, ["eepos_L", "eepos_R"])
+    p = _golden_problem(c, W_foot_vel=float(c["w_eevel"]))
+    check(p, ["eevel_L", "eevel_R"])
+    p["stance"][0, :, 1] = 0
+    check(p, ["eevel_L"])
+    p = _golden_problem(c, W_upright=float(c["w_upright"]))
+    check(p, ["upright"])
+    p = _golden_problem(c, w_balance=float(c["w_balance"]))
+    # support point = mean of the foot refs (both stance)
+    p["ee_ref"][0, :, 0, :2] = c["ref_ps"] + np.array([0.0, 0.1])
+    p["ee_ref"][0, :, 1, :2] = c["ref_ps"] - np.array([0.0, 0.1])
+    check(p, ["balance"])
+
+
+def test_total_cost_and_reference_kinematics_vs_golden():
+    c = np.load(os.path.join(G, "cost_golden.npz"))
+    for i, x in enumerate(c["x"]):
+        com, ee = ol.reference_kinematics(x)
+        assert np.abs(com - c["com_mj"][i]).max() < 1e-12
+        assert np.abs(ee - c["ee_mj"][i]).max() < 1e-12
+    # computeTotalCost restated independently in numpy (ilqr.cpp:363-518) on a short random trajectory
+    rng = np.random.default_rng(5)
+    N = 4
+    o = ol.Oracle(N, 0.02)
+    prob = sc.make_problem(ol.reference_kinematics, N=N)
+    o.set_problem(prob)
+    xs = np.tile(sc.standing_state(), (N + 1, 1)) + 0.05 * rng.normal(size=(N + 1, 51))
+    xs[:, 3:7] /= np.linalg.norm(xs[:, 3:7], axis=1, keepdims=True)
+    xs[2, 7 + 3] = 2.0   # knee beyond its soft limit
+    us = rng.uniform(-50, 50, size=(N, 19))
+    us[1, 4] = 39.0      # ankle torque beyond the 10 % margin
+    o.set_trajectory(xs, us)
+    Q, R, Qf = prob["Q"], prob["R"], prob["Qf"]
+    wu, wb = prob["task_weights"][4], prob["task_weights"][5]
+    jr, cr = c["jrange"], c["ctrlrange"]
+
+    def pen(val, rng_, w):
+        lo = rng_[:, 0] + 0.1 * (rng_[:, 1] - rng_[:, 0]); hi = rng_[:, 1] - 0.1 * (rng_[:, 1] - rng_[:, 0])
+        return w * (np.maximum(val - hi, 0) ** 2 + np.maximum(lo - val, 0) ** 2).sum()
+
+    tot = 0.0
+    for t in range(N + 1):
+        x = xs[t]; e = x - prob["x_ref"][0, t]
+        tot += 0.5 * e @ ((Qf if t == N else Q) * e)
+        if t < N:
+            eu = us[t] - prob["u_ref"][0, t]; tot += 0.5 * eu @ (R * eu)
+        qw, qx, qy, qz = x[3:7]
+        r = np.array([2 * (qx * qz + qw * qy), 2 * (qy * qz - qw * qx), 1 - 2 * (qx * qx + qy * qy) - 1.0])
+        tot += 0.5 * wu * r @ r
+        com, _ = ol.reference_kinematics(x)
+        ps = 0.5 * (prob["ee_ref"][0, t, 0, :2] + prob["ee_ref"][0, t, 1, :2])
+        rb = com[:2] + x[26:28] * np.sqrt(com[2] / 9.81) - ps
+        tot += 0.5 * wb * rb @ rb
+        tot += pen(x[7:26], jr, prob["w_joint"]) + pen(us[t] if t < N else np.zeros(19), cr, prob["w_ctrl"])
+    assert abs(o.total_cost() - tot) < 1e-9 * abs(tot)
+
+
+@pytest.mark.parametrize("case", ["spd", "bump"])
+def test_backward_pass_vs_numpy_golden(case):
+    r = np.load(os.path.join(G, "riccati_golden.npz"))
+    A, B = r[case + "_A"], r[case + "_B"]
+    N = A.shape[0]
+    o = ol.Oracle(N, 0.02)
+    o.set_options(lam=float(r["lam"]))
+    o.set_linearization(A, B)
+    o.set_quadratics(r[case + "_lx"], r[case + "_lu"], r[case + "_lxx"], r[case + "_luu"])
+    o.backward_pass()
+    for name, key in (("K", "K"), ("kff", "k"), ("Vx", "Vx"), ("Vxx", "Vxx")):
+        got, want = o.get(name), r[case + "_" + key]
+        tol = 1e-9 if case == "spd" else 1e-6
+        assert np.abs(got - want).max() <= tol * max(1.0, np.abs(want).max()), (name, np.abs(got - want).max())
+
+
+def test_analytic_jacobians_vs_finite_differences():
+    o = ol.Oracle(2, 0.02)
+    prob = sc.make_problem(ol.reference_kinematics, N=2)
+    o.set_problem(prob)
+    rng = np.random.default_rng(3)
+    x = sc.standing_state()
+    x[7:26] = rng.uniform(-0.3, 0.3, 19)
+    x[3:7] = sc._axis_angle_quat(rng.uniform(-0.5, 0.5, 3))
+    x[26:] = rng.uniform(-1, 1, 25)
+    u = rng.uniform(-5, 5, 19)
+    o.set_trajectory(np.tile(x, (3, 1)), np.tile(u, (2, 1)))
+    o.set_options(jac_mode=0)
+    o.linearize()
+    A0, B0 = o.get("A")[0], o.get("B")[0]
+    eps = 1e-6
+    Ac = np.stack([(o.step(x + eps * np.eye(51)[j], u) - o.step(x - eps * np.eye(51)[j], u)) / (2 * eps) for j in range(51)], axis=1)
+    Bc = np.stack([(o.step(x, u + eps * np.eye(19)[j]) - o.step(x, u - eps * np.eye(19)[j])) / (2 * eps) for j in range(19)], axis=1)
+    assert np.abs(A0 - Ac).max() < 1e-7 and np.abs(B0 - Bc).max() < 1e-7
+    # the quaternion block annihilates the radial direction (normalisation inside the step)
+    assert np.abs(A0[:, 3:7] @ x[3:7]).max() < 1e-10
+    o.set_options(jac_mode=1, fd_eps=1e-5)  # reference-style forward differences (robot_utils.cpp:120-160)
+    o.linearize()
+    assert np.abs(o.get("A")[0] - A0).max() < 5e-5 and np.abs(o.get("B")[0] - B0).max() < 1e-7
+
+
+def test_solve_control_flow_and_trace():
+    o = ol.Oracle(25, 0.02)
+    prob = sc.make_problem(ol.reference_kinematics)
+    o.set_problem(prob)
+    ug = o.grav_comp(sc.standing_state())
+    x0, ui = sc.synthetic_batch(2, 25, 0, ug)
+    o.set_options()
+    o.initialize(x0[0], ui[0])
+    ok, cost = o.solve(x0[0])
+    it, tc, al, lam = o.trace()
+    assert ok and 1 <= it <= 10
+    assert np.all(np.diff(tc[: it + 1]) <= 1e-12)        # monotone: line search only accepts decreases
+    assert abs(tc[it] - cost) == 0.0
+    assert np.all(np.isin(al[:it], [0.0, 1.0, 0.8, 0.6, 0.4, 0.2, 0.1, 0.05, 0.01]))
+    # closed-form quadratics and AD quadratics give the same solve
+    o2 = ol.Oracle(25, 0.02)
+    o2.set_problem(prob)
+    o2.set_options(quad_mode=1, max_iter=2)
+    o2.initialize(x0[0], ui[0])
+    o2.solve(x0[0])
+    o.set_options(max_iter=2)
+    o.initialize(x0[0], ui[0])
+    o.solve(x0[0])
+    assert np.abs(o.get("K") - o2.get("K")).max() < 1e-7 * np.abs(o.get("K")).max()
+    # warm start shift (ilqr.cpp:68-80)
+    xb, ub = o.get("xbar"), o.get("ubar")
+    o.initialize(xb[1], None, xb, ub)
+    xs, us = o.get("xbar"), o.get("ubar")
+    assert np.array_equal(us[:-1], ub[1:]) and np.array_equal(us[-1], ub[-1])
+    assert np.array_equal(xs[1:-1], xb[2:]) and np.array_equal(xs[0], xb[1])
+    assert np.allclose(xs[-1], o.step(xs[-2], us[-1]), atol=0)
+    # control law (mpc.cpp:97-101)
+    o.solve(xb[1])
+    xm = o.get("xbar")[0] + 1e-3
+    assert np.allclose(o.compute_control(xm), o.get("ubar")[0] + o.get("K")[0] @ (xm - o.get("xbar")[0]))
