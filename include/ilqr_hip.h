@@ -1,0 +1,152 @@
+/*
+ * ilqr_hip.h -- C ABI of the MI355X-native batched iLQR solver (libilqr_hip.so).
+ *
+ * Drop-in boundary for the reference's MPC_iLQR_solve path.  The reference has no FFI; its boundary
+ * is the C++ class API of `iLQR` / `MPC` / `RobotUtils`.  Every entry point below cites the
+ * reference interface it replaces (paths relative to the reference repository root).
+ * A batch of B independent rollouts (same robot, same horizon) is solved per handle; B = 1
+ * reproduces the reference call-for-call (see include/ilqr_hip.hpp for the C++ mirror classes).
+ *
+ * Conventions: row-major doubles in caller-owned HOST buffers unless a name ends in `_device`;
+ * state x = [qpos(26): p, quat wxyz, hinge(19) | qvel(25): v_lin world, omega body, hinge rates];
+ * nx = 51, nu = 19; N = horizon.  "set" arrays may be shared by all rollouts (n_sets == 1) or
+ * given per rollout (n_sets == batch).  All functions return ILQR_OK (0) or an error code;
+ * no exceptions cross the ABI; calls on one handle must be serialised by the caller; one handle
+ * per GPU.  There is NO CPU fallback: creating a handle without a HIP device fails.
+ */
+#ifndef ILQR_HIP_H
+#define ILQR_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ILQR_NX 51
+#define ILQR_NU 19
+#define ILQR_NQ 26
+#define ILQR_NV 25
+
+enum ilqr_status {
+  ILQR_OK = 0,
+  ILQR_ERR_ARG = 1,         /* null pointer / bad size (reference: size check, src/ilqr/ilqr.cpp:526-532) */
+  ILQR_ERR_HIP = 2,         /* HIP runtime error, see ilqr_hip_last_error */
+  ILQR_ERR_NO_DEVICE = 3,   /* no usable gfx950 device */
+  ILQR_ERR_STATE = 4,       /* call order violated (e.g. solve before initialize) */
+  ILQR_ERR_UNSUPPORTED = 5
+};
+
+enum ilqr_jacobian_mode {
+  ILQR_JAC_ANALYTIC = 0,    /* exact derivatives of the dynamics step (north-star mode) */
+  ILQR_JAC_FD_FORWARD = 1   /* reference-style forward differences, RobotUtils::linearizeDynamicsFD,
+                               src/common/robot_utils.cpp:120-160 (eps default 1e-5, robot_utils.hpp:51-53) */
+};
+
+typedef struct ilqr_hip_ctx ilqr_hip_ctx;
+
+/* iLQR::iLQR(RobotUtils&, int N, double dt, urdf) -- include/ilqr/ilqr.hpp:19, src/ilqr/ilqr.cpp:14-48.
+   The H1 model constants (h1.xml / h1.urdf) are compiled in.  device = HIP device ordinal. */
+int ilqr_hip_create(ilqr_hip_ctx** out, int device, int batch, int horizon, double dt);
+int ilqr_hip_destroy(ilqr_hip_ctx* ctx);
+const char* ilqr_hip_last_error(const ilqr_hip_ctx* ctx);
+int ilqr_hip_batch(const ilqr_hip_ctx* ctx);
+int ilqr_hip_horizon(const ilqr_hip_ctx* ctx);
+
+/* RobotUtils::setCostWeights -- include/common/robot_utils.hpp:60, src/common/robot_utils.cpp:253-279.
+   Q/R/Qf are diagonal by construction (Config::buildCostMatrices, src/common/config.cpp:66-122). */
+int ilqr_hip_set_cost_weights(ilqr_hip_ctx* ctx, const double* Q_diag /*51*/, const double* R_diag /*19*/, const double* Qf_diag /*51*/);
+/* RobotUtils::set{CoM,CoMVel,EEPos,EEVel,Upright,Balance}Weight -- include/common/robot_utils.hpp:120-129 */
+int ilqr_hip_set_task_weights(ilqr_hip_ctx* ctx, double w_com, double w_com_vel, double w_ee_pos, double w_ee_vel, double w_upright, double w_balance);
+/* RobotUtils::setConstraintWeights -- src/common/robot_utils.cpp:674-680 */
+int ilqr_hip_set_constraint_weights(ilqr_hip_ctx* ctx, double w_joint_limits, double w_control_limits);
+/* RobotUtils::setGravity -- src/common/robot_utils.cpp:782-789 */
+int ilqr_hip_set_gravity(ilqr_hip_ctx* ctx, double gx, double gy, double gz);
+/* RobotUtils::loadContactSchedule / isStance -- src/common/robot_utils.cpp:445-504; horizon-local rows 0..N
+   (the reference indexes the schedule with the horizon-local t). stance[n_sets][N+1][2] */
+int ilqr_hip_set_contact_schedule(ilqr_hip_ctx* ctx, const int* stance, int n_sets);
+/* RobotUtils::getEEReference / getCoMVelReference -- src/common/robot_utils.cpp:525-549.
+   ee_ref[n_sets][N+1][2][3] (left, right ankle), com_vel_ref[n_sets][N+1][3] (may be NULL -> zeros) */
+int ilqr_hip_set_ee_references(ilqr_hip_ctx* ctx, const double* ee_ref, const double* com_vel_ref, int n_sets);
+/* reference window handed to solve(): x_ref[n_sets][N+1][51], u_ref[n_sets][N][19], com_ref[n_sets][N+1][3]
+   (MPC::extractReferenceWindow, src/ilqr/mpc.cpp:163-166) */
+int ilqr_hip_set_references(ilqr_hip_ctx* ctx, const double* x_ref, const double* u_ref, const double* com_ref, int n_sets);
+
+/* iLQR::setRegularization / setMaxIterations / setTolerance -- include/ilqr/ilqr.hpp:22-24.
+   setRegularization resets every rollout's lambda (lambda persists across solves, ilqr.hpp:54). */
+int ilqr_hip_set_regularization(ilqr_hip_ctx* ctx, double lambda);
+int ilqr_hip_set_max_iterations(ilqr_hip_ctx* ctx, int max_iter);
+int ilqr_hip_set_tolerance(ilqr_hip_ctx* ctx, double tol);
+/* build-specific options: Jacobian mode, FD step, early_exit (0 = run exactly max_iter iterations) */
+int ilqr_hip_set_options(ilqr_hip_ctx* ctx, int jacobian_mode, double fd_eps, int early_exit);
+
+/* iLQR::initializeWithReference -- include/ilqr/ilqr.hpp:40-45, src/ilqr/ilqr.cpp:50-117.
+   x0[B][51]; cold start: u_init[B][N][19] or NULL (gravity compensation, RobotUtils::computeGravComp,
+   src/common/robot_utils.cpp:844-866 with the correct dof index) followed by N rollouts;
+   warm start: prev_xbar[B][N+1][51], prev_ubar[B][N][19] shifted by one knot (ilqr.cpp:68-80). */
+int ilqr_hip_initialize(ilqr_hip_ctx* ctx, const double* x0, const double* u_init, const double* prev_xbar, const double* prev_ubar);
+/* warm start from the solver's own previous solution kept on the device (MPC::stepOnce, src/ilqr/mpc.cpp:58-60) */
+int ilqr_hip_initialize_warm_resident(ilqr_hip_ctx* ctx, const double* x0);
+/* device-resident variant of the cold start: x0_device[B][51], u_init_device[B][N][19] are HIP device pointers */
+int ilqr_hip_initialize_device(ilqr_hip_ctx* ctx, const double* x0_device, const double* u_init_device);
+
+/* iLQR::solve -- include/ilqr/ilqr.hpp:27-31, src/ilqr/ilqr.cpp:521-660.  References are the ones last set
+   with ilqr_hip_set_references; x0[B][51] (host) or NULL to reuse the x0 given to initialize.
+   cost_out[B] may be NULL.  Runs asynchronously on the handle's stream and synchronises before returning. */
+int ilqr_hip_solve(ilqr_hip_ctx* ctx, const double* x0, double* cost_out);
+/* enqueue only (no host synchronisation, nothing copied back); pair with ilqr_hip_synchronize */
+int ilqr_hip_solve_async(ilqr_hip_ctx* ctx);
+int ilqr_hip_synchronize(ilqr_hip_ctx* ctx);
+
+/* accessors: iLQR::xbar/ubar/gainsK/gainsKff -- include/ilqr/ilqr.hpp:34-37 */
+int ilqr_hip_get_xbar(ilqr_hip_ctx* ctx, double* xbar /*[B][N+1][51]*/);
+int ilqr_hip_get_ubar(ilqr_hip_ctx* ctx, double* ubar /*[B][N][19]*/);
+int ilqr_hip_get_gains_K(ilqr_hip_ctx* ctx, double* K /*[B][N][19][51]*/);
+int ilqr_hip_get_gains_kff(ilqr_hip_ctx* ctx, double* kff /*[B][N][19]*/);
+int ilqr_hip_get_cost(ilqr_hip_ctx* ctx, double* cost /*[B]*/);
+int ilqr_hip_get_iterations(ilqr_hip_ctx* ctx, int* iters /*[B]*/);
+int ilqr_hip_get_lambda(ilqr_hip_ctx* ctx, double* lambda /*[B]*/);
+/* per-iteration trace (parity artefact; the reference keeps these internal):
+   cost[B][max_iter+1] (entry 0 = initial cost), alpha[B][max_iter] (0 = no step), lambda[B][max_iter] */
+int ilqr_hip_get_trace(ilqr_hip_ctx* ctx, double* cost, double* alpha, double* lambda);
+/* first-knot results gathered per MPC step: u0[B][19], K0[B][19][51] (either may be NULL); device pointers */
+int ilqr_hip_first_knot_device(ilqr_hip_ctx* ctx, const double** u0_device, const double** K0_device, const double** cost_device);
+
+/* MPC::stepOnce control law u = ubar[0] + K[0](x_meas - xbar[0]) -- src/ilqr/mpc.cpp:97-101 */
+int ilqr_hip_compute_control(ilqr_hip_ctx* ctx, const double* x_measured /*[B][51]*/, double* u_apply /*[B][19]*/);
+
+/* ---- stage entry points (one reference function each; used by the parity tests and the bench breakdown) ---- */
+int ilqr_hip_set_trajectory(ilqr_hip_ctx* ctx, const double* xbar, const double* ubar);   /* overwrite nominal trajectory */
+int ilqr_hip_stage_rollout(ilqr_hip_ctx* ctx);          /* iLQR::forwardRolloutNominal, src/ilqr/ilqr.cpp:119-124 (+ total cost) */
+int ilqr_hip_stage_linearize(ilqr_hip_ctx* ctx);        /* iLQR::computeLinearization, src/ilqr/ilqr.cpp:126-131 */
+int ilqr_hip_stage_cost_quadratics(ilqr_hip_ctx* ctx);  /* iLQR::computeCostQuadratics, src/ilqr/ilqr.cpp:133-244 */
+int ilqr_hip_stage_backward_pass(ilqr_hip_ctx* ctx);    /* iLQR::backwardPass, src/ilqr/ilqr.cpp:250-309 */
+int ilqr_hip_stage_line_search(ilqr_hip_ctx* ctx, int* improved /*[B]*/, double* new_cost /*[B]*/, double* alpha /*[B]*/); /* ilqr.cpp:311-361 */
+int ilqr_hip_stage_total_cost(ilqr_hip_ctx* ctx, double* cost /*[B]*/);  /* iLQR::computeTotalCost, src/ilqr/ilqr.cpp:363-518 */
+int ilqr_hip_get_linearization(ilqr_hip_ctx* ctx, double* A /*[B][N][51][51]*/, double* B /*[B][N][51][19]*/);
+int ilqr_hip_set_linearization(ilqr_hip_ctx* ctx, const double* A, const double* B);
+int ilqr_hip_get_quadratics(ilqr_hip_ctx* ctx, double* lx /*[B][N+1][51]*/, double* lu /*[B][N][19]*/, double* lxx /*[B][N+1][51][51]*/, double* luu_diag /*[B][N][19]*/);
+int ilqr_hip_set_quadratics(ilqr_hip_ctx* ctx, const double* lx, const double* lu, const double* lxx, const double* luu_diag);
+int ilqr_hip_get_value_function(ilqr_hip_ctx* ctx, double* Vx /*[B][51]*/, double* Vxx /*[B][51][51]*/); /* at knot 0 after the backward pass */
+/* one dynamics step for arbitrary (x,u) pairs: RobotUtils::rolloutOneStep, src/common/robot_utils.cpp:106-117 */
+int ilqr_hip_step(ilqr_hip_ctx* ctx, int count, const double* x /*[count][51]*/, const double* u /*[count][19]*/, double* x_next /*[count][51]*/);
+
+/* per-stage device time of the last solve in milliseconds, keyed like the reference's profiler
+   (src/ilqr/ilqr.cpp:537-639): 0 computeCost/rollout, 1 linearization, 2 costQuadratics, 3 backwardPass,
+   4 lineSearch, 5 control; requires ilqr_hip_enable_profiling(ctx, 1) before the solve */
+int ilqr_hip_enable_profiling(ilqr_hip_ctx* ctx, int on);
+int ilqr_hip_get_stage_ms(ilqr_hip_ctx* ctx, double* ms /*[6]*/, double* launches /*[6]*/);
+
+/* ---- host-side model helpers (no GPU needed) ---- */
+/* reference construction as RobotUtils::loadReferences does it (src/common/robot_utils.cpp:369-403):
+   whole-body CoM (MuJoCo masses) and world positions of the two ankle bodies */
+int ilqr_hip_reference_kinematics(const double* x /*51*/, double* com /*3*/, double* ee /*[2][3]*/);
+/* RobotUtils::computeGravComp (src/common/robot_utils.cpp:844-866, correct dof index): qfrc_bias[6+i] at v = 0 */
+int ilqr_hip_gravity_compensation(const double* x /*51*/, const double* gravity /*3*/, double* u /*19*/);
+
+/* the HIP stream the handle launches on (as void*), for event timing by the caller */
+void* ilqr_hip_stream(ilqr_hip_ctx* ctx);
+/* name/duration of the dominant kernel of the last profiled solve are reported by bench.py via hipEvents */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ILQR_HIP_H */

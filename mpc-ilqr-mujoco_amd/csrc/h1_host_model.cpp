@@ -1,0 +1,71 @@
+// Host-side H1 kinematics used to build references the way the reference's loader does
+// (RobotUtils::loadReferences, reference src/common/robot_utils.cpp:369-403: whole-body CoM from
+// MuJoCo masses, ankle body positions) and the gravity-compensation cold start
+// (RobotUtils::computeGravComp, reference src/common/robot_utils.cpp:844-866, with the correct dof
+// index -- SURVEY.md Appendix D #8).  World-frame formulation, MJCF constants.
+#include <cmath>
+
+#include "h1_model_data.h"
+#include "h1_host_model.h"
+
+namespace h1host {
+
+static void quat_R(const double* q, double* R) {
+  const double n = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  const double w = q[0] / n, x = q[1] / n, y = q[2] / n, z = q[3] / n;
+  R[0] = 1 - 2 * (y * y + z * z); R[1] = 2 * (x * y - w * z); R[2] = 2 * (x * z + w * y);
+  R[3] = 2 * (x * y + w * z); R[4] = 1 - 2 * (x * x + z * z); R[5] = 2 * (y * z - w * x);
+  R[6] = 2 * (x * z - w * y); R[7] = 2 * (y * z + w * x); R[8] = 1 - 2 * (x * x + y * y);
+}
+static void mul33(const double* A, const double* B, double* C) {
+  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) C[3 * i + j] = A[3 * i] * B[j] + A[3 * i + 1] * B[3 + j] + A[3 * i + 2] * B[6 + j];
+}
+static void mv(const double* A, const double* x, double* y) { for (int i = 0; i < 3; ++i) y[i] = A[3 * i] * x[0] + A[3 * i + 1] * x[1] + A[3 * i + 2] * x[2]; }
+
+void forward_kinematics(const double* x, double (*Rw)[9], double (*pw)[3]) {
+  quat_R(x + 3, Rw[0]);
+  for (int k = 0; k < 3; ++k) pw[0][k] = x[k];
+  for (int i = 1; i < H1_NB; ++i) {
+    const int p = H1_PARENT[i], a = H1_AXIS[i];
+    const double th = x[7 + i - 1], c = std::cos(th), s = std::sin(th);
+    double Ra[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    const int b = (a + 1) % 3, d = (a + 2) % 3;
+    Ra[3 * b + b] = c; Ra[3 * b + d] = -s; Ra[3 * d + b] = s; Ra[3 * d + d] = c;
+    double Rj[9]; mul33(&H1_RFIX[i][0][0], Ra, Rj);
+    mul33(Rw[p], Rj, Rw[i]);
+    double t[3]; mv(Rw[p], H1_POS[i], t);
+    for (int k = 0; k < 3; ++k) pw[i][k] = pw[p][k] + t[k];
+  }
+}
+
+void reference_kinematics(const double* x, double* com, double* ee) {
+  double Rw[H1_NB][9], pw[H1_NB][3];
+  forward_kinematics(x, Rw, pw);
+  double m = 0.0; com[0] = com[1] = com[2] = 0.0;
+  for (int i = 0; i < H1_NB; ++i) {
+    double c[3]; mv(Rw[i], H1_COM[i], c);
+    for (int k = 0; k < 3; ++k) com[k] += H1_MASS[i] * (pw[i][k] + c[k]);
+    m += H1_MASS[i];
+  }
+  for (int k = 0; k < 3; ++k) { com[k] /= m; ee[k] = pw[H1_EE_LEFT][k]; ee[3 + k] = pw[H1_EE_RIGHT][k]; }
+}
+
+// qfrc_bias[6+j] at zero velocity = minus the generalized gravity force on hinge j
+void gravity_compensation(const double* x, const double* g, double* u) {
+  double Rw[H1_NB][9], pw[H1_NB][3];
+  forward_kinematics(x, Rw, pw);
+  for (int j = 1; j < H1_NB; ++j) {
+    const double z[3] = {Rw[j][H1_AXIS[j]], Rw[j][3 + H1_AXIS[j]], Rw[j][6 + H1_AXIS[j]]};
+    double q = 0.0;
+    for (int i = j; i < H1_NB; ++i) {
+      if (!H1_ANC[j - 1][i - 1]) continue;
+      double c[3]; mv(Rw[i], H1_COM[i], c);
+      const double d[3] = {pw[i][0] + c[0] - pw[j][0], pw[i][1] + c[1] - pw[j][1], pw[i][2] + c[2] - pw[j][2]};
+      const double zxd[3] = {z[1] * d[2] - z[2] * d[1], z[2] * d[0] - z[0] * d[2], z[0] * d[1] - z[1] * d[0]};
+      q += H1_MASS[i] * (zxd[0] * g[0] + zxd[1] * g[1] + zxd[2] * g[2]);
+    }
+    u[j - 1] = -q;
+  }
+}
+
+}  // namespace h1host

@@ -1,0 +1,489 @@
+// C-ABI of the batched HIP iLQR (include/ilqr_hip.h): context, device buffers, problem data and the
+// host-side orchestration of iLQR::solve (reference src/ilqr/ilqr.cpp:521-660) as a fixed stream of
+// kernel launches with per-rollout masks on the device -- no host round trip inside a solve.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/ilqr_hip.h"
+#include "h1_cost_dev.h"
+#include "h1_host_model.h"
+#include "ilqr_kernels.h"
+
+using ilqr::DevState;
+
+struct ilqr_hip_ctx {
+  int device = 0, B = 0, N = 0;
+  hipStream_t stream = nullptr;
+  DevState S{};
+  h1::ProblemDev P{};
+  // reference sets on the device
+  double *d_xref = nullptr, *d_uref = nullptr, *d_comref = nullptr, *d_eeref = nullptr, *d_comvelref = nullptr;
+  int* d_stance = nullptr;
+  int n_xref = 0, n_stance = 0, n_ee = 0;
+  // scratch
+  double *d_tmpx = nullptr, *d_tmpu = nullptr, *d_prevx = nullptr, *d_prevu = nullptr, *d_u0 = nullptr, *d_K0 = nullptr, *d_cost_tmp = nullptr;
+  int max_iter = 10;
+  double tol = 1e-4;
+  int jac_mode = ILQR_JAC_ANALYTIC;
+  double fd_eps = 1e-5;
+  int early_exit = 1;
+  bool initialized = false, refs_set = false;
+  std::string err;
+  // profiling
+  int profiling = 0;
+  struct Span { int stage; hipEvent_t a, b; };
+  std::vector<Span> spans;
+  std::vector<hipEvent_t> pool;
+  size_t pool_next = 0;
+  double stage_ms[6] = {0, 0, 0, 0, 0, 0}, stage_launches[6] = {0, 0, 0, 0, 0, 0};
+};
+
+#define HIPCHK(ctx, call)                                                                   \
+  do {                                                                                      \
+    hipError_t e_ = (call);                                                                 \
+    if (e_ != hipSuccess) {                                                                 \
+      (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_);                       \
+      return ILQR_ERR_HIP;                                                                  \
+    }                                                                                       \
+  } while (0)
+
+template <class T> static int dalloc(ilqr_hip_ctx* c, T** p, size_t count) {
+  HIPCHK(c, hipMalloc((void**)p, count * sizeof(T)));
+  HIPCHK(c, hipMemsetAsync(*p, 0, count * sizeof(T), c->stream));
+  return ILQR_OK;
+}
+#define TRY(x) do { int r_ = (x); if (r_ != ILQR_OK) return r_; } while (0)
+
+static hipEvent_t next_event(ilqr_hip_ctx* c) {
+  if (c->pool_next == c->pool.size()) { hipEvent_t e; hipEventCreate(&e); c->pool.push_back(e); }
+  return c->pool[c->pool_next++];
+}
+struct StageTimer {
+  ilqr_hip_ctx* c; int stage; hipEvent_t a{}, b{};
+  StageTimer(ilqr_hip_ctx* c_, int s) : c(c_), stage(s) { if (c->profiling) { a = next_event(c); b = next_event(c); hipEventRecord(a, c->stream); } }
+  ~StageTimer() { if (c->profiling) { hipEventRecord(b, c->stream); c->spans.push_back({stage, a, b}); } }
+};
+
+extern "C" {
+
+int ilqr_hip_create(ilqr_hip_ctx** out, int device, int batch, int horizon, double dt) {
+  if (!out || batch <= 0 || horizon <= 0 || !(dt > 0.0)) return ILQR_ERR_ARG;
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return ILQR_ERR_NO_DEVICE;
+  ilqr_hip_ctx* c = new ilqr_hip_ctx();
+  c->device = device; c->B = batch; c->N = horizon;
+  if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&c->stream) != hipSuccess) { delete c; return ILQR_ERR_NO_DEVICE; }
+  const size_t B = batch, N = horizon, n = ILQR_NX, m = ILQR_NU;
+  DevState& S = c->S;
+  S.B = batch; S.N = horizon; S.max_iter = c->max_iter;
+  int rc = ILQR_OK;
+  auto A = [&](int r) { if (rc == ILQR_OK) rc = r; };
+  A(dalloc(c, &S.x0, B * n)); A(dalloc(c, &S.xbar, B * (N + 1) * n)); A(dalloc(c, &S.ubar, B * N * m));
+  A(dalloc(c, &S.xcand, B * 8 * (N + 1) * n)); A(dalloc(c, &S.ucand, B * 8 * N * m)); A(dalloc(c, &S.cand_cost, B * 8));
+  A(dalloc(c, &S.A, B * N * n * n)); A(dalloc(c, &S.Bm, B * N * n * m));
+  A(dalloc(c, &S.lx, B * (N + 1) * n)); A(dalloc(c, &S.lu, B * N * m)); A(dalloc(c, &S.lxx, B * (N + 1) * n * n)); A(dalloc(c, &S.luu, B * N * m));
+  A(dalloc(c, &S.K, B * N * m * n)); A(dalloc(c, &S.kff, B * N * m)); A(dalloc(c, &S.Vx, B * n)); A(dalloc(c, &S.Vxx, B * n * n));
+  A(dalloc(c, &S.J, B)); A(dalloc(c, &S.Jbase, B)); A(dalloc(c, &S.ls_cost, B)); A(dalloc(c, &S.lambda, B));
+  A(dalloc(c, &S.active, B)); A(dalloc(c, &S.need_retry, B)); A(dalloc(c, &S.iters, B)); A(dalloc(c, &S.improved, B)); A(dalloc(c, &S.alpha_idx, B));
+  A(dalloc(c, &S.trace_cost, B * (c->max_iter + 1))); A(dalloc(c, &S.trace_alpha, B * c->max_iter)); A(dalloc(c, &S.trace_lambda, B * c->max_iter));
+  A(dalloc(c, &c->d_tmpx, B * (N + 1) * n)); A(dalloc(c, &c->d_tmpu, B * N * m));
+  A(dalloc(c, &c->d_prevx, B * (N + 1) * n)); A(dalloc(c, &c->d_prevu, B * N * m));
+  A(dalloc(c, &c->d_u0, B * m)); A(dalloc(c, &c->d_K0, B * m * n)); A(dalloc(c, &c->d_cost_tmp, B));
+  // shared reference sets sized for per-rollout use
+  A(dalloc(c, &c->d_xref, B * (N + 1) * n)); A(dalloc(c, &c->d_uref, B * N * m)); A(dalloc(c, &c->d_comref, B * (N + 1) * 3));
+  A(dalloc(c, &c->d_eeref, B * (N + 1) * 6)); A(dalloc(c, &c->d_comvelref, B * (N + 1) * 3)); A(dalloc(c, &c->d_stance, B * (N + 1) * 2));
+  if (rc != ILQR_OK) { *out = c; return rc; }
+  if (ilqr::backward_needs_lds_attr() != 0) { c->err = "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed"; *out = c; return ILQR_ERR_HIP; }
+  h1::ProblemDev& P = c->P;
+  P.N = horizon; P.dyn.h = dt; P.dyn.g[0] = 0; P.dyn.g[1] = 0; P.dyn.g[2] = -9.81;
+  for (int i = 0; i < ILQR_NX; ++i) { P.Q[i] = 1.0; P.Qf[i] = 1.0; }
+  for (int i = 0; i < ILQR_NU; ++i) P.R[i] = 1.0;
+  P.w_com = P.w_com_vel = P.w_ee_pos = P.w_ee_vel = P.w_upright = P.w_balance = 0.0;
+  P.w_joint = 500.0; P.w_ctrl = 1000.0;  // RobotUtils ctor defaults, robot_utils.cpp:10
+  P.x_ref = c->d_xref; P.u_ref = c->d_uref; P.com_ref = c->d_comref; P.stance = c->d_stance; P.ee_ref = c->d_eeref; P.com_vel_ref = c->d_comvelref;
+  P.x_ref_stride = P.u_ref_stride = P.com_ref_stride = P.stance_stride = P.ee_ref_stride = P.com_vel_ref_stride = 0;
+  // default: stance everywhere (RobotUtils::isStance default, robot_utils.cpp:494-504), lambda = 1e-6 (ilqr.cpp:16)
+  std::vector<int> ones((N + 1) * 2, 1);
+  hipMemcpyAsync(c->d_stance, ones.data(), ones.size() * sizeof(int), hipMemcpyHostToDevice, c->stream);
+  std::vector<double> lam(B, 1e-6);
+  hipMemcpyAsync(S.lambda, lam.data(), B * sizeof(double), hipMemcpyHostToDevice, c->stream);
+  if (hipStreamSynchronize(c->stream) != hipSuccess) { c->err = "stream sync failed in create"; *out = c; return ILQR_ERR_HIP; }
+  *out = c;
+  return ILQR_OK;
+}
+
+int ilqr_hip_destroy(ilqr_hip_ctx* c) {
+  if (!c) return ILQR_ERR_ARG;
+  hipSetDevice(c->device);
+  DevState& S = c->S;
+  void* ptrs[] = {S.x0, S.xbar, S.ubar, S.xcand, S.ucand, S.cand_cost, S.A, S.Bm, S.lx, S.lu, S.lxx, S.luu, S.K, S.kff, S.Vx, S.Vxx, S.J, S.Jbase, S.ls_cost,
+                  S.lambda, S.active, S.need_retry, S.iters, S.improved, S.alpha_idx, S.trace_cost, S.trace_alpha, S.trace_lambda, c->d_tmpx, c->d_tmpu,
+                  c->d_prevx, c->d_prevu, c->d_u0, c->d_K0, c->d_cost_tmp, c->d_xref, c->d_uref, c->d_comref, c->d_eeref, c->d_comvelref, c->d_stance};
+  for (void* p : ptrs) if (p) hipFree(p);
+  for (hipEvent_t e : c->pool) hipEventDestroy(e);
+  if (c->stream) hipStreamDestroy(c->stream);
+  delete c;
+  return ILQR_OK;
+}
+const char* ilqr_hip_last_error(const ilqr_hip_ctx* c) { return c ? c->err.c_str() : "null context"; }
+int ilqr_hip_batch(const ilqr_hip_ctx* c) { return c ? c->B : -1; }
+int ilqr_hip_horizon(const ilqr_hip_ctx* c) { return c ? c->N : -1; }
+void* ilqr_hip_stream(ilqr_hip_ctx* c) { return c ? (void*)c->stream : nullptr; }
+
+int ilqr_hip_set_cost_weights(ilqr_hip_ctx* c, const double* Q, const double* R, const double* Qf) {
+  if (!c || !Q || !R || !Qf) return ILQR_ERR_ARG;
+  std::memcpy(c->P.Q, Q, sizeof(c->P.Q)); std::memcpy(c->P.R, R, sizeof(c->P.R)); std::memcpy(c->P.Qf, Qf, sizeof(c->P.Qf));
+  return ILQR_OK;
+}
+int ilqr_hip_set_task_weights(ilqr_hip_ctx* c, double w_com, double w_com_vel, double w_ee_pos, double w_ee_vel, double w_upright, double w_balance) {
+  if (!c) return ILQR_ERR_ARG;
+  c->P.w_com = w_com; c->P.w_com_vel = w_com_vel; c->P.w_ee_pos = w_ee_pos; c->P.w_ee_vel = w_ee_vel; c->P.w_upright = w_upright; c->P.w_balance = w_balance;
+  return ILQR_OK;
+}
+int ilqr_hip_set_constraint_weights(ilqr_hip_ctx* c, double wj, double wc) { if (!c) return ILQR_ERR_ARG; c->P.w_joint = wj; c->P.w_ctrl = wc; return ILQR_OK; }
+int ilqr_hip_set_gravity(ilqr_hip_ctx* c, double gx, double gy, double gz) { if (!c) return ILQR_ERR_ARG; c->P.dyn.g[0] = gx; c->P.dyn.g[1] = gy; c->P.dyn.g[2] = gz; return ILQR_OK; }
+
+static int check_sets(const ilqr_hip_ctx* c, int n_sets) { return (n_sets == 1 || n_sets == c->B) ? ILQR_OK : ILQR_ERR_ARG; }
+
+int ilqr_hip_set_contact_schedule(ilqr_hip_ctx* c, const int* stance, int n_sets) {
+  if (!c || !stance || check_sets(c, n_sets)) return ILQR_ERR_ARG;
+  hipSetDevice(c->device);
+  const size_t per = (size_t)(c->N + 1) * 2;
+  HIPCHK(c, hipMemcpyAsync(c->d_stance, stance, per * n_sets * sizeof(int), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->P.stance_stride = n_sets == 1 ? 0 : (long)per;
+  return ILQR_OK;
+}
+int ilqr_hip_set_ee_references(ilqr_hip_ctx* c, const double* ee_ref, const double* com_vel_ref, int n_sets) {
+  if (!c || !ee_ref || check_sets(c, n_sets)) return ILQR_ERR_ARG;
+  hipSetDevice(c->device);
+  const size_t per = (size_t)(c->N + 1);
+  HIPCHK(c, hipMemcpyAsync(c->d_eeref, ee_ref, per * 6 * n_sets * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  if (com_vel_ref) HIPCHK(c, hipMemcpyAsync(c->d_comvelref, com_vel_ref, per * 3 * n_sets * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  else HIPCHK(c, hipMemsetAsync(c->d_comvelref, 0, per * 3 * n_sets * sizeof(double), c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->P.ee_ref_stride = n_sets == 1 ? 0 : (long)(per * 6);
+  c->P.com_vel_ref_stride = n_sets == 1 ? 0 : (long)(per * 3);
+  return ILQR_OK;
+}
+int ilqr_hip_set_references(ilqr_hip_ctx* c, const double* x_ref, const double* u_ref, const double* com_ref, int n_sets) {
+  if (!c || !x_ref || !u_ref || !com_ref || check_sets(c, n_sets)) return ILQR_ERR_ARG;
+  hipSetDevice(c->device);
+  const size_t N = c->N;
+  HIPCHK(c, hipMemcpyAsync(c->d_xref, x_ref, (N + 1) * ILQR_NX * n_sets * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->d_uref, u_ref, N * ILQR_NU * n_sets * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->d_comref, com_ref, (N + 1) * 3 * n_sets * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->P.x_ref_stride = n_sets == 1 ? 0 : (long)((N + 1) * ILQR_NX);
+  c->P.u_ref_stride = n_sets == 1 ? 0 : (long)(N * ILQR_NU);
+  c->P.com_ref_stride = n_sets == 1 ? 0 : (long)((N + 1) * 3);
+  c->refs_set = true;
+  return ILQR_OK;
+}
+
+int ilqr_hip_set_regularization(ilqr_hip_ctx* c, double lambda) {
+  if (!c) return ILQR_ERR_ARG;
+  hipSetDevice(c->device);
+  std::vector<double> lam(c->B, lambda);
+  HIPCHK(c, hipMemcpyAsync(c->S.lambda, lam.data(), c->B * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return ILQR_OK;
+}
+int ilqr_hip_set_max_iterations(ilqr_hip_ctx* c, int max_iter) {
+  if (!c || max_iter <= 0) return ILQR_ERR_ARG;
+  hipSetDevice(c->device);
+  if (max_iter != c->max_iter) {
+    hipFree(c->S.trace_cost); hipFree(c->S.trace_alpha); hipFree(c->S.trace_lambda);
+    c->S.trace_cost = c->S.trace_alpha = c->S.trace_lambda = nullptr;
+    c->max_iter = max_iter; c->S.max_iter = max_iter;
+    TRY(dalloc(c, &c->S.trace_cost, (size_t)c->B * (max_iter + 1))); TRY(dalloc(c, &c->S.trace_alpha, (size_t)c->B * max_iter)); TRY(dalloc(c, &c->S.trace_lambda, (size_t)c->B * max_iter));
+  }
+  return ILQR_OK;
+}
+int ilqr_hip_set_tolerance(ilqr_hip_ctx* c, double tol) { if (!c) return ILQR_ERR_ARG; c->tol = tol; return ILQR_OK; }
+int ilqr_hip_set_options(ilqr_hip_ctx* c, int jacobian_mode, double fd_eps, int early_exit) {
+  if (!c || (jacobian_mode != ILQR_JAC_ANALYTIC && jacobian_mode != ILQR_JAC_FD_FORWARD) || !(fd_eps > 0.0)) return ILQR_ERR_ARG;
+  c->jac_mode = jacobian_mode; c->fd_eps = fd_eps; c->early_exit = early_exit ? 1 : 0;
+  return ILQR_OK;
+}
+
+// ---------------------------------------------------------------- initializeWithReference
+static int cold_start_device(ilqr_hip_ctx* c, const double* x0_dev, const double* uinit_dev) {
+  const size_t B = c->B, N = c->N;
+  HIPCHK(c, hipMemcpyAsync(c->S.x0, x0_dev, B * ILQR_NX * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->S.ubar, uinit_dev, B * N * ILQR_NU * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+  ilqr::launch_rollout(c->S, c->P, ilqr::MASK_ALL, 1, 0, c->S.Jbase, c->stream);  // N rollouts (ilqr.cpp:113-115)
+  HIPCHK(c, hipGetLastError());
+  c->initialized = true;
+  return ILQR_OK;
+}
+int ilqr_hip_initialize_device(ilqr_hip_ctx* c, const double* x0_device, const double* u_init_device) {
+  if (!c || !x0_device || !u_init_device) return ILQR_ERR_ARG;
+  hipSetDevice(c->device);
+  return cold_start_device(c, x0_device, u_init_device);
+}
+int ilqr_hip_initialize(ilqr_hip_ctx* c, const double* x0, const double* u_init, const double* prev_xbar, const double* prev_ubar) {
+  if (!c || !x0) return ILQR_ERR_ARG;
+  hipSetDevice(c->device);
+  const size_t B = c->B, N = c->N;
+  if (prev_xbar && prev_ubar) {
+    HIPCHK(c, hipMemcpyAsync(c->S.x0, x0, B * ILQR_NX * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_prevx, prev_xbar, B * (N + 1) * ILQR_NX * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_prevu, prev_ubar, B * N * ILQR_NU * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    ilqr::launch_warm_shift(c->S, c->d_prevx, c->d_prevu, c->stream);
+    ilqr::launch_last_step(c->S, c->P, c->stream);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->initialized = true;
+    return ILQR_OK;
+  }
+  std::vector<double> ug;
+  const double* uh = u_init;
+  if (!uh) {  // gravity compensation evaluated at each rollout's x0 (computeGravComp uses the plant state)
+    ug.resize(B * N * ILQR_NU);
+    for (size_t b = 0; b < B; ++b) {
+      double u1[ILQR_NU]; h1host::gravity_compensation(x0 + b * ILQR_NX, c->P.dyn.g, u1);
+      for (size_t t = 0; t < N; ++t) std::memcpy(&ug[(b * N + t) * ILQR_NU], u1, sizeof(u1));
+    }
+    uh = ug.data();
+  }
+  HIPCHK(c, hipMemcpyAsync(c->d_tmpx, x0, B * ILQR_NX * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->d_tmpu, uh, B * N * ILQR_NU * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  TRY(cold_start_device(c, c->d_tmpx, c->d_tmpu));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return ILQR_OK;
+}
+int ilqr_hip_initialize_warm_resident(ilqr_hip_ctx* c, const double* x0) {
+  if (!c || !x0) return ILQR_ERR_ARG;
+  if (!c->initialized) return ILQR_ERR_STATE;
+  hipSetDevice(c->device);
+  const size_t B = c->B, N = c->N;
+  HIPCHK(c, hipMemcpyAsync(c->S.x0, x0, B * ILQR_NX * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->d_prevx, c->S.xbar, B * (N + 1) * ILQR_NX * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->d_prevu, c->S.ubar, B * N * ILQR_NU * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+  ilqr::launch_warm_shift(c->S, c->d_prevx, c->d_prevu, c->stream);
+  ilqr::launch_last_step(c->S, c->P, c->stream);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return ILQR_OK;
+}
+
+// ---------------------------------------------------------------- solve
+static void collect_profile(ilqr_hip_ctx* c) {
+  for (int i = 0; i < 6; ++i) { c->stage_ms[i] = 0; c->stage_launches[i] = 0; }
+  for (auto& s : c->spans) { float ms = 0; hipEventElapsedTime(&ms, s.a, s.b); c->stage_ms[s.stage] += ms; c->stage_launches[s.stage] += 1; }
+  c->spans.clear(); c->pool_next = 0;
+}
+
+int ilqr_hip_solve_async(ilqr_hip_ctx* c) {
+  if (!c) return ILQR_ERR_ARG;
+  if (!c->initialized || !c->refs_set) { c->err = "solve before initialize/set_references"; return ILQR_ERR_STATE; }
+  hipSetDevice(c->device);
+  hipStream_t st = c->stream;
+  const DevState& S = c->S; const h1::ProblemDev& P = c->P;
+  c->spans.clear(); c->pool_next = 0;
+  { StageTimer T(c, 0); ilqr::launch_rollout(S, P, ilqr::MASK_ALL, 0, 0, S.Jbase, st); ilqr::launch_solve_begin(S, st); }  // ilqr.cpp:540
+  for (int iter = 0; iter < c->max_iter; ++iter) {
+    { StageTimer T(c, 0); ilqr::launch_rollout(S, P, ilqr::MASK_ACTIVE, 1, 1, S.Jbase, st); }                 // :551,563
+    { StageTimer T(c, 1); ilqr::launch_linearize(S, P, ilqr::MASK_ACTIVE, c->jac_mode, c->fd_eps, st); }      // :576
+    { StageTimer T(c, 2); ilqr::launch_cost_quadratics(S, P, ilqr::MASK_ACTIVE, st); }                        // :588
+    { StageTimer T(c, 3); ilqr::launch_backward(S, ilqr::MASK_ACTIVE, st); }                                  // :601
+    { StageTimer T(c, 4); ilqr::launch_line_search(S, P, ilqr::MASK_ACTIVE, st); }                            // :616
+    { StageTimer T(c, 5); ilqr::launch_control(S, 0, iter, c->tol, c->early_exit, st); }                      // :619-620,645-655
+    { StageTimer T(c, 3); ilqr::launch_backward(S, ilqr::MASK_RETRY, st); }                                   // :637
+    { StageTimer T(c, 4); ilqr::launch_line_search(S, P, ilqr::MASK_RETRY, st); }                             // :638
+    { StageTimer T(c, 5); ilqr::launch_control(S, 1, iter, c->tol, c->early_exit, st); }                      // :640-646
+  }
+  HIPCHK(c, hipGetLastError());
+  return ILQR_OK;
+}
+int ilqr_hip_synchronize(ilqr_hip_ctx* c) {
+  if (!c) return ILQR_ERR_ARG;
+  hipSetDevice(c->device);
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (c->profiling) collect_profile(c);
+  return ILQR_OK;
+}
+int ilqr_hip_solve(ilqr_hip_ctx* c, const double* x0, double* cost_out) {
+  if (!c) return ILQR_ERR_ARG;
+  hipSetDevice(c->device);
+  if (x0) HIPCHK(c, hipMemcpyAsync(c->S.x0, x0, (size_t)c->B * ILQR_NX * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  TRY(ilqr_hip_solve_async(c));
+  TRY(ilqr_hip_synchronize(c));
+  if (cost_out) HIPCHK(c, hipMemcpy(cost_out, c->S.J, (size_t)c->B * sizeof(double), hipMemcpyDeviceToHost));
+  return ILQR_OK;
+}
+
+// ---------------------------------------------------------------- accessors
+#define GETTER(name, ptr, count, type)                                                                          \
+  int name(ilqr_hip_ctx* c, type* out) {                                                                        \
+    if (!c || !out) return ILQR_ERR_ARG;                                                                        \
+    hipSetDevice(c->device);                                                                                    \
+    HIPCHK(c, hipStreamSynchronize(c->stream));                                                                 \
+    HIPCHK(c, hipMemcpy(out, c->S.ptr, (size_t)(count) * sizeof(type), hipMemcpyDeviceToHost));                 \
+    return ILQR_OK;                                                                                             \
+  }
+GETTER(ilqr_hip_get_xbar, xbar, (size_t)c->B*(c->N + 1) * ILQR_NX, double)
+GETTER(ilqr_hip_get_ubar, ubar, (size_t)c->B* c->N* ILQR_NU, double)
+GETTER(ilqr_hip_get_gains_K, K, (size_t)c->B* c->N* ILQR_NU* ILQR_NX, double)
+GETTER(ilqr_hip_get_gains_kff, kff, (size_t)c->B* c->N* ILQR_NU, double)
+GETTER(ilqr_hip_get_cost, J, c->B, double)
+GETTER(ilqr_hip_get_iterations, iters, c->B, int)
+GETTER(ilqr_hip_get_lambda, lambda, c->B, double)
+
+int ilqr_hip_get_trace(ilqr_hip_ctx* c, double* cost, double* alpha, double* lambda) {
+  if (!c) return ILQR_ERR_ARG;
+  hipSetDevice(c->device);
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (cost) HIPCHK(c, hipMemcpy(cost, c->S.trace_cost, (size_t)c->B * (c->max_iter + 1) * sizeof(double), hipMemcpyDeviceToHost));
+  if (alpha) HIPCHK(c, hipMemcpy(alpha, c->S.trace_alpha, (size_t)c->B * c->max_iter * sizeof(double), hipMemcpyDeviceToHost));
+  if (lambda) HIPCHK(c, hipMemcpy(lambda, c->S.trace_lambda, (size_t)c->B * c->max_iter * sizeof(double), hipMemcpyDeviceToHost));
+  return ILQR_OK;
+}
+int ilqr_hip_first_knot_device(ilqr_hip_ctx* c, const double** u0, const double** K0, const double** cost) {
+  if (!c) return ILQR_ERR_ARG;
+  hipSetDevice(c->device);
+  ilqr::launch_pack_first_knot(c->S, c->d_u0, c->d_K0, c->stream);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (u0) *u0 = c->d_u0;
+  if (K0) *K0 = c->d_K0;
+  if (cost) *cost = c->S.J;
+  return ILQR_OK;
+}
+int ilqr_hip_compute_control(ilqr_hip_ctx* c, const double* x_measured, double* u_apply) {
+  if (!c || !x_measured || !u_apply) return ILQR_ERR_ARG;
+  hipSetDevice(c->device);
+  HIPCHK(c, hipMemcpyAsync(c->d_tmpx, x_measured, (size_t)c->B * ILQR_NX * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  ilqr::launch_compute_control(c->S, c->d_tmpx, c->d_u0, c->stream);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipMemcpyAsync(u_apply, c->d_u0, (size_t)c->B * ILQR_NU * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return ILQR_OK;
+}
+
+// ---------------------------------------------------------------- stage entry points
+int ilqr_hip_set_trajectory(ilqr_hip_ctx* c, const double* xbar, const double* ubar) {
+  if (!c || !xbar || !ubar) return ILQR_ERR_ARG;
+  hipSetDevice(c->device);
+  const size_t B = c->B, N = c->N;
+  HIPCHK(c, hipMemcpyAsync(c->S.xbar, xbar, B * (N + 1) * ILQR_NX * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->S.ubar, ubar, B * N * ILQR_NU * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpy2DAsync(c->S.x0, ILQR_NX * sizeof(double), c->S.xbar, (N + 1) * ILQR_NX * sizeof(double), ILQR_NX * sizeof(double), B, hipMemcpyDeviceToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->initialized = true;
+  return ILQR_OK;
+}
+#define STAGE_PRE if (!c) return ILQR_ERR_ARG; if (!c->initialized) return ILQR_ERR_STATE; hipSetDevice(c->device)
+#define STAGE_POST HIPCHK(c, hipGetLastError()); HIPCHK(c, hipStreamSynchronize(c->stream)); return ILQR_OK
+int ilqr_hip_stage_rollout(ilqr_hip_ctx* c) { STAGE_PRE; ilqr::launch_rollout(c->S, c->P, ilqr::MASK_ALL, 1, 0, c->S.Jbase, c->stream); STAGE_POST; }
+int ilqr_hip_stage_linearize(ilqr_hip_ctx* c) { STAGE_PRE; ilqr::launch_linearize(c->S, c->P, ilqr::MASK_ALL, c->jac_mode, c->fd_eps, c->stream); STAGE_POST; }
+int ilqr_hip_stage_cost_quadratics(ilqr_hip_ctx* c) { STAGE_PRE; if (!c->refs_set) return ILQR_ERR_STATE; ilqr::launch_cost_quadratics(c->S, c->P, ilqr::MASK_ALL, c->stream); STAGE_POST; }
+int ilqr_hip_stage_backward_pass(ilqr_hip_ctx* c) { STAGE_PRE; ilqr::launch_backward(c->S, ilqr::MASK_ALL, c->stream); STAGE_POST; }
+int ilqr_hip_stage_total_cost(ilqr_hip_ctx* c, double* cost) {
+  STAGE_PRE; if (!cost || !c->refs_set) return ILQR_ERR_ARG;
+  ilqr::launch_rollout(c->S, c->P, ilqr::MASK_ALL, 0, 0, c->d_cost_tmp, c->stream);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipMemcpyAsync(cost, c->d_cost_tmp, (size_t)c->B * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return ILQR_OK;
+}
+int ilqr_hip_stage_line_search(ilqr_hip_ctx* c, int* improved, double* new_cost, double* alpha) {
+  STAGE_PRE; if (!c->refs_set) return ILQR_ERR_STATE;
+  ilqr::launch_rollout(c->S, c->P, ilqr::MASK_ALL, 0, 0, c->S.Jbase, c->stream);   // baseline = computeTotalCost(xbar, ubar), ilqr.cpp:317
+  ilqr::launch_line_search(c->S, c->P, ilqr::MASK_ALL, c->stream);
+  ilqr::launch_control(c->S, 2, 0, c->tol, 0, c->stream);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  const size_t B = c->B;
+  std::vector<int> ai(B);
+  HIPCHK(c, hipMemcpy(ai.data(), c->S.alpha_idx, B * sizeof(int), hipMemcpyDeviceToHost));
+  static const double alphas[8] = {1.0, 0.8, 0.6, 0.4, 0.2, 0.1, 0.05, 0.01};
+  for (size_t b = 0; b < B; ++b) { if (improved) improved[b] = ai[b] >= 0; if (alpha) alpha[b] = ai[b] >= 0 ? alphas[ai[b]] : 0.0; }
+  if (new_cost) HIPCHK(c, hipMemcpy(new_cost, c->S.ls_cost, B * sizeof(double), hipMemcpyDeviceToHost));
+  return ILQR_OK;
+}
+int ilqr_hip_get_linearization(ilqr_hip_ctx* c, double* A, double* Bm) {
+  if (!c) return ILQR_ERR_ARG; hipSetDevice(c->device);
+  const size_t B = c->B, N = c->N;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (A) HIPCHK(c, hipMemcpy(A, c->S.A, B * N * ILQR_NX * ILQR_NX * sizeof(double), hipMemcpyDeviceToHost));
+  if (Bm) HIPCHK(c, hipMemcpy(Bm, c->S.Bm, B * N * ILQR_NX * ILQR_NU * sizeof(double), hipMemcpyDeviceToHost));
+  return ILQR_OK;
+}
+int ilqr_hip_set_linearization(ilqr_hip_ctx* c, const double* A, const double* Bm) {
+  if (!c || !A || !Bm) return ILQR_ERR_ARG; hipSetDevice(c->device);
+  const size_t B = c->B, N = c->N;
+  HIPCHK(c, hipMemcpy(c->S.A, A, B * N * ILQR_NX * ILQR_NX * sizeof(double), hipMemcpyHostToDevice));
+  HIPCHK(c, hipMemcpy(c->S.Bm, Bm, B * N * ILQR_NX * ILQR_NU * sizeof(double), hipMemcpyHostToDevice));
+  c->initialized = true;
+  return ILQR_OK;
+}
+int ilqr_hip_get_quadratics(ilqr_hip_ctx* c, double* lx, double* lu, double* lxx, double* luu) {
+  if (!c) return ILQR_ERR_ARG; hipSetDevice(c->device);
+  const size_t B = c->B, N = c->N;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (lx) HIPCHK(c, hipMemcpy(lx, c->S.lx, B * (N + 1) * ILQR_NX * sizeof(double), hipMemcpyDeviceToHost));
+  if (lu) HIPCHK(c, hipMemcpy(lu, c->S.lu, B * N * ILQR_NU * sizeof(double), hipMemcpyDeviceToHost));
+  if (lxx) HIPCHK(c, hipMemcpy(lxx, c->S.lxx, B * (N + 1) * ILQR_NX * ILQR_NX * sizeof(double), hipMemcpyDeviceToHost));
+  if (luu) HIPCHK(c, hipMemcpy(luu, c->S.luu, B * N * ILQR_NU * sizeof(double), hipMemcpyDeviceToHost));
+  return ILQR_OK;
+}
+int ilqr_hip_set_quadratics(ilqr_hip_ctx* c, const double* lx, const double* lu, const double* lxx, const double* luu) {
+  if (!c || !lx || !lu || !lxx || !luu) return ILQR_ERR_ARG; hipSetDevice(c->device);
+  const size_t B = c->B, N = c->N;
+  HIPCHK(c, hipMemcpy(c->S.lx, lx, B * (N + 1) * ILQR_NX * sizeof(double), hipMemcpyHostToDevice));
+  HIPCHK(c, hipMemcpy(c->S.lu, lu, B * N * ILQR_NU * sizeof(double), hipMemcpyHostToDevice));
+  HIPCHK(c, hipMemcpy(c->S.lxx, lxx, B * (N + 1) * ILQR_NX * ILQR_NX * sizeof(double), hipMemcpyHostToDevice));
+  HIPCHK(c, hipMemcpy(c->S.luu, luu, B * N * ILQR_NU * sizeof(double), hipMemcpyHostToDevice));
+  return ILQR_OK;
+}
+int ilqr_hip_get_value_function(ilqr_hip_ctx* c, double* Vx, double* Vxx) {
+  if (!c) return ILQR_ERR_ARG; hipSetDevice(c->device);
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (Vx) HIPCHK(c, hipMemcpy(Vx, c->S.Vx, (size_t)c->B * ILQR_NX * sizeof(double), hipMemcpyDeviceToHost));
+  if (Vxx) HIPCHK(c, hipMemcpy(Vxx, c->S.Vxx, (size_t)c->B * ILQR_NX * ILQR_NX * sizeof(double), hipMemcpyDeviceToHost));
+  return ILQR_OK;
+}
+int ilqr_hip_step(ilqr_hip_ctx* c, int count, const double* x, const double* u, double* x_next) {
+  if (!c || count <= 0 || !x || !u || !x_next) return ILQR_ERR_ARG;
+  hipSetDevice(c->device);
+  double *dx = nullptr, *du = nullptr, *dn = nullptr;
+  HIPCHK(c, hipMalloc((void**)&dx, (size_t)count * ILQR_NX * sizeof(double)));
+  HIPCHK(c, hipMalloc((void**)&du, (size_t)count * ILQR_NU * sizeof(double)));
+  HIPCHK(c, hipMalloc((void**)&dn, (size_t)count * ILQR_NX * sizeof(double)));
+  hipMemcpy(dx, x, (size_t)count * ILQR_NX * sizeof(double), hipMemcpyHostToDevice);
+  hipMemcpy(du, u, (size_t)count * ILQR_NU * sizeof(double), hipMemcpyHostToDevice);
+  ilqr::launch_step(count, dx, du, c->P.dyn, dn, c->stream);
+  hipError_t e = hipStreamSynchronize(c->stream);
+  hipMemcpy(x_next, dn, (size_t)count * ILQR_NX * sizeof(double), hipMemcpyDeviceToHost);
+  hipFree(dx); hipFree(du); hipFree(dn);
+  HIPCHK(c, e);
+  return ILQR_OK;
+}
+
+int ilqr_hip_enable_profiling(ilqr_hip_ctx* c, int on) { if (!c) return ILQR_ERR_ARG; c->profiling = on ? 1 : 0; return ILQR_OK; }
+int ilqr_hip_get_stage_ms(ilqr_hip_ctx* c, double* ms, double* launches) {
+  if (!c || !ms) return ILQR_ERR_ARG;
+  for (int i = 0; i < 6; ++i) { ms[i] = c->stage_ms[i]; if (launches) launches[i] = c->stage_launches[i]; }
+  return ILQR_OK;
+}
+
+int ilqr_hip_reference_kinematics(const double* x, double* com, double* ee) {
+  if (!x || !com || !ee) return ILQR_ERR_ARG;
+  h1host::reference_kinematics(x, com, ee);
+  return ILQR_OK;
+}
+int ilqr_hip_gravity_compensation(const double* x, const double* gravity, double* u) {
+  if (!x || !gravity || !u) return ILQR_ERR_ARG;
+  h1host::gravity_compensation(x, gravity, u);
+  return ILQR_OK;
+}
+
+}  // extern "C"

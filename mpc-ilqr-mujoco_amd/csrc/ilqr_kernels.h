@@ -1,0 +1,64 @@
+// Device-state descriptor and kernel launchers shared by ilqr_kernels.hip and ilqr_capi.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+
+namespace h1 {
+struct ProblemDev;
+struct DynParams;
+}  // namespace h1
+
+namespace ilqr {
+
+enum { MASK_ALL = 0, MASK_ACTIVE = 1, MASK_RETRY = 2 };
+
+// All pointers are device pointers; rollout-major, row-major inside.
+struct DevState {
+  int B, N, max_iter;
+  double* x0;          // [B][51]
+  double* xbar;        // [B][N+1][51]
+  double* ubar;        // [B][N][19]
+  double* xcand;       // [B][8][N+1][51]   line-search candidates
+  double* ucand;       // [B][8][N][19]
+  double* cand_cost;   // [B][8]
+  double* A;           // [B][N][51][51]
+  double* Bm;          // [B][N][51][19]
+  double* lx;          // [B][N+1][51]
+  double* lu;          // [B][N][19]
+  double* lxx;         // [B][N+1][51][51]
+  double* luu;         // [B][N][19]        diagonal
+  double* K;           // [B][N][19][51]
+  double* kff;         // [B][N][19]
+  double* Vx;          // [B][51]           value gradient at knot 0
+  double* Vxx;         // [B][51][51]
+  double* J;           // [B] current cost
+  double* Jbase;       // [B] cost of the nominal trajectory (line-search baseline)
+  double* ls_cost;     // [B] stage API: cost after the line search
+  double* lambda;      // [B]
+  int* active;         // [B]
+  int* need_retry;     // [B]
+  int* iters;          // [B]
+  int* improved;       // [B]
+  int* alpha_idx;      // [B]
+  double* trace_cost;  // [B][max_iter+1]
+  double* trace_alpha; // [B][max_iter]
+  double* trace_lambda;// [B][max_iter]
+};
+
+void launch_rollout(const DevState& S, const h1::ProblemDev& P, int mode, int do_roll, int count_iter, double* cost_out, hipStream_t st);
+void launch_step(int count, const double* x, const double* u, const h1::DynParams& dyn, double* xn, hipStream_t st);
+void launch_linearize(const DevState& S, const h1::ProblemDev& P, int mode, int jac_mode, double eps, hipStream_t st);
+void launch_cost_quadratics(const DevState& S, const h1::ProblemDev& P, int mode, hipStream_t st);
+void launch_backward(const DevState& S, int mode, hipStream_t st);
+void launch_line_search(const DevState& S, const h1::ProblemDev& P, int mode, hipStream_t st);
+void launch_control(const DevState& S, int phase, int iter, double tol, int early_exit, hipStream_t st);
+void launch_solve_begin(const DevState& S, hipStream_t st);
+void launch_warm_shift(const DevState& S, const double* prev_x, const double* prev_u, hipStream_t st);
+void launch_last_step(const DevState& S, const h1::ProblemDev& P, hipStream_t st);
+void launch_compute_control(const DevState& S, const double* x_meas, double* u_out, hipStream_t st);
+void launch_pack_first_knot(const DevState& S, double* u0, double* K0, hipStream_t st);
+int backward_needs_lds_attr();
+size_t backward_lds_bytes();
+
+}  // namespace ilqr

@@ -1,0 +1,599 @@
+// HIP kernels of the batched H1 iLQR for gfx950 (fp64) -- the hot path behind include/ilqr_hip.h.
+//
+//   k_rollout          iLQR::forwardRolloutNominal + computeTotalCost   reference src/ilqr/ilqr.cpp:119-124, 363-518
+//   k_linearize        iLQR::computeLinearization                       reference src/ilqr/ilqr.cpp:126-131
+//   k_cost_quadratics  iLQR::computeCostQuadratics                      reference src/ilqr/ilqr.cpp:133-244
+//   k_backward         iLQR::backwardPass                               reference src/ilqr/ilqr.cpp:250-309
+//   k_line_search      iLQR::forwardPassLineSearch (8 alphas at once)   reference src/ilqr/ilqr.cpp:311-361
+//   k_control          iLQR::solve bookkeeping (lambda, accept, exit)   reference src/ilqr/ilqr.cpp:547-656
+//   k_compute_control  MPC::stepOnce control law                        reference src/ilqr/mpc.cpp:97-101
+//
+// HBM layout: every per-rollout array is rollout-major, row-major inside (b, t, i, j); one work
+// item (thread, wave or workgroup, per kernel) owns one rollout / knot and streams its own slab.
+#include <hip/hip_runtime.h>
+
+#include "h1_cost_dev.h"
+#include "ilqr_kernels.h"
+
+using namespace h1;
+
+namespace ilqr {
+
+__device__ __forceinline__ bool selected(const DevState& S, int b, int mode) {
+  if (mode == MASK_ALL) return true;
+  if (mode == MASK_ACTIVE) return S.active[b] != 0;
+  return S.active[b] != 0 && S.need_retry[b] != 0;
+}
+
+// ------------------------------------------------------------------ K1: nominal rollout + cost
+// thread per rollout. mode MASK_ALL also used by the stage API. do_roll = 0 -> cost only.
+__global__ void __launch_bounds__(64) k_rollout(DevState S, ProblemDev P, int mode, int do_roll, int count_iter, double* cost_out) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= S.B || !selected(S, b, mode)) return;
+  const int N = S.N;
+  double* xb = S.xbar + (size_t)b * (N + 1) * H1_NX;
+  const double* ub = S.ubar + (size_t)b * N * H1_NU;
+  if (count_iter) S.iters[b] += 1;
+  double x[H1_NX], xn[H1_NX], u[H1_NU];
+  if (do_roll) { for (int i = 0; i < H1_NX; ++i) { x[i] = S.x0[(size_t)b * H1_NX + i]; xb[i] = x[i]; } }
+  else { for (int i = 0; i < H1_NX; ++i) x[i] = xb[i]; }
+  double c = 0.0;
+  for (int t = 0; t < N; ++t) {
+    for (int i = 0; i < H1_NU; ++i) u[i] = ub[t * H1_NU + i];
+    c += knot_cost(P, b, t, x, u);
+    if (do_roll) {
+      step<double>(x, u, P.dyn, xn);
+      for (int i = 0; i < H1_NX; ++i) { x[i] = xn[i]; xb[(t + 1) * H1_NX + i] = xn[i]; }
+    } else {
+      for (int i = 0; i < H1_NX; ++i) x[i] = xb[(t + 1) * H1_NX + i];
+    }
+  }
+  c += knot_cost(P, b, N, x, nullptr);
+  cost_out[b] = c;
+}
+
+// plain batched step for the stage API
+__global__ void __launch_bounds__(64) k_step(int count, const double* x, const double* u, DynParams dyn, double* xn) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  double xl[H1_NX], ul[H1_NU], out[H1_NX];
+  for (int k = 0; k < H1_NX; ++k) xl[k] = x[(size_t)i * H1_NX + k];
+  for (int k = 0; k < H1_NU; ++k) ul[k] = u[(size_t)i * H1_NU + k];
+  step<double>(xl, ul, dyn, out);
+  for (int k = 0; k < H1_NX; ++k) xn[(size_t)i * H1_NX + k] = out[k];
+}
+
+// ------------------------------------------------------------------ K2: dynamics Jacobians
+// thread per (rollout, knot, column); columns 0..50 = d/dx, 51..69 = d/du.
+__global__ void __launch_bounds__(64) k_linearize(DevState S, ProblemDev P, int mode, int jac_mode, double eps) {
+  const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int NC = H1_NX + H1_NU;
+  const long total = (long)S.B * S.N * NC;
+  if (gid >= total) return;
+  const int col = (int)(gid % NC);
+  const long item = gid / NC;
+  const int t = (int)(item % S.N);
+  const int b = (int)(item / S.N);
+  if (!selected(S, b, mode)) return;
+  const double* xg = S.xbar + ((size_t)b * (S.N + 1) + t) * H1_NX;
+  const double* ug = S.ubar + ((size_t)b * S.N + t) * H1_NU;
+  double* Ag = S.A + ((size_t)b * S.N + t) * H1_NX * H1_NX;
+  double* Bg = S.Bm + ((size_t)b * S.N + t) * H1_NX * H1_NU;
+  double dcol[H1_NX];
+  if (jac_mode == 0) {
+    Dual x[H1_NX], u[H1_NU], xn[H1_NX];
+    for (int i = 0; i < H1_NX; ++i) x[i] = Dual(xg[i], i == col ? 1.0 : 0.0);
+    for (int i = 0; i < H1_NU; ++i) u[i] = Dual(ug[i], (H1_NX + i) == col ? 1.0 : 0.0);
+    step<Dual>(x, u, P.dyn, xn);
+    for (int i = 0; i < H1_NX; ++i) dcol[i] = xn[i].d;
+  } else {
+    // RobotUtils::linearizeDynamicsFD (robot_utils.cpp:120-160): forward difference on raw coordinates
+    double x[H1_NX], u[H1_NU], base[H1_NX], pert[H1_NX];
+    for (int i = 0; i < H1_NX; ++i) x[i] = xg[i];
+    for (int i = 0; i < H1_NU; ++i) u[i] = ug[i];
+    step<double>(x, u, P.dyn, base);
+    if (col < H1_NX) x[col] += eps; else u[col - H1_NX] += eps;
+    step<double>(x, u, P.dyn, pert);
+    for (int i = 0; i < H1_NX; ++i) dcol[i] = (pert[i] - base[i]) / eps;
+  }
+  if (col < H1_NX) { for (int i = 0; i < H1_NX; ++i) Ag[i * H1_NX + col] = dcol[i]; }
+  else { const int c = col - H1_NX; for (int i = 0; i < H1_NX; ++i) Bg[i * H1_NU + c] = dcol[i]; }
+}
+
+// ------------------------------------------------------------------ K3: cost quadratics
+// one wave per (knot, rollout).
+__global__ void __launch_bounds__(64) k_cost_quadratics(DevState S, ProblemDev P, int mode) {
+  const int t = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+  if (!selected(S, b, mode)) return;
+  const int N = S.N;
+  const bool term = (t == N);
+  __shared__ KnotKin K;
+  __shared__ HessCtx ctx[8];
+  __shared__ int nctx;
+  __shared__ double xs[H1_NX], us[H1_NU];
+  __shared__ double gsum[8][3];   // gradient residual vectors per Jacobian use: (set, is_vel, scale*vec)
+  __shared__ int gset[8], gvel[8], ng;
+  __shared__ double bal[8];       // balance scalars: r0 r1 om om1 om2 vc0 vc1 w
+  __shared__ int has_bal;
+
+  const double* xg = S.xbar + ((size_t)b * (N + 1) + t) * H1_NX;
+  if (lane < H1_NX) xs[lane] = xg[lane];
+  if (!term && lane < H1_NU) us[lane] = S.ubar[((size_t)b * N + t) * H1_NU + lane];
+  __syncthreads();
+  if (lane == 0) knot_base_kin(xs, K);
+  __syncthreads();
+  if (lane < 3) knot_point_set(K, lane);
+  __syncthreads();
+  if (lane < H1_NX) { knot_jac_column(K, 0, lane); knot_jac_column(K, 1, lane); knot_jac_column(K, 2, lane); }
+  __syncthreads();
+  if (lane == 0) {
+    int n = 0, g = 0; has_bal = 0;
+    const int* st = P.stance + b * P.stance_stride + 2 * t;
+    // CoM position: w ||com - ref||^2
+    if (P.w_com > 0.0) {
+      const double* ref = P.com_ref + b * P.com_ref_stride + t * 3;
+      double rb[3], e[3]; mv3(K.R0, K.S[0].beta, rb);
+      for (int k = 0; k < 3; ++k) e[k] = K.S[0].mfrac * K.xp[k] + rb[k] - ref[k];
+      make_ctx(K, ctx[n++], 0, 0, 2.0 * P.w_com, e);
+      gset[g] = 0; gvel[g] = 0; for (int k = 0; k < 3; ++k) gsum[g][k] = 2.0 * P.w_com * e[k]; ++g;
+    }
+    if (!term && P.w_com_vel > 0.0) {
+      const double* ref = P.com_vel_ref + b * P.com_vel_ref_stride + t * 3;
+      double v[3], e[3]; mv3(K.R0, K.S[0].gamma, v);
+      for (int k = 0; k < 3; ++k) e[k] = v[k] - ref[k];
+      make_ctx(K, ctx[n++], 0, 1, 2.0 * P.w_com_vel, e);
+      gset[g] = 0; gvel[g] = 1; for (int k = 0; k < 3; ++k) gsum[g][k] = 2.0 * P.w_com_vel * e[k]; ++g;
+    }
+    for (int ee = 0; ee < 2; ++ee) {
+      const int set = 1 + ee;
+      if (P.w_ee_pos > 0.0 && st[ee] != 1) {
+        const double* ref = P.ee_ref + b * P.ee_ref_stride + (t * 2 + ee) * 3;
+        double rb[3], e[3]; mv3(K.R0, K.S[set].beta, rb);
+        for (int k = 0; k < 3; ++k) e[k] = K.S[set].mfrac * K.xp[k] + rb[k] - ref[k];
+        make_ctx(K, ctx[n++], set, 0, 2.0 * P.w_ee_pos, e);
+        gset[g] = set; gvel[g] = 0; for (int k = 0; k < 3; ++k) gsum[g][k] = 2.0 * P.w_ee_pos * e[k]; ++g;
+      }
+      if (P.w_ee_vel > 0.0 && st[ee] == 1) {
+        double e[3]; mv3(K.R0, K.S[set].gamma, e);   // zero target (ilqr.cpp:734)
+        make_ctx(K, ctx[n++], set, 1, 2.0 * P.w_ee_vel, e);
+        gset[g] = set; gvel[g] = 1; for (int k = 0; k < 3; ++k) gsum[g][k] = 2.0 * P.w_ee_vel * e[k]; ++g;
+      }
+    }
+    double ps[2];
+    if (P.w_balance > 0.0 && support_point(P, b, t, ps)) {
+      const PointSetDev& C = K.S[0];
+      double rb[3], vc[3]; mv3(K.R0, C.beta, rb); mv3(K.R0, C.gamma, vc);
+      double com[3]; for (int k = 0; k < 3; ++k) com[k] = C.mfrac * K.xp[k] + rb[k];
+      const double gg = 9.81;
+      const double om = sqrt(com[2] / gg), om1 = 1.0 / (2.0 * gg * om), om2 = -1.0 / (4.0 * gg * gg * om * om * om);
+      const double r0 = com[0] + vc[0] * om - ps[0], r1 = com[1] + vc[1] * om - ps[1];
+      const double rv = r0 * vc[0] + r1 * vc[1];
+      bal[0] = r0; bal[1] = r1; bal[2] = om; bal[3] = om1; bal[4] = om2; bal[5] = vc[0]; bal[6] = vc[1]; bal[7] = rv;
+      has_bal = 1;
+      const double mu[3] = {r0, r1, om1 * rv}, nu[3] = {om * r0, om * r1, 0.0};
+      make_ctx(K, ctx[n++], 0, 0, P.w_balance, mu);
+      make_ctx(K, ctx[n++], 0, 1, P.w_balance, nu);
+    }
+    nctx = n; ng = g;
+  }
+  __syncthreads();
+
+  const double* Qd = term ? P.Qf : P.Q;
+  const double* xr = P.x_ref + b * P.x_ref_stride + t * H1_NX;
+  // upright pieces (4 quaternion slots, derivatives.cpp:646-666 labelling)
+  const double ua = K.xp[3], ub = K.xp[4], uc = K.xp[5], ud = K.xp[6];
+  const double ur[3] = {2.0 * (ub * ud + ua * uc), 2.0 * (uc * ud - ua * ub), -2.0 * (ub * ub + uc * uc)};
+  const double uJ[3][4] = {{2 * uc, 2 * ud, 2 * ua, 2 * ub}, {-2 * ub, -2 * ua, 2 * ud, 2 * uc}, {0, -4 * ub, -4 * uc, 0}};
+
+  // ---- gradient lx (lane = coordinate)
+  if (lane < H1_NX) {
+    const int a = lane;
+    double g = Qd[a] * (xs[a] - xr[a]);
+    for (int i = 0; i < ng; ++i) {
+      const double (*J)[H1_NX] = gvel[i] ? K.Jv[gset[i]] : K.Jc[gset[i]];
+      g += J[0][a] * gsum[i][0] + J[1][a] * gsum[i][1] + J[2][a] * gsum[i][2];
+    }
+    if (P.w_upright > 0.0 && a >= 3 && a < 7) g += P.w_upright * (uJ[0][a - 3] * ur[0] + uJ[1][a - 3] * ur[1] + uJ[2][a - 3] * ur[2]);
+    if (has_bal) {
+      const double om = bal[2], om1 = bal[3];
+      const double jr0 = K.Jc[0][0][a] + om * K.Jv[0][0][a] + bal[5] * om1 * K.Jc[0][2][a];
+      const double jr1 = K.Jc[0][1][a] + om * K.Jv[0][1][a] + bal[6] * om1 * K.Jc[0][2][a];
+      g += P.w_balance * (jr0 * bal[0] + jr1 * bal[1]);
+    }
+    if (a >= 7 && a < H1_NQ) {
+      double lo, hi; limit_bounds(H1_JRANGE[a - 7], lo, hi);
+      const double q = xs[a];
+      if (q > hi) g += 2.0 * P.w_joint * (q - hi);
+      if (q < lo) g += -2.0 * P.w_joint * (lo - q);
+    }
+    S.lx[((size_t)b * (N + 1) + t) * H1_NX + a] = g;
+  }
+  if (!term && lane < H1_NU) {
+    const double* ur_ = P.u_ref + b * P.u_ref_stride + t * H1_NU;
+    const double u = us[lane];
+    double g = P.R[lane] * (u - ur_[lane]), h = P.R[lane];
+    double lo, hi; limit_bounds(H1_CTRLRANGE[lane], lo, hi);
+    if (u > hi) g += 2.0 * P.w_ctrl * (u - hi);
+    if (u < lo) g += -2.0 * P.w_ctrl * (lo - u);
+    if (u > hi || u < lo) h += 2.0 * P.w_ctrl;
+    S.lu[((size_t)b * N + t) * H1_NU + lane] = g;
+    S.luu[((size_t)b * N + t) * H1_NU + lane] = h;
+  }
+
+  // ---- Hessian lxx: upper triangle entries distributed over the lanes, mirrored on store
+  double* Hg = S.lxx + ((size_t)b * (N + 1) + t) * H1_NX * H1_NX;
+  const int NT = H1_NX * (H1_NX + 1) / 2;
+  for (int idx = lane; idx < NT; idx += 64) {
+    int a = (int)((2 * H1_NX + 1 - sqrt((double)(2 * H1_NX + 1) * (2 * H1_NX + 1) - 8.0 * idx)) * 0.5);
+    while ((a + 1) * H1_NX - ((a + 1) * a) / 2 <= idx) ++a;
+    while (a * H1_NX - (a * (a - 1)) / 2 > idx) --a;
+    const int bb = a + (idx - (a * H1_NX - (a * (a - 1)) / 2));
+    double h = (a == bb) ? Qd[a] : 0.0;
+    for (int i = 0; i < ng; ++i) {
+      const double (*J)[H1_NX] = gvel[i] ? K.Jv[gset[i]] : K.Jc[gset[i]];
+      // 2w J^T J : scale is carried by ctx; recover it from the matching context (same order as ctx[0..ng))
+      h += ctx[i].scale * (J[0][a] * J[0][bb] + J[1][a] * J[1][bb] + J[2][a] * J[2][bb]);
+    }
+    for (int i = 0; i < nctx; ++i) h += ctx[i].scale * (ctx[i].is_vel ? hess_vel_entry(K, ctx[i], a, bb) : hess_pos_entry(K, ctx[i], a, bb));
+    if (P.w_upright > 0.0 && a >= 3 && bb < 7) {
+      const int i = a - 3, j = bb - 3;
+      double v = uJ[0][i] * uJ[0][j] + uJ[1][i] * uJ[1][j] + uJ[2][i] * uJ[2][j];
+      if ((i == 0 && j == 2) || (i == 1 && j == 3)) v += 2.0 * ur[0];
+      if (i == 2 && j == 3) v += 2.0 * ur[1];
+      if (i == 0 && j == 1) v += -2.0 * ur[1];
+      if ((i == 1 && j == 1) || (i == 2 && j == 2)) v += -4.0 * ur[2];
+      h += P.w_upright * v;
+    }
+    if (has_bal) {
+      const double om = bal[2], om1 = bal[3], om2 = bal[4];
+      const double jza = K.Jc[0][2][a], jzb = K.Jc[0][2][bb];
+      const double jr0a = K.Jc[0][0][a] + om * K.Jv[0][0][a] + bal[5] * om1 * jza, jr0b = K.Jc[0][0][bb] + om * K.Jv[0][0][bb] + bal[5] * om1 * jzb;
+      const double jr1a = K.Jc[0][1][a] + om * K.Jv[0][1][a] + bal[6] * om1 * jza, jr1b = K.Jc[0][1][bb] + om * K.Jv[0][1][bb] + bal[6] * om1 * jzb;
+      double v = jr0a * jr0b + jr1a * jr1b;
+      v += om1 * (bal[0] * (K.Jv[0][0][a] * jzb + jza * K.Jv[0][0][bb]) + bal[1] * (K.Jv[0][1][a] * jzb + jza * K.Jv[0][1][bb]));
+      v += bal[7] * om2 * jza * jzb;
+      h += P.w_balance * v;
+    }
+    if (a == bb && a >= 7 && a < H1_NQ) {
+      double lo, hi; limit_bounds(H1_JRANGE[a - 7], lo, hi);
+      const double q = xs[a];
+      if (q > hi || q < lo) h += 2.0 * P.w_joint;
+    }
+    Hg[a * H1_NX + bb] = h;
+    if (a != bb) Hg[bb * H1_NX + a] = h;
+  }
+}
+
+// ------------------------------------------------------------------ K4: Riccati backward pass
+// one 256-thread workgroup per rollout; Vxx, A_t, W, B_t, G, Qxu, K_t staged in LDS.
+#define LDN 52   // padded leading dimension of 51-wide LDS matrices
+#define LDM 20   // padded leading dimension of 19-wide LDS matrices
+__global__ void __launch_bounds__(256) k_backward(DevState S, int mode) {
+  const int b = blockIdx.x, tid = threadIdx.x;
+  if (!selected(S, b, mode)) return;
+  const int N = S.N, n = H1_NX, m = H1_NU;
+  extern __shared__ double sm[];
+  double* Vxx = sm;                 // n x LDN  (also holds Qxx)
+  double* At = Vxx + n * LDN;       // n x LDN
+  double* W = At + n * LDN;         // n x LDN  (also T1)
+  double* Bt = W + n * LDN;         // n x LDM
+  double* G = Bt + n * LDM;         // n x LDM
+  double* Qxu = G + n * LDM;        // n x LDM
+  double* Kt = Qxu + n * LDM;       // m x LDN
+  double* Mq = Kt + m * LDN;        // m x LDN  (Quu K)
+  double* Quu = Mq + m * LDN;       // m x LDM
+  double* Lc = Quu + m * LDM;       // m x LDM  (Cholesky factor or inverse)
+  double* Vx = Lc + m * LDM;        // n
+  double* Qx = Vx + n;              // n
+  double* Qu = Qx + n;              // m (+pad)
+  double* kt = Qu + LDM;            // m (+pad)
+  double* Quuk = kt + LDM;          // m (+pad)
+  __shared__ int chol_fail, use_inv;
+
+  const double lam = S.lambda[b];
+  const double* lxg = S.lx + (size_t)b * (N + 1) * n;
+  const double* lxxg = S.lxx + (size_t)b * (N + 1) * n * n;
+  for (int e = tid; e < n * n; e += 256) Vxx[(e / n) * LDN + (e % n)] = lxxg[(size_t)N * n * n + e];
+  if (tid < n) Vx[tid] = lxg[N * n + tid];
+  __syncthreads();
+
+  for (int t = N - 1; t >= 0; --t) {
+    const double* Ag = S.A + ((size_t)b * N + t) * n * n;
+    const double* Bg = S.Bm + ((size_t)b * N + t) * n * m;
+    for (int e = tid; e < n * n; e += 256) At[(e / n) * LDN + (e % n)] = Ag[e];
+    for (int e = tid; e < n * m; e += 256) Bt[(e / m) * LDM + (e % m)] = Bg[e];
+    __syncthreads();
+    // W = Vxx A ; G = Vxx B ; Qx = lx + A^T Vx ; Qu = lu + B^T Vx
+    for (int e = tid; e < n * n; e += 256) {
+      const int i = e / n, j = e % n; double s = 0.0;
+      for (int k = 0; k < n; ++k) s += Vxx[i * LDN + k] * At[k * LDN + j];
+      W[i * LDN + j] = s;
+    }
+    for (int e = tid; e < n * m; e += 256) {
+      const int i = e / m, j = e % m; double s = 0.0;
+      for (int k = 0; k < n; ++k) s += Vxx[i * LDN + k] * Bt[k * LDM + j];
+      G[i * LDM + j] = s;
+    }
+    if (tid < n) { double s = 0.0; for (int k = 0; k < n; ++k) s += At[k * LDN + tid] * Vx[k]; Qx[tid] = lxg[t * n + tid] + s; }
+    else if (tid >= 64 && tid < 64 + m) { const int i = tid - 64; double s = 0.0; for (int k = 0; k < n; ++k) s += Bt[k * LDM + i] * Vx[k]; Qu[i] = S.lu[((size_t)b * N + t) * m + i] + s; }
+    __syncthreads();
+    // Qxx = lxx + A^T W (into Vxx) ; Quu = luu + B^T G + lam I ; Qxu = A^T G
+    for (int e = tid; e < n * n; e += 256) {
+      const int i = e / n, j = e % n; double s = 0.0;
+      for (int k = 0; k < n; ++k) s += At[k * LDN + i] * W[k * LDN + j];
+      Vxx[i * LDN + j] = lxxg[(size_t)t * n * n + e] + s;
+    }
+    for (int e = tid; e < n * m; e += 256) {
+      const int i = e / m, j = e % m; double s = 0.0;
+      for (int k = 0; k < n; ++k) s += At[k * LDN + i] * G[k * LDM + j];
+      Qxu[i * LDM + j] = s;
+    }
+    for (int e = tid; e < m * m; e += 256) {
+      const int i = e / m, j = e % m; double s = 0.0;
+      for (int k = 0; k < n; ++k) s += Bt[k * LDM + i] * G[k * LDM + j];
+      if (i == j) s += S.luu[((size_t)b * N + t) * m + i] + lam;
+      Quu[i * LDM + j] = s;
+    }
+    __syncthreads();
+    // Cholesky (LLT check, +1e-4 I once, ilqr.cpp:278-281); single thread keeps the branchy part simple
+    if (tid == 0) {
+      use_inv = 0;
+      for (int attempt = 0; attempt < 2; ++attempt) {
+        int fail = 0;
+        for (int j = 0; j < m && !fail; ++j) {
+          double s = Quu[j * LDM + j];
+          for (int k = 0; k < j; ++k) s -= Lc[j * LDM + k] * Lc[j * LDM + k];
+          if (!(s > 0.0)) { fail = 1; break; }
+          const double d = sqrt(s); Lc[j * LDM + j] = d;
+          for (int i = j + 1; i < m; ++i) { double v = Quu[i * LDM + j]; for (int k = 0; k < j; ++k) v -= Lc[i * LDM + k] * Lc[j * LDM + k]; Lc[i * LDM + j] = v / d; }
+        }
+        chol_fail = fail;
+        if (!fail) break;
+        if (attempt == 0) for (int i = 0; i < m; ++i) Quu[i * LDM + i] += 1e-4;
+      }
+      if (chol_fail) {
+        // indefinite Quu: the reference's pivoted LDLT still solves; use Gauss-Jordan inverse with partial pivoting
+        double Mx[H1_NU][2 * H1_NU];
+        for (int i = 0; i < m; ++i) for (int j = 0; j < m; ++j) { Mx[i][j] = Quu[i * LDM + j]; Mx[i][m + j] = (i == j) ? 1.0 : 0.0; }
+        for (int c = 0; c < m; ++c) {
+          int p = c; double best = fabs(Mx[c][c]);
+          for (int r = c + 1; r < m; ++r) if (fabs(Mx[r][c]) > best) { best = fabs(Mx[r][c]); p = r; }
+          if (p != c) for (int k = 0; k < 2 * m; ++k) { const double tmp = Mx[c][k]; Mx[c][k] = Mx[p][k]; Mx[p][k] = tmp; }
+          const double ip = 1.0 / Mx[c][c];
+          for (int k = 0; k < 2 * m; ++k) Mx[c][k] *= ip;
+          for (int r = 0; r < m; ++r) if (r != c) { const double f = Mx[r][c]; for (int k = 0; k < 2 * m; ++k) Mx[r][k] -= f * Mx[c][k]; }
+        }
+        for (int i = 0; i < m; ++i) for (int j = 0; j < m; ++j) Lc[i * LDM + j] = Mx[i][m + j];
+        use_inv = 1;
+      }
+    }
+    __syncthreads();
+    // K = -Quu^-1 Qxu^T (one thread per column), k = -Quu^-1 Qu
+    if (tid <= n) {
+      double rhs[H1_NU], y[H1_NU], xsol[H1_NU];
+      if (tid < n) { for (int i = 0; i < m; ++i) rhs[i] = Qxu[tid * LDM + i]; } else { for (int i = 0; i < m; ++i) rhs[i] = Qu[i]; }
+      if (!use_inv) {
+        for (int i = 0; i < m; ++i) { double s = rhs[i]; for (int k = 0; k < i; ++k) s -= Lc[i * LDM + k] * y[k]; y[i] = s / Lc[i * LDM + i]; }
+        for (int i = m - 1; i >= 0; --i) { double s = y[i]; for (int k = i + 1; k < m; ++k) s -= Lc[k * LDM + i] * xsol[k]; xsol[i] = s / Lc[i * LDM + i]; }
+      } else {
+        for (int i = 0; i < m; ++i) { double s = 0.0; for (int k = 0; k < m; ++k) s += Lc[i * LDM + k] * rhs[k]; xsol[i] = s; }
+      }
+      if (tid < n) { for (int i = 0; i < m; ++i) Kt[i * LDN + tid] = -xsol[i]; } else { for (int i = 0; i < m; ++i) kt[i] = -xsol[i]; }
+    }
+    __syncthreads();
+    // store gains; Mq = Quu K ; Quuk = Quu k
+    double* Kg = S.K + ((size_t)b * N + t) * m * n;
+    for (int e = tid; e < m * n; e += 256) Kg[e] = Kt[(e / n) * LDN + (e % n)];
+    if (tid < m) S.kff[((size_t)b * N + t) * m + tid] = kt[tid];
+    for (int e = tid; e < m * n; e += 256) {
+      const int a = e / n, j = e % n; double s = 0.0;
+      for (int c = 0; c < m; ++c) s += Quu[a * LDM + c] * Kt[c * LDN + j];
+      Mq[a * LDN + j] = s;
+    }
+    if (tid < m) { double s = 0.0; for (int c = 0; c < m; ++c) s += Quu[tid * LDM + c] * kt[c]; Quuk[tid] = s; }
+    __syncthreads();
+    // Vx = Qx + K^T Quu k + K^T Qu + Qxu k ; T1 = Qxx + K^T Quu K + K^T Qxu^T + Qxu K (into W)
+    double nvx = 0.0;
+    if (tid < n) {
+      double s1 = 0.0, s2 = 0.0, s3 = 0.0;
+      for (int a = 0; a < m; ++a) { s1 += Kt[a * LDN + tid] * Quuk[a]; s2 += Kt[a * LDN + tid] * Qu[a]; s3 += Qxu[tid * LDM + a] * kt[a]; }
+      nvx = Qx[tid] + s1 + s2 + s3;
+    }
+    for (int e = tid; e < n * n; e += 256) {
+      const int i = e / n, j = e % n; double s1 = 0.0, s2 = 0.0, s3 = 0.0;
+      for (int a = 0; a < m; ++a) { const double kai = Kt[a * LDN + i]; s1 += kai * Mq[a * LDN + j]; s2 += kai * Qxu[j * LDM + a]; s3 += Qxu[i * LDM + a] * Kt[a * LDN + j]; }
+      W[i * LDN + j] = Vxx[i * LDN + j] + s1 + s2 + s3;
+    }
+    __syncthreads();
+    if (tid < n) Vx[tid] = nvx;
+    for (int e = tid; e < n * n; e += 256) { const int i = e / n, j = e % n; Vxx[i * LDN + j] = 0.5 * (W[i * LDN + j] + W[j * LDN + i]); }
+    __syncthreads();
+  }
+  // value function at knot 0 (parity artefact)
+  for (int e = tid; e < n * n; e += 256) S.Vxx[(size_t)b * n * n + e] = Vxx[(e / n) * LDN + (e % n)];
+  if (tid < n) S.Vx[(size_t)b * n + tid] = Vx[tid];
+}
+size_t backward_lds_bytes() {
+  const int n = H1_NX, m = H1_NU;
+  return sizeof(double) * (size_t)(3 * n * LDN + 3 * n * LDM + 2 * m * LDN + 2 * m * LDM + 2 * n + 3 * LDM);
+}
+
+// ------------------------------------------------------------------ K5: line search, all 8 alphas at once
+// thread per (rollout, alpha); candidates kept in HBM, k_control copies the accepted one.
+__constant__ double ALPHAS[8] = {1.0, 0.8, 0.6, 0.4, 0.2, 0.1, 0.05, 0.01};
+__global__ void __launch_bounds__(64) k_line_search(DevState S, ProblemDev P, int mode) {
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  const int b = gid >> 3, ai = gid & 7;
+  if (b >= S.B || !selected(S, b, mode)) return;
+  const int N = S.N, n = H1_NX, m = H1_NU;
+  const double alpha = ALPHAS[ai];
+  const double* xb = S.xbar + (size_t)b * (N + 1) * n;
+  const double* ub = S.ubar + (size_t)b * N * m;
+  const double* Kg = S.K + (size_t)b * N * m * n;
+  const double* kg = S.kff + (size_t)b * N * m;
+  double* xc = S.xcand + ((size_t)b * 8 + ai) * (N + 1) * n;
+  double* uc = S.ucand + ((size_t)b * 8 + ai) * N * m;
+  double x[H1_NX], xn[H1_NX], u[H1_NU], dx[H1_NX];
+  for (int i = 0; i < n; ++i) { x[i] = S.x0[(size_t)b * n + i]; xc[i] = x[i]; }
+  double c = 0.0;
+  for (int t = 0; t < N; ++t) {
+    for (int j = 0; j < n; ++j) dx[j] = x[j] - xb[t * n + j];
+    for (int i = 0; i < m; ++i) {
+      double s = 0.0;
+      const double* Kr = Kg + ((size_t)t * m + i) * n;
+      for (int j = 0; j < n; ++j) s += Kr[j] * dx[j];
+      u[i] = ub[t * m + i] + alpha * kg[t * m + i] + s;
+      uc[t * m + i] = u[i];
+    }
+    c += knot_cost(P, b, t, x, u);
+    step<double>(x, u, P.dyn, xn);
+    for (int i = 0; i < n; ++i) { x[i] = xn[i]; xc[(t + 1) * n + i] = xn[i]; }
+  }
+  c += knot_cost(P, b, N, x, nullptr);
+  S.cand_cost[(size_t)b * 8 + ai] = c;
+}
+
+// ------------------------------------------------------------------ K6: iteration control
+// one wave per rollout: lane 0 decides (ilqr.cpp:619-655), all lanes copy the accepted candidate.
+// phase 0: after the first line search of an iteration; phase 1: after the retry line search;
+// phase 2: stage API (report only, accept if improved, no lambda / activity bookkeeping).
+__global__ void __launch_bounds__(64) k_control(DevState S, int phase, int iter, double tol, int early_exit) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  __shared__ int s_accept;
+  const int N = S.N;
+  if (phase == 0 && !S.active[b]) return;
+  if (phase == 1 && !(S.active[b] && S.need_retry[b])) return;
+  if (lane == 0) {
+    const double base = S.Jbase[b];
+    int acc = -1;
+    for (int a = 0; a < 8; ++a) { const double c = S.cand_cost[(size_t)b * 8 + a]; if (c < base - 1e-6) { acc = a; break; } }
+    s_accept = acc;
+    S.improved[b] = acc >= 0;
+    S.alpha_idx[b] = acc;
+    if (phase == 2) {
+      S.ls_cost[b] = acc >= 0 ? S.cand_cost[(size_t)b * 8 + acc] : base;
+    } else {
+      const double lam_used = S.lambda[b];
+      const int tr = iter;  // trace slot
+      if (acc >= 0) {
+        const double Jprev = S.J[b];
+        const double Jn = S.cand_cost[(size_t)b * 8 + acc];
+        S.J[b] = Jn;
+        S.lambda[b] = fmax(lam_used / 2.0, 1e-6);
+        S.need_retry[b] = 0;
+        S.trace_cost[(size_t)b * (S.max_iter + 1) + tr + 1] = Jn;
+        S.trace_alpha[(size_t)b * S.max_iter + tr] = ALPHAS[acc];
+        S.trace_lambda[(size_t)b * S.max_iter + tr] = lam_used;
+        if (early_exit && (fabs(Jn - Jprev) < tol || Jn > 1e6)) S.active[b] = 0;
+      } else if (phase == 0) {
+        S.lambda[b] = fmin(lam_used * 10.0, 1e-3);
+        S.need_retry[b] = 1;
+      } else {
+        S.need_retry[b] = 0;
+        S.trace_cost[(size_t)b * (S.max_iter + 1) + tr + 1] = S.J[b];
+        S.trace_alpha[(size_t)b * S.max_iter + tr] = 0.0;
+        S.trace_lambda[(size_t)b * S.max_iter + tr] = lam_used;
+        if (early_exit && iter > 1) S.active[b] = 0;
+      }
+    }
+  }
+  __syncthreads();
+  const int acc = s_accept;
+  if (acc < 0) return;
+  const double* xc = S.xcand + ((size_t)b * 8 + acc) * (N + 1) * H1_NX;
+  const double* uc = S.ucand + ((size_t)b * 8 + acc) * N * H1_NU;
+  double* xb = S.xbar + (size_t)b * (N + 1) * H1_NX;
+  double* ub = S.ubar + (size_t)b * N * H1_NU;
+  for (int e = lane; e < (N + 1) * H1_NX; e += 64) xb[e] = xc[e];
+  for (int e = lane; e < N * H1_NU; e += 64) ub[e] = uc[e];
+}
+
+// solve prologue: J = initial cost, trace[0], counters
+__global__ void k_solve_begin(DevState S) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= S.B) return;
+  S.active[b] = 1; S.need_retry[b] = 0; S.iters[b] = 0;
+  const double J0 = S.Jbase[b];
+  S.J[b] = J0;
+  for (int i = 0; i <= S.max_iter; ++i) S.trace_cost[(size_t)b * (S.max_iter + 1) + i] = (i == 0) ? J0 : __builtin_nan("");
+  for (int i = 0; i < S.max_iter; ++i) { S.trace_alpha[(size_t)b * S.max_iter + i] = __builtin_nan(""); S.trace_lambda[(size_t)b * S.max_iter + i] = __builtin_nan(""); }
+}
+
+// warm start shift (ilqr.cpp:68-80): in place on the resident solution; the last state is re-rolled by the caller
+__global__ void k_warm_shift(DevState S, const double* prev_x, const double* prev_u) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const int N = S.N, n = H1_NX, m = H1_NU;
+  double* xb = S.xbar + (size_t)b * (N + 1) * n;
+  double* ub = S.ubar + (size_t)b * N * m;
+  const double* px = prev_x + (size_t)b * (N + 1) * n;
+  const double* pu = prev_u + (size_t)b * N * m;
+  for (int e = lane; e < n; e += blockDim.x) xb[e] = S.x0[(size_t)b * n + e];
+  for (int e = lane; e < (N - 1) * n; e += blockDim.x) xb[n + e] = px[2 * n + e];
+  for (int e = lane; e < (N - 1) * m; e += blockDim.x) ub[e] = pu[m + e];
+  for (int e = lane; e < m; e += blockDim.x) ub[(N - 1) * m + e] = pu[(N - 1) * m + e];
+}
+// last knot of the warm start: xbar[N] = f(xbar[N-1], ubar[N-1])
+__global__ void k_last_step(DevState S, ProblemDev P) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= S.B) return;
+  const int N = S.N;
+  double x[H1_NX], u[H1_NU], xn[H1_NX];
+  for (int i = 0; i < H1_NX; ++i) x[i] = S.xbar[((size_t)b * (N + 1) + N - 1) * H1_NX + i];
+  for (int i = 0; i < H1_NU; ++i) u[i] = S.ubar[((size_t)b * N + N - 1) * H1_NU + i];
+  step<double>(x, u, P.dyn, xn);
+  for (int i = 0; i < H1_NX; ++i) S.xbar[((size_t)b * (N + 1) + N) * H1_NX + i] = xn[i];
+}
+
+// u = ubar[0] + K[0] (x_meas - xbar[0]); also packs the first-knot results for the per-step gather
+__global__ void k_compute_control(DevState S, const double* x_meas, double* u_out) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const int N = S.N, n = H1_NX, m = H1_NU;
+  if (lane >= m) return;
+  const double* Kr = S.K + ((size_t)b * N * m + lane) * n;
+  const double* xb = S.xbar + (size_t)b * (N + 1) * n;
+  double s = S.ubar[(size_t)b * N * m + lane];
+  for (int j = 0; j < n; ++j) s += Kr[j] * (x_meas[(size_t)b * n + j] - xb[j]);
+  u_out[(size_t)b * m + lane] = s;
+}
+__global__ void k_pack_first_knot(DevState S, double* u0, double* K0) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const int N = S.N, n = H1_NX, m = H1_NU;
+  for (int e = lane; e < m; e += blockDim.x) u0[(size_t)b * m + e] = S.ubar[(size_t)b * N * m + e];
+  for (int e = lane; e < m * n; e += blockDim.x) K0[(size_t)b * m * n + e] = S.K[(size_t)b * N * m * n + e];
+}
+
+// ------------------------------------------------------------------ launchers
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+void launch_rollout(const DevState& S, const ProblemDev& P, int mode, int do_roll, int count_iter, double* cost_out, hipStream_t st) {
+  hipLaunchKernelGGL(k_rollout, dim3(cdiv(S.B, 64)), dim3(64), 0, st, S, P, mode, do_roll, count_iter, cost_out);
+}
+void launch_step(int count, const double* x, const double* u, const DynParams& dyn, double* xn, hipStream_t st) {
+  hipLaunchKernelGGL(k_step, dim3(cdiv(count, 64)), dim3(64), 0, st, count, x, u, dyn, xn);
+}
+void launch_linearize(const DevState& S, const ProblemDev& P, int mode, int jac_mode, double eps, hipStream_t st) {
+  const long total = (long)S.B * S.N * (H1_NX + H1_NU);
+  hipLaunchKernelGGL(k_linearize, dim3(cdiv(total, 64)), dim3(64), 0, st, S, P, mode, jac_mode, eps);
+}
+void launch_cost_quadratics(const DevState& S, const ProblemDev& P, int mode, hipStream_t st) {
+  hipLaunchKernelGGL(k_cost_quadratics, dim3(S.N + 1, S.B), dim3(64), 0, st, S, P, mode);
+}
+void launch_backward(const DevState& S, int mode, hipStream_t st) {
+  hipLaunchKernelGGL(k_backward, dim3(S.B), dim3(256), backward_lds_bytes(), st, S, mode);
+}
+void launch_line_search(const DevState& S, const ProblemDev& P, int mode, hipStream_t st) {
+  hipLaunchKernelGGL(k_line_search, dim3(cdiv((long)S.B * 8, 64)), dim3(64), 0, st, S, P, mode);
+}
+void launch_control(const DevState& S, int phase, int iter, double tol, int early_exit, hipStream_t st) {
+  hipLaunchKernelGGL(k_control, dim3(S.B), dim3(64), 0, st, S, phase, iter, tol, early_exit);
+}
+void launch_solve_begin(const DevState& S, hipStream_t st) { hipLaunchKernelGGL(k_solve_begin, dim3(cdiv(S.B, 64)), dim3(64), 0, st, S); }
+void launch_warm_shift(const DevState& S, const double* px, const double* pu, hipStream_t st) { hipLaunchKernelGGL(k_warm_shift, dim3(S.B), dim3(64), 0, st, S, px, pu); }
+void launch_last_step(const DevState& S, const ProblemDev& P, hipStream_t st) { hipLaunchKernelGGL(k_last_step, dim3(cdiv(S.B, 64)), dim3(64), 0, st, S, P); }
+void launch_compute_control(const DevState& S, const double* x_meas, double* u_out, hipStream_t st) { hipLaunchKernelGGL(k_compute_control, dim3(S.B), dim3(64), 0, st, S, x_meas, u_out); }
+void launch_pack_first_knot(const DevState& S, double* u0, double* K0, hipStream_t st) { hipLaunchKernelGGL(k_pack_first_knot, dim3(S.B), dim3(64), 0, st, S, u0, K0); }
+int backward_needs_lds_attr() {
+  return hipFuncSetAttribute((const void*)k_backward, hipFuncAttributeMaxDynamicSharedMemorySize, (int)backward_lds_bytes()) == hipSuccess ? 0 : 1;
+}
+
+}  // namespace ilqr

@@ -1,0 +1,316 @@
+"""Host-side Python mirror of the reference's solver interface over the C-ABI HIP library.
+
+`BatchedILQR` mirrors `iLQR` (reference include/ilqr/ilqr.hpp:17-45) for a batch of B independent
+rollouts; `BatchedMPC` mirrors `MPC::stepOnce` (reference include/ilqr/mpc.hpp:18-47,
+src/ilqr/mpc.cpp:40-127).  All compute happens in libilqr_hip.so (hand-written HIP kernels for
+gfx950); there is no CPU fallback -- constructing a solver without the library or without a GPU
+raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+NX, NU, NQ, NV = 51, 19, 26, 25
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libilqr_hip.so")
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int)
+
+STATUS = {0: "ILQR_OK", 1: "ILQR_ERR_ARG", 2: "ILQR_ERR_HIP", 3: "ILQR_ERR_NO_DEVICE", 4: "ILQR_ERR_STATE", 5: "ILQR_ERR_UNSUPPORTED"}
+JAC_ANALYTIC, JAC_FD_FORWARD = 0, 1
+
+# every symbol include/ilqr_hip.h declares (checked by the CPU test-suite against the built library)
+EXPORTS = [
+    "ilqr_hip_create", "ilqr_hip_destroy", "ilqr_hip_last_error", "ilqr_hip_batch", "ilqr_hip_horizon",
+    "ilqr_hip_set_cost_weights", "ilqr_hip_set_task_weights", "ilqr_hip_set_constraint_weights", "ilqr_hip_set_gravity",
+    "ilqr_hip_set_contact_schedule", "ilqr_hip_set_ee_references", "ilqr_hip_set_references",
+    "ilqr_hip_set_regularization", "ilqr_hip_set_max_iterations", "ilqr_hip_set_tolerance", "ilqr_hip_set_options",
+    "ilqr_hip_initialize", "ilqr_hip_initialize_warm_resident", "ilqr_hip_initialize_device",
+    "ilqr_hip_solve", "ilqr_hip_solve_async", "ilqr_hip_synchronize",
+    "ilqr_hip_get_xbar", "ilqr_hip_get_ubar", "ilqr_hip_get_gains_K", "ilqr_hip_get_gains_kff", "ilqr_hip_get_cost",
+    "ilqr_hip_get_iterations", "ilqr_hip_get_lambda", "ilqr_hip_get_trace", "ilqr_hip_first_knot_device", "ilqr_hip_compute_control",
+    "ilqr_hip_set_trajectory", "ilqr_hip_stage_rollout", "ilqr_hip_stage_linearize", "ilqr_hip_stage_cost_quadratics",
+    "ilqr_hip_stage_backward_pass", "ilqr_hip_stage_line_search", "ilqr_hip_stage_total_cost",
+    "ilqr_hip_get_linearization", "ilqr_hip_set_linearization", "ilqr_hip_get_quadratics", "ilqr_hip_set_quadratics",
+    "ilqr_hip_get_value_function", "ilqr_hip_step", "ilqr_hip_enable_profiling", "ilqr_hip_get_stage_ms",
+    "ilqr_hip_reference_kinematics", "ilqr_hip_gravity_compensation", "ilqr_hip_stream",
+]
+
+_lib = None
+
+
+class ILQRError(RuntimeError):
+    pass
+
+
+def load_library(path=LIB_PATH):
+    """Load libilqr_hip.so; fails loudly when the HIP extension has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(path):
+            raise ILQRError("HIP extension missing: %s (run __graft_entry__.build())" % path)
+        _lib = C.CDLL(path)
+        _lib.ilqr_hip_last_error.restype = C.c_char_p
+        _lib.ilqr_hip_stream.restype = C.c_void_p
+    return _lib
+
+
+def _c64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(_dp)
+
+
+def reference_kinematics(x):
+    """(com[3], ee[2,3]) as RobotUtils::loadReferences computes them (robot_utils.cpp:369-403)."""
+    L = load_library()
+    x = _c64(x)
+    com, ee = np.zeros(3), np.zeros((2, 3))
+    rc = L.ilqr_hip_reference_kinematics(_p(x), _p(com), _p(ee))
+    if rc:
+        raise ILQRError(STATUS.get(rc, str(rc)))
+    return com, ee
+
+
+def gravity_compensation(x, gravity):
+    """qfrc_bias[6+i] at zero velocity (RobotUtils::computeGravComp, robot_utils.cpp:844-866)."""
+    L = load_library()
+    x, g = _c64(x), _c64(gravity)
+    u = np.zeros(NU)
+    rc = L.ilqr_hip_gravity_compensation(_p(x), _p(g), _p(u))
+    if rc:
+        raise ILQRError(STATUS.get(rc, str(rc)))
+    return u
+
+
+class BatchedILQR:
+    """iLQR for B independent rollouts on one GPU (reference include/ilqr/ilqr.hpp:17-45)."""
+
+    def __init__(self, batch, N=25, dt=0.02, device=0):
+        self.L = load_library()
+        self.B, self.N, self.dt = int(batch), int(N), float(dt)
+        self.max_iter = 10
+        h = C.c_void_p()
+        rc = self.L.ilqr_hip_create(C.byref(h), int(device), self.B, self.N, C.c_double(self.dt))
+        self.h = h
+        if rc:
+            msg = self.L.ilqr_hip_last_error(h).decode() if h else ""
+            raise ILQRError("ilqr_hip_create failed: %s %s" % (STATUS.get(rc, rc), msg))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.ilqr_hip_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc:
+            raise ILQRError("%s: %s" % (STATUS.get(rc, rc), self.L.ilqr_hip_last_error(self.h).decode()))
+
+    # ---- problem data (RobotUtils setters)
+    def set_problem(self, prob):
+        L, h = self.L, self.h
+        self._chk(L.ilqr_hip_set_cost_weights(h, _p(_c64(prob["Q"])), _p(_c64(prob["R"])), _p(_c64(prob["Qf"]))))
+        self._chk(L.ilqr_hip_set_task_weights(h, *[C.c_double(float(v)) for v in prob["task_weights"]]))
+        self._chk(L.ilqr_hip_set_constraint_weights(h, C.c_double(prob["w_joint"]), C.c_double(prob["w_ctrl"])))
+        g = prob["gravity"]
+        self.gravity = np.array(g, dtype=np.float64)
+        self._chk(L.ilqr_hip_set_gravity(h, C.c_double(g[0]), C.c_double(g[1]), C.c_double(g[2])))
+        st = np.ascontiguousarray(prob["stance"], dtype=np.int32)
+        self._chk(L.ilqr_hip_set_contact_schedule(h, st.ctypes.data_as(_ip), int(st.shape[0])))
+        ee, cv = _c64(prob["ee_ref"]), _c64(prob["com_vel_ref"])
+        self._chk(L.ilqr_hip_set_ee_references(h, _p(ee), _p(cv), int(ee.shape[0])))
+        self.set_references(prob["x_ref"], prob["u_ref"], prob["com_ref"])
+
+    def set_references(self, x_ref, u_ref, com_ref):
+        x_ref, u_ref, com_ref = _c64(x_ref), _c64(u_ref), _c64(com_ref)
+        if x_ref.shape[1:] != (self.N + 1, NX) or u_ref.shape[1:] != (self.N, NU) or com_ref.shape[1:] != (self.N + 1, 3):
+            raise ILQRError("reference size mismatch")  # iLQR::solve returns false (ilqr.cpp:526-532)
+        self._chk(self.L.ilqr_hip_set_references(self.h, _p(x_ref), _p(u_ref), _p(com_ref), int(x_ref.shape[0])))
+
+    # ---- options (ilqr.hpp:22-24)
+    def set_regularization(self, lam):
+        self._chk(self.L.ilqr_hip_set_regularization(self.h, C.c_double(lam)))
+
+    def set_max_iterations(self, n):
+        self._chk(self.L.ilqr_hip_set_max_iterations(self.h, int(n)))
+        self.max_iter = int(n)
+
+    def set_tolerance(self, tol):
+        self._chk(self.L.ilqr_hip_set_tolerance(self.h, C.c_double(tol)))
+
+    def set_options(self, jacobian_mode=JAC_ANALYTIC, fd_eps=1e-5, early_exit=True):
+        self._chk(self.L.ilqr_hip_set_options(self.h, int(jacobian_mode), C.c_double(fd_eps), int(bool(early_exit))))
+
+    # ---- initializeWithReference / solve
+    def initialize(self, x0, u_init=None, prev_xbar=None, prev_ubar=None):
+        ks = [_c64(x0), None if u_init is None else _c64(u_init), None if prev_xbar is None else _c64(prev_xbar), None if prev_ubar is None else _c64(prev_ubar)]
+        self._chk(self.L.ilqr_hip_initialize(self.h, *[_p(k) for k in ks]))
+
+    def initialize_warm_resident(self, x0):
+        self._chk(self.L.ilqr_hip_initialize_warm_resident(self.h, _p(_c64(x0))))
+
+    def initialize_device(self, x0_ptr, u_init_ptr):
+        self._chk(self.L.ilqr_hip_initialize_device(self.h, C.c_void_p(x0_ptr), C.c_void_p(u_init_ptr)))
+
+    def solve(self, x0=None):
+        cost = np.zeros(self.B)
+        x0 = None if x0 is None else _c64(x0)
+        self._chk(self.L.ilqr_hip_solve(self.h, _p(x0), _p(cost)))
+        return cost
+
+    def solve_async(self):
+        self._chk(self.L.ilqr_hip_solve_async(self.h))
+
+    def synchronize(self):
+        self._chk(self.L.ilqr_hip_synchronize(self.h))
+
+    # ---- accessors (ilqr.hpp:34-37)
+    def _get(self, fn, shape, dtype=np.float64):
+        out = np.zeros(shape, dtype=dtype)
+        ptr = out.ctypes.data_as(_dp if dtype == np.float64 else _ip)
+        self._chk(getattr(self.L, fn)(self.h, ptr))
+        return out
+
+    def xbar(self):
+        return self._get("ilqr_hip_get_xbar", (self.B, self.N + 1, NX))
+
+    def ubar(self):
+        return self._get("ilqr_hip_get_ubar", (self.B, self.N, NU))
+
+    def gains_K(self):
+        return self._get("ilqr_hip_get_gains_K", (self.B, self.N, NU, NX))
+
+    def gains_kff(self):
+        return self._get("ilqr_hip_get_gains_kff", (self.B, self.N, NU))
+
+    def cost(self):
+        return self._get("ilqr_hip_get_cost", (self.B,))
+
+    def iterations(self):
+        return self._get("ilqr_hip_get_iterations", (self.B,), np.int32)
+
+    def lambdas(self):
+        return self._get("ilqr_hip_get_lambda", (self.B,))
+
+    def trace(self):
+        cost = np.zeros((self.B, self.max_iter + 1))
+        alpha = np.zeros((self.B, self.max_iter))
+        lam = np.zeros((self.B, self.max_iter))
+        self._chk(self.L.ilqr_hip_get_trace(self.h, _p(cost), _p(alpha), _p(lam)))
+        return cost, alpha, lam
+
+    def first_knot_device(self):
+        """Device pointers (u0[B][19], K0[B][19][51], cost[B]) -- the payload of the per-step gather."""
+        u0, K0, c = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        self._chk(self.L.ilqr_hip_first_knot_device(self.h, C.byref(u0), C.byref(K0), C.byref(c)))
+        return u0.value, K0.value, c.value
+
+    def compute_control(self, x_measured):
+        u = np.zeros((self.B, NU))
+        self._chk(self.L.ilqr_hip_compute_control(self.h, _p(_c64(x_measured)), _p(u)))
+        return u
+
+    # ---- stage entry points
+    def set_trajectory(self, xbar, ubar):
+        self._chk(self.L.ilqr_hip_set_trajectory(self.h, _p(_c64(xbar)), _p(_c64(ubar))))
+
+    def stage_rollout(self):
+        self._chk(self.L.ilqr_hip_stage_rollout(self.h))
+
+    def stage_linearize(self):
+        self._chk(self.L.ilqr_hip_stage_linearize(self.h))
+
+    def stage_cost_quadratics(self):
+        self._chk(self.L.ilqr_hip_stage_cost_quadratics(self.h))
+
+    def stage_backward_pass(self):
+        self._chk(self.L.ilqr_hip_stage_backward_pass(self.h))
+
+    def stage_line_search(self):
+        imp = np.zeros(self.B, dtype=np.int32)
+        cost, alpha = np.zeros(self.B), np.zeros(self.B)
+        self._chk(self.L.ilqr_hip_stage_line_search(self.h, imp.ctypes.data_as(_ip), _p(cost), _p(alpha)))
+        return imp.astype(bool), cost, alpha
+
+    def stage_total_cost(self):
+        cost = np.zeros(self.B)
+        self._chk(self.L.ilqr_hip_stage_total_cost(self.h, _p(cost)))
+        return cost
+
+    def linearization(self):
+        A = np.zeros((self.B, self.N, NX, NX))
+        Bm = np.zeros((self.B, self.N, NX, NU))
+        self._chk(self.L.ilqr_hip_get_linearization(self.h, _p(A), _p(Bm)))
+        return A, Bm
+
+    def set_linearization(self, A, Bm):
+        self._chk(self.L.ilqr_hip_set_linearization(self.h, _p(_c64(A)), _p(_c64(Bm))))
+
+    def quadratics(self):
+        lx, lu = np.zeros((self.B, self.N + 1, NX)), np.zeros((self.B, self.N, NU))
+        lxx, luu = np.zeros((self.B, self.N + 1, NX, NX)), np.zeros((self.B, self.N, NU))
+        self._chk(self.L.ilqr_hip_get_quadratics(self.h, _p(lx), _p(lu), _p(lxx), _p(luu)))
+        return lx, lu, lxx, luu
+
+    def set_quadratics(self, lx, lu, lxx, luu):
+        self._chk(self.L.ilqr_hip_set_quadratics(self.h, _p(_c64(lx)), _p(_c64(lu)), _p(_c64(lxx)), _p(_c64(luu))))
+
+    def value_function(self):
+        Vx, Vxx = np.zeros((self.B, NX)), np.zeros((self.B, NX, NX))
+        self._chk(self.L.ilqr_hip_get_value_function(self.h, _p(Vx), _p(Vxx)))
+        return Vx, Vxx
+
+    def step(self, x, u):
+        x, u = _c64(x), _c64(u)
+        xn = np.zeros_like(x)
+        self._chk(self.L.ilqr_hip_step(self.h, int(x.shape[0]), _p(x), _p(u), _p(xn)))
+        return xn
+
+    def enable_profiling(self, on=True):
+        self._chk(self.L.ilqr_hip_enable_profiling(self.h, int(bool(on))))
+
+    def stage_ms(self):
+        ms, n = np.zeros(6), np.zeros(6)
+        self._chk(self.L.ilqr_hip_get_stage_ms(self.h, _p(ms), _p(n)))
+        keys = ["iLQR_computeCost+forwardRollout", "iLQR_linearization", "iLQR_costQuadratics", "iLQR_backwardPass", "iLQR_lineSearch", "iLQR_control"]
+        return dict(zip(keys, ms)), dict(zip(keys, n))
+
+    @property
+    def stream(self):
+        return self.L.ilqr_hip_stream(self.h)
+
+
+class BatchedMPC:
+    """MPC::stepOnce for a batch (reference src/ilqr/mpc.cpp:40-127): window -> warm start -> solve ->
+    u = ubar0 + K0 (x - xbar0).  `window(t_idx)` returns (x_ref, u_ref, com_ref) for the current step
+    (RobotUtils::getReferenceWindow, robot_utils.cpp:422-443)."""
+
+    def __init__(self, solver, window):
+        self.ilqr, self.window = solver, window
+        self.t_idx, self.has_prev = 0, False
+        self.last_solve_cost = None
+
+    def reset(self):
+        self.t_idx, self.has_prev = 0, False
+
+    def step_once(self, x_measured):
+        x_ref, u_ref, com_ref = self.window(self.t_idx)
+        self.ilqr.set_references(x_ref, u_ref, com_ref)
+        if self.has_prev:
+            self.ilqr.initialize_warm_resident(x_measured)
+        else:
+            self.ilqr.initialize(x_measured)
+        self.last_solve_cost = self.ilqr.solve(x_measured)
+        u = self.ilqr.compute_control(x_measured)
+        self.has_prev = True
+        self.t_idx += 1
+        return u

@@ -1,0 +1,64 @@
+"""CPU checks of the boundary: the C-ABI library builds, loads and exports every symbol include/ilqr_hip.h
+declares; the GPU-free host helpers agree with the oracle; the product fails loudly without a GPU."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+from conftest import ROOT, load_package
+
+pkg = load_package()
+sc = pkg.scenario
+
+
+def _lib():
+    import __graft_entry__ as ge
+    ge.build_library()
+    from mpc_ilqr_mujoco_amd import solver as sv
+    return sv, sv.load_library()
+
+
+def test_library_exports_every_declared_symbol():
+    sv, L = _lib()
+    hdr = open(os.path.join(ROOT, "include", "ilqr_hip.h")).read()
+    declared = set(re.findall(r"\b(ilqr_hip_[A-Za-z_0-9]+)\s*\(", hdr))
+    assert declared == set(sv.EXPORTS), declared ^ set(sv.EXPORTS)
+    for name in declared:
+        assert hasattr(L, name), name
+
+
+def test_host_helpers_match_oracle_cpu():
+    sv, L = _lib()
+    rng = np.random.default_rng(0)
+    for _ in range(5):
+        x = sc.standing_state(); x[7:26] = rng.uniform(-0.5, 0.5, 19); x[3:7] = sc._axis_angle_quat(rng.uniform(-1, 1, 3))
+        c1, e1 = sv.reference_kinematics(x); c2, e2 = ol.reference_kinematics(x)
+        assert np.abs(c1 - c2).max() < 1e-13 and np.abs(e1 - e2).max() < 1e-13
+        o = ol.Oracle(25, 0.02); o.set_problem(sc.make_problem(ol.reference_kinematics, gravity=(0, 0, -9.81)))
+        assert np.abs(sv.gravity_compensation(x, (0, 0, -9.81)) - o.grav_comp(x)).max() < 1e-11
+
+
+def test_no_cpu_fallback_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    sv, L = _lib()
+    with pytest.raises(sv.ILQRError):
+        sv.BatchedILQR(4)
+    h = C.c_void_p()
+    assert L.ilqr_hip_create(C.byref(h), 0, 4, 25, C.c_double(0.02)) == 3  # ILQR_ERR_NO_DEVICE
+    assert L.ilqr_hip_create(None, 0, 4, 25, C.c_double(0.02)) == 1        # ILQR_ERR_ARG
+
+
+def test_cost_matrix_rule_and_scenario():
+    Q, R, Qf = sc.build_cost_matrices()
+    assert Q[0] == 200 and Q[1] == 50 and Q[2] == 200 and Q[3] == 50 and Q[7] == 50 and Q[26] == 150 and Q[27] == 50 and Q[29] == 75 and Q[50] == 75
+    assert np.all(R == 0.001)
+    assert Qf[0] == 2000 and Qf[1] == 200 and Qf[2] == 2000 and Qf[28] == 1200 and Qf[10] == 100
+    x0, u = sc.synthetic_batch(16, 25, 0, np.zeros(19))
+    assert np.allclose(np.linalg.norm(x0[:, 3:7], axis=1), 1.0) and np.all(np.abs(u) <= 0.8 * sc.CTRLRANGE + 1e-12)
+    x1, _ = sc.synthetic_batch(16, 25, 0, np.zeros(19))
+    assert np.array_equal(x0, x1)

@@ -1,0 +1,283 @@
+"""GPU parity: the HIP path (through the C ABI, include/ilqr_hip.h) against the CPU oracle on the same
+seeded inputs, against the committed goldens, and size-independent properties at the bench size.
+Tolerance: 1e-5 relative on per-iteration costs and feedback gains (BASELINE.json north_star);
+the individual stages are held to much tighter bounds."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+from conftest import load_package
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+pkg = load_package()
+sc = pkg.scenario
+
+
+def _solver(*a, **k):
+    from mpc_ilqr_mujoco_amd import solver as sv
+    return sv.BatchedILQR(*a, **k)
+
+
+def rel(a, b):
+    return np.abs(a - b).max() / max(1e-300, np.abs(b).max())
+
+
+def make(B, N=25, seed=0, gravity=None, walking=False, w_com_vel=0.0):
+    from mpc_ilqr_mujoco_amd import solver as sv
+    cfg = dict(sc.SHIPPED_CONFIG)
+    cfg["W_com_vel"] = w_com_vel
+    stance = None
+    if walking:  # contact pattern with swing phases so the foot-position term is exercised
+        stance = np.ones((N + 1, 2), dtype=np.int32)
+        stance[3:9, 0] = 0
+        stance[12:20, 1] = 0
+        stance[N, :] = 0 if N > 20 else 1
+    prob = sc.make_problem(sv.reference_kinematics, N=N, cfg=cfg, stance=stance, gravity=gravity)
+    if w_com_vel > 0:
+        prob["com_vel_ref"][:] = np.array([0.05, -0.02, 0.01])
+    ug = sv.gravity_compensation(sc.standing_state(), prob["gravity"])
+    x0, ui = sc.synthetic_batch(B, N, seed, ug)
+    return prob, x0, ui
+
+
+def oracle_for(prob, b=0, **opts):
+    o = ol.Oracle(prob["N"], prob["dt"])
+    o.set_problem(prob, b)
+    o.set_options(**opts)
+    return o
+
+
+def test_host_helpers_match_oracle():
+    from mpc_ilqr_mujoco_amd import solver as sv
+    rng = np.random.default_rng(0)
+    for _ in range(4):
+        x = sc.standing_state(); x[7:26] = rng.uniform(-0.5, 0.5, 19); x[3:7] = sc._axis_angle_quat(rng.uniform(-1, 1, 3))
+        c1, e1 = sv.reference_kinematics(x); c2, e2 = ol.reference_kinematics(x)
+        assert np.abs(c1 - c2).max() < 1e-13 and np.abs(e1 - e2).max() < 1e-13
+        for g in ((0, 0, -9.81), (0, 0, -1.0)):
+            o = ol.Oracle(25, 0.02); p = sc.make_problem(ol.reference_kinematics, gravity=g); o.set_problem(p)
+            assert np.abs(sv.gravity_compensation(x, g) - o.grav_comp(x)).max() < 1e-11
+
+
+def test_step_matches_oracle_and_kane_golden():
+    d = np.load(os.path.join(G, "dynamics_golden.npz"))
+    for g in (np.array([0, 0, -9.81]), np.array([0.0, 0.0, -1.0])):
+        idx = [i for i in range(len(d["x"])) if np.allclose(d["gravity"][i], g)]
+        prob, x0, ui = make(4, gravity=tuple(g))
+        s = _solver(4); s.set_problem(prob)
+        got = s.step(d["x"][idx], d["u"][idx])
+        assert np.abs(got - d["x_next"][idx]).max() < 1e-10
+        o = oracle_for(prob)
+        rng = np.random.default_rng(1)
+        xs = np.tile(sc.standing_state(), (64, 1)); xs[:, 7:26] = rng.uniform(-0.6, 0.6, (64, 19))
+        xs[:, 3:7] = sc._axis_angle_quat(rng.uniform(-2, 2, (64, 3))); xs[:, 26:] = rng.uniform(-2, 2, (64, 25)); xs[0, 26:] = 0
+        us = rng.uniform(-60, 60, (64, 19))
+        got = s.step(xs, us)
+        want = np.array([o.step(x, u) for x, u in zip(xs, us)])
+        assert np.abs(got - want).max() < 1e-11
+        s.close()
+
+
+@pytest.mark.parametrize("jac_mode", [0, 1])
+def test_linearization_matches_oracle(jac_mode):
+    prob, x0, ui = make(3, seed=2)
+    s = _solver(3); s.set_problem(prob); s.set_options(jacobian_mode=jac_mode)
+    s.initialize(x0, ui)
+    s.stage_linearize()
+    A, Bm = s.linearization()
+    xb, ub = s.xbar(), s.ubar()
+    for b in range(3):
+        o = oracle_for(prob, jac_mode=jac_mode)
+        o.set_trajectory(xb[b], ub[b]); o.linearize()
+        tol = 1e-9 if jac_mode == 0 else 2e-5   # FD mode divides O(1e-16) round-off by eps = 1e-5
+        assert np.abs(A[b] - o.get("A")).max() < tol and np.abs(Bm[b] - o.get("B")).max() < tol
+    s.close()
+
+
+@pytest.mark.parametrize("walking,w_com_vel", [(False, 0.0), (True, 3.0)])
+def test_cost_quadratics_and_total_cost_match_oracle(walking, w_com_vel):
+    prob, x0, ui = make(4, seed=3, walking=walking, w_com_vel=w_com_vel)
+    ui[1, 5, 4] = 39.5; ui[2, 7, 13] = -17.9      # into the soft torque-limit margin
+    x0[3, 7 + 3] = 1.95                            # knee into the soft joint-limit margin
+    s = _solver(4); s.set_problem(prob)
+    s.initialize(x0, ui)
+    s.stage_cost_quadratics()
+    lx, lu, lxx, luu = s.quadratics()
+    cost = s.stage_total_cost()
+    xb, ub = s.xbar(), s.ubar()
+    for b in range(4):
+        o = oracle_for(prob)
+        o.set_trajectory(xb[b], ub[b]); o.cost_quadratics()
+        for name, got in (("lx", lx[b]), ("lu", lu[b]), ("lxx", lxx[b]), ("luu", luu[b])):
+            want = o.get(name)
+            assert np.abs(got - want).max() <= 1e-10 * max(1.0, np.abs(want).max()), (name, b, np.abs(got - want).max())
+        assert abs(cost[b] - o.total_cost()) <= 1e-11 * abs(cost[b])
+    s.close()
+
+
+@pytest.mark.parametrize("case", ["spd", "bump"])
+def test_backward_pass_vs_numpy_golden(case):
+    r = np.load(os.path.join(G, "riccati_golden.npz"))
+    A, Bm = r[case + "_A"], r[case + "_B"]
+    N = A.shape[0]
+    s = _solver(2, N=N)
+    s.set_regularization(float(r["lam"]))
+    rep = lambda a: np.stack([a, a])
+    s.set_linearization(rep(A), rep(Bm))
+    s.set_quadratics(rep(r[case + "_lx"]), rep(r[case + "_lu"]), rep(r[case + "_lxx"]), rep(r[case + "_luu"]))
+    s.stage_backward_pass()
+    K, kff = s.gains_K(), s.gains_kff()
+    Vx, Vxx = s.value_function()
+    tol = 1e-9 if case == "spd" else 1e-6
+    for got, key in ((K, "K"), (kff, "k"), (Vx, "Vx"), (Vxx, "Vxx")):
+        want = r[case + "_" + key]
+        for b in range(2):
+            assert np.abs(got[b] - want).max() <= tol * max(1.0, np.abs(want).max()), (key, np.abs(got[b] - want).max())
+    s.close()
+
+
+def test_backward_pass_and_line_search_match_oracle():
+    prob, x0, ui = make(3, seed=4)
+    s = _solver(3); s.set_problem(prob)
+    s.initialize(x0, ui)
+    s.stage_linearize(); s.stage_cost_quadratics(); s.stage_backward_pass()
+    K, kff = s.gains_K(), s.gains_kff()
+    xb, ub = s.xbar(), s.ubar()
+    A, Bm = s.linearization(); lx, lu, lxx, luu = s.quadratics()
+    imp, cost, alpha = s.stage_line_search()
+    xn, un = s.xbar(), s.ubar()
+    for b in range(3):
+        o = oracle_for(prob)
+        o.set_trajectory(xb[b], ub[b]); o.set_linearization(A[b], Bm[b]); o.set_quadratics(lx[b], lu[b], lxx[b], luu[b])
+        o.backward_pass()
+        assert rel(K[b], o.get("K")) < 1e-8 and rel(kff[b], o.get("kff")) < 1e-8
+        ok, c, a = o.line_search(x0[b])
+        assert ok == bool(imp[b]) and a == alpha[b] and abs(c - cost[b]) < 1e-8 * abs(c)
+        assert rel(xn[b], o.get("xbar")) < 1e-8 and rel(un[b], o.get("ubar")) < 1e-7
+    s.close()
+
+
+@pytest.mark.parametrize("walking,gravity,seed", [(False, None, 0), (True, (0.0, 0.0, -2.0), 5)])
+def test_full_solve_parity_trace_and_gains(walking, gravity, seed):
+    """north_star: per-iteration costs and feedback gains within 1e-5 relative of the CPU reference."""
+    B = 6
+    prob, x0, ui = make(B, seed=seed, walking=walking, gravity=gravity)
+    s = _solver(B); s.set_problem(prob)
+    s.initialize(x0, ui)
+    cost = s.solve(x0)
+    tc, ta, tl = s.trace()
+    K, kff, xb, ub, it, lam = s.gains_K(), s.gains_kff(), s.xbar(), s.ubar(), s.iterations(), s.lambdas()
+    for b in range(B):
+        o = oracle_for(prob)
+        o.initialize(x0[b], ui[b])
+        ok, c = o.solve(x0[b])
+        n, oc, oa, olam = o.trace()
+        assert n == it[b], (b, n, it[b])
+        assert np.allclose(tc[b, : n + 1], oc[: n + 1], rtol=1e-5, atol=0), (b, tc[b, : n + 1], oc[: n + 1])
+        assert np.array_equal(ta[b, :n], oa[:n]) and np.allclose(tl[b, :n], olam[:n], rtol=1e-12)
+        assert abs(cost[b] - c) <= 1e-5 * abs(c)
+        assert rel(K[b], o.get("K")) < 1e-5 and rel(kff[b], o.get("kff")) < 1e-5
+        assert rel(xb[b], o.get("xbar")) < 1e-5 and rel(ub[b], o.get("ubar")) < 1e-5
+        assert abs(lam[b] - o.get_lambda()) < 1e-18
+    s.close()
+
+
+def test_fixed_iteration_mode_and_fd_mode_parity():
+    B = 3
+    prob, x0, ui = make(B, seed=6)
+    s = _solver(B); s.set_problem(prob); s.set_options(jacobian_mode=1, fd_eps=1e-5, early_exit=False); s.set_max_iterations(4)
+    s.initialize(x0, ui)
+    cost = s.solve(x0)
+    tc, ta, tl = s.trace()
+    assert np.all(s.iterations() == 4)
+    for b in range(B):
+        o = oracle_for(prob, jac_mode=1, fd_eps=1e-5, early_exit=0, max_iter=4)
+        o.initialize(x0[b], ui[b]); ok, c = o.solve(x0[b])
+        n, oc, oa, ol_ = o.trace()
+        assert n == 4 and np.allclose(tc[b], oc, rtol=1e-5) and np.array_equal(ta[b], oa)
+        assert rel(s.gains_K()[b], o.get("K")) < 1e-4   # FD noise (1e-16/1e-5) amplified through the recursion
+    s.close()
+
+
+def test_warm_start_mpc_step_and_control_law():
+    from mpc_ilqr_mujoco_amd import solver as sv
+    B = 2
+    prob, x0, ui = make(B, seed=7)
+    s = _solver(B); s.set_problem(prob); s.set_max_iterations(3)
+    mpc = sv.BatchedMPC(s, lambda t: (prob["x_ref"], prob["u_ref"], prob["com_ref"]))
+    os_ = [oracle_for(prob, max_iter=3) for _ in range(B)]
+    x = x0.copy()
+    prev = [None] * B
+    for step in range(3):
+        u = mpc.step_once(x)
+        xb, ub = s.xbar(), s.ubar()
+        for b in range(B):
+            o = os_[b]
+            if prev[b] is None:
+                o.initialize(x[b])       # gravity-compensation cold start
+            else:
+                o.initialize(x[b], None, prev[b][0], prev[b][1])
+            o.solve(x[b])
+            prev[b] = (o.get("xbar"), o.get("ubar"))
+            assert rel(u[b], o.compute_control(x[b])) < 1e-5
+            assert rel(xb[b], prev[b][0]) < 1e-5 and rel(ub[b], prev[b][1]) < 1e-5
+        x = s.step(x, u)                 # plant = same smooth dynamics
+    xm = x + 1e-3
+    uc = s.compute_control(xm)
+    Kk, xb, ub = s.gains_K(), s.xbar(), s.ubar()
+    for b in range(B):
+        assert np.allclose(uc[b], ub[b, 0] + Kk[b, 0] @ (xm[b] - xb[b, 0]), rtol=1e-12, atol=1e-12)
+    s.close()
+
+
+def test_per_rollout_reference_sets():
+    B, N = 3, 25
+    prob, x0, ui = make(B, seed=8)
+    # give every rollout its own reference window / contact schedule
+    rng = np.random.default_rng(0)
+    for k in ("x_ref", "u_ref", "com_ref", "ee_ref", "com_vel_ref", "stance"):
+        prob[k] = np.repeat(prob[k], B, axis=0)
+    prob["x_ref"][:, :, 0] += rng.uniform(-0.02, 0.02, (B, 1))
+    prob["com_ref"][:, :, 0] += rng.uniform(-0.02, 0.02, (B, 1))
+    prob["stance"][1, 5:10, 0] = 0
+    s = _solver(B); s.set_problem(prob); s.set_max_iterations(2)
+    s.initialize(x0, ui); cost = s.solve(x0)
+    for b in range(B):
+        o = oracle_for(prob, b=b, max_iter=2)
+        o.initialize(x0[b], ui[b]); ok, c = o.solve(x0[b])
+        assert abs(cost[b] - c) <= 1e-5 * abs(c) and rel(s.gains_K()[b], o.get("K")) < 1e-5
+    s.close()
+
+
+def test_bench_size_properties():
+    """B = 4096 (BASELINE.json configs[2]): size-independent properties instead of a full oracle run."""
+    B = 4096
+    prob, x0, ui = make(B, seed=0)
+    s = _solver(B); s.set_problem(prob)
+    s.initialize(x0, ui)
+    cost = s.solve(x0)
+    tc, ta, tl = s.trace()
+    it = s.iterations()
+    assert np.all(np.isfinite(cost)) and np.all(it >= 1) and np.all(it <= 10)
+    # the line search only ever accepts strict decreases
+    for b in range(0, B, 97):
+        c = tc[b, : it[b] + 1]
+        assert np.all(np.diff(c) <= 0)
+    xb = s.xbar()
+    assert np.abs(np.linalg.norm(xb[:, :, 3:7], axis=2) - 1).max() < 1e-12   # quaternions stay normalised
+    assert np.array_equal(xb[:, 0], x0)
+    # batch invariance: any rollout solved alone gives bit-identical results (no cross-rollout coupling)
+    pick = [0, 1, 777, 2048, 4095]
+    K_all = s.gains_K()[pick]
+    s.close()
+    s2 = _solver(len(pick)); s2.set_problem(prob)
+    s2.initialize(x0[pick], ui[pick]); c2 = s2.solve(x0[pick])
+    assert np.array_equal(c2, cost[pick]) and np.array_equal(s2.gains_K(), K_all)
+    # spot-check against the oracle
+    o = oracle_for(prob)
+    o.initialize(x0[777], ui[777]); ok, c = o.solve(x0[777])
+    assert abs(c - cost[777]) <= 1e-5 * abs(c)
+    s2.close()

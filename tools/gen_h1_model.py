@@ -112,14 +112,14 @@ def carr(name, a, fmt="%.17g"):
     a = np.asarray(a)
     flat = ", ".join(fmt % v for v in a.reshape(-1))
     dims = "".join("[%d]" % d for d in a.shape)
-    return "static const double %s%s = {%s};\n" % (name, dims, flat)
+    return "H1_CONST double %s%s = {%s};\n" % (name, dims, flat)
 
 
 def iarr(name, a):
     a = np.asarray(a)
     flat = ", ".join("%d" % v for v in a.reshape(-1))
     dims = "".join("[%d]" % d for d in a.shape)
-    return "static const int %s%s = {%s};\n" % (name, dims, flat)
+    return "H1_CONST int %s%s = {%s};\n" % (name, dims, flat)
 
 
 def main():
@@ -184,6 +184,7 @@ def main():
     out.append("// ctrlrange, default damping/armature h1.xml:7) and robots/h1_description/urdf/h1.urdf\n")
     out.append("// (link masses / CoM offsets used by the Pinocchio-side cost terms, derivatives.cpp:29).\n")
     out.append("#ifndef H1_MODEL_DATA_H\n#define H1_MODEL_DATA_H\n\n")
+    out.append("/* storage qualifier of the tables (a HIP translation unit sets it to __constant__) */\n#ifndef H1_CONST\n#define H1_CONST static const\n#endif\n")
     out.append("#define H1_NB 20   /* bodies: pelvis + 19 hinge links */\n")
     out.append("#define H1_NJ 19   /* hinge joints == actuators */\n")
     out.append("#define H1_NQ 26\n#define H1_NV 25\n#define H1_NX 51\n#define H1_NU 19\n\n")
@@ -195,7 +196,7 @@ def main():
     out.append(iarr("H1_AXIS", axis))
     out.append(iarr("H1_DEPTH", depth))
     out.append(iarr("H1_ANC", anc))
-    out.append("static const double H1_DAMPING = %.17g;\nstatic const double H1_ARMATURE = %.17g;\n" % (damping, armature))
+    out.append("#define H1_DAMPING %.17g\n#define H1_ARMATURE %.17g\n" % (damping, armature))
     out.append(carr("H1_POS", pos))
     out.append(carr("H1_RFIX", rfix))
     out.append(carr("H1_MASS", mass))
