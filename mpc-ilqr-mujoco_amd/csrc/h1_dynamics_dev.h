@@ -210,7 +210,7 @@ template <class T> DEVFN void solve6(const T* A, const T* b, T* y) {
 // ---------- forward dynamics in MuJoCo coordinates ----------
 // quat_hat unit (wxyz); theta[19]; v = qvel[25]; tau[19]; returns qacc[25]
 template <class T>
-__device__ __noinline__ void forward_dynamics(const T* quat_hat, const T* theta, const T* v, const T* tau, double arm_eff,
+DEVFN void forward_dynamics(const T* quat_hat, const T* theta, const T* v, const T* tau, double arm_eff,
                                               const double* grav, T* qacc) {
   T R0[9]; quat_wxyz_R(quat_hat[0], quat_hat[1], quat_hat[2], quat_hat[3], R0);
   // per-body state kept for the outward acceleration sweep
@@ -333,7 +333,7 @@ template <class T> DEVFN void half_angle_cs(const T& s, T& c, T& so) {
 
 // x_next = f(x, u)
 template <class T>
-__device__ void step(const T* x, const T* u, const DynParams& P, T* xn) {
+DEVFN void step(const T* x, const T* u, const DynParams& P, T* xn) {
   const double h = P.h;
   const T qn = dsqrt(x[3] * x[3] + x[4] * x[4] + x[5] * x[5] + x[6] * x[6]);
   const T qh[4] = {x[3] / qn, x[4] / qn, x[5] / qn, x[6] / qn};

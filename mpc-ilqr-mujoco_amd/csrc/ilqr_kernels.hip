@@ -65,7 +65,10 @@ __global__ void __launch_bounds__(64) k_step(int count, const double* x, const d
 
 // ------------------------------------------------------------------ K2: dynamics Jacobians
 // thread per (rollout, knot, column); columns 0..50 = d/dx, 51..69 = d/du.
-__global__ void __launch_bounds__(64) k_linearize(DevState S, ProblemDev P, int mode, int jac_mode, double eps) {
+#ifndef LIN_THREADS
+#define LIN_THREADS 256  /* <=128 VGPRs: the 64-thread build (256 VGPR + AGPR spills) faulted on gfx950 at -O3 */
+#endif
+__global__ void __launch_bounds__(LIN_THREADS) k_linearize(DevState S, ProblemDev P, int mode, int jac_mode, double eps) {
   const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const int NC = H1_NX + H1_NU;
   const long total = (long)S.B * S.N * NC;
@@ -573,7 +576,7 @@ void launch_step(int count, const double* x, const double* u, const DynParams& d
 }
 void launch_linearize(const DevState& S, const ProblemDev& P, int mode, int jac_mode, double eps, hipStream_t st) {
   const long total = (long)S.B * S.N * (H1_NX + H1_NU);
-  hipLaunchKernelGGL(k_linearize, dim3(cdiv(total, 64)), dim3(64), 0, st, S, P, mode, jac_mode, eps);
+  hipLaunchKernelGGL(k_linearize, dim3(cdiv(total, LIN_THREADS)), dim3(LIN_THREADS), 0, st, S, P, mode, jac_mode, eps);
 }
 void launch_cost_quadratics(const DevState& S, const ProblemDev& P, int mode, hipStream_t st) {
   hipLaunchKernelGGL(k_cost_quadratics, dim3(S.N + 1, S.B), dim3(64), 0, st, S, P, mode);

@@ -13,7 +13,7 @@ import numpy as np
 
 NX, NU, NQ, NV = 51, 19, 26, 25
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libilqr_hip.so")
+LIB_PATH = os.environ.get("ILQR_HIP_LIB", os.path.join(_HERE, "lib", "libilqr_hip.so"))
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int)
 
