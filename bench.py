@@ -1,0 +1,200 @@
+#!/usr/bin/env python3
+"""Headline benchmark: iLQR iterations/s, Unitree H1 (nx=51, nu=19), N=25, batched standing-balance.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+One "step" = one MPC step of the hot path over the whole batch with inputs resident in HBM:
+cold-start initializeWithReference (gravity-comp + noise controls, N rollouts) followed by
+iLQR::solve with exactly `--iters` iterations per rollout (early exit disabled, the headline mode of
+BASELINE.md section 3) and the per-step pack of {u0, cost} (plus one RCCL gather to rank 0 when N > 1).
+Workload: BASELINE.json configs[2] "Batch=4096 full iLQR, N=25, 1xMI355X" (the config the metric
+"iLQR iterations/sec" is quoted on); weak scaling: 4096 rollouts per GPU (configs[3] at 8 GPUs).
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP64_PEAK_TFLOPS = 78.6   # MI355X FP64 vector == matrix peak (AMD spec; the microarch guide lists no fp64 row)
+HBM_PEAK_GBS = 8000.0
+# algorithmic work per rollout: Riccati backward pass, minimal-reuse formulation
+RICCATI_FLOPS_PER_KNOT = 914786.0
+# dynamics Jacobians: planning estimate of SURVEY.md 8(d) (analytic A_t, B_t of one knot)
+JACOBIAN_FLOPS_PER_KNOT = 120000.0
+STEP_FLOPS = 12000.0      # one ABA dynamics step
+QUAD_FLOPS_PER_KNOT = 50000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=4096, help="rollouts per GPU")
+    ap.add_argument("--horizon", type=int, default=25)
+    ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--gather-gains", action="store_true", help="include K0[19x51] in the per-step gather payload")
+    return ap.parse_args()
+
+
+def cpu_baseline(pkg, prob, x0, ui, iters, budget_s):
+    """Oracle (CPU restatement, kind 'port') timed on the host cores on a bounded sample of the same batch."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as ol
+    o = ol.Oracle(prob["N"], prob["dt"])
+    o.set_problem(prob)
+    o.set_options(max_iter=iters, early_exit=0)
+    cores = ol.max_threads()
+    n0 = max(cores, 1)
+    t0 = time.perf_counter()
+    tot0, *_ = o.batch_solve(x0[:n0], ui[:n0], nthreads=cores)
+    dt0 = time.perf_counter() - t0
+    rate0 = tot0 / dt0
+    n1 = int(min(x0.shape[0], max(n0, (budget_s * rate0 / iters) // cores * cores)))
+    t0 = time.perf_counter()
+    tot1, *_ = o.batch_solve(x0[:n1], ui[:n1], nthreads=cores)
+    dt1 = time.perf_counter() - t0
+    return dict(value=tot1 / dt1, unit="iLQR iterations/s", cores=int(cores), kind="port",
+                sample="oracle (CPU restatement, analytic-AD Jacobians) on the first %d rollouts of the same batch, %d fixed iterations each, OpenMP over rollouts, %.1f s" % (n1, iters, dt1))
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback in the product path)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    import __graft_entry__ as ge
+    pkg = ge._load_package()
+    from mpc_ilqr_mujoco_amd import solver as sv
+    sc = pkg.scenario
+    B, N, iters = args.batch, args.horizon, args.iters
+
+    prob = sc.make_problem(sv.reference_kinematics, N=N)
+    ug = sv.gravity_compensation(sc.standing_state(), prob["gravity"])
+    # every rank draws its own shard of the global batch (contiguous rollout ranges)
+    x0, ui = sc.synthetic_batch(B, N, args.seed + rank, ug)
+    s = sv.BatchedILQR(B, N=N, dt=prob["dt"], device=local_rank)
+    s.set_problem(prob)
+    s.set_max_iterations(iters)
+    s.set_options(jacobian_mode=sv.JAC_ANALYTIC, early_exit=False)
+    s.enable_profiling(True)
+
+    dev = torch.device("cuda", local_rank)
+    x0_d = torch.from_numpy(x0).to(dev)
+    ui_d = torch.from_numpy(ui).to(dev)
+    width = 19 + 1 + (19 * 51 if args.gather_gains else 0)
+    payload = torch.zeros(B, width, dtype=torch.float64, device=dev)   # [u0 | cost | (K0)] per rollout
+    u0_d = torch.zeros(B, 19, dtype=torch.float64, device=dev)
+    c_d = torch.zeros(B, dtype=torch.float64, device=dev)
+    K0_d = torch.zeros(B, 19 * 51, dtype=torch.float64, device=dev) if args.gather_gains else None
+    gathered = [torch.zeros_like(payload) for _ in range(world)] if (world > 1 and rank == 0) else None
+    torch.cuda.synchronize()
+
+    stage_ms, stage_n = {}, {}
+
+    def one_step(timed):
+        s.initialize_device(x0_d.data_ptr(), ui_d.data_ptr())
+        s.solve_async()
+        s.synchronize()
+        s.pack_first_knot_device(u0_d.data_ptr(), None if K0_d is None else K0_d.data_ptr(), c_d.data_ptr())
+        payload[:, :19] = u0_d
+        payload[:, 19] = c_d
+        if K0_d is not None:
+            payload[:, 20:] = K0_d
+        if world > 1:
+            dist.gather(payload, gathered, dst=0)   # the ONE collective of an MPC step (RCCL over xGMI)
+        if timed:
+            ms, n = s.stage_ms()
+            for k in ms:
+                stage_ms[k] = stage_ms.get(k, 0.0) + ms[k]
+                stage_n[k] = stage_n.get(k, 0.0) + n[k]
+
+    for _ in range(args.warmup):
+        one_step(False)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step(True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    it_done = s.iterations()
+    assert np.all(it_done == iters), "fixed-iteration mode must run exactly --iters iterations per rollout"
+    cost = s.cost()
+    assert np.all(np.isfinite(cost))
+
+    if rank == 0:
+        total_iters = float(world) * B * iters * args.steps
+        value = total_iters / elapsed
+        # dominant kernel (by device time over the timed region, HIP events on the solver's stream)
+        main_keys = ["iLQR_computeCost+forwardRollout", "iLQR_linearization", "iLQR_costQuadratics", "iLQR_backwardPass", "iLQR_lineSearch"]
+        dom = max(main_keys, key=lambda k: stage_ms.get(k, 0.0))
+        flops_per_launch = {
+            "iLQR_backwardPass": RICCATI_FLOPS_PER_KNOT * N * B,
+            "iLQR_linearization": JACOBIAN_FLOPS_PER_KNOT * N * B,
+            "iLQR_costQuadratics": QUAD_FLOPS_PER_KNOT * (N + 1) * B,
+            "iLQR_lineSearch": STEP_FLOPS * N * B,           # the accepted alpha's rollout is the algorithmic work
+            "iLQR_computeCost+forwardRollout": STEP_FLOPS * N * B,
+        }[dom]
+        avg_ms = stage_ms[dom] / max(stage_n[dom], 1.0)
+        achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12
+        kernel_of = {"iLQR_backwardPass": "k_backward", "iLQR_linearization": "k_linearize", "iLQR_costQuadratics": "k_cost_quadratics",
+                     "iLQR_lineSearch": "k_line_search", "iLQR_computeCost+forwardRollout": "k_rollout"}
+        out = {
+            "metric": "iLQR iterations/sec (H1 nx=51 nu=19 N=%d)" % N, "value": value, "unit": "iterations/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "BASELINE.json configs[2]: batch=%d/GPU full iLQR (rollout+Jacobians+cost quadratics+Riccati+8-alpha line search), "
+                                   "H1 standing balance, N=%d, dt=0.02, %d fixed iterations per rollout, shipped config.yaml weights, gravity %s"
+                                   % (B, N, iters, list(prob["gravity"])),
+                       "batch_per_gpu": B, "global_batch": B * world, "horizon": N, "iterations_per_solve": iters,
+                       "jacobians": "analytic", "gather": "u0+cost" + ("+K0" if args.gather_gains else "")},
+            "roofline": {"bound": "mfma", "kernel": kernel_of[dom], "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / FP64_PEAK_TFLOPS, "traffic": None,
+                         "avg_launch_ms": avg_ms, "launches": stage_n[dom], "algorithmic_flops_per_launch": flops_per_launch},
+            "stage_ms_per_step": {k: stage_ms[k] / args.steps for k in stage_ms},
+        }
+        if not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(pkg, prob, x0, ui, iters, args.cpu_seconds)
+            except Exception as e:  # the oracle is optional test infrastructure
+                out["cpu_baseline"] = {"error": repr(e)}
+        print(json.dumps(out))
+    s.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

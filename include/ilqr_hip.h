@@ -109,6 +109,9 @@ int ilqr_hip_get_lambda(ilqr_hip_ctx* ctx, double* lambda /*[B]*/);
 int ilqr_hip_get_trace(ilqr_hip_ctx* ctx, double* cost, double* alpha, double* lambda);
 /* first-knot results gathered per MPC step: u0[B][19], K0[B][19][51] (either may be NULL); device pointers */
 int ilqr_hip_first_knot_device(ilqr_hip_ctx* ctx, const double** u0_device, const double** K0_device, const double** cost_device);
+/* same payload written into CALLER-owned device buffers (the send buffer of the per-step RCCL gather):
+   u0_out[B][19], K0_out[B][19][51] (nullable), cost_out[B] (nullable); synchronises the handle's stream */
+int ilqr_hip_pack_first_knot_device(ilqr_hip_ctx* ctx, double* u0_out_device, double* K0_out_device, double* cost_out_device);
 
 /* MPC::stepOnce control law u = ubar[0] + K[0](x_meas - xbar[0]) -- src/ilqr/mpc.cpp:97-101 */
 int ilqr_hip_compute_control(ilqr_hip_ctx* ctx, const double* x_measured /*[B][51]*/, double* u_apply /*[B][19]*/);
@@ -131,9 +134,10 @@ int ilqr_hip_step(ilqr_hip_ctx* ctx, int count, const double* x /*[count][51]*/,
 
 /* per-stage device time of the last solve in milliseconds, keyed like the reference's profiler
    (src/ilqr/ilqr.cpp:537-639): 0 computeCost/rollout, 1 linearization, 2 costQuadratics, 3 backwardPass,
-   4 lineSearch, 5 control; requires ilqr_hip_enable_profiling(ctx, 1) before the solve */
+   4 lineSearch, 5 control, 6 backwardPass (lambda-retry launch), 7 lineSearch (lambda-retry launch);
+   requires ilqr_hip_enable_profiling(ctx, 1) before the solve */
 int ilqr_hip_enable_profiling(ilqr_hip_ctx* ctx, int on);
-int ilqr_hip_get_stage_ms(ilqr_hip_ctx* ctx, double* ms /*[6]*/, double* launches /*[6]*/);
+int ilqr_hip_get_stage_ms(ilqr_hip_ctx* ctx, double* ms /*[8]*/, double* launches /*[8]*/);
 
 /* ---- host-side model helpers (no GPU needed) ---- */
 /* reference construction as RobotUtils::loadReferences does it (src/common/robot_utils.cpp:369-403):

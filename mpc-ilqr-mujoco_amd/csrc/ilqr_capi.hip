@@ -40,7 +40,7 @@ struct ilqr_hip_ctx {
   std::vector<Span> spans;
   std::vector<hipEvent_t> pool;
   size_t pool_next = 0;
-  double stage_ms[6] = {0, 0, 0, 0, 0, 0}, stage_launches[6] = {0, 0, 0, 0, 0, 0};
+  double stage_ms[8] = {0}, stage_launches[8] = {0};
 };
 
 #define HIPCHK(ctx, call)                                                                   \
@@ -276,7 +276,7 @@ int ilqr_hip_initialize_warm_resident(ilqr_hip_ctx* c, const double* x0) {
 
 // ---------------------------------------------------------------- solve
 static void collect_profile(ilqr_hip_ctx* c) {
-  for (int i = 0; i < 6; ++i) { c->stage_ms[i] = 0; c->stage_launches[i] = 0; }
+  for (int i = 0; i < 8; ++i) { c->stage_ms[i] = 0; c->stage_launches[i] = 0; }
   for (auto& s : c->spans) { float ms = 0; hipEventElapsedTime(&ms, s.a, s.b); c->stage_ms[s.stage] += ms; c->stage_launches[s.stage] += 1; }
   c->spans.clear(); c->pool_next = 0;
 }
@@ -296,8 +296,8 @@ int ilqr_hip_solve_async(ilqr_hip_ctx* c) {
     { StageTimer T(c, 3); ilqr::launch_backward(S, ilqr::MASK_ACTIVE, st); }                                  // :601
     { StageTimer T(c, 4); ilqr::launch_line_search(S, P, ilqr::MASK_ACTIVE, st); }                            // :616
     { StageTimer T(c, 5); ilqr::launch_control(S, 0, iter, c->tol, c->early_exit, st); }                      // :619-620,645-655
-    { StageTimer T(c, 3); ilqr::launch_backward(S, ilqr::MASK_RETRY, st); }                                   // :637
-    { StageTimer T(c, 4); ilqr::launch_line_search(S, P, ilqr::MASK_RETRY, st); }                             // :638
+    { StageTimer T(c, 6); ilqr::launch_backward(S, ilqr::MASK_RETRY, st); }                                   // :637
+    { StageTimer T(c, 7); ilqr::launch_line_search(S, P, ilqr::MASK_RETRY, st); }                             // :638
     { StageTimer T(c, 5); ilqr::launch_control(S, 1, iter, c->tol, c->early_exit, st); }                      // :640-646
   }
   HIPCHK(c, hipGetLastError());
@@ -355,6 +355,15 @@ int ilqr_hip_first_knot_device(ilqr_hip_ctx* c, const double** u0, const double*
   if (u0) *u0 = c->d_u0;
   if (K0) *K0 = c->d_K0;
   if (cost) *cost = c->S.J;
+  return ILQR_OK;
+}
+int ilqr_hip_pack_first_knot_device(ilqr_hip_ctx* c, double* u0_out, double* K0_out, double* cost_out) {
+  if (!c || !u0_out) return ILQR_ERR_ARG;
+  hipSetDevice(c->device);
+  ilqr::launch_pack_first_knot(c->S, u0_out, K0_out ? K0_out : c->d_K0, c->stream);
+  HIPCHK(c, hipGetLastError());
+  if (cost_out) HIPCHK(c, hipMemcpyAsync(cost_out, c->S.J, (size_t)c->B * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
   return ILQR_OK;
 }
 int ilqr_hip_compute_control(ilqr_hip_ctx* c, const double* x_measured, double* u_apply) {
@@ -471,7 +480,7 @@ int ilqr_hip_step(ilqr_hip_ctx* c, int count, const double* x, const double* u, 
 int ilqr_hip_enable_profiling(ilqr_hip_ctx* c, int on) { if (!c) return ILQR_ERR_ARG; c->profiling = on ? 1 : 0; return ILQR_OK; }
 int ilqr_hip_get_stage_ms(ilqr_hip_ctx* c, double* ms, double* launches) {
   if (!c || !ms) return ILQR_ERR_ARG;
-  for (int i = 0; i < 6; ++i) { ms[i] = c->stage_ms[i]; if (launches) launches[i] = c->stage_launches[i]; }
+  for (int i = 0; i < 8; ++i) { ms[i] = c->stage_ms[i]; if (launches) launches[i] = c->stage_launches[i]; }
   return ILQR_OK;
 }
 

@@ -29,7 +29,8 @@ EXPORTS = [
     "ilqr_hip_initialize", "ilqr_hip_initialize_warm_resident", "ilqr_hip_initialize_device",
     "ilqr_hip_solve", "ilqr_hip_solve_async", "ilqr_hip_synchronize",
     "ilqr_hip_get_xbar", "ilqr_hip_get_ubar", "ilqr_hip_get_gains_K", "ilqr_hip_get_gains_kff", "ilqr_hip_get_cost",
-    "ilqr_hip_get_iterations", "ilqr_hip_get_lambda", "ilqr_hip_get_trace", "ilqr_hip_first_knot_device", "ilqr_hip_compute_control",
+    "ilqr_hip_get_iterations", "ilqr_hip_get_lambda", "ilqr_hip_get_trace", "ilqr_hip_first_knot_device", "ilqr_hip_pack_first_knot_device",
+    "ilqr_hip_compute_control",
     "ilqr_hip_set_trajectory", "ilqr_hip_stage_rollout", "ilqr_hip_stage_linearize", "ilqr_hip_stage_cost_quadratics",
     "ilqr_hip_stage_backward_pass", "ilqr_hip_stage_line_search", "ilqr_hip_stage_total_cost",
     "ilqr_hip_get_linearization", "ilqr_hip_set_linearization", "ilqr_hip_get_quadratics", "ilqr_hip_set_quadratics",
@@ -214,6 +215,10 @@ class BatchedILQR:
         self._chk(self.L.ilqr_hip_first_knot_device(self.h, C.byref(u0), C.byref(K0), C.byref(c)))
         return u0.value, K0.value, c.value
 
+    def pack_first_knot_device(self, u0_ptr, K0_ptr=None, cost_ptr=None):
+        """Write u0[B][19] (+ K0[B][19][51], cost[B]) into caller-owned device buffers (gather payload)."""
+        self._chk(self.L.ilqr_hip_pack_first_knot_device(self.h, C.c_void_p(u0_ptr), C.c_void_p(K0_ptr), C.c_void_p(cost_ptr)))
+
     def compute_control(self, x_measured):
         u = np.zeros((self.B, NU))
         self._chk(self.L.ilqr_hip_compute_control(self.h, _p(_c64(x_measured)), _p(u)))
@@ -279,9 +284,10 @@ class BatchedILQR:
         self._chk(self.L.ilqr_hip_enable_profiling(self.h, int(bool(on))))
 
     def stage_ms(self):
-        ms, n = np.zeros(6), np.zeros(6)
+        ms, n = np.zeros(8), np.zeros(8)
         self._chk(self.L.ilqr_hip_get_stage_ms(self.h, _p(ms), _p(n)))
-        keys = ["iLQR_computeCost+forwardRollout", "iLQR_linearization", "iLQR_costQuadratics", "iLQR_backwardPass", "iLQR_lineSearch", "iLQR_control"]
+        keys = ["iLQR_computeCost+forwardRollout", "iLQR_linearization", "iLQR_costQuadratics", "iLQR_backwardPass", "iLQR_lineSearch", "iLQR_control",
+                "iLQR_backwardPass_retry", "iLQR_lineSearch_retry"]
         return dict(zip(keys, ms)), dict(zip(keys, n))
 
     @property
