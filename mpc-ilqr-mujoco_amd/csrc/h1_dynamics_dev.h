@@ -209,9 +209,20 @@ template <class T> DEVFN void solve6(const T* A, const T* b, T* y) {
 
 // ---------- forward dynamics in MuJoCo coordinates ----------
 // quat_hat unit (wxyz); theta[19]; v = qvel[25]; tau[19]; returns qacc[25]
-template <class T>
+// Optional extras: tau_base = generalized force on the free joint in MuJoCo coordinates (world-frame
+// linear force, body-frame torque); dump = primal per-body quantities for the linearisation kernel.
+struct KnotDump {
+  double R0[9];                 // base rotation, body -> world
+  double aL[3];                 // R0^T (qacc_lin - g)
+  double qacc[H1_NV];           // MuJoCo-coordinate acceleration of the knot
+  double Rj[H1_NB][9];          // joint rotations child -> parent ([0] unused)
+  double v[H1_NB][6];           // body spatial velocities (body coordinates, [ang; lin])
+  double a[H1_NB][6];           // gravity-offset spatial accelerations
+  double F[H1_NB][6];           // accumulated inverse-dynamics forces (body i and its subtree)
+};
+template <class T, bool DUMP = false>
 DEVFN void forward_dynamics(const T* quat_hat, const T* theta, const T* v, const T* tau, double arm_eff,
-                                              const double* grav, T* qacc) {
+                            const double* grav, T* qacc, const T* tau_base = nullptr, KnotDump* dump = nullptr) {
   T R0[9]; quat_wxyz_R(quat_hat[0], quat_hat[1], quat_hat[2], quat_hat[3], R0);
   // per-body state kept for the outward acceleration sweep
   T vel[H1_NB][6];                   // body spatial velocity (body coordinates)
@@ -291,6 +302,11 @@ DEVFN void forward_dynamics(const T* quat_hat, const T* theta, const T* v, const
   T rhs[6];
 #pragma unroll
   for (int k = 0; k < 6; ++k) rhs[k] = -pA[0][k];
+  if (tau_base) {  // external generalized force on the free joint: (body torque, R0^T world force)
+    T fl[3]; mtv3(R0, tau_base, fl);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { rhs[k] += tau_base[3 + k]; rhs[3 + k] += fl[k]; }
+  }
   T acc[H1_NB][6];
   solve6(IA0, rhs, acc[0]);
   T mg[3] = {T(-grav[0]), T(-grav[1]), T(-grav[2])};
@@ -318,6 +334,24 @@ DEVFN void forward_dynamics(const T* quat_hat, const T* theta, const T* v, const
   T lin[3] = {nudot[3] + wxv[0], nudot[4] + wxv[1], nudot[5] + wxv[2]};
   mv3(R0, lin, qacc);
   qacc[3] = nudot[0]; qacc[4] = nudot[1]; qacc[5] = nudot[2];
+  if constexpr (DUMP) {
+    KnotDump& Dm = *dump;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) Dm.R0[k] = R0[k];
+    for (int k = 0; k < H1_NV; ++k) Dm.qacc[k] = qacc[k];
+    // aL = R0^T (qacc_lin - g) = a0_lin(gravity-offset) + omega x v_O
+    for (int k = 0; k < 3; ++k) Dm.aL[k] = acc[0][3 + k] + wxv[k];
+    for (int i = 0; i < H1_NB; ++i) {
+      for (int k = 0; k < 6; ++k) { Dm.v[i][k] = vel[i][k]; Dm.a[i][k] = acc[i][k]; }
+      T Iv[6], Ia_[6], vIv[6]; inertia_mul(i, vel[i], Iv); inertia_mul(i, acc[i], Ia_); crf(vel[i], Iv, vIv);
+      for (int k = 0; k < 6; ++k) Dm.F[i][k] = Ia_[k] + vIv[k];
+    }
+    for (int i = H1_NB - 1; i >= 1; --i) {
+      T Rj[9]; joint_rot(i, theta[i - 1], H1_RFIX, Rj);
+      for (int k = 0; k < 9; ++k) Dm.Rj[i][k] = Rj[k];
+      xf_force_acc(Rj, H1_POS[i], Dm.F[i], Dm.F[H1_PARENT[i]]);
+    }
+  }
 }
 
 // cos(a/2) and sin(a/2)/a as smooth functions of s = a^2

@@ -1,0 +1,265 @@
+// Analytic dynamics Jacobians A_t = df/dx (51x51), B_t = df/du (51x19) of the H1 step, one wave per knot.
+//
+// Replaces iLQR::computeLinearization -> RobotUtils::linearizeDynamicsFD (reference
+// src/ilqr/ilqr.cpp:126-131, src/common/robot_utils.cpp:120-160: 71 finite-difference steps per knot)
+// with exact derivatives in raw coordinates (the quaternion block contains the normalisation
+// projector):
+//   qacc = Minv (tau - D v - ID(q, v, 0))  =>  d qacc/d z = -Minv ( d ID(q, v, qacc)/d z + D dv/dz )
+// * every lane owns one tangent direction z (3 base-rotation, 19 hinge angles, 3 + 3 base velocity,
+//   19 hinge rates) and runs a tangent recursive-Newton-Euler sweep down and up the H1 tree with the
+//   primal per-body quantities (KnotDump) broadcast from LDS; chains are processed one at a time so
+//   only <= 5 tangent body forces are live per lane,
+// * the 25x47 tangent generalized forces are multiplied by Minv (25x25) from LDS,
+// * each lane then assembles one column of A / B through the integrator
+//   (v' = v + h qacc, p' = p + h v'_lin, theta' = theta + h thetadot', quat' = qhat (x) exp(h w')).
+#pragma once
+#include "h1_dynamics_dev.h"
+
+namespace h1 {
+
+#define LIN_NDIR 47   // tangent directions: phi(3) theta(19) v_lin(3) omega(3) thetadot(19)
+#define LIN_LD 48     // padded lane stride of the direction arrays
+
+struct LinShared {
+  KnotDump D;
+  double Minv[H1_NV][H1_NV];     // d qacc / d tau in MuJoCo coordinates
+  double dT[H1_NV][LIN_LD];      // tangent generalized forces, then d qacc / d direction
+  double x[H1_NX], u[H1_NU];
+  double qh[4], qn, e[4], dE[4][3], Hq[3][4];
+  double free_u[H1_NU];
+  double h;
+};
+
+// a x e_ax and e_ax x a for a principal axis
+DEVFN void cross_axis(const double* a, int ax, double* o) {   // a x e_ax
+  if (ax == 0) { o[0] = 0.0; o[1] = a[2]; o[2] = -a[1]; }
+  else if (ax == 1) { o[0] = -a[2]; o[1] = 0.0; o[2] = a[0]; }
+  else { o[0] = a[1]; o[1] = -a[0]; o[2] = 0.0; }
+}
+
+enum { DIR_PHI = 0, DIR_THETA = 1, DIR_VLIN = 2, DIR_OMEGA = 3, DIR_THETADOT = 4, DIR_NONE = 5 };
+DEVFN void lane_direction(int lane, int& kind, int& idx) {
+  if (lane < 3) { kind = DIR_PHI; idx = lane; }
+  else if (lane < 22) { kind = DIR_THETA; idx = lane - 3 + 1; }       // body index 1..19
+  else if (lane < 25) { kind = DIR_VLIN; idx = lane - 22; }
+  else if (lane < 28) { kind = DIR_OMEGA; idx = lane - 25; }
+  else if (lane < LIN_NDIR) { kind = DIR_THETADOT; idx = lane - 28 + 1; }
+  else { kind = DIR_NONE; idx = 0; }
+}
+
+// tangent of (v_i, a_i, f_i) of body i given its parent's tangent (pv, pa)
+DEVFN void tan_body_fwd(const LinShared& L, int i, int kind, int idx, const double* pv, const double* pa,
+                        double* dv, double* da, double* df) {
+  const KnotDump& D = L.D;
+  const int ax = H1_AXIS[i];
+  const double* Rj = D.Rj[i];
+  const double qd = L.x[H1_NQ + 6 + i - 1];
+  xf_motion(Rj, H1_POS[i], pv, dv);
+  xf_motion(Rj, H1_POS[i], pa, da);
+  if (kind == DIR_THETA && idx == i) {
+    // d(X u)/d theta = -S x (X u)
+    double t[3], xa[6];
+    cross_axis(D.v[i], ax, t);      dv[0] += t[0]; dv[1] += t[1]; dv[2] += t[2];        // -(e x w) = w x e
+    cross_axis(D.v[i] + 3, ax, t);  dv[3] += t[0]; dv[4] += t[1]; dv[5] += t[2];
+    xf_motion(Rj, H1_POS[i], D.a[H1_PARENT[i]], xa);
+    cross_axis(xa, ax, t);          da[0] += t[0]; da[1] += t[1]; da[2] += t[2];
+    cross_axis(xa + 3, ax, t);      da[3] += t[0]; da[4] += t[1]; da[5] += t[2];
+  }
+  if (kind == DIR_THETADOT && idx == i) dv[ax] += 1.0;
+  {  // + dv x (S qd)
+    double t[3];
+    cross_axis(dv, ax, t);     da[0] += qd * t[0]; da[1] += qd * t[1]; da[2] += qd * t[2];
+    cross_axis(dv + 3, ax, t); da[3] += qd * t[0]; da[4] += qd * t[1]; da[5] += qd * t[2];
+  }
+  if (kind == DIR_THETADOT && idx == i) {  // + v_i x S
+    double t[3];
+    cross_axis(D.v[i], ax, t);     da[0] += t[0]; da[1] += t[1]; da[2] += t[2];
+    cross_axis(D.v[i] + 3, ax, t); da[3] += t[0]; da[4] += t[1]; da[5] += t[2];
+  }
+  double Ida[6], Idv[6], h[6], t1[6], t2[6];
+  inertia_mul(i, da, Ida); inertia_mul(i, dv, Idv); inertia_mul(i, D.v[i], h);
+  crf(dv, h, t1); crf(D.v[i], Idv, t2);
+#pragma unroll
+  for (int k = 0; k < 6; ++k) df[k] = Ida[k] + t1[k] + t2[k];
+}
+// body i's total tangent force tot -> its generalized force row and the contribution to the parent
+DEVFN double tan_body_bwd(const LinShared& L, int i, int kind, int idx, const double* tot, double* parent_acc) {
+  const KnotDump& D = L.D;
+  const int ax = H1_AXIS[i];
+  double g[6] = {tot[0], tot[1], tot[2], tot[3], tot[4], tot[5]};
+  if (kind == DIR_THETA && idx == i) {   // d(X^T f)/d theta = X^T (S x* F) = X^T (e x n ; e x f)
+    double t[3];
+    cross_axis(D.F[i], ax, t);     g[0] -= t[0]; g[1] -= t[1]; g[2] -= t[2];
+    cross_axis(D.F[i] + 3, ax, t); g[3] -= t[0]; g[4] -= t[1]; g[5] -= t[2];
+  }
+  xf_force_acc(D.Rj[i], H1_POS[i], g, parent_acc);
+  return tot[ax];
+}
+template <int LEN>
+DEVFN void tan_chain(LinShared& L, int first, int kind, int idx, const double* jv, const double* ja, double* dFj, int lane) {
+  double df[LEN][6], cv[6], ca[6], nv[6], na[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) { cv[k] = jv[k]; ca[k] = ja[k]; }
+#pragma unroll
+  for (int k = 0; k < LEN; ++k) {
+    tan_body_fwd(L, first + k, kind, idx, cv, ca, nv, na, df[k]);
+#pragma unroll
+    for (int c = 0; c < 6; ++c) { cv[c] = nv[c]; ca[c] = na[c]; }
+  }
+  double acc[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+  for (int k = LEN - 1; k >= 0; --k) {
+    const int i = first + k;
+    double tot[6];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) { tot[c] = df[k][c] + acc[c]; acc[c] = 0.0; }
+    L.dT[5 + i][lane] = tan_body_bwd(L, i, kind, idx, tot, (k == 0) ? dFj : acc);
+  }
+}
+
+// one lane: tangent generalized forces d ID_mj / d direction (+ damping), written to L.dT[:, lane]
+DEVFN void lin_tangent_lane(LinShared& L, int lane) {
+  int kind, idx; lane_direction(lane, kind, idx);
+  if (kind == DIR_NONE) return;
+  const KnotDump& D = L.D;
+  double dv0[6] = {0, 0, 0, 0, 0, 0}, da0[6] = {0, 0, 0, 0, 0, 0};
+  const double* w = D.v[0];       // omega_body
+  const double* vO = D.v[0] + 3;  // R0^T v_lin
+  if (kind == DIR_PHI) {          // R0 -> R0 (I + [dphi]x): d(R0^T u) = (R0^T u) x dphi
+    double t[3];
+    cross_axis(vO, idx, t); dv0[3] = t[0]; dv0[4] = t[1]; dv0[5] = t[2];
+    cross_axis(D.aL, idx, t);
+    double wx[3]; cross3(w, dv0 + 3, wx);
+    da0[3] = t[0] - wx[0]; da0[4] = t[1] - wx[1]; da0[5] = t[2] - wx[2];
+  } else if (kind == DIR_VLIN) {  // dv_O = R0^T e_k
+    dv0[3] = D.R0[3 * idx]; dv0[4] = D.R0[3 * idx + 1]; dv0[5] = D.R0[3 * idx + 2];
+    double wx[3]; cross3(w, dv0 + 3, wx);
+    da0[3] = -wx[0]; da0[4] = -wx[1]; da0[5] = -wx[2];
+  } else if (kind == DIR_OMEGA) { // a0_lin = aL - w x v_O
+    dv0[idx] = 1.0;
+    double t[3]; cross_axis(vO, idx, t);   // v_O x e_k = -(e_k x v_O)
+    da0[3] = t[0]; da0[4] = t[1]; da0[5] = t[2];
+  }
+  double dF0[6];
+  {
+    double Ida[6], Idv[6], h[6], t1[6], t2[6];
+    inertia_mul(0, da0, Ida); inertia_mul(0, dv0, Idv); inertia_mul(0, D.v[0], h);
+    crf(dv0, h, t1); crf(D.v[0], Idv, t2);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) dF0[k] = Ida[k] + t1[k] + t2[k];
+  }
+  // torso and the two arms hanging off it
+  double tv[6], ta[6], dF11[6];
+  tan_body_fwd(L, 11, kind, idx, dv0, da0, tv, ta, dF11);
+  tan_chain<4>(L, 12, kind, idx, tv, ta, dF11, lane);
+  tan_chain<4>(L, 16, kind, idx, tv, ta, dF11, lane);
+  L.dT[5 + 11][lane] = tan_body_bwd(L, 11, kind, idx, dF11, dF0);
+  // legs
+  tan_chain<5>(L, 1, kind, idx, dv0, da0, dF0, lane);
+  tan_chain<5>(L, 6, kind, idx, dv0, da0, dF0, lane);
+  // free joint rows: torque in the body frame, force in the world frame
+  double fl[3] = {dF0[3], dF0[4], dF0[5]};
+  if (kind == DIR_PHI) {  // d(R0 f) = R0 (dphi x f + df)
+    double t[3]; cross_axis(D.F[0] + 3, idx, t);   // F x e_k = -(e_k x F)
+    fl[0] -= t[0]; fl[1] -= t[1]; fl[2] -= t[2];
+  }
+  double fw[3]; mv3(D.R0, fl, fw);
+  L.dT[0][lane] = fw[0]; L.dT[1][lane] = fw[1]; L.dT[2][lane] = fw[2];
+  L.dT[3][lane] = dF0[0]; L.dT[4][lane] = dF0[1]; L.dT[5][lane] = dF0[2];
+  if (kind == DIR_THETADOT) L.dT[5 + idx][lane] += H1_DAMPING;
+}
+
+// d qacc / d direction = -Minv dT  (in place, one lane per direction)
+DEVFN void lin_apply_minv_lane(LinShared& L, int lane) {
+  if (lane >= LIN_NDIR) return;
+  double col[H1_NV], out[H1_NV];
+#pragma unroll
+  for (int c = 0; c < H1_NV; ++c) col[c] = L.dT[c][lane];
+#pragma unroll
+  for (int r = 0; r < H1_NV; ++r) {
+    double s = 0.0;
+#pragma unroll
+    for (int c = 0; c < H1_NV; ++c) s -= L.Minv[r][c] * col[c];
+    out[r] = s;
+  }
+#pragma unroll
+  for (int r = 0; r < H1_NV; ++r) L.dT[r][lane] = out[r];
+}
+
+// uniform integrator quantities (one lane)
+DEVFN void lin_prologue(LinShared& L) {
+  const double* x = L.x; const double h = L.h;
+  const double qn = sqrt(x[3] * x[3] + x[4] * x[4] + x[5] * x[5] + x[6] * x[6]);
+  L.qn = qn;
+  const double qw = x[3] / qn, qx = x[4] / qn, qy = x[5] / qn, qz = x[6] / qn;
+  L.qh[0] = qw; L.qh[1] = qx; L.qh[2] = qy; L.qh[3] = qz;
+  const double s2 = 2.0 / qn;
+  // dphi = Hq dquat_raw (body-frame rotation tangent of a raw quaternion perturbation)
+  L.Hq[0][0] = -qx * s2; L.Hq[0][1] = qw * s2;  L.Hq[0][2] = qz * s2;  L.Hq[0][3] = -qy * s2;
+  L.Hq[1][0] = -qy * s2; L.Hq[1][1] = -qz * s2; L.Hq[1][2] = qw * s2;  L.Hq[1][3] = qx * s2;
+  L.Hq[2][0] = -qz * s2; L.Hq[2][1] = qy * s2;  L.Hq[2][2] = -qx * s2; L.Hq[2][3] = qw * s2;
+  double wn[3];
+  for (int k = 0; k < 3; ++k) wn[k] = x[H1_NQ + 3 + k] + h * L.D.qacc[3 + k];
+  const double s = (wn[0] * wn[0] + wn[1] * wn[1] + wn[2] * wn[2]) * h * h;
+  double c, so, dso;
+  if (s < 1e-6) {
+    c = 1.0 - s / 8.0 + s * s / 384.0 - s * s * s / 46080.0;
+    so = 0.5 - s / 48.0 + s * s / 3840.0 - s * s * s / 645120.0;
+    dso = -1.0 / 48.0 + s / 1920.0 - s * s / 215040.0;
+  } else {
+    const double a = sqrt(s); double sn, cn; sincos(0.5 * a, &sn, &cn);
+    c = cn; so = sn / a; dso = (0.25 * c - 0.5 * so) / s;
+  }
+  L.e[0] = c; L.e[1] = so * h * wn[0]; L.e[2] = so * h * wn[1]; L.e[3] = so * h * wn[2];
+  for (int j = 0; j < 3; ++j) {
+    L.dE[0][j] = -0.5 * so * h * h * wn[j];
+    for (int i = 0; i < 3; ++i) L.dE[1 + i][j] = (i == j ? so * h : 0.0) + h * wn[i] * dso * 2.0 * h * h * wn[j];
+  }
+  for (int i = 0; i < H1_NU; ++i) L.free_u[i] = (L.u[i] < H1_CTRLRANGE[i][0] || L.u[i] > H1_CTRLRANGE[i][1]) ? 0.0 : 1.0;
+}
+
+DEVFN void quat_mul(const double* a, const double* b, double* r) {
+  r[0] = a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3];
+  r[1] = a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2];
+  r[2] = a[0] * b[2] - a[1] * b[3] + a[2] * b[0] + a[3] * b[1];
+  r[3] = a[0] * b[3] + a[1] * b[2] - a[2] * b[1] + a[3] * b[0];
+}
+
+// column k of A (is_u = 0, k in 0..50) or of B (is_u = 1, k in 0..18); col[51]
+DEVFN void lin_column(const LinShared& L, int is_u, int k, double* col) {
+  const double h = L.h;
+  double dq[H1_NV];
+  double dphi[3] = {0.0, 0.0, 0.0};
+  if (is_u) {
+#pragma unroll
+    for (int r = 0; r < H1_NV; ++r) dq[r] = L.Minv[r][6 + k] * L.free_u[k];
+  } else if (k < 3) {
+#pragma unroll
+    for (int r = 0; r < H1_NV; ++r) dq[r] = 0.0;
+  } else if (k < 7) {
+    for (int j = 0; j < 3; ++j) dphi[j] = L.Hq[j][k - 3];
+#pragma unroll
+    for (int r = 0; r < H1_NV; ++r) dq[r] = L.dT[r][0] * dphi[0] + L.dT[r][1] * dphi[1] + L.dT[r][2] * dphi[2];
+  } else {
+    const int lane = (k < H1_NQ) ? (3 + k - 7) : (22 + k - H1_NQ);
+#pragma unroll
+    for (int r = 0; r < H1_NV; ++r) dq[r] = L.dT[r][lane];
+  }
+  double dvn[H1_NV];
+#pragma unroll
+  for (int r = 0; r < H1_NV; ++r) { dvn[r] = h * dq[r] + ((!is_u && k >= H1_NQ && r == k - H1_NQ) ? 1.0 : 0.0); col[H1_NQ + r] = dvn[r]; }
+#pragma unroll
+  for (int i = 0; i < 3; ++i) col[i] = ((!is_u && k == i) ? 1.0 : 0.0) + h * dvn[i];
+#pragma unroll
+  for (int j = 0; j < H1_NJ; ++j) col[7 + j] = ((!is_u && k == 7 + j) ? 1.0 : 0.0) + h * dvn[6 + j];
+  // quaternion rows: d(qhat (x) e) = dqhat (x) e + qhat (x) de
+  double dqh[4] = {0, 0, 0, 0}, de[4], t1[4], t2[4];
+  if (!is_u && k >= 3 && k < 7) { const double hp[4] = {0.0, 0.5 * dphi[0], 0.5 * dphi[1], 0.5 * dphi[2]}; quat_mul(L.qh, hp, dqh); }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) de[i] = L.dE[i][0] * dvn[3] + L.dE[i][1] * dvn[4] + L.dE[i][2] * dvn[5];
+  quat_mul(dqh, L.e, t1); quat_mul(L.qh, de, t2);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) col[3 + i] = t1[i] + t2[i];
+}
+
+}  // namespace h1

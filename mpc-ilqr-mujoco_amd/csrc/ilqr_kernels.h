@@ -30,6 +30,8 @@ struct DevState {
   double* luu;         // [B][N][19]        diagonal
   double* K;           // [B][N][19][51]
   double* kff;         // [B][N][19]
+  double* lin_dump;    // [B][N][sizeof(KnotDump)/8] primal per-body quantities of every knot
+  double* lin_Y;       // [B][N][26][25]    forward dynamics under unit generalized forces (+ nominal)
   double* Vx;          // [B][51]           value gradient at knot 0
   double* Vxx;         // [B][51][51]
   double* J;           // [B] current cost
@@ -60,5 +62,6 @@ void launch_compute_control(const DevState& S, const double* x_meas, double* u_o
 void launch_pack_first_knot(const DevState& S, double* u0, double* K0, hipStream_t st);
 int backward_needs_lds_attr();
 size_t backward_lds_bytes();
+size_t lin_dump_doubles();
 
 }  // namespace ilqr

@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 
 #include "h1_cost_dev.h"
+#include "h1_linearize_dev.h"
 #include "ilqr_kernels.h"
 
 using namespace h1;
@@ -64,11 +65,86 @@ __global__ void __launch_bounds__(64) k_step(int count, const double* x, const d
 }
 
 // ------------------------------------------------------------------ K2: dynamics Jacobians
+// Analytic mode = two kernels (h1_linearize_dev.h):
+//   k_lin_primal : 32 threads per knot; thread 25 runs the nominal forward dynamics and dumps the primal
+//                  per-body quantities, threads 0..24 run it with a unit generalized force on one dof
+//                  (forward dynamics is affine in tau, so the differences are the columns of Minv).
+//   k_lin_tangent: one wave per knot; lanes = tangent directions, then lanes = Jacobian columns.
+#define LINP_ROLES 32
+__global__ void __launch_bounds__(256) k_lin_primal(DevState S, ProblemDev P, int mode) {
+  const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long knot = gid / LINP_ROLES;
+  const int role = (int)(gid % LINP_ROLES);
+  if (knot >= (long)S.B * S.N || role > H1_NV) return;
+  const int t = (int)(knot % S.N), b = (int)(knot / S.N);
+  if (!selected(S, b, mode)) return;
+  const double* xg = S.xbar + ((size_t)b * (S.N + 1) + t) * H1_NX;
+  const double* ug = S.ubar + ((size_t)b * S.N + t) * H1_NU;
+  const double h = P.dyn.h;
+  double x[H1_NX], tau[H1_NU], tb[6] = {0, 0, 0, 0, 0, 0}, qacc[H1_NV];
+  for (int i = 0; i < H1_NX; ++i) x[i] = xg[i];
+  const double qn = sqrt(x[3] * x[3] + x[4] * x[4] + x[5] * x[5] + x[6] * x[6]);
+  const double qh[4] = {x[3] / qn, x[4] / qn, x[5] / qn, x[6] / qn};
+  for (int i = 0; i < H1_NU; ++i) {
+    double ui = ug[i];
+    if (ui < H1_CTRLRANGE[i][0]) ui = H1_CTRLRANGE[i][0];
+    if (ui > H1_CTRLRANGE[i][1]) ui = H1_CTRLRANGE[i][1];
+    tau[i] = ui - H1_DAMPING * x[H1_NQ + 6 + i] + ((role == 6 + i) ? 1.0 : 0.0);
+  }
+  if (role < 6) tb[role] = 1.0;
+  double* Y = S.lin_Y + ((size_t)knot * (H1_NV + 1) + role) * H1_NV;
+  if (role == H1_NV) {
+    KnotDump* dump = reinterpret_cast<KnotDump*>(S.lin_dump + (size_t)knot * (sizeof(KnotDump) / sizeof(double)));
+    KnotDump local;
+    forward_dynamics<double, true>(qh, x + 7, x + H1_NQ, tau, H1_ARMATURE + h * H1_DAMPING, P.dyn.g, qacc, (const double*)nullptr, &local);
+    const double* src = reinterpret_cast<const double*>(&local);
+    double* dst = reinterpret_cast<double*>(dump);
+    for (int i = 0; i < (int)(sizeof(KnotDump) / sizeof(double)); ++i) dst[i] = src[i];
+  } else {
+    forward_dynamics<double, false>(qh, x + 7, x + H1_NQ, tau, H1_ARMATURE + h * H1_DAMPING, P.dyn.g, qacc, tb, (KnotDump*)nullptr);
+  }
+  for (int i = 0; i < H1_NV; ++i) Y[i] = qacc[i];
+}
+
+__global__ void __launch_bounds__(64) k_lin_tangent(DevState S, ProblemDev P, int mode) {
+  const int t = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+  if (!selected(S, b, mode)) return;
+  __shared__ LinShared L;
+  const size_t knot = (size_t)b * S.N + t;
+  {
+    const double* src = S.lin_dump + knot * (sizeof(KnotDump) / sizeof(double));
+    double* dst = reinterpret_cast<double*>(&L.D);
+    for (int i = lane; i < (int)(sizeof(KnotDump) / sizeof(double)); i += 64) dst[i] = src[i];
+    const double* Y = S.lin_Y + knot * (H1_NV + 1) * H1_NV;
+    for (int e = lane; e < H1_NV * H1_NV; e += 64) { const int c = e / H1_NV, r = e % H1_NV; L.Minv[r][c] = Y[c * H1_NV + r] - Y[H1_NV * H1_NV + r]; }
+    if (lane < H1_NX) L.x[lane] = S.xbar[((size_t)b * (S.N + 1) + t) * H1_NX + lane];
+    if (lane < H1_NU) L.u[lane] = S.ubar[((size_t)b * S.N + t) * H1_NU + lane];
+    if (lane == 0) L.h = P.dyn.h;
+  }
+  __syncthreads();
+  if (lane == 0) lin_prologue(L);
+  lin_tangent_lane(L, lane);
+  __syncthreads();
+  lin_apply_minv_lane(L, lane);
+  __syncthreads();
+  double col[H1_NX];
+  double* Ag = S.A + knot * H1_NX * H1_NX;
+  double* Bg = S.Bm + knot * H1_NX * H1_NU;
+  if (lane < H1_NX) {
+    lin_column(L, 0, lane, col);
+#pragma unroll
+    for (int r = 0; r < H1_NX; ++r) Ag[r * H1_NX + lane] = col[r];
+  }
+  if (lane < H1_NU) {
+    lin_column(L, 1, lane, col);
+#pragma unroll
+    for (int r = 0; r < H1_NX; ++r) Bg[r * H1_NU + lane] = col[r];
+  }
+}
+
+// Reference-style forward differences (RobotUtils::linearizeDynamicsFD, robot_utils.cpp:120-160):
 // thread per (rollout, knot, column); columns 0..50 = d/dx, 51..69 = d/du.
-#ifndef LIN_THREADS
-#define LIN_THREADS 256  /* <=128 VGPRs: the 64-thread build (256 VGPR + AGPR spills) faulted on gfx950 at -O3 */
-#endif
-__global__ void __launch_bounds__(LIN_THREADS) k_linearize(DevState S, ProblemDev P, int mode, int jac_mode, double eps) {
+__global__ void __launch_bounds__(256) k_linearize_fd(DevState S, ProblemDev P, int mode, double eps) {
   const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const int NC = H1_NX + H1_NU;
   const long total = (long)S.B * S.N * NC;
@@ -82,25 +158,14 @@ __global__ void __launch_bounds__(LIN_THREADS) k_linearize(DevState S, ProblemDe
   const double* ug = S.ubar + ((size_t)b * S.N + t) * H1_NU;
   double* Ag = S.A + ((size_t)b * S.N + t) * H1_NX * H1_NX;
   double* Bg = S.Bm + ((size_t)b * S.N + t) * H1_NX * H1_NU;
-  double dcol[H1_NX];
-  if (jac_mode == 0) {
-    Dual x[H1_NX], u[H1_NU], xn[H1_NX];
-    for (int i = 0; i < H1_NX; ++i) x[i] = Dual(xg[i], i == col ? 1.0 : 0.0);
-    for (int i = 0; i < H1_NU; ++i) u[i] = Dual(ug[i], (H1_NX + i) == col ? 1.0 : 0.0);
-    step<Dual>(x, u, P.dyn, xn);
-    for (int i = 0; i < H1_NX; ++i) dcol[i] = xn[i].d;
-  } else {
-    // RobotUtils::linearizeDynamicsFD (robot_utils.cpp:120-160): forward difference on raw coordinates
-    double x[H1_NX], u[H1_NU], base[H1_NX], pert[H1_NX];
-    for (int i = 0; i < H1_NX; ++i) x[i] = xg[i];
-    for (int i = 0; i < H1_NU; ++i) u[i] = ug[i];
-    step<double>(x, u, P.dyn, base);
-    if (col < H1_NX) x[col] += eps; else u[col - H1_NX] += eps;
-    step<double>(x, u, P.dyn, pert);
-    for (int i = 0; i < H1_NX; ++i) dcol[i] = (pert[i] - base[i]) / eps;
-  }
-  if (col < H1_NX) { for (int i = 0; i < H1_NX; ++i) Ag[i * H1_NX + col] = dcol[i]; }
-  else { const int c = col - H1_NX; for (int i = 0; i < H1_NX; ++i) Bg[i * H1_NU + c] = dcol[i]; }
+  double x[H1_NX], u[H1_NU], base[H1_NX], pert[H1_NX];
+  for (int i = 0; i < H1_NX; ++i) x[i] = xg[i];
+  for (int i = 0; i < H1_NU; ++i) u[i] = ug[i];
+  step<double>(x, u, P.dyn, base);
+  if (col < H1_NX) x[col] += eps; else u[col - H1_NX] += eps;
+  step<double>(x, u, P.dyn, pert);
+  if (col < H1_NX) { for (int i = 0; i < H1_NX; ++i) Ag[i * H1_NX + col] = (pert[i] - base[i]) / eps; }
+  else { const int c = col - H1_NX; for (int i = 0; i < H1_NX; ++i) Bg[i * H1_NU + c] = (pert[i] - base[i]) / eps; }
 }
 
 // ------------------------------------------------------------------ K3: cost quadratics
@@ -575,9 +640,16 @@ void launch_step(int count, const double* x, const double* u, const DynParams& d
   hipLaunchKernelGGL(k_step, dim3(cdiv(count, 64)), dim3(64), 0, st, count, x, u, dyn, xn);
 }
 void launch_linearize(const DevState& S, const ProblemDev& P, int mode, int jac_mode, double eps, hipStream_t st) {
-  const long total = (long)S.B * S.N * (H1_NX + H1_NU);
-  hipLaunchKernelGGL(k_linearize, dim3(cdiv(total, LIN_THREADS)), dim3(LIN_THREADS), 0, st, S, P, mode, jac_mode, eps);
+  if (jac_mode == 0) {
+    const long threads = (long)S.B * S.N * LINP_ROLES;
+    hipLaunchKernelGGL(k_lin_primal, dim3(cdiv(threads, 256)), dim3(256), 0, st, S, P, mode);
+    hipLaunchKernelGGL(k_lin_tangent, dim3(S.N, S.B), dim3(64), 0, st, S, P, mode);
+  } else {
+    const long total = (long)S.B * S.N * (H1_NX + H1_NU);
+    hipLaunchKernelGGL(k_linearize_fd, dim3(cdiv(total, 256)), dim3(256), 0, st, S, P, mode, eps);
+  }
 }
+size_t lin_dump_doubles() { return sizeof(KnotDump) / sizeof(double); }
 void launch_cost_quadratics(const DevState& S, const ProblemDev& P, int mode, hipStream_t st) {
   hipLaunchKernelGGL(k_cost_quadratics, dim3(S.N + 1, S.B), dim3(64), 0, st, S, P, mode);
 }
