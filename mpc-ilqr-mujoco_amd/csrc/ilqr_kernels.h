@@ -63,5 +63,8 @@ void launch_pack_first_knot(const DevState& S, double* u0, double* K0, hipStream
 int backward_needs_lds_attr();
 size_t backward_lds_bytes();
 size_t lin_dump_doubles();
+void launch_backward_mfma(const DevState& S, int mode, hipStream_t st);
+int backward_mfma_set_attr();
+size_t backward_mfma_lds_bytes();
 
 }  // namespace ilqr

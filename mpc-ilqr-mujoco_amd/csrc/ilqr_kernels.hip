@@ -12,6 +12,8 @@
 // item (thread, wave or workgroup, per kernel) owns one rollout / knot and streams its own slab.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "h1_cost_dev.h"
 #include "h1_linearize_dev.h"
 #include "ilqr_kernels.h"
@@ -653,8 +655,15 @@ size_t lin_dump_doubles() { return sizeof(KnotDump) / sizeof(double); }
 void launch_cost_quadratics(const DevState& S, const ProblemDev& P, int mode, hipStream_t st) {
   hipLaunchKernelGGL(k_cost_quadratics, dim3(S.N + 1, S.B), dim3(64), 0, st, S, P, mode);
 }
+// ILQR_BACKWARD=valu selects the LDS + VALU kernel (kept as an on-device cross-check); default = MFMA kernel
+static int use_valu_backward() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("ILQR_BACKWARD"); v = (e && e[0] == 'v') ? 1 : 0; }
+  return v;
+}
 void launch_backward(const DevState& S, int mode, hipStream_t st) {
-  hipLaunchKernelGGL(k_backward, dim3(S.B), dim3(256), backward_lds_bytes(), st, S, mode);
+  if (use_valu_backward()) hipLaunchKernelGGL(k_backward, dim3(S.B), dim3(256), backward_lds_bytes(), st, S, mode);
+  else launch_backward_mfma(S, mode, st);
 }
 void launch_line_search(const DevState& S, const ProblemDev& P, int mode, hipStream_t st) {
   hipLaunchKernelGGL(k_line_search, dim3(cdiv((long)S.B * 8, 64)), dim3(64), 0, st, S, P, mode);
@@ -668,6 +677,7 @@ void launch_last_step(const DevState& S, const ProblemDev& P, hipStream_t st) { 
 void launch_compute_control(const DevState& S, const double* x_meas, double* u_out, hipStream_t st) { hipLaunchKernelGGL(k_compute_control, dim3(S.B), dim3(64), 0, st, S, x_meas, u_out); }
 void launch_pack_first_knot(const DevState& S, double* u0, double* K0, hipStream_t st) { hipLaunchKernelGGL(k_pack_first_knot, dim3(S.B), dim3(64), 0, st, S, u0, K0); }
 int backward_needs_lds_attr() {
+  if (backward_mfma_set_attr() != 0) return 1;
   return hipFuncSetAttribute((const void*)k_backward, hipFuncAttributeMaxDynamicSharedMemorySize, (int)backward_lds_bytes()) == hipSuccess ? 0 : 1;
 }
 
