@@ -219,6 +219,9 @@ struct KnotDump {
   double v[H1_NB][6];           // body spatial velocities (body coordinates, [ang; lin])
   double a[H1_NB][6];           // gravity-offset spatial accelerations
   double F[H1_NB][6];           // accumulated inverse-dynamics forces (body i and its subtree)
+  double U[H1_NB][6];           // articulated-body U_i = IA_i S_i ([0] unused)
+  double Dinv[H1_NB];           // 1 / (S_i^T U_i + effective armature)
+  double IA0inv[36];            // inverse of the pelvis articulated inertia
 };
 template <class T, bool DUMP = false>
 DEVFN void forward_dynamics(const T* quat_hat, const T* theta, const T* v, const T* tau, double arm_eff,
@@ -350,6 +353,14 @@ DEVFN void forward_dynamics(const T* quat_hat, const T* theta, const T* v, const
       T Rj[9]; joint_rot(i, theta[i - 1], H1_RFIX, Rj);
       for (int k = 0; k < 9; ++k) Dm.Rj[i][k] = Rj[k];
       xf_force_acc(Rj, H1_POS[i], Dm.F[i], Dm.F[H1_PARENT[i]]);
+      for (int k = 0; k < 6; ++k) Dm.U[i][k] = U[i][k];
+      Dm.Dinv[i] = Dinv[i];
+    }
+    for (int c = 0; c < 6; ++c) {   // explicit inverse of the SPD 6x6 pelvis articulated inertia
+      T e[6] = {T(0.0), T(0.0), T(0.0), T(0.0), T(0.0), T(0.0)}, col[6];
+      e[c] = T(1.0);
+      solve6(IA0, e, col);
+      for (int r = 0; r < 6; ++r) Dm.IA0inv[6 * r + c] = col[r];
     }
   }
 }

@@ -24,6 +24,7 @@ struct LinShared {
   KnotDump D;
   double Minv[H1_NV][H1_NV];     // d qacc / d tau in MuJoCo coordinates
   double dT[H1_NV][LIN_LD];      // tangent generalized forces, then d qacc / d direction
+  double du[H1_NB][32];          // Minv sweeps: per-lane joint force increments
   double x[H1_NX], u[H1_NU];
   double qh[4], qn, e[4], dE[4][3], Hq[3][4];
   double free_u[H1_NU];
@@ -167,6 +168,90 @@ DEVFN void lin_tangent_lane(LinShared& L, int lane) {
   L.dT[0][lane] = fw[0]; L.dT[1][lane] = fw[1]; L.dT[2][lane] = fw[2];
   L.dT[3][lane] = dF0[0]; L.dT[4][lane] = dF0[1]; L.dT[5][lane] = dF0[2];
   if (kind == DIR_THETADOT) L.dT[5 + idx][lane] += H1_DAMPING;
+}
+
+// Column c (= lane, 0..24) of Minv = d qacc / d tau in MuJoCo coordinates: response of the articulated-body
+// recursion to a unit generalized force on dof c with zero velocity and gravity (the recursion is linear in
+// the force): inward sweep of the bias-force increments, pelvis solve, outward sweep of the accelerations.
+// du[i] (19 per lane) is kept in LDS between the sweeps: L.du[i][lane].
+template <int LEN>
+DEVFN void minv_chain_in(LinShared& L, int first, int c, double* pJ, int lane) {
+  double acc[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+  for (int k = LEN - 1; k >= 0; --k) {
+    const int i = first + k, ax = H1_AXIS[i];
+    const double du = ((c == 5 + i) ? 1.0 : 0.0) - acc[ax];
+    L.du[i][lane] = du;
+    double pa[6];
+    const double s = du * L.D.Dinv[i];
+#pragma unroll
+    for (int r = 0; r < 6; ++r) { pa[r] = acc[r] + L.D.U[i][r] * s; acc[r] = 0.0; }
+    xf_force_acc(L.D.Rj[i], H1_POS[i], pa, (k == 0) ? pJ : acc);
+  }
+}
+template <int LEN>
+DEVFN void minv_chain_out(LinShared& L, int first, const double* aJ, int lane) {
+  double ap[6] = {aJ[0], aJ[1], aJ[2], aJ[3], aJ[4], aJ[5]};
+#pragma unroll
+  for (int k = 0; k < LEN; ++k) {
+    const int i = first + k, ax = H1_AXIS[i];
+    double a[6]; xf_motion(L.D.Rj[i], H1_POS[i], ap, a);
+    double s = L.du[i][lane];
+#pragma unroll
+    for (int r = 0; r < 6; ++r) s -= L.D.U[i][r] * a[r];
+    const double qdd = s * L.D.Dinv[i];
+    a[ax] += qdd;
+    L.Minv[5 + i][lane] = qdd;
+#pragma unroll
+    for (int r = 0; r < 6; ++r) ap[r] = a[r];
+  }
+}
+DEVFN void lin_minv_lane(LinShared& L, int lane) {
+  if (lane >= H1_NV) return;
+  const int c = lane;
+  double p11[6] = {0, 0, 0, 0, 0, 0}, p0[6] = {0, 0, 0, 0, 0, 0};
+  minv_chain_in<4>(L, 12, c, p11, lane);
+  minv_chain_in<4>(L, 16, c, p11, lane);
+  {  // torso
+    const int i = 11, ax = H1_AXIS[i];
+    const double du = ((c == 5 + i) ? 1.0 : 0.0) - p11[ax];
+    L.du[i][lane] = du;
+    const double s = du * L.D.Dinv[i];
+    double pa[6];
+#pragma unroll
+    for (int r = 0; r < 6; ++r) pa[r] = p11[r] + L.D.U[i][r] * s;
+    xf_force_acc(L.D.Rj[i], H1_POS[i], pa, p0);
+  }
+  minv_chain_in<5>(L, 1, c, p0, lane);
+  minv_chain_in<5>(L, 6, c, p0, lane);
+  // pelvis: IA0 a0 = f_ext - p0 ; f_ext = (body torque e_{c-3}, R0^T e_c) for the free-joint dofs
+  double rhs[6] = {-p0[0], -p0[1], -p0[2], -p0[3], -p0[4], -p0[5]};
+  if (c < 3) { rhs[3] += L.D.R0[3 * c]; rhs[4] += L.D.R0[3 * c + 1]; rhs[5] += L.D.R0[3 * c + 2]; }
+  else if (c < 6) rhs[c - 3] += 1.0;
+  double a0[6];
+#pragma unroll
+  for (int r = 0; r < 6; ++r) { double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) s += L.D.IA0inv[6 * r + k] * rhs[k];
+    a0[r] = s; }
+  double lw[3]; mv3(L.D.R0, a0 + 3, lw);
+  L.Minv[0][lane] = lw[0]; L.Minv[1][lane] = lw[1]; L.Minv[2][lane] = lw[2];
+  L.Minv[3][lane] = a0[0]; L.Minv[4][lane] = a0[1]; L.Minv[5][lane] = a0[2];
+  double a11[6];
+  {  // torso outward
+    const int i = 11, ax = H1_AXIS[i];
+    xf_motion(L.D.Rj[i], H1_POS[i], a0, a11);
+    double s = L.du[i][lane];
+#pragma unroll
+    for (int r = 0; r < 6; ++r) s -= L.D.U[i][r] * a11[r];
+    const double qdd = s * L.D.Dinv[i];
+    a11[ax] += qdd;
+    L.Minv[5 + i][lane] = qdd;
+  }
+  minv_chain_out<4>(L, 12, a11, lane);
+  minv_chain_out<4>(L, 16, a11, lane);
+  minv_chain_out<5>(L, 1, a0, lane);
+  minv_chain_out<5>(L, 6, a0, lane);
 }
 
 // d qacc / d direction = -Minv dT  (in place, one lane per direction)

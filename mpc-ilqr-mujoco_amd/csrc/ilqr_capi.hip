@@ -88,7 +88,7 @@ int ilqr_hip_create(ilqr_hip_ctx** out, int device, int batch, int horizon, doub
   A(dalloc(c, &S.xcand, B * 8 * (N + 1) * n)); A(dalloc(c, &S.ucand, B * 8 * N * m)); A(dalloc(c, &S.cand_cost, B * 8));
   A(dalloc(c, &S.A, B * N * n * n)); A(dalloc(c, &S.Bm, B * N * n * m));
   A(dalloc(c, &S.lx, B * (N + 1) * n)); A(dalloc(c, &S.lu, B * N * m)); A(dalloc(c, &S.lxx, B * (N + 1) * n * n)); A(dalloc(c, &S.luu, B * N * m));
-  A(dalloc(c, &S.lin_dump, B * N * ilqr::lin_dump_doubles())); A(dalloc(c, &S.lin_Y, B * N * (ILQR_NV + 1) * ILQR_NV));
+  A(dalloc(c, &S.lin_dump, B * N * ilqr::lin_dump_doubles()));
   A(dalloc(c, &S.K, B * N * m * n)); A(dalloc(c, &S.kff, B * N * m)); A(dalloc(c, &S.Vx, B * n)); A(dalloc(c, &S.Vxx, B * n * n));
   A(dalloc(c, &S.J, B)); A(dalloc(c, &S.Jbase, B)); A(dalloc(c, &S.ls_cost, B)); A(dalloc(c, &S.lambda, B));
   A(dalloc(c, &S.active, B)); A(dalloc(c, &S.need_retry, B)); A(dalloc(c, &S.iters, B)); A(dalloc(c, &S.improved, B)); A(dalloc(c, &S.alpha_idx, B));
@@ -123,7 +123,7 @@ int ilqr_hip_destroy(ilqr_hip_ctx* c) {
   if (!c) return ILQR_ERR_ARG;
   hipSetDevice(c->device);
   DevState& S = c->S;
-  void* ptrs[] = {S.lin_dump, S.lin_Y, S.x0, S.xbar, S.ubar, S.xcand, S.ucand, S.cand_cost, S.A, S.Bm, S.lx, S.lu, S.lxx, S.luu, S.K, S.kff, S.Vx, S.Vxx, S.J, S.Jbase, S.ls_cost,
+  void* ptrs[] = {S.lin_dump, S.x0, S.xbar, S.ubar, S.xcand, S.ucand, S.cand_cost, S.A, S.Bm, S.lx, S.lu, S.lxx, S.luu, S.K, S.kff, S.Vx, S.Vxx, S.J, S.Jbase, S.ls_cost,
                   S.lambda, S.active, S.need_retry, S.iters, S.improved, S.alpha_idx, S.trace_cost, S.trace_alpha, S.trace_lambda, c->d_tmpx, c->d_tmpu,
                   c->d_prevx, c->d_prevu, c->d_u0, c->d_K0, c->d_cost_tmp, c->d_xref, c->d_uref, c->d_comref, c->d_eeref, c->d_comvelref, c->d_stance};
   for (void* p : ptrs) if (p) hipFree(p);

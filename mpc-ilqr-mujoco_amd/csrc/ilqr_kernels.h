@@ -31,7 +31,6 @@ struct DevState {
   double* K;           // [B][N][19][51]
   double* kff;         // [B][N][19]
   double* lin_dump;    // [B][N][sizeof(KnotDump)/8] primal per-body quantities of every knot
-  double* lin_Y;       // [B][N][26][25]    forward dynamics under unit generalized forces (+ nominal)
   double* Vx;          // [B][51]           value gradient at knot 0
   double* Vxx;         // [B][51][51]
   double* J;           // [B] current cost

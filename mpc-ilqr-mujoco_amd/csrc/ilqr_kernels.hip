@@ -68,22 +68,19 @@ __global__ void __launch_bounds__(64) k_step(int count, const double* x, const d
 
 // ------------------------------------------------------------------ K2: dynamics Jacobians
 // Analytic mode = two kernels (h1_linearize_dev.h):
-//   k_lin_primal : 32 threads per knot; thread 25 runs the nominal forward dynamics and dumps the primal
-//                  per-body quantities, threads 0..24 run it with a unit generalized force on one dof
-//                  (forward dynamics is affine in tau, so the differences are the columns of Minv).
-//   k_lin_tangent: one wave per knot; lanes = tangent directions, then lanes = Jacobian columns.
-#define LINP_ROLES 32
-__global__ void __launch_bounds__(256) k_lin_primal(DevState S, ProblemDev P, int mode) {
-  const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  const long knot = gid / LINP_ROLES;
-  const int role = (int)(gid % LINP_ROLES);
-  if (knot >= (long)S.B * S.N || role > H1_NV) return;
+//   k_lin_primal : thread per knot; forward dynamics of the nominal knot, dumping the primal per-body
+//                  quantities (velocities, accelerations, forces, articulated-body U / D / pelvis inverse).
+//   k_lin_tangent: one wave per knot; lanes = columns of Minv (unit-force sweeps) and tangent directions
+//                  (tangent RNEA sweeps), then lanes = Jacobian columns.
+__global__ void __launch_bounds__(64) k_lin_primal(DevState S, ProblemDev P, int mode) {
+  const long knot = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (knot >= (long)S.B * S.N) return;
   const int t = (int)(knot % S.N), b = (int)(knot / S.N);
   if (!selected(S, b, mode)) return;
   const double* xg = S.xbar + ((size_t)b * (S.N + 1) + t) * H1_NX;
   const double* ug = S.ubar + ((size_t)b * S.N + t) * H1_NU;
   const double h = P.dyn.h;
-  double x[H1_NX], tau[H1_NU], tb[6] = {0, 0, 0, 0, 0, 0}, qacc[H1_NV];
+  double x[H1_NX], tau[H1_NU], qacc[H1_NV];
   for (int i = 0; i < H1_NX; ++i) x[i] = xg[i];
   const double qn = sqrt(x[3] * x[3] + x[4] * x[4] + x[5] * x[5] + x[6] * x[6]);
   const double qh[4] = {x[3] / qn, x[4] / qn, x[5] / qn, x[6] / qn};
@@ -91,21 +88,13 @@ __global__ void __launch_bounds__(256) k_lin_primal(DevState S, ProblemDev P, in
     double ui = ug[i];
     if (ui < H1_CTRLRANGE[i][0]) ui = H1_CTRLRANGE[i][0];
     if (ui > H1_CTRLRANGE[i][1]) ui = H1_CTRLRANGE[i][1];
-    tau[i] = ui - H1_DAMPING * x[H1_NQ + 6 + i] + ((role == 6 + i) ? 1.0 : 0.0);
+    tau[i] = ui - H1_DAMPING * x[H1_NQ + 6 + i];
   }
-  if (role < 6) tb[role] = 1.0;
-  double* Y = S.lin_Y + ((size_t)knot * (H1_NV + 1) + role) * H1_NV;
-  if (role == H1_NV) {
-    KnotDump* dump = reinterpret_cast<KnotDump*>(S.lin_dump + (size_t)knot * (sizeof(KnotDump) / sizeof(double)));
-    KnotDump local;
-    forward_dynamics<double, true>(qh, x + 7, x + H1_NQ, tau, H1_ARMATURE + h * H1_DAMPING, P.dyn.g, qacc, (const double*)nullptr, &local);
-    const double* src = reinterpret_cast<const double*>(&local);
-    double* dst = reinterpret_cast<double*>(dump);
-    for (int i = 0; i < (int)(sizeof(KnotDump) / sizeof(double)); ++i) dst[i] = src[i];
-  } else {
-    forward_dynamics<double, false>(qh, x + 7, x + H1_NQ, tau, H1_ARMATURE + h * H1_DAMPING, P.dyn.g, qacc, tb, (KnotDump*)nullptr);
-  }
-  for (int i = 0; i < H1_NV; ++i) Y[i] = qacc[i];
+  KnotDump local;
+  forward_dynamics<double, true>(qh, x + 7, x + H1_NQ, tau, H1_ARMATURE + h * H1_DAMPING, P.dyn.g, qacc, (const double*)nullptr, &local);
+  const double* src = reinterpret_cast<const double*>(&local);
+  double* dst = S.lin_dump + (size_t)knot * (sizeof(KnotDump) / sizeof(double));
+  for (int i = 0; i < (int)(sizeof(KnotDump) / sizeof(double)); ++i) dst[i] = src[i];
 }
 
 __global__ void __launch_bounds__(64) k_lin_tangent(DevState S, ProblemDev P, int mode) {
@@ -117,15 +106,14 @@ __global__ void __launch_bounds__(64) k_lin_tangent(DevState S, ProblemDev P, in
     const double* src = S.lin_dump + knot * (sizeof(KnotDump) / sizeof(double));
     double* dst = reinterpret_cast<double*>(&L.D);
     for (int i = lane; i < (int)(sizeof(KnotDump) / sizeof(double)); i += 64) dst[i] = src[i];
-    const double* Y = S.lin_Y + knot * (H1_NV + 1) * H1_NV;
-    for (int e = lane; e < H1_NV * H1_NV; e += 64) { const int c = e / H1_NV, r = e % H1_NV; L.Minv[r][c] = Y[c * H1_NV + r] - Y[H1_NV * H1_NV + r]; }
     if (lane < H1_NX) L.x[lane] = S.xbar[((size_t)b * (S.N + 1) + t) * H1_NX + lane];
     if (lane < H1_NU) L.u[lane] = S.ubar[((size_t)b * S.N + t) * H1_NU + lane];
     if (lane == 0) L.h = P.dyn.h;
   }
   __syncthreads();
   if (lane == 0) lin_prologue(L);
-  lin_tangent_lane(L, lane);
+  lin_minv_lane(L, lane);       // lanes 0..24: columns of Minv
+  lin_tangent_lane(L, lane);    // lanes 0..46: tangent generalized forces
   __syncthreads();
   lin_apply_minv_lane(L, lane);
   __syncthreads();
@@ -643,8 +631,7 @@ void launch_step(int count, const double* x, const double* u, const DynParams& d
 }
 void launch_linearize(const DevState& S, const ProblemDev& P, int mode, int jac_mode, double eps, hipStream_t st) {
   if (jac_mode == 0) {
-    const long threads = (long)S.B * S.N * LINP_ROLES;
-    hipLaunchKernelGGL(k_lin_primal, dim3(cdiv(threads, 256)), dim3(256), 0, st, S, P, mode);
+    hipLaunchKernelGGL(k_lin_primal, dim3(cdiv((long)S.B * S.N, 64)), dim3(64), 0, st, S, P, mode);
     hipLaunchKernelGGL(k_lin_tangent, dim3(S.N, S.B), dim3(64), 0, st, S, P, mode);
   } else {
     const long total = (long)S.B * S.N * (H1_NX + H1_NU);

@@ -34,12 +34,15 @@ int main() {
     for (int i = 0; i < H1_NU; ++i) L.u[i] = u[i];
     double y0[H1_NV];
     qacc_for(x, u, P, nullptr, nullptr, y0, &L.D);
+    static double Mref[H1_NV][H1_NV];
     for (int c = 0; c < H1_NV; ++c) {
       double tb[6] = {0,0,0,0,0,0}, dt[H1_NU] = {0}, y[H1_NV];
       if (c < 6) tb[c] = 1.0; else dt[c-6] = 1.0;
       qacc_for(x, u, P, tb, dt, y, nullptr);
-      for (int r = 0; r < H1_NV; ++r) L.Minv[r][c] = y[r] - y0[r];
+      for (int r = 0; r < H1_NV; ++r) Mref[r][c] = y[r] - y0[r];
     }
+    for (int lane = 0; lane < 64; ++lane) lin_minv_lane(L, lane);
+    { double em = 0; for (int r = 0; r < H1_NV; ++r) for (int c = 0; c < H1_NV; ++c) em = std::fmax(em, std::fabs(Mref[r][c] - L.Minv[r][c])); printf("  Minv sweep vs unit-force differences: %.3e\n", em); }
     lin_prologue(L);
     for (int lane = 0; lane < 64; ++lane) lin_tangent_lane(L, lane);
     for (int lane = 0; lane < 64; ++lane) lin_apply_minv_lane(L, lane);
