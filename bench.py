@@ -88,6 +88,7 @@ def main():
 
     import __graft_entry__ as ge
     pkg = ge._load_package()
+    from mpc_ilqr_mujoco_amd import sharding as sh
     from mpc_ilqr_mujoco_amd import solver as sv
     sc = pkg.scenario
     B, N, iters = args.batch, args.horizon, args.iters
@@ -105,12 +106,10 @@ def main():
     dev = torch.device("cuda", local_rank)
     x0_d = torch.from_numpy(x0).to(dev)
     ui_d = torch.from_numpy(ui).to(dev)
-    width = 19 + 1 + (19 * 51 if args.gather_gains else 0)
-    payload = torch.zeros(B, width, dtype=torch.float64, device=dev)   # [u0 | cost | (K0)] per rollout
+    payload = torch.zeros(B, sh.payload_width(args.gather_gains), dtype=torch.float64, device=dev)   # [u0 | cost | (K0)] per rollout
     u0_d = torch.zeros(B, 19, dtype=torch.float64, device=dev)
     c_d = torch.zeros(B, dtype=torch.float64, device=dev)
     K0_d = torch.zeros(B, 19 * 51, dtype=torch.float64, device=dev) if args.gather_gains else None
-    gathered = [torch.zeros_like(payload) for _ in range(world)] if (world > 1 and rank == 0) else None
     torch.cuda.synchronize()
 
     stage_ms, stage_n = {}, {}
@@ -120,12 +119,8 @@ def main():
         s.solve_async()
         s.synchronize()
         s.pack_first_knot_device(u0_d.data_ptr(), None if K0_d is None else K0_d.data_ptr(), c_d.data_ptr())
-        payload[:, :19] = u0_d
-        payload[:, 19] = c_d
-        if K0_d is not None:
-            payload[:, 20:] = K0_d
-        if world > 1:
-            dist.gather(payload, gathered, dst=0)   # the ONE collective of an MPC step (RCCL over xGMI)
+        sh.pack_payload(payload, u0_d, c_d, K0_d)
+        sh.gather_first_knot(payload, dst=0)        # the ONE collective of an MPC step (RCCL over xGMI)
         if timed:
             ms, n = s.stage_ms()
             for k in ms:
