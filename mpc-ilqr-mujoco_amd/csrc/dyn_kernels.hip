@@ -1,0 +1,211 @@
+// Dynamics-bound kernels on the register/LDS-resident ABA (h1_aba_reg.h): one rollout (or one
+// (rollout, alpha) pair, or one knot) per lane, 64 lanes per workgroup, 152 LDS slots per lane.
+//   k_rollout_r      iLQR::forwardRolloutNominal + computeTotalCost   reference src/ilqr/ilqr.cpp:119-124, 363-518
+//   k_line_search_r  iLQR::forwardPassLineSearch, 8 alphas at once    reference src/ilqr/ilqr.cpp:311-361
+//   k_lin_primal_r   primal quantities of every knot for k_lin_tangent
+//   k_step_r, k_last_step_r
+#include <hip/hip_runtime.h>
+
+#include "h1_cost_dev.h"
+#include "h1_linearize_dev.h"
+#include "h1_aba_reg.h"
+#include "ilqr_kernels.h"
+
+using namespace h1;
+
+namespace ilqr {
+
+#define DYN_LDS_BYTES (h1r::LDS_SLOTS * 64 * sizeof(double))
+
+struct ComReg { DEVFN void operator()(const double* x, double* com) const { h1r::com_mj(x, com); } };
+
+__device__ __forceinline__ bool sel(const DevState& S, int b, int mode) {
+  if (mode == MASK_ALL) return true;
+  if (mode == MASK_ACTIVE) return S.active[b] != 0;
+  return S.active[b] != 0 && S.need_retry[b] != 0;
+}
+
+__global__ void __launch_bounds__(64) k_rollout_r(DevState S, ProblemDev P, int mode, int do_roll, int count_iter, double* cost_out) {
+  extern __shared__ double lds[];
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= S.B || !sel(S, b, mode)) return;
+  const h1r::LaneLds L{lds, 64, (int)threadIdx.x};
+  const int N = S.N;
+  double* xb = S.xbar + (size_t)b * (N + 1) * H1_NX;
+  const double* ub = S.ubar + (size_t)b * N * H1_NU;
+  if (count_iter) S.iters[b] += 1;
+  double x[H1_NX], xn[H1_NX], u[H1_NU];
+  if (do_roll) {
+#pragma unroll
+    for (int i = 0; i < H1_NX; ++i) { x[i] = S.x0[(size_t)b * H1_NX + i]; xb[i] = x[i]; }
+  } else {
+#pragma unroll
+    for (int i = 0; i < H1_NX; ++i) x[i] = xb[i];
+  }
+  double c = 0.0;
+  for (int t = 0; t < N; ++t) {
+#pragma unroll
+    for (int i = 0; i < H1_NU; ++i) u[i] = ub[t * H1_NU + i];
+    c += knot_cost_t(P, b, t, x, u, ComReg());
+    if (do_roll) {
+      h1r::step(x, u, P.dyn.h, P.dyn.g, L, xn);
+#pragma unroll
+      for (int i = 0; i < H1_NX; ++i) { x[i] = xn[i]; xb[(t + 1) * H1_NX + i] = xn[i]; }
+    } else {
+#pragma unroll
+      for (int i = 0; i < H1_NX; ++i) x[i] = xb[(t + 1) * H1_NX + i];
+    }
+  }
+  c += knot_cost_t(P, b, N, x, (const double*)nullptr, ComReg());
+  cost_out[b] = c;
+}
+
+__global__ void __launch_bounds__(64) k_step_r(int count, const double* x, const double* u, DynParams dyn, double* xn) {
+  extern __shared__ double lds[];
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  const h1r::LaneLds L{lds, 64, (int)threadIdx.x};
+  double xl[H1_NX], ul[H1_NU], out[H1_NX];
+#pragma unroll
+  for (int k = 0; k < H1_NX; ++k) xl[k] = x[(size_t)i * H1_NX + k];
+#pragma unroll
+  for (int k = 0; k < H1_NU; ++k) ul[k] = u[(size_t)i * H1_NU + k];
+  h1r::step(xl, ul, dyn.h, dyn.g, L, out);
+#pragma unroll
+  for (int k = 0; k < H1_NX; ++k) xn[(size_t)i * H1_NX + k] = out[k];
+}
+
+__global__ void __launch_bounds__(64) k_last_step_r(DevState S, ProblemDev P) {
+  extern __shared__ double lds[];
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= S.B) return;
+  const h1r::LaneLds L{lds, 64, (int)threadIdx.x};
+  const int N = S.N;
+  double x[H1_NX], u[H1_NU], xn[H1_NX];
+#pragma unroll
+  for (int i = 0; i < H1_NX; ++i) x[i] = S.xbar[((size_t)b * (N + 1) + N - 1) * H1_NX + i];
+#pragma unroll
+  for (int i = 0; i < H1_NU; ++i) u[i] = S.ubar[((size_t)b * N + N - 1) * H1_NU + i];
+  h1r::step(x, u, P.dyn.h, P.dyn.g, L, xn);
+#pragma unroll
+  for (int i = 0; i < H1_NX; ++i) S.xbar[((size_t)b * (N + 1) + N) * H1_NX + i] = xn[i];
+}
+
+// thread per (rollout, alpha); candidates kept in HBM, k_control copies the accepted one
+__constant__ double ALPHAS_R[8] = {1.0, 0.8, 0.6, 0.4, 0.2, 0.1, 0.05, 0.01};
+__global__ void __launch_bounds__(64) k_line_search_r(DevState S, ProblemDev P, int mode) {
+  extern __shared__ double lds[];
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  const int b = gid >> 3, ai = gid & 7;
+  if (b >= S.B || !sel(S, b, mode)) return;
+  const h1r::LaneLds L{lds, 64, (int)threadIdx.x};
+  const int N = S.N, n = H1_NX, m = H1_NU;
+  const double alpha = ALPHAS_R[ai];
+  const double* xb = S.xbar + (size_t)b * (N + 1) * n;
+  const double* ub = S.ubar + (size_t)b * N * m;
+  const double* Kg = S.K + (size_t)b * N * m * n;
+  const double* kg = S.kff + (size_t)b * N * m;
+  double* xc = S.xcand + ((size_t)b * 8 + ai) * (N + 1) * n;
+  double* uc = S.ucand + ((size_t)b * 8 + ai) * N * m;
+  double x[H1_NX], xn[H1_NX], u[H1_NU], dx[H1_NX];
+#pragma unroll
+  for (int i = 0; i < H1_NX; ++i) { x[i] = S.x0[(size_t)b * n + i]; xc[i] = x[i]; }
+  double c = 0.0;
+  for (int t = 0; t < N; ++t) {
+#pragma unroll
+    for (int j = 0; j < H1_NX; ++j) dx[j] = x[j] - xb[t * n + j];
+#pragma unroll
+    for (int i = 0; i < H1_NU; ++i) {
+      double s = 0.0;
+      const double* Kr = Kg + ((size_t)t * m + i) * n;
+#pragma unroll
+      for (int j = 0; j < H1_NX; ++j) s += Kr[j] * dx[j];
+      u[i] = ub[t * m + i] + alpha * kg[t * m + i] + s;
+      uc[t * m + i] = u[i];
+    }
+    c += knot_cost_t(P, b, t, x, u, ComReg());
+    h1r::step(x, u, P.dyn.h, P.dyn.g, L, xn);
+#pragma unroll
+    for (int i = 0; i < H1_NX; ++i) { x[i] = xn[i]; xc[(t + 1) * n + i] = xn[i]; }
+  }
+  c += knot_cost_t(P, b, N, x, (const double*)nullptr, ComReg());
+  S.cand_cost[(size_t)b * 8 + ai] = c;
+}
+
+// primal dump of one knot per lane: see LinDumpG in h1_linearize_dev.h
+struct DumpSink {
+  double* g;   // this knot's LinDumpG as doubles
+  DEVFN void operator()(int i, const double* v, const double* a, double s, double c) const {
+    double* sc = g + LinDumpG_sc + 2 * i; sc[0] = s; sc[1] = c;
+    double* vv = g + LinDumpG_v + 6 * i; double* aa = g + LinDumpG_a + 6 * i;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) { vv[k] = v[k]; aa[k] = a[k]; }
+  }
+};
+__global__ void __launch_bounds__(64) k_lin_primal_r(DevState S, ProblemDev P, int mode) {
+  extern __shared__ double lds[];
+  const long knot = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (knot >= (long)S.B * S.N) return;
+  const int t = (int)(knot % S.N), b = (int)(knot / S.N);
+  if (!sel(S, b, mode)) return;
+  const h1r::LaneLds L{lds, 64, (int)threadIdx.x};
+  const double* xg = S.xbar + ((size_t)b * (S.N + 1) + t) * H1_NX;
+  const double* ug = S.ubar + ((size_t)b * S.N + t) * H1_NU;
+  const double h = P.dyn.h;
+  double x[H1_NX], tau[H1_NU], qacc[H1_NV];
+#pragma unroll
+  for (int i = 0; i < H1_NX; ++i) x[i] = xg[i];
+  const double qn = sqrt(x[3] * x[3] + x[4] * x[4] + x[5] * x[5] + x[6] * x[6]);
+  double R0[9]; h1r::quat_R(x[3] / qn, x[4] / qn, x[5] / qn, x[6] / qn, R0);
+#pragma unroll
+  for (int i = 0; i < H1_NU; ++i) {
+    double ui = ug[i];
+    if (ui < h1c::C_CTRLRANGE[i][0]) ui = h1c::C_CTRLRANGE[i][0];
+    if (ui > h1c::C_CTRLRANGE[i][1]) ui = h1c::C_CTRLRANGE[i][1];
+    tau[i] = ui - H1_DAMPING * x[H1_NQ + 6 + i];
+  }
+  double* g = S.lin_dump + (size_t)knot * LinDumpG_SIZE;
+  DumpSink sink{g};
+  double inv36[36], aL[3];
+  h1r::forward_dynamics(R0, x + 7, x + H1_NQ, tau, H1_ARMATURE + h * H1_DAMPING, P.dyn.g, L, qacc, sink, inv36, aL);
+#pragma unroll
+  for (int k = 0; k < 9; ++k) g[LinDumpG_R0 + k] = R0[k];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) g[LinDumpG_aL + k] = aL[k];
+#pragma unroll
+  for (int k = 0; k < H1_NV; ++k) g[LinDumpG_qacc + k] = qacc[k];
+#pragma unroll
+  for (int k = 0; k < 36; ++k) g[LinDumpG_IA0inv + k] = inv36[k];
+  for (int i = 1; i < H1_NB; ++i) {
+    for (int k = 0; k < 6; ++k) g[LinDumpG_U + 6 * i + k] = L[8 * (i - 1) + k];
+    g[LinDumpG_Dinv + i] = L[8 * (i - 1) + 6];
+  }
+}
+
+static inline int cdiv2(long a, long b) { return (int)((a + b - 1) / b); }
+int dyn_kernels_set_attr() {
+  int rc = 0;
+  rc |= hipFuncSetAttribute((const void*)k_rollout_r, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DYN_LDS_BYTES) != hipSuccess;
+  rc |= hipFuncSetAttribute((const void*)k_step_r, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DYN_LDS_BYTES) != hipSuccess;
+  rc |= hipFuncSetAttribute((const void*)k_last_step_r, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DYN_LDS_BYTES) != hipSuccess;
+  rc |= hipFuncSetAttribute((const void*)k_line_search_r, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DYN_LDS_BYTES) != hipSuccess;
+  rc |= hipFuncSetAttribute((const void*)k_lin_primal_r, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DYN_LDS_BYTES) != hipSuccess;
+  return rc;
+}
+void launch_rollout_r(const DevState& S, const ProblemDev& P, int mode, int do_roll, int count_iter, double* cost_out, hipStream_t st) {
+  hipLaunchKernelGGL(k_rollout_r, dim3(cdiv2(S.B, 64)), dim3(64), DYN_LDS_BYTES, st, S, P, mode, do_roll, count_iter, cost_out);
+}
+void launch_step_r(int count, const double* x, const double* u, const DynParams& dyn, double* xn, hipStream_t st) {
+  hipLaunchKernelGGL(k_step_r, dim3(cdiv2(count, 64)), dim3(64), DYN_LDS_BYTES, st, count, x, u, dyn, xn);
+}
+void launch_last_step_r(const DevState& S, const ProblemDev& P, hipStream_t st) {
+  hipLaunchKernelGGL(k_last_step_r, dim3(cdiv2(S.B, 64)), dim3(64), DYN_LDS_BYTES, st, S, P);
+}
+void launch_line_search_r(const DevState& S, const ProblemDev& P, int mode, hipStream_t st) {
+  hipLaunchKernelGGL(k_line_search_r, dim3(cdiv2((long)S.B * 8, 64)), dim3(64), DYN_LDS_BYTES, st, S, P, mode);
+}
+void launch_lin_primal_r(const DevState& S, const ProblemDev& P, int mode, hipStream_t st) {
+  hipLaunchKernelGGL(k_lin_primal_r, dim3(cdiv2((long)S.B * S.N, 64)), dim3(64), DYN_LDS_BYTES, st, S, P, mode);
+}
+
+}  // namespace ilqr

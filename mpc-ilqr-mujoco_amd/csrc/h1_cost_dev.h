@@ -71,7 +71,8 @@ DEVFN bool support_point(const ProblemDev& P, int b, int t, double* ps) {
   return false;
 }
 // one knot of computeTotalCost (ilqr.cpp:370-443 / 447-510) including its share of the penalties (512-515)
-__device__ inline double knot_cost(const ProblemDev& P, int b, int t, const double* x, const double* u /*null at t==N*/) {
+template <class ComFn>
+DEVFN double knot_cost_t(const ProblemDev& P, int b, int t, const double* x, const double* u /*null at t==N*/, ComFn com_fn) {
   const bool term = (t == P.N);
   const double* xr = P.x_ref + b * P.x_ref_stride + t * H1_NX;
   const double* Qd = term ? P.Qf : P.Q;
@@ -92,7 +93,7 @@ __device__ inline double knot_cost(const ProblemDev& P, int b, int t, const doub
   if (P.w_balance > 0.0) {
     double ps[2];
     if (support_point(P, b, t, ps)) {
-      double com[3]; com_mj(x, com);
+      double com[3]; com_fn(x, com);
       const double om = sqrt(com[2] / 9.81);
       const double rx = com[0] + x[H1_NQ] * om - ps[0], ry = com[1] + x[H1_NQ + 1] * om - ps[1];
       c += 0.5 * P.w_balance * (rx * rx + ry * ry);
@@ -102,6 +103,8 @@ __device__ inline double knot_cost(const ProblemDev& P, int b, int t, const doub
   if (!term) c += ctrl_penalty(P, u);
   return c;
 }
+struct ComLoop { DEVFN void operator()(const double* x, double* com) const { com_mj(x, com); } };
+__device__ inline double knot_cost(const ProblemDev& P, int b, int t, const double* x, const double* u) { return knot_cost_t(P, b, t, x, u, ComLoop()); }
 
 // ------------------------------------------------------------------ closed-form task-term quadratics
 DEVFN double dot3(const double* a, const double* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }

@@ -17,6 +17,10 @@
 
 namespace h1 {
 
+// global (HBM) layout of the primal dump of one knot, written by k_lin_primal_r (doubles)
+enum { LinDumpG_R0 = 0, LinDumpG_aL = 9, LinDumpG_qacc = 12, LinDumpG_sc = 37, LinDumpG_v = 77, LinDumpG_a = 197,
+       LinDumpG_U = 317, LinDumpG_Dinv = 437, LinDumpG_IA0inv = 457, LinDumpG_SIZE = 493 };
+
 #define LIN_NDIR 47   // tangent directions: phi(3) theta(19) v_lin(3) omega(3) thetadot(19)
 #define LIN_LD 48     // padded lane stride of the direction arrays
 
@@ -269,6 +273,36 @@ DEVFN void lin_apply_minv_lane(LinShared& L, int lane) {
   }
 #pragma unroll
   for (int r = 0; r < H1_NV; ++r) L.dT[r][lane] = out[r];
+}
+
+// cooperative load of the global dump into LDS (all lanes of one wave); rebuilds the joint rotations from
+// their sine/cosine and the accumulated inverse-dynamics forces F_i
+DEVFN void lin_load_dump(LinShared& L, const double* g, int lane) {
+  KnotDump& D = L.D;
+  for (int e = lane; e < 9; e += 64) D.R0[e] = g[LinDumpG_R0 + e];
+  for (int e = lane; e < 3; e += 64) D.aL[e] = g[LinDumpG_aL + e];
+  for (int e = lane; e < H1_NV; e += 64) D.qacc[e] = g[LinDumpG_qacc + e];
+  for (int e = lane; e < H1_NB * 6; e += 64) { (&D.v[0][0])[e] = g[LinDumpG_v + e]; (&D.a[0][0])[e] = g[LinDumpG_a + e]; (&D.U[0][0])[e] = g[LinDumpG_U + e]; }
+  for (int e = lane; e < H1_NB; e += 64) D.Dinv[e] = g[LinDumpG_Dinv + e];
+  for (int e = lane; e < 36; e += 64) D.IA0inv[e] = g[LinDumpG_IA0inv + e];
+  if (lane >= 1 && lane < H1_NB) {
+    const int i = lane, a = H1_AXIS[i], b = (a + 1) % 3, d = (a + 2) % 3;
+    const double s = g[LinDumpG_sc + 2 * i], c = g[LinDumpG_sc + 2 * i + 1];
+    for (int r = 0; r < 3; ++r) {
+      const double fa = H1_RFIX[i][r][a], fb = H1_RFIX[i][r][b], fd = H1_RFIX[i][r][d];
+      D.Rj[i][3 * r + a] = fa; D.Rj[i][3 * r + b] = fb * c + fd * s; D.Rj[i][3 * r + d] = fd * c - fb * s;
+    }
+  }
+  if (lane < H1_NB) {
+    const int i = lane;
+    double v[6], a[6], Iv[6], Ia[6], vIv[6];
+    for (int k = 0; k < 6; ++k) { v[k] = g[LinDumpG_v + 6 * i + k]; a[k] = g[LinDumpG_a + 6 * i + k]; }
+    inertia_mul(i, v, Iv); inertia_mul(i, a, Ia); crf(v, Iv, vIv);
+    for (int k = 0; k < 6; ++k) D.F[i][k] = Ia[k] + vIv[k];
+  }
+}
+DEVFN void lin_accumulate_forces(LinShared& L) {   // one lane: F_parent += X_i^T F_i, leaves first
+  for (int i = H1_NB - 1; i >= 1; --i) xf_force_acc(L.D.Rj[i], H1_POS[i], L.D.F[i], L.D.F[H1_PARENT[i]]);
 }
 
 // uniform integrator quantities (one lane)

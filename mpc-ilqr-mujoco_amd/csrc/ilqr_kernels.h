@@ -62,6 +62,12 @@ void launch_pack_first_knot(const DevState& S, double* u0, double* K0, hipStream
 int backward_needs_lds_attr();
 size_t backward_lds_bytes();
 size_t lin_dump_doubles();
+void launch_rollout_r(const DevState& S, const h1::ProblemDev& P, int mode, int do_roll, int count_iter, double* cost_out, hipStream_t st);
+void launch_step_r(int count, const double* x, const double* u, const h1::DynParams& dyn, double* xn, hipStream_t st);
+void launch_last_step_r(const DevState& S, const h1::ProblemDev& P, hipStream_t st);
+void launch_line_search_r(const DevState& S, const h1::ProblemDev& P, int mode, hipStream_t st);
+void launch_lin_primal_r(const DevState& S, const h1::ProblemDev& P, int mode, hipStream_t st);
+int dyn_kernels_set_attr();
 void launch_backward_mfma(const DevState& S, int mode, hipStream_t st);
 int backward_mfma_set_attr();
 size_t backward_mfma_lds_bytes();

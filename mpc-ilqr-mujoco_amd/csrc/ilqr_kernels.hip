@@ -72,44 +72,17 @@ __global__ void __launch_bounds__(64) k_step(int count, const double* x, const d
 //                  quantities (velocities, accelerations, forces, articulated-body U / D / pelvis inverse).
 //   k_lin_tangent: one wave per knot; lanes = columns of Minv (unit-force sweeps) and tangent directions
 //                  (tangent RNEA sweeps), then lanes = Jacobian columns.
-__global__ void __launch_bounds__(64) k_lin_primal(DevState S, ProblemDev P, int mode) {
-  const long knot = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (knot >= (long)S.B * S.N) return;
-  const int t = (int)(knot % S.N), b = (int)(knot / S.N);
-  if (!selected(S, b, mode)) return;
-  const double* xg = S.xbar + ((size_t)b * (S.N + 1) + t) * H1_NX;
-  const double* ug = S.ubar + ((size_t)b * S.N + t) * H1_NU;
-  const double h = P.dyn.h;
-  double x[H1_NX], tau[H1_NU], qacc[H1_NV];
-  for (int i = 0; i < H1_NX; ++i) x[i] = xg[i];
-  const double qn = sqrt(x[3] * x[3] + x[4] * x[4] + x[5] * x[5] + x[6] * x[6]);
-  const double qh[4] = {x[3] / qn, x[4] / qn, x[5] / qn, x[6] / qn};
-  for (int i = 0; i < H1_NU; ++i) {
-    double ui = ug[i];
-    if (ui < H1_CTRLRANGE[i][0]) ui = H1_CTRLRANGE[i][0];
-    if (ui > H1_CTRLRANGE[i][1]) ui = H1_CTRLRANGE[i][1];
-    tau[i] = ui - H1_DAMPING * x[H1_NQ + 6 + i];
-  }
-  KnotDump local;
-  forward_dynamics<double, true>(qh, x + 7, x + H1_NQ, tau, H1_ARMATURE + h * H1_DAMPING, P.dyn.g, qacc, (const double*)nullptr, &local);
-  const double* src = reinterpret_cast<const double*>(&local);
-  double* dst = S.lin_dump + (size_t)knot * (sizeof(KnotDump) / sizeof(double));
-  for (int i = 0; i < (int)(sizeof(KnotDump) / sizeof(double)); ++i) dst[i] = src[i];
-}
-
 __global__ void __launch_bounds__(64) k_lin_tangent(DevState S, ProblemDev P, int mode) {
   const int t = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
   if (!selected(S, b, mode)) return;
   __shared__ LinShared L;
   const size_t knot = (size_t)b * S.N + t;
-  {
-    const double* src = S.lin_dump + knot * (sizeof(KnotDump) / sizeof(double));
-    double* dst = reinterpret_cast<double*>(&L.D);
-    for (int i = lane; i < (int)(sizeof(KnotDump) / sizeof(double)); i += 64) dst[i] = src[i];
-    if (lane < H1_NX) L.x[lane] = S.xbar[((size_t)b * (S.N + 1) + t) * H1_NX + lane];
-    if (lane < H1_NU) L.u[lane] = S.ubar[((size_t)b * S.N + t) * H1_NU + lane];
-    if (lane == 0) L.h = P.dyn.h;
-  }
+  lin_load_dump(L, S.lin_dump + knot * LinDumpG_SIZE, lane);
+  if (lane < H1_NX) L.x[lane] = S.xbar[((size_t)b * (S.N + 1) + t) * H1_NX + lane];
+  if (lane < H1_NU) L.u[lane] = S.ubar[((size_t)b * S.N + t) * H1_NU + lane];
+  if (lane == 0) L.h = P.dyn.h;
+  __syncthreads();
+  if (lane == 0) lin_accumulate_forces(L);
   __syncthreads();
   if (lane == 0) lin_prologue(L);
   lin_minv_lane(L, lane);       // lanes 0..24: columns of Minv
@@ -623,22 +596,30 @@ __global__ void k_pack_first_knot(DevState S, double* u0, double* K0) {
 // ------------------------------------------------------------------ launchers
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+// ILQR_DYN=scalar selects the scratch-resident scalar ABA kernels (kept as an on-device cross-check)
+static int use_scalar_dyn() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("ILQR_DYN"); v = (e && e[0] == 's') ? 1 : 0; }
+  return v;
+}
 void launch_rollout(const DevState& S, const ProblemDev& P, int mode, int do_roll, int count_iter, double* cost_out, hipStream_t st) {
+  if (!use_scalar_dyn()) { launch_rollout_r(S, P, mode, do_roll, count_iter, cost_out, st); return; }
   hipLaunchKernelGGL(k_rollout, dim3(cdiv(S.B, 64)), dim3(64), 0, st, S, P, mode, do_roll, count_iter, cost_out);
 }
 void launch_step(int count, const double* x, const double* u, const DynParams& dyn, double* xn, hipStream_t st) {
+  if (!use_scalar_dyn()) { launch_step_r(count, x, u, dyn, xn, st); return; }
   hipLaunchKernelGGL(k_step, dim3(cdiv(count, 64)), dim3(64), 0, st, count, x, u, dyn, xn);
 }
 void launch_linearize(const DevState& S, const ProblemDev& P, int mode, int jac_mode, double eps, hipStream_t st) {
   if (jac_mode == 0) {
-    hipLaunchKernelGGL(k_lin_primal, dim3(cdiv((long)S.B * S.N, 64)), dim3(64), 0, st, S, P, mode);
+    launch_lin_primal_r(S, P, mode, st);
     hipLaunchKernelGGL(k_lin_tangent, dim3(S.N, S.B), dim3(64), 0, st, S, P, mode);
   } else {
     const long total = (long)S.B * S.N * (H1_NX + H1_NU);
     hipLaunchKernelGGL(k_linearize_fd, dim3(cdiv(total, 256)), dim3(256), 0, st, S, P, mode, eps);
   }
 }
-size_t lin_dump_doubles() { return sizeof(KnotDump) / sizeof(double); }
+size_t lin_dump_doubles() { return LinDumpG_SIZE; }
 void launch_cost_quadratics(const DevState& S, const ProblemDev& P, int mode, hipStream_t st) {
   hipLaunchKernelGGL(k_cost_quadratics, dim3(S.N + 1, S.B), dim3(64), 0, st, S, P, mode);
 }
@@ -653,6 +634,7 @@ void launch_backward(const DevState& S, int mode, hipStream_t st) {
   else launch_backward_mfma(S, mode, st);
 }
 void launch_line_search(const DevState& S, const ProblemDev& P, int mode, hipStream_t st) {
+  if (!use_scalar_dyn()) { launch_line_search_r(S, P, mode, st); return; }
   hipLaunchKernelGGL(k_line_search, dim3(cdiv((long)S.B * 8, 64)), dim3(64), 0, st, S, P, mode);
 }
 void launch_control(const DevState& S, int phase, int iter, double tol, int early_exit, hipStream_t st) {
@@ -660,11 +642,12 @@ void launch_control(const DevState& S, int phase, int iter, double tol, int earl
 }
 void launch_solve_begin(const DevState& S, hipStream_t st) { hipLaunchKernelGGL(k_solve_begin, dim3(cdiv(S.B, 64)), dim3(64), 0, st, S); }
 void launch_warm_shift(const DevState& S, const double* px, const double* pu, hipStream_t st) { hipLaunchKernelGGL(k_warm_shift, dim3(S.B), dim3(64), 0, st, S, px, pu); }
-void launch_last_step(const DevState& S, const ProblemDev& P, hipStream_t st) { hipLaunchKernelGGL(k_last_step, dim3(cdiv(S.B, 64)), dim3(64), 0, st, S, P); }
+void launch_last_step(const DevState& S, const ProblemDev& P, hipStream_t st) { if (!use_scalar_dyn()) { launch_last_step_r(S, P, st); return; } hipLaunchKernelGGL(k_last_step, dim3(cdiv(S.B, 64)), dim3(64), 0, st, S, P); }
 void launch_compute_control(const DevState& S, const double* x_meas, double* u_out, hipStream_t st) { hipLaunchKernelGGL(k_compute_control, dim3(S.B), dim3(64), 0, st, S, x_meas, u_out); }
 void launch_pack_first_knot(const DevState& S, double* u0, double* K0, hipStream_t st) { hipLaunchKernelGGL(k_pack_first_knot, dim3(S.B), dim3(64), 0, st, S, u0, K0); }
 int backward_needs_lds_attr() {
   if (backward_mfma_set_attr() != 0) return 1;
+  if (dyn_kernels_set_attr() != 0) return 1;
   return hipFuncSetAttribute((const void*)k_backward, hipFuncAttributeMaxDynamicSharedMemorySize, (int)backward_lds_bytes()) == hipSuccess ? 0 : 1;
 }
 

@@ -13,6 +13,7 @@ so the oracle never includes product code and vice versa.  Run only in the build
 """
 import math
 import os
+import re
 import sys
 import xml.etree.ElementTree as ET
 
@@ -215,6 +216,17 @@ def main():
     for dst in ("oracle/h1_model_data.h", "mpc-ilqr-mujoco_amd/csrc/h1_model_data.h"):
         with open(os.path.join(ROOT, dst), "w") as f:
             f.write(text)
+    # compile-time variant for the fully unrolled (register-resident) dynamics: every table is constexpr so
+    # that the unrolled code folds the constants (identity rotations, zero offsets, axis selection)
+    ce = text.replace("H1_MODEL_DATA_H", "H1_MODEL_CONSTEXPR_H")
+    ce = ce.replace("#ifndef H1_CONST\n#define H1_CONST static const\n#endif\n", "")
+    ce = ce.replace("H1_CONST ", "static constexpr ")
+    for name in ("H1_NB", "H1_NJ", "H1_NQ", "H1_NV", "H1_NX", "H1_NU", "H1_DAMPING", "H1_ARMATURE", "H1_EE_LEFT", "H1_EE_RIGHT"):
+        ce = re.sub(r"#define %s [^\n]*\n" % name, "", ce)
+    ce = re.sub(r"\bH1U?_([A-Z]+)\b", lambda m: ("CU_" if m.group(0).startswith("H1U_") else "C_") + m.group(1), ce)
+    ce = ce.replace("#ifndef C_MODEL", "#ifndef H1_MODEL_CONSTEXPR_H").replace("#define C_MODEL", "#define H1_MODEL_CONSTEXPR_H")
+    with open(os.path.join(ROOT, "mpc-ilqr-mujoco_amd/csrc/h1_model_constexpr.h"), "w") as f:
+        f.write("namespace h1c {\n" + ce.replace("#ifndef H1_MODEL_CONSTEXPR_H\n#define H1_MODEL_CONSTEXPR_H\n", "").replace("#endif\n", "") + "}  // namespace h1c\n")
     print("total mass mjcf %.6f urdf %.6f" % (mass.sum(), u_mass.sum()))
     print("wrote headers; bodies:", [b["name"] for b in bodies])
 
