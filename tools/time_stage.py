@@ -1,0 +1,36 @@
+#!/usr/bin/env python3
+"""Time one stage of the HIP path at the bench size (B=4096, N=25): python tools/time_stage.py backward [reps]"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import __graft_entry__ as ge
+pkg = ge._load_package()
+from mpc_ilqr_mujoco_amd import solver as sv
+sc = pkg.scenario
+stage = sys.argv[1] if len(sys.argv) > 1 else "backward"
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+B, N = 4096, 25
+prob = sc.make_problem(sv.reference_kinematics, N=N)
+ug = sv.gravity_compensation(sc.standing_state(), prob["gravity"])
+x0, ui = sc.synthetic_batch(B, N, 0, ug)
+s = sv.BatchedILQR(B, N=N)
+s.set_problem(prob)
+s.initialize(x0, ui)
+s.stage_linearize(); s.stage_cost_quadratics(); s.stage_backward_pass()
+fn = {"backward": s.stage_backward_pass, "linearize": s.stage_linearize, "quadratics": s.stage_cost_quadratics,
+      "rollout": s.stage_rollout, "line_search": s.stage_line_search}[stage]
+fn()
+t0 = time.perf_counter()
+for _ in range(reps):
+    fn()
+dt = (time.perf_counter() - t0) / reps
+print("%s: %.3f ms per call (host-timed, includes sync)  K checksum %.9e" % (stage, dt * 1e3, float(np.abs(s.gains_K()[::97]).sum())))
+if os.environ.get("ILQR_STAMPS"):
+    names = ["regs<-staging", "sync", "P1", "P2", "Qx/Qu", "sync", "P3", "P4+P5", "sync", "chol+Linv (wave0)", "sync", "P6a+P6b", "sync", "P7+Vx", "sync", "-"]
+    st = s.cost()[:16]
+    tot = st.sum()
+    for nme, v in zip(names, st):
+        print("  %-24s %10.0f cycles  %5.1f %%" % (nme, v / 25, 100 * v / tot))
+    print("  per knot total %.0f cycles (clock64 ticks)" % (tot / 25))
+s.close()
