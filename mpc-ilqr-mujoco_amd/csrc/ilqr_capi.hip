@@ -19,6 +19,8 @@ using ilqr::DevState;
 struct ilqr_hip_ctx {
   int device = 0, B = 0, N = 0;
   hipStream_t stream = nullptr;
+  hipStream_t stream2 = nullptr;          // cost quadratics run here, concurrently with the linearisation
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   DevState S{};
   h1::ProblemDev P{};
   // reference sets on the device
@@ -64,9 +66,9 @@ static hipEvent_t next_event(ilqr_hip_ctx* c) {
   return c->pool[c->pool_next++];
 }
 struct StageTimer {
-  ilqr_hip_ctx* c; int stage; hipEvent_t a{}, b{};
-  StageTimer(ilqr_hip_ctx* c_, int s) : c(c_), stage(s) { if (c->profiling) { a = next_event(c); b = next_event(c); hipEventRecord(a, c->stream); } }
-  ~StageTimer() { if (c->profiling) { hipEventRecord(b, c->stream); c->spans.push_back({stage, a, b}); } }
+  ilqr_hip_ctx* c; int stage; hipStream_t st; hipEvent_t a{}, b{};
+  StageTimer(ilqr_hip_ctx* c_, int s, hipStream_t st_ = nullptr) : c(c_), stage(s), st(st_ ? st_ : c_->stream) { if (c->profiling) { a = next_event(c); b = next_event(c); hipEventRecord(a, st); } }
+  ~StageTimer() { if (c->profiling) { hipEventRecord(b, st); c->spans.push_back({stage, a, b}); } }
 };
 
 extern "C" {
@@ -78,7 +80,8 @@ int ilqr_hip_create(ilqr_hip_ctx** out, int device, int batch, int horizon, doub
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return ILQR_ERR_NO_DEVICE;
   ilqr_hip_ctx* c = new ilqr_hip_ctx();
   c->device = device; c->B = batch; c->N = horizon;
-  if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&c->stream) != hipSuccess) { delete c; return ILQR_ERR_NO_DEVICE; }
+  if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&c->stream) != hipSuccess || hipStreamCreate(&c->stream2) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) { delete c; return ILQR_ERR_NO_DEVICE; }
   const size_t B = batch, N = horizon, n = ILQR_NX, m = ILQR_NU;
   DevState& S = c->S;
   S.B = batch; S.N = horizon; S.max_iter = c->max_iter;
@@ -128,6 +131,9 @@ int ilqr_hip_destroy(ilqr_hip_ctx* c) {
                   c->d_prevx, c->d_prevu, c->d_u0, c->d_K0, c->d_cost_tmp, c->d_xref, c->d_uref, c->d_comref, c->d_eeref, c->d_comvelref, c->d_stance};
   for (void* p : ptrs) if (p) hipFree(p);
   for (hipEvent_t e : c->pool) hipEventDestroy(e);
+  if (c->ev_fork) hipEventDestroy(c->ev_fork);
+  if (c->ev_join) hipEventDestroy(c->ev_join);
+  if (c->stream2) hipStreamDestroy(c->stream2);
   if (c->stream) hipStreamDestroy(c->stream);
   delete c;
   return ILQR_OK;
@@ -292,8 +298,13 @@ int ilqr_hip_solve_async(ilqr_hip_ctx* c) {
   { StageTimer T(c, 0); ilqr::launch_rollout(S, P, ilqr::MASK_ALL, 0, 0, S.Jbase, st); ilqr::launch_solve_begin(S, st); }  // ilqr.cpp:540
   for (int iter = 0; iter < c->max_iter; ++iter) {
     { StageTimer T(c, 0); ilqr::launch_rollout(S, P, ilqr::MASK_ACTIVE, 1, 1, S.Jbase, st); }                 // :551,563
-    { StageTimer T(c, 1); ilqr::launch_linearize(S, P, ilqr::MASK_ACTIVE, c->jac_mode, c->fd_eps, st); }      // :576
-    { StageTimer T(c, 2); ilqr::launch_cost_quadratics(S, P, ilqr::MASK_ACTIVE, st); }                        // :588
+    // linearisation (:576) and cost quadratics (:588) only depend on the rollout: run them concurrently
+    HIPCHK(c, hipEventRecord(c->ev_fork, st));
+    HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
+    { StageTimer T(c, 2, c->stream2); ilqr::launch_cost_quadratics(S, P, ilqr::MASK_ACTIVE, c->stream2); }
+    HIPCHK(c, hipEventRecord(c->ev_join, c->stream2));
+    { StageTimer T(c, 1); ilqr::launch_linearize(S, P, ilqr::MASK_ACTIVE, c->jac_mode, c->fd_eps, st); }
+    HIPCHK(c, hipStreamWaitEvent(st, c->ev_join, 0));
     { StageTimer T(c, 3); ilqr::launch_backward(S, ilqr::MASK_ACTIVE, st); }                                  // :601
     { StageTimer T(c, 4); ilqr::launch_line_search(S, P, ilqr::MASK_ACTIVE, st); }                            // :616
     { StageTimer T(c, 5); ilqr::launch_control(S, 0, iter, c->tol, c->early_exit, st); }                      // :619-620,645-655

@@ -22,6 +22,14 @@ using namespace h1;
 
 namespace ilqr {
 
+// waves per SIMD requested from the register allocator (measured on MI355X: 2 -> 7.4 ms, 1 -> 12.3 ms per launch)
+#ifndef QUAD_WAVES
+#define QUAD_WAVES 2
+#endif
+#ifndef LINT_WAVES
+#define LINT_WAVES 1
+#endif
+
 __device__ __forceinline__ bool selected(const DevState& S, int b, int mode) {
   if (mode == MASK_ALL) return true;
   if (mode == MASK_ACTIVE) return S.active[b] != 0;
@@ -72,7 +80,7 @@ __global__ void __launch_bounds__(64) k_step(int count, const double* x, const d
 //                  quantities (velocities, accelerations, forces, articulated-body U / D / pelvis inverse).
 //   k_lin_tangent: one wave per knot; lanes = columns of Minv (unit-force sweeps) and tangent directions
 //                  (tangent RNEA sweeps), then lanes = Jacobian columns.
-__global__ void __launch_bounds__(64) k_lin_tangent(DevState S, ProblemDev P, int mode) {
+__global__ void __launch_bounds__(64, LINT_WAVES) k_lin_tangent(DevState S, ProblemDev P, int mode) {
   const int t = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
   if (!selected(S, b, mode)) return;
   __shared__ LinShared L;
@@ -133,7 +141,7 @@ __global__ void __launch_bounds__(256) k_linearize_fd(DevState S, ProblemDev P, 
 
 // ------------------------------------------------------------------ K3: cost quadratics
 // one wave per (knot, rollout).
-__global__ void __launch_bounds__(64) k_cost_quadratics(DevState S, ProblemDev P, int mode) {
+__global__ void __launch_bounds__(64, QUAD_WAVES) k_cost_quadratics(DevState S, ProblemDev P, int mode) {
   const int t = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
   if (!selected(S, b, mode)) return;
   const int N = S.N;
