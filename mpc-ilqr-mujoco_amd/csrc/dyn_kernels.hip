@@ -34,7 +34,7 @@ __global__ void __launch_bounds__(64) k_rollout_r(DevState S, ProblemDev P, int 
   double* xb = S.xbar + (size_t)b * (N + 1) * H1_NX;
   const double* ub = S.ubar + (size_t)b * N * H1_NU;
   if (count_iter) S.iters[b] += 1;
-  double x[H1_NX], xn[H1_NX], u[H1_NU];
+  double x[H1_NX], u[H1_NU];
   if (do_roll) {
 #pragma unroll
     for (int i = 0; i < H1_NX; ++i) { x[i] = S.x0[(size_t)b * H1_NX + i]; xb[i] = x[i]; }
@@ -48,9 +48,9 @@ __global__ void __launch_bounds__(64) k_rollout_r(DevState S, ProblemDev P, int 
     for (int i = 0; i < H1_NU; ++i) u[i] = ub[t * H1_NU + i];
     c += knot_cost_t(P, b, t, x, u, ComReg());
     if (do_roll) {
-      h1r::step(x, u, P.dyn.h, P.dyn.g, L, xn);
+      h1r::step(x, u, P.dyn.h, P.dyn.g, L, x);
 #pragma unroll
-      for (int i = 0; i < H1_NX; ++i) { x[i] = xn[i]; xb[(t + 1) * H1_NX + i] = xn[i]; }
+      for (int i = 0; i < H1_NX; ++i) xb[(t + 1) * H1_NX + i] = x[i];
     } else {
 #pragma unroll
       for (int i = 0; i < H1_NX; ++i) x[i] = xb[(t + 1) * H1_NX + i];
@@ -107,26 +107,25 @@ __global__ void __launch_bounds__(64) k_line_search_r(DevState S, ProblemDev P, 
   const double* kg = S.kff + (size_t)b * N * m;
   double* xc = S.xcand + ((size_t)b * 8 + ai) * (N + 1) * n;
   double* uc = S.ucand + ((size_t)b * 8 + ai) * N * m;
-  double x[H1_NX], xn[H1_NX], u[H1_NU], dx[H1_NX];
+  // register budget: only x[51] and u[19] stay live across the dynamics step (no dx / x_next copies)
+  double x[H1_NX], u[H1_NU];
 #pragma unroll
   for (int i = 0; i < H1_NX; ++i) { x[i] = S.x0[(size_t)b * n + i]; xc[i] = x[i]; }
   double c = 0.0;
   for (int t = 0; t < N; ++t) {
-#pragma unroll
-    for (int j = 0; j < H1_NX; ++j) dx[j] = x[j] - xb[t * n + j];
-#pragma unroll
-    for (int i = 0; i < H1_NU; ++i) {
+    const double* xbt = xb + t * n;
+    for (int i = 0; i < H1_NU; ++i) {   // u = ubar + alpha k + K (x - xbar)   (ilqr.cpp:332-333)
       double s = 0.0;
       const double* Kr = Kg + ((size_t)t * m + i) * n;
 #pragma unroll
-      for (int j = 0; j < H1_NX; ++j) s += Kr[j] * dx[j];
+      for (int j = 0; j < H1_NX; ++j) s += Kr[j] * (x[j] - xbt[j]);
       u[i] = ub[t * m + i] + alpha * kg[t * m + i] + s;
       uc[t * m + i] = u[i];
     }
     c += knot_cost_t(P, b, t, x, u, ComReg());
-    h1r::step(x, u, P.dyn.h, P.dyn.g, L, xn);
+    h1r::step(x, u, P.dyn.h, P.dyn.g, L, x);       // in place: every read of x precedes the integrator's writes
 #pragma unroll
-    for (int i = 0; i < H1_NX; ++i) { x[i] = xn[i]; xc[(t + 1) * n + i] = xn[i]; }
+    for (int i = 0; i < H1_NX; ++i) xc[(t + 1) * n + i] = x[i];
   }
   c += knot_cost_t(P, b, N, x, (const double*)nullptr, ComReg());
   S.cand_cost[(size_t)b * 8 + ai] = c;
