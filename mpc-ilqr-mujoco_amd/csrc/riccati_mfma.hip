@@ -2,21 +2,27 @@
 //
 // Replaces iLQR::backwardPass (reference src/ilqr/ilqr.cpp:250-309).  All 51x51 / 51x19 contractions AND the
 // gain solves of a knot run on v_mfma_f64_16x16x4_f64 (16x16 output tile, K step 4; C/D layout: lane l holds
-// D[(l>>4) + 4r][l & 15], r = 0..3; A operand lane l = A[l & 15][l >> 4]; B operand lane l = B[l >> 4][l & 15]):
-//   P1  W   = Vxx A          wave w -> column tile w of W           (A_t column tile held in registers)
-//   P2  G   = Vxx B          wave w -> row tile w of G              (B_t held in registers)
-//   P3  Qxx = lxx + A^T W    wave w -> row tile w  (A^T operand == the registers of P1)
-//   P4  Qxu = A^T G          wave w -> row tile w  (row 51 of the Qxu buffer carries Qu, so k comes with K)
-//   P5  Quu = luu + B^T G + lambda I   (2x2 tiles over the 4 waves)
-//   --  wave 0: Cholesky Quu = L L^T and Linv = L^-1 in registers (row / column per lane, v_readlane
-//       broadcasts; LLT failure -> +1e-4 I once, ilqr.cpp:278-281);  waves 1-3 meanwhile copy the next knot's
-//       A, B, lxx from HBM into LDS staging, so the operand fetch never sits on the critical path
-//   P6  Y = Linv Qxu^T,  [K | k] = -Linv^T Y     (wave w -> column tile w)
-//   P7  Vxx = Qxx + 1/2 (Qxu K + K^T Qxu^T),  Vx = Qx + Qxu k
-// The value-function update uses K^T Quu K + K^T Qxu^T = K^T (Quu K + Qxu^T) = 0 for the solved gains, i.e.
-// Vxx = Qxx + Qxu K and Vx = Qx + Qxu k -- algebraically identical to the reference's long form
-// (ilqr.cpp:294-307), differing only in rounding (covered by the parity tests); the symmetrisation
-// 0.5 (V + V^T) of ilqr.cpp:307 is applied to the Qxu K term by running the product in both operand orders.
+// D[(l>>4) + 4r][l & 15], r = 0..3; A operand lane l = A[l & 15][l >> 4]; B operand lane l = B[l >> 4][l & 15]).
+// The C/D layout of one product IS the B-operand layout of the next one (register r of row tile I is k-step
+// 4I + r), so chained products never leave the registers:
+//   P1  W[:, w]   = Vxx A[:, w]            wave w -> column tile w, kept in registers
+//   P2  G[w, :]   = Vxx[w, :] B            wave w -> row tile w, to LDS
+//   P3  Qxx[:, w] = lxx + A^T W[:, w]      B operand = the accumulators of P1; result stays in registers until P7
+//   P4  Qux[:, w] = G^T A[:, w]            column tile w in registers (column 51 is replaced by Qu)
+//   P5  Quu       = luu + B^T G + lambda I (2x2 tiles over the 4 waves), to LDS
+//   --  wave 0: right-looking Cholesky Quu = L L^T fused with the forward substitution for Linv = L^-1
+//       (row of Quu / column of Linv per lane, one v_readlane broadcast of L[k][j] feeds both updates;
+//       LLT failure -> +1e-4 I once, ilqr.cpp:278-281);  waves 1-3 meanwhile copy the next knot's A, B, lx, lu, luu
+//       from HBM into LDS, so the operand fetch never sits on the critical path
+//   P6a Y[:, w]   = Linv [Qux | Qu][:, w]  B operand = the accumulators of P4; to LDS (A operand of P7)
+//   P6b [K | k][:, w] = -Linv^T Y[:, w]    B operand = the accumulators of P6a; straight to HBM
+//   P7  Vxx[:, w] = Qxx[:, w] - Y^T Y[:, w]   accumulates onto the registers of P3
+// Vectors ride in the padding: row 51 of the Vxx buffer holds Vx, so row 51 of W / G is A^T Vx / B^T Vx, row 51 of
+// the Qxx accumulators is Qx = lx + A^T Vx, column 51 of Qux is Qu, column 51 of Y gives k, and row 51 of P7 is
+// Vx = Qx - Y^T y_u.  The value-function update uses K = -Quu^-1 Qux with Quu = L L^T (the regularised Quu,
+// as in the reference, which adds lambda in place): K^T Quu K + K^T Qux + Qxu K = -Qxu Quu^-1 Qux = -Y^T Y and
+// K^T Quu k + K^T Qu + Qxu k = -Y^T y_u -- algebraically identical to the reference's long form
+// (ilqr.cpp:294-307), symmetric by construction (ilqr.cpp:307), differing only in rounding (parity tests).
 // LDS operands use leading dimensions chosen so that the MFMA operand reads are bank-conflict free:
 // 54 / 22 for [i][k]-pattern reads, 80 / 48 for [k][j]-pattern reads of 64 / 32 columns.
 #include <hip/hip_runtime.h>
@@ -37,27 +43,22 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 #define RN 51
 #define RM 19
 #define KS 13          // k-steps of 4 over the padded inner dimension 52
-#define LDV 54         // Vxx / Qxx rows [i][k]
-#define LDW 80         // W rows [k][j], 64 columns
-#define LDG 48         // G rows [k][j2], 32 columns
-#define LDQ 22         // Qxu rows [i][a]
-#define LDK 80         // K / Y rows [a][j]
+#define LDV 54         // Vxx rows [i][k]
+#define LDA 54         // A^T rows [j][k]
+#define LDG 48         // G rows [k][c], 32 columns
+#define LDK 80         // Y rows [a][j], 64 columns
 #define LDU 20         // Quu rows
 #define LDLA 22        // Linv rows read as [i][k]
 #define LDLB 48        // Linv rows read as [k][i]
 
 struct RiccatiLds {
-  double Vxx[52 * LDV];   // rows 0..50 valid, row 51 and columns 51.. zero
-  double W[52 * LDW];     // W = Vxx A; afterwards staging of the next knot's A_t (51 x 51, dense)
-  double G[52 * LDG];     // G = Vxx B; afterwards staging of the next knot's B_t (51 x 19, dense)
-  double Qxu[64 * LDQ];   // rows 0..50 = Qxu, row 51 = Qu
-  double Kt[20 * LDK];    // K[a][j], column 51 = k
-  double Y[20 * LDK];     // Linv Qxu^T
-  double lxxS[RN * RN + 7];
+  double Vxx[52 * LDV];   // rows/cols 0..50 = Vxx, row 51 = Vx, column 51 = don't care (finite)
+  double At[52 * LDA];    // At[j][k] = A_t[k][j]; row 51 and column 51 stay zero
+  double G[52 * LDG];     // staging of B_t ([k][c], dense rows re-pitched), then G = Vxx B with row 51 = B^T Vx
+  double Y[20 * LDK];     // Linv [Qux | Qu]; scratch of the indefinite fallback
   double LinvA[32 * LDLA];
   double LinvB[20 * LDLB];
   double Quu[RM * LDU];
-  double Vx[64], Qx[64], Qu[32], kt[32];
   double lxS[64], luS[32], luuS[32];   // staged lx_t, lu_t, luu_t
   int flags[4];
 };
@@ -85,22 +86,25 @@ __global__ void __launch_bounds__(256) k_backward_mfma(DevState S, int mode) {
   for (int e = tid; e < (int)(sizeof(RiccatiLds) / sizeof(double)); e += 256) smem[e] = 0.0;
   __syncthreads();
   for (int e = tid; e < n * n; e += 256) L.Vxx[(e / n) * LDV + (e % n)] = lxxg[(size_t)N * n * n + e];
-  if (tid < n) L.Vx[tid] = lxg[N * n + tid];
-  // HBM -> LDS staging of A_t, B_t, lxx_t, lx_t, lu_t, luu_t; 8 loads in flight per thread
-  // (dense rows of `width` doubles are re-pitched to `ld` so that the operand reads are conflict free)
-  auto copy_pipelined = [&](double* dst, const double* src, int count, int width, int ld, int first, int nthreads) {
-    for (int e0 = first; e0 < count; e0 += 8 * nthreads) {
+  if (tid < n) L.Vxx[51 * LDV + tid] = lxg[N * n + tid];
+  // HBM -> LDS staging of A_t (transposed), B_t, lx_t, lu_t, luu_t; 8 loads in flight per thread
+  auto stage_knot = [&](int t, int first, int nthreads) {
+    const double* Ag = S.A + ((size_t)b * N + t) * n * n;
+    for (int e0 = first; e0 < n * n; e0 += 8 * nthreads) {
       double v[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) { const int e = e0 + u * nthreads; v[u] = (e < count) ? src[e] : 0.0; }
+      for (int u = 0; u < 8; ++u) { const int e = e0 + u * nthreads; v[u] = (e < n * n) ? Ag[e] : 0.0; }
 #pragma unroll
-      for (int u = 0; u < 8; ++u) { const int e = e0 + u * nthreads; if (e < count) dst[(e / width) * ld + (e % width)] = v[u]; }
+      for (int u = 0; u < 8; ++u) { const int e = e0 + u * nthreads; if (e < n * n) L.At[(e % n) * LDA + (e / n)] = v[u]; }
     }
-  };
-  auto stage_knot = [&](int t, int first, int nthreads) {
-    copy_pipelined(L.W, S.A + ((size_t)b * N + t) * n * n, n * n, n, LDW, first, nthreads);
-    copy_pipelined(L.lxxS, lxxg + (size_t)t * n * n, n * n, n, n, first, nthreads);
-    copy_pipelined(L.G, S.Bm + ((size_t)b * N + t) * n * m, n * m, m, LDG, first, nthreads);
+    const double* Bg = S.Bm + ((size_t)b * N + t) * n * m;
+    for (int e0 = first; e0 < n * m; e0 += 8 * nthreads) {
+      double v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { const int e = e0 + u * nthreads; v[u] = (e < n * m) ? Bg[e] : 0.0; }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { const int e = e0 + u * nthreads; if (e < n * m) L.G[(e / m) * LDG + (e % m)] = v[u]; }
+    }
     if (first < n) L.lxS[first] = lxg[t * n + first];
     else if (first >= 64 && first < 64 + m) { L.luS[first - 64] = S.lu[((size_t)b * N + t) * m + first - 64]; L.luuS[first - 64] = S.luu[((size_t)b * N + t) * m + first - 64]; }
   };
@@ -110,44 +114,49 @@ __global__ void __launch_bounds__(256) k_backward_mfma(DevState S, int mode) {
 #ifdef RIC_STAMP
   long long ph[16] = {0}; long long tlast = clock64();
 #endif
+  const int jcol = 16 * w + lr;                  // the column this lane owns in every column-tile product
+  const int jrow = jcol > 51 ? 51 : jcol;        // clamped: row 51 of At is zero
   for (int t = N - 1; t >= 0; --t) {
-    // ---- operands from the LDS staging into registers
-    double areg[KS];          // A[4s + lk][16w + lr]
-    double breg[2][KS];       // B[4s + lk][16j2 + lr]
+    // ---- lxx_t straight from HBM into the accumulators of P3 (consumed after P1/P2, latency hidden)
+    v4d qxx[4];
     {
-      const int col = 16 * w + lr;
-#pragma unroll
-      for (int s = 0; s < KS; ++s) { const int k = 4 * s + lk; areg[s] = (k < n && col < n) ? L.W[k * LDW + col] : 0.0; }
-#pragma unroll
-      for (int j2 = 0; j2 < 2; ++j2) {
-        const int c2 = 16 * j2 + lr;
-#pragma unroll
-        for (int s = 0; s < KS; ++s) { const int k = 4 * s + lk; breg[j2][s] = (k < n && c2 < m) ? L.G[k * LDG + c2] : 0.0; }
-      }
-    }
-    STAMP(0)
-    __syncthreads();   // staging consumed: W and G may be overwritten
-    STAMP(1)
-    // ---- P1: W[:, tile w] = Vxx A[:, tile w]
-    {
-      v4d acc[4];
-#pragma unroll
-      for (int I = 0; I < 4; ++I) acc[I] = (v4d){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-      for (int s = 0; s < KS; ++s) {
-#pragma unroll
-        for (int I = 0; I < 4; ++I) {
-          int row = 16 * I + lr; row = row > 51 ? 51 : row;
-          acc[I] = mfma(L.Vxx[row * LDV + 4 * s + lk], areg[s], acc[I]);
-        }
-      }
+      const double* lg = lxxg + (size_t)t * n * n;
 #pragma unroll
       for (int I = 0; I < 4; ++I)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { const int row = 16 * I + lk + 4 * r; if (row < 52) L.W[row * LDW + 16 * w + lr] = acc[I][r]; }
+        for (int r = 0; r < 4; ++r) {
+          const int row = 16 * I + lk + 4 * r;
+          qxx[I][r] = (row < n && jcol < n) ? lg[row * n + jcol] : 0.0;
+        }
+    }
+    // ---- operands from the LDS staging into registers
+    double areg[KS];          // A[4s + lk][16w + lr]
+    double breg[2][KS];       // B[4s + lk][16j2 + lr]
+#pragma unroll
+    for (int s = 0; s < KS; ++s) areg[s] = L.At[jrow * LDA + 4 * s + lk];
+#pragma unroll
+    for (int j2 = 0; j2 < 2; ++j2) {
+      const int c2 = 16 * j2 + lr;
+#pragma unroll
+      for (int s = 0; s < KS; ++s) { const int k = 4 * s + lk; breg[j2][s] = (k < n && c2 < m) ? L.G[k * LDG + c2] : 0.0; }
+    }
+    STAMP(0)
+    __syncthreads();   // B staging consumed: G may be overwritten
+    STAMP(1)
+    // ---- P1: W[:, tile w] = Vxx A[:, tile w]   (row 51 of the Vxx buffer is Vx -> row 51 of W is A^T Vx)
+    v4d wacc[4];
+#pragma unroll
+    for (int I = 0; I < 4; ++I) wacc[I] = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+#pragma unroll
+      for (int I = 0; I < 4; ++I) {
+        int row = 16 * I + lr; row = row > 51 ? 51 : row;
+        wacc[I] = mfma(L.Vxx[row * LDV + 4 * s + lk], areg[s], wacc[I]);
+      }
     }
     STAMP(2)
-    // ---- P2: G[tile w, :] = Vxx[tile w, :] B
+    // ---- P2: G[tile w, :] = Vxx[tile w, :] B   (row 51: B^T Vx)
     {
       v4d acc[2] = {(v4d){0.0, 0.0, 0.0, 0.0}, (v4d){0.0, 0.0, 0.0, 0.0}};
       int row = 16 * w + lr; row = row > 51 ? 51 : row;
@@ -163,66 +172,40 @@ __global__ void __launch_bounds__(256) k_backward_mfma(DevState S, int mode) {
         for (int r = 0; r < 4; ++r) { const int rr = 16 * w + lk + 4 * r; if (rr < 52) L.G[rr * LDG + 16 * j2 + lr] = acc[j2][r]; }
     }
     STAMP(3)
-    // Qx = lx + A^T Vx (row tile w), Qu = lu + B^T Vx (waves 0, 1) -> also row 51 of the Qxu buffer
-    {
-      double s1 = 0.0;
+    // ---- P3: Qxx[:, tile w] = lxx + A^T W[:, tile w]; row 51 <- Qx = lx + A^T Vx (row 51 of At is zero)
+    if (lk == 3) qxx[3][0] = ((jcol < n) ? L.lxS[jcol] : 0.0) + wacc[3][0];
 #pragma unroll
-      for (int s = 0; s < KS; ++s) s1 += areg[s] * L.Vx[4 * s + lk];
-      s1 += __shfl_xor(s1, 16); s1 += __shfl_xor(s1, 32);
-      const int i = 16 * w + lr;
-      if (lk == 0 && i < n) L.Qx[i] = L.lxS[i] + s1;
-      if (w < 2) {
-        double s2 = 0.0;
+    for (int s = 0; s < KS; ++s) {
+      const double wb = wacc[s >> 2][s & 3];
 #pragma unroll
-        for (int s = 0; s < KS; ++s) s2 += breg[w][s] * L.Vx[4 * s + lk];
-        s2 += __shfl_xor(s2, 16); s2 += __shfl_xor(s2, 32);
-        const int a = 16 * w + lr;
-        if (lk == 0 && a < m) { const double qu = L.luS[a] + s2; L.Qu[a] = qu; L.Qxu[51 * LDQ + a] = qu; }
+      for (int I = 0; I < 4; ++I) {
+        int row = 16 * I + lr; row = row > 51 ? 51 : row;
+        qxx[I] = mfma(L.At[row * LDA + 4 * s + lk], wb, qxx[I]);
       }
     }
     STAMP(4)
-    __syncthreads();   // W, G complete; every wave is done reading Vxx
+    __syncthreads();   // G complete; every wave is done reading Vxx
     STAMP(5)
-    // ---- P3: Qxx[tile w, :] = lxx + A^T W  -> Vxx buffer
-    {
-      v4d acc[4];
+    // ---- P4: Qux[:, tile w] = G^T A[:, tile w]; column 51 <- Qu = lu + B^T Vx
+    v4d qux[2] = {(v4d){0.0, 0.0, 0.0, 0.0}, (v4d){0.0, 0.0, 0.0, 0.0}};
 #pragma unroll
-      for (int J = 0; J < 4; ++J)
+    for (int s = 0; s < KS; ++s) {
+      qux[0] = mfma(L.G[(4 * s + lk) * LDG + lr], areg[s], qux[0]);
+      qux[1] = mfma(L.G[(4 * s + lk) * LDG + 16 + lr], areg[s], qux[1]);
+    }
+    if (jcol == 51) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = 16 * w + lk + 4 * r, col = 16 * J + lr;
-          acc[J][r] = (row < n && col < n) ? L.lxxS[row * n + col] : 0.0;
-        }
+      for (int I = 0; I < 2; ++I)
 #pragma unroll
-      for (int s = 0; s < KS; ++s) {
-#pragma unroll
-        for (int J = 0; J < 4; ++J) acc[J] = mfma(areg[s], L.W[(4 * s + lk) * LDW + 16 * J + lr], acc[J]);
-      }
-#pragma unroll
-      for (int J = 0; J < 4; ++J)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { const int row = 16 * w + lk + 4 * r, col = 16 * J + lr; if (row < n && col < n) L.Vxx[row * LDV + col] = acc[J][r]; }
+        for (int r = 0; r < 4; ++r) { const int a = 16 * I + lk + 4 * r; qux[I][r] = (a < m) ? L.luS[a] + L.G[51 * LDG + a] : 0.0; }
     }
     STAMP(6)
-    // ---- P4: Qxu[tile w, :] = A^T G
-    {
-      v4d acc[2] = {(v4d){0.0, 0.0, 0.0, 0.0}, (v4d){0.0, 0.0, 0.0, 0.0}};
-#pragma unroll
-      for (int s = 0; s < KS; ++s) {
-        acc[0] = mfma(areg[s], L.G[(4 * s + lk) * LDG + lr], acc[0]);
-        acc[1] = mfma(areg[s], L.G[(4 * s + lk) * LDG + 16 + lr], acc[1]);
-      }
-#pragma unroll
-      for (int j2 = 0; j2 < 2; ++j2)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { const int row = 16 * w + lk + 4 * r, col = 16 * j2 + lr; if (row < n && col < m) L.Qxu[row * LDQ + col] = acc[j2][r]; }
-    }
     // ---- P5: Quu tile (w >> 1, w & 1) = B^T G (+ luu + lambda on the diagonal)
     {
       v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
       const int Ia = w >> 1, Jb = w & 1;
 #pragma unroll
-      for (int s = 0; s < KS; ++s) acc = mfma(breg[Ia][s], L.G[(4 * s + lk) * LDG + 16 * Jb + lr], acc);
+      for (int s = 0; s < KS; ++s) acc = mfma(Ia ? breg[1][s] : breg[0][s], L.G[(4 * s + lk) * LDG + 16 * Jb + lr], acc);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = 16 * Ia + lk + 4 * r, col = 16 * Jb + lr;
@@ -230,44 +213,42 @@ __global__ void __launch_bounds__(256) k_backward_mfma(DevState S, int mode) {
       }
     }
     STAMP(7)
-    __syncthreads();   // Quu, Qxu, Qxx complete; W and G are free again
+    __syncthreads();   // Quu complete; At, G, lxS, luS, luuS are free for the next knot's staging
     STAMP(8)
     if (w == 0) {
-      // ---- wave 0: Cholesky of Quu (row per lane) and Linv = L^-1 (column per lane), all in registers
-      double row[RM], dinv[RM];
+      // ---- wave 0: right-looking Cholesky of Quu (row per lane) fused with Linv = L^-1 (column per lane)
+      double row[RM], x[RM];
       int fail = 0;
       for (int attempt = 0; attempt < 2; ++attempt) {
 #pragma unroll
-        for (int c = 0; c < RM; ++c) row[c] = (lane < m) ? L.Quu[lane * LDU + c] : 0.0;
+        for (int c = 0; c < RM; ++c) { row[c] = (lane < m) ? L.Quu[lane * LDU + c] : 0.0; x[c] = (c == lane) ? 1.0 : 0.0; }
         fail = 0;
+#ifndef NO_CHOL
 #pragma unroll
         for (int j = 0; j < RM; ++j) {
-          double s = row[j];
-#pragma unroll
-          for (int k = 0; k < j; ++k) s -= row[k] * bcast(row[k], j);
-          const double piv = bcast(s, j);
+          const double piv = bcast(row[j], j);
           if (!(piv > 0.0)) fail = 1;
           const double di = rsqrt(piv > 0.0 ? piv : 1.0);   // 1 / L[j][j]
-          dinv[j] = di;
-          row[j] = s * di;                                  // lane j: piv / sqrt(piv) = L[j][j]
+          const double lij = row[j] * di;                    // lane i >= j: L[i][j]
+          const double xj = x[j] * di;                       // lane c: Linv[j][c]
+          x[j] = xj;
+#pragma unroll
+          for (int k = j + 1; k < RM; ++k) {
+            const double lkj = bcast(lij, k);                // L[k][j]
+            row[k] -= lij * lkj;
+            x[k] -= lkj * xj;
+            asm volatile("" : "+v"(x[k]));                   // pin the update here: LLVM otherwise sinks the whole Linv chain
+            __builtin_amdgcn_sched_barrier(0);             // below the loop and keeps 171 broadcasts alive in spilled SGPRs
+          }
         }
+#endif
         if (!fail) break;
         if (attempt == 0 && lane < m) L.Quu[lane * LDU + lane] += 1e-4;   // ilqr.cpp:280
       }
       if (lane == 0) L.flags[0] = fail;
-      if (!fail) {
-        double x[RM];   // column `lane` of L^-1
+      if (!fail && lane < m) {
 #pragma unroll
-        for (int i = 0; i < RM; ++i) {
-          double s = (i == lane) ? 1.0 : 0.0;
-#pragma unroll
-          for (int k = 0; k < i; ++k) s -= bcast(row[k], i) * x[k];
-          x[i] = s * dinv[i];
-        }
-        if (lane < m) {
-#pragma unroll
-          for (int i = 0; i < RM; ++i) { L.LinvA[i * LDLA + lane] = x[i]; L.LinvB[i * LDLB + lane] = x[i]; }
-        }
+        for (int i = 0; i < RM; ++i) { L.LinvA[i * LDLA + lane] = x[i]; L.LinvB[i * LDLB + lane] = x[i]; }
       }
     } else if (t > 0) {
       // ---- waves 1-3: fetch the next knot's operands while wave 0 factorises
@@ -276,51 +257,64 @@ __global__ void __launch_bounds__(256) k_backward_mfma(DevState S, int mode) {
     STAMP(9)
     __syncthreads();
     STAMP(10)
+    double* Kg = S.K + ((size_t)b * N + t) * m * n;
+    double* kg = S.kff + ((size_t)b * N + t) * m;
     if (!L.flags[0]) {
-      // ---- P6a: Y[:, tile w] = Linv Qxu^T   (Qxu^T[k][j] = Qxu[j][k])
-      {
-        v4d acc[2] = {(v4d){0.0, 0.0, 0.0, 0.0}, (v4d){0.0, 0.0, 0.0, 0.0}};
+      // ---- P6a: Y[:, tile w] = Linv [Qux | Qu][:, tile w]
+      v4d yacc[2] = {(v4d){0.0, 0.0, 0.0, 0.0}, (v4d){0.0, 0.0, 0.0, 0.0}};
 #pragma unroll
-        for (int s = 0; s < 5; ++s) {
-          const double bq = L.Qxu[(16 * w + lr) * LDQ + 4 * s + lk];
-          acc[0] = mfma(L.LinvA[lr * LDLA + 4 * s + lk], bq, acc[0]);
-          acc[1] = mfma(L.LinvA[(16 + lr) * LDLA + 4 * s + lk], bq, acc[1]);
-        }
-#pragma unroll
-        for (int I = 0; I < 2; ++I)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) { const int row = 16 * I + lk + 4 * r; if (row < 20) L.Y[row * LDK + 16 * w + lr] = acc[I][r]; }
+      for (int s = 0; s < 5; ++s) {
+        const double qb = qux[s >> 2][s & 3];
+        yacc[0] = mfma(L.LinvA[lr * LDLA + 4 * s + lk], qb, yacc[0]);
+        yacc[1] = mfma(L.LinvA[(16 + lr) * LDLA + 4 * s + lk], qb, yacc[1]);
       }
-      __syncthreads();
-      // ---- P6b: [K | k][:, tile w] = -Linv^T Y
+#pragma unroll
+      for (int r = 0; r < 4; ++r) L.Y[(lk + 4 * r) * LDK + jcol] = yacc[0][r];
+      L.Y[(16 + lk) * LDK + jcol] = yacc[1][0];
+      // ---- P6b: [K | k][:, tile w] = -Linv^T Y[:, tile w]
       {
         v4d acc[2] = {(v4d){0.0, 0.0, 0.0, 0.0}, (v4d){0.0, 0.0, 0.0, 0.0}};
 #pragma unroll
         for (int s = 0; s < 5; ++s) {
-          const double by = L.Y[(4 * s + lk) * LDK + 16 * w + lr];
-          acc[0] = mfma(L.LinvB[(4 * s + lk) * LDLB + lr], by, acc[0]);
-          acc[1] = mfma(L.LinvB[(4 * s + lk) * LDLB + 16 + lr], by, acc[1]);
+          const double yb = yacc[s >> 2][s & 3];
+          acc[0] = mfma(L.LinvB[(4 * s + lk) * LDLB + lr], yb, acc[0]);
+          acc[1] = mfma(L.LinvB[(4 * s + lk) * LDLB + 16 + lr], yb, acc[1]);
         }
-        double* Kg = S.K + ((size_t)b * N + t) * m * n;
-        const int col = 16 * w + lr;
 #pragma unroll
         for (int I = 0; I < 2; ++I)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int a = 16 * I + lk + 4 * r;
             if (a < m) {
-              const double v = -acc[I][r];
-              L.Kt[a * LDK + col] = v;
-              if (col < n) Kg[a * n + col] = v;
-              else if (col == n) { L.kt[a] = v; S.kff[((size_t)b * N + t) * m + a] = v; }
+              if (jcol < n) Kg[a * n + jcol] = -acc[I][r];
+              else if (jcol == n) kg[a] = -acc[I][r];
             }
           }
       }
+      STAMP(11)
+      __syncthreads();   // Y complete
+      STAMP(12)
+      // ---- P7: Vxx[:, tile w] = Qxx[:, tile w] - Y^T Y[:, tile w]; row 51: Vx = Qx - Y^T y_u
+#pragma unroll
+      for (int s = 0; s < 5; ++s) {
+        const double yb = -yacc[s >> 2][s & 3];
+#pragma unroll
+        for (int I = 0; I < 4; ++I) qxx[I] = mfma(L.Y[(4 * s + lk) * LDK + 16 * I + lr], yb, qxx[I]);
+      }
     } else {
+#ifndef NO_FALLBACK
       // indefinite Quu even after the bump (rare): explicit inverse by Gauss-Jordan with partial pivoting,
-      // standing in for the reference's pivoted LDLT; the staged operands in W are not touched (Y is scratch)
+      // standing in for the reference's pivoted LDLT.  Scratch: the Vxx buffer (dead between P2 and P7) takes
+      // [Qux | Qu] and the augmented matrix, the Y buffer takes [K | k]; the update is Vxx = Qxx + sym(Qxu K).
+      double* Qd = L.Vxx;                    // Qd[a * 52 + j], a < 20
+      double* Mx = L.Vxx + 20 * 52;          // 19 x 38 augmented
+      double* Kd = L.Y;                      // Kd[a * 52 + j]
+      const int ld = 2 * RM;
+#pragma unroll
+      for (int I = 0; I < 2; ++I)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const int a = 16 * I + lk + 4 * r; if (a < 20 && jcol < 52) Qd[a * 52 + jcol] = qux[I][r]; }
       if (tid == 0) {
-        double* Mx = L.Y; const int ld = 2 * RM;
         for (int i = 0; i < m; ++i) for (int j = 0; j < m; ++j) { Mx[i * ld + j] = L.Quu[i * LDU + j]; Mx[i * ld + m + j] = (i == j) ? 1.0 : 0.0; }
         for (int c = 0; c < m; ++c) {
           int p = c; double best = fabs(Mx[c * ld + c]);
@@ -332,50 +326,39 @@ __global__ void __launch_bounds__(256) k_backward_mfma(DevState S, int mode) {
         }
       }
       __syncthreads();
-      double* Kg = S.K + ((size_t)b * N + t) * m * n;
-      for (int e = tid; e < m * (n + 1); e += 256) {
-        const int a = e / (n + 1), j = e % (n + 1);
+      for (int e = tid; e < m * 52; e += 256) {
+        const int a = e / 52, j = e % 52;
         double s = 0.0;
-        for (int c = 0; c < m; ++c) s += L.Y[a * 2 * RM + m + c] * L.Qxu[j * LDQ + c];
-        L.Kt[a * LDK + j] = -s;
-        if (j < n) Kg[a * n + j] = -s; else { L.kt[a] = -s; S.kff[((size_t)b * N + t) * m + a] = -s; }
+#pragma nounroll
+        for (int c = 0; c < m; ++c) s += Mx[a * ld + m + c] * Qd[c * 52 + j];
+        Kd[a * 52 + j] = -s;
+        if (j < n) Kg[a * n + j] = -s; else kg[a] = -s;
       }
-    }
-    STAMP(11)
-    __syncthreads();
-    STAMP(12)
-    // ---- P7: Vxx <- Qxx + 1/2 (Qxu K + K^T Qxu^T) (row tile w); Vx <- Qx + Qxu k
-    {
-      v4d acc[4];
+      __syncthreads();
 #pragma unroll
-      for (int J = 0; J < 4; ++J)
+      for (int I = 0; I < 4; ++I)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int row = 16 * w + lk + 4 * r, col = 16 * J + lr;
-          acc[J][r] = (row < n && col < n) ? L.Vxx[row * LDV + col] : ((row < n && col == n) ? L.Qx[row] : 0.0);   // column 51 carries Vx
+          const int i = 16 * I + lk + 4 * r;
+          if (i < n && jcol < n) {
+            double s = 0.0;
+#pragma nounroll
+            for (int a = 0; a < m; ++a) s += Qd[a * 52 + i] * Kd[a * 52 + jcol] + Kd[a * 52 + i] * Qd[a * 52 + jcol];
+            qxx[I][r] += 0.5 * s;
+          } else if (i == n && jcol < n) {
+            double s = 0.0;
+#pragma nounroll
+            for (int a = 0; a < m; ++a) s += Qd[a * 52 + jcol] * Kd[a * 52 + n];
+            qxx[I][r] += s;
+          }
         }
-      const int qrow = 16 * w + lr;
-#pragma unroll
-      for (int s = 0; s < 5; ++s) {
-        const int a = 4 * s + lk;
-        const double qa = (qrow < n) ? 0.5 * L.Qxu[qrow * LDQ + a] : 0.0;   // row 51 holds Qu, not part of Qxu
-        const double ka = (qrow < n) ? 0.5 * L.Kt[a * LDK + qrow] : 0.0;
-#pragma unroll
-        for (int J = 0; J < 4; ++J) {
-          const int jc = 16 * J + lr;
-          acc[J] = mfma(qa, (jc < n) ? L.Kt[a * LDK + jc] : ((jc == n) ? 2.0 * L.Kt[a * LDK + jc] : 0.0), acc[J]);   // col 51: Qx + Qxu k
-          acc[J] = mfma(ka, (jc < n) ? L.Qxu[jc * LDQ + a] : 0.0, acc[J]);
-        }
-      }
-#pragma unroll
-      for (int J = 0; J < 4; ++J)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = 16 * w + lk + 4 * r, col = 16 * J + lr;
-          if (row < n && col < n) L.Vxx[row * LDV + col] = acc[J][r];
-          else if (row < n && col == n) L.Vx[row] = acc[J][r];
-        }
+      __syncthreads();   // scratch in the Vxx buffer consumed
+#endif
     }
+#pragma unroll
+    for (int I = 0; I < 4; ++I)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { const int row = 16 * I + lk + 4 * r; if (row < 52 && jcol < 52) L.Vxx[row * LDV + jcol] = qxx[I][r]; }
     STAMP(13)
     __syncthreads();
     STAMP(14)
@@ -384,7 +367,7 @@ __global__ void __launch_bounds__(256) k_backward_mfma(DevState S, int mode) {
   if (b == 0 && tid == 0) for (int k = 0; k < 16; ++k) S.J[k] = (double)ph[k];
 #endif
   for (int e = tid; e < n * n; e += 256) S.Vxx[(size_t)b * n * n + e] = L.Vxx[(e / n) * LDV + (e % n)];
-  if (tid < n) S.Vx[(size_t)b * n + tid] = L.Vx[tid];
+  if (tid < n) S.Vx[(size_t)b * n + tid] = L.Vxx[51 * LDV + tid];
 }
 
 size_t backward_mfma_lds_bytes() { return sizeof(RiccatiLds); }
