@@ -10,7 +10,7 @@
 //   P3  Qxx[:, w] = lxx + A^T W[:, w]      B operand = the accumulators of P1; result stays in registers until P7
 //   P4  Qux[:, w] = G^T A[:, w]            column tile w in registers (column 51 is replaced by Qu)
 //   P5  Quu       = luu + B^T G + lambda I (2x2 tiles over the 4 waves), to LDS
-//   --  wave 0: right-looking Cholesky Quu = L L^T fused with the forward substitution for Linv = L^-1
+//   --  one wave (rotating per knot): right-looking Cholesky Quu = L L^T fused with the forward substitution for Linv = L^-1
 //       (row of Quu / column of Linv per lane, one v_readlane broadcast of L[k][j] feeds both updates;
 //       LLT failure -> +1e-4 I once, ilqr.cpp:278-281);  waves 1-3 meanwhile copy the next knot's A, B, lx, lu, luu
 //       from HBM into LDS, so the operand fetch never sits on the critical path
@@ -45,20 +45,24 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 #define KS 13          // k-steps of 4 over the padded inner dimension 52
 #define LDV 54         // Vxx rows [i][k]
 #define LDA 54         // A^T rows [j][k]
-#define LDG 48         // G rows [k][c], 32 columns
-#define LDK 80         // Y rows [a][j], 64 columns
-#define LDU 20         // Quu rows
 #define LDLA 22        // Linv rows read as [i][k]
-#define LDLB 48        // Linv rows read as [k][i]
+// [k][j]-pattern buffers (G, Y, LinvB) use a power-of-two pitch and an XOR swizzle of the column by 16 on odd
+// rows: a half-wave reads rows k, k+1 x 16 columns and lands on 32 distinct 8-byte bank pairs.
+#define SWZ(k, c, ld) ((k) * (ld) + ((c) ^ (((k) & 1) << 4)))
+#define LDG 32
+#define LDY 64
+#define LDLB 32
+#define LDU 20         // Quu rows (aliases the Y buffer)
 
+// 78,336 B: two workgroups per CU (160 KB LDS), i.e. two waves per SIMD -- while one wave of one rollout runs the
+// latency-bound Cholesky, the other rollout's waves keep the matrix cores busy.
 struct RiccatiLds {
   double Vxx[52 * LDV];   // rows/cols 0..50 = Vxx, row 51 = Vx, column 51 = don't care (finite)
   double At[52 * LDA];    // At[j][k] = A_t[k][j]; row 51 and column 51 stay zero
-  double G[52 * LDG];     // staging of B_t ([k][c], dense rows re-pitched), then G = Vxx B with row 51 = B^T Vx
-  double Y[20 * LDK];     // Linv [Qux | Qu]; scratch of the indefinite fallback
-  double LinvA[32 * LDLA];
+  double G[52 * LDG];     // staging of B_t ([k][c] swizzled), then G = Vxx B with row 51 = B^T Vx
+  double Y[20 * LDY];     // Quu (P5 .. Cholesky), then Y = Linv [Qux | Qu]; scratch of the indefinite fallback
+  double LinvA[21 * LDLA];  // row 20 stays zero (rows 20..31 of the padded operand read it)
   double LinvB[20 * LDLB];
-  double Quu[RM * LDU];
   double lxS[64], luS[32], luuS[32];   // staged lx_t, lu_t, luu_t
   int flags[4];
 };
@@ -70,13 +74,47 @@ __device__ __forceinline__ double bcast(double x, int lane) {
   return __hiloint2double(hi, lo);
 }
 
-__global__ void __launch_bounds__(256) k_backward_mfma(DevState S, int mode) {
+// HBM -> LDS staging of A_t (transposed), B_t, lx_t, lu_t, luu_t by NW waves (thread f of 64 NW); 8 loads in
+// flight per thread, affine addressing (lane = column, wave-strided rows) so nothing but two bases stays live
+template <int NW>
+__device__ __forceinline__ void stage_knot(RiccatiLds& L, const DevState& S, int b, int t, int f) {
+  const int N = S.N, n = RN, m = RM;
+  {
+    const double* Ag = S.A + ((size_t)b * N + t) * n * n;
+    const int j = f & 63, kk = f >> 6;
+    for (int k0 = kk; k0 < n; k0 += 8 * NW) {
+      double v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { const int k = k0 + u * NW; v[u] = (k < n && j < n) ? Ag[k * n + j] : 0.0; }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { const int k = k0 + u * NW; if (k < n && j < n) L.At[j * LDA + k] = v[u]; }
+    }
+  }
+  {
+    const double* Bg = S.Bm + ((size_t)b * N + t) * n * m;
+    const int c = f & 31, kk = f >> 5;
+    for (int k0 = kk; k0 < n; k0 += 8 * 2 * NW) {
+      double v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { const int k = k0 + u * 2 * NW; v[u] = (k < n && c < m) ? Bg[k * m + c] : 0.0; }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { const int k = k0 + u * 2 * NW; if (k < n && c < m) L.G[SWZ(k, c, LDG)] = v[u]; }
+    }
+  }
+  if (f < n) L.lxS[f] = S.lx[((size_t)b * (N + 1) + t) * n + f];
+  else if (f >= 64 && f < 64 + m) { L.luS[f - 64] = S.lu[((size_t)b * N + t) * m + f - 64]; L.luuS[f - 64] = S.luu[((size_t)b * N + t) * m + f - 64]; }
+}
+
+__global__ void __launch_bounds__(256, 2) k_backward_mfma(DevState S, int mode) {
   const int b = blockIdx.x;
   if (mode == MASK_ACTIVE && !S.active[b]) return;
   if (mode == MASK_RETRY && !(S.active[b] && S.need_retry[b])) return;
-  extern __shared__ double smem[];
-  RiccatiLds& L = *reinterpret_cast<RiccatiLds*>(smem);
-  const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, lr = lane & 15, lk = lane >> 4;
+  // static allocation: LDS addresses are immediates (with a dynamic array every address constant is a hoisted,
+  // spilled SGPR)
+  __shared__ RiccatiLds L;
+  double* const smem = reinterpret_cast<double*>(&L);
+  double* const Quu = L.Y;
+  const int tid = threadIdx.x, w0 = __builtin_amdgcn_readfirstlane(tid >> 6), lane0 = tid & 63;
   const int N = S.N, n = RN, m = RM;
   const double lam = S.lambda[b];
   const double* lxg = S.lx + (size_t)b * (N + 1) * n;
@@ -87,48 +125,20 @@ __global__ void __launch_bounds__(256) k_backward_mfma(DevState S, int mode) {
   __syncthreads();
   for (int e = tid; e < n * n; e += 256) L.Vxx[(e / n) * LDV + (e % n)] = lxxg[(size_t)N * n * n + e];
   if (tid < n) L.Vxx[51 * LDV + tid] = lxg[N * n + tid];
-  // HBM -> LDS staging of A_t (transposed), B_t, lx_t, lu_t, luu_t; 8 loads in flight per thread
-  auto stage_knot = [&](int t, int first, int nthreads) {
-    const double* Ag = S.A + ((size_t)b * N + t) * n * n;
-    for (int e0 = first; e0 < n * n; e0 += 8 * nthreads) {
-      double v[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) { const int e = e0 + u * nthreads; v[u] = (e < n * n) ? Ag[e] : 0.0; }
-#pragma unroll
-      for (int u = 0; u < 8; ++u) { const int e = e0 + u * nthreads; if (e < n * n) L.At[(e % n) * LDA + (e / n)] = v[u]; }
-    }
-    const double* Bg = S.Bm + ((size_t)b * N + t) * n * m;
-    for (int e0 = first; e0 < n * m; e0 += 8 * nthreads) {
-      double v[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) { const int e = e0 + u * nthreads; v[u] = (e < n * m) ? Bg[e] : 0.0; }
-#pragma unroll
-      for (int u = 0; u < 8; ++u) { const int e = e0 + u * nthreads; if (e < n * m) L.G[(e / m) * LDG + (e % m)] = v[u]; }
-    }
-    if (first < n) L.lxS[first] = lxg[t * n + first];
-    else if (first >= 64 && first < 64 + m) { L.luS[first - 64] = S.lu[((size_t)b * N + t) * m + first - 64]; L.luuS[first - 64] = S.luu[((size_t)b * N + t) * m + first - 64]; }
-  };
-  stage_knot(N - 1, tid, 256);
+  stage_knot<4>(L, S, b, N - 1, tid);
   __syncthreads();
 
 #ifdef RIC_STAMP
   long long ph[16] = {0}; long long tlast = clock64();
 #endif
-  const int jcol = 16 * w + lr;                  // the column this lane owns in every column-tile product
-  const int jrow = jcol > 51 ? 51 : jcol;        // clamped: row 51 of At is zero
   for (int t = N - 1; t >= 0; --t) {
-    // ---- lxx_t straight from HBM into the accumulators of P3 (consumed after P1/P2, latency hidden)
-    v4d qxx[4];
-    {
-      const double* lg = lxxg + (size_t)t * n * n;
-#pragma unroll
-      for (int I = 0; I < 4; ++I)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = 16 * I + lk + 4 * r;
-          qxx[I][r] = (row < n && jcol < n) ? lg[row * n + jcol] : 0.0;
-        }
-    }
+    // lane / wave indices are re-derived behind an opaque barrier every knot: otherwise LICM hoists ~100 LDS
+    // addresses and predicates out of this loop and the register allocator spills them (and reloads each knot)
+    int lane = lane0, w = w0;
+    asm volatile("" : "+v"(lane), "+s"(w));
+    const int lr = lane & 15, lk = lane >> 4;
+    const int jcol = 16 * w + lr;                  // the column this lane owns in every column-tile product
+    const int jrow = jcol > 51 ? 51 : jcol;        // clamped: row 51 of At is zero
     // ---- operands from the LDS staging into registers
     double areg[KS];          // A[4s + lk][16w + lr]
     double breg[2][KS];       // B[4s + lk][16j2 + lr]
@@ -138,7 +148,7 @@ __global__ void __launch_bounds__(256) k_backward_mfma(DevState S, int mode) {
     for (int j2 = 0; j2 < 2; ++j2) {
       const int c2 = 16 * j2 + lr;
 #pragma unroll
-      for (int s = 0; s < KS; ++s) { const int k = 4 * s + lk; breg[j2][s] = (k < n && c2 < m) ? L.G[k * LDG + c2] : 0.0; }
+      for (int s = 0; s < KS; ++s) { const int k = 4 * s + lk; breg[j2][s] = (k < n && c2 < m) ? L.G[SWZ(k, c2, LDG)] : 0.0; }
     }
     STAMP(0)
     __syncthreads();   // B staging consumed: G may be overwritten
@@ -156,6 +166,18 @@ __global__ void __launch_bounds__(256) k_backward_mfma(DevState S, int mode) {
       }
     }
     STAMP(2)
+    // ---- lxx_t straight from HBM into the accumulators of P3 (latency hidden behind P2)
+    v4d qxx[4];
+    {
+      const double* lg = lxxg + (size_t)t * n * n;
+#pragma unroll
+      for (int I = 0; I < 4; ++I)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = 16 * I + lk + 4 * r;
+          qxx[I][r] = (row < n && jcol < n) ? lg[row * n + jcol] : 0.0;
+        }
+    }
     // ---- P2: G[tile w, :] = Vxx[tile w, :] B   (row 51: B^T Vx)
     {
       v4d acc[2] = {(v4d){0.0, 0.0, 0.0, 0.0}, (v4d){0.0, 0.0, 0.0, 0.0}};
@@ -169,7 +191,7 @@ __global__ void __launch_bounds__(256) k_backward_mfma(DevState S, int mode) {
 #pragma unroll
       for (int j2 = 0; j2 < 2; ++j2)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { const int rr = 16 * w + lk + 4 * r; if (rr < 52) L.G[rr * LDG + 16 * j2 + lr] = acc[j2][r]; }
+        for (int r = 0; r < 4; ++r) { const int rr = 16 * w + lk + 4 * r; if (rr < 52) L.G[SWZ(rr, 16 * j2 + lr, LDG)] = acc[j2][r]; }
     }
     STAMP(3)
     // ---- P3: Qxx[:, tile w] = lxx + A^T W[:, tile w]; row 51 <- Qx = lx + A^T Vx (row 51 of At is zero)
@@ -190,14 +212,15 @@ __global__ void __launch_bounds__(256) k_backward_mfma(DevState S, int mode) {
     v4d qux[2] = {(v4d){0.0, 0.0, 0.0, 0.0}, (v4d){0.0, 0.0, 0.0, 0.0}};
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
-      qux[0] = mfma(L.G[(4 * s + lk) * LDG + lr], areg[s], qux[0]);
-      qux[1] = mfma(L.G[(4 * s + lk) * LDG + 16 + lr], areg[s], qux[1]);
+      const int k = 4 * s + lk;
+      qux[0] = mfma(L.G[SWZ(k, lr, LDG)], areg[s], qux[0]);
+      qux[1] = mfma(L.G[SWZ(k, 16 + lr, LDG)], areg[s], qux[1]);
     }
     if (jcol == 51) {
 #pragma unroll
       for (int I = 0; I < 2; ++I)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { const int a = 16 * I + lk + 4 * r; qux[I][r] = (a < m) ? L.luS[a] + L.G[51 * LDG + a] : 0.0; }
+        for (int r = 0; r < 4; ++r) { const int a = 16 * I + lk + 4 * r; qux[I][r] = (a < m) ? L.luS[a] + L.G[SWZ(51, a, LDG)] : 0.0; }
     }
     STAMP(6)
     // ---- P5: Quu tile (w >> 1, w & 1) = B^T G (+ luu + lambda on the diagonal)
@@ -205,25 +228,25 @@ __global__ void __launch_bounds__(256) k_backward_mfma(DevState S, int mode) {
       v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
       const int Ia = w >> 1, Jb = w & 1;
 #pragma unroll
-      for (int s = 0; s < KS; ++s) acc = mfma(Ia ? breg[1][s] : breg[0][s], L.G[(4 * s + lk) * LDG + 16 * Jb + lr], acc);
+      for (int s = 0; s < KS; ++s) { const int k = 4 * s + lk; acc = mfma(Ia ? breg[1][s] : breg[0][s], L.G[SWZ(k, 16 * Jb + lr, LDG)], acc); }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = 16 * Ia + lk + 4 * r, col = 16 * Jb + lr;
-        if (row < m && col < m) L.Quu[row * LDU + col] = acc[r] + ((row == col) ? (L.luuS[row] + lam) : 0.0);
+        if (row < m && col < m) Quu[row * LDU + col] = acc[r] + ((row == col) ? (L.luuS[row] + lam) : 0.0);
       }
     }
     STAMP(7)
     __syncthreads();   // Quu complete; At, G, lxS, luS, luuS are free for the next knot's staging
     STAMP(8)
-    if (w == 0) {
-      // ---- wave 0: right-looking Cholesky of Quu (row per lane) fused with Linv = L^-1 (column per lane)
+    const int cw = (t + (b >> 8)) & 3;   // the factorising wave rotates, so co-resident workgroups load all four SIMDs evenly
+    if (w == cw) {
+      // ---- wave cw: right-looking Cholesky of Quu (row per lane) fused with Linv = L^-1 (column per lane)
       double row[RM], x[RM];
       int fail = 0;
       for (int attempt = 0; attempt < 2; ++attempt) {
 #pragma unroll
-        for (int c = 0; c < RM; ++c) { row[c] = (lane < m) ? L.Quu[lane * LDU + c] : 0.0; x[c] = (c == lane) ? 1.0 : 0.0; }
+        for (int c = 0; c < RM; ++c) { row[c] = (lane < m) ? Quu[lane * LDU + c] : 0.0; x[c] = (c == lane) ? 1.0 : 0.0; }
         fail = 0;
-#ifndef NO_CHOL
 #pragma unroll
         for (int j = 0; j < RM; ++j) {
           const double piv = bcast(row[j], j);
@@ -241,18 +264,17 @@ __global__ void __launch_bounds__(256) k_backward_mfma(DevState S, int mode) {
             __builtin_amdgcn_sched_barrier(0);             // below the loop and keeps 171 broadcasts alive in spilled SGPRs
           }
         }
-#endif
         if (!fail) break;
-        if (attempt == 0 && lane < m) L.Quu[lane * LDU + lane] += 1e-4;   // ilqr.cpp:280
+        if (attempt == 0 && lane < m) Quu[lane * LDU + lane] += 1e-4;   // ilqr.cpp:280
       }
       if (lane == 0) L.flags[0] = fail;
       if (!fail && lane < m) {
 #pragma unroll
-        for (int i = 0; i < RM; ++i) { L.LinvA[i * LDLA + lane] = x[i]; L.LinvB[i * LDLB + lane] = x[i]; }
+        for (int i = 0; i < RM; ++i) { L.LinvA[i * LDLA + lane] = x[i]; L.LinvB[SWZ(i, lane, LDLB)] = x[i]; }
       }
     } else if (t > 0) {
-      // ---- waves 1-3: fetch the next knot's operands while wave 0 factorises
-      stage_knot(t - 1, tid - 64, 192);
+      // ---- the other three waves: fetch the next knot's operands while wave cw factorises
+      stage_knot<3>(L, S, b, t - 1, ((w - cw - 1) & 3) * 64 + lane);
     }
     STAMP(9)
     __syncthreads();
@@ -262,23 +284,25 @@ __global__ void __launch_bounds__(256) k_backward_mfma(DevState S, int mode) {
     if (!L.flags[0]) {
       // ---- P6a: Y[:, tile w] = Linv [Qux | Qu][:, tile w]
       v4d yacc[2] = {(v4d){0.0, 0.0, 0.0, 0.0}, (v4d){0.0, 0.0, 0.0, 0.0}};
+      const int ra1 = (16 + lr) > 20 ? 20 : (16 + lr);
 #pragma unroll
       for (int s = 0; s < 5; ++s) {
         const double qb = qux[s >> 2][s & 3];
         yacc[0] = mfma(L.LinvA[lr * LDLA + 4 * s + lk], qb, yacc[0]);
-        yacc[1] = mfma(L.LinvA[(16 + lr) * LDLA + 4 * s + lk], qb, yacc[1]);
+        yacc[1] = mfma(L.LinvA[ra1 * LDLA + 4 * s + lk], qb, yacc[1]);
       }
 #pragma unroll
-      for (int r = 0; r < 4; ++r) L.Y[(lk + 4 * r) * LDK + jcol] = yacc[0][r];
-      L.Y[(16 + lk) * LDK + jcol] = yacc[1][0];
+      for (int r = 0; r < 4; ++r) L.Y[SWZ(lk + 4 * r, jcol, LDY)] = yacc[0][r];
+      L.Y[SWZ(16 + lk, jcol, LDY)] = yacc[1][0];
       // ---- P6b: [K | k][:, tile w] = -Linv^T Y[:, tile w]
       {
         v4d acc[2] = {(v4d){0.0, 0.0, 0.0, 0.0}, (v4d){0.0, 0.0, 0.0, 0.0}};
 #pragma unroll
         for (int s = 0; s < 5; ++s) {
           const double yb = yacc[s >> 2][s & 3];
-          acc[0] = mfma(L.LinvB[(4 * s + lk) * LDLB + lr], yb, acc[0]);
-          acc[1] = mfma(L.LinvB[(4 * s + lk) * LDLB + 16 + lr], yb, acc[1]);
+          const int k = 4 * s + lk;
+          acc[0] = mfma(L.LinvB[SWZ(k, lr, LDLB)], yb, acc[0]);
+          acc[1] = mfma(L.LinvB[SWZ(k, 16 + lr, LDLB)], yb, acc[1]);
         }
 #pragma unroll
         for (int I = 0; I < 2; ++I)
@@ -298,14 +322,16 @@ __global__ void __launch_bounds__(256) k_backward_mfma(DevState S, int mode) {
 #pragma unroll
       for (int s = 0; s < 5; ++s) {
         const double yb = -yacc[s >> 2][s & 3];
+        const int k = 4 * s + lk;
 #pragma unroll
-        for (int I = 0; I < 4; ++I) qxx[I] = mfma(L.Y[(4 * s + lk) * LDK + 16 * I + lr], yb, qxx[I]);
+        for (int I = 0; I < 4; ++I) qxx[I] = mfma(L.Y[SWZ(k, 16 * I + lr, LDY)], yb, qxx[I]);
       }
     } else {
 #ifndef NO_FALLBACK
       // indefinite Quu even after the bump (rare): explicit inverse by Gauss-Jordan with partial pivoting,
       // standing in for the reference's pivoted LDLT.  Scratch: the Vxx buffer (dead between P2 and P7) takes
-      // [Qux | Qu] and the augmented matrix, the Y buffer takes [K | k]; the update is Vxx = Qxx + sym(Qxu K).
+      // [Qux | Qu] and the augmented matrix, the Y buffer takes [K | k] once Quu has been copied out of it;
+      // the update is Vxx = Qxx + sym(Qxu K), Vx = Qx + Qxu k.
       double* Qd = L.Vxx;                    // Qd[a * 52 + j], a < 20
       double* Mx = L.Vxx + 20 * 52;          // 19 x 38 augmented
       double* Kd = L.Y;                      // Kd[a * 52 + j]
@@ -315,7 +341,7 @@ __global__ void __launch_bounds__(256) k_backward_mfma(DevState S, int mode) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) { const int a = 16 * I + lk + 4 * r; if (a < 20 && jcol < 52) Qd[a * 52 + jcol] = qux[I][r]; }
       if (tid == 0) {
-        for (int i = 0; i < m; ++i) for (int j = 0; j < m; ++j) { Mx[i * ld + j] = L.Quu[i * LDU + j]; Mx[i * ld + m + j] = (i == j) ? 1.0 : 0.0; }
+        for (int i = 0; i < m; ++i) for (int j = 0; j < m; ++j) { Mx[i * ld + j] = Quu[i * LDU + j]; Mx[i * ld + m + j] = (i == j) ? 1.0 : 0.0; }
         for (int c = 0; c < m; ++c) {
           int p = c; double best = fabs(Mx[c * ld + c]);
           for (int r = c + 1; r < m; ++r) if (fabs(Mx[r * ld + c]) > best) { best = fabs(Mx[r * ld + c]); p = r; }
@@ -371,11 +397,9 @@ __global__ void __launch_bounds__(256) k_backward_mfma(DevState S, int mode) {
 }
 
 size_t backward_mfma_lds_bytes() { return sizeof(RiccatiLds); }
-int backward_mfma_set_attr() {
-  return hipFuncSetAttribute((const void*)k_backward_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(RiccatiLds)) == hipSuccess ? 0 : 1;
-}
+int backward_mfma_set_attr() { return 0; }   // LDS is allocated statically
 void launch_backward_mfma(const DevState& S, int mode, hipStream_t st) {
-  hipLaunchKernelGGL(k_backward_mfma, dim3(S.B), dim3(256), sizeof(RiccatiLds), st, S, mode);
+  hipLaunchKernelGGL(k_backward_mfma, dim3(S.B), dim3(256), 0, st, S, mode);
 }
 
 }  // namespace ilqr
