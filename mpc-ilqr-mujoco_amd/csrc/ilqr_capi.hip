@@ -297,7 +297,10 @@ int ilqr_hip_solve_async(ilqr_hip_ctx* c) {
   c->spans.clear(); c->pool_next = 0;
   { StageTimer T(c, 0); ilqr::launch_rollout(S, P, ilqr::MASK_ALL, 0, 0, S.Jbase, st); ilqr::launch_solve_begin(S, st); }  // ilqr.cpp:540
   for (int iter = 0; iter < c->max_iter; ++iter) {
-    { StageTimer T(c, 0); ilqr::launch_rollout(S, P, ilqr::MASK_ACTIVE, 1, 1, S.Jbase, st); }                 // :551,563
+    // :551,563 -- from the second iteration on the nominal trajectory IS the candidate the line search accepted
+    // (or the unchanged previous one): it is already dynamically consistent and its cost is in Jbase, so the
+    // reference's re-rollout would reproduce it and is skipped
+    if (iter == 0) { StageTimer T(c, 0); ilqr::launch_rollout(S, P, ilqr::MASK_ACTIVE, 1, 0, S.Jbase, st); }
     // linearisation (:576) and cost quadratics (:588) only depend on the rollout: run them concurrently
     HIPCHK(c, hipEventRecord(c->ev_fork, st));
     HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));

@@ -22,10 +22,6 @@ using namespace h1;
 
 namespace ilqr {
 
-// waves per SIMD requested from the register allocator (measured on MI355X: 2 -> 7.4 ms, 1 -> 12.3 ms per launch)
-#ifndef QUAD_WAVES
-#define QUAD_WAVES 2
-#endif
 #ifndef LINT_WAVES
 #define LINT_WAVES 1
 #endif
@@ -139,169 +135,7 @@ __global__ void __launch_bounds__(256) k_linearize_fd(DevState S, ProblemDev P, 
   else { const int c = col - H1_NX; for (int i = 0; i < H1_NX; ++i) Bg[i * H1_NU + c] = (pert[i] - base[i]) / eps; }
 }
 
-// ------------------------------------------------------------------ K3: cost quadratics
-// one wave per (knot, rollout).
-__global__ void __launch_bounds__(64, QUAD_WAVES) k_cost_quadratics(DevState S, ProblemDev P, int mode) {
-  const int t = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
-  if (!selected(S, b, mode)) return;
-  const int N = S.N;
-  const bool term = (t == N);
-  __shared__ KnotKin K;
-  __shared__ HessCtx ctx[8];
-  __shared__ int nctx;
-  __shared__ double xs[H1_NX], us[H1_NU];
-  __shared__ double gsum[8][3];   // gradient residual vectors per Jacobian use: (set, is_vel, scale*vec)
-  __shared__ int gset[8], gvel[8], ng;
-  __shared__ double bal[8];       // balance scalars: r0 r1 om om1 om2 vc0 vc1 w
-  __shared__ int has_bal;
-
-  const double* xg = S.xbar + ((size_t)b * (N + 1) + t) * H1_NX;
-  if (lane < H1_NX) xs[lane] = xg[lane];
-  if (!term && lane < H1_NU) us[lane] = S.ubar[((size_t)b * N + t) * H1_NU + lane];
-  __syncthreads();
-  if (lane == 0) knot_base_kin(xs, K);
-  __syncthreads();
-  if (lane < 3) knot_point_set(K, lane);
-  __syncthreads();
-  if (lane < H1_NX) { knot_jac_column(K, 0, lane); knot_jac_column(K, 1, lane); knot_jac_column(K, 2, lane); }
-  __syncthreads();
-  if (lane == 0) {
-    int n = 0, g = 0; has_bal = 0;
-    const int* st = P.stance + b * P.stance_stride + 2 * t;
-    // CoM position: w ||com - ref||^2
-    if (P.w_com > 0.0) {
-      const double* ref = P.com_ref + b * P.com_ref_stride + t * 3;
-      double rb[3], e[3]; mv3(K.R0, K.S[0].beta, rb);
-      for (int k = 0; k < 3; ++k) e[k] = K.S[0].mfrac * K.xp[k] + rb[k] - ref[k];
-      make_ctx(K, ctx[n++], 0, 0, 2.0 * P.w_com, e);
-      gset[g] = 0; gvel[g] = 0; for (int k = 0; k < 3; ++k) gsum[g][k] = 2.0 * P.w_com * e[k]; ++g;
-    }
-    if (!term && P.w_com_vel > 0.0) {
-      const double* ref = P.com_vel_ref + b * P.com_vel_ref_stride + t * 3;
-      double v[3], e[3]; mv3(K.R0, K.S[0].gamma, v);
-      for (int k = 0; k < 3; ++k) e[k] = v[k] - ref[k];
-      make_ctx(K, ctx[n++], 0, 1, 2.0 * P.w_com_vel, e);
-      gset[g] = 0; gvel[g] = 1; for (int k = 0; k < 3; ++k) gsum[g][k] = 2.0 * P.w_com_vel * e[k]; ++g;
-    }
-    for (int ee = 0; ee < 2; ++ee) {
-      const int set = 1 + ee;
-      if (P.w_ee_pos > 0.0 && st[ee] != 1) {
-        const double* ref = P.ee_ref + b * P.ee_ref_stride + (t * 2 + ee) * 3;
-        double rb[3], e[3]; mv3(K.R0, K.S[set].beta, rb);
-        for (int k = 0; k < 3; ++k) e[k] = K.S[set].mfrac * K.xp[k] + rb[k] - ref[k];
-        make_ctx(K, ctx[n++], set, 0, 2.0 * P.w_ee_pos, e);
-        gset[g] = set; gvel[g] = 0; for (int k = 0; k < 3; ++k) gsum[g][k] = 2.0 * P.w_ee_pos * e[k]; ++g;
-      }
-      if (P.w_ee_vel > 0.0 && st[ee] == 1) {
-        double e[3]; mv3(K.R0, K.S[set].gamma, e);   // zero target (ilqr.cpp:734)
-        make_ctx(K, ctx[n++], set, 1, 2.0 * P.w_ee_vel, e);
-        gset[g] = set; gvel[g] = 1; for (int k = 0; k < 3; ++k) gsum[g][k] = 2.0 * P.w_ee_vel * e[k]; ++g;
-      }
-    }
-    double ps[2];
-    if (P.w_balance > 0.0 && support_point(P, b, t, ps)) {
-      const PointSetDev& C = K.S[0];
-      double rb[3], vc[3]; mv3(K.R0, C.beta, rb); mv3(K.R0, C.gamma, vc);
-      double com[3]; for (int k = 0; k < 3; ++k) com[k] = C.mfrac * K.xp[k] + rb[k];
-      const double gg = 9.81;
-      const double om = sqrt(com[2] / gg), om1 = 1.0 / (2.0 * gg * om), om2 = -1.0 / (4.0 * gg * gg * om * om * om);
-      const double r0 = com[0] + vc[0] * om - ps[0], r1 = com[1] + vc[1] * om - ps[1];
-      const double rv = r0 * vc[0] + r1 * vc[1];
-      bal[0] = r0; bal[1] = r1; bal[2] = om; bal[3] = om1; bal[4] = om2; bal[5] = vc[0]; bal[6] = vc[1]; bal[7] = rv;
-      has_bal = 1;
-      const double mu[3] = {r0, r1, om1 * rv}, nu[3] = {om * r0, om * r1, 0.0};
-      make_ctx(K, ctx[n++], 0, 0, P.w_balance, mu);
-      make_ctx(K, ctx[n++], 0, 1, P.w_balance, nu);
-    }
-    nctx = n; ng = g;
-  }
-  __syncthreads();
-
-  const double* Qd = term ? P.Qf : P.Q;
-  const double* xr = P.x_ref + b * P.x_ref_stride + t * H1_NX;
-  // upright pieces (4 quaternion slots, derivatives.cpp:646-666 labelling)
-  const double ua = K.xp[3], ub = K.xp[4], uc = K.xp[5], ud = K.xp[6];
-  const double ur[3] = {2.0 * (ub * ud + ua * uc), 2.0 * (uc * ud - ua * ub), -2.0 * (ub * ub + uc * uc)};
-  const double uJ[3][4] = {{2 * uc, 2 * ud, 2 * ua, 2 * ub}, {-2 * ub, -2 * ua, 2 * ud, 2 * uc}, {0, -4 * ub, -4 * uc, 0}};
-
-  // ---- gradient lx (lane = coordinate)
-  if (lane < H1_NX) {
-    const int a = lane;
-    double g = Qd[a] * (xs[a] - xr[a]);
-    for (int i = 0; i < ng; ++i) {
-      const double (*J)[H1_NX] = gvel[i] ? K.Jv[gset[i]] : K.Jc[gset[i]];
-      g += J[0][a] * gsum[i][0] + J[1][a] * gsum[i][1] + J[2][a] * gsum[i][2];
-    }
-    if (P.w_upright > 0.0 && a >= 3 && a < 7) g += P.w_upright * (uJ[0][a - 3] * ur[0] + uJ[1][a - 3] * ur[1] + uJ[2][a - 3] * ur[2]);
-    if (has_bal) {
-      const double om = bal[2], om1 = bal[3];
-      const double jr0 = K.Jc[0][0][a] + om * K.Jv[0][0][a] + bal[5] * om1 * K.Jc[0][2][a];
-      const double jr1 = K.Jc[0][1][a] + om * K.Jv[0][1][a] + bal[6] * om1 * K.Jc[0][2][a];
-      g += P.w_balance * (jr0 * bal[0] + jr1 * bal[1]);
-    }
-    if (a >= 7 && a < H1_NQ) {
-      double lo, hi; limit_bounds(H1_JRANGE[a - 7], lo, hi);
-      const double q = xs[a];
-      if (q > hi) g += 2.0 * P.w_joint * (q - hi);
-      if (q < lo) g += -2.0 * P.w_joint * (lo - q);
-    }
-    S.lx[((size_t)b * (N + 1) + t) * H1_NX + a] = g;
-  }
-  if (!term && lane < H1_NU) {
-    const double* ur_ = P.u_ref + b * P.u_ref_stride + t * H1_NU;
-    const double u = us[lane];
-    double g = P.R[lane] * (u - ur_[lane]), h = P.R[lane];
-    double lo, hi; limit_bounds(H1_CTRLRANGE[lane], lo, hi);
-    if (u > hi) g += 2.0 * P.w_ctrl * (u - hi);
-    if (u < lo) g += -2.0 * P.w_ctrl * (lo - u);
-    if (u > hi || u < lo) h += 2.0 * P.w_ctrl;
-    S.lu[((size_t)b * N + t) * H1_NU + lane] = g;
-    S.luu[((size_t)b * N + t) * H1_NU + lane] = h;
-  }
-
-  // ---- Hessian lxx: upper triangle entries distributed over the lanes, mirrored on store
-  double* Hg = S.lxx + ((size_t)b * (N + 1) + t) * H1_NX * H1_NX;
-  const int NT = H1_NX * (H1_NX + 1) / 2;
-  for (int idx = lane; idx < NT; idx += 64) {
-    int a = (int)((2 * H1_NX + 1 - sqrt((double)(2 * H1_NX + 1) * (2 * H1_NX + 1) - 8.0 * idx)) * 0.5);
-    while ((a + 1) * H1_NX - ((a + 1) * a) / 2 <= idx) ++a;
-    while (a * H1_NX - (a * (a - 1)) / 2 > idx) --a;
-    const int bb = a + (idx - (a * H1_NX - (a * (a - 1)) / 2));
-    double h = (a == bb) ? Qd[a] : 0.0;
-    for (int i = 0; i < ng; ++i) {
-      const double (*J)[H1_NX] = gvel[i] ? K.Jv[gset[i]] : K.Jc[gset[i]];
-      // 2w J^T J : scale is carried by ctx; recover it from the matching context (same order as ctx[0..ng))
-      h += ctx[i].scale * (J[0][a] * J[0][bb] + J[1][a] * J[1][bb] + J[2][a] * J[2][bb]);
-    }
-    for (int i = 0; i < nctx; ++i) h += ctx[i].scale * (ctx[i].is_vel ? hess_vel_entry(K, ctx[i], a, bb) : hess_pos_entry(K, ctx[i], a, bb));
-    if (P.w_upright > 0.0 && a >= 3 && bb < 7) {
-      const int i = a - 3, j = bb - 3;
-      double v = uJ[0][i] * uJ[0][j] + uJ[1][i] * uJ[1][j] + uJ[2][i] * uJ[2][j];
-      if ((i == 0 && j == 2) || (i == 1 && j == 3)) v += 2.0 * ur[0];
-      if (i == 2 && j == 3) v += 2.0 * ur[1];
-      if (i == 0 && j == 1) v += -2.0 * ur[1];
-      if ((i == 1 && j == 1) || (i == 2 && j == 2)) v += -4.0 * ur[2];
-      h += P.w_upright * v;
-    }
-    if (has_bal) {
-      const double om = bal[2], om1 = bal[3], om2 = bal[4];
-      const double jza = K.Jc[0][2][a], jzb = K.Jc[0][2][bb];
-      const double jr0a = K.Jc[0][0][a] + om * K.Jv[0][0][a] + bal[5] * om1 * jza, jr0b = K.Jc[0][0][bb] + om * K.Jv[0][0][bb] + bal[5] * om1 * jzb;
-      const double jr1a = K.Jc[0][1][a] + om * K.Jv[0][1][a] + bal[6] * om1 * jza, jr1b = K.Jc[0][1][bb] + om * K.Jv[0][1][bb] + bal[6] * om1 * jzb;
-      double v = jr0a * jr0b + jr1a * jr1b;
-      v += om1 * (bal[0] * (K.Jv[0][0][a] * jzb + jza * K.Jv[0][0][bb]) + bal[1] * (K.Jv[0][1][a] * jzb + jza * K.Jv[0][1][bb]));
-      v += bal[7] * om2 * jza * jzb;
-      h += P.w_balance * v;
-    }
-    if (a == bb && a >= 7 && a < H1_NQ) {
-      double lo, hi; limit_bounds(H1_JRANGE[a - 7], lo, hi);
-      const double q = xs[a];
-      if (q > hi || q < lo) h += 2.0 * P.w_joint;
-    }
-    Hg[a * H1_NX + bb] = h;
-    if (a != bb) Hg[bb * H1_NX + a] = h;
-  }
-}
+// K3 (cost quadratics) lives in quad_kernels.hip
 
 // ------------------------------------------------------------------ K4: Riccati backward pass
 // one 256-thread workgroup per rollout; Vxx, A_t, W, B_t, G, Qxu, K_t staged in LDS.
@@ -503,6 +337,7 @@ __global__ void __launch_bounds__(64) k_control(DevState S, int phase, int iter,
   if (phase == 0 && !S.active[b]) return;
   if (phase == 1 && !(S.active[b] && S.need_retry[b])) return;
   if (lane == 0) {
+    if (phase == 0) S.iters[b] += 1;
     const double base = S.Jbase[b];
     int acc = -1;
     for (int a = 0; a < 8; ++a) { const double c = S.cand_cost[(size_t)b * 8 + a]; if (c < base - 1e-6) { acc = a; break; } }
@@ -518,6 +353,7 @@ __global__ void __launch_bounds__(64) k_control(DevState S, int phase, int iter,
         const double Jprev = S.J[b];
         const double Jn = S.cand_cost[(size_t)b * 8 + acc];
         S.J[b] = Jn;
+        S.Jbase[b] = Jn;   // the accepted candidate is the next nominal trajectory: its cost is the next baseline
         S.lambda[b] = fmax(lam_used / 2.0, 1e-6);
         S.need_retry[b] = 0;
         S.trace_cost[(size_t)b * (S.max_iter + 1) + tr + 1] = Jn;
@@ -628,9 +464,6 @@ void launch_linearize(const DevState& S, const ProblemDev& P, int mode, int jac_
   }
 }
 size_t lin_dump_doubles() { return LinDumpG_SIZE; }
-void launch_cost_quadratics(const DevState& S, const ProblemDev& P, int mode, hipStream_t st) {
-  hipLaunchKernelGGL(k_cost_quadratics, dim3(S.N + 1, S.B), dim3(64), 0, st, S, P, mode);
-}
 // ILQR_BACKWARD=valu selects the LDS + VALU kernel (kept as an on-device cross-check); default = MFMA kernel
 static int use_valu_backward() {
   static int v = -1;

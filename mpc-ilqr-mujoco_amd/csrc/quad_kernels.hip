@@ -1,0 +1,516 @@
+// K3: cost quadratics -- iLQR::computeCostQuadratics (reference src/ilqr/ilqr.cpp:133-244) with the exact task-term
+// Hessians of add{CoM,CoMVel,EEPos,EEVel,Upright,Balance}CostDerivatives (ilqr.cpp:662-800; closed forms of
+// derivatives.cpp:525-707, see h1_cost_dev.h).  One wave per (knot, rollout); every phase is lane-parallel:
+//   1  pelvis-frame kinematics of the URDF tree, lane = body, one barrier per tree level (5 levels)
+//   2  point sets (whole-body CoM, left / right ankle origin), lane = (set, body): subtree aggregates are direct
+//      sums over the ancestor bitmask instead of an inward sweep, so there is no sequential dependency
+//   3  Jacobian columns of c and cdot, lane = coordinate
+//   4  weighted functionals (one per active cost term) and their per-joint vectors til x z_j, P'_j, lane = (term, joint)
+//   5  gradient, lane = coordinate
+//   6  Hessian, upper-triangle entries distributed over the lanes block by block of the coordinate classes
+//      p | quat | theta | v_b | omega_b | thetadot, so that every lane of an iteration runs the same formula
+//      (the 2 w J^T J part is generic; the second-order part exists in 8 of the 21 class pairs only)
+// lxx is written twice per entry (a,b) and (b,a); the L2 merges the partial lines before they reach HBM.
+#include <hip/hip_runtime.h>
+
+#include "h1_cost_dev.h"
+#include "ilqr_kernels.h"
+
+using namespace h1;
+
+namespace ilqr {
+
+#ifndef QUAD_WAVES
+#define QUAD_WAVES 2   // waves per SIMD requested from the register allocator
+#endif
+// -DQUAD_STAMP: diagnostic build only -- per-phase cycle counts of workgroup (0, 0) land in S.J[0..7]
+#ifdef QUAD_STAMP
+#define QSTAMP(k) { const long long tn_ = clock64(); if (t == 0 && b == 0 && lane == 0) S.J[k] = (double)(tn_ - qlast); qlast = tn_; }
+#else
+#define QSTAMP(k)
+#endif
+
+#define QMAXC 6   // at most: CoM pos, CoM vel, one functional per foot (swing: position / stance: velocity), 2 balance
+struct QuadCtx { int set, is_vel; double scale; double vec[3], til[3], Dv[4][3]; };
+// 20,2xx B of LDS: 8 waves per CU.  Phase-1/2 temporaries share storage with the per-joint vectors of phase 4.
+struct QuadLds {
+  double xp[H1_NX];                      // Pinocchio-ordered state (derivatives.cpp:12-24)
+  double R0[9], D[4][9];                 // base rotation (Eigen toRotationMatrix polynomial), dR/dquat_k
+  double zh[H1_NB][3], Om[H1_NB][3];     // joint axes and body angular velocities, pelvis frame
+  double beta[3][3], gamma[3][3], mfrac[3];
+  double w[3][H1_NB][3], dgam[3][H1_NB][3];
+  int on[3][H1_NB];
+  double Jc[3][3][H1_NX], Jv[3][3][H1_NX];   // d c / d x_p, d cdot / d x_p per point set
+  QuadCtx ctx[QMAXC];
+  double jr[2][H1_NX];                   // balance rows jr0, jr1 (jz, Jv0, Jv1 are rows of Jc[0] / Jv[0])
+  double us[H1_NU];
+  double gsum[QMAXC][3]; int gset[QMAXC], gvel[QMAXC]; int nctx, ng, has_bal; double bal[8];
+  double uJ[3][4], ur[3];                // upright pieces
+  unsigned anc[H1_NB];                   // bit j of anc[i]: body i is an ancestor of (or is) body j
+  union {
+    struct { double Rh[H1_NB][9], ph[H1_NB][3], mu[3][H1_NB], q[3][H1_NB][3]; } k;   // phases 1-2
+    struct { double tz[QMAXC][H1_NJ][3], Pp[QMAXC][H1_NJ][3]; } j;                    // phases 4-6: til_c x z_j, P'_j
+  } u;
+};
+static_assert(sizeof(QuadLds) <= 20480, "QuadLds must fit 8 waves per CU");
+
+__device__ __forceinline__ bool quad_selected(const DevState& S, int b, int mode) {
+  if (mode == MASK_ALL) return true;
+  if (mode == MASK_ACTIVE) return S.active[b] != 0;
+  return S.active[b] != 0 && S.need_retry[b] != 0;
+}
+DEVFN bool related_mask(const unsigned* anc, int ja, int jb, int& lo, int& hi) {
+  if ((anc[ja] >> jb) & 1u) { lo = ja; hi = jb; return true; }
+  if ((anc[jb] >> ja) & 1u) { lo = jb; hi = ja; return true; }
+  return false;
+}
+DEVFN double sel3(const double* v, int k) { return k == 0 ? v[0] : (k == 1 ? v[1] : v[2]); }   // no dynamic register index
+// d2R/dquat_k dquat_l: dR_dquat is linear in q, so this is dR_dquat(k, e_l)
+DEVFN void d2R_sel(int k, int l, double* D) {
+  const double q[4] = {l == 0 ? 1.0 : 0.0, l == 1 ? 1.0 : 0.0, l == 2 ? 1.0 : 0.0, l == 3 ? 1.0 : 0.0};
+  dR_dquat(k, q, D);
+}
+
+__global__ void __launch_bounds__(64, QUAD_WAVES) k_cost_quadratics(DevState S, ProblemDev P, int mode) {
+  const int t = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+  if (!quad_selected(S, b, mode)) return;
+  const int N = S.N;
+  const bool term = (t == N);
+  __shared__ QuadLds L;
+#ifdef QUAD_STAMP
+  long long qlast = clock64();
+#endif
+  const double* xg = S.xbar + ((size_t)b * (N + 1) + t) * H1_NX;
+
+  // ---- phase 0: state (Pinocchio slot order of the quaternion), ancestor masks
+  if (lane < H1_NX) {
+    const int src = (lane == 3) ? 4 : (lane == 4) ? 5 : (lane == 5) ? 6 : (lane == 6) ? 3 : lane;
+    L.xp[lane] = xg[src];
+  }
+  if (!term && lane < H1_NU) L.us[lane] = S.ubar[((size_t)b * N + t) * H1_NU + lane];
+  if (lane < H1_NB) {
+    unsigned m = 0;
+    if (lane == 0) m = (1u << H1_NB) - 1u;
+    else for (int j = 1; j < H1_NB; ++j) m |= (H1_ANC[lane - 1][j - 1] ? 1u : 0u) << j;
+    L.anc[lane] = m;
+  }
+  __syncthreads();
+  QSTAMP(0)
+
+  // ---- phase 1: base kinematics, lane = body; Rj = Rfix * Rot(axis, theta) (child -> parent)
+  {
+    double Rj[9];
+    int par = 0, ax = 0, dep = -1;
+    if (lane >= 1 && lane < H1_NB) {
+      par = H1_PARENT[lane]; ax = H1_AXIS[lane]; dep = H1_DEPTH[lane];
+      double sn, cs; sincos(L.xp[7 + lane - 1], &sn, &cs);
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        const double f0 = H1U_RFIX[lane][r][0], f1 = H1U_RFIX[lane][r][1], f2 = H1U_RFIX[lane][r][2];
+        Rj[3 * r + 0] = ax == 0 ? f0 : (ax == 1 ? f0 * cs - f2 * sn : f0 * cs + f1 * sn);
+        Rj[3 * r + 1] = ax == 0 ? f1 * cs + f2 * sn : (ax == 1 ? f1 : f1 * cs - f0 * sn);
+        Rj[3 * r + 2] = ax == 0 ? f2 * cs - f1 * sn : (ax == 1 ? f2 * cs + f0 * sn : f2);
+      }
+    } else if (lane == 0) {
+      const double qx = L.xp[3], qy = L.xp[4], qz = L.xp[5], qw = L.xp[6];
+      const double tx = 2 * qx, ty = 2 * qy, tz = 2 * qz;
+      const double twx = tx * qw, twy = ty * qw, twz = tz * qw, txx = tx * qx, txy = ty * qx, txz = tz * qx, tyy = ty * qy, tyz = tz * qy, tzz = tz * qz;
+      L.R0[0] = 1 - (tyy + tzz); L.R0[1] = txy - twz; L.R0[2] = txz + twy;
+      L.R0[3] = txy + twz; L.R0[4] = 1 - (txx + tzz); L.R0[5] = tyz - twx;
+      L.R0[6] = txz - twy; L.R0[7] = tyz + twx; L.R0[8] = 1 - (txx + tyy);
+#pragma unroll
+      for (int k = 0; k < 9; ++k) L.u.k.Rh[0][k] = (k % 4 == 0) ? 1.0 : 0.0;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { L.u.k.ph[0][k] = 0.0; L.zh[0][k] = 0.0; L.Om[0][k] = L.xp[H1_NQ + 3 + k]; }
+      // upright pieces (4 quaternion slots, derivatives.cpp:646-666 labelling)
+      const double ua = qx, ub = qy, uc = qz, ud = qw;
+      L.ur[0] = 2.0 * (ub * ud + ua * uc); L.ur[1] = 2.0 * (uc * ud - ua * ub); L.ur[2] = -2.0 * (ub * ub + uc * uc);
+      L.uJ[0][0] = 2 * uc; L.uJ[0][1] = 2 * ud; L.uJ[0][2] = 2 * ua; L.uJ[0][3] = 2 * ub;
+      L.uJ[1][0] = -2 * ub; L.uJ[1][1] = -2 * ua; L.uJ[1][2] = 2 * ud; L.uJ[1][3] = 2 * uc;
+      L.uJ[2][0] = 0.0; L.uJ[2][1] = -4 * ub; L.uJ[2][2] = -4 * uc; L.uJ[2][3] = 0.0;
+    } else if (lane >= 32 && lane < 36) {
+      dR_dquat(lane - 32, L.xp + 3, L.D[lane - 32]);
+    }
+    __syncthreads();
+    for (int d = 1; d <= 5; ++d) {
+      if (dep == d) {
+        const int i = lane, p = par;
+        double Rp[9], Ri[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) Rp[k] = L.u.k.Rh[p][k];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+          for (int c = 0; c < 3; ++c) Ri[3 * r + c] = Rp[3 * r] * Rj[c] + Rp[3 * r + 1] * Rj[3 + c] + Rp[3 * r + 2] * Rj[6 + c];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) L.u.k.Rh[i][k] = Ri[k];
+        const double px = H1U_POS[i][0], py = H1U_POS[i][1], pz = H1U_POS[i][2];
+        const double qd = L.xp[H1_NQ + 6 + i - 1];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          const double z = sel3(Ri + 3 * k, ax);
+          L.u.k.ph[i][k] = L.u.k.ph[p][k] + (Rp[3 * k] * px + Rp[3 * k + 1] * py + Rp[3 * k + 2] * pz);
+          L.zh[i][k] = z;
+          L.Om[i][k] = L.Om[p][k] + z * qd;
+        }
+      }
+      __syncthreads();
+    }
+  }
+  QSTAMP(1)
+
+  // ---- phase 2: point sets, lane = (set, body)
+  {
+    const int s = lane / H1_NB, i = lane - s * H1_NB;
+    const bool act = lane < 3 * H1_NB;
+    if (act) {
+      double mu;
+      if (s == 0) { double mtot = 0.0; for (int k = 0; k < H1_NB; ++k) mtot += H1U_MASS[k]; mu = H1U_MASS[i] / mtot; }
+      else mu = (i == ((s == 1) ? H1_EE_LEFT : H1_EE_RIGHT)) ? 1.0 : 0.0;
+      double ch[3] = {0.0, 0.0, 0.0};
+      if (s == 0) mv3(L.u.k.Rh[i], H1U_COM[i], ch);
+      L.u.k.mu[s][i] = mu;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) L.u.k.q[s][i][k] = mu * (L.u.k.ph[i][k] + ch[k]);
+    }
+    __syncthreads();
+    if (act) {
+      const unsigned m = L.anc[i];
+      double msub = 0.0, h[3] = {0.0, 0.0, 0.0};
+      for (int j = H1_NB - 1; j >= 0; --j)
+        if ((m >> j) & 1u) { msub += L.u.k.mu[s][j]; h[0] += L.u.k.q[s][j][0]; h[1] += L.u.k.q[s][j][1]; h[2] += L.u.k.q[s][j][2]; }
+      if (i == 0) {
+        L.mfrac[s] = msub; L.on[s][0] = 1;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { L.beta[s][k] = h[k]; L.w[s][0][k] = 0.0; L.dgam[s][0][k] = 0.0; }
+      } else {
+        L.on[s][i] = msub > 0.0 ? 1 : 0;
+        double r[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) r[k] = h[k] - msub * L.u.k.ph[i][k];
+        cross(L.zh[i], r, L.w[s][i]);
+      }
+    }
+    __syncthreads();
+    if (act) {
+      if (i == 0) {
+        const double* vb = L.xp + H1_NQ; const double* wb = L.xp + H1_NQ + 3;
+        double wxb[3]; cross(wb, L.beta[s], wxb);
+        double g[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) g[k] = L.mfrac[s] * vb[k] + wxb[k];
+        for (int j = 1; j < H1_NB; ++j) { const double qd = L.xp[H1_NQ + 6 + j - 1]; g[0] += qd * L.w[s][j][0]; g[1] += qd * L.w[s][j][1]; g[2] += qd * L.w[s][j][2]; }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) L.gamma[s][k] = g[k];
+      } else {
+        const unsigned m = L.anc[i] & ~(1u << i);   // strict descendants
+        double sv[3] = {0.0, 0.0, 0.0};
+        for (int j = H1_NB - 1; j >= 1; --j)
+          if ((m >> j) & 1u) { const double qd = L.xp[H1_NQ + 6 + j - 1]; sv[0] += qd * L.w[s][j][0]; sv[1] += qd * L.w[s][j][1]; sv[2] += qd * L.w[s][j][2]; }
+        double a3[3], b3[3]; cross(L.Om[i], L.w[s][i], a3); cross(L.zh[i], sv, b3);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) L.dgam[s][i][k] = a3[k] + b3[k];
+      }
+    }
+    __syncthreads();
+  }
+  QSTAMP(2)
+
+  // ---- phase 3: Jacobian columns of c and cdot, lane = coordinate (h1_cost_dev.h knot_jac_column)
+  if (lane < H1_NX) {
+    const int c = lane;
+    for (int s = 0; s < 3; ++s) {
+      double jc[3] = {0, 0, 0}, jv[3] = {0, 0, 0};
+      if (c < 3) { jc[0] = c == 0 ? L.mfrac[s] : 0.0; jc[1] = c == 1 ? L.mfrac[s] : 0.0; jc[2] = c == 2 ? L.mfrac[s] : 0.0; }
+      else if (c < 7) { mv3(L.D[c - 3], L.beta[s], jc); mv3(L.D[c - 3], L.gamma[s], jv); }
+      else if (c < H1_NQ) { const int j = c - 7 + 1; if (L.on[s][j]) { mv3(L.R0, L.w[s][j], jc); mv3(L.R0, L.dgam[s][j], jv); } }
+      else {
+        const int cv = c - H1_NQ;
+        double col[3] = {0, 0, 0};
+        if (cv < 3) { col[0] = cv == 0 ? L.mfrac[s] : 0.0; col[1] = cv == 1 ? L.mfrac[s] : 0.0; col[2] = cv == 2 ? L.mfrac[s] : 0.0; }
+        else if (cv < 6) {  // -[beta]x column
+          const int k = cv - 3; const double* bt = L.beta[s];
+          if (k == 0) { col[1] = -bt[2]; col[2] = bt[1]; } else if (k == 1) { col[0] = bt[2]; col[2] = -bt[0]; } else { col[0] = -bt[1]; col[1] = bt[0]; }
+        } else { const int j = cv - 6 + 1; if (L.on[s][j]) { col[0] = L.w[s][j][0]; col[1] = L.w[s][j][1]; col[2] = L.w[s][j][2]; } }
+        mv3(L.R0, col, jv);
+      }
+#pragma unroll
+      for (int r = 0; r < 3; ++r) { L.Jc[s][r][c] = jc[r]; L.Jv[s][r][c] = jv[r]; }
+    }
+  }
+  __syncthreads();
+  QSTAMP(3)
+
+  // ---- phase 4: the weighted functionals of the active terms (order = ilqr.cpp:154-181)
+  if (lane == 0) {
+    int n = 0, g = 0; L.has_bal = 0;
+    const int* st = P.stance + b * P.stance_stride + 2 * t;
+    auto push = [&](int set, int is_vel, double scale, const double* vec, bool grad) {
+      L.ctx[n].set = set; L.ctx[n].is_vel = is_vel; L.ctx[n].scale = scale;
+      for (int k = 0; k < 3; ++k) L.ctx[n].vec[k] = vec[k];
+      if (grad) { L.gset[g] = set; L.gvel[g] = is_vel; for (int k = 0; k < 3; ++k) L.gsum[g][k] = scale * vec[k]; ++g; }
+      ++n;
+    };
+    if (P.w_com > 0.0) {   // CoM position: w ||com - ref||^2
+      const double* ref = P.com_ref + b * P.com_ref_stride + t * 3;
+      double rb[3], e[3]; mv3(L.R0, L.beta[0], rb);
+      for (int k = 0; k < 3; ++k) e[k] = L.mfrac[0] * L.xp[k] + rb[k] - ref[k];
+      push(0, 0, 2.0 * P.w_com, e, true);
+    }
+    if (!term && P.w_com_vel > 0.0) {
+      const double* ref = P.com_vel_ref + b * P.com_vel_ref_stride + t * 3;
+      double v[3], e[3]; mv3(L.R0, L.gamma[0], v);
+      for (int k = 0; k < 3; ++k) e[k] = v[k] - ref[k];
+      push(0, 1, 2.0 * P.w_com_vel, e, true);
+    }
+    for (int ee = 0; ee < 2; ++ee) {
+      const int set = 1 + ee;
+      if (P.w_ee_pos > 0.0 && st[ee] != 1) {
+        const double* ref = P.ee_ref + b * P.ee_ref_stride + (t * 2 + ee) * 3;
+        double rb[3], e[3]; mv3(L.R0, L.beta[set], rb);
+        for (int k = 0; k < 3; ++k) e[k] = L.mfrac[set] * L.xp[k] + rb[k] - ref[k];
+        push(set, 0, 2.0 * P.w_ee_pos, e, true);
+      }
+      if (P.w_ee_vel > 0.0 && st[ee] == 1) {
+        double e[3]; mv3(L.R0, L.gamma[set], e);   // zero target (ilqr.cpp:734)
+        push(set, 1, 2.0 * P.w_ee_vel, e, true);
+      }
+    }
+    double ps[2];
+    if (P.w_balance > 0.0 && support_point(P, b, t, ps)) {
+      double rb[3], vc[3]; mv3(L.R0, L.beta[0], rb); mv3(L.R0, L.gamma[0], vc);
+      double com[3]; for (int k = 0; k < 3; ++k) com[k] = L.mfrac[0] * L.xp[k] + rb[k];
+      const double gg = 9.81;
+      const double om = sqrt(com[2] / gg), om1 = 1.0 / (2.0 * gg * om), om2 = -1.0 / (4.0 * gg * gg * om * om * om);
+      const double r0 = com[0] + vc[0] * om - ps[0], r1 = com[1] + vc[1] * om - ps[1];
+      const double rv = r0 * vc[0] + r1 * vc[1];
+      L.bal[0] = r0; L.bal[1] = r1; L.bal[2] = om; L.bal[3] = om1; L.bal[4] = om2; L.bal[5] = vc[0]; L.bal[6] = vc[1]; L.bal[7] = rv;
+      L.has_bal = 1;
+      const double mu[3] = {r0, r1, om1 * rv}, nu[3] = {om * r0, om * r1, 0.0};
+      push(0, 0, P.w_balance, mu, false);
+      push(0, 1, P.w_balance, nu, false);
+    }
+    L.nctx = n; L.ng = g;
+  }
+  __syncthreads();
+  const int nctx = L.nctx, ng = L.ng, has_bal = L.has_bal;
+  if (lane < nctx) {
+    QuadCtx& C = L.ctx[lane];
+    mtv3(L.R0, C.vec, C.til);
+    for (int k = 0; k < 4; ++k) mtv3(L.D[k], C.vec, C.Dv[k]);
+  }
+  if (has_bal && lane < H1_NX) {
+    const int a = lane;
+    const double om = L.bal[2], om1 = L.bal[3];
+    const double jz = L.Jc[0][2][a];
+    L.jr[0][a] = L.Jc[0][0][a] + om * L.Jv[0][0][a] + L.bal[5] * om1 * jz;
+    L.jr[1][a] = L.Jc[0][1][a] + om * L.Jv[0][1][a] + L.bal[6] * om1 * jz;
+  }
+  __syncthreads();   // (also: the phase-1/2 temporaries are dead, their storage becomes tz / Pp)
+  for (int e = lane; e < nctx * H1_NJ; e += 64) {
+    const int c = e / H1_NJ, j = 1 + e - c * H1_NJ;
+    const QuadCtx& C = L.ctx[c];
+    double tz[3]; cross(C.til, L.zh[j], tz);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) L.u.j.tz[c][j - 1][k] = tz[k];
+    if (C.is_vel) {
+      double tO[3], p1[3], p2[3]; cross(C.til, L.Om[j], tO); cross(tO, L.zh[j], p1); cross(tz, L.Om[j], p2);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) L.u.j.Pp[c][j - 1][k] = p1[k] - p2[k];
+    }
+  }
+  __syncthreads();
+  QSTAMP(4)
+
+  const double* Qd = term ? P.Qf : P.Q;
+  const double* xr = P.x_ref + b * P.x_ref_stride + t * H1_NX;
+
+  // ---- phase 5: gradient lx (lane = coordinate), lu / luu
+  if (lane < H1_NX) {
+    const int a = lane;
+    double g = Qd[a] * (xg[a] - xr[a]);   // Q acts on the MuJoCo-ordered state
+    for (int i = 0; i < ng; ++i) {
+      const double (*J)[H1_NX] = L.gvel[i] ? L.Jv[L.gset[i]] : L.Jc[L.gset[i]];
+      g += J[0][a] * L.gsum[i][0] + J[1][a] * L.gsum[i][1] + J[2][a] * L.gsum[i][2];
+    }
+    if (P.w_upright > 0.0 && a >= 3 && a < 7) g += P.w_upright * (L.uJ[0][a - 3] * L.ur[0] + L.uJ[1][a - 3] * L.ur[1] + L.uJ[2][a - 3] * L.ur[2]);
+    if (has_bal) g += P.w_balance * (L.jr[0][a] * L.bal[0] + L.jr[1][a] * L.bal[1]);
+    if (a >= 7 && a < H1_NQ) {
+      double lo, hi; limit_bounds(H1_JRANGE[a - 7], lo, hi);
+      const double q = L.xp[a];
+      if (q > hi) g += 2.0 * P.w_joint * (q - hi);
+      if (q < lo) g += -2.0 * P.w_joint * (lo - q);
+    }
+    S.lx[((size_t)b * (N + 1) + t) * H1_NX + a] = g;
+  }
+  if (!term && lane < H1_NU) {
+    const double* ur_ = P.u_ref + b * P.u_ref_stride + t * H1_NU;
+    const double u = L.us[lane];
+    double g = P.R[lane] * (u - ur_[lane]), h = P.R[lane];
+    double lo, hi; limit_bounds(H1_CTRLRANGE[lane], lo, hi);
+    if (u > hi) g += 2.0 * P.w_ctrl * (u - hi);
+    if (u < lo) g += -2.0 * P.w_ctrl * (lo - u);
+    if (u > hi || u < lo) h += 2.0 * P.w_ctrl;
+    S.lu[((size_t)b * N + t) * H1_NU + lane] = g;
+    S.luu[((size_t)b * N + t) * H1_NU + lane] = h;
+  }
+  QSTAMP(5)
+
+  // ---- phase 6: Hessian lxx, block by block of the coordinate classes
+  double* Hg = S.lxx + ((size_t)b * (N + 1) + t) * H1_NX * H1_NX;
+  // first-order (Gauss-Newton) part common to every entry: sum_i scale_i J_i^T J_i, then the balance rows
+  auto dense = [&](int a, int bb) -> double {
+    double h = 0.0;
+    for (int i = 0; i < ng; ++i) {
+      const double (*J)[H1_NX] = L.gvel[i] ? L.Jv[L.gset[i]] : L.Jc[L.gset[i]];
+      h += L.ctx[i].scale * (J[0][a] * J[0][bb] + J[1][a] * J[1][bb] + J[2][a] * J[2][bb]);
+    }
+    return h;
+  };
+  auto balance = [&](int a, int bb) -> double {
+    const double om1 = L.bal[3], om2 = L.bal[4];
+    const double jza = L.Jc[0][2][a], jzb = L.Jc[0][2][bb];
+    double v = L.jr[0][a] * L.jr[0][bb] + L.jr[1][a] * L.jr[1][bb];
+    v += om1 * (L.bal[0] * (L.Jv[0][0][a] * jzb + jza * L.Jv[0][0][bb]) + L.bal[1] * (L.Jv[0][1][a] * jzb + jza * L.Jv[0][1][bb]));
+    v += L.bal[7] * om2 * jza * jzb;
+    return P.w_balance * v;
+  };
+  auto store = [&](int a, int bb, double h) {
+    Hg[a * H1_NX + bb] = h;
+    if (a != bb) Hg[bb * H1_NX + a] = h;
+  };
+  // triangular index -> (i, j), i <= j < n
+  auto tri = [](int idx, int n, int& i, int& j) {
+    int a = (int)((2 * n + 1 - sqrt((double)(2 * n + 1) * (2 * n + 1) - 8.0 * idx)) * 0.5);
+    while ((a + 1) * n - ((a + 1) * a) / 2 <= idx) ++a;
+    while (a * n - (a * (a - 1)) / 2 > idx) --a;
+    i = a; j = a + (idx - (a * n - (a * (a - 1)) / 2));
+  };
+  const int Q0 = 3, T0 = 7, V0 = H1_NQ, W0 = H1_NQ + 3, D0 = H1_NQ + 6, NJ = H1_NJ;
+
+  // (p, *) rows 0..2 and (v_b | omega_b, v_b | omega_b | thetadot) rows 26..31: first-order part only
+  for (int idx = lane; idx < 150 + 135; idx += 64) {
+    int a, bb;
+    if (idx < 150) { a = idx < 51 ? 0 : (idx < 101 ? 1 : 2); bb = a + idx - (a == 0 ? 0 : (a == 1 ? 51 : 101)); }
+    else { int r, c; tri(idx - 150, 25, r, c); a = V0 + r; bb = V0 + c; }
+    double h = (a == bb) ? Qd[a] : 0.0;
+    h += dense(a, bb);
+    if (has_bal) h += balance(a, bb);
+    store(a, bb, h);
+  }
+  // (thetadot, thetadot) and (theta, v_b): first-order part only
+  for (int idx = lane; idx < 190 + 57; idx += 64) {
+    int a, bb;
+    if (idx < 190) { int r, c; tri(idx, NJ, r, c); a = D0 + r; bb = D0 + c; }
+    else { const int e = idx - 190; a = T0 + e / 3; bb = V0 + e % 3; }
+    double h = (a == bb) ? Qd[a] : 0.0;
+    h += dense(a, bb);
+    if (has_bal) h += balance(a, bb);
+    store(a, bb, h);
+  }
+  // (quat, quat): d2R/dq2 terms + upright
+  if (lane < 10) {
+    int ka, kb; tri(lane, 4, ka, kb);
+    const int a = Q0 + ka, bb = Q0 + kb;
+    double h = (a == bb) ? Qd[a] : 0.0;
+    h += dense(a, bb);
+    double D2[9]; d2R_sel(ka, kb, D2);
+    for (int c = 0; c < nctx; ++c) {
+      const QuadCtx& C = L.ctx[c];
+      double tv[3]; mv3(D2, C.is_vel ? L.gamma[C.set] : L.beta[C.set], tv);
+      h += C.scale * dot3(C.vec, tv);
+    }
+    if (P.w_upright > 0.0) {
+      const int i = ka, j = kb;
+      double v = L.uJ[0][i] * L.uJ[0][j] + L.uJ[1][i] * L.uJ[1][j] + L.uJ[2][i] * L.uJ[2][j];
+      if ((i == 0 && j == 2) || (i == 1 && j == 3)) v += 2.0 * L.ur[0];
+      if (i == 2 && j == 3) v += 2.0 * L.ur[1];
+      if (i == 0 && j == 1) v += -2.0 * L.ur[1];
+      if ((i == 1 && j == 1) || (i == 2 && j == 2)) v += -4.0 * L.ur[2];
+      h += P.w_upright * v;
+    }
+    if (has_bal) h += balance(a, bb);
+    store(a, bb, h);
+  }
+  // (quat, theta) and (quat, thetadot): Dv . w / Dv . dgam
+  for (int idx = lane; idx < 2 * 4 * NJ; idx += 64) {
+    const bool isd = idx >= 4 * NJ;
+    const int e = isd ? idx - 4 * NJ : idx;
+    const int k = e / NJ, j = 1 + e % NJ;
+    const int a = Q0 + k, bb = (isd ? D0 : T0) + j - 1;
+    double h = dense(a, bb);
+    for (int c = 0; c < nctx; ++c) {
+      const QuadCtx& C = L.ctx[c];
+      if (!L.on[C.set][j]) continue;
+      if (!isd) h += C.scale * dot3(C.Dv[k], C.is_vel ? L.dgam[C.set][j] : L.w[C.set][j]);
+      else if (C.is_vel) h += C.scale * dot3(C.Dv[k], L.w[C.set][j]);
+    }
+    if (has_bal) h += balance(a, bb);
+    store(a, bb, h);
+  }
+  // (quat, v_b) and (quat, omega_b)
+  if (lane < 24) {
+    const bool isw = lane >= 12;
+    const int e = isw ? lane - 12 : lane;
+    const int k = e / 3, cc = e % 3;
+    const int a = Q0 + k, bb = (isw ? W0 : V0) + cc;
+    double h = dense(a, bb);
+    for (int c = 0; c < nctx; ++c) {
+      const QuadCtx& C = L.ctx[c];
+      if (!C.is_vel) continue;
+      if (!isw) h += C.scale * C.Dv[k][cc] * L.mfrac[C.set];
+      else { double tv[3]; cross(L.beta[C.set], C.Dv[k], tv); h += C.scale * sel3(tv, cc); }   // Dv . (-[beta]x e_c) = (beta x Dv)_c
+    }
+    if (has_bal) h += balance(a, bb);
+    store(a, bb, h);
+  }
+  // (theta, theta) upper triangle and (theta, thetadot) full block: related joints only
+  for (int idx = lane; idx < 190 + NJ * NJ; idx += 64) {
+    const bool isd = idx >= 190;
+    int ja, jb;
+    if (!isd) { int r, c; tri(idx, NJ, r, c); ja = 1 + r; jb = 1 + c; }
+    else { const int e = idx - 190; ja = 1 + e / NJ; jb = 1 + e % NJ; }
+    const int a = T0 + ja - 1, bb = (isd ? D0 : T0) + jb - 1;
+    double h = (a == bb) ? Qd[a] : 0.0;
+    h += dense(a, bb);
+    int lo, hi;
+    if (related_mask(L.anc, ja, jb, lo, hi)) {
+      for (int c = 0; c < nctx; ++c) {
+        const QuadCtx& C = L.ctx[c];
+        if (!L.on[C.set][ja] || !L.on[C.set][jb]) continue;
+        if (isd && !C.is_vel) continue;
+        double v = dot3(L.u.j.tz[c][lo - 1], L.w[C.set][hi]);
+        if (!isd && C.is_vel) v = dot3(L.u.j.Pp[c][lo - 1], L.w[C.set][hi]) + dot3(L.u.j.tz[c][lo - 1], L.dgam[C.set][hi]);
+        h += C.scale * v;
+      }
+    }
+    if (has_bal) h += balance(a, bb);
+    if (a == bb) {
+      double lo_, hi_; limit_bounds(H1_JRANGE[a - 7], lo_, hi_);
+      const double q = L.xp[a];
+      if (q > hi_ || q < lo_) h += 2.0 * P.w_joint;
+    }
+    store(a, bb, h);
+  }
+  // (theta, omega_b): (w_j x til)_c
+  if (lane < 3 * NJ) {
+    const int ja = 1 + lane / 3, cc = lane % 3;
+    const int a = T0 + ja - 1, bb = W0 + cc;
+    double h = dense(a, bb);
+    for (int c = 0; c < nctx; ++c) {
+      const QuadCtx& C = L.ctx[c];
+      if (!C.is_vel || !L.on[C.set][ja]) continue;
+      double tv[3]; cross(L.w[C.set][ja], C.til, tv);
+      h += C.scale * sel3(tv, cc);
+    }
+    if (has_bal) h += balance(a, bb);
+    store(a, bb, h);
+  }
+  QSTAMP(6)
+}
+
+void launch_cost_quadratics(const DevState& S, const ProblemDev& P, int mode, hipStream_t st) {
+  hipLaunchKernelGGL(k_cost_quadratics, dim3(S.N + 1, S.B), dim3(64), 0, st, S, P, mode);
+}
+
+}  // namespace ilqr

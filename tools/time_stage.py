@@ -26,6 +26,12 @@ for _ in range(reps):
     fn()
 dt = (time.perf_counter() - t0) / reps
 print("%s: %.3f ms per call (host-timed, includes sync)  K checksum %.9e" % (stage, dt * 1e3, float(np.abs(s.gains_K()[::97]).sum())))
+if os.environ.get("ILQR_QSTAMPS"):
+    names = ["load x,u", "base_kin (lane 0)", "point sets (3 lanes)", "jac columns", "contexts (lane 0)", "gradient", "hessian"]
+    st = s.cost()[:7]
+    for nme, v in zip(names, st):
+        print("  %-24s %10.0f cycles  %5.1f %%" % (nme, v, 100 * v / st.sum()))
+    print("  total %.0f cycles" % st.sum())
 if os.environ.get("ILQR_STAMPS"):
     names = ["regs<-staging", "sync", "P1", "P2", "Qx/Qu", "sync", "P3", "P4+P5", "sync", "chol+Linv (wave0)", "sync", "P6a+P6b", "sync", "P7+Vx", "sync", "-"]
     st = s.cost()[:16]
