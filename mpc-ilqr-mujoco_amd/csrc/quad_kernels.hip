@@ -14,6 +14,7 @@
 #include <hip/hip_runtime.h>
 
 #include "h1_cost_dev.h"
+#include "h1_model_constexpr.h"
 #include "ilqr_kernels.h"
 
 using namespace h1;
@@ -29,6 +30,16 @@ namespace ilqr {
 #else
 #define QSTAMP(k)
 #endif
+
+// bit j of QANC.m[i]: body i is an ancestor of (or is) body j -- built at compile time from the model table
+struct QAncTable { unsigned m[H1_NB]; };
+constexpr QAncTable make_anc_table() {
+  QAncTable T{};
+  T.m[0] = (1u << H1_NB) - 1u;
+  for (int i = 1; i < H1_NB; ++i) { unsigned v = 0; for (int j = 1; j < H1_NB; ++j) v |= (h1c::C_ANC[i - 1][j - 1] ? 1u : 0u) << j; T.m[i] = v; }
+  return T;
+}
+__constant__ static const QAncTable QANC = make_anc_table();
 
 #define QMAXC 6   // at most: CoM pos, CoM vel, one functional per foot (swing: position / stance: velocity), 2 balance
 struct QuadCtx { int set, is_vel; double scale; double vec[3], til[3], Dv[4][3]; };
@@ -52,6 +63,7 @@ struct QuadLds {
     struct { double tz[QMAXC][H1_NJ][3], Pp[QMAXC][H1_NJ][3]; } j;                    // phases 4-6: til_c x z_j, P'_j
   } u;
 };
+static_assert(H1_NB * 3 >= H1_NX, "balance row m aliases Om");
 static_assert(sizeof(QuadLds) <= 20480, "QuadLds must fit 8 waves per CU");
 
 __device__ __forceinline__ bool quad_selected(const DevState& S, int b, int mode) {
@@ -88,12 +100,7 @@ __global__ void __launch_bounds__(64, QUAD_WAVES) k_cost_quadratics(DevState S, 
     L.xp[lane] = xg[src];
   }
   if (!term && lane < H1_NU) L.us[lane] = S.ubar[((size_t)b * N + t) * H1_NU + lane];
-  if (lane < H1_NB) {
-    unsigned m = 0;
-    if (lane == 0) m = (1u << H1_NB) - 1u;
-    else for (int j = 1; j < H1_NB; ++j) m |= (H1_ANC[lane - 1][j - 1] ? 1u : 0u) << j;
-    L.anc[lane] = m;
-  }
+  if (lane < H1_NB) L.anc[lane] = QANC.m[lane];
   __syncthreads();
   QSTAMP(0)
 
@@ -320,6 +327,9 @@ __global__ void __launch_bounds__(64, QUAD_WAVES) k_cost_quadratics(DevState S, 
     }
   }
   __syncthreads();
+  double* const balm = &L.Om[0][0];   // Om is dead from here on: its storage takes the balance row m = om1 (r0 Jv0 + r1 Jv1) + rv om2 jz / 2
+  if (has_bal && lane < H1_NX) balm[lane] = L.bal[3] * (L.bal[0] * L.Jv[0][0][lane] + L.bal[1] * L.Jv[0][1][lane]) + 0.5 * L.bal[7] * L.bal[4] * L.Jc[0][2][lane];
+  __syncthreads();
   QSTAMP(4)
 
   const double* Qd = term ? P.Qf : P.Q;
@@ -359,20 +369,23 @@ __global__ void __launch_bounds__(64, QUAD_WAVES) k_cost_quadratics(DevState S, 
   // ---- phase 6: Hessian lxx, block by block of the coordinate classes
   double* Hg = S.lxx + ((size_t)b * (N + 1) + t) * H1_NX * H1_NX;
   // first-order (Gauss-Newton) part common to every entry: sum_i scale_i J_i^T J_i, then the balance rows
+  const double* Jrow[4]; double Jscale[4];   // at most 4 functionals carry a Gauss-Newton part (CoM pos / vel, one per foot)
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int ii = i < ng ? i : 0;
+    Jrow[i] = L.gvel[ii] ? &L.Jv[L.gset[ii]][0][0] : &L.Jc[L.gset[ii]][0][0];
+    Jscale[i] = i < ng ? L.ctx[ii].scale : 0.0;
+  }
   auto dense = [&](int a, int bb) -> double {
     double h = 0.0;
-    for (int i = 0; i < ng; ++i) {
-      const double (*J)[H1_NX] = L.gvel[i] ? L.Jv[L.gset[i]] : L.Jc[L.gset[i]];
-      h += L.ctx[i].scale * (J[0][a] * J[0][bb] + J[1][a] * J[1][bb] + J[2][a] * J[2][bb]);
-    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (i < ng) { const double* J = Jrow[i]; h += Jscale[i] * (J[a] * J[bb] + J[H1_NX + a] * J[H1_NX + bb] + J[2 * H1_NX + a] * J[2 * H1_NX + bb]); }
     return h;
   };
+  // balance: jr0 jr0' + jr1 jr1' + om1 (r0 (Jv0 jz' + jz Jv0') + r1 (Jv1 jz' + jz Jv1')) + rv om2 jz jz' = ... + jz m' + m jz'
   auto balance = [&](int a, int bb) -> double {
-    const double om1 = L.bal[3], om2 = L.bal[4];
-    const double jza = L.Jc[0][2][a], jzb = L.Jc[0][2][bb];
-    double v = L.jr[0][a] * L.jr[0][bb] + L.jr[1][a] * L.jr[1][bb];
-    v += om1 * (L.bal[0] * (L.Jv[0][0][a] * jzb + jza * L.Jv[0][0][bb]) + L.bal[1] * (L.Jv[0][1][a] * jzb + jza * L.Jv[0][1][bb]));
-    v += L.bal[7] * om2 * jza * jzb;
+    const double v = L.jr[0][a] * L.jr[0][bb] + L.jr[1][a] * L.jr[1][bb] + L.Jc[0][2][a] * balm[bb] + balm[a] * L.Jc[0][2][bb];
     return P.w_balance * v;
   };
   auto store = [&](int a, int bb, double h) {
@@ -381,7 +394,7 @@ __global__ void __launch_bounds__(64, QUAD_WAVES) k_cost_quadratics(DevState S, 
   };
   // triangular index -> (i, j), i <= j < n
   auto tri = [](int idx, int n, int& i, int& j) {
-    int a = (int)((2 * n + 1 - sqrt((double)(2 * n + 1) * (2 * n + 1) - 8.0 * idx)) * 0.5);
+    int a = (int)((2 * n + 1 - sqrtf((float)((2 * n + 1) * (2 * n + 1) - 8 * idx))) * 0.5f);   // exact integers in fp32; corrected below
     while ((a + 1) * n - ((a + 1) * a) / 2 <= idx) ++a;
     while (a * n - (a * (a - 1)) / 2 > idx) --a;
     i = a; j = a + (idx - (a * n - (a * (a - 1)) / 2));
@@ -415,7 +428,9 @@ __global__ void __launch_bounds__(64, QUAD_WAVES) k_cost_quadratics(DevState S, 
     double h = (a == bb) ? Qd[a] : 0.0;
     h += dense(a, bb);
     double D2[9]; d2R_sel(ka, kb, D2);
-    for (int c = 0; c < nctx; ++c) {
+#pragma unroll
+    for (int c = 0; c < QMAXC; ++c) {
+      if (c >= nctx) break;
       const QuadCtx& C = L.ctx[c];
       double tv[3]; mv3(D2, C.is_vel ? L.gamma[C.set] : L.beta[C.set], tv);
       h += C.scale * dot3(C.vec, tv);
@@ -439,7 +454,9 @@ __global__ void __launch_bounds__(64, QUAD_WAVES) k_cost_quadratics(DevState S, 
     const int k = e / NJ, j = 1 + e % NJ;
     const int a = Q0 + k, bb = (isd ? D0 : T0) + j - 1;
     double h = dense(a, bb);
-    for (int c = 0; c < nctx; ++c) {
+#pragma unroll
+    for (int c = 0; c < QMAXC; ++c) {
+      if (c >= nctx) break;
       const QuadCtx& C = L.ctx[c];
       if (!L.on[C.set][j]) continue;
       if (!isd) h += C.scale * dot3(C.Dv[k], C.is_vel ? L.dgam[C.set][j] : L.w[C.set][j]);
@@ -455,7 +472,9 @@ __global__ void __launch_bounds__(64, QUAD_WAVES) k_cost_quadratics(DevState S, 
     const int k = e / 3, cc = e % 3;
     const int a = Q0 + k, bb = (isw ? W0 : V0) + cc;
     double h = dense(a, bb);
-    for (int c = 0; c < nctx; ++c) {
+#pragma unroll
+    for (int c = 0; c < QMAXC; ++c) {
+      if (c >= nctx) break;
       const QuadCtx& C = L.ctx[c];
       if (!C.is_vel) continue;
       if (!isw) h += C.scale * C.Dv[k][cc] * L.mfrac[C.set];
@@ -475,7 +494,9 @@ __global__ void __launch_bounds__(64, QUAD_WAVES) k_cost_quadratics(DevState S, 
     h += dense(a, bb);
     int lo, hi;
     if (related_mask(L.anc, ja, jb, lo, hi)) {
-      for (int c = 0; c < nctx; ++c) {
+#pragma unroll
+      for (int c = 0; c < QMAXC; ++c) {
+        if (c >= nctx) break;
         const QuadCtx& C = L.ctx[c];
         if (!L.on[C.set][ja] || !L.on[C.set][jb]) continue;
         if (isd && !C.is_vel) continue;
@@ -497,7 +518,9 @@ __global__ void __launch_bounds__(64, QUAD_WAVES) k_cost_quadratics(DevState S, 
     const int ja = 1 + lane / 3, cc = lane % 3;
     const int a = T0 + ja - 1, bb = W0 + cc;
     double h = dense(a, bb);
-    for (int c = 0; c < nctx; ++c) {
+#pragma unroll
+    for (int c = 0; c < QMAXC; ++c) {
+      if (c >= nctx) break;
       const QuadCtx& C = L.ctx[c];
       if (!C.is_vel || !L.on[C.set][ja]) continue;
       double tv[3]; cross(L.w[C.set][ja], C.til, tv);
