@@ -91,14 +91,24 @@ __global__ void __launch_bounds__(64) k_last_step_r(DevState S, ProblemDev P) {
   for (int i = 0; i < H1_NX; ++i) S.xbar[((size_t)b * (N + 1) + N) * H1_NX + i] = xn[i];
 }
 
-// thread per (rollout, alpha); candidates kept in HBM, k_control copies the accepted one
+// thread per (rollout, alpha), the 8 alphas of a rollout in 8 adjacent lanes; candidates kept in HBM, k_control
+// copies the accepted one.  The feedback K (x - xbar) is evaluated cooperatively by the 8 lanes of a rollout:
+// lane a owns the columns j = a, a+8, ... of K_t (one fully used 64-byte line per row and load instruction, every
+// element of K fetched once per rollout instead of once per alpha), multiplies them with the state deviations
+// of all 8 candidates (exchanged through the LDS columns the dynamics step is not using at that point) and the
+// 8 x 8 partial sums are reduce-scattered over the lanes with three exchange steps.
 __constant__ double ALPHAS_R[8] = {1.0, 0.8, 0.6, 0.4, 0.2, 0.1, 0.05, 0.01};
+__device__ __forceinline__ double shfl_xor_f64(double v, int mask) {
+  const int lo = __shfl_xor(__double2loint(v), mask), hi = __shfl_xor(__double2hiint(v), mask);
+  return __hiloint2double(hi, lo);
+}
 __global__ void __launch_bounds__(64) k_line_search_r(DevState S, ProblemDev P, int mode) {
   extern __shared__ double lds[];
   const int gid = blockIdx.x * blockDim.x + threadIdx.x;
   const int b = gid >> 3, ai = gid & 7;
   if (b >= S.B || !sel(S, b, mode)) return;
-  const h1r::LaneLds L{lds, 64, (int)threadIdx.x};
+  const int lane = threadIdx.x, grp = lane & ~7;
+  const h1r::LaneLds L{lds, 64, lane};
   const int N = S.N, n = H1_NX, m = H1_NU;
   const double alpha = ALPHAS_R[ai];
   const double* xb = S.xbar + (size_t)b * (N + 1) * n;
@@ -107,6 +117,7 @@ __global__ void __launch_bounds__(64) k_line_search_r(DevState S, ProblemDev P, 
   const double* kg = S.kff + (size_t)b * N * m;
   double* xc = S.xcand + ((size_t)b * 8 + ai) * (N + 1) * n;
   double* uc = S.ucand + ((size_t)b * 8 + ai) * N * m;
+  const bool b4 = (ai & 4) != 0, b2 = (ai & 2) != 0, b1 = (ai & 1) != 0;
   // register budget: only x[51] and u[19] stay live across the dynamics step (no dx / x_next copies)
   double x[H1_NX], u[H1_NU];
 #pragma unroll
@@ -114,15 +125,49 @@ __global__ void __launch_bounds__(64) k_line_search_r(DevState S, ProblemDev P, 
   double c = 0.0;
   for (int t = 0; t < N; ++t) {
     const double* xbt = xb + t * n;
-    for (int i = 0; i < H1_NU; ++i) {   // u = ubar + alpha k + K (x - xbar)   (ilqr.cpp:332-333)
-      double s = 0.0;
-      const double* Kr = Kg + ((size_t)t * m + i) * n;
+    // ---- u = ubar + alpha k + K (x - xbar)   (ilqr.cpp:332-333)
+    // state deviations of this candidate -> LDS slot j of this lane's column
 #pragma unroll
-      for (int j = 0; j < H1_NX; ++j) s += Kr[j] * (x[j] - xbt[j]);
+    for (int j = 0; j < H1_NX; ++j) lds[j * 64 + lane] = x[j] - xbt[j];
+    __syncthreads();
+    double dxs[7][8];   // dx_{8q + ai} of the 8 candidates of this rollout
+#pragma unroll
+    for (int q = 0; q < 7; ++q) {
+      const int j = 8 * q + ai;
+#pragma unroll
+      for (int a = 0; a < 8; ++a) dxs[q][a] = (j < H1_NX) ? lds[j * 64 + grp + a] : 0.0;
+    }
+    __syncthreads();   // the dynamics step below reuses these LDS columns
+#ifdef LS_NOK   // ablation build: no feedback term
+    for (int i = 0; i < H1_NU; ++i) { u[i] = ub[t * m + i] + alpha * kg[t * m + i] + dxs[i % 7][i % 8]; uc[t * m + i] = u[i]; }
+#else
+    for (int i = 0; i < H1_NU; ++i) {
+      const double* Kr = Kg + ((size_t)t * m + i) * n;
+      double kv[7];
+#pragma unroll
+      for (int q = 0; q < 7; ++q) { const int j = 8 * q + ai; kv[q] = (j < H1_NX) ? Kr[j] : 0.0; }
+      double acc[8];
+#pragma unroll
+      for (int a = 0; a < 8; ++a) acc[a] = 0.0;
+#pragma unroll
+      for (int q = 0; q < 7; ++q)
+#pragma unroll
+        for (int a = 0; a < 8; ++a) acc[a] += kv[q] * dxs[q][a];
+      // reduce-scatter: lane a ends up with sum over the 8 lanes of acc[a]
+      double r1[4], r2[2];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { const double keep = b4 ? acc[4 + q] : acc[q], send = b4 ? acc[q] : acc[4 + q]; r1[q] = keep + shfl_xor_f64(send, 4); }
+#pragma unroll
+      for (int q = 0; q < 2; ++q) { const double keep = b2 ? r1[2 + q] : r1[q], send = b2 ? r1[q] : r1[2 + q]; r2[q] = keep + shfl_xor_f64(send, 2); }
+      const double keep = b1 ? r2[1] : r2[0], send = b1 ? r2[0] : r2[1];
+      const double s = keep + shfl_xor_f64(send, 1);
       u[i] = ub[t * m + i] + alpha * kg[t * m + i] + s;
       uc[t * m + i] = u[i];
     }
+#endif
+#ifndef LS_NOCOST
     c += knot_cost_t(P, b, t, x, u, ComReg());
+#endif
     h1r::step(x, u, P.dyn.h, P.dyn.g, L, x);       // in place: every read of x precedes the integrator's writes
 #pragma unroll
     for (int i = 0; i < H1_NX; ++i) xc[(t + 1) * n + i] = x[i];

@@ -76,24 +76,39 @@ __global__ void __launch_bounds__(64) k_step(int count, const double* x, const d
 //                  quantities (velocities, accelerations, forces, articulated-body U / D / pelvis inverse).
 //   k_lin_tangent: one wave per knot; lanes = columns of Minv (unit-force sweeps) and tangent directions
 //                  (tangent RNEA sweeps), then lanes = Jacobian columns.
+// -DLIN_STAMP: diagnostic build only -- per-phase cycle counts of workgroup (0, 0) land in S.J[0..7]
+#ifdef LIN_STAMP
+#define LSTAMP(k) { const long long tn_ = clock64(); if (t == 0 && b == 0 && lane == 0) S.J[k] = (double)(tn_ - qlast); qlast = tn_; }
+#else
+#define LSTAMP(k)
+#endif
 __global__ void __launch_bounds__(64, LINT_WAVES) k_lin_tangent(DevState S, ProblemDev P, int mode) {
   const int t = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
   if (!selected(S, b, mode)) return;
   __shared__ LinShared L;
+#ifdef LIN_STAMP
+  long long qlast = clock64();
+#endif
   const size_t knot = (size_t)b * S.N + t;
   lin_load_dump(L, S.lin_dump + knot * LinDumpG_SIZE, lane);
   if (lane < H1_NX) L.x[lane] = S.xbar[((size_t)b * (S.N + 1) + t) * H1_NX + lane];
   if (lane < H1_NU) L.u[lane] = S.ubar[((size_t)b * S.N + t) * H1_NU + lane];
   if (lane == 0) L.h = P.dyn.h;
   __syncthreads();
+  LSTAMP(0)
   if (lane == 0) lin_accumulate_forces(L);
   __syncthreads();
+  LSTAMP(1)
   if (lane == 0) lin_prologue(L);
+  LSTAMP(2)
   lin_minv_lane(L, lane);       // lanes 0..24: columns of Minv
+  LSTAMP(3)
   lin_tangent_lane(L, lane);    // lanes 0..46: tangent generalized forces
   __syncthreads();
+  LSTAMP(4)
   lin_apply_minv_lane(L, lane);
   __syncthreads();
+  LSTAMP(5)
   double col[H1_NX];
   double* Ag = S.A + knot * H1_NX * H1_NX;
   double* Bg = S.Bm + knot * H1_NX * H1_NU;
@@ -107,6 +122,7 @@ __global__ void __launch_bounds__(64, LINT_WAVES) k_lin_tangent(DevState S, Prob
 #pragma unroll
     for (int r = 0; r < H1_NX; ++r) Bg[r * H1_NU + lane] = col[r];
   }
+  LSTAMP(6)
 }
 
 // Reference-style forward differences (RobotUtils::linearizeDynamicsFD, robot_utils.cpp:120-160):
