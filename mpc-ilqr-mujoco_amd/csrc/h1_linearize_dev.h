@@ -29,6 +29,7 @@ struct LinShared {
   double Minv[H1_NV][H1_NV];     // d qacc / d tau in MuJoCo coordinates
   double dT[H1_NV][LIN_LD];      // tangent generalized forces, then d qacc / d direction
   double du[H1_NB][32];          // Minv sweeps: per-lane joint force increments
+  double Iv[H1_NB][6];           // I_i v_i (momentum of body i), shared by every tangent direction
   double x[H1_NX], u[H1_NU];
   double qh[4], qn, e[4], dE[4][3], Hq[3][4];
   double free_u[H1_NU];
@@ -82,7 +83,9 @@ DEVFN void tan_body_fwd(const LinShared& L, int i, int kind, int idx, const doub
     cross_axis(D.v[i] + 3, ax, t); da[3] += t[0]; da[4] += t[1]; da[5] += t[2];
   }
   double Ida[6], Idv[6], h[6], t1[6], t2[6];
-  inertia_mul(i, da, Ida); inertia_mul(i, dv, Idv); inertia_mul(i, D.v[i], h);
+  inertia_mul(i, da, Ida); inertia_mul(i, dv, Idv);
+#pragma unroll
+  for (int k = 0; k < 6; ++k) h[k] = L.Iv[i][k];
   crf(dv, h, t1); crf(D.v[i], Idv, t2);
 #pragma unroll
   for (int k = 0; k < 6; ++k) df[k] = Ida[k] + t1[k] + t2[k];
@@ -148,7 +151,9 @@ DEVFN void lin_tangent_lane(LinShared& L, int lane) {
   double dF0[6];
   {
     double Ida[6], Idv[6], h[6], t1[6], t2[6];
-    inertia_mul(0, da0, Ida); inertia_mul(0, dv0, Idv); inertia_mul(0, D.v[0], h);
+    inertia_mul(0, da0, Ida); inertia_mul(0, dv0, Idv);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) h[k] = L.Iv[0][k];
     crf(dv0, h, t1); crf(D.v[0], Idv, t2);
 #pragma unroll
     for (int k = 0; k < 6; ++k) dF0[k] = Ida[k] + t1[k] + t2[k];
@@ -213,21 +218,32 @@ DEVFN void minv_chain_out(LinShared& L, int first, const double* aJ, int lane) {
 DEVFN void lin_minv_lane(LinShared& L, int lane) {
   if (lane >= H1_NV) return;
   const int c = lane;
-  double p11[6] = {0, 0, 0, 0, 0, 0}, p0[6] = {0, 0, 0, 0, 0, 0};
-  minv_chain_in<4>(L, 12, c, p11, lane);
-  minv_chain_in<4>(L, 16, c, p11, lane);
-  {  // torso
-    const int i = 11, ax = H1_AXIS[i];
-    const double du = ((c == 5 + i) ? 1.0 : 0.0) - p11[ax];
-    L.du[i][lane] = du;
-    const double s = du * L.D.Dinv[i];
-    double pa[6];
+  // inward sweep: a unit force on hinge dof c only loads the bodies on the path from that hinge to the pelvis,
+  // so every lane walks its own path (<= 5 bodies, lane-dependent body index) instead of all 19 bodies
+  double p0[6] = {0, 0, 0, 0, 0, 0};
 #pragma unroll
-    for (int r = 0; r < 6; ++r) pa[r] = p11[r] + L.D.U[i][r] * s;
-    xf_force_acc(L.D.Rj[i], H1_POS[i], pa, p0);
+  for (int i = 1; i < H1_NB; ++i) L.du[i][lane] = 0.0;
+  {
+    int i = (c >= 6) ? c - 5 : 0;        // current body on the path (0: done)
+    double acc[6] = {0, 0, 0, 0, 0, 0};
+    bool first = true;
+    for (int d = 5; d >= 1; --d) {
+      if (i > 0 && H1_DEPTH[i] == d) {
+        const int ax = H1_AXIS[i];
+        const double du = (first ? 1.0 : 0.0) - (ax == 0 ? acc[0] : (ax == 1 ? acc[1] : acc[2]));
+        first = false;
+        L.du[i][lane] = du;
+        const double s = du * L.D.Dinv[i];
+        double pa[6];
+#pragma unroll
+        for (int r = 0; r < 6; ++r) { pa[r] = acc[r] + L.D.U[i][r] * s; acc[r] = 0.0; }
+        xf_force_acc(L.D.Rj[i], H1_POS[i], pa, acc);
+        i = H1_PARENT[i];
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 6; ++r) p0[r] = acc[r];
   }
-  minv_chain_in<5>(L, 1, c, p0, lane);
-  minv_chain_in<5>(L, 6, c, p0, lane);
   // pelvis: IA0 a0 = f_ext - p0 ; f_ext = (body torque e_{c-3}, R0^T e_c) for the free-joint dofs
   double rhs[6] = {-p0[0], -p0[1], -p0[2], -p0[3], -p0[4], -p0[5]};
   if (c < 3) { rhs[3] += L.D.R0[3 * c]; rhs[4] += L.D.R0[3 * c + 1]; rhs[5] += L.D.R0[3 * c + 2]; }
@@ -298,11 +314,34 @@ DEVFN void lin_load_dump(LinShared& L, const double* g, int lane) {
     double v[6], a[6], Iv[6], Ia[6], vIv[6];
     for (int k = 0; k < 6; ++k) { v[k] = g[LinDumpG_v + 6 * i + k]; a[k] = g[LinDumpG_a + 6 * i + k]; }
     inertia_mul(i, v, Iv); inertia_mul(i, a, Ia); crf(v, Iv, vIv);
-    for (int k = 0; k < 6; ++k) D.F[i][k] = Ia[k] + vIv[k];
+    for (int k = 0; k < 6; ++k) { D.F[i][k] = Ia[k] + vIv[k]; L.Iv[i][k] = Iv[k]; }
   }
 }
-DEVFN void lin_accumulate_forces(LinShared& L) {   // one lane: F_parent += X_i^T F_i, leaves first
-  for (int i = H1_NB - 1; i >= 1; --i) xf_force_acc(L.D.Rj[i], H1_POS[i], L.D.F[i], L.D.F[H1_PARENT[i]]);
+// F_parent += X_i^T F_i, leaves first.  Lane = parent body, one pass per tree level (4 .. 0); a parent gathers its
+// children in a fixed order (pelvis: legs then torso, torso: left then right arm), so the sums are deterministic.
+// Call with all lanes; contains the level barriers.
+DEVFN void lin_accumulate_forces(LinShared& L, int lane) {
+  const int i = lane;
+  int dep = -1, c0 = 0, c1 = 0, c2 = 0;
+  if (i < H1_NB) {
+    dep = H1_DEPTH[i];
+    if (i == 0) { c0 = 1; c1 = 6; c2 = 11; }
+    else if (i == 11) { c0 = 12; c1 = 16; }
+    else if (i != 5 && i != 10 && i != 15 && i != 19) c0 = i + 1;
+  }
+  for (int d = 4; d >= 0; --d) {
+    if (dep == d && c0) {
+      double acc[6];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) acc[k] = L.D.F[i][k];
+      xf_force_acc(L.D.Rj[c0], H1_POS[c0], L.D.F[c0], acc);
+      if (c1) xf_force_acc(L.D.Rj[c1], H1_POS[c1], L.D.F[c1], acc);
+      if (c2) xf_force_acc(L.D.Rj[c2], H1_POS[c2], L.D.F[c2], acc);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) L.D.F[i][k] = acc[k];
+    }
+    __syncthreads();
+  }
 }
 
 // uniform integrator quantities (one lane)

@@ -96,8 +96,7 @@ __global__ void __launch_bounds__(64, LINT_WAVES) k_lin_tangent(DevState S, Prob
   if (lane == 0) L.h = P.dyn.h;
   __syncthreads();
   LSTAMP(0)
-  if (lane == 0) lin_accumulate_forces(L);
-  __syncthreads();
+  lin_accumulate_forces(L, lane);
   LSTAMP(1)
   if (lane == 0) lin_prologue(L);
   LSTAMP(2)
