@@ -30,6 +30,7 @@ struct LinShared {
   double dT[H1_NV][LIN_LD];      // tangent generalized forces, then d qacc / d direction
   double du[H1_NB][32];          // Minv sweeps: per-lane joint force increments
   double Iv[H1_NB][6];           // I_i v_i (momentum of body i), shared by every tangent direction
+  double xa[H1_NB][6];           // X_i a_parent(i): the parent's acceleration in body i's frame
   double x[H1_NX], u[H1_NU];
   double qh[4], qn, e[4], dE[4][3], Hq[3][4];
   double free_u[H1_NU];
@@ -67,7 +68,8 @@ DEVFN void tan_body_fwd(const LinShared& L, int i, int kind, int idx, const doub
     double t[3], xa[6];
     cross_axis(D.v[i], ax, t);      dv[0] += t[0]; dv[1] += t[1]; dv[2] += t[2];        // -(e x w) = w x e
     cross_axis(D.v[i] + 3, ax, t);  dv[3] += t[0]; dv[4] += t[1]; dv[5] += t[2];
-    xf_motion(Rj, H1_POS[i], D.a[H1_PARENT[i]], xa);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) xa[k] = L.xa[i][k];
     cross_axis(xa, ax, t);          da[0] += t[0]; da[1] += t[1]; da[2] += t[2];
     cross_axis(xa + 3, ax, t);      da[3] += t[0]; da[4] += t[1]; da[5] += t[2];
   }
@@ -113,6 +115,7 @@ DEVFN void tan_chain(LinShared& L, int first, int kind, int idx, const double* j
     tan_body_fwd(L, first + k, kind, idx, cv, ca, nv, na, df[k]);
 #pragma unroll
     for (int c = 0; c < 6; ++c) { cv[c] = nv[c]; ca[c] = na[c]; }
+    __builtin_amdgcn_sched_barrier(0);   // one body at a time: keeps the scheduler from hoisting the next bodies' LDS operands
   }
   double acc[6] = {0, 0, 0, 0, 0, 0};
 #pragma unroll
@@ -122,6 +125,7 @@ DEVFN void tan_chain(LinShared& L, int first, int kind, int idx, const double* j
 #pragma unroll
     for (int c = 0; c < 6; ++c) { tot[c] = df[k][c] + acc[c]; acc[c] = 0.0; }
     L.dT[5 + i][lane] = tan_body_bwd(L, i, kind, idx, tot, (k == 0) ? dFj : acc);
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
 
@@ -213,6 +217,7 @@ DEVFN void minv_chain_out(LinShared& L, int first, const double* aJ, int lane) {
     L.Minv[5 + i][lane] = qdd;
 #pragma unroll
     for (int r = 0; r < 6; ++r) ap[r] = a[r];
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
 DEVFN void lin_minv_lane(LinShared& L, int lane) {
@@ -286,6 +291,7 @@ DEVFN void lin_apply_minv_lane(LinShared& L, int lane) {
 #pragma unroll
     for (int c = 0; c < H1_NV; ++c) s -= L.Minv[r][c] * col[c];
     out[r] = s;
+    __builtin_amdgcn_sched_barrier(0);   // one row at a time (the scheduler otherwise hoists all 625 LDS operands)
   }
 #pragma unroll
   for (int r = 0; r < H1_NV; ++r) L.dT[r][lane] = out[r];
@@ -308,6 +314,10 @@ DEVFN void lin_load_dump(LinShared& L, const double* g, int lane) {
       const double fa = H1_RFIX[i][r][a], fb = H1_RFIX[i][r][b], fd = H1_RFIX[i][r][d];
       D.Rj[i][3 * r + a] = fa; D.Rj[i][3 * r + b] = fb * c + fd * s; D.Rj[i][3 * r + d] = fd * c - fb * s;
     }
+    double ap[6], xa[6];
+    for (int k = 0; k < 6; ++k) ap[k] = g[LinDumpG_a + 6 * H1_PARENT[i] + k];
+    xf_motion(D.Rj[i], H1_POS[i], ap, xa);
+    for (int k = 0; k < 6; ++k) L.xa[i][k] = xa[k];
   }
   if (lane < H1_NB) {
     const int i = lane;
