@@ -155,26 +155,53 @@ def main():
         # dominant kernel = largest device time over the timed region (HIP events on the streams the kernels are
         # launched on); the lambda-retry launches of backward pass / line search are the same kernels on a subset
         # of the rollouts, so they count towards the kernel's total but the roofline uses the full-batch launches
-        groups = {
-            "k_backward_mfma": ["iLQR_backwardPass", "iLQR_backwardPass_retry"],
-            "k_line_search_r": ["iLQR_lineSearch", "iLQR_lineSearch_retry"],
-            "k_lin_primal_r+k_lin_tangent": ["iLQR_linearization"],
-            "k_cost_quadratics": ["iLQR_costQuadratics"],
-            "k_rollout_r": ["iLQR_computeCost+forwardRollout"],
+        # per kernel group: stage keys, algorithmic flops and HBM bytes of ONE full-batch launch
+        D = 8.0
+        kernels = {
+            "k_backward_mfma": dict(stages=["iLQR_backwardPass", "iLQR_backwardPass_retry"], unit="fp64 MFMA",
+                                    flops=RICCATI_FLOPS_PER_KNOT * N * B,
+                                    bytes=D * B * (N * (2601 + 969 + 2601 + 51 + 19 + 19 + 969 + 19) + 2 * (2601 + 51))),
+            "k_line_search_r": dict(stages=["iLQR_lineSearch", "iLQR_lineSearch_retry"], unit="fp64 VALU",
+                                    flops=STEP_FLOPS * N * B,      # the accepted alpha's rollout is the algorithmic work
+                                    bytes=D * B * N * ((969 + 19 + 51 + 19) + 8 * (51 + 19))),
+            "k_lin_primal_r+k_lin_tangent": dict(stages=["iLQR_linearization"], unit="fp64 VALU",
+                                                 flops=JACOBIAN_FLOPS_PER_KNOT * N * B,
+                                                 bytes=D * B * N * (70 + 493 + 493 + 70 + 2601 + 969)),
+            "k_cost_quadratics": dict(stages=["iLQR_costQuadratics"], unit="fp64 VALU",
+                                      flops=QUAD_FLOPS_PER_KNOT * (N + 1) * B,
+                                      bytes=D * B * (N + 1) * (70 + 2601 + 51 + 19 + 19)),
+            "k_rollout_r": dict(stages=["iLQR_computeCost+forwardRollout"], unit="fp64 VALU",
+                                flops=STEP_FLOPS * N * B, bytes=D * B * N * (51 + 19 + 51)),
         }
-        totals = {k: sum(stage_ms.get(x, 0.0) for x in v) for k, v in groups.items()}
-        dom_kernel = max(totals, key=totals.get)
-        dom = groups[dom_kernel][0]
-        flops_per_launch = {
-            "iLQR_backwardPass": RICCATI_FLOPS_PER_KNOT * N * B,
-            "iLQR_linearization": JACOBIAN_FLOPS_PER_KNOT * N * B,
-            "iLQR_costQuadratics": QUAD_FLOPS_PER_KNOT * (N + 1) * B,
-            "iLQR_lineSearch": STEP_FLOPS * N * B,           # the accepted alpha's rollout is the algorithmic work
-            "iLQR_computeCost+forwardRollout": STEP_FLOPS * N * B,
-        }[dom]
-        avg_ms = stage_ms[dom] / max(stage_n[dom], 1.0)
-        achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12
-        kernel_of = {dom: dom_kernel}
+        traffic_file = os.path.join(ROOT, "profiles", "traffic_latest.json")
+        measured = json.load(open(traffic_file)) if os.path.exists(traffic_file) else {}
+        table = {}
+        for name, k in kernels.items():
+            total = sum(stage_ms.get(x, 0.0) for x in k["stages"])
+            full = k["stages"][0]                      # the full-batch launches (retry launches run a subset)
+            avg_ms = stage_ms.get(full, 0.0) / max(stage_n.get(full, 0.0), 1.0)
+            tf = k["flops"] / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+            gbs = k["bytes"] / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+            table[name] = dict(total_ms_per_step=total / args.steps, avg_launch_ms=avg_ms, launches=stage_n.get(full, 0.0),
+                               tflops=tf, frac_compute=tf / FP64_PEAK_TFLOPS, gbs=gbs, frac_hbm=gbs / HBM_PEAK_GBS,
+                               compute_unit=k["unit"], algorithmic_flops_per_launch=k["flops"], algorithmic_bytes_per_launch=k["bytes"])
+        dom_kernel = max(table, key=lambda n: table[n]["total_ms_per_step"])
+        d = table[dom_kernel]
+        # the roof the dominant kernel sits closer to: fp64 compute (78.6 TFLOP/s, vector == matrix peak) or HBM
+        if d["frac_compute"] >= d["frac_hbm"]:
+            roof = {"bound": "mfma", "achieved": d["tflops"], "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": d["frac_compute"]}
+        else:
+            roof = {"bound": "hbm", "achieved": d["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": d["frac_hbm"]}
+        m = measured.get(dom_kernel.split("+")[-1])
+        roof["traffic"] = None if m is None else 2.0 * 1024.0 * m["FETCH_SIZE_KiB"] + 1024.0 * m["WRITE_SIZE_KiB"]
+        roof.update({"kernel": dom_kernel, "compute_unit": d["compute_unit"], "avg_launch_ms": d["avg_launch_ms"], "launches": d["launches"],
+                     "algorithmic_flops_per_launch": d["algorithmic_flops_per_launch"],
+                     "algorithmic_bytes_per_launch": d["algorithmic_bytes_per_launch"],
+                     "frac_compute": d["frac_compute"], "frac_hbm": d["frac_hbm"],
+                     "kernel_total_ms_per_step": d["total_ms_per_step"],
+                     "note": "full-batch launches only (HIP events on the launch stream); traffic = 2 x FETCH_SIZE + WRITE_SIZE per launch from "
+                             "separate rocprofv3 --pmc passes of this command (profiles/traffic_latest.json), null if not collected; "
+                             "cost quadratics and linearisation overlap on two streams, so their stage times include contention"})
         out = {
             "metric": "iLQR iterations/sec (H1 nx=51 nu=19 N=%d)" % N, "value": value, "unit": "iterations/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
@@ -184,11 +211,9 @@ def main():
                                    % (B, N, iters, list(prob["gravity"])),
                        "batch_per_gpu": B, "global_batch": B * world, "horizon": N, "iterations_per_solve": iters,
                        "jacobians": "analytic", "gather": "u0+cost" + ("+K0" if args.gather_gains else "")},
-            "roofline": {"bound": "mfma", "kernel": kernel_of[dom], "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / FP64_PEAK_TFLOPS, "traffic": None,
-                         "avg_launch_ms": avg_ms, "launches": stage_n[dom], "algorithmic_flops_per_launch": flops_per_launch,
-                         "kernel_total_ms_per_step": totals[dom_kernel] / args.steps,
-                         "note": "full-batch launches only; cost quadratics and linearisation overlap on two streams, so their stage times include contention"},
+            "roofline": roof,
+            "kernels": {n: {k: (round(v, 6) if isinstance(v, float) else v) for k, v in t.items() if k in
+                            ("total_ms_per_step", "avg_launch_ms", "frac_compute", "frac_hbm")} for n, t in table.items()},
             "stage_ms_per_step": {k: stage_ms[k] / args.steps for k in stage_ms},
         }
         if not args.no_cpu_baseline:

@@ -138,9 +138,6 @@ __global__ void __launch_bounds__(64) k_line_search_r(DevState S, ProblemDev P, 
       for (int a = 0; a < 8; ++a) dxs[q][a] = (j < H1_NX) ? lds[j * 64 + grp + a] : 0.0;
     }
     __syncthreads();   // the dynamics step below reuses these LDS columns
-#ifdef LS_NOK   // ablation build: no feedback term
-    for (int i = 0; i < H1_NU; ++i) { u[i] = ub[t * m + i] + alpha * kg[t * m + i] + dxs[i % 7][i % 8]; uc[t * m + i] = u[i]; }
-#else
     for (int i = 0; i < H1_NU; ++i) {
       const double* Kr = Kg + ((size_t)t * m + i) * n;
       double kv[7];
@@ -164,10 +161,7 @@ __global__ void __launch_bounds__(64) k_line_search_r(DevState S, ProblemDev P, 
       u[i] = ub[t * m + i] + alpha * kg[t * m + i] + s;
       uc[t * m + i] = u[i];
     }
-#endif
-#ifndef LS_NOCOST
     c += knot_cost_t(P, b, t, x, u, ComReg());
-#endif
     h1r::step(x, u, P.dyn.h, P.dyn.g, L, x);       // in place: every read of x precedes the integrator's writes
 #pragma unroll
     for (int i = 0; i < H1_NX; ++i) xc[(t + 1) * n + i] = x[i];

@@ -469,11 +469,12 @@ void launch_step(int count, const double* x, const double* u, const DynParams& d
   if (!use_scalar_dyn()) { launch_step_r(count, x, u, dyn, xn, st); return; }
   hipLaunchKernelGGL(k_step, dim3(cdiv(count, 64)), dim3(64), 0, st, count, x, u, dyn, xn);
 }
-void launch_linearize(const DevState& S, const ProblemDev& P, int mode, int jac_mode, double eps, hipStream_t st) {
+// phases: 1 = primal dump only, 2 = tangent sweeps / FD only, 3 = both
+void launch_linearize(const DevState& S, const ProblemDev& P, int mode, int jac_mode, double eps, hipStream_t st, int phases) {
   if (jac_mode == 0) {
-    launch_lin_primal_r(S, P, mode, st);
-    hipLaunchKernelGGL(k_lin_tangent, dim3(S.N, S.B), dim3(64), 0, st, S, P, mode);
-  } else {
+    if (phases & 1) launch_lin_primal_r(S, P, mode, st);
+    if (phases & 2) hipLaunchKernelGGL(k_lin_tangent, dim3(S.N, S.B), dim3(64), 0, st, S, P, mode);
+  } else if (phases & 2) {
     const long total = (long)S.B * S.N * (H1_NX + H1_NU);
     hipLaunchKernelGGL(k_linearize_fd, dim3(cdiv(total, 256)), dim3(256), 0, st, S, P, mode, eps);
   }

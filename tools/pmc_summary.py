@@ -1,10 +1,30 @@
 #!/usr/bin/env python3
-"""Per-kernel mean of rocprofv3 --pmc counters: python tools/pmc_summary.py <counter_collection.csv> [...]"""
-import csv, sys, collections
-for path in sys.argv[1:]:
+"""Per-kernel summary of rocprofv3 --pmc counter_collection.csv files.
+
+  python tools/pmc_summary.py <counter_collection.csv> [...]            # table: n, mean, max per (kernel, counter)
+  python tools/pmc_summary.py --traffic-json OUT <fetch.csv> <write.csv>  # per kernel: FETCH_SIZE / WRITE_SIZE of the
+      largest launch (= the full-batch launch; the lambda-retry launches of the same kernel run a subset), in KiB as
+      rocprofv3 reports them.  bench.py turns them into bytes: 2 x FETCH_SIZE (gfx950 counts 64 B per 128-B request,
+      MI355X_MICROARCH.md "HBM"; re-checked for 8-byte-per-lane accesses with tools/probes/pmc_calib.hip) + WRITE_SIZE.
+"""
+import csv, sys, json, collections
+
+def load(paths):
     acc = collections.defaultdict(list)
-    for r in csv.DictReader(open(path)):
-        acc[(r["Kernel_Name"].split("(")[0], r["Counter_Name"])].append(float(r["Counter_Value"]))
-    for (k, c), v in sorted(acc.items()):
-        v = sorted(v)
-        print("%-40s %-22s n=%4d  mean=%.6g  max=%.6g" % (k, c, len(v), sum(v) / len(v), v[-1]))
+    for path in paths:
+        for r in csv.DictReader(open(path)):
+            acc[(r["Kernel_Name"].split("(")[0].replace("ilqr::", ""), r["Counter_Name"])].append(float(r["Counter_Value"]))
+    return acc
+
+if len(sys.argv) > 2 and sys.argv[1] == "--traffic-json":
+    acc = load(sys.argv[3:])
+    out = {}
+    for (k, c), v in acc.items():
+        if c in ("FETCH_SIZE", "WRITE_SIZE") and k.startswith("k_"):
+            out.setdefault(k, {})[c + "_KiB"] = max(v)
+    out = {k: v for k, v in out.items() if len(v) == 2}
+    json.dump(out, open(sys.argv[2], "w"), indent=1, sort_keys=True)
+    print(json.dumps(out, indent=1, sort_keys=True))
+else:
+    for (k, c), v in sorted(load(sys.argv[1:]).items()):
+        print("%-40s %-22s n=%4d  mean=%.6g  max=%.6g" % (k, c, len(v), sum(v) / len(v), max(v)))
