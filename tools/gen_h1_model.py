@@ -226,7 +226,7 @@ def main():
     ce = re.sub(r"\bH1U?_([A-Z]+)\b", lambda m: ("CU_" if m.group(0).startswith("H1U_") else "C_") + m.group(1), ce)
     ce = ce.replace("#ifndef C_MODEL", "#ifndef H1_MODEL_CONSTEXPR_H").replace("#define C_MODEL", "#define H1_MODEL_CONSTEXPR_H")
     with open(os.path.join(ROOT, "mpc-ilqr-mujoco_amd/csrc/h1_model_constexpr.h"), "w") as f:
-        f.write("namespace h1c {\n" + ce.replace("#ifndef H1_MODEL_CONSTEXPR_H\n#define H1_MODEL_CONSTEXPR_H\n", "").replace("#endif\n", "") + "}  // namespace h1c\n")
+        f.write("#pragma once\nnamespace h1c {\n" + ce.replace("#ifndef H1_MODEL_CONSTEXPR_H\n#define H1_MODEL_CONSTEXPR_H\n", "").replace("#endif\n", "") + "}  // namespace h1c\n")
     print("total mass mjcf %.6f urdf %.6f" % (mass.sum(), u_mass.sum()))
     print("wrote headers; bodies:", [b["name"] for b in bodies])
 
