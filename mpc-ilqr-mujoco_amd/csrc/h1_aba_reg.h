@@ -10,6 +10,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "h1_fast_math.h"
 #include "h1_model_constexpr.h"
 
 #ifndef DEVFN
@@ -168,7 +169,7 @@ struct BodyState { double v[6], pA[6], s, c; };   // chain-local between the out
 
 template <int I> DEVFN void body_out(const double* vp, double theta, double qd, BodyState& S) {
   constexpr int AX = C_AXIS[I];
-  sincos(theta, &S.s, &S.c);
+  h1f::sincos_fast(theta, &S.s, &S.c);
   xf_motion<I>(vp, S.s, S.c, S.v);
   S.v[AX] += qd;
   double Iv[6]; inertia_mul<I>(S.v, Iv);
@@ -213,7 +214,7 @@ template <int I> DEVFN void body_in(Art& Y, BodyState& S, double tau, double qd,
 // outward acceleration step: in (vp, ap) of the parent, out (v, a) of body I and its joint acceleration
 template <int I> DEVFN double body_acc(const double* vp, const double* ap, double theta, double qd, const LaneLds& L, double* v, double* a, double* sc = nullptr) {
   constexpr int AX = C_AXIS[I];
-  double s, c; sincos(theta, &s, &c);
+  double s, c; h1f::sincos_fast(theta, &s, &c);
   if (sc) { sc[0] = s; sc[1] = c; }
   xf_motion<I>(vp, s, c, v); v[AX] += qd;
   xf_motion<I>(ap, s, c, a);
@@ -411,7 +412,7 @@ DEVFN void step(const double* x, const double* u, double h, const double* grav, 
   const double s = (vn[3] * vn[3] + vn[4] * vn[4] + vn[5] * vn[5]) * (h * h);
   double c, so;
   if (s < 1e-6) { c = 1.0 - s / 8.0 + s * s / 384.0 - s * s * s / 46080.0; so = 0.5 - s / 48.0 + s * s / 3840.0 - s * s * s / 645120.0; }
-  else { const double a = sqrt(s); double sn, cn; sincos(0.5 * a, &sn, &cn); c = cn; so = sn / a; }
+  else { const double a = sqrt(s); double sn, cn; h1f::sincos_fast(0.5 * a, &sn, &cn); c = cn; so = sn / a; }
   const double ew = c, ex = so * h * vn[3], ey = so * h * vn[4], ez = so * h * vn[5];
   const double rw = qh[0] * ew - qh[1] * ex - qh[2] * ey - qh[3] * ez;
   const double rx = qh[0] * ex + qh[1] * ew + qh[2] * ez - qh[3] * ey;
@@ -424,7 +425,7 @@ DEVFN void step(const double* x, const double* u, double h, const double* grav, 
 // whole-body CoM with MuJoCo masses (RobotUtils::computeCoM, reference src/common/robot_utils.cpp:810-833)
 template <int I> DEVFN void com_body(const double* Rp, const double* pp, const double* x, double* acc) {
   constexpr int a = C_AXIS[I], b = (a + 1) % 3, d = (a + 2) % 3;
-  double s, c; sincos(x[7 + I - 1], &s, &c);
+  double s, c; h1f::sincos_fast(x[7 + I - 1], &s, &c);
   // R = Rp * Rfix * Rot
   double R[9];
 #pragma unroll

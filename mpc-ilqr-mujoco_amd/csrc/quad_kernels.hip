@@ -14,6 +14,7 @@
 #include <hip/hip_runtime.h>
 
 #include "h1_cost_dev.h"
+#include "h1_fast_math.h"
 #include "h1_model_constexpr.h"
 #include "ilqr_kernels.h"
 
@@ -110,7 +111,7 @@ __global__ void __launch_bounds__(64, QUAD_WAVES) k_cost_quadratics(DevState S, 
     int par = 0, ax = 0, dep = -1;
     if (lane >= 1 && lane < H1_NB) {
       par = H1_PARENT[lane]; ax = H1_AXIS[lane]; dep = H1_DEPTH[lane];
-      double sn, cs; sincos(L.xp[7 + lane - 1], &sn, &cs);
+      double sn, cs; h1f::sincos_fast(L.xp[7 + lane - 1], &sn, &cs);
 #pragma unroll
       for (int r = 0; r < 3; ++r) {
         const double f0 = H1U_RFIX[lane][r][0], f1 = H1U_RFIX[lane][r][1], f2 = H1U_RFIX[lane][r][2];
