@@ -30,7 +30,9 @@ struct LaneLds {           // per-lane column of the LDS scratch: slot s lives a
 };
 
 struct Art { double A[6], B[9], C[6]; };   // [[A, B], [B^T, C]], A and C symmetric (xx, xy, xz, yy, yz, zz)
-DEVFN constexpr int sidx(int r, int c) { return r <= c ? (r == 0 ? c : (r == 1 ? 2 + c : 5)) : sidx(c, r); }
+// index of (r, c) in the packed symmetric storage (xx, xy, xz, yy, yz, zz).  NOT recursive on purpose: the recursive
+// form survives to the backend as a run-time loop, its result indexes the arrays dynamically and they end up in scratch.
+DEVFN constexpr int sidx(int r, int c) { const int lo = r < c ? r : c, hi = r < c ? c : r; return lo * 3 - lo * (lo + 1) / 2 + hi; }
 
 DEVFN void cross(const double* a, const double* b, double* c) {
   const double c0 = a[1] * b[2] - a[2] * b[1], c1 = a[2] * b[0] - a[0] * b[2], c2 = a[0] * b[1] - a[1] * b[0];
