@@ -63,26 +63,30 @@ DEVFN void tan_body_fwd(const LinShared& L, int i, int kind, int idx, const doub
   const double qd = L.x[H1_NQ + 6 + i - 1];
   xf_motion(Rj, H1_POS[i], pv, dv);
   xf_motion(Rj, H1_POS[i], pa, da);
-  if (kind == DIR_THETA && idx == i) {
+  // the direction's own hinge adds a few terms; they are applied through 0/1 factors instead of lane-divergent
+  // branches (one lane per body would take them: 3 exec-masked branches per body break the instruction stream)
+  const double mt = (kind == DIR_THETA && idx == i) ? 1.0 : 0.0;
+  const double md = (kind == DIR_THETADOT && idx == i) ? 1.0 : 0.0;
+  {
     // d(X u)/d theta = -S x (X u)
     double t[3], xa[6];
-    cross_axis(D.v[i], ax, t);      dv[0] += t[0]; dv[1] += t[1]; dv[2] += t[2];        // -(e x w) = w x e
-    cross_axis(D.v[i] + 3, ax, t);  dv[3] += t[0]; dv[4] += t[1]; dv[5] += t[2];
+    cross_axis(D.v[i], ax, t);      dv[0] += mt * t[0]; dv[1] += mt * t[1]; dv[2] += mt * t[2];        // -(e x w) = w x e
+    cross_axis(D.v[i] + 3, ax, t);  dv[3] += mt * t[0]; dv[4] += mt * t[1]; dv[5] += mt * t[2];
 #pragma unroll
     for (int k = 0; k < 6; ++k) xa[k] = L.xa[i][k];
-    cross_axis(xa, ax, t);          da[0] += t[0]; da[1] += t[1]; da[2] += t[2];
-    cross_axis(xa + 3, ax, t);      da[3] += t[0]; da[4] += t[1]; da[5] += t[2];
+    cross_axis(xa, ax, t);          da[0] += mt * t[0]; da[1] += mt * t[1]; da[2] += mt * t[2];
+    cross_axis(xa + 3, ax, t);      da[3] += mt * t[0]; da[4] += mt * t[1]; da[5] += mt * t[2];
   }
-  if (kind == DIR_THETADOT && idx == i) dv[ax] += 1.0;
+  dv[ax] += md;
   {  // + dv x (S qd)
     double t[3];
     cross_axis(dv, ax, t);     da[0] += qd * t[0]; da[1] += qd * t[1]; da[2] += qd * t[2];
     cross_axis(dv + 3, ax, t); da[3] += qd * t[0]; da[4] += qd * t[1]; da[5] += qd * t[2];
   }
-  if (kind == DIR_THETADOT && idx == i) {  // + v_i x S
+  {  // + v_i x S
     double t[3];
-    cross_axis(D.v[i], ax, t);     da[0] += t[0]; da[1] += t[1]; da[2] += t[2];
-    cross_axis(D.v[i] + 3, ax, t); da[3] += t[0]; da[4] += t[1]; da[5] += t[2];
+    cross_axis(D.v[i], ax, t);     da[0] += md * t[0]; da[1] += md * t[1]; da[2] += md * t[2];
+    cross_axis(D.v[i] + 3, ax, t); da[3] += md * t[0]; da[4] += md * t[1]; da[5] += md * t[2];
   }
   double Ida[6], Idv[6], h[6], t1[6], t2[6];
   inertia_mul(i, da, Ida); inertia_mul(i, dv, Idv);
@@ -97,10 +101,11 @@ DEVFN double tan_body_bwd(const LinShared& L, int i, int kind, int idx, const do
   const KnotDump& D = L.D;
   const int ax = H1_AXIS[i];
   double g[6] = {tot[0], tot[1], tot[2], tot[3], tot[4], tot[5]};
-  if (kind == DIR_THETA && idx == i) {   // d(X^T f)/d theta = X^T (S x* F) = X^T (e x n ; e x f)
+  {   // d(X^T f)/d theta = X^T (S x* F) = X^T (e x n ; e x f), own hinge only (0/1 factor instead of a branch)
+    const double mt = (kind == DIR_THETA && idx == i) ? 1.0 : 0.0;
     double t[3];
-    cross_axis(D.F[i], ax, t);     g[0] -= t[0]; g[1] -= t[1]; g[2] -= t[2];
-    cross_axis(D.F[i] + 3, ax, t); g[3] -= t[0]; g[4] -= t[1]; g[5] -= t[2];
+    cross_axis(D.F[i], ax, t);     g[0] -= mt * t[0]; g[1] -= mt * t[1]; g[2] -= mt * t[2];
+    cross_axis(D.F[i] + 3, ax, t); g[3] -= mt * t[0]; g[4] -= mt * t[1]; g[5] -= mt * t[2];
   }
   xf_force_acc(D.Rj[i], H1_POS[i], g, parent_acc);
   return tot[ax];
