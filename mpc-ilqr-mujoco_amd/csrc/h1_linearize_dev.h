@@ -13,6 +13,7 @@
 // * each lane then assembles one column of A / B through the integrator
 //   (v' = v + h qacc, p' = p + h v'_lin, theta' = theta + h thetadot', quat' = qhat (x) exp(h w')).
 #pragma once
+#include "h1_aba_reg.h"
 #include "h1_dynamics_dev.h"
 
 namespace h1 {
@@ -28,7 +29,6 @@ struct LinShared {
   KnotDump D;
   double Minv[H1_NV][H1_NV];     // d qacc / d tau in MuJoCo coordinates
   double dT[H1_NV][LIN_LD];      // tangent generalized forces, then d qacc / d direction
-  double du[H1_NB][32];          // Minv sweeps: per-lane joint force increments
   double Iv[H1_NB][6];           // I_i v_i (momentum of body i), shared by every tangent direction
   double xa[H1_NB][6];           // X_i a_parent(i): the parent's acceleration in body i's frame
   double x[H1_NX], u[H1_NU];
@@ -54,85 +54,89 @@ DEVFN void lane_direction(int lane, int& kind, int& idx) {
   else { kind = DIR_NONE; idx = 0; }
 }
 
-// tangent of (v_i, a_i, f_i) of body i given its parent's tangent (pv, pa)
-DEVFN void tan_body_fwd(const LinShared& L, int i, int kind, int idx, const double* pv, const double* pa,
+// tangent of (v_i, a_i, f_i) of body I given its parent's tangent (pv, pa).  The body index is a template parameter:
+// joint axis, offset and inertia are immediates (h1_model_constexpr.h) and no array is indexed at run time.
+template <int I>
+DEVFN void tan_body_fwd(const LinShared& L, int kind, int idx, const double* pv, const double* pa,
                         double* dv, double* da, double* df) {
   const KnotDump& D = L.D;
-  const int ax = H1_AXIS[i];
-  const double* Rj = D.Rj[i];
-  const double qd = L.x[H1_NQ + 6 + i - 1];
-  xf_motion(Rj, H1_POS[i], pv, dv);
-  xf_motion(Rj, H1_POS[i], pa, da);
+  constexpr int ax = h1c::C_AXIS[I];
+  const double* Rj = D.Rj[I];
+  const double qd = L.x[H1_NQ + 6 + I - 1];
+  const double r[3] = {h1c::C_POS[I][0], h1c::C_POS[I][1], h1c::C_POS[I][2]};
+  xf_motion(Rj, r, pv, dv);
+  xf_motion(Rj, r, pa, da);
   // the direction's own hinge adds a few terms; they are applied through 0/1 factors instead of lane-divergent
   // branches (one lane per body would take them: 3 exec-masked branches per body break the instruction stream)
-  const double mt = (kind == DIR_THETA && idx == i) ? 1.0 : 0.0;
-  const double md = (kind == DIR_THETADOT && idx == i) ? 1.0 : 0.0;
+  const double mt = (kind == DIR_THETA && idx == I) ? 1.0 : 0.0;
+  const double md = (kind == DIR_THETADOT && idx == I) ? 1.0 : 0.0;
   {
     // d(X u)/d theta = -S x (X u)
     double t[3], xa[6];
-    cross_axis(D.v[i], ax, t);      dv[0] += mt * t[0]; dv[1] += mt * t[1]; dv[2] += mt * t[2];        // -(e x w) = w x e
-    cross_axis(D.v[i] + 3, ax, t);  dv[3] += mt * t[0]; dv[4] += mt * t[1]; dv[5] += mt * t[2];
+    h1r::cross_axis<ax>(D.v[I], t);      dv[0] += mt * t[0]; dv[1] += mt * t[1]; dv[2] += mt * t[2];        // -(e x w) = w x e
+    h1r::cross_axis<ax>(D.v[I] + 3, t);  dv[3] += mt * t[0]; dv[4] += mt * t[1]; dv[5] += mt * t[2];
 #pragma unroll
-    for (int k = 0; k < 6; ++k) xa[k] = L.xa[i][k];
-    cross_axis(xa, ax, t);          da[0] += mt * t[0]; da[1] += mt * t[1]; da[2] += mt * t[2];
-    cross_axis(xa + 3, ax, t);      da[3] += mt * t[0]; da[4] += mt * t[1]; da[5] += mt * t[2];
+    for (int k = 0; k < 6; ++k) xa[k] = L.xa[I][k];
+    h1r::cross_axis<ax>(xa, t);          da[0] += mt * t[0]; da[1] += mt * t[1]; da[2] += mt * t[2];
+    h1r::cross_axis<ax>(xa + 3, t);      da[3] += mt * t[0]; da[4] += mt * t[1]; da[5] += mt * t[2];
   }
   dv[ax] += md;
   {  // + dv x (S qd)
     double t[3];
-    cross_axis(dv, ax, t);     da[0] += qd * t[0]; da[1] += qd * t[1]; da[2] += qd * t[2];
-    cross_axis(dv + 3, ax, t); da[3] += qd * t[0]; da[4] += qd * t[1]; da[5] += qd * t[2];
+    h1r::cross_axis<ax>(dv, t);     da[0] += qd * t[0]; da[1] += qd * t[1]; da[2] += qd * t[2];
+    h1r::cross_axis<ax>(dv + 3, t); da[3] += qd * t[0]; da[4] += qd * t[1]; da[5] += qd * t[2];
   }
   {  // + v_i x S
     double t[3];
-    cross_axis(D.v[i], ax, t);     da[0] += md * t[0]; da[1] += md * t[1]; da[2] += md * t[2];
-    cross_axis(D.v[i] + 3, ax, t); da[3] += md * t[0]; da[4] += md * t[1]; da[5] += md * t[2];
+    h1r::cross_axis<ax>(D.v[I], t);     da[0] += md * t[0]; da[1] += md * t[1]; da[2] += md * t[2];
+    h1r::cross_axis<ax>(D.v[I] + 3, t); da[3] += md * t[0]; da[4] += md * t[1]; da[5] += md * t[2];
   }
   double Ida[6], Idv[6], h[6], t1[6], t2[6];
-  inertia_mul(i, da, Ida); inertia_mul(i, dv, Idv);
+  h1r::inertia_mul<I>(da, Ida); h1r::inertia_mul<I>(dv, Idv);
 #pragma unroll
-  for (int k = 0; k < 6; ++k) h[k] = L.Iv[i][k];
-  crf(dv, h, t1); crf(D.v[i], Idv, t2);
+  for (int k = 0; k < 6; ++k) h[k] = L.Iv[I][k];
+  h1r::crf(dv, h, t1); h1r::crf(D.v[I], Idv, t2);
 #pragma unroll
   for (int k = 0; k < 6; ++k) df[k] = Ida[k] + t1[k] + t2[k];
 }
-// body i's total tangent force tot -> its generalized force row and the contribution to the parent
-DEVFN double tan_body_bwd(const LinShared& L, int i, int kind, int idx, const double* tot, double* parent_acc) {
+// body I's total tangent force tot -> its generalized force row and the contribution to the parent
+template <int I>
+DEVFN double tan_body_bwd(const LinShared& L, int kind, int idx, const double* tot, double* parent_acc) {
   const KnotDump& D = L.D;
-  const int ax = H1_AXIS[i];
+  constexpr int ax = h1c::C_AXIS[I];
   double g[6] = {tot[0], tot[1], tot[2], tot[3], tot[4], tot[5]};
   {   // d(X^T f)/d theta = X^T (S x* F) = X^T (e x n ; e x f), own hinge only (0/1 factor instead of a branch)
-    const double mt = (kind == DIR_THETA && idx == i) ? 1.0 : 0.0;
+    const double mt = (kind == DIR_THETA && idx == I) ? 1.0 : 0.0;
     double t[3];
-    cross_axis(D.F[i], ax, t);     g[0] -= mt * t[0]; g[1] -= mt * t[1]; g[2] -= mt * t[2];
-    cross_axis(D.F[i] + 3, ax, t); g[3] -= mt * t[0]; g[4] -= mt * t[1]; g[5] -= mt * t[2];
+    h1r::cross_axis<ax>(D.F[I], t);     g[0] -= mt * t[0]; g[1] -= mt * t[1]; g[2] -= mt * t[2];
+    h1r::cross_axis<ax>(D.F[I] + 3, t); g[3] -= mt * t[0]; g[4] -= mt * t[1]; g[5] -= mt * t[2];
   }
-  xf_force_acc(D.Rj[i], H1_POS[i], g, parent_acc);
+  const double r[3] = {h1c::C_POS[I][0], h1c::C_POS[I][1], h1c::C_POS[I][2]};
+  xf_force_acc(D.Rj[I], r, g, parent_acc);
   return tot[ax];
 }
-template <int LEN>
-DEVFN void tan_chain(LinShared& L, int first, int kind, int idx, const double* jv, const double* ja, double* dFj, int lane) {
-  double df[LEN][6], cv[6], ca[6], nv[6], na[6];
-#pragma unroll
-  for (int k = 0; k < 6; ++k) { cv[k] = jv[k]; ca[k] = ja[k]; }
-#pragma unroll
-  for (int k = 0; k < LEN; ++k) {
-    tan_body_fwd(L, first + k, kind, idx, cv, ca, nv, na, df[k]);
-#pragma unroll
-    for (int c = 0; c < 6; ++c) { cv[c] = nv[c]; ca[c] = na[c]; }
+template <int FIRST, int LEN> struct TanChain {
+  template <int K> static DEVFN void fwd(const LinShared& L, int kind, int idx, const double* pv, const double* pa, double (*df)[6]) {
+    double nv[6], na[6];
+    tan_body_fwd<FIRST + K>(L, kind, idx, pv, pa, nv, na, df[K]);
     __builtin_amdgcn_sched_barrier(0);   // one body at a time: keeps the scheduler from hoisting the next bodies' LDS operands
+    if constexpr (K + 1 < LEN) fwd<K + 1>(L, kind, idx, nv, na, df);
   }
-  double acc[6] = {0, 0, 0, 0, 0, 0};
-#pragma unroll
-  for (int k = LEN - 1; k >= 0; --k) {
-    const int i = first + k;
+  template <int K> static DEVFN void bwd(LinShared& L, int kind, int idx, double (*df)[6], double* acc, double* dFj, int lane) {
     double tot[6];
 #pragma unroll
-    for (int c = 0; c < 6; ++c) { tot[c] = df[k][c] + acc[c]; acc[c] = 0.0; }
-    L.dT[5 + i][lane] = tan_body_bwd(L, i, kind, idx, tot, (k == 0) ? dFj : acc);
+    for (int c = 0; c < 6; ++c) { tot[c] = df[K][c] + acc[c]; acc[c] = 0.0; }
+    L.dT[5 + FIRST + K][lane] = tan_body_bwd<FIRST + K>(L, kind, idx, tot, (K == 0) ? dFj : acc);
     __builtin_amdgcn_sched_barrier(0);
+    if constexpr (K > 0) bwd<K - 1>(L, kind, idx, df, acc, dFj, lane);
   }
-}
+  static DEVFN void run(LinShared& L, int kind, int idx, const double* jv, const double* ja, double* dFj, int lane) {
+    double df[LEN][6];
+    fwd<0>(L, kind, idx, jv, ja, df);
+    double acc[6] = {0, 0, 0, 0, 0, 0};
+    bwd<LEN - 1>(L, kind, idx, df, acc, dFj, lane);
+  }
+};
 
 // one lane: tangent generalized forces d ID_mj / d direction (+ damping), written to L.dT[:, lane]
 DEVFN void lin_tangent_lane(LinShared& L, int lane) {
@@ -160,22 +164,22 @@ DEVFN void lin_tangent_lane(LinShared& L, int lane) {
   double dF0[6];
   {
     double Ida[6], Idv[6], h[6], t1[6], t2[6];
-    inertia_mul(0, da0, Ida); inertia_mul(0, dv0, Idv);
+    h1r::inertia_mul<0>(da0, Ida); h1r::inertia_mul<0>(dv0, Idv);
 #pragma unroll
     for (int k = 0; k < 6; ++k) h[k] = L.Iv[0][k];
-    crf(dv0, h, t1); crf(D.v[0], Idv, t2);
+    h1r::crf(dv0, h, t1); h1r::crf(D.v[0], Idv, t2);
 #pragma unroll
     for (int k = 0; k < 6; ++k) dF0[k] = Ida[k] + t1[k] + t2[k];
   }
   // torso and the two arms hanging off it
   double tv[6], ta[6], dF11[6];
-  tan_body_fwd(L, 11, kind, idx, dv0, da0, tv, ta, dF11);
-  tan_chain<4>(L, 12, kind, idx, tv, ta, dF11, lane);
-  tan_chain<4>(L, 16, kind, idx, tv, ta, dF11, lane);
-  L.dT[5 + 11][lane] = tan_body_bwd(L, 11, kind, idx, dF11, dF0);
+  tan_body_fwd<11>(L, kind, idx, dv0, da0, tv, ta, dF11);
+  TanChain<12, 4>::run(L, kind, idx, tv, ta, dF11, lane);
+  TanChain<16, 4>::run(L, kind, idx, tv, ta, dF11, lane);
+  L.dT[5 + 11][lane] = tan_body_bwd<11>(L, kind, idx, dF11, dF0);
   // legs
-  tan_chain<5>(L, 1, kind, idx, dv0, da0, dF0, lane);
-  tan_chain<5>(L, 6, kind, idx, dv0, da0, dF0, lane);
+  TanChain<1, 5>::run(L, kind, idx, dv0, da0, dF0, lane);
+  TanChain<6, 5>::run(L, kind, idx, dv0, da0, dF0, lane);
   // free joint rows: torque in the body frame, force in the world frame
   double fl[3] = {dF0[3], dF0[4], dF0[5]};
   if (kind == DIR_PHI) {  // d(R0 f) = R0 (dphi x f + df)
@@ -191,58 +195,44 @@ DEVFN void lin_tangent_lane(LinShared& L, int lane) {
 // Column c (= lane, 0..24) of Minv = d qacc / d tau in MuJoCo coordinates: response of the articulated-body
 // recursion to a unit generalized force on dof c with zero velocity and gravity (the recursion is linear in
 // the force): inward sweep of the bias-force increments, pelvis solve, outward sweep of the accelerations.
-// du[i] (19 per lane) is kept in LDS between the sweeps: L.du[i][lane].
-template <int LEN>
-DEVFN void minv_chain_in(LinShared& L, int first, int c, double* pJ, int lane) {
-  double acc[6] = {0, 0, 0, 0, 0, 0};
+// The joint-force increments du are nonzero only on the path from the forced hinge to the pelvis (one body per
+// tree level): they stay in registers as (body, value) per level.
+struct MinvPath { int body[6]; double du[6]; };   // index = tree depth 1..5
+template <int FIRST, int LEN> struct MinvChainOut {
+  template <int K> static DEVFN void step(LinShared& L, const MinvPath& P, const double* ap, int lane) {
+    constexpr int I = FIRST + K, ax = h1c::C_AXIS[I], dep = h1c::C_DEPTH[I];
+    const double r[3] = {h1c::C_POS[I][0], h1c::C_POS[I][1], h1c::C_POS[I][2]};
+    double a[6]; xf_motion(L.D.Rj[I], r, ap, a);
+    double s = (P.body[dep] == I) ? P.du[dep] : 0.0;
 #pragma unroll
-  for (int k = LEN - 1; k >= 0; --k) {
-    const int i = first + k, ax = H1_AXIS[i];
-    const double du = ((c == 5 + i) ? 1.0 : 0.0) - acc[ax];
-    L.du[i][lane] = du;
-    double pa[6];
-    const double s = du * L.D.Dinv[i];
-#pragma unroll
-    for (int r = 0; r < 6; ++r) { pa[r] = acc[r] + L.D.U[i][r] * s; acc[r] = 0.0; }
-    xf_force_acc(L.D.Rj[i], H1_POS[i], pa, (k == 0) ? pJ : acc);
-  }
-}
-template <int LEN>
-DEVFN void minv_chain_out(LinShared& L, int first, const double* aJ, int lane) {
-  double ap[6] = {aJ[0], aJ[1], aJ[2], aJ[3], aJ[4], aJ[5]};
-#pragma unroll
-  for (int k = 0; k < LEN; ++k) {
-    const int i = first + k, ax = H1_AXIS[i];
-    double a[6]; xf_motion(L.D.Rj[i], H1_POS[i], ap, a);
-    double s = L.du[i][lane];
-#pragma unroll
-    for (int r = 0; r < 6; ++r) s -= L.D.U[i][r] * a[r];
-    const double qdd = s * L.D.Dinv[i];
+    for (int q = 0; q < 6; ++q) s -= L.D.U[I][q] * a[q];
+    const double qdd = s * L.D.Dinv[I];
     a[ax] += qdd;
-    L.Minv[5 + i][lane] = qdd;
-#pragma unroll
-    for (int r = 0; r < 6; ++r) ap[r] = a[r];
+    L.Minv[5 + I][lane] = qdd;
     __builtin_amdgcn_sched_barrier(0);
+    if constexpr (K + 1 < LEN) step<K + 1>(L, P, a, lane);
   }
-}
+};
 DEVFN void lin_minv_lane(LinShared& L, int lane) {
   if (lane >= H1_NV) return;
   const int c = lane;
   // inward sweep: a unit force on hinge dof c only loads the bodies on the path from that hinge to the pelvis,
   // so every lane walks its own path (<= 5 bodies, lane-dependent body index) instead of all 19 bodies
   double p0[6] = {0, 0, 0, 0, 0, 0};
+  MinvPath P;
 #pragma unroll
-  for (int i = 1; i < H1_NB; ++i) L.du[i][lane] = 0.0;
+  for (int d = 0; d < 6; ++d) { P.body[d] = -1; P.du[d] = 0.0; }
   {
     int i = (c >= 6) ? c - 5 : 0;        // current body on the path (0: done)
     double acc[6] = {0, 0, 0, 0, 0, 0};
     bool first = true;
+#pragma unroll
     for (int d = 5; d >= 1; --d) {
       if (i > 0 && H1_DEPTH[i] == d) {
         const int ax = H1_AXIS[i];
         const double du = (first ? 1.0 : 0.0) - (ax == 0 ? acc[0] : (ax == 1 ? acc[1] : acc[2]));
         first = false;
-        L.du[i][lane] = du;
+        P.body[d] = i; P.du[d] = du;
         const double s = du * L.D.Dinv[i];
         double pa[6];
 #pragma unroll
@@ -269,25 +259,26 @@ DEVFN void lin_minv_lane(LinShared& L, int lane) {
   L.Minv[3][lane] = a0[0]; L.Minv[4][lane] = a0[1]; L.Minv[5][lane] = a0[2];
   double a11[6];
   {  // torso outward
-    const int i = 11, ax = H1_AXIS[i];
-    xf_motion(L.D.Rj[i], H1_POS[i], a0, a11);
-    double s = L.du[i][lane];
+    constexpr int I = 11, ax = h1c::C_AXIS[11];
+    const double r[3] = {h1c::C_POS[I][0], h1c::C_POS[I][1], h1c::C_POS[I][2]};
+    xf_motion(L.D.Rj[I], r, a0, a11);
+    double s = (P.body[1] == I) ? P.du[1] : 0.0;
 #pragma unroll
-    for (int r = 0; r < 6; ++r) s -= L.D.U[i][r] * a11[r];
-    const double qdd = s * L.D.Dinv[i];
+    for (int q = 0; q < 6; ++q) s -= L.D.U[I][q] * a11[q];
+    const double qdd = s * L.D.Dinv[I];
     a11[ax] += qdd;
-    L.Minv[5 + i][lane] = qdd;
+    L.Minv[5 + I][lane] = qdd;
   }
-  minv_chain_out<4>(L, 12, a11, lane);
-  minv_chain_out<4>(L, 16, a11, lane);
-  minv_chain_out<5>(L, 1, a0, lane);
-  minv_chain_out<5>(L, 6, a0, lane);
+  MinvChainOut<12, 4>::step<0>(L, P, a11, lane);
+  MinvChainOut<16, 4>::step<0>(L, P, a11, lane);
+  MinvChainOut<1, 5>::step<0>(L, P, a0, lane);
+  MinvChainOut<6, 5>::step<0>(L, P, a0, lane);
 }
 
 // d qacc / d direction = -Minv dT  (in place, one lane per direction)
 DEVFN void lin_apply_minv_lane(LinShared& L, int lane) {
   if (lane >= LIN_NDIR) return;
-  double col[H1_NV], out[H1_NV];
+  double col[H1_NV];
 #pragma unroll
   for (int c = 0; c < H1_NV; ++c) col[c] = L.dT[c][lane];
 #pragma unroll
@@ -295,11 +286,9 @@ DEVFN void lin_apply_minv_lane(LinShared& L, int lane) {
     double s = 0.0;
 #pragma unroll
     for (int c = 0; c < H1_NV; ++c) s -= L.Minv[r][c] * col[c];
-    out[r] = s;
+    L.dT[r][lane] = s;                   // this lane's column only: every input is already in registers
     __builtin_amdgcn_sched_barrier(0);   // one row at a time (the scheduler otherwise hoists all 625 LDS operands)
   }
-#pragma unroll
-  for (int r = 0; r < H1_NV; ++r) L.dT[r][lane] = out[r];
 }
 
 // cooperative load of the global dump into LDS (all lanes of one wave); rebuilds the joint rotations from
@@ -398,41 +387,40 @@ DEVFN void quat_mul(const double* a, const double* b, double* r) {
   r[3] = a[0] * b[3] + a[1] * b[2] - a[2] * b[1] + a[3] * b[0];
 }
 
-// column k of A (is_u = 0, k in 0..50) or of B (is_u = 1, k in 0..18); col[51]
-DEVFN void lin_column(const LinShared& L, int is_u, int k, double* col) {
+// column k of A (is_u = 0, k in 0..50) or of B (is_u = 1, k in 0..18), streamed row by row into out(row, value):
+// nothing but the three angular rows of d v' survives between rows
+template <class Out>
+DEVFN void lin_column(const LinShared& L, int is_u, int k, Out&& out) {
   const double h = L.h;
-  double dq[H1_NV];
   double dphi[3] = {0.0, 0.0, 0.0};
-  if (is_u) {
+  int src = -1;                 // lane of dT holding d qacc / d direction for this column (theta, velocity columns)
+  double fu = 0.0;
+  if (is_u) fu = L.free_u[k];
+  else if (k >= 3 && k < 7) { dphi[0] = L.Hq[0][k - 3]; dphi[1] = L.Hq[1][k - 3]; dphi[2] = L.Hq[2][k - 3]; }
+  else if (k >= 7) src = (k < H1_NQ) ? (3 + k - 7) : (22 + k - H1_NQ);
+  const int kv = (!is_u && k >= H1_NQ) ? k - H1_NQ : -1;   // velocity column: identity entry of d v'/d v
+  double dw[3] = {0.0, 0.0, 0.0};
 #pragma unroll
-    for (int r = 0; r < H1_NV; ++r) dq[r] = L.Minv[r][6 + k] * L.free_u[k];
-  } else if (k < 3) {
-#pragma unroll
-    for (int r = 0; r < H1_NV; ++r) dq[r] = 0.0;
-  } else if (k < 7) {
-    for (int j = 0; j < 3; ++j) dphi[j] = L.Hq[j][k - 3];
-#pragma unroll
-    for (int r = 0; r < H1_NV; ++r) dq[r] = L.dT[r][0] * dphi[0] + L.dT[r][1] * dphi[1] + L.dT[r][2] * dphi[2];
-  } else {
-    const int lane = (k < H1_NQ) ? (3 + k - 7) : (22 + k - H1_NQ);
-#pragma unroll
-    for (int r = 0; r < H1_NV; ++r) dq[r] = L.dT[r][lane];
+  for (int r = 0; r < H1_NV; ++r) {
+    double dq;
+    if (is_u) dq = L.Minv[r][6 + k] * fu;
+    else if (k < 3) dq = 0.0;
+    else if (k < 7) dq = L.dT[r][0] * dphi[0] + L.dT[r][1] * dphi[1] + L.dT[r][2] * dphi[2];
+    else dq = L.dT[r][src];
+    const double dvn = h * dq + ((r == kv) ? 1.0 : 0.0);
+    out(H1_NQ + r, dvn);
+    if (r < 3) out(r, ((!is_u && k == r) ? 1.0 : 0.0) + h * dvn);
+    else if (r < 6) dw[r - 3] = dvn;
+    else out(7 + r - 6, ((!is_u && k == 7 + r - 6) ? 1.0 : 0.0) + h * dvn);
   }
-  double dvn[H1_NV];
-#pragma unroll
-  for (int r = 0; r < H1_NV; ++r) { dvn[r] = h * dq[r] + ((!is_u && k >= H1_NQ && r == k - H1_NQ) ? 1.0 : 0.0); col[H1_NQ + r] = dvn[r]; }
-#pragma unroll
-  for (int i = 0; i < 3; ++i) col[i] = ((!is_u && k == i) ? 1.0 : 0.0) + h * dvn[i];
-#pragma unroll
-  for (int j = 0; j < H1_NJ; ++j) col[7 + j] = ((!is_u && k == 7 + j) ? 1.0 : 0.0) + h * dvn[6 + j];
   // quaternion rows: d(qhat (x) e) = dqhat (x) e + qhat (x) de
   double dqh[4] = {0, 0, 0, 0}, de[4], t1[4], t2[4];
   if (!is_u && k >= 3 && k < 7) { const double hp[4] = {0.0, 0.5 * dphi[0], 0.5 * dphi[1], 0.5 * dphi[2]}; quat_mul(L.qh, hp, dqh); }
 #pragma unroll
-  for (int i = 0; i < 4; ++i) de[i] = L.dE[i][0] * dvn[3] + L.dE[i][1] * dvn[4] + L.dE[i][2] * dvn[5];
+  for (int i = 0; i < 4; ++i) de[i] = L.dE[i][0] * dw[0] + L.dE[i][1] * dw[1] + L.dE[i][2] * dw[2];
   quat_mul(dqh, L.e, t1); quat_mul(L.qh, de, t2);
 #pragma unroll
-  for (int i = 0; i < 4; ++i) col[3 + i] = t1[i] + t2[i];
+  for (int i = 0; i < 4; ++i) out(3 + i, t1[i] + t2[i]);
 }
 
 }  // namespace h1

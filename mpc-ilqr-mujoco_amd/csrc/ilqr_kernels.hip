@@ -108,19 +108,11 @@ __global__ void __launch_bounds__(64, LINT_WAVES) k_lin_tangent(DevState S, Prob
   lin_apply_minv_lane(L, lane);
   __syncthreads();
   LSTAMP(5)
-  double col[H1_NX];
   double* Ag = S.A + knot * H1_NX * H1_NX;
   double* Bg = S.Bm + knot * H1_NX * H1_NU;
-  if (lane < H1_NX) {
-    lin_column(L, 0, lane, col);
-#pragma unroll
-    for (int r = 0; r < H1_NX; ++r) Ag[r * H1_NX + lane] = col[r];
-  }
-  if (lane < H1_NU) {
-    lin_column(L, 1, lane, col);
-#pragma unroll
-    for (int r = 0; r < H1_NX; ++r) Bg[r * H1_NU + lane] = col[r];
-  }
+  // each lane streams one column; for a fixed row the lanes write consecutive addresses
+  if (lane < H1_NX) lin_column(L, 0, lane, [&](int r, double v) { Ag[r * H1_NX + lane] = v; });
+  if (lane < H1_NU) lin_column(L, 1, lane, [&](int r, double v) { Bg[r * H1_NU + lane] = v; });
   LSTAMP(6)
 }
 

@@ -34,6 +34,10 @@ int main() {
     for (int i = 0; i < H1_NU; ++i) L.u[i] = u[i];
     double y0[H1_NV];
     qacc_for(x, u, P, nullptr, nullptr, y0, &L.D);
+    for (int i = 0; i < H1_NB; ++i) {   // what lin_load_dump derives from the dump on the device
+      inertia_mul(i, L.D.v[i], L.Iv[i]);
+      if (i > 0) xf_motion(L.D.Rj[i], H1_POS[i], L.D.a[H1_PARENT[i]], L.xa[i]);
+    }
     static double Mref[H1_NV][H1_NV];
     for (int c = 0; c < H1_NV; ++c) {
       double tb[6] = {0,0,0,0,0,0}, dt[H1_NU] = {0}, y[H1_NV];
@@ -47,8 +51,8 @@ int main() {
     for (int lane = 0; lane < 64; ++lane) lin_tangent_lane(L, lane);
     for (int lane = 0; lane < 64; ++lane) lin_apply_minv_lane(L, lane);
     std::vector<double> A(51*51), B(51*19), Ao(51*51), Bo(51*19);
-    for (int k = 0; k < 51; ++k) { double col[51]; lin_column(L, 0, k, col); for (int r = 0; r < 51; ++r) A[r*51+k] = col[r]; }
-    for (int k = 0; k < 19; ++k) { double col[51]; lin_column(L, 1, k, col); for (int r = 0; r < 51; ++r) B[r*19+k] = col[r]; }
+    for (int k = 0; k < 51; ++k) lin_column(L, 0, k, [&](int r, double v) { A[r*51+k] = v; });
+    for (int k = 0; k < 19; ++k) lin_column(L, 1, k, [&](int r, double v) { B[r*19+k] = v; });
     oracle_linearize(x, u, P.h, P.g, Ao.data(), Bo.data());
     double ea = 0, eb = 0; int wa = 0;
     for (int i = 0; i < 51*51; ++i) { double d = std::fabs(A[i]-Ao[i]); if (d > ea) { ea = d; wa = i; } }

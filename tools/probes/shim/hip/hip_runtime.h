@@ -11,3 +11,6 @@
 #define __launch_bounds__(...)
 inline void sincos(double a, double* s, double* c) { *s = std::sin(a); *c = std::cos(a); }
 using std::sqrt; using std::fma; using std::fabs; using std::fmax; using std::fmin;
+using std::rint;
+#define __builtin_amdgcn_sched_barrier(x) ((void)0)
+inline void __syncthreads() {}
