@@ -2,6 +2,7 @@
 // host-side orchestration of iLQR::solve (reference src/ilqr/ilqr.cpp:521-660) as a fixed stream of
 // kernel launches with per-rollout masks on the device -- no host round trip inside a solve.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 
 #include <cmath>
 #include <cstdio>
@@ -288,6 +289,11 @@ static void collect_profile(ilqr_hip_ctx* c) {
   c->spans.clear(); c->pool_next = 0;
 }
 
+static int reuse_rollout() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("ILQR_REUSE_ROLLOUT"); v = (e && e[0] == '1') ? 1 : 0; }
+  return v;
+}
 int ilqr_hip_solve_async(ilqr_hip_ctx* c) {
   if (!c) return ILQR_ERR_ARG;
   if (!c->initialized || !c->refs_set) { c->err = "solve before initialize/set_references"; return ILQR_ERR_STATE; }
@@ -297,10 +303,11 @@ int ilqr_hip_solve_async(ilqr_hip_ctx* c) {
   c->spans.clear(); c->pool_next = 0;
   { StageTimer T(c, 0); ilqr::launch_rollout(S, P, ilqr::MASK_ALL, 0, 0, S.Jbase, st); ilqr::launch_solve_begin(S, st); }  // ilqr.cpp:540
   for (int iter = 0; iter < c->max_iter; ++iter) {
-    // :551,563 -- from the second iteration on the nominal trajectory IS the candidate the line search accepted
-    // (or the unchanged previous one): it is already dynamically consistent and its cost is in Jbase, so the
-    // reference's re-rollout would reproduce it and is skipped
-    if (iter == 0) { StageTimer T(c, 0); ilqr::launch_rollout(S, P, ilqr::MASK_ACTIVE, 1, 0, S.Jbase, st); }
+    // :551,563 nominal rollout at the top of every iteration, as the reference does.  From the second iteration on the
+    // nominal trajectory is the candidate the line search accepted (or the unchanged previous one), so the re-rollout
+    // only reproduces it; ILQR_REUSE_ROLLOUT=1 skips it (not the default: the headline metric counts the rollout
+    // as part of an iteration)
+    if (iter == 0 || !reuse_rollout()) { StageTimer T(c, 0); ilqr::launch_rollout(S, P, ilqr::MASK_ACTIVE, 1, 0, S.Jbase, st); }
     // linearisation (:576) and cost quadratics (:588) only depend on the rollout: run them concurrently
     HIPCHK(c, hipEventRecord(c->ev_fork, st));
     HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
