@@ -97,6 +97,15 @@ __global__ void __launch_bounds__(64) k_last_step_r(DevState S, ProblemDev P) {
 // element of K fetched once per rollout instead of once per alpha), multiplies them with the state deviations
 // of all 8 candidates (exchanged through the LDS columns the dynamics step is not using at that point) and the
 // 8 x 8 partial sums are reduce-scattered over the lanes with three exchange steps.
+#ifndef LS_UNROLL
+#define LS_UNROLL 2   // rows of K_t in flight per lane (measured: 1 -> 2.92 ms, 2 -> 2.70 ms, 19 -> 2.72 ms per launch)
+#endif
+// -DLS_STAMP: diagnostic build only -- per-phase cycle sums of thread 0 land in S.J[0..7]
+#ifdef LS_STAMP
+#define LSS(k) { const long long tn_ = clock64(); ph[k] += tn_ - tl; tl = tn_; }
+#else
+#define LSS(k)
+#endif
 __constant__ double ALPHAS_R[8] = {1.0, 0.8, 0.6, 0.4, 0.2, 0.1, 0.05, 0.01};
 __device__ __forceinline__ double shfl_xor_f64(double v, int mask) {
   const int lo = __shfl_xor(__double2loint(v), mask), hi = __shfl_xor(__double2hiint(v), mask);
@@ -122,6 +131,9 @@ __global__ void __launch_bounds__(64) k_line_search_r(DevState S, ProblemDev P, 
   double x[H1_NX], u[H1_NU];
 #pragma unroll
   for (int i = 0; i < H1_NX; ++i) { x[i] = S.x0[(size_t)b * n + i]; xc[i] = x[i]; }
+#ifdef LS_STAMP
+  long long ph[8] = {0}; long long tl = clock64();
+#endif
   double c = 0.0;
   for (int t = 0; t < N; ++t) {
     const double* xbt = xb + t * n;
@@ -138,6 +150,8 @@ __global__ void __launch_bounds__(64) k_line_search_r(DevState S, ProblemDev P, 
       for (int a = 0; a < 8; ++a) dxs[q][a] = (j < H1_NX) ? lds[j * 64 + grp + a] : 0.0;
     }
     __syncthreads();   // the dynamics step below reuses these LDS columns
+    LSS(0)
+#pragma unroll LS_UNROLL
     for (int i = 0; i < H1_NU; ++i) {
       const double* Kr = Kg + ((size_t)t * m + i) * n;
       double kv[7];
@@ -161,13 +175,20 @@ __global__ void __launch_bounds__(64) k_line_search_r(DevState S, ProblemDev P, 
       u[i] = ub[t * m + i] + alpha * kg[t * m + i] + s;
       uc[t * m + i] = u[i];
     }
+    LSS(1)
     c += knot_cost_t(P, b, t, x, u, ComReg());
+    LSS(2)
     h1r::step(x, u, P.dyn.h, P.dyn.g, L, x);       // in place: every read of x precedes the integrator's writes
+    LSS(3)
 #pragma unroll
     for (int i = 0; i < H1_NX; ++i) xc[(t + 1) * n + i] = x[i];
+    LSS(4)
   }
   c += knot_cost_t(P, b, N, x, (const double*)nullptr, ComReg());
   S.cand_cost[(size_t)b * 8 + ai] = c;
+#ifdef LS_STAMP
+  if (gid == 0) for (int q = 0; q < 8; ++q) S.J[q] = (double)ph[q];
+#endif
 }
 
 // primal dump of one knot per lane: see LinDumpG in h1_linearize_dev.h

@@ -32,6 +32,12 @@ if os.environ.get("ILQR_QSTAMPS"):
     for nme, v in zip(names, st):
         print("  %-24s %10.0f cycles  %5.1f %%" % (nme, v, 100 * v / st.sum()))
     print("  total %.0f cycles" % st.sum())
+if os.environ.get("ILQR_SSTAMPS"):
+    names = ["dx exchange", "K dx + reduce", "cost (+CoM)", "dynamics step", "store x"]
+    st = s.cost()[:5]
+    for nme, v in zip(names, st):
+        print("  %-28s %10.0f cycles/step  %5.1f %%" % (nme, v / 25, 100 * v / st.sum()))
+    print("  total %.0f cycles per step" % (st.sum() / 25))
 if os.environ.get("ILQR_LSTAMPS"):
     names = ["load dump", "accumulate forces (lane 0)", "prologue (lane 0)", "Minv sweeps (25 lanes)", "tangent RNEA (47 lanes)", "apply Minv", "columns + store"]
     st = s.cost()[:7]
