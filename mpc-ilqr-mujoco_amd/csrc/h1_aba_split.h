@@ -1,0 +1,580 @@
+// Articulated-body forward dynamics of the H1 on TWO lanes per rollout: the even lane owns the left leg and
+// the left arm, the odd lane the right ones; pelvis and torso are computed redundantly by both.
+//
+// Same algorithm, MuJoCo semantics and block representation as h1_aba_reg.h (one lane per rollout), but half
+// the hinge state and half the serial chain length per lane, and twice the waves (the line search has only
+// 8 x batch candidates: with one lane each, half of the chip's SIMDs would have no wave at all).  Left / right bodies are mirror images with identical joint axes, so both lanes run the
+// same instruction stream; a body constant is `side ? right : left`, which folds to an immediate wherever the
+// two values coincide (masses, x/z offsets, ...).  The two lanes meet three times per dynamics evaluation:
+// the arms' articulated inertia / bias at the torso, the legs' at the pelvis (DPP quad-permute exchange + add,
+// bitwise identical on both lanes), and nowhere in the outward acceleration sweep.
+// U_i, 1/D_i, u_i of the lane's 10 hinges live in LDS between the sweeps (80 slots per lane).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "h1_fast_math.h"
+#include "h1_model_constexpr.h"
+
+#ifndef DEVFN
+#define DEVFN __device__ __forceinline__
+#endif
+
+namespace h1s {
+using namespace h1c;
+
+constexpr int NB = 20, NJ = 19, NQ = 26, NV = 25, NX = 51, NU = 19;
+constexpr double DAMPING = 1.0, ARMATURE = 0.1;
+constexpr int LDS_SLOTS = 8 * 10;   // U(6), Dinv, u for torso + 5 leg + 4 arm hinges of this lane's side
+
+struct LaneLds {           // per-lane column of the LDS scratch: slot s lives at base[s * stride + lane]
+  double* base; int stride, lane;
+  DEVFN double& operator[](int s) const { return base[s * stride + lane]; }
+};
+
+// value of the partner lane (lane ^ 1)
+DEVFN double xch(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0xB1, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+DEVFN double pair_sum(double v) { return v + xch(v); }   // a + b == b + a: identical on both lanes
+
+#define SD(IL, IR, expr_l, expr_r) ((IL) == (IR) ? (expr_l) : (side ? (expr_r) : (expr_l)))
+
+struct Art { double A[6], B[9], C[6]; };   // [[A, B], [B^T, C]], A and C symmetric (xx, xy, xz, yy, yz, zz)
+// packed symmetric index (xx, xy, xz, yy, yz, zz); not recursive on purpose (see h1_aba_reg.h)
+DEVFN constexpr int sidx(int r, int c) { const int lo = r < c ? r : c, hi = r < c ? c : r; return lo * 3 - lo * (lo + 1) / 2 + hi; }
+
+DEVFN void cross(const double* a, const double* b, double* c) {
+  const double c0 = a[1] * b[2] - a[2] * b[1], c1 = a[2] * b[0] - a[0] * b[2], c2 = a[0] * b[1] - a[1] * b[0];
+  c[0] = c0; c[1] = c1; c[2] = c2;
+}
+template <int AX> DEVFN void cross_axis(const double* a, double* o) {   // a x e_AX
+  if constexpr (AX == 0) { o[0] = 0.0; o[1] = a[2]; o[2] = -a[1]; }
+  else if constexpr (AX == 1) { o[0] = -a[2]; o[1] = 0.0; o[2] = a[0]; }
+  else { o[0] = a[1]; o[1] = -a[0]; o[2] = 0.0; }
+}
+template <int I> constexpr bool rfix_identity() {
+  return C_RFIX[I][0][0] == 1.0 && C_RFIX[I][1][1] == 1.0 && C_RFIX[I][2][2] == 1.0;
+}
+#define RF(r, c) SD(IL, IR, C_RFIX[IL][r][c], C_RFIX[IR][r][c])
+#define PS(k) SD(IL, IR, C_POS[IL][k], C_POS[IR][k])
+#define CM(k) SD(IL, IR, C_COM[IL][k], C_COM[IR][k])
+#define IN(r, c) SD(IL, IR, C_INERTIA[IL][r][c], C_INERTIA[IR][r][c])
+#define MS SD(IL, IR, C_MASS[IL], C_MASS[IR])
+
+// y = Rj x with Rj = Rfix * Rot(AX, theta) (child -> parent coordinates)
+template <int IL, int IR> DEVFN void rot(bool side, const double* x, double s, double c, double* y) {
+  static_assert(C_AXIS[IL] == C_AXIS[IR] && rfix_identity<IL>() == rfix_identity<IR>(), "mirror bodies");
+  constexpr int a = C_AXIS[IL], b = (a + 1) % 3, d = (a + 2) % 3;
+  double t[3];
+  t[a] = x[a]; t[b] = c * x[b] - s * x[d]; t[d] = s * x[b] + c * x[d];
+  if constexpr (rfix_identity<IL>()) { y[0] = t[0]; y[1] = t[1]; y[2] = t[2]; }
+  else {
+    y[0] = RF(0, 0) * t[0] + RF(0, 1) * t[1] + RF(0, 2) * t[2];
+    y[1] = RF(1, 0) * t[0] + RF(1, 1) * t[1] + RF(1, 2) * t[2];
+    y[2] = RF(2, 0) * t[0] + RF(2, 1) * t[1] + RF(2, 2) * t[2];
+  }
+}
+// y = Rj^T x
+template <int IL, int IR> DEVFN void rotT(bool side, const double* x, double s, double c, double* y) {
+  constexpr int a = C_AXIS[IL], b = (a + 1) % 3, d = (a + 2) % 3;
+  double t[3];
+  if constexpr (rfix_identity<IL>()) { t[0] = x[0]; t[1] = x[1]; t[2] = x[2]; }
+  else {
+    t[0] = RF(0, 0) * x[0] + RF(1, 0) * x[1] + RF(2, 0) * x[2];
+    t[1] = RF(0, 1) * x[0] + RF(1, 1) * x[1] + RF(2, 1) * x[2];
+    t[2] = RF(0, 2) * x[0] + RF(1, 2) * x[1] + RF(2, 2) * x[2];
+  }
+  y[a] = t[a]; y[b] = c * t[b] + s * t[d]; y[d] = -s * t[b] + c * t[d];
+}
+// motion transform parent -> child
+template <int IL, int IR> DEVFN void xf_motion(bool side, const double* vp, double s, double c, double* vc) {
+  const double r[3] = {PS(0), PS(1), PS(2)};
+  double t[3]; cross(vp, r, t);
+  const double lin[3] = {vp[3] + t[0], vp[4] + t[1], vp[5] + t[2]};
+  rotT<IL, IR>(side, vp, s, c, vc); rotT<IL, IR>(side, lin, s, c, vc + 3);
+}
+// inverse motion transform child -> parent: vp = X^-1 vc
+template <int IL, int IR> DEVFN void xf_motion_inv(bool side, const double* vc, double s, double c, double* vp) {
+  const double r[3] = {PS(0), PS(1), PS(2)};
+  double lin[3], t[3];
+  rot<IL, IR>(side, vc, s, c, vp); rot<IL, IR>(side, vc + 3, s, c, lin);
+  cross(vp, r, t);
+  vp[3] = lin[0] - t[0]; vp[4] = lin[1] - t[1]; vp[5] = lin[2] - t[2];
+}
+// force transform child -> parent, accumulating
+template <int IL, int IR> DEVFN void xf_force_acc(bool side, const double* fc, double s, double c, double* fp) {
+  const double r[3] = {PS(0), PS(1), PS(2)};
+  double n[3], f[3], rf[3]; rot<IL, IR>(side, fc, s, c, n); rot<IL, IR>(side, fc + 3, s, c, f); cross(r, f, rf);
+  fp[0] += n[0] + rf[0]; fp[1] += n[1] + rf[1]; fp[2] += n[2] + rf[2];
+  fp[3] += f[0]; fp[4] += f[1]; fp[5] += f[2];
+}
+// spatial inertia (about the body frame origin) times a motion vector
+template <int IL, int IR> DEVFN void inertia_mul(bool side, const double* a, double* f) {
+  const double m = MS;
+  const double c[3] = {CM(0), CM(1), CM(2)};
+  const double Iw0 = IN(0, 0) * a[0] + IN(0, 1) * a[1] + IN(0, 2) * a[2];
+  const double Iw1 = IN(1, 0) * a[0] + IN(1, 1) * a[1] + IN(1, 2) * a[2];
+  const double Iw2 = IN(2, 0) * a[0] + IN(2, 1) * a[1] + IN(2, 2) * a[2];
+  const double wc[3] = {a[1] * c[2] - a[2] * c[1], a[2] * c[0] - a[0] * c[2], a[0] * c[1] - a[1] * c[0]};
+  const double fl[3] = {m * (a[3] + wc[0]), m * (a[4] + wc[1]), m * (a[5] + wc[2])};
+  f[0] = Iw0 + (c[1] * fl[2] - c[2] * fl[1]);
+  f[1] = Iw1 + (c[2] * fl[0] - c[0] * fl[2]);
+  f[2] = Iw2 + (c[0] * fl[1] - c[1] * fl[0]);
+  f[3] = fl[0]; f[4] = fl[1]; f[5] = fl[2];
+}
+// v x* f
+DEVFN void crf(const double* v, const double* f, double* out) {
+  double a[3], b[3], c[3]; cross(v, f, a); cross(v + 3, f + 3, b); cross(v, f + 3, c);
+  out[0] = a[0] + b[0]; out[1] = a[1] + b[1]; out[2] = a[2] + b[2]; out[3] = c[0]; out[4] = c[1]; out[5] = c[2];
+}
+// rigid-body inertia as blocks
+template <int IL, int IR> DEVFN void body_inertia(bool side, Art& Y) {
+  const double m = MS;
+  const double cx = CM(0), cy = CM(1), cz = CM(2), cc = cx * cx + cy * cy + cz * cz;
+  Y.A[0] = IN(0, 0) + m * (cc - cx * cx); Y.A[1] = IN(0, 1) - m * cx * cy; Y.A[2] = IN(0, 2) - m * cx * cz;
+  Y.A[3] = IN(1, 1) + m * (cc - cy * cy); Y.A[4] = IN(1, 2) - m * cy * cz; Y.A[5] = IN(2, 2) + m * (cc - cz * cz);
+  Y.B[0] = 0.0; Y.B[1] = -m * cz; Y.B[2] = m * cy; Y.B[3] = m * cz; Y.B[4] = 0.0; Y.B[5] = -m * cx; Y.B[6] = -m * cy; Y.B[7] = m * cx; Y.B[8] = 0.0;
+  Y.C[0] = m; Y.C[1] = 0.0; Y.C[2] = 0.0; Y.C[3] = m; Y.C[4] = 0.0; Y.C[5] = m;
+}
+DEVFN void art_add(Art& Y, const Art& X) {
+#pragma unroll
+  for (int k = 0; k < 6; ++k) { Y.A[k] += X.A[k]; Y.C[k] += X.C[k]; }
+#pragma unroll
+  for (int k = 0; k < 9; ++k) Y.B[k] += X.B[k];
+}
+DEVFN void art_zero(Art& Y) {
+#pragma unroll
+  for (int k = 0; k < 6; ++k) { Y.A[k] = 0.0; Y.C[k] = 0.0; }
+#pragma unroll
+  for (int k = 0; k < 9; ++k) Y.B[k] = 0.0;
+}
+DEVFN void art_pair_sum(Art& Y) {
+#pragma unroll
+  for (int k = 0; k < 6; ++k) { Y.A[k] = pair_sum(Y.A[k]); Y.C[k] = pair_sum(Y.C[k]); }
+#pragma unroll
+  for (int k = 0; k < 9; ++k) Y.B[k] = pair_sum(Y.B[k]);
+}
+// M (general 3x3, row-major) <- Rj M Rj^T
+template <int IL, int IR> DEVFN void rot_congruence(bool side, double* M, double s, double c) {
+  double T[9];
+#pragma unroll
+  for (int col = 0; col < 3; ++col) { const double x[3] = {M[col], M[3 + col], M[6 + col]}; double y[3]; rot<IL, IR>(side, x, s, c, y); T[col] = y[0]; T[3 + col] = y[1]; T[6 + col] = y[2]; }
+#pragma unroll
+  for (int row = 0; row < 3; ++row) { double y[3]; rot<IL, IR>(side, T + 3 * row, s, c, y); M[3 * row] = y[0]; M[3 * row + 1] = y[1]; M[3 * row + 2] = y[2]; }
+}
+DEVFN void sym_to_full(const double* S, double* M) { M[0] = S[0]; M[1] = S[1]; M[2] = S[2]; M[3] = S[1]; M[4] = S[3]; M[5] = S[4]; M[6] = S[2]; M[7] = S[4]; M[8] = S[5]; }
+// Yp += X^T Ya X for the joint transform (rotation Rj, then translation by r = pos)
+template <int IL, int IR> DEVFN void fold_art(bool side, const Art& Ya, double s, double c, Art& Yp) {
+  double A[9], B[9], C[9];
+  sym_to_full(Ya.A, A); sym_to_full(Ya.C, C);
+#pragma unroll
+  for (int k = 0; k < 9; ++k) B[k] = Ya.B[k];
+  rot_congruence<IL, IR>(side, A, s, c); rot_congruence<IL, IR>(side, B, s, c); rot_congruence<IL, IR>(side, C, s, c);
+  const double rx = PS(0), ry = PS(1), rz = PS(2);
+  const double R[9] = {0.0, -rz, ry, rz, 0.0, -rx, -ry, rx, 0.0};
+  double RC[9], Bp[9];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { RC[3 * i + j] = R[3 * i] * C[j] + R[3 * i + 1] * C[3 + j] + R[3 * i + 2] * C[6 + j]; Bp[3 * i + j] = B[3 * i + j] + RC[3 * i + j]; }
+  double Ap[9];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const double rbt = R[3 * i] * B[3 * j] + R[3 * i + 1] * B[3 * j + 1] + R[3 * i + 2] * B[3 * j + 2];
+      const double bprt = Bp[3 * i] * R[3 * j] + Bp[3 * i + 1] * R[3 * j + 1] + Bp[3 * i + 2] * R[3 * j + 2];
+      Ap[3 * i + j] = A[3 * i + j] + rbt + bprt;
+    }
+  Yp.A[0] += Ap[0]; Yp.A[1] += 0.5 * (Ap[1] + Ap[3]); Yp.A[2] += 0.5 * (Ap[2] + Ap[6]); Yp.A[3] += Ap[4]; Yp.A[4] += 0.5 * (Ap[5] + Ap[7]); Yp.A[5] += Ap[8];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) Yp.B[k] += Bp[k];
+  Yp.C[0] += C[0]; Yp.C[1] += 0.5 * (C[1] + C[3]); Yp.C[2] += 0.5 * (C[2] + C[6]); Yp.C[3] += C[4]; Yp.C[4] += 0.5 * (C[5] + C[7]); Yp.C[5] += C[8];
+}
+
+// ---- per-body sweeps -------------------------------------------------------------------------------
+struct BodyState { double v[6], pA[6], s, c; };   // chain-local between the outward and inward sweeps
+
+template <int IL, int IR> DEVFN void body_out(bool side, const double* vp, double theta, double qd, BodyState& S) {
+  constexpr int AX = C_AXIS[IL];
+  h1f::sincos_fast(theta, &S.s, &S.c);
+  xf_motion<IL, IR>(side, vp, S.s, S.c, S.v);
+  S.v[AX] += qd;
+  double Iv[6]; inertia_mul<IL, IR>(side, S.v, Iv);
+  crf(S.v, Iv, S.pA);
+}
+// inward step of a hinge body: Y = its articulated inertia (own + children), S.pA = bias (own + children).
+// Writes U, 1/D, u to LDS slot block `slot`, folds the projected inertia / bias into the parent's accumulators.
+template <int IL, int IR> DEVFN void body_in(bool side, Art& Y, BodyState& S, double tau, double qd, double arm_eff, const LaneLds& L, int slot, Art& Yp, double* pAp) {
+  constexpr int AX = C_AXIS[IL];
+  double Ua[3], Ul[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { Ua[k] = Y.A[sidx(k, AX)]; Ul[k] = Y.B[3 * AX + k]; }
+  const double D = Ua[AX] + arm_eff, di = 1.0 / D;
+  const double u = tau - S.pA[AX];
+  L[slot + 0] = Ua[0]; L[slot + 1] = Ua[1]; L[slot + 2] = Ua[2]; L[slot + 3] = Ul[0]; L[slot + 4] = Ul[1]; L[slot + 5] = Ul[2];
+  L[slot + 6] = di; L[slot + 7] = u;
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = r; c < 3; ++c) { Y.A[sidx(r, c)] -= Ua[r] * Ua[c] * di; Y.C[sidx(r, c)] -= Ul[r] * Ul[c] * di; }
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) Y.B[3 * r + c] -= Ua[r] * Ul[c] * di;
+  double ca[3], cl[3]; cross_axis<AX>(S.v, ca); cross_axis<AX>(S.v + 3, cl);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { ca[k] *= qd; cl[k] *= qd; }
+  double pa[6];
+  const double ud = u * di;
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    pa[r] = S.pA[r] + Ua[r] * ud + Y.A[sidx(r, 0)] * ca[0] + Y.A[sidx(r, 1)] * ca[1] + Y.A[sidx(r, 2)] * ca[2] + Y.B[3 * r] * cl[0] + Y.B[3 * r + 1] * cl[1] + Y.B[3 * r + 2] * cl[2];
+    pa[3 + r] = S.pA[3 + r] + Ul[r] * ud + Y.B[r] * ca[0] + Y.B[3 + r] * ca[1] + Y.B[6 + r] * ca[2] + Y.C[sidx(r, 0)] * cl[0] + Y.C[sidx(r, 1)] * cl[1] + Y.C[sidx(r, 2)] * cl[2];
+  }
+  fold_art<IL, IR>(side, Y, S.s, S.c, Yp);
+  xf_force_acc<IL, IR>(side, pa, S.s, S.c, pAp);
+}
+// outward acceleration step: in (vp, ap) of the parent, out (v, a) of the body and its joint acceleration
+template <int IL, int IR> DEVFN double body_acc(bool side, const double* vp, const double* ap, double theta, double qd, const LaneLds& L, int slot, double* v, double* a) {
+  constexpr int AX = C_AXIS[IL];
+  double s, c; h1f::sincos_fast(theta, &s, &c);
+  xf_motion<IL, IR>(side, vp, s, c, v); v[AX] += qd;
+  xf_motion<IL, IR>(side, ap, s, c, a);
+  double ca[3], cl[3]; cross_axis<AX>(v, ca); cross_axis<AX>(v + 3, cl);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { a[k] += qd * ca[k]; a[3 + k] += qd * cl[k]; }
+  double sum = L[slot + 7];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) sum -= L[slot + k] * a[k];
+  const double qdd = sum * L[slot + 6];
+  a[AX] += qdd;
+  return qdd;
+}
+
+// ---- mirrored chains: bodies FL.. (even lane) / FR.. (odd lane), LEN hinges, LDS slot blocks from SLOT0 ------
+// Register-lean sweeps: the outward pass keeps only the running velocity and the joint sines / cosines; the inward
+// pass recovers each parent velocity with the inverse joint transform (v_parent = X^-1 (v - S qd)) and recomputes
+// the velocity-product force from it, instead of holding 12 numbers per body across the two passes.
+template <int FL, int FR, int LEN, int SLOT0> struct Chain {
+  // th, qd, tau: this lane's LEN hinge values.  Yj / pAj accumulate this lane's chain only.
+  static DEVFN void in(bool side, const double* vj, const double* th, const double* qd, const double* tau, double arm_eff, const LaneLds& L,
+                       Art& Yj, double* pAj) {
+    double sn[LEN], cs[LEN], v[6];
+    step_out<0>(side, vj, th, qd, sn, cs, v);          // v = velocity of the chain's last body
+    Art carry; double pc[6];
+    step_in<LEN - 1>(side, qd, tau, arm_eff, L, sn, cs, v, carry, pc, Yj, pAj);
+  }
+  template <int K> static DEVFN void step_out(bool side, const double* vp, const double* th, const double* qd, double* sn, double* cs, double* vlast) {
+    constexpr int AX = C_AXIS[FL + K];
+    h1f::sincos_fast(th[K], &sn[K], &cs[K]);
+    double v[6];
+    xf_motion<FL + K, FR + K>(side, vp, sn[K], cs[K], v);
+    v[AX] += qd[K];
+    if constexpr (K + 1 < LEN) step_out<K + 1>(side, v, th, qd, sn, cs, vlast);
+    else {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) vlast[k] = v[k];
+    }
+  }
+  template <int K> static DEVFN void step_in(bool side, const double* qd, const double* tau, double arm_eff, const LaneLds& L,
+                                             const double* sn, const double* cs, double* v, Art& carry, double* pc, Art& Yj, double* pAj) {
+    constexpr int AX = C_AXIS[FL + K];
+    BodyState S;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) S.v[k] = v[k];
+    S.s = sn[K]; S.c = cs[K];
+    { double Iv[6]; inertia_mul<FL + K, FR + K>(side, S.v, Iv); crf(S.v, Iv, S.pA); }
+    Art Y; body_inertia<FL + K, FR + K>(side, Y);
+    if constexpr (K < LEN - 1) {
+      art_add(Y, carry);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) S.pA[k] += pc[k];
+    }
+    if constexpr (K > 0) {
+      art_zero(carry);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) pc[k] = 0.0;
+      body_in<FL + K, FR + K>(side, Y, S, tau[K], qd[K], arm_eff, L, SLOT0 + 8 * K, carry, pc);
+      // parent's velocity for the next inward step
+      double vc[6] = {v[0], v[1], v[2], v[3], v[4], v[5]};
+      vc[AX] -= qd[K];
+      xf_motion_inv<FL + K, FR + K>(side, vc, sn[K], cs[K], v);
+      step_in<K - 1>(side, qd, tau, arm_eff, L, sn, cs, v, carry, pc, Yj, pAj);
+    } else {
+      body_in<FL + K, FR + K>(side, Y, S, tau[K], qd[K], arm_eff, L, SLOT0 + 8 * K, Yj, pAj);
+    }
+  }
+  template <int K> static DEVFN void acc(bool side, const double* vp, const double* ap, const double* th, const double* qd, const LaneLds& L, double* qdd) {
+    double v[6], a[6];
+    qdd[K] = body_acc<FL + K, FR + K>(side, vp, ap, th[K], qd[K], L, SLOT0 + 8 * K, v, a);
+    if constexpr (K + 1 < LEN) acc<K + 1>(side, v, a, th, qd, L, qdd);
+  }
+};
+
+// solve the SPD 6x6 system (blocks of Art) Y a = rhs by LDL^T
+DEVFN void solve6(const Art& Y, const double* rhs, double* out) {
+  double M[36];
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { M[6 * r + c] = Y.A[sidx(r, c)]; M[6 * r + 3 + c] = Y.B[3 * r + c]; M[6 * (3 + r) + c] = Y.B[3 * c + r]; M[6 * (3 + r) + 3 + c] = Y.C[sidx(r, c)]; }
+  double Lm[36], d[6];
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    double s = M[6 * j + j];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) if (k < j) s -= Lm[6 * j + k] * Lm[6 * j + k] * d[k];
+    d[j] = s;
+    const double inv = 1.0 / s;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) if (i > j) {
+      double t = M[6 * i + j];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) if (k < j) t -= Lm[6 * i + k] * Lm[6 * j + k] * d[k];
+      Lm[6 * i + j] = t * inv;
+    }
+  }
+  double z[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) { double s = rhs[i];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) if (k < i) s -= Lm[6 * i + k] * z[k];
+    z[i] = s; }
+#pragma unroll
+  for (int i = 0; i < 6; ++i) z[i] = z[i] / d[i];
+#pragma unroll
+  for (int i = 5; i >= 0; --i) { double s = z[i];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) if (k > i) s -= Lm[6 * k + i] * out[k];
+    out[i] = s; }
+}
+
+// this lane's share of the hinge state: torso + own leg (5) + own arm (4)
+struct HalfState {
+  double th11, qd11, thL[5], qdL[5], thA[4], qdA[4];
+};
+struct HalfTau { double t11, tL[5], tA[4]; };
+struct HalfAcc { double q11, qL[5], qA[4]; };
+
+typedef Chain<1, 6, 5, 8> LegChain;      // bodies 1..5 / 6..10, LDS slots 8..47
+typedef Chain<12, 16, 4, 48> ArmChain;   // bodies 12..15 / 16..19, LDS slots 48..79
+
+// Forward dynamics in MuJoCo coordinates.  R0: base rotation from the unit quaternion; vb = qvel[0..5];
+// qbase[6] (identical on both lanes) and this lane's hinge accelerations out.
+DEVFN void forward_dynamics(bool side, const double* R0, const double* vb, const HalfState& q, const HalfTau& tau, double arm_eff,
+                            const double* grav, const LaneLds& L, double* qbase, HalfAcc& qacc) {
+  double v0[6] = {vb[3], vb[4], vb[5], 0, 0, 0};
+  v0[3] = R0[0] * vb[0] + R0[3] * vb[1] + R0[6] * vb[2];
+  v0[4] = R0[1] * vb[0] + R0[4] * vb[1] + R0[7] * vb[2];
+  v0[5] = R0[2] * vb[0] + R0[5] * vb[1] + R0[8] * vb[2];
+  // torso velocity is needed by the arm before the torso's own inward step
+  BodyState T11; body_out<11, 11>(side, v0, q.th11, q.qd11, T11);
+  Art Y0; double p0[6];
+  {
+    Art Yt; art_zero(Yt); double pt[6] = {0, 0, 0, 0, 0, 0};
+    ArmChain::in(side, T11.v, q.thA, q.qdA, tau.tA, arm_eff, L, Yt, pt);
+    art_pair_sum(Yt);                         // left + right arm
+#pragma unroll
+    for (int k = 0; k < 6; ++k) pt[k] = pair_sum(pt[k]);
+    Art Y; body_inertia<11, 11>(side, Y); art_add(Y, Yt);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) T11.pA[k] += pt[k];
+    art_zero(Y0);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) p0[k] = 0.0;
+    body_in<11, 11>(side, Y, T11, tau.t11, q.qd11, arm_eff, L, 0, Y0, p0);   // torso's share of the pelvis (both lanes)
+  }
+  {
+    Art Yl; art_zero(Yl); double pl[6] = {0, 0, 0, 0, 0, 0};
+    LegChain::in(side, v0, q.thL, q.qdL, tau.tL, arm_eff, L, Yl, pl);
+    art_pair_sum(Yl);                         // left + right leg
+#pragma unroll
+    for (int k = 0; k < 6; ++k) pl[k] = pair_sum(pl[k]);
+    art_add(Y0, Yl);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) p0[k] += pl[k];
+    Art Yb; body_inertia<0, 0>(side, Yb); art_add(Y0, Yb);
+    double Iv[6], pv[6]; inertia_mul<0, 0>(side, v0, Iv); crf(v0, Iv, pv);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) p0[k] += pv[k];
+  }
+  // pelvis
+  double rhs[6] = {-p0[0], -p0[1], -p0[2], -p0[3], -p0[4], -p0[5]}, a0[6];
+  solve6(Y0, rhs, a0);
+  const double mg[3] = {-grav[0], -grav[1], -grav[2]};
+  const double a0p[3] = {R0[0] * mg[0] + R0[3] * mg[1] + R0[6] * mg[2], R0[1] * mg[0] + R0[4] * mg[1] + R0[7] * mg[2], R0[2] * mg[0] + R0[5] * mg[1] + R0[8] * mg[2]};
+  double wxv[3]; cross(v0, v0 + 3, wxv);
+  const double lin[3] = {a0[3] - a0p[0] + wxv[0], a0[4] - a0p[1] + wxv[1], a0[5] - a0p[2] + wxv[2]};
+  qbase[0] = R0[0] * lin[0] + R0[1] * lin[1] + R0[2] * lin[2];
+  qbase[1] = R0[3] * lin[0] + R0[4] * lin[1] + R0[5] * lin[2];
+  qbase[2] = R0[6] * lin[0] + R0[7] * lin[1] + R0[8] * lin[2];
+  qbase[3] = a0[0]; qbase[4] = a0[1]; qbase[5] = a0[2];
+  // outward accelerations
+  double v11[6], a11[6];
+  qacc.q11 = body_acc<11, 11>(side, v0, a0, q.th11, q.qd11, L, 0, v11, a11);
+  ArmChain::acc<0>(side, v11, a11, q.thA, q.qdA, L, qacc.qA);
+  LegChain::acc<0>(side, v0, a0, q.thL, q.qdL, L, qacc.qL);
+}
+
+DEVFN void quat_R(double w, double x, double y, double z, double* R) {
+  R[0] = 1.0 - 2.0 * (y * y + z * z); R[1] = 2.0 * (x * y - w * z); R[2] = 2.0 * (x * z + w * y);
+  R[3] = 2.0 * (x * y + w * z); R[4] = 1.0 - 2.0 * (x * x + z * z); R[5] = 2.0 * (y * z - w * x);
+  R[6] = 2.0 * (x * z - w * y); R[7] = 2.0 * (y * z + w * x); R[8] = 1.0 - 2.0 * (x * x + y * y);
+}
+
+// this lane's view of one state x = [qpos(26), qvel(25)]: the floating base (both lanes) + its HalfState
+struct HalfX { double p[3], quat[4], vb[6]; HalfState q; };
+struct HalfU { double u11, uL[5], uA[4]; };
+// hinge j of this lane: leg k -> 5 side + k, arm k -> 11 + 4 side + k, torso -> 10
+DEVFN int jleg(bool side, int k) { return (side ? 5 : 0) + k; }
+DEVFN int jarm(bool side, int k) { return (side ? 15 : 11) + k; }
+
+DEVFN void load_half(bool side, const double* x, HalfX& h) {
+#pragma unroll
+  for (int k = 0; k < 3; ++k) h.p[k] = x[k];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) h.quat[k] = x[3 + k];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) h.vb[k] = x[NQ + k];
+  h.q.th11 = x[7 + 10]; h.q.qd11 = x[NQ + 6 + 10];
+#pragma unroll
+  for (int k = 0; k < 5; ++k) { h.q.thL[k] = x[7 + jleg(side, k)]; h.q.qdL[k] = x[NQ + 6 + jleg(side, k)]; }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { h.q.thA[k] = x[7 + jarm(side, k)]; h.q.qdA[k] = x[NQ + 6 + jarm(side, k)]; }
+}
+// the even lane stores the shared coordinates, every lane its own hinges
+DEVFN void store_half(bool side, const HalfX& h, double* x) {
+  if (!side) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) x[k] = h.p[k];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) x[3 + k] = h.quat[k];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) x[NQ + k] = h.vb[k];
+    x[7 + 10] = h.q.th11; x[NQ + 6 + 10] = h.q.qd11;
+  }
+#pragma unroll
+  for (int k = 0; k < 5; ++k) { x[7 + jleg(side, k)] = h.q.thL[k]; x[NQ + 6 + jleg(side, k)] = h.q.qdL[k]; }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { x[7 + jarm(side, k)] = h.q.thA[k]; x[NQ + 6 + jarm(side, k)] = h.q.qdA[k]; }
+}
+DEVFN double clampu(double u, const double* range) { return u < range[0] ? range[0] : (u > range[1] ? range[1] : u); }
+
+// x <- f(x, u) in place: RobotUtils::rolloutOneStep (reference src/common/robot_utils.cpp:106-117), smooth regime
+DEVFN void step(bool side, HalfX& h, const HalfU& u, double dt, const double* grav, const LaneLds& L) {
+  const double qn = sqrt(h.quat[0] * h.quat[0] + h.quat[1] * h.quat[1] + h.quat[2] * h.quat[2] + h.quat[3] * h.quat[3]);
+  const double qh[4] = {h.quat[0] / qn, h.quat[1] / qn, h.quat[2] / qn, h.quat[3] / qn};
+  double R0[9]; quat_R(qh[0], qh[1], qh[2], qh[3], R0);
+  HalfTau tau;
+  tau.t11 = clampu(u.u11, C_CTRLRANGE[10]) - DAMPING * h.q.qd11;
+#pragma unroll
+  for (int k = 0; k < 5; ++k) {
+    const double lo = side ? C_CTRLRANGE[5 + k][0] : C_CTRLRANGE[k][0], hi = side ? C_CTRLRANGE[5 + k][1] : C_CTRLRANGE[k][1];
+    const double uc = u.uL[k] < lo ? lo : (u.uL[k] > hi ? hi : u.uL[k]);
+    tau.tL[k] = uc - DAMPING * h.q.qdL[k];
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const double lo = side ? C_CTRLRANGE[15 + k][0] : C_CTRLRANGE[11 + k][0], hi = side ? C_CTRLRANGE[15 + k][1] : C_CTRLRANGE[11 + k][1];
+    const double uc = u.uA[k] < lo ? lo : (u.uA[k] > hi ? hi : u.uA[k]);
+    tau.tA[k] = uc - DAMPING * h.q.qdA[k];
+  }
+  double qb[6]; HalfAcc qa;
+  forward_dynamics(side, R0, h.vb, h.q, tau, ARMATURE + dt * DAMPING, grav, L, qb, qa);
+  // semi-implicit Euler: v' = v + h qacc, q' = q (+) h v'
+#pragma unroll
+  for (int k = 0; k < 6; ++k) h.vb[k] += dt * qb[k];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) h.p[k] += dt * h.vb[k];
+  h.q.qd11 += dt * qa.q11; h.q.th11 += dt * h.q.qd11;
+#pragma unroll
+  for (int k = 0; k < 5; ++k) { h.q.qdL[k] += dt * qa.qL[k]; h.q.thL[k] += dt * h.q.qdL[k]; }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { h.q.qdA[k] += dt * qa.qA[k]; h.q.thA[k] += dt * h.q.qdA[k]; }
+  const double s = (h.vb[3] * h.vb[3] + h.vb[4] * h.vb[4] + h.vb[5] * h.vb[5]) * (dt * dt);
+  double c, so;
+  if (s < 1e-6) { c = 1.0 - s / 8.0 + s * s / 384.0 - s * s * s / 46080.0; so = 0.5 - s / 48.0 + s * s / 3840.0 - s * s * s / 645120.0; }
+  else { const double a = sqrt(s); double sn, cn; h1f::sincos_fast(0.5 * a, &sn, &cn); c = cn; so = sn / a; }
+  const double ew = c, ex = so * dt * h.vb[3], ey = so * dt * h.vb[4], ez = so * dt * h.vb[5];
+  const double rw = qh[0] * ew - qh[1] * ex - qh[2] * ey - qh[3] * ez;
+  const double rx = qh[0] * ex + qh[1] * ew + qh[2] * ez - qh[3] * ey;
+  const double ry = qh[0] * ey - qh[1] * ez + qh[2] * ew + qh[3] * ex;
+  const double rz = qh[0] * ez + qh[1] * ey - qh[2] * ex + qh[3] * ew;
+  const double rn = sqrt(rw * rw + rx * rx + ry * ry + rz * rz);
+  h.quat[0] = rw / rn; h.quat[1] = rx / rn; h.quat[2] = ry / rn; h.quat[3] = rz / rn;
+}
+
+// ---- whole-body CoM with MuJoCo masses (RobotUtils::computeCoM, reference src/common/robot_utils.cpp:810-833):
+// each lane sums the bodies of its side, pelvis and torso are counted by the even lane, then the pair adds up
+template <int IL, int IR, int LEN, int K> DEVFN void com_chain(bool side, const double* Rp, const double* pp, const double* th, double* acc) {
+  constexpr int a = C_AXIS[IL], b = (a + 1) % 3, d = (a + 2) % 3;
+  double s, c; h1f::sincos_fast(th[K], &s, &c);
+  double R[9];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    double f[3];
+    if constexpr (rfix_identity<IL>()) { f[0] = Rp[3 * r]; f[1] = Rp[3 * r + 1]; f[2] = Rp[3 * r + 2]; }
+    else {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) f[k] = Rp[3 * r] * RF(0, k) + Rp[3 * r + 1] * RF(1, k) + Rp[3 * r + 2] * RF(2, k);
+    }
+    R[3 * r + a] = f[a]; R[3 * r + b] = f[b] * c + f[d] * s; R[3 * r + d] = f[d] * c - f[b] * s;
+  }
+  double p[3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) p[r] = pp[r] + Rp[3 * r] * PS(0) + Rp[3 * r + 1] * PS(1) + Rp[3 * r + 2] * PS(2);
+#pragma unroll
+  for (int r = 0; r < 3; ++r) acc[r] += MS * (p[r] + R[3 * r] * CM(0) + R[3 * r + 1] * CM(1) + R[3 * r + 2] * CM(2));
+  if constexpr (K + 1 < LEN) com_chain<IL + 1, IR + 1, LEN, K + 1>(side, R, p, th, acc);
+}
+DEVFN void com_mj(bool side, const HalfX& h, double* com) {
+  const double qn = sqrt(h.quat[0] * h.quat[0] + h.quat[1] * h.quat[1] + h.quat[2] * h.quat[2] + h.quat[3] * h.quat[3]);
+  double R0[9]; quat_R(h.quat[0] / qn, h.quat[1] / qn, h.quat[2] / qn, h.quat[3] / qn, R0);
+  double acc[3] = {0.0, 0.0, 0.0};
+  // torso frame (both lanes need it for the arm)
+  double R11[9], p11[3];
+  {
+    constexpr int IL = 11, IR = 11;
+    constexpr int a = C_AXIS[11], b = (a + 1) % 3, d = (a + 2) % 3;
+    double s, c; h1f::sincos_fast(h.q.th11, &s, &c);
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      double f[3];
+      if constexpr (rfix_identity<11>()) { f[0] = R0[3 * r]; f[1] = R0[3 * r + 1]; f[2] = R0[3 * r + 2]; }
+      else {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) f[k] = R0[3 * r] * C_RFIX[11][0][k] + R0[3 * r + 1] * C_RFIX[11][1][k] + R0[3 * r + 2] * C_RFIX[11][2][k];
+      }
+      R11[3 * r + a] = f[a]; R11[3 * r + b] = f[b] * c + f[d] * s; R11[3 * r + d] = f[d] * c - f[b] * s;
+    }
+#pragma unroll
+    for (int r = 0; r < 3; ++r) p11[r] = h.p[r] + R0[3 * r] * C_POS[11][0] + R0[3 * r + 1] * C_POS[11][1] + R0[3 * r + 2] * C_POS[11][2];
+    (void)IL; (void)IR;
+  }
+  if (!side) {
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      acc[r] += C_MASS[0] * (h.p[r] + R0[3 * r] * C_COM[0][0] + R0[3 * r + 1] * C_COM[0][1] + R0[3 * r + 2] * C_COM[0][2]);
+      acc[r] += C_MASS[11] * (p11[r] + R11[3 * r] * C_COM[11][0] + R11[3 * r + 1] * C_COM[11][1] + R11[3 * r + 2] * C_COM[11][2]);
+    }
+  }
+  com_chain<1, 6, 5, 0>(side, R0, h.p, h.q.thL, acc);
+  com_chain<12, 16, 4, 0>(side, R11, p11, h.q.thA, acc);
+  double mtot = 0.0;
+#pragma unroll
+  for (int i = 0; i < NB; ++i) mtot += C_MASS[i];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) com[r] = pair_sum(acc[r]) / mtot;
+}
+
+#undef RF
+#undef PS
+#undef CM
+#undef IN
+#undef MS
+#undef SD
+
+}  // namespace h1s

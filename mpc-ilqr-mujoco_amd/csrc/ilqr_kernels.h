@@ -68,6 +68,10 @@ void launch_last_step_r(const DevState& S, const h1::ProblemDev& P, hipStream_t 
 void launch_line_search_r(const DevState& S, const h1::ProblemDev& P, int mode, hipStream_t st);
 void launch_lin_primal_r(const DevState& S, const h1::ProblemDev& P, int mode, hipStream_t st);
 int dyn_kernels_set_attr();
+// dyn_split_kernels.hip: two lanes per rollout / candidate
+void launch_rollout_s(const DevState& S, const h1::ProblemDev& P, int mode, int do_roll, int count_iter, double* cost_out, hipStream_t st);
+void launch_line_search_s(const DevState& S, const h1::ProblemDev& P, int mode, hipStream_t st);
+int dyn_split_kernels_set_attr();
 void launch_backward_mfma(const DevState& S, int mode, hipStream_t st);
 int backward_mfma_set_attr();
 size_t backward_mfma_lds_bytes();
