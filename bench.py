@@ -170,7 +170,7 @@ def main():
             "k_cost_quadratics": dict(stages=["iLQR_costQuadratics"], unit="fp64 VALU",
                                       flops=QUAD_FLOPS_PER_KNOT * (N + 1) * B,
                                       bytes=D * B * (N + 1) * (70 + 2601 + 51 + 19 + 19)),
-            "k_rollout_r": dict(stages=["iLQR_computeCost+forwardRollout"], unit="fp64 VALU",
+            "k_rollout_s": dict(stages=["iLQR_computeCost+forwardRollout"], unit="fp64 VALU",
                                 flops=STEP_FLOPS * N * B, bytes=D * B * N * (51 + 19 + 51)),
         }
         traffic_file = os.path.join(ROOT, "profiles", "traffic_latest.json")
