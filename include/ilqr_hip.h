@@ -143,6 +143,8 @@ int ilqr_hip_get_stage_ms(ilqr_hip_ctx* ctx, double* ms /*[8]*/, double* launche
 /* reference construction as RobotUtils::loadReferences does it (src/common/robot_utils.cpp:369-403):
    whole-body CoM (MuJoCo masses) and world positions of the two ankle bodies */
 int ilqr_hip_reference_kinematics(const double* x /*51*/, double* com /*3*/, double* ee /*[2][3]*/);
+/* CoM-velocity reference of the same loader (mj_jacSubtreeCom(root) * qvel, src/common/robot_utils.cpp:383-391) */
+int ilqr_hip_reference_com_velocity(const double* x /*51*/, double* comvel /*3*/);
 /* RobotUtils::computeGravComp (src/common/robot_utils.cpp:844-866, correct dof index): qfrc_bias[6+i] at v = 0 */
 int ilqr_hip_gravity_compensation(const double* x /*51*/, const double* gravity /*3*/, double* u /*19*/);
 

@@ -50,6 +50,33 @@ void reference_kinematics(const double* x, double* com, double* ee) {
   for (int k = 0; k < 3; ++k) { com[k] /= m; ee[k] = pw[H1_EE_LEFT][k]; ee[3 + k] = pw[H1_EE_RIGHT][k]; }
 }
 
+// whole-body CoM velocity J_com(q) qvel (mj_jacSubtreeCom of the root times qvel, robot_utils.cpp:383-391).
+// MuJoCo free-joint velocity convention: qvel[0:3] linear velocity of the pelvis origin in the world frame,
+// qvel[3:6] angular velocity in the pelvis frame, qvel[6:] hinge rates.
+void reference_com_velocity(const double* x, double* cv) {
+  double Rw[H1_NB][9], pw[H1_NB][3];
+  forward_kinematics(x, Rw, pw);
+  const double* v = x + H1_NQ;
+  double ww[3]; mv(Rw[0], v + 3, ww);   // base angular velocity in the world frame
+  double m = 0.0; cv[0] = cv[1] = cv[2] = 0.0;
+  for (int i = 0; i < H1_NB; ++i) {
+    double c[3]; mv(Rw[i], H1_COM[i], c);
+    const double ci[3] = {pw[i][0] + c[0], pw[i][1] + c[1], pw[i][2] + c[2]};
+    const double d0[3] = {ci[0] - pw[0][0], ci[1] - pw[0][1], ci[2] - pw[0][2]};
+    double vel[3] = {v[0] + ww[1] * d0[2] - ww[2] * d0[1], v[1] + ww[2] * d0[0] - ww[0] * d0[2], v[2] + ww[0] * d0[1] - ww[1] * d0[0]};
+    for (int j = 1; j < H1_NB; ++j) {
+      if (!(j <= i && H1_ANC[j - 1][i - 1])) continue;   // hinge j moves body i
+      const double z[3] = {Rw[j][H1_AXIS[j]], Rw[j][3 + H1_AXIS[j]], Rw[j][6 + H1_AXIS[j]]};
+      const double d[3] = {ci[0] - pw[j][0], ci[1] - pw[j][1], ci[2] - pw[j][2]};
+      const double qd = v[6 + j - 1];
+      vel[0] += qd * (z[1] * d[2] - z[2] * d[1]); vel[1] += qd * (z[2] * d[0] - z[0] * d[2]); vel[2] += qd * (z[0] * d[1] - z[1] * d[0]);
+    }
+    for (int k = 0; k < 3; ++k) cv[k] += H1_MASS[i] * vel[k];
+    m += H1_MASS[i];
+  }
+  for (int k = 0; k < 3; ++k) cv[k] /= m;
+}
+
 // qfrc_bias[6+j] at zero velocity = minus the generalized gravity force on hinge j
 void gravity_compensation(const double* x, const double* g, double* u) {
   double Rw[H1_NB][9], pw[H1_NB][3];

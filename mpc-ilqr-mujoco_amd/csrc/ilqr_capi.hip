@@ -511,6 +511,11 @@ int ilqr_hip_reference_kinematics(const double* x, double* com, double* ee) {
   h1host::reference_kinematics(x, com, ee);
   return ILQR_OK;
 }
+int ilqr_hip_reference_com_velocity(const double* x, double* comvel) {
+  if (!x || !comvel) return ILQR_ERR_ARG;
+  h1host::reference_com_velocity(x, comvel);
+  return ILQR_OK;
+}
 int ilqr_hip_gravity_compensation(const double* x, const double* gravity, double* u) {
   if (!x || !gravity || !u) return ILQR_ERR_ARG;
   h1host::gravity_compensation(x, gravity, u);

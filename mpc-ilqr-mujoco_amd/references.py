@@ -1,0 +1,103 @@
+"""Reference / contact-schedule loader of the MPC (host side, numpy only) -- SURVEY.md 8(f) row f1.
+
+Mirrors, on the reference's own file formats:
+  * RobotUtils::loadReferences       /root/reference/src/common/robot_utils.cpp:281-420
+      q_ref CSV (26 columns, MuJoCo order: p, quat wxyz, 19 hinges) + v_ref CSV (25 columns), no header, one row per
+      time step; rows with the wrong number of columns are skipped; u_ref = 0; per row the whole-body CoM
+      (subtree_com of the pelvis), the CoM velocity J_com qvel and the world positions of the two ankle bodies.
+  * RobotUtils::getReferenceWindow   robot_utils.cpp:422-443   rows t0 .. t0+N, clamped to the last row
+  * RobotUtils::loadContactSchedule  robot_utils.cpp:445-492   CSV with one header line, one row of 0/1 per time step
+  * RobotUtils::isStance             robot_utils.cpp:494-504   out-of-range -> stance
+  * the solver's use of them         ilqr.cpp:703,729-734,767-791 with the HORIZON-LOCAL index t = 0..N for the
+      stance flags, foot references and CoM-velocity references: whatever the MPC step, the
+      solver reads rows 0..N of the full arrays.  `problem_at` reproduces that; `follow_schedule=True` reads rows
+      t0..t0+N instead (what the reference presumably intended).
+The kinematics come from the C ABI (`ilqr_hip_reference_kinematics`, `ilqr_hip_reference_com_velocity`: host code,
+no GPU needed) or any callable with the same signature (the tests pass the oracle's).
+"""
+import numpy as np
+
+NQ, NV, NX, NU = 26, 25, 51, 19
+
+
+def _read_rows(path, ncol, skip_header=False):
+    rows = []
+    with open(path) as f:
+        for k, line in enumerate(f):
+            if skip_header and k == 0:
+                continue
+            vals = []
+            for tok in line.strip().split(","):
+                try:
+                    vals.append(float(tok))
+                except ValueError:       # the reference logs and drops the token (robot_utils.cpp:318-325)
+                    continue
+            if ncol is not None and len(vals) != ncol:
+                continue                 # dimension mismatch: row skipped (robot_utils.cpp:336-341)
+            if vals:
+                rows.append(vals)
+    return rows
+
+
+class ReferenceData:
+    """Full-length references as RobotUtils holds them (x_ref_full_, com_ref_full_, ..., contact_schedule_)."""
+
+    def __init__(self, kin, com_vel=None):
+        self.kin, self.com_vel = kin, com_vel
+        self.x_ref = np.zeros((0, NX)); self.u_ref = np.zeros((0, NU))
+        self.com_ref = np.zeros((0, 3)); self.com_vel_ref = np.zeros((0, 3)); self.ee_ref = np.zeros((0, 2, 3))
+        self.contact = np.zeros((0, 2), dtype=np.int32)
+
+    # -- RobotUtils::loadReferences
+    def load(self, q_ref_path, v_ref_path):
+        q, v = _read_rows(q_ref_path, None), _read_rows(v_ref_path, None)
+        rows = [(a, b) for a, b in zip(q, v) if len(a) == NQ and len(b) == NV]   # lines are consumed pairwise
+        if not rows:
+            return False
+        return self.set_states(np.array([a + b for a, b in rows], dtype=np.float64))
+
+    def set_states(self, x_full):
+        x_full = np.asarray(x_full, dtype=np.float64).reshape(-1, NX)
+        T = x_full.shape[0]
+        self.x_ref = x_full.copy()
+        self.u_ref = np.zeros((T, NU))
+        self.com_ref = np.zeros((T, 3)); self.ee_ref = np.zeros((T, 2, 3)); self.com_vel_ref = np.zeros((T, 3))
+        for t in range(T):
+            self.com_ref[t], self.ee_ref[t] = self.kin(x_full[t])
+            if self.com_vel is not None:
+                self.com_vel_ref[t] = self.com_vel(x_full[t])
+        return T > 0
+
+    # -- RobotUtils::loadContactSchedule
+    def load_contact_schedule(self, path):
+        rows = _read_rows(path, None, skip_header=True)
+        self.contact = np.array([[int(v) for v in r] for r in rows], dtype=np.int32).reshape(len(rows), -1) if rows else np.zeros((0, 2), dtype=np.int32)
+        return len(rows) > 0
+
+    def is_stance(self, ee, t):
+        if t < 0 or t >= self.contact.shape[0] or ee < 0 or ee >= self.contact.shape[1]:
+            return True
+        return int(self.contact[t, ee]) == 1
+
+    # -- RobotUtils::getReferenceWindow
+    def window(self, t0, N):
+        T = self.x_ref.shape[0]
+        idx = np.minimum(t0 + np.arange(N + 1), T - 1)
+        return self.x_ref[idx], self.u_ref[idx[:N]], self.com_ref[idx]
+
+    def _rows(self, arr, t0, N):
+        """rows t0..t0+N of a full-length array; the reference throws past the end (robot_utils.cpp:525-549)."""
+        if t0 + N >= arr.shape[0]:
+            raise IndexError("reference index %d beyond the %d loaded rows" % (t0 + N, arr.shape[0]))
+        return arr[t0:t0 + N + 1]
+
+    def problem_at(self, t0, N, base_problem, follow_schedule=False):
+        """Problem dict for the solve of MPC step t0: window of x_ref / u_ref / com_ref (MPC::extractReferenceWindow,
+        mpc.cpp:163-166) + stance flags, foot and CoM-velocity references by the horizon-local index."""
+        prob = dict(base_problem)
+        xw, uw, cw = self.window(t0, N)
+        s0 = t0 if follow_schedule else 0
+        prob.update(N=N, x_ref=xw[None], u_ref=uw[None], com_ref=cw[None],
+                    stance=np.array([[1 if self.is_stance(e, s0 + t) else 0 for e in range(2)] for t in range(N + 1)], dtype=np.int32)[None],
+                    ee_ref=self._rows(self.ee_ref, s0, N)[None].copy(), com_vel_ref=self._rows(self.com_vel_ref, s0, N)[None].copy())
+        return prob

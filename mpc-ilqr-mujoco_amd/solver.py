@@ -35,7 +35,7 @@ EXPORTS = [
     "ilqr_hip_stage_backward_pass", "ilqr_hip_stage_line_search", "ilqr_hip_stage_total_cost",
     "ilqr_hip_get_linearization", "ilqr_hip_set_linearization", "ilqr_hip_get_quadratics", "ilqr_hip_set_quadratics",
     "ilqr_hip_get_value_function", "ilqr_hip_step", "ilqr_hip_enable_profiling", "ilqr_hip_get_stage_ms",
-    "ilqr_hip_reference_kinematics", "ilqr_hip_gravity_compensation", "ilqr_hip_stream",
+    "ilqr_hip_reference_kinematics", "ilqr_hip_reference_com_velocity", "ilqr_hip_gravity_compensation", "ilqr_hip_stream",
 ]
 
 _lib = None
@@ -74,6 +74,17 @@ def reference_kinematics(x):
     if rc:
         raise ILQRError(STATUS.get(rc, str(rc)))
     return com, ee
+
+
+def reference_com_velocity(x):
+    """CoM-velocity reference J_com(q) qvel as RobotUtils::loadReferences computes it (robot_utils.cpp:383-391)."""
+    L = load_library()
+    x = _c64(x)
+    cv = np.zeros(3)
+    rc = L.ilqr_hip_reference_com_velocity(_p(x), _p(cv))
+    if rc:
+        raise ILQRError(STATUS.get(rc, str(rc)))
+    return cv
 
 
 def gravity_compensation(x, gravity):

@@ -233,6 +233,50 @@ def test_warm_start_mpc_step_and_control_law():
     s.close()
 
 
+def test_mpc_on_loaded_walking_references_matches_oracle():
+    """references + contact schedule from the reference's data files (excerpt in tests/golden),
+    reference windows with the horizon-local contact index, warm-started MPC steps, GPU vs oracle."""
+    from mpc_ilqr_mujoco_amd import references as rf
+    from mpc_ilqr_mujoco_amd import solver as sv
+    r = np.load(os.path.join(G, "refdata_golden.npz"))
+    rd = rf.ReferenceData(sv.reference_kinematics, sv.reference_com_velocity)
+    rd.set_states(np.concatenate([r["q_ref2_mj"], r["v_ref2"]], axis=1))
+    rd.contact = r["contact_walking"].astype(np.int32)
+    B, N = 2, 25
+    cfg = dict(sc.SHIPPED_CONFIG); cfg["W_com_vel"] = 2.0
+    base = sc.make_problem(sv.reference_kinematics, N=N, cfg=cfg, gravity=(0.0, 0.0, -2.0))
+    s = _solver(B); s.set_max_iterations(3)
+    rng = np.random.default_rng(11)
+    x = np.repeat(rd.x_ref[:1], B, axis=0); x[:, 7:26] += rng.uniform(-0.01, 0.01, (B, 19))
+    prev = [None] * B
+    os_ = [ol.Oracle(N, base["dt"]) for _ in range(B)]
+    for step in range(2):
+        prob = rd.problem_at(step, N, base)
+        assert prob["stance"].min() == 0          # the excerpt contains swing phases
+        s.set_problem(prob)
+        if step == 0:
+            ug = sv.gravity_compensation(sc.standing_state(), prob["gravity"])
+            s.initialize(x, np.repeat(np.tile(ug, (N, 1))[None], B, axis=0))
+        else:
+            s.initialize_warm_resident(x)
+        s.solve(x)
+        xb, ub, K = s.xbar(), s.ubar(), s.gains_K()
+        tr_cost = s.trace()[0]
+        for b in range(B):
+            o = os_[b]; o.set_problem(prob); o.set_options(max_iter=3)
+            if prev[b] is None:
+                o.initialize(x[b], np.tile(ug, (N, 1)))      # same cold-start controls as the GPU handle
+            else:
+                o.initialize(x[b], None, prev[b][0], prev[b][1])
+            o.solve(x[b])
+            prev[b] = (o.get("xbar"), o.get("ubar"))
+            assert rel(xb[b], prev[b][0]) < 1e-5 and rel(ub[b], prev[b][1]) < 1e-5 and rel(K[b], o.get("K")) < 1e-5
+            it, ocost, _, _ = o.trace()
+            assert np.allclose(tr_cost[b][:it + 1], ocost[:it + 1], rtol=1e-5)
+        x = s.step(x, s.compute_control(x))
+    s.close()
+
+
 def test_per_rollout_reference_sets():
     B, N = 3, 25
     prob, x0, ui = make(B, seed=8)
