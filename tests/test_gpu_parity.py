@@ -277,6 +277,41 @@ def test_mpc_on_loaded_walking_references_matches_oracle():
     s.close()
 
 
+def test_single_rollout_and_long_horizon_configs():
+    """BASELINE.json configs[0] (one trajectory, shipped config, N = 25) and the N = 50 contact-scheduled walking
+    window of configs[4] (references and contact schedule through the loader), each against the oracle."""
+    from mpc_ilqr_mujoco_amd import references as rf
+    from mpc_ilqr_mujoco_amd import solver as sv
+    # --- configs[0]: B = 1
+    prob, x0, ui = make(1, seed=21)
+    s = _solver(1); s.set_problem(prob); s.initialize(x0, ui); cost = s.solve(x0)
+    o = oracle_for(prob); o.initialize(x0[0], ui[0]); ok, c = o.solve(x0[0])
+    n, oc, oa, _ = o.trace()
+    assert n == s.iterations()[0] and np.allclose(s.trace()[0][0, : n + 1], oc[: n + 1], rtol=1e-5) and abs(cost[0] - c) <= 1e-5 * abs(c)
+    assert rel(s.gains_K()[0], o.get("K")) < 1e-5
+    s.close()
+    # --- configs[4]: N = 50, walking references + contact schedule
+    r = np.load(os.path.join(G, "refdata_golden.npz"))
+    rd = rf.ReferenceData(sv.reference_kinematics, sv.reference_com_velocity)
+    rd.set_states(np.concatenate([r["q_ref2_mj"], r["v_ref2"]], axis=1)); rd.contact = r["contact_walking"].astype(np.int32)
+    B, N = 3, 50
+    base = sc.make_problem(sv.reference_kinematics, N=N, gravity=(0.0, 0.0, -2.0))
+    prob = rd.problem_at(4, N, base)
+    assert prob["x_ref"].shape == (1, N + 1, 51) and prob["stance"].min() == 0
+    rng = np.random.default_rng(5)
+    x0 = np.repeat(rd.x_ref[4:5], B, axis=0); x0[:, 7:26] += rng.uniform(-0.02, 0.02, (B, 19)); x0[:, 26:] *= 0.2
+    ug = sv.gravity_compensation(sc.standing_state(), prob["gravity"])
+    ui = np.repeat(np.tile(ug, (N, 1))[None], B, axis=0) + rng.uniform(-0.5, 0.5, (B, N, 19))
+    s = _solver(B, N=N); s.set_problem(prob); s.set_max_iterations(4); s.initialize(x0, ui); cost = s.solve(x0)
+    tc = s.trace()[0]
+    for b in range(B):
+        o = oracle_for(prob, max_iter=4); o.initialize(x0[b], ui[b]); ok, c = o.solve(x0[b])
+        n, oc, oa, _ = o.trace()
+        assert n == s.iterations()[b] and np.allclose(tc[b, : n + 1], oc[: n + 1], rtol=1e-5), (b, tc[b], oc)
+        assert rel(s.gains_K()[b], o.get("K")) < 1e-5 and rel(s.xbar()[b], o.get("xbar")) < 1e-5
+    s.close()
+
+
 def test_per_rollout_reference_sets():
     B, N = 3, 25
     prob, x0, ui = make(B, seed=8)
