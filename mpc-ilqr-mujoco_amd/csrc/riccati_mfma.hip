@@ -6,9 +6,10 @@
 // The C/D layout of one product IS the B-operand layout of the next one (register r of row tile I is k-step
 // 4I + r), so chained products never leave the registers:
 //   P1  W[:, w]   = Vxx A[:, w]            wave w -> column tile w, kept in registers
-//   P2  G[w, :]   = Vxx[w, :] B            wave w -> row tile w, to LDS
+//   P2  G[w, 0..15] = Vxx[w, :] B[:, 0..15]  wave w -> row tile w, to LDS; G[:, 16..18] comes out of P1: the padding
+//       columns 52..54 of A carry B[:, 16..18], and P3 turns them into Qxu[:, 16..18] (26 MFMA per wave saved)
 //   P3  Qxx[:, w] = lxx + A^T W[:, w]      B operand = the accumulators of P1; result stays in registers until P7
-//   P4  Qux[:, w] = G^T A[:, w]            column tile w in registers (column 51 is replaced by Qu)
+//   P4  Qux[0..15, w] = G[:, 0..15]^T A[:, w]   column tile w in registers (column 51 is replaced by Qu)
 //   P5  Quu       = luu + B^T G + lambda I (2x2 tiles over the 4 waves), to LDS
 //   --  one wave (rotating per knot): right-looking Cholesky Quu = L L^T fused with the forward substitution for Linv = L^-1
 //       (row of Quu / column of Linv per lane, one v_readlane broadcast of L[k][j] feeds both updates;
@@ -54,15 +55,16 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 #define LDLB 32
 #define LDU 20         // Quu rows (aliases the Y buffer)
 
-// 78,336 B: two workgroups per CU (160 KB LDS), i.e. two waves per SIMD -- while one wave of one rollout runs the
+// 81,296 B: two workgroups per CU (160 KB LDS), i.e. two waves per SIMD -- while one wave of one rollout runs the
 // latency-bound Cholesky, the other rollout's waves keep the matrix cores busy.
 struct RiccatiLds {
   double Vxx[52 * LDV];   // rows/cols 0..50 = Vxx, row 51 = Vx, column 51 = don't care (finite)
-  double At[52 * LDA];    // At[j][k] = A_t[k][j]; row 51 and column 51 stay zero
+  double At[55 * LDA];    // At[j][k] = A_t[k][j]; row 51 and column 51 stay zero; rows 52..54 = columns 16..18 of B_t (see P1)
   double G[52 * LDG];     // staging of B_t ([k][c] swizzled), then G = Vxx B with row 51 = B^T Vx
   double Y[20 * LDY];     // Quu (P5 .. Cholesky), then Y = Linv [Qux | Qu]; scratch of the indefinite fallback
   double LinvA[21 * LDLA];  // row 20 stays zero (rows 20..31 of the padded operand read it)
   double LinvB[20 * LDLB];
+  double QH[52 * 4];      // Qxu[:, 16..18] (row 51: Qu[16..18]) on its way from wave 3's P3 accumulators to P6a
   double lxS[64], luS[32], luuS[32];   // staged lx_t, lu_t, luu_t
   int flags[4];
 };
@@ -98,7 +100,10 @@ __device__ __forceinline__ void stage_knot(RiccatiLds& L, const DevState& S, int
 #pragma unroll
       for (int u = 0; u < 8; ++u) { const int k = k0 + u * 2 * NW; v[u] = (k < n && c < m) ? Bg[k * m + c] : 0.0; }
 #pragma unroll
-      for (int u = 0; u < 8; ++u) { const int k = k0 + u * 2 * NW; if (k < n && c < m) L.G[SWZ(k, c, LDG)] = v[u]; }
+      for (int u = 0; u < 8; ++u) {
+        const int k = k0 + u * 2 * NW;
+        if (k < n && c < m) { L.G[SWZ(k, c, LDG)] = v[u]; if (c >= 16) L.At[(52 + c - 16) * LDA + k] = v[u]; }
+      }
     }
   }
   if (f < n) L.lxS[f] = S.lx[((size_t)b * (N + 1) + t) * n + f];
@@ -138,7 +143,7 @@ __global__ void __launch_bounds__(256, 2) k_backward_mfma(DevState S, int mode) 
     asm volatile("" : "+v"(lane), "+s"(w));
     const int lr = lane & 15, lk = lane >> 4;
     const int jcol = 16 * w + lr;                  // the column this lane owns in every column-tile product
-    const int jrow = jcol > 51 ? 51 : jcol;        // clamped: row 51 of At is zero
+    const int jrow = jcol > 54 ? 51 : jcol;        // rows 52..54: B_t columns 16..18; beyond: the zero row 51
     // ---- operands from the LDS staging into registers
     double areg[KS];          // A[4s + lk][16w + lr]
     double breg[2][KS];       // B[4s + lk][16j2 + lr]
@@ -178,20 +183,22 @@ __global__ void __launch_bounds__(256, 2) k_backward_mfma(DevState S, int mode) 
           qxx[I][r] = (row < n && jcol < n) ? lg[row * n + jcol] : 0.0;
         }
     }
-    // ---- P2: G[tile w, :] = Vxx[tile w, :] B   (row 51: B^T Vx)
+    // columns 52..54 of wave 3's W tile are Vxx B[:, 16..18] = G[:, 16..18] (the padding columns of A carry them for
+    // free): into the G buffer for P5
+    if (w == 3 && lr >= 4 && lr < 7) {
+#pragma unroll
+      for (int I = 0; I < 4; ++I)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const int row = 16 * I + lk + 4 * r; if (row < 52) L.G[SWZ(row, 16 + lr - 4, LDG)] = wacc[I][r]; }
+    }
+    // ---- P2: G[tile w, 0..15] = Vxx[tile w, :] B[:, 0..15]   (row 51: B^T Vx)
     {
-      v4d acc[2] = {(v4d){0.0, 0.0, 0.0, 0.0}, (v4d){0.0, 0.0, 0.0, 0.0}};
+      v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
       int row = 16 * w + lr; row = row > 51 ? 51 : row;
 #pragma unroll
-      for (int s = 0; s < KS; ++s) {
-        const double a = L.Vxx[row * LDV + 4 * s + lk];
-        acc[0] = mfma(a, breg[0][s], acc[0]);
-        acc[1] = mfma(a, breg[1][s], acc[1]);
-      }
+      for (int s = 0; s < KS; ++s) acc = mfma(L.Vxx[row * LDV + 4 * s + lk], breg[0][s], acc);
 #pragma unroll
-      for (int j2 = 0; j2 < 2; ++j2)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { const int rr = 16 * w + lk + 4 * r; if (rr < 52) L.G[SWZ(rr, 16 * j2 + lr, LDG)] = acc[j2][r]; }
+      for (int r = 0; r < 4; ++r) { const int rr = 16 * w + lk + 4 * r; if (rr < 52) L.G[SWZ(rr, lr, LDG)] = acc[r]; }
     }
     STAMP(3)
     // ---- P3: Qxx[:, tile w] = lxx + A^T W[:, tile w]; row 51 <- Qx = lx + A^T Vx (row 51 of At is zero)
@@ -205,23 +212,29 @@ __global__ void __launch_bounds__(256, 2) k_backward_mfma(DevState S, int mode) 
         qxx[I] = mfma(L.At[row * LDA + 4 * s + lk], wb, qxx[I]);
       }
     }
+    // columns 52..54 of wave 3's tile are A^T G[:, 16..18] = Qxu[:, 16..18]; row 51 carries B^T Vx -> Qu[16..18]
+    if (w == 3 && lr >= 4 && lr < 7) {
+#pragma unroll
+      for (int I = 0; I < 4; ++I)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = 16 * I + lk + 4 * r;
+          if (row < 51) L.QH[row * 4 + lr - 4] = qxx[I][r];
+          else if (row == 51) L.QH[51 * 4 + lr - 4] = L.luS[16 + lr - 4] + qxx[I][r];
+        }
+    }
     STAMP(4)
-    __syncthreads();   // G complete; every wave is done reading Vxx
+    __syncthreads();   // G and QH complete; every wave is done reading Vxx
     STAMP(5)
-    // ---- P4: Qux[:, tile w] = G^T A[:, tile w]; column 51 <- Qu = lu + B^T Vx
+    // ---- P4: Qux[0..15, tile w] = G[:, 0..15]^T A[:, tile w]; column 51 <- Qu = lu + B^T Vx; rows 16..18 from QH
     v4d qux[2] = {(v4d){0.0, 0.0, 0.0, 0.0}, (v4d){0.0, 0.0, 0.0, 0.0}};
 #pragma unroll
-    for (int s = 0; s < KS; ++s) {
-      const int k = 4 * s + lk;
-      qux[0] = mfma(L.G[SWZ(k, lr, LDG)], areg[s], qux[0]);
-      qux[1] = mfma(L.G[SWZ(k, 16 + lr, LDG)], areg[s], qux[1]);
-    }
+    for (int s = 0; s < KS; ++s) qux[0] = mfma(L.G[SWZ(4 * s + lk, lr, LDG)], areg[s], qux[0]);
     if (jcol == 51) {
 #pragma unroll
-      for (int I = 0; I < 2; ++I)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { const int a = 16 * I + lk + 4 * r; qux[I][r] = (a < m) ? L.luS[a] + L.G[SWZ(51, a, LDG)] : 0.0; }
+      for (int r = 0; r < 4; ++r) { const int a = lk + 4 * r; qux[0][r] = L.luS[a] + L.G[SWZ(51, a, LDG)]; }
     }
+    qux[1][0] = (lk < 3 && jcol < 52) ? L.QH[jcol * 4 + lk] : 0.0;   // row 16 + lk (row 19 is padding)
     STAMP(6)
     // ---- P5: Quu tile (w >> 1, w & 1) = B^T G (+ luu + lambda on the diagonal)
     {
