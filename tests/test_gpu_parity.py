@@ -312,6 +312,34 @@ def test_single_rollout_and_long_horizon_configs():
     s.close()
 
 
+def test_closed_loop_runner_with_logs(tmp_path):
+    """closed-loop batched MPC on loaded references; the logged first knot / control equal the solver state."""
+    from mpc_ilqr_mujoco_amd import mpc_loop as ml
+    from mpc_ilqr_mujoco_amd import references as rf
+    from mpc_ilqr_mujoco_amd import solver as sv
+    r = np.load(os.path.join(G, "refdata_golden.npz"))
+    rd = rf.ReferenceData(sv.reference_kinematics, sv.reference_com_velocity)
+    rd.set_states(np.concatenate([r["q_ref2_mj"], r["v_ref2"]], axis=1)); rd.contact = r["contact_walking"].astype(np.int32)
+    B, N = 3, 25
+    base = sc.make_problem(sv.reference_kinematics, N=N, gravity=(0.0, 0.0, -2.0))
+    s = _solver(B); s.set_max_iterations(2)
+    run = ml.MPCRunner(s, rd, base, log_dir=str(tmp_path), log_rollouts=(0, 2))
+    x0 = np.repeat(rd.x_ref[:1], B, axis=0); x0[:, 26:] *= 0.1
+    ug = sv.gravity_compensation(sc.standing_state(), base["gravity"])
+    xs, us = run.run(x0, 3, u_init=np.repeat(np.tile(ug, (N, 1))[None], B, axis=0))
+    run.close()
+    assert xs.shape == (4, B, 51) and us.shape == (3, B, 19) and np.all(np.isfinite(xs))
+    assert np.allclose(xs[1], s.step(xs[0], us[0]), rtol=0, atol=1e-12)        # the plant is the model's own step
+    for b in (0, 2):
+        rows = np.loadtxt(os.path.join(str(tmp_path), "rollout_%d" % b, "mpc_log.csv"), delimiter=",", skiprows=1)
+        assert rows.shape == (3, 4 + 2 * 70) and np.array_equal(rows[:, 0], [1, 2, 3])
+        assert np.allclose(rows[:, 4:55], xs[:3, b], rtol=1e-5, atol=1e-6) and np.allclose(rows[:, 55:74], us[:, b], rtol=1e-5, atol=1e-6)
+        assert np.allclose(rows[2, 74:125], rd.x_ref[2], rtol=1e-5, atol=1e-6)
+        q = np.loadtxt(os.path.join(str(tmp_path), "rollout_%d" % b, "q_optimal.csv"), delimiter=",", skiprows=1)
+        assert q.shape == (3, 28) and np.allclose(q[:, 2:], xs[:3, b, :26], rtol=1e-5, atol=1e-6)   # xbar[0] == x_measured after a solve
+    s.close()
+
+
 def test_per_rollout_reference_sets():
     B, N = 3, 25
     prob, x0, ui = make(B, seed=8)

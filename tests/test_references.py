@@ -96,3 +96,24 @@ def test_com_velocity_reference_is_the_time_derivative_of_the_com():
     # a pure base translation moves the CoM with it
     x = sc.standing_state(); x[26:29] = [0.3, -0.2, 0.1]
     assert np.allclose(sv.reference_com_velocity(x), [0.3, -0.2, 0.1], atol=1e-15)
+
+
+def test_mpc_log_formats_match_the_reference(tmp_path):
+    """Headers and row layout of MPC::initCSVLog / logAppliedOptimal (mpc.cpp:181-343)."""
+    from mpc_ilqr_mujoco_amd import mpc_loop as ml
+    lg = ml.MPCLogs(str(tmp_path), 0.02)
+    x, u = np.arange(51) * 0.5, np.arange(19) * -1.0
+    lg.log(1, 16.27, 3.5, x, u, x + 1, u * 0, x + 2, u + 2)
+    lg.log(2, 15.0, 3.4, x, u, x + 1, u * 0, x + 2, u + 2)
+    lg.close()
+    main = (tmp_path / "mpc_log.csv").read_text().splitlines()
+    hdr = main[0].split(",")
+    assert hdr[:4] == ["time_index", "time_sec", "solve_cost", "solve_time_ms"] and hdr[4] == "x_0" and hdr[4 + 51] == "u_0"
+    assert hdr[4 + 51 + 19] == "x_ref_0" and hdr[-1] == "u_ref_18" and len(hdr) == 4 + 2 * (51 + 19) and len(main) == 3
+    row = main[1].split(",")
+    assert row[0] == "1" and float(row[1]) == 0.02 and float(row[2]) == 16.27 and float(row[4 + 3]) == 1.5 and len(row) == len(hdr)
+    q = (tmp_path / "q_optimal.csv").read_text().splitlines()
+    assert q[0] == "step,time_sec," + ",".join("q_%d" % i for i in range(26)) and q[2].split(",")[0] == "2"
+    assert [float(v) for v in q[1].split(",")[2:]] == list(x[:26] + 2)
+    uo = (tmp_path / "u_optimal.csv").read_text().splitlines()
+    assert uo[0] == "step,time_sec," + ",".join("u_%d" % i for i in range(19)) and len(uo[1].split(",")) == 21
