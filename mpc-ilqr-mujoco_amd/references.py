@@ -39,6 +39,37 @@ def _read_rows(path, ncol, skip_header=False):
     return rows
 
 
+# ---- offline data prep (SURVEY 8(f) f2, the parts that need no collision geometry): /root/reference/get_contacts.py:18-41
+def pinocchio_to_mujoco(q_pin):
+    """[x y z qx qy qz qw joints] -> [x y z qw qx qy qz joints] (get_contacts.py convert_pinocchio_to_mujoco)."""
+    q = np.array(q_pin, dtype=np.float64, copy=True)
+    q[..., 3], q[..., 4:7] = np.asarray(q_pin)[..., 6], np.asarray(q_pin)[..., 3:6]
+    return q
+
+
+def differentiate_positions(q_mj, dt):
+    """Velocity file of a position reference, MuJoCo's mj_differentiatePos rule row to row (how data/v_ref2.csv relates
+    to data/q_ref2_mj.csv): world-frame linear velocity, BODY-frame angular velocity = log(q_t^-1 (x)
+    q_{t+1}) / dt, plain hinge differences; the last row repeats the previous one."""
+    q = np.asarray(q_mj, dtype=np.float64)
+    T = q.shape[0]
+    v = np.zeros((T, NV))
+    for t in range(T - 1):
+        qa, qb = q[t, 3:7], q[t + 1, 3:7]
+        ca = qa * np.array([1.0, -1.0, -1.0, -1.0])
+        dq = np.concatenate([[ca[0] * qb[0] - ca[1:] @ qb[1:]], ca[0] * qb[1:] + qb[0] * ca[1:] + np.cross(ca[1:], qb[1:])])
+        sn = np.linalg.norm(dq[1:])
+        speed = 2.0 * np.arctan2(sn, dq[0])
+        if speed > np.pi:
+            speed -= 2.0 * np.pi
+        v[t, 0:3] = (q[t + 1, 0:3] - q[t, 0:3]) / dt
+        v[t, 3:6] = (dq[1:] / sn if sn > 1e-15 else np.zeros(3)) * speed / dt
+        v[t, 6:] = (q[t + 1, 7:] - q[t, 7:]) / dt
+    if T > 1:
+        v[T - 1] = v[T - 2]
+    return v
+
+
 class ReferenceData:
     """Full-length references as RobotUtils holds them (x_ref_full_, com_ref_full_, ..., contact_schedule_)."""
 

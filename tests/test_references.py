@@ -117,3 +117,12 @@ def test_mpc_log_formats_match_the_reference(tmp_path):
     assert [float(v) for v in q[1].split(",")[2:]] == list(x[:26] + 2)
     uo = (tmp_path / "u_optimal.csv").read_text().splitlines()
     assert uo[0] == "step,time_sec," + ",".join("u_%d" % i for i in range(19)) and len(uo[1].split(",")) == 21
+
+
+def test_offline_prep_reproduces_the_reference_data_files():
+    """get_contacts.py's quaternion reorder and the velocity file: data/q_ref2_mj.csv from q_ref2_pin.csv
+    exactly, data/v_ref2.csv from q_ref2_mj.csv to the CSV's precision."""
+    r = np.load(os.path.join(G, "refdata_golden.npz"))
+    assert np.array_equal(rf.pinocchio_to_mujoco(r["q_ref2_pin"]), r["q_ref2_mj"])
+    v = rf.differentiate_positions(r["q_ref2_mj"], float(r["dt"]))
+    assert np.abs(v[:-1] - r["v_ref2"][:-1]).max() < 1e-9
