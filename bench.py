@@ -149,6 +149,28 @@ def main():
     cost = s.cost()
     assert np.all(np.isfinite(cost))
 
+    # second number: the same MPC step with the reference's convergence exit enabled -- iterations
+    # actually executed per second; not the headline value
+    s.set_options(jacobian_mode=sv.JAC_ANALYTIC, early_exit=True)
+    s.enable_profiling(False)
+    one_step(False)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    ee_iters = 0.0
+    for _ in range(max(1, args.steps // 2)):
+        one_step(False)
+        ee_iters += float(s.iterations().sum())
+    torch.cuda.synchronize()
+    ee_elapsed = time.perf_counter() - t1
+    if world > 1:
+        t = torch.tensor([ee_elapsed, -ee_iters], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        ee_elapsed = float(t[0].item())
+        t2 = torch.tensor([ee_iters], dtype=torch.float64, device=dev)
+        dist.all_reduce(t2, op=dist.ReduceOp.SUM)
+        ee_iters = float(t2.item())
+    ee_steps = max(1, args.steps // 2)
+
     if rank == 0:
         total_iters = float(world) * B * iters * args.steps
         value = total_iters / elapsed
@@ -215,6 +237,9 @@ def main():
             "kernels": {n: {k: (round(v, 6) if isinstance(v, float) else v) for k, v in t.items() if k in
                             ("total_ms_per_step", "avg_launch_ms", "frac_compute", "frac_hbm")} for n, t in table.items()},
             "stage_ms_per_step": {k: stage_ms[k] / args.steps for k in stage_ms},
+            "early_exit": {"value": ee_iters / ee_elapsed, "unit": "iterations/s", "mean_iterations_per_solve": ee_iters / (world * B * ee_steps),
+                           "ms_per_step": 1e3 * ee_elapsed / ee_steps,
+                           "note": "same step with the reference's convergence exit (|dJ| < 1e-4) enabled: executed iterations per second; not the headline"},
         }
         if not args.no_cpu_baseline:
             try:
