@@ -102,7 +102,7 @@ __global__ void __launch_bounds__(64) k_last_step_r(DevState S, ProblemDev P) {
 #endif
 // -DLS_STAMP: diagnostic build only -- per-phase cycle sums of thread 0 land in S.J[0..7]
 #ifdef LS_STAMP
-#define LSS(k) { const long long tn_ = clock64(); ph[k] += tn_ - tl; tl = tn_; }
+#define LSS(k) { __builtin_amdgcn_s_waitcnt(0); const long long tn_ = clock64(); ph[k] += tn_ - tl; tl = tn_; }
 #else
 #define LSS(k)
 #endif

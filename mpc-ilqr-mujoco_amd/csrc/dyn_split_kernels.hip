@@ -17,7 +17,7 @@ namespace ilqr {
 #define LS_UNROLL 2
 #endif
 #ifdef LS_STAMP
-#define LSS(k) { const long long tn_ = clock64(); ph[k] += tn_ - tl; tl = tn_; }
+#define LSS(k) { __builtin_amdgcn_s_waitcnt(0); const long long tn_ = clock64(); ph[k] += tn_ - tl; tl = tn_; }
 #else
 #define LSS(k)
 #endif
