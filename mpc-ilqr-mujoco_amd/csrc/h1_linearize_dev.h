@@ -14,6 +14,7 @@
 //   (v' = v + h qacc, p' = p + h v'_lin, theta' = theta + h thetadot', quat' = qhat (x) exp(h w')).
 #pragma once
 #include "h1_aba_reg.h"
+#include "h1_aba_split.h"
 #include "h1_dynamics_dev.h"
 
 namespace h1 {
@@ -31,6 +32,8 @@ struct LinShared {
   double dT[H1_NV][LIN_LD];      // tangent generalized forces, then d qacc / d direction
   double Iv[H1_NB][6];           // I_i v_i (momentum of body i), shared by every tangent direction
   double xa[H1_NB][6];           // X_i a_parent(i): the parent's acceleration in body i's frame
+  double part[4][6][LIN_LD];     // pelvis force tangents of the four chain groups (LL, RL, torso+LA, torso+RA) per direction
+  double part11[2][LIN_LD];      // torso hinge row: the two arm groups' shares per direction
   double x[H1_NX], u[H1_NU];
   double qh[4], qn, e[4], dE[4][3], Hq[3][4];
   double free_u[H1_NU];
@@ -138,12 +141,34 @@ template <int FIRST, int LEN> struct TanChain {
   }
 };
 
-// one lane: tangent generalized forces d ID_mj / d direction (+ damping), written to L.dT[:, lane]
-DEVFN void lin_tangent_lane(LinShared& L, int lane) {
-  int kind, idx; lane_direction(lane, kind, idx);
-  if (kind == DIR_NONE) return;
+// ---- tangent sweeps grouped by chain ------------------------------------------------------------------------------
+// A direction only moves the bodies below its own hinge, and the inverse-dynamics force of a hinge only sees its own
+// subtree: the rows of a chain's hinges are nonzero for 19 directions only (9 base directions + the chain's own hinge
+// angles and rates; for an arm also the torso's).  So instead of 47 lanes sweeping all 20 bodies, 2 x 19 lanes sweep
+// the two legs side by side (5 bodies), then 2 x 19 lanes the torso + the two arms (5 bodies): half the body steps.
+// Left / right bodies are mirror images with the same axes; a lane's body constants are `side ? right : left`
+// (h1_aba_split.h).  The chains meet at the pelvis (and the arms at the torso hinge): their shares go through
+// L.part / L.part11 and are added per direction in a fixed order.
+DEVFN int dir_lane(int kind, int idx) {   // inverse of lane_direction
+  return kind == DIR_PHI ? idx : (kind == DIR_THETA ? 3 + idx - 1 : (kind == DIR_VLIN ? 22 + idx : (kind == DIR_OMEGA ? 25 + idx : 28 + idx - 1)));
+}
+// direction of slot q (0..18) of a chain group: 9 base directions, then the chain's own hinges
+DEVFN void slot_direction(bool arms, bool side, int q, int& kind, int& idx) {
+  if (q < 3) { kind = DIR_PHI; idx = q; }
+  else if (q < 6) { kind = DIR_VLIN; idx = q - 3; }
+  else if (q < 9) { kind = DIR_OMEGA; idx = q - 6; }
+  else if (!arms) { const int first = side ? 6 : 1; if (q < 14) { kind = DIR_THETA; idx = first + q - 9; } else { kind = DIR_THETADOT; idx = first + q - 14; } }
+  else {
+    const int first = side ? 16 : 12;
+    if (q == 9) { kind = DIR_THETA; idx = 11; } else if (q == 10) { kind = DIR_THETADOT; idx = 11; }
+    else if (q < 15) { kind = DIR_THETA; idx = first + q - 11; } else { kind = DIR_THETADOT; idx = first + q - 15; }
+  }
+}
+// tangent of the pelvis velocity / acceleration and of the pelvis body's own force for one direction
+DEVFN void tan_base(const LinShared& L, int kind, int idx, double* dv0, double* da0) {
   const KnotDump& D = L.D;
-  double dv0[6] = {0, 0, 0, 0, 0, 0}, da0[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+  for (int k = 0; k < 6; ++k) { dv0[k] = 0.0; da0[k] = 0.0; }
   const double* w = D.v[0];       // omega_body
   const double* vO = D.v[0] + 3;  // R0^T v_lin
   if (kind == DIR_PHI) {          // R0 -> R0 (I + [dphi]x): d(R0^T u) = (R0^T u) x dphi
@@ -157,39 +182,160 @@ DEVFN void lin_tangent_lane(LinShared& L, int lane) {
     double wx[3]; cross3(w, dv0 + 3, wx);
     da0[3] = -wx[0]; da0[4] = -wx[1]; da0[5] = -wx[2];
   } else if (kind == DIR_OMEGA) { // a0_lin = aL - w x v_O
-    dv0[idx] = 1.0;
+    dv0[0] = idx == 0 ? 1.0 : 0.0; dv0[1] = idx == 1 ? 1.0 : 0.0; dv0[2] = idx == 2 ? 1.0 : 0.0;
     double t[3]; cross_axis(vO, idx, t);   // v_O x e_k = -(e_k x v_O)
     da0[3] = t[0]; da0[4] = t[1]; da0[5] = t[2];
   }
-  double dF0[6];
+}
+// mirrored-pair versions of tan_body_fwd / tan_body_bwd: body IL on the even group, IR on the odd one
+template <int IL, int IR>
+DEVFN void tan_body_fwd2(const LinShared& L, bool side, int kind, int idx, const double* pv, const double* pa, double* dv, double* da, double* df) {
+  const KnotDump& D = L.D;
+  constexpr int ax = h1c::C_AXIS[IL];
+  static_assert(h1c::C_AXIS[IL] == h1c::C_AXIS[IR], "mirror bodies");
+  const int i = side ? IR : IL;
+  const double* Rj = D.Rj[i];
+  const double qd = L.x[H1_NQ + 6 + i - 1];
+  const double r[3] = {side ? h1c::C_POS[IR][0] : h1c::C_POS[IL][0], side ? h1c::C_POS[IR][1] : h1c::C_POS[IL][1], side ? h1c::C_POS[IR][2] : h1c::C_POS[IL][2]};
+  xf_motion(Rj, r, pv, dv);
+  xf_motion(Rj, r, pa, da);
+  const double mt = (kind == DIR_THETA && idx == i) ? 1.0 : 0.0;
+  const double md = (kind == DIR_THETADOT && idx == i) ? 1.0 : 0.0;
   {
-    double Ida[6], Idv[6], h[6], t1[6], t2[6];
-    h1r::inertia_mul<0>(da0, Ida); h1r::inertia_mul<0>(dv0, Idv);
+    double t[3], xa[6];
+    h1r::cross_axis<ax>(D.v[i], t);      dv[0] += mt * t[0]; dv[1] += mt * t[1]; dv[2] += mt * t[2];
+    h1r::cross_axis<ax>(D.v[i] + 3, t);  dv[3] += mt * t[0]; dv[4] += mt * t[1]; dv[5] += mt * t[2];
 #pragma unroll
-    for (int k = 0; k < 6; ++k) h[k] = L.Iv[0][k];
-    h1r::crf(dv0, h, t1); h1r::crf(D.v[0], Idv, t2);
+    for (int k = 0; k < 6; ++k) xa[k] = L.xa[i][k];
+    h1r::cross_axis<ax>(xa, t);          da[0] += mt * t[0]; da[1] += mt * t[1]; da[2] += mt * t[2];
+    h1r::cross_axis<ax>(xa + 3, t);      da[3] += mt * t[0]; da[4] += mt * t[1]; da[5] += mt * t[2];
+  }
+  dv[ax] += md;
+  {
+    double t[3];
+    h1r::cross_axis<ax>(dv, t);     da[0] += qd * t[0]; da[1] += qd * t[1]; da[2] += qd * t[2];
+    h1r::cross_axis<ax>(dv + 3, t); da[3] += qd * t[0]; da[4] += qd * t[1]; da[5] += qd * t[2];
+  }
+  {
+    double t[3];
+    h1r::cross_axis<ax>(D.v[i], t);     da[0] += md * t[0]; da[1] += md * t[1]; da[2] += md * t[2];
+    h1r::cross_axis<ax>(D.v[i] + 3, t); da[3] += md * t[0]; da[4] += md * t[1]; da[5] += md * t[2];
+  }
+  double Ida[6], Idv[6], h[6], t1[6], t2[6];
+  h1s::inertia_mul<IL, IR>(side, da, Ida); h1s::inertia_mul<IL, IR>(side, dv, Idv);
 #pragma unroll
-    for (int k = 0; k < 6; ++k) dF0[k] = Ida[k] + t1[k] + t2[k];
+  for (int k = 0; k < 6; ++k) h[k] = L.Iv[i][k];
+  h1r::crf(dv, h, t1); h1r::crf(D.v[i], Idv, t2);
+#pragma unroll
+  for (int k = 0; k < 6; ++k) df[k] = Ida[k] + t1[k] + t2[k];
+}
+template <int IL, int IR>
+DEVFN double tan_body_bwd2(const LinShared& L, bool side, int kind, int idx, const double* tot, double* parent_acc) {
+  const KnotDump& D = L.D;
+  constexpr int ax = h1c::C_AXIS[IL];
+  const int i = side ? IR : IL;
+  double g[6] = {tot[0], tot[1], tot[2], tot[3], tot[4], tot[5]};
+  {
+    const double mt = (kind == DIR_THETA && idx == i) ? 1.0 : 0.0;
+    double t[3];
+    h1r::cross_axis<ax>(D.F[i], t);     g[0] -= mt * t[0]; g[1] -= mt * t[1]; g[2] -= mt * t[2];
+    h1r::cross_axis<ax>(D.F[i] + 3, t); g[3] -= mt * t[0]; g[4] -= mt * t[1]; g[5] -= mt * t[2];
   }
-  // torso and the two arms hanging off it
-  double tv[6], ta[6], dF11[6];
-  tan_body_fwd<11>(L, kind, idx, dv0, da0, tv, ta, dF11);
-  TanChain<12, 4>::run(L, kind, idx, tv, ta, dF11, lane);
-  TanChain<16, 4>::run(L, kind, idx, tv, ta, dF11, lane);
-  L.dT[5 + 11][lane] = tan_body_bwd<11>(L, kind, idx, dF11, dF0);
-  // legs
-  TanChain<1, 5>::run(L, kind, idx, dv0, da0, dF0, lane);
-  TanChain<6, 5>::run(L, kind, idx, dv0, da0, dF0, lane);
-  // free joint rows: torque in the body frame, force in the world frame
-  double fl[3] = {dF0[3], dF0[4], dF0[5]};
-  if (kind == DIR_PHI) {  // d(R0 f) = R0 (dphi x f + df)
-    double t[3]; cross_axis(D.F[0] + 3, idx, t);   // F x e_k = -(e_k x F)
-    fl[0] -= t[0]; fl[1] -= t[1]; fl[2] -= t[2];
+  const double r[3] = {side ? h1c::C_POS[IR][0] : h1c::C_POS[IL][0], side ? h1c::C_POS[IR][1] : h1c::C_POS[IL][1], side ? h1c::C_POS[IR][2] : h1c::C_POS[IL][2]};
+  xf_force_acc(D.Rj[i], r, g, parent_acc);
+  return tot[ax];
+}
+template <int FL, int FR, int LEN> struct TanChain2 {
+  template <int K> static DEVFN void fwd(const LinShared& L, bool side, int kind, int idx, const double* pv, const double* pa, double (*df)[6]) {
+    double nv[6], na[6];
+    tan_body_fwd2<FL + K, FR + K>(L, side, kind, idx, pv, pa, nv, na, df[K]);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (K + 1 < LEN) fwd<K + 1>(L, side, kind, idx, nv, na, df);
   }
-  double fw[3]; mv3(D.R0, fl, fw);
-  L.dT[0][lane] = fw[0]; L.dT[1][lane] = fw[1]; L.dT[2][lane] = fw[2];
-  L.dT[3][lane] = dF0[0]; L.dT[4][lane] = dF0[1]; L.dT[5][lane] = dF0[2];
-  if (kind == DIR_THETADOT) L.dT[5 + idx][lane] += H1_DAMPING;
+  template <int K> static DEVFN void bwd(LinShared& L, bool side, int kind, int idx, double (*df)[6], double* acc, double* dFj, int col) {
+    double tot[6];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) { tot[c] = df[K][c] + acc[c]; acc[c] = 0.0; }
+    L.dT[5 + (side ? FR : FL) + K][col] = tan_body_bwd2<FL + K, FR + K>(L, side, kind, idx, tot, (K == 0) ? dFj : acc);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (K > 0) bwd<K - 1>(L, side, kind, idx, df, acc, dFj, col);
+  }
+  // sweeps the chain for one direction; adds the chain's force tangent at its root to dFj; rows -> L.dT[.][col]
+  static DEVFN void run(LinShared& L, bool side, int kind, int idx, const double* jv, const double* ja, double* dFj, int col) {
+    double df[LEN][6];
+    fwd<0>(L, side, kind, idx, jv, ja, df);
+    double acc[6] = {0, 0, 0, 0, 0, 0};
+    bwd<LEN - 1>(L, side, kind, idx, df, acc, dFj, col);
+  }
+};
+
+// all lanes of the wave: tangent generalized forces d ID_mj / d direction (+ damping) -> L.dT[:, 0..46].  Contains barriers.
+DEVFN void lin_tangent_all(LinShared& L, int lane) {
+  const KnotDump& D = L.D;
+  // rows of the hinges are written only for the directions of their own chain group: zero the rest (and the shares)
+  for (int e = lane; e < (H1_NV - 6) * LIN_LD; e += 64) (&L.dT[6][0])[e] = 0.0;
+  for (int e = lane; e < 4 * 6 * LIN_LD; e += 64) (&L.part[0][0][0])[e] = 0.0;
+  for (int e = lane; e < 2 * LIN_LD; e += 64) (&L.part11[0][0])[e] = 0.0;
+  __syncthreads();
+  const int grp = lane / 19, q = lane - 19 * grp;
+  const bool side = grp == 1;
+  // ---- pass 1: the two legs
+  if (grp < 2) {
+    int kind, idx; slot_direction(false, side, q, kind, idx);
+    const int col = dir_lane(kind, idx);
+    double dv0[6], da0[6]; tan_base(L, kind, idx, dv0, da0);
+    double dFj[6] = {0, 0, 0, 0, 0, 0};
+    TanChain2<1, 6, 5>::run(L, side, kind, idx, dv0, da0, dFj, col);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) L.part[grp][k][col] = dFj[k];
+  }
+  // ---- pass 2: torso + the two arms
+  if (grp < 2) {
+    int kind, idx; slot_direction(true, side, q, kind, idx);
+    const int col = dir_lane(kind, idx);
+    double dv0[6], da0[6]; tan_base(L, kind, idx, dv0, da0);
+    double tv[6], ta[6], dF11[6];
+    tan_body_fwd<11>(L, kind, idx, dv0, da0, tv, ta, dF11);     // the torso's own force tangent: counted by the left group only
+    if (side) {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) dF11[k] = 0.0;
+    }
+    TanChain2<12, 16, 4>::run(L, side, kind, idx, tv, ta, dF11, col);
+    // torso hinge: its row is the sum of the two groups' shares; the own-hinge correction is linear and applied once (left)
+    double dFj[6] = {0, 0, 0, 0, 0, 0};
+    L.part11[grp][col] = tan_body_bwd<11>(L, side ? DIR_NONE : kind, idx, dF11, dFj);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) L.part[2 + grp][k][col] = dFj[k];
+  }
+  __syncthreads();
+  // ---- pelvis: own force tangent + the four chain shares, per direction (lane = direction, fixed order)
+  int kind, idx; lane_direction(lane, kind, idx);
+  if (kind != DIR_NONE) {
+    double dv0[6], da0[6]; tan_base(L, kind, idx, dv0, da0);
+    double dF0[6];
+    {
+      double Ida[6], Idv[6], h[6], t1[6], t2[6];
+      h1r::inertia_mul<0>(da0, Ida); h1r::inertia_mul<0>(dv0, Idv);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) h[k] = L.Iv[0][k];
+      h1r::crf(dv0, h, t1); h1r::crf(D.v[0], Idv, t2);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) dF0[k] = Ida[k] + t1[k] + t2[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) dF0[k] += ((L.part[2][k][lane] + L.part[3][k][lane]) + L.part[0][k][lane]) + L.part[1][k][lane];
+    L.dT[5 + 11][lane] = L.part11[0][lane] + L.part11[1][lane];
+    // free joint rows: torque in the body frame, force in the world frame
+    double fl[3] = {dF0[3], dF0[4], dF0[5]};
+    if (kind == DIR_PHI) {  // d(R0 f) = R0 (dphi x f + df)
+      double t[3]; cross_axis(D.F[0] + 3, idx, t);   // F x e_k = -(e_k x F)
+      fl[0] -= t[0]; fl[1] -= t[1]; fl[2] -= t[2];
+    }
+    double fw[3]; mv3(D.R0, fl, fw);
+    L.dT[0][lane] = fw[0]; L.dT[1][lane] = fw[1]; L.dT[2][lane] = fw[2];
+    L.dT[3][lane] = dF0[0]; L.dT[4][lane] = dF0[1]; L.dT[5][lane] = dF0[2];
+    if (kind == DIR_THETADOT) L.dT[5 + idx][lane] += H1_DAMPING;
+  }
 }
 
 // Column c (= lane, 0..24) of Minv = d qacc / d tau in MuJoCo coordinates: response of the articulated-body

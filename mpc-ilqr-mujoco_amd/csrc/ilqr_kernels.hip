@@ -102,7 +102,8 @@ __global__ void __launch_bounds__(64, LINT_WAVES) k_lin_tangent(DevState S, Prob
   LSTAMP(2)
   lin_minv_lane(L, lane);       // lanes 0..24: columns of Minv
   LSTAMP(3)
-  lin_tangent_lane(L, lane);    // lanes 0..46: tangent generalized forces
+  __syncthreads();
+  lin_tangent_all(L, lane);     // chain-grouped tangent sweeps -> tangent generalized forces of the 47 directions
   __syncthreads();
   LSTAMP(4)
   lin_apply_minv_lane(L, lane);
