@@ -26,15 +26,24 @@ enum { LinDumpG_R0 = 0, LinDumpG_aL = 9, LinDumpG_qacc = 12, LinDumpG_sc = 37, L
 #define LIN_NDIR 47   // tangent directions: phi(3) theta(19) v_lin(3) omega(3) thetadot(19)
 #define LIN_LD 48     // padded lane stride of the direction arrays
 
+// primal quantities of the knot every phase needs (subset of KnotDump)
+struct LinDump {
+  double R0[9], aL[3], qacc[H1_NV];
+  double Rj[H1_NB][9];          // joint rotations child -> parent ([0] unused)
+  double v[H1_NB][6];           // body spatial velocities
+  double F[H1_NB][6];           // accumulated inverse-dynamics forces (body i and its subtree)
+};
 struct LinShared {
-  KnotDump D;
+  LinDump D;
+  union {                        // 25 KB in all: six waves per CU
+    struct { double U[H1_NB][6], Dinv[H1_NB], IA0inv[36]; } m;      // Minv sweeps only: articulated-body U_i, 1 / D_i, pelvis inverse
+    struct { double part[4][6][19], part11[2][19]; } t;             // tangent sweeps only: pelvis / torso-hinge shares of the four
+  } u;                                                              // chain groups (LL, RL, torso+LA, torso+RA) per group slot
   double Minv[H1_NV][H1_NV];     // d qacc / d tau in MuJoCo coordinates
   double dT[H1_NV][LIN_LD];      // tangent generalized forces, then d qacc / d direction
   double Iv[H1_NB][6];           // I_i v_i (momentum of body i), shared by every tangent direction
   double xa[H1_NB][6];           // X_i a_parent(i): the parent's acceleration in body i's frame
-  double part[4][6][LIN_LD];     // pelvis force tangents of the four chain groups (LL, RL, torso+LA, torso+RA) per direction
-  double part11[2][LIN_LD];      // torso hinge row: the two arm groups' shares per direction
-  double x[H1_NX], u[H1_NU];
+  double x[H1_NX], u_[H1_NU];
   double qh[4], qn, e[4], dE[4][3], Hq[3][4];
   double free_u[H1_NU];
   double h;
@@ -62,7 +71,7 @@ DEVFN void lane_direction(int lane, int& kind, int& idx) {
 template <int I>
 DEVFN void tan_body_fwd(const LinShared& L, int kind, int idx, const double* pv, const double* pa,
                         double* dv, double* da, double* df) {
-  const KnotDump& D = L.D;
+  const LinDump& D = L.D;
   constexpr int ax = h1c::C_AXIS[I];
   const double* Rj = D.Rj[I];
   const double qd = L.x[H1_NQ + 6 + I - 1];
@@ -105,7 +114,7 @@ DEVFN void tan_body_fwd(const LinShared& L, int kind, int idx, const double* pv,
 // body I's total tangent force tot -> its generalized force row and the contribution to the parent
 template <int I>
 DEVFN double tan_body_bwd(const LinShared& L, int kind, int idx, const double* tot, double* parent_acc) {
-  const KnotDump& D = L.D;
+  const LinDump& D = L.D;
   constexpr int ax = h1c::C_AXIS[I];
   double g[6] = {tot[0], tot[1], tot[2], tot[3], tot[4], tot[5]};
   {   // d(X^T f)/d theta = X^T (S x* F) = X^T (e x n ; e x f), own hinge only (0/1 factor instead of a branch)
@@ -118,28 +127,6 @@ DEVFN double tan_body_bwd(const LinShared& L, int kind, int idx, const double* t
   xf_force_acc(D.Rj[I], r, g, parent_acc);
   return tot[ax];
 }
-template <int FIRST, int LEN> struct TanChain {
-  template <int K> static DEVFN void fwd(const LinShared& L, int kind, int idx, const double* pv, const double* pa, double (*df)[6]) {
-    double nv[6], na[6];
-    tan_body_fwd<FIRST + K>(L, kind, idx, pv, pa, nv, na, df[K]);
-    __builtin_amdgcn_sched_barrier(0);   // one body at a time: keeps the scheduler from hoisting the next bodies' LDS operands
-    if constexpr (K + 1 < LEN) fwd<K + 1>(L, kind, idx, nv, na, df);
-  }
-  template <int K> static DEVFN void bwd(LinShared& L, int kind, int idx, double (*df)[6], double* acc, double* dFj, int lane) {
-    double tot[6];
-#pragma unroll
-    for (int c = 0; c < 6; ++c) { tot[c] = df[K][c] + acc[c]; acc[c] = 0.0; }
-    L.dT[5 + FIRST + K][lane] = tan_body_bwd<FIRST + K>(L, kind, idx, tot, (K == 0) ? dFj : acc);
-    __builtin_amdgcn_sched_barrier(0);
-    if constexpr (K > 0) bwd<K - 1>(L, kind, idx, df, acc, dFj, lane);
-  }
-  static DEVFN void run(LinShared& L, int kind, int idx, const double* jv, const double* ja, double* dFj, int lane) {
-    double df[LEN][6];
-    fwd<0>(L, kind, idx, jv, ja, df);
-    double acc[6] = {0, 0, 0, 0, 0, 0};
-    bwd<LEN - 1>(L, kind, idx, df, acc, dFj, lane);
-  }
-};
 
 // ---- tangent sweeps grouped by chain ------------------------------------------------------------------------------
 // A direction only moves the bodies below its own hinge, and the inverse-dynamics force of a hinge only sees its own
@@ -148,7 +135,7 @@ template <int FIRST, int LEN> struct TanChain {
 // the two legs side by side (5 bodies), then 2 x 19 lanes the torso + the two arms (5 bodies): half the body steps.
 // Left / right bodies are mirror images with the same axes; a lane's body constants are `side ? right : left`
 // (h1_aba_split.h).  The chains meet at the pelvis (and the arms at the torso hinge): their shares go through
-// L.part / L.part11 and are added per direction in a fixed order.
+// L.u.t.part / part11 and are added per direction in a fixed order.
 DEVFN int dir_lane(int kind, int idx) {   // inverse of lane_direction
   return kind == DIR_PHI ? idx : (kind == DIR_THETA ? 3 + idx - 1 : (kind == DIR_VLIN ? 22 + idx : (kind == DIR_OMEGA ? 25 + idx : 28 + idx - 1)));
 }
@@ -164,9 +151,20 @@ DEVFN void slot_direction(bool arms, bool side, int q, int& kind, int& idx) {
     else if (q < 15) { kind = DIR_THETA; idx = first + q - 11; } else { kind = DIR_THETADOT; idx = first + q - 15; }
   }
 }
+// slot of direction (kind, idx) in chain group c (0 LL, 1 RL, 2 torso+LA, 3 torso+RA), -1 if the group does not sweep it
+DEVFN int slot_in_group(int c, int kind, int idx) {
+  if (kind == DIR_PHI) return idx;
+  if (kind == DIR_VLIN) return 3 + idx;
+  if (kind == DIR_OMEGA) return 6 + idx;
+  const int off = kind == DIR_THETA ? 0 : 1;
+  if (c < 2) { const int first = c ? 6 : 1; return (idx >= first && idx < first + 5) ? 9 + 5 * off + (idx - first) : -1; }
+  if (idx == 11) return 9 + off;
+  const int first = c == 2 ? 12 : 16;
+  return (idx >= first && idx < first + 4) ? 11 + 4 * off + (idx - first) : -1;
+}
 // tangent of the pelvis velocity / acceleration and of the pelvis body's own force for one direction
 DEVFN void tan_base(const LinShared& L, int kind, int idx, double* dv0, double* da0) {
-  const KnotDump& D = L.D;
+  const LinDump& D = L.D;
 #pragma unroll
   for (int k = 0; k < 6; ++k) { dv0[k] = 0.0; da0[k] = 0.0; }
   const double* w = D.v[0];       // omega_body
@@ -190,7 +188,7 @@ DEVFN void tan_base(const LinShared& L, int kind, int idx, double* dv0, double* 
 // mirrored-pair versions of tan_body_fwd / tan_body_bwd: body IL on the even group, IR on the odd one
 template <int IL, int IR>
 DEVFN void tan_body_fwd2(const LinShared& L, bool side, int kind, int idx, const double* pv, const double* pa, double* dv, double* da, double* df) {
-  const KnotDump& D = L.D;
+  const LinDump& D = L.D;
   constexpr int ax = h1c::C_AXIS[IL];
   static_assert(h1c::C_AXIS[IL] == h1c::C_AXIS[IR], "mirror bodies");
   const int i = side ? IR : IL;
@@ -231,7 +229,7 @@ DEVFN void tan_body_fwd2(const LinShared& L, bool side, int kind, int idx, const
 }
 template <int IL, int IR>
 DEVFN double tan_body_bwd2(const LinShared& L, bool side, int kind, int idx, const double* tot, double* parent_acc) {
-  const KnotDump& D = L.D;
+  const LinDump& D = L.D;
   constexpr int ax = h1c::C_AXIS[IL];
   const int i = side ? IR : IL;
   double g[6] = {tot[0], tot[1], tot[2], tot[3], tot[4], tot[5]};
@@ -269,14 +267,14 @@ template <int FL, int FR, int LEN> struct TanChain2 {
   }
 };
 
-// all lanes of the wave: tangent generalized forces d ID_mj / d direction (+ damping) -> L.dT[:, 0..46].  Contains barriers.
-DEVFN void lin_tangent_all(LinShared& L, int lane) {
-  const KnotDump& D = L.D;
-  // rows of the hinges are written only for the directions of their own chain group: zero the rest (and the shares)
+// Tangent generalized forces d ID_mj / d direction (+ damping) -> L.dT[:, 0..46], in three steps with a barrier
+// between them (lin_tangent_all; the host probe runs each step over all lanes instead).
+// step 1: rows of the hinges are written only for the directions of their own chain group: zero the rest
+DEVFN void lin_tangent_zero(LinShared& L, int lane) {
   for (int e = lane; e < (H1_NV - 6) * LIN_LD; e += 64) (&L.dT[6][0])[e] = 0.0;
-  for (int e = lane; e < 4 * 6 * LIN_LD; e += 64) (&L.part[0][0][0])[e] = 0.0;
-  for (int e = lane; e < 2 * LIN_LD; e += 64) (&L.part11[0][0])[e] = 0.0;
-  __syncthreads();
+}
+// step 2: 2 x 19 lanes sweep the two legs, then torso + the two arms; shares of the pelvis / torso hinge -> L.u.t
+DEVFN void lin_tangent_chains(LinShared& L, int lane) {
   const int grp = lane / 19, q = lane - 19 * grp;
   const bool side = grp == 1;
   // ---- pass 1: the two legs
@@ -287,7 +285,7 @@ DEVFN void lin_tangent_all(LinShared& L, int lane) {
     double dFj[6] = {0, 0, 0, 0, 0, 0};
     TanChain2<1, 6, 5>::run(L, side, kind, idx, dv0, da0, dFj, col);
 #pragma unroll
-    for (int k = 0; k < 6; ++k) L.part[grp][k][col] = dFj[k];
+    for (int k = 0; k < 6; ++k) L.u.t.part[grp][k][q] = dFj[k];
   }
   // ---- pass 2: torso + the two arms
   if (grp < 2) {
@@ -303,12 +301,14 @@ DEVFN void lin_tangent_all(LinShared& L, int lane) {
     TanChain2<12, 16, 4>::run(L, side, kind, idx, tv, ta, dF11, col);
     // torso hinge: its row is the sum of the two groups' shares; the own-hinge correction is linear and applied once (left)
     double dFj[6] = {0, 0, 0, 0, 0, 0};
-    L.part11[grp][col] = tan_body_bwd<11>(L, side ? DIR_NONE : kind, idx, dF11, dFj);
+    L.u.t.part11[grp][q] = tan_body_bwd<11>(L, side ? DIR_NONE : kind, idx, dF11, dFj);
 #pragma unroll
-    for (int k = 0; k < 6; ++k) L.part[2 + grp][k][col] = dFj[k];
+    for (int k = 0; k < 6; ++k) L.u.t.part[2 + grp][k][q] = dFj[k];
   }
-  __syncthreads();
-  // ---- pelvis: own force tangent + the four chain shares, per direction (lane = direction, fixed order)
+}
+// step 3: pelvis: own force tangent + the four chain shares, per direction (lane = direction, fixed order)
+DEVFN void lin_tangent_pelvis(LinShared& L, int lane) {
+  const LinDump& D = L.D;
   int kind, idx; lane_direction(lane, kind, idx);
   if (kind != DIR_NONE) {
     double dv0[6], da0[6]; tan_base(L, kind, idx, dv0, da0);
@@ -322,9 +322,17 @@ DEVFN void lin_tangent_all(LinShared& L, int lane) {
 #pragma unroll
       for (int k = 0; k < 6; ++k) dF0[k] = Ida[k] + t1[k] + t2[k];
     }
+    // this direction's slot in each chain group (-1: the group does not contain it, its share is zero)
+    int qs[4];
 #pragma unroll
-    for (int k = 0; k < 6; ++k) dF0[k] += ((L.part[2][k][lane] + L.part[3][k][lane]) + L.part[0][k][lane]) + L.part[1][k][lane];
-    L.dT[5 + 11][lane] = L.part11[0][lane] + L.part11[1][lane];
+    for (int c = 0; c < 4; ++c) qs[c] = slot_in_group(c, kind, idx);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      const double p2 = qs[2] >= 0 ? L.u.t.part[2][k][qs[2] < 0 ? 0 : qs[2]] : 0.0, p3 = qs[3] >= 0 ? L.u.t.part[3][k][qs[3] < 0 ? 0 : qs[3]] : 0.0;
+      const double p0 = qs[0] >= 0 ? L.u.t.part[0][k][qs[0] < 0 ? 0 : qs[0]] : 0.0, p1 = qs[1] >= 0 ? L.u.t.part[1][k][qs[1] < 0 ? 0 : qs[1]] : 0.0;
+      dF0[k] += ((p2 + p3) + p0) + p1;
+    }
+    L.dT[5 + 11][lane] = (qs[2] >= 0 ? L.u.t.part11[0][qs[2] < 0 ? 0 : qs[2]] : 0.0) + (qs[3] >= 0 ? L.u.t.part11[1][qs[3] < 0 ? 0 : qs[3]] : 0.0);
     // free joint rows: torque in the body frame, force in the world frame
     double fl[3] = {dF0[3], dF0[4], dF0[5]};
     if (kind == DIR_PHI) {  // d(R0 f) = R0 (dphi x f + df)
@@ -336,6 +344,14 @@ DEVFN void lin_tangent_all(LinShared& L, int lane) {
     L.dT[3][lane] = dF0[0]; L.dT[4][lane] = dF0[1]; L.dT[5][lane] = dF0[2];
     if (kind == DIR_THETADOT) L.dT[5 + idx][lane] += H1_DAMPING;
   }
+}
+
+DEVFN void lin_tangent_all(LinShared& L, int lane) {
+  lin_tangent_zero(L, lane);
+  __syncthreads();
+  lin_tangent_chains(L, lane);
+  __syncthreads();
+  lin_tangent_pelvis(L, lane);
 }
 
 // Column c (= lane, 0..24) of Minv = d qacc / d tau in MuJoCo coordinates: response of the articulated-body
@@ -351,8 +367,8 @@ template <int FIRST, int LEN> struct MinvChainOut {
     double a[6]; xf_motion(L.D.Rj[I], r, ap, a);
     double s = (P.body[dep] == I) ? P.du[dep] : 0.0;
 #pragma unroll
-    for (int q = 0; q < 6; ++q) s -= L.D.U[I][q] * a[q];
-    const double qdd = s * L.D.Dinv[I];
+    for (int q = 0; q < 6; ++q) s -= L.u.m.U[I][q] * a[q];
+    const double qdd = s * L.u.m.Dinv[I];
     a[ax] += qdd;
     L.Minv[5 + I][lane] = qdd;
     __builtin_amdgcn_sched_barrier(0);
@@ -379,10 +395,10 @@ DEVFN void lin_minv_lane(LinShared& L, int lane) {
         const double du = (first ? 1.0 : 0.0) - (ax == 0 ? acc[0] : (ax == 1 ? acc[1] : acc[2]));
         first = false;
         P.body[d] = i; P.du[d] = du;
-        const double s = du * L.D.Dinv[i];
+        const double s = du * L.u.m.Dinv[i];
         double pa[6];
 #pragma unroll
-        for (int r = 0; r < 6; ++r) { pa[r] = acc[r] + L.D.U[i][r] * s; acc[r] = 0.0; }
+        for (int r = 0; r < 6; ++r) { pa[r] = acc[r] + L.u.m.U[i][r] * s; acc[r] = 0.0; }
         xf_force_acc(L.D.Rj[i], H1_POS[i], pa, acc);
         i = H1_PARENT[i];
       }
@@ -398,7 +414,7 @@ DEVFN void lin_minv_lane(LinShared& L, int lane) {
 #pragma unroll
   for (int r = 0; r < 6; ++r) { double s = 0.0;
 #pragma unroll
-    for (int k = 0; k < 6; ++k) s += L.D.IA0inv[6 * r + k] * rhs[k];
+    for (int k = 0; k < 6; ++k) s += L.u.m.IA0inv[6 * r + k] * rhs[k];
     a0[r] = s; }
   double lw[3]; mv3(L.D.R0, a0 + 3, lw);
   L.Minv[0][lane] = lw[0]; L.Minv[1][lane] = lw[1]; L.Minv[2][lane] = lw[2];
@@ -410,8 +426,8 @@ DEVFN void lin_minv_lane(LinShared& L, int lane) {
     xf_motion(L.D.Rj[I], r, a0, a11);
     double s = (P.body[1] == I) ? P.du[1] : 0.0;
 #pragma unroll
-    for (int q = 0; q < 6; ++q) s -= L.D.U[I][q] * a11[q];
-    const double qdd = s * L.D.Dinv[I];
+    for (int q = 0; q < 6; ++q) s -= L.u.m.U[I][q] * a11[q];
+    const double qdd = s * L.u.m.Dinv[I];
     a11[ax] += qdd;
     L.Minv[5 + I][lane] = qdd;
   }
@@ -440,13 +456,13 @@ DEVFN void lin_apply_minv_lane(LinShared& L, int lane) {
 // cooperative load of the global dump into LDS (all lanes of one wave); rebuilds the joint rotations from
 // their sine/cosine and the accumulated inverse-dynamics forces F_i
 DEVFN void lin_load_dump(LinShared& L, const double* g, int lane) {
-  KnotDump& D = L.D;
+  LinDump& D = L.D;
   for (int e = lane; e < 9; e += 64) D.R0[e] = g[LinDumpG_R0 + e];
   for (int e = lane; e < 3; e += 64) D.aL[e] = g[LinDumpG_aL + e];
   for (int e = lane; e < H1_NV; e += 64) D.qacc[e] = g[LinDumpG_qacc + e];
-  for (int e = lane; e < H1_NB * 6; e += 64) { (&D.v[0][0])[e] = g[LinDumpG_v + e]; (&D.a[0][0])[e] = g[LinDumpG_a + e]; (&D.U[0][0])[e] = g[LinDumpG_U + e]; }
-  for (int e = lane; e < H1_NB; e += 64) D.Dinv[e] = g[LinDumpG_Dinv + e];
-  for (int e = lane; e < 36; e += 64) D.IA0inv[e] = g[LinDumpG_IA0inv + e];
+  for (int e = lane; e < H1_NB * 6; e += 64) { (&D.v[0][0])[e] = g[LinDumpG_v + e]; (&L.u.m.U[0][0])[e] = g[LinDumpG_U + e]; }
+  for (int e = lane; e < H1_NB; e += 64) L.u.m.Dinv[e] = g[LinDumpG_Dinv + e];
+  for (int e = lane; e < 36; e += 64) L.u.m.IA0inv[e] = g[LinDumpG_IA0inv + e];
   if (lane >= 1 && lane < H1_NB) {
     const int i = lane, a = H1_AXIS[i], b = (a + 1) % 3, d = (a + 2) % 3;
     const double s = g[LinDumpG_sc + 2 * i], c = g[LinDumpG_sc + 2 * i + 1];
@@ -523,7 +539,7 @@ DEVFN void lin_prologue(LinShared& L) {
     L.dE[0][j] = -0.5 * so * h * h * wn[j];
     for (int i = 0; i < 3; ++i) L.dE[1 + i][j] = (i == j ? so * h : 0.0) + h * wn[i] * dso * 2.0 * h * h * wn[j];
   }
-  for (int i = 0; i < H1_NU; ++i) L.free_u[i] = (L.u[i] < H1_CTRLRANGE[i][0] || L.u[i] > H1_CTRLRANGE[i][1]) ? 0.0 : 1.0;
+  for (int i = 0; i < H1_NU; ++i) L.free_u[i] = (L.u_[i] < H1_CTRLRANGE[i][0] || L.u_[i] > H1_CTRLRANGE[i][1]) ? 0.0 : 1.0;
 }
 
 DEVFN void quat_mul(const double* a, const double* b, double* r) {

@@ -92,7 +92,7 @@ __global__ void __launch_bounds__(64, LINT_WAVES) k_lin_tangent(DevState S, Prob
   const size_t knot = (size_t)b * S.N + t;
   lin_load_dump(L, S.lin_dump + knot * LinDumpG_SIZE, lane);
   if (lane < H1_NX) L.x[lane] = S.xbar[((size_t)b * (S.N + 1) + t) * H1_NX + lane];
-  if (lane < H1_NU) L.u[lane] = S.ubar[((size_t)b * S.N + t) * H1_NU + lane];
+  if (lane < H1_NU) L.u_[lane] = S.ubar[((size_t)b * S.N + t) * H1_NU + lane];
   if (lane == 0) L.h = P.dyn.h;
   __syncthreads();
   LSTAMP(0)

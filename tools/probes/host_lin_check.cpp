@@ -31,12 +31,21 @@ int main() {
     static LinShared L;
     L.h = P.h;
     for (int i = 0; i < H1_NX; ++i) L.x[i] = x[i];
-    for (int i = 0; i < H1_NU; ++i) L.u[i] = u[i];
+    for (int i = 0; i < H1_NU; ++i) L.u_[i] = u[i];
     double y0[H1_NV];
-    qacc_for(x, u, P, nullptr, nullptr, y0, &L.D);
-    for (int i = 0; i < H1_NB; ++i) {   // what lin_load_dump derives from the dump on the device
-      inertia_mul(i, L.D.v[i], L.Iv[i]);
-      if (i > 0) xf_motion(L.D.Rj[i], H1_POS[i], L.D.a[H1_PARENT[i]], L.xa[i]);
+    static KnotDump KD;
+    qacc_for(x, u, P, nullptr, nullptr, y0, &KD);
+    // what lin_load_dump + lin_accumulate_forces leave in LDS on the device
+    for (int k = 0; k < 9; ++k) L.D.R0[k] = KD.R0[k];
+    for (int k = 0; k < 3; ++k) L.D.aL[k] = KD.aL[k];
+    for (int k = 0; k < H1_NV; ++k) L.D.qacc[k] = KD.qacc[k];
+    for (int k = 0; k < 36; ++k) L.u.m.IA0inv[k] = KD.IA0inv[k];
+    for (int i = 0; i < H1_NB; ++i) {
+      for (int k = 0; k < 9; ++k) L.D.Rj[i][k] = KD.Rj[i][k];
+      for (int k = 0; k < 6; ++k) { L.D.v[i][k] = KD.v[i][k]; L.D.F[i][k] = KD.F[i][k]; L.u.m.U[i][k] = KD.U[i][k]; }
+      L.u.m.Dinv[i] = KD.Dinv[i];
+      inertia_mul(i, KD.v[i], L.Iv[i]);
+      if (i > 0) xf_motion(KD.Rj[i], H1_POS[i], KD.a[H1_PARENT[i]], L.xa[i]);
     }
     static double Mref[H1_NV][H1_NV];
     for (int c = 0; c < H1_NV; ++c) {
@@ -48,7 +57,9 @@ int main() {
     for (int lane = 0; lane < 64; ++lane) lin_minv_lane(L, lane);
     { double em = 0; for (int r = 0; r < H1_NV; ++r) for (int c = 0; c < H1_NV; ++c) em = std::fmax(em, std::fabs(Mref[r][c] - L.Minv[r][c])); printf("  Minv sweep vs unit-force differences: %.3e\n", em); }
     lin_prologue(L);
-    for (int lane = 0; lane < 64; ++lane) lin_tangent_lane(L, lane);
+    for (int lane = 0; lane < 64; ++lane) lin_tangent_zero(L, lane);
+    for (int lane = 0; lane < 64; ++lane) lin_tangent_chains(L, lane);
+    for (int lane = 0; lane < 64; ++lane) lin_tangent_pelvis(L, lane);
     for (int lane = 0; lane < 64; ++lane) lin_apply_minv_lane(L, lane);
     std::vector<double> A(51*51), B(51*19), Ao(51*51), Bo(51*19);
     for (int k = 0; k < 51; ++k) lin_column(L, 0, k, [&](int r, double v) { A[r*51+k] = v; });

@@ -14,3 +14,9 @@ using std::sqrt; using std::fma; using std::fabs; using std::fmax; using std::fm
 using std::rint;
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
 inline void __syncthreads() {}
+// lane-exchange intrinsics: single-lane host runs never take the split-lane paths; these only have to compile
+#include <cstring>
+inline int __double2loint(double d) { long long b; std::memcpy(&b, &d, 8); return (int)(b & 0xffffffff); }
+inline int __double2hiint(double d) { long long b; std::memcpy(&b, &d, 8); return (int)(b >> 32); }
+inline double __hiloint2double(int hi, int lo) { long long b = ((long long)hi << 32) | (unsigned)lo; double d; std::memcpy(&d, &b, 8); return d; }
+#define __builtin_amdgcn_update_dpp(old, src, ctrl, rmask, bmask, bc) (src)
