@@ -145,6 +145,10 @@ int ilqr_hip_get_stage_ms(ilqr_hip_ctx* ctx, double* ms /*[8]*/, double* launche
 int ilqr_hip_reference_kinematics(const double* x /*51*/, double* com /*3*/, double* ee /*[2][3]*/);
 /* CoM-velocity reference of the same loader (mj_jacSubtreeCom(root) * qvel, src/common/robot_utils.cpp:383-391) */
 int ilqr_hip_reference_com_velocity(const double* x /*51*/, double* comvel /*3*/);
+/* offline contact-schedule tool (get_contacts.py:96-147): height of the lowest point of each foot's collision hull
+   (ankle-link mesh, h1.xml:81,116) above the floor plane z = 0 for the configuration qpos; the tool's stance flag is
+   clearance < 0 (MuJoCo reports a floor contact, margin 0).  clearance[0] left, [1] right */
+int ilqr_hip_foot_clearance(const double* qpos /*26*/, double* clearance /*2*/);
 /* RobotUtils::computeGravComp (src/common/robot_utils.cpp:844-866, correct dof index): qfrc_bias[6+i] at v = 0 */
 int ilqr_hip_gravity_compensation(const double* x /*51*/, const double* gravity /*3*/, double* u /*19*/);
 

@@ -7,6 +7,7 @@
 
 #include "h1_model_data.h"
 #include "h1_host_model.h"
+#include "h1_foot_hull.h"
 
 namespace h1host {
 
@@ -75,6 +76,27 @@ void reference_com_velocity(const double* x, double* cv) {
     m += H1_MASS[i];
   }
   for (int k = 0; k < 3; ++k) cv[k] /= m;
+}
+
+// Height of the lowest point of each foot's collision hull above the floor plane z = 0 (negative: penetration).
+// The reference's schedule tool (get_contacts.py:96-147) sets qpos, runs mj_forward and marks a foot as in stance
+// when MuJoCo reports a contact between the floor and an ankle-link geom: with the default margin 0 that is
+// exactly "the lowest hull vertex is below the plane".  q = qpos[26] (MuJoCo order).
+void foot_clearance(const double* q, double* clr) {
+  double x[H1_NX] = {0};
+  for (int i = 0; i < H1_NQ; ++i) x[i] = q[i];
+  double Rw[H1_NB][9], pw[H1_NB][3];
+  forward_kinematics(x, Rw, pw);
+  const int body[2] = {H1_EE_LEFT, H1_EE_RIGHT};
+  for (int f = 0; f < 2; ++f) {
+    const double* R = Rw[body[f]];
+    double zmin = 1e300;
+    for (int i = 0; i < H1_FOOT_HULL_N; ++i) {
+      const double z = R[6] * H1_FOOT_HULL[i][0] + R[7] * H1_FOOT_HULL[i][1] + R[8] * H1_FOOT_HULL[i][2];
+      if (z < zmin) zmin = z;
+    }
+    clr[f] = pw[body[f]][2] + zmin;
+  }
 }
 
 // qfrc_bias[6+j] at zero velocity = minus the generalized gravity force on hinge j

@@ -516,6 +516,11 @@ int ilqr_hip_reference_com_velocity(const double* x, double* comvel) {
   h1host::reference_com_velocity(x, comvel);
   return ILQR_OK;
 }
+int ilqr_hip_foot_clearance(const double* qpos, double* clearance) {
+  if (!qpos || !clearance) return ILQR_ERR_ARG;
+  h1host::foot_clearance(qpos, clearance);
+  return ILQR_OK;
+}
 int ilqr_hip_gravity_compensation(const double* x, const double* gravity, double* u) {
   if (!x || !gravity || !u) return ILQR_ERR_ARG;
   h1host::gravity_compensation(x, gravity, u);

@@ -39,7 +39,7 @@ def _read_rows(path, ncol, skip_header=False):
     return rows
 
 
-# ---- offline data prep (SURVEY 8(f) f2, the parts that need no collision geometry): /root/reference/get_contacts.py:18-41
+# ---- offline data prep (SURVEY 8(f) f2): /root/reference/get_contacts.py:18-41 (conventions), :96-147 (contact schedule)
 def pinocchio_to_mujoco(q_pin):
     """[x y z qx qy qz qw joints] -> [x y z qw qx qy qz joints] (get_contacts.py convert_pinocchio_to_mujoco)."""
     q = np.array(q_pin, dtype=np.float64, copy=True)
@@ -68,6 +68,56 @@ def differentiate_positions(q_mj, dt):
     if T > 1:
         v[T - 1] = v[T - 2]
     return v
+
+
+def contact_schedule(q_mj, clearance):
+    """Stance flags [T][2] (left, right) of a position reference, the way get_contacts.py:96-147 makes them: per row set
+    qpos, run the kinematics and mark a foot as in stance when its collision hull touches the floor plane.  The tool
+    tests `contact.dist < 0.001` on MuJoCo's contact list, but MuJoCo only lists a floor contact once the hull
+    penetrates (margin 0), so the effective rule is "lowest hull point below z = 0"; it reproduces all 800 flags of
+    the reference's data/contact_walking.csv and the 400 of contact_standing.csv (tests/test_references.py).
+    `clearance(qpos[26]) -> [left, right]` is `solver.foot_clearance` (C ABI `ilqr_hip_foot_clearance`)."""
+    q = np.atleast_2d(np.asarray(q_mj, dtype=np.float64))
+    if q.shape[1] != NQ:
+        raise ValueError("position rows must have %d columns" % NQ)
+    flags = np.zeros((q.shape[0], 2), dtype=np.int32)
+    for t in range(q.shape[0]):
+        flags[t] = np.asarray(clearance(q[t])) < 0.0
+    return flags
+
+
+def write_contact_schedule(path, flags):
+    """The tool's output format (get_contacts.py:141-143): header `left_foot,right_foot`, one 0/1 row per time step --
+    what RobotUtils::loadContactSchedule / ReferenceData.load_contact_schedule read back."""
+    with open(path, "w") as f:
+        f.write("left_foot,right_foot\n")
+        for a, b in np.asarray(flags, dtype=int):
+            f.write("%d,%d\n" % (a, b))
+
+
+def write_rows(path, rows):
+    """Header-less CSV of float rows (the format of q_ref*.csv / v_ref*.csv), full double precision."""
+    with open(path, "w") as f:
+        for r in np.asarray(rows, dtype=np.float64):
+            f.write(",".join(repr(float(a)) for a in r) + "\n")
+
+
+def prepare_reference(q_pin_path, dt, clearance, out_prefix=None):
+    """The whole offline preparation of a Pinocchio-convention position file (e.g. the 7840-row data/h1_walking_pin.csv,
+    which ships without velocity and contact files): quaternion reorder, velocities by `differentiate_positions`,
+    stance flags by `contact_schedule`.  Returns (q_mj, v, flags); with `out_prefix` also writes
+    <prefix>_q_mj.csv, <prefix>_v.csv, <prefix>_contact.csv in the reference's formats."""
+    q_pin = np.asarray(_read_rows(q_pin_path, NQ), dtype=np.float64)
+    if q_pin.size == 0:
+        raise ValueError("no %d-column rows in %s" % (NQ, q_pin_path))
+    q_mj = pinocchio_to_mujoco(q_pin)
+    v = differentiate_positions(q_mj, dt)
+    flags = contact_schedule(q_mj, clearance)
+    if out_prefix is not None:
+        write_rows(out_prefix + "_q_mj.csv", q_mj)
+        write_rows(out_prefix + "_v.csv", v)
+        write_contact_schedule(out_prefix + "_contact.csv", flags)
+    return q_mj, v, flags
 
 
 class ReferenceData:

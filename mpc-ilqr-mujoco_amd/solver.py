@@ -35,7 +35,7 @@ EXPORTS = [
     "ilqr_hip_stage_backward_pass", "ilqr_hip_stage_line_search", "ilqr_hip_stage_total_cost",
     "ilqr_hip_get_linearization", "ilqr_hip_set_linearization", "ilqr_hip_get_quadratics", "ilqr_hip_set_quadratics",
     "ilqr_hip_get_value_function", "ilqr_hip_step", "ilqr_hip_enable_profiling", "ilqr_hip_get_stage_ms",
-    "ilqr_hip_reference_kinematics", "ilqr_hip_reference_com_velocity", "ilqr_hip_gravity_compensation", "ilqr_hip_stream",
+    "ilqr_hip_reference_kinematics", "ilqr_hip_reference_com_velocity", "ilqr_hip_foot_clearance", "ilqr_hip_gravity_compensation", "ilqr_hip_stream",
 ]
 
 _lib = None
@@ -85,6 +85,19 @@ def reference_com_velocity(x):
     if rc:
         raise ILQRError(STATUS.get(rc, str(rc)))
     return cv
+
+
+def foot_clearance(qpos):
+    """Height of the lowest point of each foot's collision hull above the floor (get_contacts.py:96-147); [left, right]."""
+    L = load_library()
+    q = _c64(qpos)
+    if q.shape != (26,):
+        raise ValueError("qpos must have 26 entries (MuJoCo order)")
+    clr = np.zeros(2)
+    rc = L.ilqr_hip_foot_clearance(_p(q), _p(clr))
+    if rc:
+        raise ILQRError(STATUS.get(rc, str(rc)))
+    return clr
 
 
 def gravity_compensation(x, gravity):

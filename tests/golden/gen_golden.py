@@ -364,11 +364,47 @@ def gen_refdata():
     qp = np.loadtxt(os.path.join(REF, "data/q_ref2_pin.csv"), delimiter=",")
     cw = np.loadtxt(os.path.join(REF, "data/contact_walking.csv"), delimiter=",", skiprows=1).astype(np.int32)
     rows = slice(0, 80)
-    np.savez_compressed(os.path.join(HERE, "refdata_golden.npz"), q_ref2_mj=q[rows], v_ref2=v[rows], q_ref2_pin=qp[rows], contact_walking=cw[rows], dt=0.02)
-    print("refdata rows", q[rows].shape, v[rows].shape)
+    # contact-schedule tool (get_contacts.py:96-147): the reference's own input / output pairs (q_ref2_mj.csv ->
+    # contact_walking.csv, q_standing.csv -> contact_standing.csv) and, for rows of h1_walking_pin.csv beyond the 400
+    # that ship with a schedule, foot clearances from an independent numpy FK over ALL vertices of the ankle STL
+    import struct
+    raw = open(os.path.join(REF, "robots/h1_description/meshes/left_ankle_link.STL"), "rb").read()
+    ntri = struct.unpack("<I", raw[80:84])[0]
+    verts = np.unique(np.frombuffer(raw[84:84 + 50 * ntri], dtype=np.dtype([("n", "<f4", 3), ("v", "<f4", (3, 3)), ("a", "<u2")]))["v"].reshape(-1, 3).astype(np.float64), axis=0)
+    bodies, _ = load_mjcf()
+    names = [b["name"] for b in bodies]
+    feet = [names.index("left_ankle_link"), names.index("right_ankle_link")]
+
+    def axis_R(ax, th):
+        K = np.array([[0, -ax[2], ax[1]], [ax[2], 0, -ax[0]], [-ax[1], ax[0], 0]])
+        return np.eye(3) + math.sin(th) * K + (1 - math.cos(th)) * K @ K
+
+    def clearance(qrow):
+        R, p = [q2R(qrow[3:7])], [qrow[:3]]
+        for i in range(1, len(bodies)):
+            b = bodies[i]
+            R.append(R[b["parent"]] @ b["R"] @ axis_R(b["axis"], qrow[6 + i]))
+            p.append(p[b["parent"]] + R[b["parent"]] @ b["pos"])
+        return [float((verts @ R[i].T + p[i])[:, 2].min()) for i in feet]
+
+    clr2 = np.array([clearance(r) for r in q])
+    assert np.array_equal((clr2 < 0).astype(np.int32), cw), "hull-below-plane rule does not reproduce contact_walking.csv"
+    qs = np.loadtxt(os.path.join(REF, "data/q_standing.csv"), delimiter=",")
+    cs = np.loadtxt(os.path.join(REF, "data/contact_standing.csv"), delimiter=",", skiprows=1).astype(np.int32)
+    wp = np.loadtxt(os.path.join(REF, "data/h1_walking_pin.csv"), delimiter=",")[360:560]
+    wp_mj = wp.copy(); wp_mj[:, 3] = wp[:, 6]; wp_mj[:, 4:7] = wp[:, 3:6]
+    clrw = np.array([clearance(r) for r in wp_mj])
+    np.savez_compressed(os.path.join(HERE, "refdata_golden.npz"), q_ref2_mj=q[rows], v_ref2=v[rows], q_ref2_pin=qp[rows], contact_walking=cw[rows], dt=0.02,
+                        q_ref2_mj_full=q, contact_walking_full=cw, clearance_ref2=clr2, q_standing=qs[:3], contact_standing=cs[:3],
+                        walking_pin_rows=wp, walking_pin_row0=360, walking_pin_clearance=clrw)
+    print("refdata rows", q[rows].shape, v[rows].shape, "contact flags reproduced:", cw.shape, "walking_pin stance counts", (clrw < 0).sum(0), "min |clr|", np.abs(clrw).min(), np.abs(clr2).min())
 
 
 if __name__ == "__main__":
+    import sys
+    if len(sys.argv) > 1 and sys.argv[1] == "refdata":
+        gen_refdata()
+        sys.exit(0)
     gen_dynamics()
     gen_costs()
     gen_riccati()

@@ -126,3 +126,52 @@ def test_offline_prep_reproduces_the_reference_data_files():
     assert np.array_equal(rf.pinocchio_to_mujoco(r["q_ref2_pin"]), r["q_ref2_mj"])
     v = rf.differentiate_positions(r["q_ref2_mj"], float(r["dt"]))
     assert np.abs(v[:-1] - r["v_ref2"][:-1]).max() < 1e-9
+
+
+def test_contact_schedule_reproduces_the_reference_files():
+    """get_contacts.py:96-147 restated: the reference's own input/output pairs are the known answers
+    (data/q_ref2_mj.csv -> data/contact_walking.csv, all 800 flags; data/q_standing.csv -> data/contact_standing.csv)."""
+    r = np.load(os.path.join(G, "refdata_golden.npz"))
+    q, flags_ref, clr_ref = r["q_ref2_mj_full"], r["contact_walking_full"], r["clearance_ref2"]
+    assert q.shape == (400, 26) and flags_ref.shape == (400, 2)
+    flags = rf.contact_schedule(q, sv.foot_clearance)
+    assert flags.dtype == np.int32 and np.array_equal(flags, flags_ref)
+    assert 0 < flags[:, 0].sum() < 400 and 0 < flags[:, 1].sum() < 400           # both feet leave the ground in the file
+    # clearances against an independent numpy FK over all mesh vertices (not only the hull's)
+    clr = np.array([sv.foot_clearance(row) for row in q])
+    assert np.abs(clr - clr_ref).max() < 1e-12
+    assert np.array_equal(rf.contact_schedule(r["q_standing"], sv.foot_clearance), r["contact_standing"])
+    assert np.allclose(sv.foot_clearance(r["q_standing"][0]), -0.001, atol=1e-7)  # the standing pose sinks the soles 1 mm into the floor
+    with pytest.raises(ValueError):
+        sv.foot_clearance(np.zeros(25))
+    with pytest.raises(ValueError):
+        rf.contact_schedule(np.zeros((3, 25)), sv.foot_clearance)
+    # lifting the robot by 2 mm clears both feet; a pure yaw changes nothing
+    up = r["q_standing"][0].copy(); up[2] += 0.002
+    assert np.array_equal(rf.contact_schedule(up, sv.foot_clearance), [[0, 0]])
+    yaw = r["q_standing"][0].copy(); yaw[3], yaw[6] = np.cos(0.4), np.sin(0.4)
+    assert np.allclose(sv.foot_clearance(yaw), sv.foot_clearance(r["q_standing"][0]), atol=1e-15)
+
+
+def test_prepare_reference_on_walking_pin_rows_beyond_the_shipped_schedule(tmp_path):
+    """The offline preparation of data/h1_walking_pin.csv (no velocity / contact file ships for it; rows 360..559 here):
+    reorder + velocities + stance flags, written in the reference's formats and read back by the loader."""
+    r = np.load(os.path.join(G, "refdata_golden.npz"))
+    wp, row0, clr_ref = r["walking_pin_rows"], int(r["walking_pin_row0"]), r["walking_pin_clearance"]
+    src = tmp_path / "walking_pin.csv"
+    rf.write_rows(str(src), wp)
+    q_mj, v, flags = rf.prepare_reference(str(src), 0.02, sv.foot_clearance, out_prefix=str(tmp_path / "prep"))
+    assert np.array_equal(q_mj, rf.pinocchio_to_mujoco(wp)) and np.array_equal(v, rf.differentiate_positions(q_mj, 0.02))
+    assert np.array_equal(flags, (clr_ref < 0).astype(np.int32))
+    # the file's first 400 rows are q_ref2: the overlap with the shipped schedule agrees flag by flag
+    n = 400 - row0
+    assert np.array_equal(q_mj[:n], r["q_ref2_mj_full"][row0:]) and np.array_equal(flags[:n], r["contact_walking_full"][row0:])
+    assert flags[n:].min() == 0 and flags[n:].max() == 1
+    rd = rf.ReferenceData(sv.reference_kinematics, sv.reference_com_velocity)
+    assert rd.load(str(tmp_path / "prep_q_mj.csv"), str(tmp_path / "prep_v.csv")) and rd.load_contact_schedule(str(tmp_path / "prep_contact.csv"))
+    assert np.array_equal(rd.x_ref[:, :26], q_mj) and np.array_equal(rd.x_ref[:, 26:], v)
+    assert all(rd.is_stance(e, t) == bool(flags[t, e]) for t in range(len(flags)) for e in (0, 1))
+    assert open(tmp_path / "prep_contact.csv").readline() == "left_foot,right_foot\n"
+    with pytest.raises(ValueError):
+        (tmp_path / "empty.csv").write_text("1,2,3\n")
+        rf.prepare_reference(str(tmp_path / "empty.csv"), 0.02, sv.foot_clearance)

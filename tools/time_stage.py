@@ -10,7 +10,7 @@ from mpc_ilqr_mujoco_amd import solver as sv
 sc = pkg.scenario
 stage = sys.argv[1] if len(sys.argv) > 1 else "backward"
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
-B, N = 4096, 25
+B, N = int(os.environ.get("ILQR_B", "4096")), int(os.environ.get("ILQR_N", "25"))
 prob = sc.make_problem(sv.reference_kinematics, N=N)
 ug = sv.gravity_compensation(sc.standing_state(), prob["gravity"])
 x0, ui = sc.synthetic_batch(B, N, 0, ug)
