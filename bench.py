@@ -179,8 +179,10 @@ def main():
         # of the rollouts, so they count towards the kernel's total but the roofline uses the full-batch launches
         # per kernel group: stage keys, algorithmic flops and HBM bytes of ONE full-batch launch
         D = 8.0
+        bk_env = os.environ.get("ILQR_BACKWARD", "wave")
+        bk_name = {"wg": "k_backward_mfma", "va": "k_backward"}.get(bk_env[:2], "k_backward_wave")
         kernels = {
-            "k_backward_mfma": dict(stages=["iLQR_backwardPass", "iLQR_backwardPass_retry"], unit="fp64 MFMA",
+            bk_name: dict(stages=["iLQR_backwardPass", "iLQR_backwardPass_retry"], unit="fp64 MFMA",
                                     flops=RICCATI_FLOPS_PER_KNOT * N * B,
                                     bytes=D * B * (N * (2601 + 969 + 2601 + 51 + 19 + 19 + 969 + 19) + 2 * (2601 + 51))),
             "k_line_search_r": dict(stages=["iLQR_lineSearch", "iLQR_lineSearch_retry"], unit="fp64 VALU",

@@ -90,7 +90,7 @@ int ilqr_hip_create(ilqr_hip_ctx** out, int device, int batch, int horizon, doub
   auto A = [&](int r) { if (rc == ILQR_OK) rc = r; };
   A(dalloc(c, &S.x0, B * n)); A(dalloc(c, &S.xbar, B * (N + 1) * n)); A(dalloc(c, &S.ubar, B * N * m));
   A(dalloc(c, &S.xcand, B * 8 * (N + 1) * n)); A(dalloc(c, &S.ucand, B * 8 * N * m)); A(dalloc(c, &S.cand_cost, B * 8));
-  A(dalloc(c, &S.A, B * N * n * n)); A(dalloc(c, &S.Bm, B * N * n * m));
+  A(dalloc(c, &S.A, B * N * n * n + 32)); A(dalloc(c, &S.Bm, B * N * n * m + 32));   // slack: riccati_wave.hip stages 16-byte pairs that may straddle the end of the last row
   A(dalloc(c, &S.lx, B * (N + 1) * n)); A(dalloc(c, &S.lu, B * N * m)); A(dalloc(c, &S.lxx, B * (N + 1) * n * n)); A(dalloc(c, &S.luu, B * N * m));
   A(dalloc(c, &S.lin_dump, B * N * ilqr::lin_dump_doubles()));
   A(dalloc(c, &S.K, B * N * m * n)); A(dalloc(c, &S.kff, B * N * m)); A(dalloc(c, &S.Vx, B * n)); A(dalloc(c, &S.Vxx, B * n * n));

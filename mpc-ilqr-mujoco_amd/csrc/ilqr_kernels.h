@@ -74,6 +74,7 @@ void launch_line_search_s(const DevState& S, const h1::ProblemDev& P, int mode, 
 int dyn_split_kernels_set_attr();
 void launch_backward_mfma(const DevState& S, int mode, hipStream_t st);
 int backward_mfma_set_attr();
+void launch_backward_wave(const DevState& S, int mode, hipStream_t st);
 size_t backward_mfma_lds_bytes();
 
 }  // namespace ilqr

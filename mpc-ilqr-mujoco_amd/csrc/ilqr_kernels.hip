@@ -488,14 +488,20 @@ void launch_linearize(const DevState& S, const ProblemDev& P, int mode, int jac_
   }
 }
 size_t lin_dump_doubles() { return LinDumpG_SIZE; }
-// ILQR_BACKWARD=valu selects the LDS + VALU kernel (kept as an on-device cross-check); default = MFMA kernel
-static int use_valu_backward() {
+// ILQR_BACKWARD=valu selects the LDS + VALU kernel (kept as an on-device cross-check), =wg the four-wave MFMA
+// kernel (riccati_mfma.hip), =wave the one-wave-per-rollout MFMA kernel (riccati_wave.hip)
+#ifndef BACKWARD_DEFAULT
+#define BACKWARD_DEFAULT 2
+#endif
+static int backward_kind() {
   static int v = -1;
-  if (v < 0) { const char* e = getenv("ILQR_BACKWARD"); v = (e && e[0] == 'v') ? 1 : 0; }
+  if (v < 0) { const char* e = getenv("ILQR_BACKWARD"); v = !e ? BACKWARD_DEFAULT : (e[0] == 'v') ? 1 : (e[0] == 'w' && e[1] == 'a') ? 2 : 0; }
   return v;
 }
 void launch_backward(const DevState& S, int mode, hipStream_t st) {
-  if (use_valu_backward()) hipLaunchKernelGGL(k_backward, dim3(S.B), dim3(256), backward_lds_bytes(), st, S, mode);
+  const int kind = backward_kind();
+  if (kind == 1) hipLaunchKernelGGL(k_backward, dim3(S.B), dim3(256), backward_lds_bytes(), st, S, mode);
+  else if (kind == 2) launch_backward_wave(S, mode, st);
   else launch_backward_mfma(S, mode, st);
 }
 void launch_line_search(const DevState& S, const ProblemDev& P, int mode, hipStream_t st) {

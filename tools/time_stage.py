@@ -44,6 +44,13 @@ if os.environ.get("ILQR_LSTAMPS"):
     for nme, v in zip(names, st):
         print("  %-28s %10.0f cycles  %5.1f %%" % (nme, v, 100 * v / st.sum()))
     print("  total %.0f cycles" % st.sum())
+if os.environ.get("ILQR_WSTAMPS"):
+    names = ["wait staging, fix, lxx loads", "P2", "P4+P5", "P1 tile 3, P3 (3,3)", "Qu, Quu -> LDS", "rest of P1, P3", "chol + Linv", "stage next + P6a", "P6b + K store", "P7", "transposes"]
+    st = s.cost()[:11]
+    tot = st.sum()
+    for nme, v in zip(names, st):
+        print("  %-24s %10.0f cycles  %5.1f %%" % (nme, v / 25, 100 * v / tot))
+    print("  per knot total %.0f cycles (clock64 ticks)" % (tot / 25))
 if os.environ.get("ILQR_STAMPS"):
     names = ["regs<-staging", "sync", "P1", "P2", "Qx/Qu", "sync", "P3", "P4+P5", "sync", "chol+Linv (wave0)", "sync", "P6a+P6b", "sync", "P7+Vx", "sync", "-"]
     st = s.cost()[:16]
