@@ -179,23 +179,25 @@ def main():
         # of the rollouts, so they count towards the kernel's total but the roofline uses the full-batch launches
         # per kernel group: stage keys, algorithmic flops and HBM bytes of ONE full-batch launch
         D = 8.0
+        n_slices = max(1, s.num_slices())
+        Bl = B / n_slices      # rollouts per kernel launch (a solve is enqueued slice by slice, include/ilqr_hip.h)
         bk_env = os.environ.get("ILQR_BACKWARD", "wave")
         bk_name = {"wg": "k_backward_mfma", "va": "k_backward"}.get(bk_env[:2], "k_backward_wave")
         kernels = {
             bk_name: dict(stages=["iLQR_backwardPass", "iLQR_backwardPass_retry"], unit="fp64 MFMA",
-                                    flops=RICCATI_FLOPS_PER_KNOT * N * B,
-                                    bytes=D * B * (N * (2601 + 969 + 2601 + 51 + 19 + 19 + 969 + 19) + 2 * (2601 + 51))),
+                                    flops=RICCATI_FLOPS_PER_KNOT * N * Bl,
+                                    bytes=D * Bl * (N * (2601 + 969 + 2601 + 51 + 19 + 19 + 969 + 19) + 2 * (2601 + 51))),
             "k_line_search_r": dict(stages=["iLQR_lineSearch", "iLQR_lineSearch_retry"], unit="fp64 VALU",
-                                    flops=STEP_FLOPS * N * B,      # the accepted alpha's rollout is the algorithmic work
-                                    bytes=D * B * N * ((969 + 19 + 51 + 19) + 8 * (51 + 19))),
+                                    flops=STEP_FLOPS * N * Bl,      # the accepted alpha's rollout is the algorithmic work
+                                    bytes=D * Bl * N * ((969 + 19 + 51 + 19) + 8 * (51 + 19))),
             "k_lin_primal_r+k_lin_tangent": dict(stages=["iLQR_linearization"], unit="fp64 VALU",
-                                                 flops=JACOBIAN_FLOPS_PER_KNOT * N * B,
-                                                 bytes=D * B * N * (70 + 493 + 493 + 70 + 2601 + 969)),
+                                                 flops=JACOBIAN_FLOPS_PER_KNOT * N * Bl,
+                                                 bytes=D * Bl * N * (70 + 493 + 493 + 70 + 2601 + 969)),
             "k_cost_quadratics": dict(stages=["iLQR_costQuadratics"], unit="fp64 VALU",
-                                      flops=QUAD_FLOPS_PER_KNOT * (N + 1) * B,
-                                      bytes=D * B * (N + 1) * (70 + 2601 + 51 + 19 + 19)),
+                                      flops=QUAD_FLOPS_PER_KNOT * (N + 1) * Bl,
+                                      bytes=D * Bl * (N + 1) * (70 + 2601 + 51 + 19 + 19)),
             "k_rollout_s": dict(stages=["iLQR_computeCost+forwardRollout"], unit="fp64 VALU",
-                                flops=STEP_FLOPS * N * B, bytes=D * B * N * (51 + 19 + 51)),
+                                flops=STEP_FLOPS * N * Bl, bytes=D * Bl * N * (51 + 19 + 51)),
         }
         traffic_file = os.path.join(ROOT, "profiles", "traffic_latest.json")
         measured = json.load(open(traffic_file)) if os.path.exists(traffic_file) else {}
@@ -217,13 +219,13 @@ def main():
         else:
             roof = {"bound": "hbm", "achieved": d["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": d["frac_hbm"]}
         m = measured.get(dom_kernel.split("+")[-1])
-        roof["traffic"] = None if m is None else 2.0 * 1024.0 * m["FETCH_SIZE_KiB"] + 1024.0 * m["WRITE_SIZE_KiB"]
+        roof["traffic"] = None if m is None else (2.0 * 1024.0 * m["FETCH_SIZE_KiB"] + 1024.0 * m["WRITE_SIZE_KiB"]) / n_slices
         roof.update({"kernel": dom_kernel, "compute_unit": d["compute_unit"], "avg_launch_ms": d["avg_launch_ms"], "launches": d["launches"],
                      "algorithmic_flops_per_launch": d["algorithmic_flops_per_launch"],
                      "algorithmic_bytes_per_launch": d["algorithmic_bytes_per_launch"],
                      "frac_compute": d["frac_compute"], "frac_hbm": d["frac_hbm"],
                      "kernel_total_ms_per_step": d["total_ms_per_step"],
-                     "note": "full-batch launches only (HIP events on the launch stream); traffic = 2 x FETCH_SIZE + WRITE_SIZE per launch from "
+                     "note": "full-batch launches only (HIP events on the launch stream); traffic = 2 x FETCH_SIZE + WRITE_SIZE of a full-batch launch (x 1 / batch_slices when the solve is sliced) from "
                              "separate rocprofv3 --pmc passes of this command (profiles/traffic_latest.json), null if not collected; "
                              "cost quadratics and linearisation overlap on two streams, so their stage times include contention"})
         out = {
@@ -234,7 +236,7 @@ def main():
                                    "H1 standing balance, N=%d, dt=0.02, %d fixed iterations per rollout, shipped config.yaml weights, gravity %s"
                                    % (B, N, iters, list(prob["gravity"])),
                        "batch_per_gpu": B, "global_batch": B * world, "horizon": N, "iterations_per_solve": iters,
-                       "jacobians": "analytic", "gather": "u0+cost" + ("+K0" if args.gather_gains else "")},
+                       "jacobians": "analytic", "batch_slices": n_slices, "gather": "u0+cost" + ("+K0" if args.gather_gains else "")},
             "roofline": roof,
             "kernels": {n: {k: (round(v, 6) if isinstance(v, float) else v) for k, v in t.items() if k in
                             ("total_ms_per_step", "avg_launch_ms", "frac_compute", "frac_hbm")} for n, t in table.items()},

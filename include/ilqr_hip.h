@@ -50,6 +50,10 @@ int ilqr_hip_destroy(ilqr_hip_ctx* ctx);
 const char* ilqr_hip_last_error(const ilqr_hip_ctx* ctx);
 int ilqr_hip_batch(const ilqr_hip_ctx* ctx);
 int ilqr_hip_horizon(const ilqr_hip_ctx* ctx);
+/* Number of contiguous batch slices a solve is enqueued as (each on its own streams, so that the line search of one
+   slice overlaps with the Riccati / Jacobian kernels of the others; environment ILQR_SLICES, 1 = one launch sequence
+   for the whole batch).  No reference counterpart: the reference solves one trajectory at a time. */
+int ilqr_hip_num_slices(const ilqr_hip_ctx* ctx);
 
 /* RobotUtils::setCostWeights -- include/common/robot_utils.hpp:60, src/common/robot_utils.cpp:253-279.
    Q/R/Qf are diagonal by construction (Config::buildCostMatrices, src/common/config.cpp:66-122). */

@@ -44,6 +44,13 @@ struct ilqr_hip_ctx {
   std::vector<hipEvent_t> pool;
   size_t pool_next = 0;
   double stage_ms[8] = {0}, stage_launches[8] = {0};
+  // batch slices: the solve of each contiguous slice of the batch is enqueued on its own pair of streams, so that the
+  // latency-bound stages of one slice (line search: 8 waves per 64 rollouts, nominal rollout) overlap with the
+  // throughput-bound stages of the others (ILQR_SLICES, default SLICES_DEFAULT; 1 = whole batch on one stream pair)
+  struct Slice { hipStream_t st = nullptr, st2 = nullptr; hipEvent_t fork = nullptr, join = nullptr, done = nullptr, lead = nullptr; };
+  std::vector<Slice> slices;
+  hipEvent_t ev_begin = nullptr;
+  int n_slices = 1;
 };
 
 #define HIPCHK(ctx, call)                                                                   \
@@ -132,6 +139,8 @@ int ilqr_hip_destroy(ilqr_hip_ctx* c) {
                   c->d_prevx, c->d_prevu, c->d_u0, c->d_K0, c->d_cost_tmp, c->d_xref, c->d_uref, c->d_comref, c->d_eeref, c->d_comvelref, c->d_stance};
   for (void* p : ptrs) if (p) hipFree(p);
   for (hipEvent_t e : c->pool) hipEventDestroy(e);
+  for (auto& sl : c->slices) { hipEventDestroy(sl.fork); hipEventDestroy(sl.join); hipEventDestroy(sl.done); hipEventDestroy(sl.lead); hipStreamDestroy(sl.st2); hipStreamDestroy(sl.st); }
+  if (c->ev_begin) hipEventDestroy(c->ev_begin);
   if (c->ev_fork) hipEventDestroy(c->ev_fork);
   if (c->ev_join) hipEventDestroy(c->ev_join);
   if (c->stream2) hipStreamDestroy(c->stream2);
@@ -294,6 +303,84 @@ static int reuse_rollout() {
   if (v < 0) { const char* e = getenv("ILQR_REUSE_ROLLOUT"); v = (e && e[0] == '1') ? 1 : 0; }
   return v;
 }
+#ifndef SLICES_DEFAULT
+#define SLICES_DEFAULT 1
+#endif
+static int slices_wanted(int B) {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("ILQR_SLICES"); v = e ? atoi(e) : SLICES_DEFAULT; if (v < 1) v = 1; if (v > 32) v = 32; }
+  int k = v;
+  while (k > 1 && B / k < 64) --k;   // a slice is at least one wave of the widest kernels
+  return k;
+}
+static int stagger_wanted() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("ILQR_STAGGER"); v = e ? atoi(e) : 1; }
+  return v;
+}
+// view of rollouts [b0, b0 + Bs) of the batch (every array is rollout-major)
+static DevState slice_state(const DevState& S, size_t b0, int Bs) {
+  DevState T = S;
+  const size_t N = S.N, n = ILQR_NX, m = ILQR_NU, mi = S.max_iter;
+  T.B = Bs;
+  T.x0 += b0 * n; T.xbar += b0 * (N + 1) * n; T.ubar += b0 * N * m;
+  T.xcand += b0 * 8 * (N + 1) * n; T.ucand += b0 * 8 * N * m; T.cand_cost += b0 * 8;
+  T.A += b0 * N * n * n; T.Bm += b0 * N * n * m;
+  T.lx += b0 * (N + 1) * n; T.lu += b0 * N * m; T.lxx += b0 * (N + 1) * n * n; T.luu += b0 * N * m;
+  T.K += b0 * N * m * n; T.kff += b0 * N * m; T.lin_dump += b0 * N * ilqr::lin_dump_doubles();
+  T.Vx += b0 * n; T.Vxx += b0 * n * n;
+  T.J += b0; T.Jbase += b0; T.ls_cost += b0; T.lambda += b0;
+  T.active += b0; T.need_retry += b0; T.iters += b0; T.improved += b0; T.alpha_idx += b0;
+  T.trace_cost += b0 * (mi + 1); T.trace_alpha += b0 * mi; T.trace_lambda += b0 * mi;
+  return T;
+}
+static h1::ProblemDev slice_problem(const h1::ProblemDev& P, long b0) {
+  h1::ProblemDev T = P;
+  T.x_ref += b0 * P.x_ref_stride; T.u_ref += b0 * P.u_ref_stride; T.com_ref += b0 * P.com_ref_stride;
+  T.stance += b0 * P.stance_stride; T.ee_ref += b0 * P.ee_ref_stride; T.com_vel_ref += b0 * P.com_vel_ref_stride;
+  return T;
+}
+static int ensure_slices(ilqr_hip_ctx* c, int k) {
+  if (!c->ev_begin) HIPCHK(c, hipEventCreateWithFlags(&c->ev_begin, hipEventDisableTiming));
+  while ((int)c->slices.size() < k) {
+    ilqr_hip_ctx::Slice sl;
+    HIPCHK(c, hipStreamCreate(&sl.st)); HIPCHK(c, hipStreamCreate(&sl.st2));
+    HIPCHK(c, hipEventCreateWithFlags(&sl.fork, hipEventDisableTiming)); HIPCHK(c, hipEventCreateWithFlags(&sl.join, hipEventDisableTiming));
+    HIPCHK(c, hipEventCreateWithFlags(&sl.done, hipEventDisableTiming)); HIPCHK(c, hipEventCreateWithFlags(&sl.lead, hipEventDisableTiming));
+    c->slices.push_back(sl);
+  }
+  return ILQR_OK;
+}
+// the launch sequence of iLQR::solve (ilqr.cpp:521-660) for one slice on its streams; `wait_lead` (optional) delays the
+// first throughput-bound stage until the previous slice has finished its first backward pass, `lead` is recorded there
+static int enqueue_solve(ilqr_hip_ctx* c, const DevState& S, const h1::ProblemDev& P, hipStream_t st, hipStream_t st2,
+                         hipEvent_t ev_fork, hipEvent_t ev_join, hipEvent_t wait_lead, hipEvent_t lead) {
+  { StageTimer T(c, 0, st); ilqr::launch_rollout(S, P, ilqr::MASK_ALL, 0, 0, S.Jbase, st); ilqr::launch_solve_begin(S, st); }  // ilqr.cpp:540
+  for (int iter = 0; iter < c->max_iter; ++iter) {
+    // :551,563 nominal rollout at the top of every iteration, as the reference does.  From the second iteration on the
+    // nominal trajectory is the candidate the line search accepted (or the unchanged previous one), so the re-rollout
+    // only reproduces it; ILQR_REUSE_ROLLOUT=1 skips it (not the default: the headline metric counts the rollout
+    // as part of an iteration, SURVEY 8(d))
+    if (iter == 0 || !reuse_rollout()) { StageTimer T(c, 0, st); ilqr::launch_rollout(S, P, ilqr::MASK_ACTIVE, 1, 0, S.Jbase, st); }
+    if (iter == 0 && wait_lead) HIPCHK(c, hipStreamWaitEvent(st, wait_lead, 0));
+    // linearisation (:576) and cost quadratics (:588) only depend on the rollout: run them concurrently
+    HIPCHK(c, hipEventRecord(ev_fork, st));
+    HIPCHK(c, hipStreamWaitEvent(st2, ev_fork, 0));
+    { StageTimer T(c, 2, st2); ilqr::launch_cost_quadratics(S, P, ilqr::MASK_ACTIVE, st2); }
+    HIPCHK(c, hipEventRecord(ev_join, st2));
+    { StageTimer T(c, 1, st); ilqr::launch_linearize(S, P, ilqr::MASK_ACTIVE, c->jac_mode, c->fd_eps, st); }
+    HIPCHK(c, hipStreamWaitEvent(st, ev_join, 0));
+    { StageTimer T(c, 3, st); ilqr::launch_backward(S, ilqr::MASK_ACTIVE, st); }                                  // :601
+    if (iter == 0 && lead) HIPCHK(c, hipEventRecord(lead, st));
+    { StageTimer T(c, 4, st); ilqr::launch_line_search(S, P, ilqr::MASK_ACTIVE, st); }                            // :616
+    { StageTimer T(c, 5, st); ilqr::launch_control(S, 0, iter, c->tol, c->early_exit, st); }                      // :619-620,645-655
+    { StageTimer T(c, 6, st); ilqr::launch_backward(S, ilqr::MASK_RETRY, st); }                                   // :637
+    { StageTimer T(c, 7, st); ilqr::launch_line_search(S, P, ilqr::MASK_RETRY, st); }                             // :638
+    { StageTimer T(c, 5, st); ilqr::launch_control(S, 1, iter, c->tol, c->early_exit, st); }                      // :640-646
+  }
+  return ILQR_OK;
+}
+int ilqr_hip_num_slices(const ilqr_hip_ctx* c) { return c ? slices_wanted(c->B) : -1; }
 int ilqr_hip_solve_async(ilqr_hip_ctx* c) {
   if (!c) return ILQR_ERR_ARG;
   if (!c->initialized || !c->refs_set) { c->err = "solve before initialize/set_references"; return ILQR_ERR_STATE; }
@@ -301,26 +388,26 @@ int ilqr_hip_solve_async(ilqr_hip_ctx* c) {
   hipStream_t st = c->stream;
   const DevState& S = c->S; const h1::ProblemDev& P = c->P;
   c->spans.clear(); c->pool_next = 0;
-  { StageTimer T(c, 0); ilqr::launch_rollout(S, P, ilqr::MASK_ALL, 0, 0, S.Jbase, st); ilqr::launch_solve_begin(S, st); }  // ilqr.cpp:540
-  for (int iter = 0; iter < c->max_iter; ++iter) {
-    // :551,563 nominal rollout at the top of every iteration, as the reference does.  From the second iteration on the
-    // nominal trajectory is the candidate the line search accepted (or the unchanged previous one), so the re-rollout
-    // only reproduces it; ILQR_REUSE_ROLLOUT=1 skips it (not the default: the headline metric counts the rollout
-    // as part of an iteration, SURVEY 8(d))
-    if (iter == 0 || !reuse_rollout()) { StageTimer T(c, 0); ilqr::launch_rollout(S, P, ilqr::MASK_ACTIVE, 1, 0, S.Jbase, st); }
-    // linearisation (:576) and cost quadratics (:588) only depend on the rollout: run them concurrently
-    HIPCHK(c, hipEventRecord(c->ev_fork, st));
-    HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
-    { StageTimer T(c, 2, c->stream2); ilqr::launch_cost_quadratics(S, P, ilqr::MASK_ACTIVE, c->stream2); }
-    HIPCHK(c, hipEventRecord(c->ev_join, c->stream2));
-    { StageTimer T(c, 1); ilqr::launch_linearize(S, P, ilqr::MASK_ACTIVE, c->jac_mode, c->fd_eps, st); }
-    HIPCHK(c, hipStreamWaitEvent(st, c->ev_join, 0));
-    { StageTimer T(c, 3); ilqr::launch_backward(S, ilqr::MASK_ACTIVE, st); }                                  // :601
-    { StageTimer T(c, 4); ilqr::launch_line_search(S, P, ilqr::MASK_ACTIVE, st); }                            // :616
-    { StageTimer T(c, 5); ilqr::launch_control(S, 0, iter, c->tol, c->early_exit, st); }                      // :619-620,645-655
-    { StageTimer T(c, 6); ilqr::launch_backward(S, ilqr::MASK_RETRY, st); }                                   // :637
-    { StageTimer T(c, 7); ilqr::launch_line_search(S, P, ilqr::MASK_RETRY, st); }                             // :638
-    { StageTimer T(c, 5); ilqr::launch_control(S, 1, iter, c->tol, c->early_exit, st); }                      // :640-646
+  const int k = slices_wanted(c->B);
+  c->n_slices = k;
+  if (k <= 1) {
+    TRY(enqueue_solve(c, S, P, st, c->stream2, c->ev_fork, c->ev_join, nullptr, nullptr));
+  } else {
+    TRY(ensure_slices(c, k));
+    HIPCHK(c, hipEventRecord(c->ev_begin, st));
+    const int per = (c->B + k - 1) / k;
+    const bool stagger = stagger_wanted() != 0;
+    for (int i = 0; i < k; ++i) {
+      const int b0 = i * per, Bs = (b0 + per <= c->B) ? per : (c->B - b0);
+      if (Bs <= 0) continue;
+      auto& sl = c->slices[i];
+      HIPCHK(c, hipStreamWaitEvent(sl.st, c->ev_begin, 0));
+      const DevState Ss = slice_state(S, (size_t)b0, Bs);
+      const h1::ProblemDev Ps = slice_problem(P, b0);
+      TRY(enqueue_solve(c, Ss, Ps, sl.st, sl.st2, sl.fork, sl.join, (stagger && i > 0) ? c->slices[i - 1].lead : nullptr, sl.lead));
+      HIPCHK(c, hipEventRecord(sl.done, sl.st));
+      HIPCHK(c, hipStreamWaitEvent(st, sl.done, 0));
+    }
   }
   HIPCHK(c, hipGetLastError());
   return ILQR_OK;

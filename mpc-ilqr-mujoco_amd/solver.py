@@ -22,7 +22,7 @@ JAC_ANALYTIC, JAC_FD_FORWARD = 0, 1
 
 # every symbol include/ilqr_hip.h declares (checked by the CPU test-suite against the built library)
 EXPORTS = [
-    "ilqr_hip_create", "ilqr_hip_destroy", "ilqr_hip_last_error", "ilqr_hip_batch", "ilqr_hip_horizon",
+    "ilqr_hip_create", "ilqr_hip_destroy", "ilqr_hip_last_error", "ilqr_hip_batch", "ilqr_hip_horizon", "ilqr_hip_num_slices",
     "ilqr_hip_set_cost_weights", "ilqr_hip_set_task_weights", "ilqr_hip_set_constraint_weights", "ilqr_hip_set_gravity",
     "ilqr_hip_set_contact_schedule", "ilqr_hip_set_ee_references", "ilqr_hip_set_references",
     "ilqr_hip_set_regularization", "ilqr_hip_set_max_iterations", "ilqr_hip_set_tolerance", "ilqr_hip_set_options",
@@ -306,6 +306,10 @@ class BatchedILQR:
 
     def enable_profiling(self, on=True):
         self._chk(self.L.ilqr_hip_enable_profiling(self.h, int(bool(on))))
+
+    def num_slices(self):
+        """Batch slices a solve is enqueued as (ILQR_SLICES)."""
+        return int(self.L.ilqr_hip_num_slices(self.h))
 
     def stage_ms(self):
         ms, n = np.zeros(8), np.zeros(8)

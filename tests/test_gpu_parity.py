@@ -139,6 +139,49 @@ def test_backward_pass_vs_numpy_golden(case):
     s.close()
 
 
+def test_backward_pass_indefinite_quu_fallback():
+    """Quu indefinite even after the +1e-4 bump (ilqr.cpp:278-281): the reference's ldlt() solves the symmetric
+    indefinite system; the kernels fall back to an explicit pivoted inverse.  Checked against a NumPy restatement of
+    ilqr.cpp:250-309 (long-form Vx / Vxx, symmetrised)."""
+    rng = np.random.default_rng(11)
+    N, n, m, lam = 4, 51, 19, 1e-6
+    A = np.eye(n)[None] + 0.05 * rng.standard_normal((N, n, n))
+    Bm = 0.1 * rng.standard_normal((N, n, m))
+    lx = rng.standard_normal((N + 1, n)); lu = rng.standard_normal((N, m))
+    lxx = np.stack([np.diag(rng.uniform(1.0, 3.0, n)) for _ in range(N + 1)])
+    luu = rng.uniform(0.5, 1.5, (N, m))
+    luu[2, 3] = -40.0; luu[1, 7] = -25.0            # indefinite Quu at knots 2 and 1
+    Vx, Vxx = lx[N].copy(), lxx[N].copy()
+    Kw, kw = np.zeros((N, m, n)), np.zeros((N, m))
+    n_indef = 0
+    for t in range(N - 1, -1, -1):
+        Qx = lx[t] + A[t].T @ Vx; Qu = lu[t] + Bm[t].T @ Vx
+        Qxx = lxx[t] + A[t].T @ Vxx @ A[t]
+        Quu = np.diag(luu[t]) + Bm[t].T @ Vxx @ Bm[t] + lam * np.eye(m)
+        Qxu = A[t].T @ Vxx @ Bm[t]
+        if np.linalg.eigvalsh(Quu).min() <= 0:
+            Quu = Quu + 1e-4 * np.eye(m)
+            n_indef += int(np.linalg.eigvalsh(Quu).min() <= 0)
+        K = -np.linalg.solve(Quu, Qxu.T); k = -np.linalg.solve(Quu, Qu)
+        Vx = Qx + K.T @ Quu @ k + K.T @ Qu + Qxu @ k
+        Vxx = Qxx + K.T @ Quu @ K + K.T @ Qxu.T + Qxu @ K
+        Vxx = 0.5 * (Vxx + Vxx.T)
+        Kw[t], kw[t] = K, k
+    assert n_indef >= 2
+    s = _solver(3, N=N)
+    s.set_regularization(lam)
+    rep = lambda a: np.stack([a] * 3)
+    s.set_linearization(rep(A), rep(Bm))
+    s.set_quadratics(rep(lx), rep(lu), rep(lxx), rep(luu))
+    s.stage_backward_pass()
+    K, kff = s.gains_K(), s.gains_kff()
+    gVx, gVxx = s.value_function()
+    for got, want, key in ((K, Kw, "K"), (kff, kw, "k"), (gVx, Vx, "Vx"), (gVxx, Vxx, "Vxx")):
+        for b in range(3):
+            assert np.abs(got[b] - want).max() <= 1e-7 * max(1.0, np.abs(want).max()), (key, np.abs(got[b] - want).max())
+    s.close()
+
+
 def test_backward_pass_and_line_search_match_oracle():
     prob, x0, ui = make(3, seed=4)
     s = _solver(3); s.set_problem(prob)
