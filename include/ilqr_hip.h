@@ -136,6 +136,18 @@ int ilqr_hip_get_value_function(ilqr_hip_ctx* ctx, double* Vx /*[B][51]*/, doubl
 /* one dynamics step for arbitrary (x,u) pairs: RobotUtils::rolloutOneStep, src/common/robot_utils.cpp:106-117 */
 int ilqr_hip_step(ilqr_hip_ctx* ctx, int count, const double* x /*[count][51]*/, const double* u /*[count][19]*/, double* x_next /*[count][51]*/);
 
+/* Contact row.  The reference's plant is MuJoCo with floor contacts (mj_step inside
+   RobotUtils::rolloutOneStep, src/common/robot_utils.cpp:106-117).  ILQR_CONTACT_RIGID_STANCE restates the regime its
+   scenarios run in: a foot the contact schedule (ilqr_hip_set_contact_schedule, horizon-local rows) marks as stance does
+   not move -- velocity-level constraint on the ankle link over one step, solved through the articulated-body
+   quantities; `softness` (> 0: set, <= 0: keep, default 1e-5 / kg) regularises the constraint-space inertia.  In this
+   mode the rollout, line search and warm-start step run on the scalar kernels and the Jacobians are the reference's
+   forward differences (robot_utils.cpp:120-160), whatever ilqr_hip_set_options selected.
+   ilqr_hip_step_stance: one step with explicit stance flags (the flags only matter in contact mode). */
+enum ilqr_contact_mode { ILQR_CONTACT_NONE = 0, ILQR_CONTACT_RIGID_STANCE = 1 };
+int ilqr_hip_set_contact_mode(ilqr_hip_ctx* ctx, int mode, double softness);
+int ilqr_hip_step_stance(ilqr_hip_ctx* ctx, int count, const double* x, const double* u, int stance_left, int stance_right, double* x_next);
+
 /* per-stage device time of the last solve in milliseconds, keyed like the reference's profiler
    (src/ilqr/ilqr.cpp:537-639): 0 computeCost/rollout, 1 linearization, 2 costQuadratics, 3 backwardPass,
    4 lineSearch, 5 control, 6 backwardPass (lambda-retry launch), 7 lineSearch (lambda-retry launch);

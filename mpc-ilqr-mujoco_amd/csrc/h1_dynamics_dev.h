@@ -10,6 +10,7 @@
 // Templated on the scalar: double for rollouts, Dual for exact directional derivatives
 // (one Jacobian column per thread in the linearisation kernel).
 #pragma once
+#include <type_traits>
 #include <hip/hip_runtime.h>
 
 #define H1_CONST __constant__ static const
@@ -53,6 +54,8 @@ DEVFN double val(Dual a) { return a.v; }
 struct DynParams {
   double h;
   double g[3];
+  int contact;      // 0: constraint-free step; 1: rigid stance constraints on the scheduled feet
+  double soft;      // diagonal softness of the stance constraint (1 / kg)
 };
 
 // ---------- 3-vectors / 3x3 (row-major) ----------
@@ -365,6 +368,96 @@ DEVFN void forward_dynamics(const T* quat_hat, const T* theta, const T* v, const
   }
 }
 
+// ---------- forward dynamics with schedule-driven rigid stance constraints ----------
+// The reference's plant is MuJoCo with floor contacts (RobotUtils::rolloutOneStep, src/common/robot_utils.cpp:106-117).
+// Restated as the regime its standing / walking scenarios run in: a foot the contact schedule marks as stance
+// (RobotUtils::isStance, robot_utils.cpp:494-504) does not move.  Velocity-level constraint over one step, consistent
+// with the semi-implicit Euler integrator:  v_f + h a_f = 0  (spatial velocity / acceleration of the ankle link in link
+// coordinates),  a_f = a_f,free + C lambda,  C = J Mhat^-1 J^T.  C is built by propagating unit wrenches through the
+// articulated-body quantities of the free solve (inward along the leg, pelvis solve, outward) -- neither M nor J is
+// formed; (C + soft I) lambda = rhs by Cholesky; the wrench is propagated once more for the joint accelerations.
+// Scalar (scratch-resident) path, one lane per rollout; Jacobians of this step come from k_linearize_fd
+// (the reference's own forward differences, robot_utils.cpp:120-160).
+__device__ inline bool chol_solve_small(double* A, double* b, int n) {
+  for (int j = 0; j < n; ++j) {
+    double d = A[j * n + j];
+    for (int k = 0; k < j; ++k) d -= A[j * n + k] * A[j * n + k];
+    if (!(d > 0.0)) return false;
+    d = sqrt(d);
+    A[j * n + j] = d;
+    for (int i = j + 1; i < n; ++i) {
+      double s = A[i * n + j];
+      for (int k = 0; k < j; ++k) s -= A[i * n + k] * A[j * n + k];
+      A[i * n + j] = s / d;
+    }
+  }
+  for (int i = 0; i < n; ++i) { double s = b[i]; for (int k = 0; k < i; ++k) s -= A[i * n + k] * b[k]; b[i] = s / A[i * n + i]; }
+  for (int i = n - 1; i >= 0; --i) { double s = b[i]; for (int k = i + 1; k < n; ++k) s -= A[k * n + i] * b[k]; b[i] = s / A[i * n + i]; }
+  return true;
+}
+// response to wrenches fext[g] (link coordinates) on the stance feet fb[0..nf): accelerations of those feet and, if
+// `full`, of the pelvis (dbase) and every hinge (dqdd[1..19])
+__device__ inline void stance_respond(const KnotDump& Dm, int nf, const int* fb, const double (*fext)[6], double (*da_feet)[6],
+                                      bool full, double* dqdd, double* dbase) {
+  double dpA[H1_NB][6], du[H1_NB], da[H1_NB][6];
+  for (int i = 0; i < H1_NB; ++i) { du[i] = 0.0; for (int k = 0; k < 6; ++k) dpA[i][k] = 0.0; }
+  for (int g = 0; g < nf; ++g) for (int k = 0; k < 6; ++k) dpA[fb[g]][k] -= fext[g][k];
+  for (int i = 10; i >= 1; --i) {                       // the two leg chains
+    const int a = H1_AXIS[i];
+    du[i] = -dpA[i][a];
+    double dpa[6]; for (int k = 0; k < 6; ++k) dpa[k] = dpA[i][k] + Dm.U[i][k] * (du[i] * Dm.Dinv[i]);
+    xf_force_acc(Dm.Rj[i], H1_POS[i], dpa, dpA[H1_PARENT[i]]);
+  }
+  for (int r = 0; r < 6; ++r) { double s = 0.0; for (int c = 0; c < 6; ++c) s -= Dm.IA0inv[6 * r + c] * dpA[0][c]; da[0][r] = s; }
+  const int last = full ? H1_NB - 1 : 10;
+  for (int i = 1; i <= last; ++i) {
+    const int a = H1_AXIS[i];
+    double ap[6]; xf_motion(Dm.Rj[i], H1_POS[i], da[H1_PARENT[i]], ap);
+    double s = du[i]; for (int k = 0; k < 6; ++k) s -= Dm.U[i][k] * ap[k];
+    const double q = s * Dm.Dinv[i];
+    for (int k = 0; k < 6; ++k) da[i][k] = ap[k];
+    da[i][a] += q;
+    if (full) dqdd[i] = q;
+  }
+  for (int g = 0; g < nf; ++g) for (int k = 0; k < 6; ++k) da_feet[g][k] = da[fb[g]][k];
+  if (full) for (int k = 0; k < 6; ++k) dbase[k] = da[0][k];
+}
+__device__ inline void forward_dynamics_stance(const double* quat_hat, const double* theta, const double* v, const double* tau, double arm_eff,
+                                               const double* grav, double h, double soft, const int* stance, double* qacc) {
+  KnotDump Dm;
+  forward_dynamics<double, true>(quat_hat, theta, v, tau, arm_eff, grav, qacc, nullptr, &Dm);
+  int nf = 0, fb[2];
+  if (stance[0] == 1) fb[nf++] = 5;      // left ankle link
+  if (stance[1] == 1) fb[nf++] = 10;     // right ankle link
+  if (nf == 0) return;
+  const int nc = 6 * nf;
+  double C[144], b[12];
+  for (int g = 0; g < nf; ++g)
+    for (int c = 0; c < 6; ++c) {
+      double fext[2][6], daf[2][6];
+      for (int g2 = 0; g2 < 2; ++g2) for (int k = 0; k < 6; ++k) fext[g2][k] = 0.0;
+      fext[g][c] = 1.0;
+      stance_respond(Dm, nf, fb, fext, daf, false, nullptr, nullptr);
+      for (int g2 = 0; g2 < nf; ++g2) for (int k = 0; k < 6; ++k) C[(6 * g2 + k) * nc + 6 * g + c] = daf[g2][k];
+    }
+  for (int i = 0; i < nc; ++i) C[i * nc + i] += soft;
+  // true (not gravity-offset) spatial acceleration of the foot: a_f - X_{f<-0} (0, R0^T(-g))
+  const double mg[3] = {-grav[0], -grav[1], -grav[2]};
+  double a0p[3]; mtv3(Dm.R0, mg, a0p);
+  for (int g = 0; g < nf; ++g) {
+    double off[6] = {0.0, 0.0, 0.0, a0p[0], a0p[1], a0p[2]};
+    for (int i = fb[g] - 4; i <= fb[g]; ++i) { double o2[6]; xf_motion(Dm.Rj[i], H1_POS[i], off, o2); for (int k = 0; k < 6; ++k) off[k] = o2[k]; }
+    for (int k = 0; k < 6; ++k) b[6 * g + k] = -Dm.v[fb[g]][k] / h - (Dm.a[fb[g]][k] - off[k]);
+  }
+  chol_solve_small(C, b, nc);
+  double fext[2][6], daf[2][6], dq[H1_NB], da0[6];
+  for (int g = 0; g < 2; ++g) for (int k = 0; k < 6; ++k) fext[g][k] = g < nf ? b[6 * g + k] : 0.0;
+  stance_respond(Dm, nf, fb, fext, daf, true, dq, da0);
+  for (int i = 1; i < H1_NB; ++i) qacc[6 + i - 1] += dq[i];
+  double dl[3]; mv3(Dm.R0, da0 + 3, dl);
+  for (int k = 0; k < 3; ++k) { qacc[k] += dl[k]; qacc[3 + k] += da0[k]; }
+}
+
 // cos(a/2) and sin(a/2)/a as smooth functions of s = a^2
 template <class T> DEVFN void half_angle_cs(const T& s, T& c, T& so) {
   if (val(s) < 1e-6) {
@@ -376,9 +469,9 @@ template <class T> DEVFN void half_angle_cs(const T& s, T& c, T& so) {
   }
 }
 
-// x_next = f(x, u)
+// x_next = f(x, u); `stance` (left / right flag of the knot being stepped) is used when P.contact != 0 (double only)
 template <class T>
-DEVFN void step(const T* x, const T* u, const DynParams& P, T* xn) {
+DEVFN void step(const T* x, const T* u, const DynParams& P, T* xn, const int* stance = nullptr) {
   const double h = P.h;
   const T qn = dsqrt(x[3] * x[3] + x[4] * x[4] + x[5] * x[5] + x[6] * x[6]);
   const T qh[4] = {x[3] / qn, x[4] / qn, x[5] / qn, x[6] / qn};
@@ -391,7 +484,11 @@ DEVFN void step(const T* x, const T* u, const DynParams& P, T* xn) {
     tau[i] = ui - H1_DAMPING * x[H1_NQ + 6 + i];
   }
   T qacc[H1_NV];
-  forward_dynamics(qh, x + 7, x + H1_NQ, tau, H1_ARMATURE + h * H1_DAMPING, P.g, qacc);
+  bool done = false;
+  if constexpr (std::is_same<T, double>::value) {
+    if (P.contact && stance) { forward_dynamics_stance(qh, x + 7, x + H1_NQ, tau, H1_ARMATURE + h * H1_DAMPING, P.g, h, P.soft, stance, qacc); done = true; }
+  }
+  if (!done) forward_dynamics(qh, x + 7, x + H1_NQ, tau, H1_ARMATURE + h * H1_DAMPING, P.g, qacc);
   T vn[H1_NV];
 #pragma unroll
   for (int i = 0; i < H1_NV; ++i) { vn[i] = x[H1_NQ + i] + h * qacc[i]; xn[H1_NQ + i] = vn[i]; }

@@ -113,7 +113,7 @@ int ilqr_hip_create(ilqr_hip_ctx** out, int device, int batch, int horizon, doub
   if (rc != ILQR_OK) { *out = c; return rc; }
   if (ilqr::backward_needs_lds_attr() != 0) { c->err = "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed"; *out = c; return ILQR_ERR_HIP; }
   h1::ProblemDev& P = c->P;
-  P.N = horizon; P.dyn.h = dt; P.dyn.g[0] = 0; P.dyn.g[1] = 0; P.dyn.g[2] = -9.81;
+  P.N = horizon; P.dyn.h = dt; P.dyn.g[0] = 0; P.dyn.g[1] = 0; P.dyn.g[2] = -9.81; P.dyn.contact = 0; P.dyn.soft = 1e-5;
   for (int i = 0; i < ILQR_NX; ++i) { P.Q[i] = 1.0; P.Qf[i] = 1.0; }
   for (int i = 0; i < ILQR_NU; ++i) P.R[i] = 1.0;
   P.w_com = P.w_com_vel = P.w_ee_pos = P.w_ee_vel = P.w_upright = P.w_balance = 0.0;
@@ -569,7 +569,17 @@ int ilqr_hip_get_value_function(ilqr_hip_ctx* c, double* Vx, double* Vxx) {
   if (Vxx) HIPCHK(c, hipMemcpy(Vxx, c->S.Vxx, (size_t)c->B * ILQR_NX * ILQR_NX * sizeof(double), hipMemcpyDeviceToHost));
   return ILQR_OK;
 }
+int ilqr_hip_step_stance(ilqr_hip_ctx* c, int count, const double* x, const double* u, int stance_left, int stance_right, double* x_next);
 int ilqr_hip_step(ilqr_hip_ctx* c, int count, const double* x, const double* u, double* x_next) {
+  return ilqr_hip_step_stance(c, count, x, u, 1, 1, x_next);
+}
+int ilqr_hip_set_contact_mode(ilqr_hip_ctx* c, int mode, double softness) {
+  if (!c || (mode != ILQR_CONTACT_NONE && mode != ILQR_CONTACT_RIGID_STANCE)) return ILQR_ERR_ARG;
+  c->P.dyn.contact = mode;
+  if (softness > 0.0) c->P.dyn.soft = softness;
+  return ILQR_OK;
+}
+int ilqr_hip_step_stance(ilqr_hip_ctx* c, int count, const double* x, const double* u, int stance_left, int stance_right, double* x_next) {
   if (!c || count <= 0 || !x || !u || !x_next) return ILQR_ERR_ARG;
   hipSetDevice(c->device);
   double *dx = nullptr, *du = nullptr, *dn = nullptr;
@@ -578,7 +588,7 @@ int ilqr_hip_step(ilqr_hip_ctx* c, int count, const double* x, const double* u, 
   HIPCHK(c, hipMalloc((void**)&dn, (size_t)count * ILQR_NX * sizeof(double)));
   hipMemcpy(dx, x, (size_t)count * ILQR_NX * sizeof(double), hipMemcpyHostToDevice);
   hipMemcpy(du, u, (size_t)count * ILQR_NU * sizeof(double), hipMemcpyHostToDevice);
-  ilqr::launch_step(count, dx, du, c->P.dyn, dn, c->stream);
+  ilqr::launch_step(count, dx, du, c->P.dyn, dn, c->stream, stance_left, stance_right);
   hipError_t e = hipStreamSynchronize(c->stream);
   hipMemcpy(x_next, dn, (size_t)count * ILQR_NX * sizeof(double), hipMemcpyDeviceToHost);
   hipFree(dx); hipFree(du); hipFree(dn);

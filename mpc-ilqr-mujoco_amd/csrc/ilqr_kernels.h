@@ -48,7 +48,7 @@ struct DevState {
 };
 
 void launch_rollout(const DevState& S, const h1::ProblemDev& P, int mode, int do_roll, int count_iter, double* cost_out, hipStream_t st);
-void launch_step(int count, const double* x, const double* u, const h1::DynParams& dyn, double* xn, hipStream_t st);
+void launch_step(int count, const double* x, const double* u, const h1::DynParams& dyn, double* xn, hipStream_t st, int stance_l = 1, int stance_r = 1);
 void launch_linearize(const DevState& S, const h1::ProblemDev& P, int mode, int jac_mode, double eps, hipStream_t st, int phases = 3);
 void launch_cost_quadratics(const DevState& S, const h1::ProblemDev& P, int mode, hipStream_t st);
 void launch_backward(const DevState& S, int mode, hipStream_t st);

@@ -49,7 +49,7 @@ __global__ void __launch_bounds__(64) k_rollout(DevState S, ProblemDev P, int mo
     for (int i = 0; i < H1_NU; ++i) u[i] = ub[t * H1_NU + i];
     c += knot_cost(P, b, t, x, u);
     if (do_roll) {
-      step<double>(x, u, P.dyn, xn);
+      step<double>(x, u, P.dyn, xn, P.stance + b * P.stance_stride + 2 * t);
       for (int i = 0; i < H1_NX; ++i) { x[i] = xn[i]; xb[(t + 1) * H1_NX + i] = xn[i]; }
     } else {
       for (int i = 0; i < H1_NX; ++i) x[i] = xb[(t + 1) * H1_NX + i];
@@ -60,13 +60,14 @@ __global__ void __launch_bounds__(64) k_rollout(DevState S, ProblemDev P, int mo
 }
 
 // plain batched step for the stage API
-__global__ void __launch_bounds__(64) k_step(int count, const double* x, const double* u, DynParams dyn, double* xn) {
+__global__ void __launch_bounds__(64) k_step(int count, const double* x, const double* u, DynParams dyn, double* xn, int stance_l, int stance_r) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= count) return;
   double xl[H1_NX], ul[H1_NU], out[H1_NX];
   for (int k = 0; k < H1_NX; ++k) xl[k] = x[(size_t)i * H1_NX + k];
   for (int k = 0; k < H1_NU; ++k) ul[k] = u[(size_t)i * H1_NU + k];
-  step<double>(xl, ul, dyn, out);
+  const int stance[2] = {stance_l, stance_r};
+  step<double>(xl, ul, dyn, out, stance);
   for (int k = 0; k < H1_NX; ++k) xn[(size_t)i * H1_NX + k] = out[k];
 }
 
@@ -136,9 +137,10 @@ __global__ void __launch_bounds__(256) k_linearize_fd(DevState S, ProblemDev P, 
   double x[H1_NX], u[H1_NU], base[H1_NX], pert[H1_NX];
   for (int i = 0; i < H1_NX; ++i) x[i] = xg[i];
   for (int i = 0; i < H1_NU; ++i) u[i] = ug[i];
-  step<double>(x, u, P.dyn, base);
+  const int* stance = P.stance + b * P.stance_stride + 2 * t;
+  step<double>(x, u, P.dyn, base, stance);
   if (col < H1_NX) x[col] += eps; else u[col - H1_NX] += eps;
-  step<double>(x, u, P.dyn, pert);
+  step<double>(x, u, P.dyn, pert, stance);
   if (col < H1_NX) { for (int i = 0; i < H1_NX; ++i) Ag[i * H1_NX + col] = (pert[i] - base[i]) / eps; }
   else { const int c = col - H1_NX; for (int i = 0; i < H1_NX; ++i) Bg[i * H1_NU + c] = (pert[i] - base[i]) / eps; }
 }
@@ -327,7 +329,7 @@ __global__ void __launch_bounds__(64) k_line_search(DevState S, ProblemDev P, in
       uc[t * m + i] = u[i];
     }
     c += knot_cost(P, b, t, x, u);
-    step<double>(x, u, P.dyn, xn);
+    step<double>(x, u, P.dyn, xn, P.stance + b * P.stance_stride + 2 * t);
     for (int i = 0; i < n; ++i) { x[i] = xn[i]; xc[(t + 1) * n + i] = xn[i]; }
   }
   c += knot_cost(P, b, N, x, nullptr);
@@ -423,7 +425,7 @@ __global__ void k_last_step(DevState S, ProblemDev P) {
   double x[H1_NX], u[H1_NU], xn[H1_NX];
   for (int i = 0; i < H1_NX; ++i) x[i] = S.xbar[((size_t)b * (N + 1) + N - 1) * H1_NX + i];
   for (int i = 0; i < H1_NU; ++i) u[i] = S.ubar[((size_t)b * N + N - 1) * H1_NU + i];
-  step<double>(x, u, P.dyn, xn);
+  step<double>(x, u, P.dyn, xn, P.stance + b * P.stance_stride + 2 * (N - 1));
   for (int i = 0; i < H1_NX; ++i) S.xbar[((size_t)b * (N + 1) + N) * H1_NX + i] = xn[i];
 }
 
@@ -470,16 +472,16 @@ static int use_split(const char* var, int dflt) {
 }
 void launch_rollout(const DevState& S, const ProblemDev& P, int mode, int do_roll, int count_iter, double* cost_out, hipStream_t st) {
   static const int split = use_split("ILQR_ROLLOUT", ROLLOUT_SPLIT_DEFAULT);
-  if (!use_scalar_dyn()) { if (split) launch_rollout_s(S, P, mode, do_roll, count_iter, cost_out, st); else launch_rollout_r(S, P, mode, do_roll, count_iter, cost_out, st); return; }
+  if (!use_scalar_dyn() && !P.dyn.contact) { if (split) launch_rollout_s(S, P, mode, do_roll, count_iter, cost_out, st); else launch_rollout_r(S, P, mode, do_roll, count_iter, cost_out, st); return; }
   hipLaunchKernelGGL(k_rollout, dim3(cdiv(S.B, 64)), dim3(64), 0, st, S, P, mode, do_roll, count_iter, cost_out);
 }
-void launch_step(int count, const double* x, const double* u, const DynParams& dyn, double* xn, hipStream_t st) {
-  if (!use_scalar_dyn()) { launch_step_r(count, x, u, dyn, xn, st); return; }
-  hipLaunchKernelGGL(k_step, dim3(cdiv(count, 64)), dim3(64), 0, st, count, x, u, dyn, xn);
+void launch_step(int count, const double* x, const double* u, const DynParams& dyn, double* xn, hipStream_t st, int stance_l, int stance_r) {
+  if (!use_scalar_dyn() && !dyn.contact) { launch_step_r(count, x, u, dyn, xn, st); return; }
+  hipLaunchKernelGGL(k_step, dim3(cdiv(count, 64)), dim3(64), 0, st, count, x, u, dyn, xn, stance_l, stance_r);
 }
 // phases: 1 = primal dump only, 2 = tangent sweeps / FD only, 3 = both
 void launch_linearize(const DevState& S, const ProblemDev& P, int mode, int jac_mode, double eps, hipStream_t st, int phases) {
-  if (jac_mode == 0) {
+  if (jac_mode == 0 && !P.dyn.contact) {   // contact mode (f4): the stance-constrained step is differentiated by forward differences
     if (phases & 1) launch_lin_primal_r(S, P, mode, st);
     if (phases & 2) hipLaunchKernelGGL(k_lin_tangent, dim3(S.N, S.B), dim3(64), 0, st, S, P, mode);
   } else if (phases & 2) {
@@ -506,7 +508,7 @@ void launch_backward(const DevState& S, int mode, hipStream_t st) {
 }
 void launch_line_search(const DevState& S, const ProblemDev& P, int mode, hipStream_t st) {
   static const int split = use_split("ILQR_LS", LS_SPLIT_DEFAULT);
-  if (!use_scalar_dyn()) { if (split) launch_line_search_s(S, P, mode, st); else launch_line_search_r(S, P, mode, st); return; }
+  if (!use_scalar_dyn() && !P.dyn.contact) { if (split) launch_line_search_s(S, P, mode, st); else launch_line_search_r(S, P, mode, st); return; }
   hipLaunchKernelGGL(k_line_search, dim3(cdiv((long)S.B * 8, 64)), dim3(64), 0, st, S, P, mode);
 }
 void launch_control(const DevState& S, int phase, int iter, double tol, int early_exit, hipStream_t st) {
@@ -514,7 +516,7 @@ void launch_control(const DevState& S, int phase, int iter, double tol, int earl
 }
 void launch_solve_begin(const DevState& S, hipStream_t st) { hipLaunchKernelGGL(k_solve_begin, dim3(cdiv(S.B, 64)), dim3(64), 0, st, S); }
 void launch_warm_shift(const DevState& S, const double* px, const double* pu, hipStream_t st) { hipLaunchKernelGGL(k_warm_shift, dim3(S.B), dim3(64), 0, st, S, px, pu); }
-void launch_last_step(const DevState& S, const ProblemDev& P, hipStream_t st) { if (!use_scalar_dyn()) { launch_last_step_r(S, P, st); return; } hipLaunchKernelGGL(k_last_step, dim3(cdiv(S.B, 64)), dim3(64), 0, st, S, P); }
+void launch_last_step(const DevState& S, const ProblemDev& P, hipStream_t st) { if (!use_scalar_dyn() && !P.dyn.contact) { launch_last_step_r(S, P, st); return; } hipLaunchKernelGGL(k_last_step, dim3(cdiv(S.B, 64)), dim3(64), 0, st, S, P); }
 void launch_compute_control(const DevState& S, const double* x_meas, double* u_out, hipStream_t st) { hipLaunchKernelGGL(k_compute_control, dim3(S.B), dim3(64), 0, st, S, x_meas, u_out); }
 void launch_pack_first_knot(const DevState& S, double* u0, double* K0, hipStream_t st) { hipLaunchKernelGGL(k_pack_first_knot, dim3(S.B), dim3(64), 0, st, S, u0, K0); }
 int backward_needs_lds_attr() {

@@ -61,7 +61,7 @@ struct WaveLds {
     struct {
       double Qd[20 * 52];        // fallback: [Qux | Qu]
       double Kd[20 * 52];        // fallback: [K | k]
-      double Mx[WM * 2 * WM];    // fallback: augmented Gauss-Jordan matrix
+      double Mx[WM * 40];        // fallback: augmented Gauss-Jordan matrix [Quu | I], pitch 40
     };
   };
 };
@@ -220,6 +220,54 @@ __device__ __forceinline__ void fix_A(WaveLds& L, int lane) {
 #pragma unroll
     for (int T = 0; T < 3; ++T) L.Aop[(T * 13 + 12) * 64 + lane] = 0.0;
   }
+}
+
+// Quu^-1 by Gauss-Jordan with partial pivoting (Quu in L.QL, pitch WLDQ), result back into L.QL as an operand buffer
+// (row 19 and column 19 zero).  Lane = (row r = lane % 19, column group q = lane / 19 of 13 columns); rows are not
+// swapped: perm[c] remembers which row became the pivot of column c.  Scratch aliases the A~ staging area.
+__device__ __forceinline__ void gauss_jordan_inverse(WaveLds& L, int lane) {
+  constexpr int m = WM, ld = 40;
+  double* Mx = L.Mx;            // [19][40]: [Quu | I | pad]
+  int* perm = reinterpret_cast<int*>(L.Kd);
+  for (int e = lane; e < m * ld; e += 64) {
+    const int i = e / ld, j = e % ld;
+    Mx[e] = (j < m) ? L.QL[i * WLDQ + j] : ((j - m == i) ? 1.0 : 0.0);
+  }
+  __syncthreads();
+  const int r = lane % m, q = lane / m;
+  unsigned used = 0u;
+  for (int c = 0; c < m; ++c) {
+    double a = (lane < m && !((used >> lane) & 1u)) ? fabs(Mx[lane * ld + c]) : -1.0;
+    int idx = lane;
+#pragma unroll
+    for (int off = 16; off >= 1; off >>= 1) {
+      const int lo = __shfl_xor(__double2loint(a), off), hi = __shfl_xor(__double2hiint(a), off);
+      const double a2 = __hiloint2double(hi, lo);
+      const int i2 = __shfl_xor(idx, off);
+      if (a2 > a || (a2 == a && i2 < idx)) { a = a2; idx = i2; }
+    }
+    const int p = __builtin_amdgcn_readfirstlane(idx);
+    used |= 1u << p;
+    if (lane == 0) perm[c] = p;
+    const double ip = 1.0 / Mx[p * ld + c];
+    const double f = Mx[r * ld + c] * ip;
+    __syncthreads();
+    if (q < 3) {
+#pragma unroll
+      for (int kk = 0; kk < 13; ++kk) {
+        const int k = q * 13 + kk;
+        const double pk = Mx[p * ld + k], own = Mx[r * ld + k];
+        // (all lanes of the wave read before any writes: one instruction stream)
+        Mx[r * ld + k] = (r == p) ? own * ip : own - f * pk;
+      }
+    }
+    __syncthreads();
+  }
+  for (int e = lane; e < 20 * WLDQ; e += 64) {
+    const int c = e / WLDQ, j = e % WLDQ;
+    L.QL[e] = (c < m && j < m) ? Mx[perm[c] * ld + m + j] : 0.0;
+  }
+  __syncthreads();
 }
 
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) k_backward_wave(DevState S, int mode) {
@@ -400,17 +448,27 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
     WSTAMP(6)
     double* Kg = S.K + ((size_t)b * N + t) * m * n;
     double* kg = S.kff + ((size_t)b * N + t) * m;
-    if (!fail) {
-      // ---- every operand of this knot has left the A~ buffer: stage the next knot behind P6a / P6b / P7
+    if (fail) {
+      // ---- indefinite Quu even after the bump: the reference's ldlt() is a pivoted factorisation that still solves the
+      // system; here Quu^-1 explicitly, by Gauss-Jordan with partial pivoting spread over the lanes (lane = row x
+      // one of three column groups; the pivot row is read at wave-uniform LDS addresses).  Quu^-1 then takes the place
+      // of Linv in the buffer and the products below run in their "explicit inverse" form.
+      gauss_jordan_inverse(L, lane);
+    }
+    // ---- every operand of this knot has left the A~ buffer: stage the next knot behind P6 / P7
 #ifndef WAVE_SKIP_STAGE
-      if (t > 0) {
-        asm volatile("" ::: "memory");
-        stage_A(L, Ag - n * n, Bg - n * m, lane);
-        load_b0(b0, Bg - n * m, lk, lr);
-      }
+    if (t > 0) {
+      asm volatile("" ::: "memory");
+      stage_A(L, Ag - n * n, Bg - n * m, lane);
+      load_b0(b0, Bg - n * m, lk, lr);
+    }
 #endif
-      // ---- P6a: Y = Linv Qux~   (k-steps 0..3: qux0, k-step 4: rows 52..55 of Q = Qux[16..18], 0)
+    {
+      // ---- P6a: Y = Linv Qux~ (fallback: Z = Quu^-1 Qux~)   (k-steps 0..3: qux0, k-step 4: rows 52..55 of Q = Qux[16..18], 0)
       v4d y[2][4];
+      double q16[4];
+#pragma unroll
+      for (int J = 0; J < 4; ++J) q16[J] = Q[3][J][1];
 #pragma unroll
       for (int Ia = 0; Ia < 2; ++Ia)
 #pragma unroll
@@ -422,15 +480,15 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
         const double la1 = L.QL[ra1 * WLDQ + 4 * s + lk];
 #pragma unroll
         for (int J = 0; J < 4; ++J) {
-          const double qb = (s < 4) ? qux0[J][s & 3] : Q[3][J][1];
+          const double qb = (s < 4) ? qux0[J][s & 3] : q16[J];
           y[0][J] = wmfma(la0, qb, y[0][J]);
           y[1][J] = wmfma(la1, qb, y[1][J]);
         }
       }
       WSTAMP(7)
-      // ---- P6b: [K | k] = -Linv^T Y, straight to HBM
-      {
-        v4d kk[2][4];
+      // ---- P6b: [K | k] = -Linv^T Y, straight to HBM (fallback: [K | k] = -Z, no second product)
+      v4d kk[2][4];
+      if (!fail) {
 #pragma unroll
         for (int Ia = 0; Ia < 2; ++Ia)
 #pragma unroll
@@ -447,99 +505,54 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
             kk[1][J] = wmfma(lb1, yb, kk[1][J]);
           }
         }
-        // rows 0..15: columns < 48 unconditionally, column tile 3 = K[:, 48..50] and k; rows 16..18: register 0
+      } else {
+#pragma unroll
+        for (int Ia = 0; Ia < 2; ++Ia)
+#pragma unroll
+          for (int J = 0; J < 4; ++J) kk[Ia][J] = y[Ia][J];
+      }
+      // rows 0..15: columns < 48 unconditionally, column tile 3 = K[:, 48..50] and k; rows 16..18: register 0
 #ifdef WAVE_SKIP_KSTORE
-        if (kk[0][0][0] == 123.456)
+      if (kk[0][0][0] == 123.456)
 #endif
-        {
-          double* Kl = Kg + lk * n + lr;
+      {
+        double* Kl = Kg + lk * n + lr;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
+        for (int r = 0; r < 4; ++r) {
 #pragma unroll
-            for (int J = 0; J < 3; ++J) Kl[4 * r * n + 16 * J] = -kk[0][J][r];
-            double* p = (lr < 3) ? (Kl + 4 * r * n + 48) : (kg + 4 * r + lk);
-            if (lr <= 3) *p = -kk[0][3][r];
-          }
-          if (lk < 3) {
+          for (int J = 0; J < 3; ++J) Kl[4 * r * n + 16 * J] = -kk[0][J][r];
+          double* p = (lr < 3) ? (Kl + 4 * r * n + 48) : (kg + 4 * r + lk);
+          if (lr <= 3) *p = -kk[0][3][r];
+        }
+        if (lk < 3) {
 #pragma unroll
-            for (int J = 0; J < 3; ++J) Kl[16 * n + 16 * J] = -kk[1][J][0];
-            double* p = (lr < 3) ? (Kl + 16 * n + 48) : (kg + 16 + lk);
-            if (lr <= 3) *p = -kk[1][3][0];
-          }
+          for (int J = 0; J < 3; ++J) Kl[16 * n + 16 * J] = -kk[1][J][0];
+          double* p = (lr < 3) ? (Kl + 16 * n + 48) : (kg + 16 + lk);
+          if (lr <= 3) *p = -kk[1][3][0];
         }
       }
       WSTAMP(8)
-      // ---- P7: M = Q - Y^T Y, tiles I >= J
+      // ---- P7: M = Q - Y^T Y, tiles I >= J   (fallback: M = Q - Qux~^T Z = Qxx + Qxu K, Vx = Qx + Qxu k: with the
+      // explicit inverse the reference's long form ilqr.cpp:294-307 reduces to this; symmetric because Quu^-1 is)
+      if (!fail) {
 #pragma unroll
-      for (int s = 0; s < 5; ++s)
+        for (int s = 0; s < 5; ++s)
 #pragma unroll
-        for (int I = 0; I < 4; ++I) {
-          const double ya = -y[s >> 2][I][s & 3];
+          for (int I = 0; I < 4; ++I) {
+            const double ya = -y[s >> 2][I][s & 3];
 #pragma unroll
-          for (int J = 0; J <= I; ++J) Q[I][J] = wmfma(ya, y[s >> 2][J][s & 3], Q[I][J]);
-        }
-    } else {
-#ifndef WAVE_NO_FALLBACK
-      // indefinite Quu even after the bump (rare): explicit inverse by Gauss-Jordan with partial pivoting, standing
-      // in for the reference's pivoted LDLT; Vxx = Qxx + sym(Qxu K), Vx = Qx + Qxu k.
-      constexpr int ld = 2 * WM;
-#pragma unroll
-      for (int J = 0; J < 4; ++J) {
-        const int col = 16 * J + lr;
-        if (col < 52) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) L.Qd[(4 * r + lk) * 52 + col] = qux0[J][r];
-          if (lk < 3) L.Qd[(16 + lk) * 52 + col] = Q[3][J][1];
-        }
-      }
-      if (lane == 0) {
-        for (int i = 0; i < m; ++i) for (int j = 0; j < m; ++j) { L.Mx[i * ld + j] = L.QL[i * WLDQ + j]; L.Mx[i * ld + m + j] = (i == j) ? 1.0 : 0.0; }
-        for (int c = 0; c < m; ++c) {
-          int p = c; double best = fabs(L.Mx[c * ld + c]);
-          for (int r = c + 1; r < m; ++r) if (fabs(L.Mx[r * ld + c]) > best) { best = fabs(L.Mx[r * ld + c]); p = r; }
-          if (p != c) for (int k = 0; k < 2 * m; ++k) { const double tmp = L.Mx[c * ld + k]; L.Mx[c * ld + k] = L.Mx[p * ld + k]; L.Mx[p * ld + k] = tmp; }
-          const double ip = 1.0 / L.Mx[c * ld + c];
-          for (int k = 0; k < 2 * m; ++k) L.Mx[c * ld + k] *= ip;
-          for (int r = 0; r < m; ++r) if (r != c) { const double f = L.Mx[r * ld + c]; for (int k = 0; k < 2 * m; ++k) L.Mx[r * ld + k] -= f * L.Mx[c * ld + k]; }
-        }
-      }
-      __syncthreads();
-      for (int e = lane; e < m * 52; e += 64) {
-        const int ar = e / 52, j = e % 52;
-        double s = 0.0;
-#pragma nounroll
-        for (int c = 0; c < m; ++c) s += L.Mx[ar * ld + m + c] * L.Qd[c * 52 + j];
-        L.Kd[ar * 52 + j] = -s;
-        if (j < n) Kg[ar * n + j] = -s; else kg[ar] = -s;
-      }
-      __syncthreads();
-#pragma unroll
-      for (int I = 0; I < 4; ++I)
-#pragma unroll
-        for (int J = 0; J <= I; ++J)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int i = 16 * I + 4 * r + lk, j = 16 * J + lr;
-            if (i < n && j < n) {
-              double s = 0.0;
-#pragma nounroll
-              for (int c = 0; c < m; ++c) s += L.Qd[c * 52 + i] * L.Kd[c * 52 + j] + L.Kd[c * 52 + i] * L.Qd[c * 52 + j];
-              Q[I][J][r] += 0.5 * s;
-            } else if ((i == n && j < n) || (j == n && i < n)) {
-              const int q = (i == n) ? j : i;
-              double s = 0.0;
-#pragma nounroll
-              for (int c = 0; c < m; ++c) s += L.Qd[c * 52 + q] * L.Kd[c * 52 + n];
-              Q[I][J][r] += s;
-            }
+            for (int J = 0; J <= I; ++J) Q[I][J] = wmfma(ya, y[s >> 2][J][s & 3], Q[I][J]);
           }
-      __syncthreads();
-      if (t > 0) {
-        asm volatile("" ::: "memory");
-        stage_A(L, Ag - n * n, Bg - n * m, lane);
-        load_b0(b0, Bg - n * m, lk, lr);
+      } else {
+#pragma unroll
+        for (int s = 0; s < 5; ++s)
+#pragma unroll
+          for (int I = 0; I < 4; ++I) {
+            const double qa = -((s < 4) ? qux0[I][s & 3] : q16[I]);
+#pragma unroll
+            for (int J = 0; J <= I; ++J) Q[I][J] = wmfma(qa, y[s >> 2][J][s & 3], Q[I][J]);
+          }
       }
-#endif
     }
     WSTAMP(9)
     // ---- M <- Q; the strictly upper tiles are the transposes of the lower ones (through LDS: written in C layout,

@@ -34,7 +34,7 @@ EXPORTS = [
     "ilqr_hip_set_trajectory", "ilqr_hip_stage_rollout", "ilqr_hip_stage_linearize", "ilqr_hip_stage_cost_quadratics",
     "ilqr_hip_stage_backward_pass", "ilqr_hip_stage_line_search", "ilqr_hip_stage_total_cost",
     "ilqr_hip_get_linearization", "ilqr_hip_set_linearization", "ilqr_hip_get_quadratics", "ilqr_hip_set_quadratics",
-    "ilqr_hip_get_value_function", "ilqr_hip_step", "ilqr_hip_enable_profiling", "ilqr_hip_get_stage_ms",
+    "ilqr_hip_get_value_function", "ilqr_hip_step", "ilqr_hip_step_stance", "ilqr_hip_set_contact_mode", "ilqr_hip_enable_profiling", "ilqr_hip_get_stage_ms",
     "ilqr_hip_reference_kinematics", "ilqr_hip_reference_com_velocity", "ilqr_hip_foot_clearance", "ilqr_hip_gravity_compensation", "ilqr_hip_stream",
 ]
 
@@ -303,6 +303,17 @@ class BatchedILQR:
         xn = np.zeros_like(x)
         self._chk(self.L.ilqr_hip_step(self.h, int(x.shape[0]), _p(x), _p(u), _p(xn)))
         return xn
+
+    def step_stance(self, x, u, stance_left, stance_right):
+        """One step with explicit stance flags (they matter in contact mode only)."""
+        x, u = _c64(x), _c64(u)
+        xn = np.zeros_like(x)
+        self._chk(self.L.ilqr_hip_step_stance(self.h, int(x.shape[0]), _p(x), _p(u), int(stance_left), int(stance_right), _p(xn)))
+        return xn
+
+    def set_contact_mode(self, mode, softness=0.0):
+        """0: constraint-free step; 1: rigid stance constraints on the feet the contact schedule marks."""
+        self._chk(self.L.ilqr_hip_set_contact_mode(self.h, int(mode), C.c_double(softness)))
 
     def enable_profiling(self, on=True):
         self._chk(self.L.ilqr_hip_enable_profiling(self.h, int(bool(on))))

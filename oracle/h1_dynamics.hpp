@@ -27,6 +27,8 @@ using std::sqrt;
 struct DynParams {
   double h;     // timestep
   double g[3];  // world gravity vector
+  int contact = 0;       // 0: constraint-free step; 1: rigid stance constraints on the scheduled feet
+  double soft = 1e-5;    // diagonal softness of the stance constraint (1 / kg), keeps J Minv J^T invertible with straight knees
 };
 
 // ---------- small dense helpers (row-major) ----------
@@ -232,6 +234,157 @@ inline void inverse_dynamics_mj(const T* quat_hat, const T* theta, const T* v, c
   for (int k = 0; k < 3; ++k) tau[3 + k] = f[0][k];
 }
 
+
+// ---------- forward dynamics with schedule-driven rigid stance constraints ----------
+// The reference's plant is MuJoCo with soft floor contacts (robot_utils.cpp:106-117 -> mj_step); MuJoCo is not
+// available here, so the contact row is restated as the limit the reference's standing / walking scenarios operate in:
+// a foot the contact schedule marks as stance (RobotUtils::isStance, robot_utils.cpp:494-504) does not move.  The
+// constraint is imposed at velocity level over one step, consistently with the semi-implicit Euler integrator:
+//     v_f + h a_f = 0        (v_f, a_f: spatial velocity / acceleration of the ankle link, link coordinates)
+// with a_f = a_f,free + C lambda, C = J Mhat^-1 J^T (Mhat = M + armature + h D), lambda = constraint wrench on the link.
+// C is built column by column by propagating unit wrenches through the articulated-body quantities of the free
+// solve (inward along the leg, pelvis solve, outward), i.e. without forming M or J; (C + soft I) lambda = rhs is solved
+// by Cholesky and the wrench is propagated once more for the joint accelerations.  Bilateral on purpose (a scheduled
+// stance foot sticks): unilateral / friction-cone effects are outside this row.
+template <class T> inline bool chol_solve_inplace(T* A, T* b, int n) {  // A (n x n, row-major, SPD) b -> x; false if not PD
+  for (int j = 0; j < n; ++j) {
+    T d = A[j * n + j];
+    for (int k = 0; k < j; ++k) d -= A[j * n + k] * A[j * n + k];
+    if (!(val(d) > 0.0)) return false;
+    d = sqrt(d);
+    A[j * n + j] = d;
+    for (int i = j + 1; i < n; ++i) {
+      T s = A[i * n + j];
+      for (int k = 0; k < j; ++k) s -= A[i * n + k] * A[j * n + k];
+      A[i * n + j] = s / d;
+    }
+  }
+  for (int i = 0; i < n; ++i) { T s = b[i]; for (int k = 0; k < i; ++k) s -= A[i * n + k] * b[k]; b[i] = s / A[i * n + i]; }
+  for (int i = n - 1; i >= 0; --i) { T s = b[i]; for (int k = i + 1; k < n; ++k) s -= A[k * n + i] * b[k]; b[i] = s / A[i * n + i]; }
+  return true;
+}
+constexpr int H1_FOOT_BODY[2] = {5, 10};   // left / right ankle link (leaf of each leg chain)
+
+template <class T>
+inline void forward_dynamics_mj_stance(const T* quat_hat, const T* theta, const T* v, const T* tau, double arm_eff,
+                                       const double* grav, double h, double soft, const int* stance, T* qacc) {
+  double Isp[H1_NB][36];
+  for (int i = 0; i < H1_NB; ++i) spatial_inertia(H1_MASS[i], H1_COM[i], H1_INERTIA[i], Isp[i]);
+  T R0[9]; quat_wxyz_to_R(quat_hat[0], quat_hat[1], quat_hat[2], quat_hat[3], R0);
+  T Rj[H1_NB][9], vel[H1_NB][6], cb[H1_NB][6], IA[H1_NB][36], pA[H1_NB][6];
+  for (int k = 0; k < 3; ++k) vel[0][k] = v[3 + k];
+  mat3T_vec(R0, v, vel[0] + 3);
+  for (int k = 0; k < 6; ++k) cb[0][k] = T(0.0);
+  for (int i = 0; i < H1_NB; ++i) {
+    if (i > 0) {
+      joint_rot(i, theta[i - 1], H1_RFIX, Rj[i]);
+      xf_motion(Rj[i], H1_POS[i], vel[H1_PARENT[i]], vel[i]);
+      T vJ[6]; for (int k = 0; k < 6; ++k) vJ[k] = T(0.0);
+      vJ[H1_AXIS[i]] = v[6 + i - 1];
+      vel[i][H1_AXIS[i]] += v[6 + i - 1];
+      crm(vel[i], vJ, cb[i]);
+    }
+    for (int k = 0; k < 36; ++k) IA[i][k] = T(Isp[i][k]);
+    T Iv[6]; mat6_vec(Isp[i], vel[i], Iv);
+    crf(vel[i], Iv, pA[i]);
+  }
+  T U[H1_NB][6], D[H1_NB], uu[H1_NB];
+  for (int i = H1_NB - 1; i >= 1; --i) {
+    const int a = H1_AXIS[i];
+    for (int k = 0; k < 6; ++k) U[i][k] = IA[i][6 * k + a];
+    D[i] = U[i][a] + arm_eff;
+    uu[i] = tau[i - 1] - pA[i][a];
+    T Ia[36], pa[6];
+    for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c) Ia[6 * r + c] = IA[i][6 * r + c] - U[i][r] * U[i][c] / D[i];
+    T Iac[6]; mat6_vec(Ia, cb[i], Iac);
+    for (int k = 0; k < 6; ++k) pa[k] = pA[i][k] + Iac[k] + U[i][k] * (uu[i] / D[i]);
+    T X[36]; plucker(Rj[i], H1_POS[i], X);
+    T tmp[36];
+    for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c) { T s = Ia[6 * r] * X[c]; for (int k = 1; k < 6; ++k) s += Ia[6 * r + k] * X[6 * k + c]; tmp[6 * r + c] = s; }
+    const int p = H1_PARENT[i];
+    for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c) { T s = X[r] * tmp[c]; for (int k = 1; k < 6; ++k) s += X[6 * k + r] * tmp[6 * k + c]; IA[p][6 * r + c] += s; }
+    xf_force_acc(Rj[i], H1_POS[i], pa, pA[p]);
+  }
+  T a0p[6]; for (int k = 0; k < 3; ++k) a0p[k] = T(0.0);
+  T mg[3] = {T(-grav[0]), T(-grav[1]), T(-grav[2])};
+  mat3T_vec(R0, mg, a0p + 3);
+  T acc[H1_NB][6];
+  T rhs0[6]; for (int k = 0; k < 6; ++k) rhs0[k] = -pA[0][k];
+  solve6_spd(IA[0], rhs0, acc[0]);
+  T qdd[H1_NB];
+  for (int i = 1; i < H1_NB; ++i) {
+    const int a = H1_AXIS[i];
+    T ap[6]; xf_motion(Rj[i], H1_POS[i], acc[H1_PARENT[i]], ap);
+    for (int k = 0; k < 6; ++k) ap[k] += cb[i][k];
+    T s = uu[i]; for (int k = 0; k < 6; ++k) s -= U[i][k] * ap[k];
+    qdd[i] = s / D[i];
+    for (int k = 0; k < 6; ++k) acc[i][k] = ap[k];
+    acc[i][a] += qdd[i];
+  }
+  // ---- stance constraints
+  int nf = 0, fb[2];
+  for (int f = 0; f < 2; ++f) if (stance[f] == 1) fb[nf++] = H1_FOOT_BODY[f];
+  T da0[6]; for (int k = 0; k < 6; ++k) da0[k] = T(0.0);
+  if (nf > 0) {
+    const int nc = 6 * nf;
+    // response to wrenches fext[g] (link coordinates, acting on stance foot g): accelerations of the stance feet,
+    // and (full = true) of the pelvis and every hinge
+    auto respond = [&](const T (*fext)[6], T (*da_feet)[6], bool full, T* dqdd, T* dbase) {
+      T dpA[H1_NB][6], du[H1_NB], da[H1_NB][6];
+      for (int i = 0; i < H1_NB; ++i) { du[i] = T(0.0); for (int k = 0; k < 6; ++k) dpA[i][k] = T(0.0); }
+      for (int g = 0; g < nf; ++g) for (int k = 0; k < 6; ++k) dpA[fb[g]][k] -= fext[g][k];
+      for (int i = 10; i >= 1; --i) {                       // the two leg chains
+        const int a = H1_AXIS[i];
+        du[i] = -dpA[i][a];
+        T dpa[6]; for (int k = 0; k < 6; ++k) dpa[k] = dpA[i][k] + U[i][k] * (du[i] / D[i]);
+        xf_force_acc(Rj[i], H1_POS[i], dpa, dpA[H1_PARENT[i]]);
+      }
+      T r6[6]; for (int k = 0; k < 6; ++k) r6[k] = -dpA[0][k];
+      solve6_spd(IA[0], r6, da[0]);
+      const int last = full ? H1_NB - 1 : 10;
+      for (int i = 1; i <= last; ++i) {
+        const int a = H1_AXIS[i];
+        T ap[6]; xf_motion(Rj[i], H1_POS[i], da[H1_PARENT[i]], ap);
+        T s = du[i]; for (int k = 0; k < 6; ++k) s -= U[i][k] * ap[k];
+        const T q = s / D[i];
+        for (int k = 0; k < 6; ++k) da[i][k] = ap[k];
+        da[i][a] += q;
+        if (full) dqdd[i] = q;
+      }
+      for (int g = 0; g < nf; ++g) for (int k = 0; k < 6; ++k) da_feet[g][k] = da[fb[g]][k];
+      if (full) for (int k = 0; k < 6; ++k) dbase[k] = da[0][k];
+    };
+    T C[144], b[12];
+    for (int g = 0; g < nf; ++g)
+      for (int c = 0; c < 6; ++c) {
+        T fext[2][6], daf[2][6];
+        for (int g2 = 0; g2 < 2; ++g2) for (int k = 0; k < 6; ++k) fext[g2][k] = T(0.0);
+        fext[g][c] = T(1.0);
+        respond(fext, daf, false, nullptr, nullptr);
+        for (int g2 = 0; g2 < nf; ++g2) for (int k = 0; k < 6; ++k) C[(6 * g2 + k) * nc + 6 * g + c] = daf[g2][k];
+      }
+    for (int i = 0; i < nc; ++i) C[i * nc + i] += soft;
+    // true (not gravity-offset) spatial acceleration of a leg body: acc_i - X_{i<-0} (0, R0^T(-g))
+    for (int g = 0; g < nf; ++g) {
+      T off[6]; for (int k = 0; k < 6; ++k) off[k] = a0p[k];
+      const int first = fb[g] - 4;
+      for (int i = first; i <= fb[g]; ++i) { T o2[6]; xf_motion(Rj[i], H1_POS[i], off, o2); for (int k = 0; k < 6; ++k) off[k] = o2[k]; }
+      for (int k = 0; k < 6; ++k) b[6 * g + k] = -vel[fb[g]][k] / h - (acc[fb[g]][k] - off[k]);
+    }
+    chol_solve_inplace(C, b, nc);
+    T fext[2][6], daf[2][6], dq[H1_NB];
+    for (int g = 0; g < 2; ++g) for (int k = 0; k < 6; ++k) fext[g][k] = g < nf ? b[6 * g + k] : T(0.0);
+    respond(fext, daf, true, dq, da0);
+    for (int i = 1; i < H1_NB; ++i) qdd[i] += dq[i];
+  }
+  for (int i = 1; i < H1_NB; ++i) qacc[6 + i - 1] = qdd[i];
+  T nudot[6]; for (int k = 0; k < 6; ++k) nudot[k] = acc[0][k] - a0p[k] + da0[k];
+  T wxv[3]; cross3(vel[0], vel[0] + 3, wxv);
+  T lin[3] = {nudot[3] + wxv[0], nudot[4] + wxv[1], nudot[5] + wxv[2]};
+  mat3_vec(R0, lin, qacc);
+  for (int k = 0; k < 3; ++k) qacc[3 + k] = nudot[k];
+}
+
 // smooth cos(a/2), sin(a/2)/a as functions of s = a^2 (AD-safe at a = 0)
 template <class T> inline void half_angle_cs(const T& s, T& c, T& sn_over_a) {
   if (val(s) < 1e-6) {
@@ -243,8 +396,9 @@ template <class T> inline void half_angle_cs(const T& s, T& c, T& sn_over_a) {
 }
 
 // One dynamics step x_next = f(x, u): restates rolloutOneStep (robot_utils.cpp:106-117).
+// `stance` (two flags, left / right, of the knot being stepped) is used when P.contact != 0.
 template <class T>
-inline void h1_step(const T* x, const T* u, const DynParams& P, T* xn) {
+inline void h1_step(const T* x, const T* u, const DynParams& P, T* xn, const int* stance = nullptr) {
   const double h = P.h;
   T qn = sqrt(x[3] * x[3] + x[4] * x[4] + x[5] * x[5] + x[6] * x[6]);
   T qh[4] = {x[3] / qn, x[4] / qn, x[5] / qn, x[6] / qn};
@@ -256,7 +410,8 @@ inline void h1_step(const T* x, const T* u, const DynParams& P, T* xn) {
     tau[i] = ui - H1_DAMPING * x[H1_NQ + 6 + i];
   }
   T qacc[H1_NV];
-  forward_dynamics_mj(qh, x + 7, x + H1_NQ, tau, H1_ARMATURE + h * H1_DAMPING, P.g, qacc);
+  if (P.contact && stance) forward_dynamics_mj_stance(qh, x + 7, x + H1_NQ, tau, H1_ARMATURE + h * H1_DAMPING, P.g, h, P.soft, stance, qacc);
+  else forward_dynamics_mj(qh, x + 7, x + H1_NQ, tau, H1_ARMATURE + h * H1_DAMPING, P.g, qacc);
   T vn[H1_NV];
   for (int i = 0; i < H1_NV; ++i) { vn[i] = x[H1_NQ + i] + h * qacc[i]; xn[H1_NQ + i] = vn[i]; }
   for (int k = 0; k < 3; ++k) xn[k] = x[k] + h * vn[k];

@@ -65,35 +65,36 @@ struct Solver {
     Vx_last.assign(H1_NX, 0.0); Vxx_last.assign(H1_NX * H1_NX, 0.0);
   }
 
-  void step(const double* x, const double* u, double* xn) const { h1_step<double>(x, u, P.dyn, xn); }
+  // t = horizon-local knot index of the state being stepped: selects the stance flags in contact mode (f4)
+  void step(const double* x, const double* u, double* xn, int t) const { h1_step<double>(x, u, P.dyn, xn, &P.stance[2 * t]); }
 
-  void rollout_nominal() { for (int t = 0; t < N; ++t) step(&xbar[t * H1_NX], &ubar[t * H1_NU], &xbar[(t + 1) * H1_NX]); }
+  void rollout_nominal() { for (int t = 0; t < N; ++t) step(&xbar[t * H1_NX], &ubar[t * H1_NU], &xbar[(t + 1) * H1_NX], t); }
 
-  void linearize_knot(const double* x, const double* u, double* At, double* Bt) const {
+  void linearize_knot(int t, const double* x, const double* u, double* At, double* Bt) const {
     if (jac_mode == JAC_ANALYTIC) {
       typedef D1<H1_NX + H1_NU> T;
       std::vector<T> xs(H1_NX), us(H1_NU), xn(H1_NX);
       for (int i = 0; i < H1_NX; ++i) xs[i] = T::var(x[i], i);
       for (int i = 0; i < H1_NU; ++i) us[i] = T::var(u[i], H1_NX + i);
-      h1_step<T>(xs.data(), us.data(), P.dyn, xn.data());
+      h1_step<T>(xs.data(), us.data(), P.dyn, xn.data(), &P.stance[2 * t]);
       for (int i = 0; i < H1_NX; ++i) {
         for (int j = 0; j < H1_NX; ++j) At[i * H1_NX + j] = xn[i].g[j];
         for (int j = 0; j < H1_NU; ++j) Bt[i * H1_NU + j] = xn[i].g[H1_NX + j];
       }
     } else {  // robot_utils.cpp:120-160 verbatim: forward differences on raw coordinates
       double base[H1_NX], pert[H1_NX], xp[H1_NX], up[H1_NU];
-      step(x, u, base);
+      step(x, u, base, t);
       for (int j = 0; j < H1_NX; ++j) {
-        std::memcpy(xp, x, sizeof(xp)); xp[j] += fd_eps; step(xp, u, pert);
+        std::memcpy(xp, x, sizeof(xp)); xp[j] += fd_eps; step(xp, u, pert, t);
         for (int i = 0; i < H1_NX; ++i) At[i * H1_NX + j] = (pert[i] - base[i]) / fd_eps;
       }
       for (int j = 0; j < H1_NU; ++j) {
-        std::memcpy(up, u, sizeof(up)); up[j] += fd_eps; step(x, up, pert);
+        std::memcpy(up, u, sizeof(up)); up[j] += fd_eps; step(x, up, pert, t);
         for (int i = 0; i < H1_NX; ++i) Bt[i * H1_NU + j] = (pert[i] - base[i]) / fd_eps;
       }
     }
   }
-  void linearize() { for (int t = 0; t < N; ++t) linearize_knot(&xbar[t * H1_NX], &ubar[t * H1_NU], &A[t * H1_NX * H1_NX], &B[t * H1_NX * H1_NU]); }
+  void linearize() { for (int t = 0; t < N; ++t) linearize_knot(t, &xbar[t * H1_NX], &ubar[t * H1_NU], &A[t * H1_NX * H1_NX], &B[t * H1_NX * H1_NU]); }
 
   void cost_quadratics() {
     for (int t = 0; t <= N; ++t)
@@ -190,7 +191,7 @@ struct Solver {
           double s = 0; for (int j = 0; j < n; ++j) s += K[(t * m + i) * n + j] * (xn[t * n + j] - xbar[t * n + j]);
           un[t * m + i] = ubar[t * m + i] + alpha * kff[t * m + i] + s;
         }
-        step(&xn[t * n], &un[t * m], &xn[(t + 1) * n]);
+        step(&xn[t * n], &un[t * m], &xn[(t + 1) * n], t);
       }
       const double c = total_cost_of(xn.data(), un.data());
       if (c < baseline - 1e-6) { xbar = xn; ubar = un; new_cost = c; alpha_out = alpha; return true; }
@@ -255,7 +256,7 @@ struct Solver {
       for (int t = 0; t < N - 1; ++t) std::memcpy(&ubar[t * m], &prev_ubar[(t + 1) * m], m * sizeof(double));
       std::memcpy(&ubar[(N - 1) * m], &prev_ubar[(N - 1) * m], m * sizeof(double));
       for (int t = 0; t < N - 1; ++t) std::memcpy(&xbar[(t + 1) * n], &prev_xbar[(t + 2) * n], n * sizeof(double));
-      step(&xbar[(N - 1) * n], &ubar[(N - 1) * m], &xbar[N * n]);
+      step(&xbar[(N - 1) * n], &ubar[(N - 1) * m], &xbar[N * n], N - 1);
     } else {
       if (u_init) std::memcpy(&ubar[0], u_init, N * m * sizeof(double));
       else { double ug[H1_NU]; grav_comp(x0, ug); for (int t = 0; t < N; ++t) std::memcpy(&ubar[t * m], ug, m * sizeof(double)); }
@@ -301,7 +302,10 @@ void orc_set_trajectory(void* s, const double* xbar, const double* ubar) { Solve
 int orc_solve(void* s, const double* x0, double* cost_out) { double c = 0; bool ok = ((Solver*)s)->solve(x0, c); *cost_out = c; return ok ? 0 : 1; }
 
 // stage entry points (parity per kernel)
-void orc_step(void* s, const double* x, const double* u, double* xn) { ((Solver*)s)->step(x, u, xn); }
+void orc_step(void* s, const double* x, const double* u, double* xn) { Solver* S = (Solver*)s; orc::h1_step<double>(x, u, S->P.dyn, xn, nullptr); }
+// one step with explicit stance flags (left, right) -- contact mode only uses them when set_contact_mode(1)
+void orc_step_stance(void* s, const double* x, const double* u, const int* stance, double* xn) { Solver* S = (Solver*)s; orc::h1_step<double>(x, u, S->P.dyn, xn, stance); }
+void orc_set_contact_mode(void* s, int mode, double soft) { Solver* S = (Solver*)s; S->P.dyn.contact = mode; if (soft > 0.0) S->P.dyn.soft = soft; }
 void orc_rollout(void* s) { ((Solver*)s)->rollout_nominal(); }
 void orc_linearize(void* s) { ((Solver*)s)->linearize(); }
 void orc_cost_quadratics(void* s) { ((Solver*)s)->cost_quadratics(); }

@@ -81,6 +81,17 @@ class Oracle:
         self.L.orc_set_options(self.h, C.c_double(lam), int(max_iter), C.c_double(tol), int(jac_mode), C.c_double(fd_eps), int(quad_mode), int(early_exit))
         self.max_iter = max_iter
 
+    def set_contact_mode(self, mode, soft=0.0):
+        """0: constraint-free step; 1: rigid stance constraints on the feet the contact schedule marks."""
+        self.L.orc_set_contact_mode(self.h, int(mode), C.c_double(soft))
+
+    def step_stance(self, x, u, stance):
+        x, u = c64(x), c64(u)
+        st = np.ascontiguousarray(stance, dtype=np.int32)
+        xn = np.zeros(NX)
+        self.L.orc_step_stance(self.h, _p(x), _p(u), st.ctypes.data_as(_ip), _p(xn))
+        return xn
+
     def get_lambda(self):
         return self.L.orc_get_lambda(self.h)
 

@@ -245,6 +245,41 @@ def test_fixed_iteration_mode_and_fd_mode_parity():
     s.close()
 
 
+def test_contact_mode_step_and_solve_match_oracle():
+    """rigid stance constraints on the scheduled feet.  (i) the stance-constrained step on the GPU equals
+    the oracle's for every stance pattern; (ii) a full solve in contact mode (scalar kernels, forward-difference
+    Jacobians as the reference takes them) reproduces the oracle's cost trace, accepted step sizes and gains on a
+    schedule with swing phases, under physical gravity (the feet carry the robot)."""
+    B = 3
+    prob, x0, ui = make(B, seed=8, gravity=[0.0, 0.0, -9.81], walking=True)
+    s = _solver(B); s.set_problem(prob); s.set_contact_mode(1)
+    o = oracle_for(prob); o.set_contact_mode(1)
+    rng = np.random.default_rng(5)
+    xs = x0.copy(); xs[:, 26:] += rng.uniform(-0.2, 0.2, (B, 25)); xs[:, 7 + 3] += 0.3; xs[:, 7 + 8] += 0.3
+    us = ui[:, 0, :]
+    free = s.step_stance(xs, us, 0, 0)
+    for sl, sr in ((1, 1), (1, 0), (0, 1), (0, 0)):
+        got = s.step_stance(xs, us, sl, sr)
+        for b in range(B):
+            want = o.step_stance(xs[b], us[b], [sl, sr])
+            assert np.abs(got[b] - want).max() < 1e-9 * max(1.0, np.abs(want).max()), (sl, sr, b, np.abs(got[b] - want).max())
+        if sl or sr:
+            assert np.abs(got - free).max() > 1e-3
+    s.set_options(jacobian_mode=1, fd_eps=1e-5, early_exit=False); s.set_max_iterations(3)
+    s.initialize(x0, ui)
+    cost = s.solve(x0)
+    tc, ta, tl = s.trace()
+    for b in range(B):
+        ob = oracle_for(prob, jac_mode=1, fd_eps=1e-5, early_exit=0, max_iter=3); ob.set_contact_mode(1)
+        ob.initialize(x0[b], ui[b]); ok, c = ob.solve(x0[b])
+        n, oc, oa, ol_ = ob.trace()
+        assert n == 3 and np.allclose(tc[b], oc, rtol=1e-5) and np.array_equal(ta[b], oa), (tc[b], oc, ta[b], oa)
+        assert abs(cost[b] - c) <= 1e-5 * abs(c)
+        assert rel(s.gains_K()[b], ob.get("K")) < 1e-4
+        assert rel(s.xbar()[b], ob.get("xbar")) < 1e-5
+    s.close()
+
+
 def test_warm_start_mpc_step_and_control_law():
     from mpc_ilqr_mujoco_amd import solver as sv
     B = 2

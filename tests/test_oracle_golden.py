@@ -261,3 +261,55 @@ def test_solve_control_flow_and_trace():
     o.solve(xb[1])
     xm = o.get("xbar")[0] + 1e-3
     assert np.allclose(o.compute_control(xm), o.get("ubar")[0] + o.get("K")[0] @ (xm - o.get("xbar")[0]))
+
+
+def test_stance_constrained_step_identities():
+    """Contact row: rigid stance constraints on the scheduled feet.  No reference fixture exists (the
+    reference's contacts live inside MuJoCo), so the restatement is pinned by what defines it: (i) no stance flag ->
+    the constraint-free step bit for bit; (ii) a stance foot does not move over the step (velocity-level constraint:
+    its origin travels O(h^2), orders of magnitude less than unconstrained); (iii) the constraint acts through the
+    stance legs only: M_hat (qacc_c - qacc_free) has no component on the pelvis-fixed torso / arm hinges beyond what the
+    leg wrenches transmit, i.e. it is zero on every hinge outside the stance legs; (iv) left / right symmetry of which
+    leg carries it."""
+    pkg = load_package()
+    sc = pkg.scenario
+    g = np.array([0.0, 0.0, -9.81])
+    prob = sc.make_problem(ol.reference_kinematics, N=5, gravity=list(g))
+    o = ol.Oracle(5, prob["dt"]); o.set_problem(prob)
+    h = prob["dt"]
+    rng = np.random.default_rng(3)
+    x = sc.standing_state()
+    x[7:26] += rng.uniform(-0.1, 0.1, 19); x[7 + 3] += 0.4; x[7 + 8] += 0.4     # bent knees
+    x[3:7] = np.array([0.995, 0.05, -0.06, 0.03]); x[3:7] /= np.linalg.norm(x[3:7])
+    x[26:] = rng.uniform(-0.3, 0.3, 25)
+    u = rng.uniform(-20, 20, 19)
+    free = o.step(x, u)
+    o.set_contact_mode(1)
+    assert np.array_equal(o.step_stance(x, u, [0, 0]), free)
+    arm_eff = 0.1 + h * 1.0        # h1.xml: armature 0.1, damping 1 (implicit in the step)
+    ee0 = ol.reference_kinematics(x)[1]
+    move_free = np.linalg.norm(ol.reference_kinematics(free)[1] - ee0, axis=1)
+    qacc_free = (free[26:] - x[26:]) / h
+    leg = {0: list(range(6, 11)), 1: list(range(11, 16))}      # qvel indices of the left / right leg hinges
+    for st in ([1, 1], [1, 0], [0, 1]):
+        xn = o.step_stance(x, u, st)
+        move = np.linalg.norm(ol.reference_kinematics(xn)[1] - ee0, axis=1)
+        for f in range(2):
+            if st[f]:
+                assert move[f] < 5e-4 and move[f] < 0.1 * move_free[f], (st, f, move, move_free)
+        qacc_c = (xn[26:] - x[26:]) / h
+        dtau = ol.inverse_dynamics(x, qacc_c, arm_eff, g) - ol.inverse_dynamics(x, qacc_free, arm_eff, g)
+        carried = sorted(i for f in range(2) if st[f] for i in leg[f])
+        others = [i for i in range(6, 25) if i not in carried]
+        assert np.abs(dtau[others]).max() < 1e-7 * max(1.0, np.abs(dtau).max()), (st, dtau)
+        assert np.abs(dtau[carried]).max() > 1.0
+    # the step stays differentiable: forward-mode AD Jacobians of the constrained step agree with central differences
+    o2 = ol.Oracle(5, h); o2.set_problem(prob); o2.set_contact_mode(1)
+    xb = np.tile(x, (6, 1)); ub = np.tile(u, (5, 1))
+    o2.set_trajectory(xb, ub); o2.linearize()
+    A = o2.get("A")[0]
+    eps = 1e-6
+    for j in (2, 10, 30, 45):
+        xp, xm = x.copy(), x.copy(); xp[j] += eps; xm[j] -= eps
+        col = (o2.step_stance(xp, u, [1, 1]) - o2.step_stance(xm, u, [1, 1])) / (2 * eps)
+        assert np.abs(A[:, j] - col).max() < 1e-5 * max(1.0, np.abs(col).max()), (j, np.abs(A[:, j] - col).max())

@@ -16,7 +16,11 @@ ug = sv.gravity_compensation(sc.standing_state(), prob["gravity"])
 x0, ui = sc.synthetic_batch(B, N, 0, ug)
 s = sv.BatchedILQR(B, N=N)
 s.set_problem(prob)
+if os.environ.get("ILQR_LAMBDA"):
+    s.set_regularization(float(os.environ["ILQR_LAMBDA"]))
 s.initialize(x0, ui)
+if os.environ.get("ILQR_BENIGN"):   # every knot = the standing state with gravity-compensation controls
+    s.set_trajectory(np.tile(sc.standing_state(), (B, N + 1, 1)), np.tile(ug, (B, N, 1)))
 s.stage_linearize(); s.stage_cost_quadratics(); s.stage_backward_pass()
 fn = {"backward": s.stage_backward_pass, "linearize": s.stage_linearize, "quadratics": s.stage_cost_quadratics,
       "rollout": s.stage_rollout, "line_search": s.stage_line_search}[stage]
