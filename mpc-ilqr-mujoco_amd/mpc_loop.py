@@ -3,7 +3,8 @@
 Mirrors (host side; the solve itself is the HIP library):
   * runSimulation / MPC::stepOnce       /root/reference/main/humanoid_mpc.cpp:126-190, src/ilqr/mpc.cpp:40-127
       per step: reference window -> warm start (shifted previous solution) -> solve -> u = ubar0 + K0 (x - xbar0)
-      -> plant step.  The plant here is the same constraint-free dynamics as the model (`BatchedILQR.step`); the
+      -> plant step.  The plant here is the same dynamics as the model (`BatchedILQR.step`, or `step_stance` with the
+      stance flags of the current schedule row when the solver is in contact mode); the
       reference steps MuJoCo with contacts and clobbers its plant state while solving
        -- neither is reproduced.
   * MPC::initCSVLog / logCurrentStep    src/ilqr/mpc.cpp:181-262   main log, one row per step
@@ -64,6 +65,7 @@ class MPCRunner:
         t0 = time.perf_counter()
         prob = self.refs.problem_at(self.t_idx, self.s.N, self.base, follow_schedule=self.follow_schedule)   # extractReferenceWindow
         self.s.set_problem(prob)
+        self.last_stance0 = prob["stance"][0, 0]
         if self.has_prev:
             self.s.initialize_warm_resident(x_measured)       # ilqr.cpp:68-80
         else:
@@ -85,7 +87,11 @@ class MPCRunner:
         xs, us = [x.copy()], []
         for _ in range(steps):
             u = self.step_once(x, u_init)
-            x = self.s.step(x, u)
+            if getattr(self.s, "contact_mode", 0):    # contact row: the plant holds the feet in stance now
+                st = np.asarray(self.last_stance0).reshape(-1)
+                x = self.s.step_stance(x, u, int(st[0]), int(st[1]))
+            else:
+                x = self.s.step(x, u)
             xs.append(x.copy()); us.append(u.copy())
         return np.array(xs), np.array(us)
 

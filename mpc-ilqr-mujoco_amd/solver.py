@@ -314,6 +314,7 @@ class BatchedILQR:
     def set_contact_mode(self, mode, softness=0.0):
         """0: constraint-free step; 1: rigid stance constraints on the feet the contact schedule marks."""
         self._chk(self.L.ilqr_hip_set_contact_mode(self.h, int(mode), C.c_double(softness)))
+        self.contact_mode = int(mode)
 
     def enable_profiling(self, on=True):
         self._chk(self.L.ilqr_hip_enable_profiling(self.h, int(bool(on))))

@@ -418,6 +418,32 @@ def test_closed_loop_runner_with_logs(tmp_path):
     s.close()
 
 
+def test_closed_loop_standing_under_physical_gravity_needs_the_contact_row(tmp_path):
+    """with the constraint-free plant a robot under -9.81 gravity is in free fall (the balance term turns
+    NaN within the horizon); with the scheduled feet held in stance the same closed loop stands."""
+    from mpc_ilqr_mujoco_amd import mpc_loop as ml
+    from mpc_ilqr_mujoco_amd import references as rf
+    from mpc_ilqr_mujoco_amd import solver as sv
+    B, N = 2, 25
+    base = sc.make_problem(sv.reference_kinematics, N=N, gravity=(0.0, 0.0, -9.81))
+    rd = rf.ReferenceData(sv.reference_kinematics, sv.reference_com_velocity)
+    rd.set_states(np.tile(sc.standing_state(), (60, 1))); rd.contact = np.ones((60, 2), dtype=np.int32)
+    ug = sv.gravity_compensation(sc.standing_state(), base["gravity"])
+    x0, ui = sc.synthetic_batch(B, N, 0, ug)
+    s = _solver(B); s.set_max_iterations(3); s.set_contact_mode(1)
+    run = ml.MPCRunner(s, rd, base)
+    xs, us = run.run(x0, 8, u_init=ui)
+    assert np.all(np.isfinite(xs)) and np.all(np.isfinite(us))
+    assert xs[:, :, 2].min() > 0.97 and np.abs(xs[-1, :, 26:]).max() < 5.0      # pelvis height kept, no runaway velocity
+    com0, ee0 = sv.reference_kinematics(xs[0, 0]); com8, ee8 = sv.reference_kinematics(xs[-1, 0])
+    assert np.abs(ee8 - ee0).max() < 5e-3                                        # the stance feet stayed where they were
+    s.close()
+    s = _solver(B); s.set_max_iterations(3)
+    free = ml.MPCRunner(s, rd, base).run(x0, 8, u_init=ui)[0]
+    assert (not np.all(np.isfinite(free))) or free[-1, :, 2].max() < xs[-1, :, 2].min() - 0.1
+    s.close()
+
+
 def test_per_rollout_reference_sets():
     B, N = 3, 25
     prob, x0, ui = make(B, seed=8)
