@@ -21,7 +21,9 @@ struct ilqr_hip_ctx {
   int device = 0, B = 0, N = 0;
   hipStream_t stream = nullptr;
   hipStream_t stream2 = nullptr;          // cost quadratics run here, concurrently with the linearisation
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  hipStream_t stream3 = nullptr;          // nominal re-rollout of iterations >= 1, concurrently with both
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_roll = nullptr;
+  double* d_shadowx = nullptr;            // [B][N+1][51] target of the concurrent re-rollout
   DevState S{};
   h1::ProblemDev P{};
   // reference sets on the device
@@ -47,7 +49,7 @@ struct ilqr_hip_ctx {
   // batch slices: the solve of each contiguous slice of the batch is enqueued on its own pair of streams, so that the
   // latency-bound stages of one slice (line search: 8 waves per 64 rollouts, nominal rollout) overlap with the
   // throughput-bound stages of the others (ILQR_SLICES, default SLICES_DEFAULT; 1 = whole batch on one stream pair)
-  struct Slice { hipStream_t st = nullptr, st2 = nullptr; hipEvent_t fork = nullptr, join = nullptr, done = nullptr, lead = nullptr; };
+  struct Slice { hipStream_t st = nullptr, st2 = nullptr, st3 = nullptr; hipEvent_t fork = nullptr, join = nullptr, done = nullptr, lead = nullptr, roll = nullptr; };
   std::vector<Slice> slices;
   hipEvent_t ev_begin = nullptr;
   int n_slices = 1;
@@ -88,7 +90,7 @@ int ilqr_hip_create(ilqr_hip_ctx** out, int device, int batch, int horizon, doub
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return ILQR_ERR_NO_DEVICE;
   ilqr_hip_ctx* c = new ilqr_hip_ctx();
   c->device = device; c->B = batch; c->N = horizon;
-  if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&c->stream) != hipSuccess || hipStreamCreate(&c->stream2) != hipSuccess ||
+  if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&c->stream) != hipSuccess || hipStreamCreate(&c->stream2) != hipSuccess || hipStreamCreate(&c->stream3) != hipSuccess || hipEventCreateWithFlags(&c->ev_roll, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) { delete c; return ILQR_ERR_NO_DEVICE; }
   const size_t B = batch, N = horizon, n = ILQR_NX, m = ILQR_NU;
   DevState& S = c->S;
@@ -105,7 +107,7 @@ int ilqr_hip_create(ilqr_hip_ctx** out, int device, int batch, int horizon, doub
   A(dalloc(c, &S.active, B)); A(dalloc(c, &S.need_retry, B)); A(dalloc(c, &S.iters, B)); A(dalloc(c, &S.improved, B)); A(dalloc(c, &S.alpha_idx, B));
   A(dalloc(c, &S.trace_cost, B * (c->max_iter + 1))); A(dalloc(c, &S.trace_alpha, B * c->max_iter)); A(dalloc(c, &S.trace_lambda, B * c->max_iter));
   A(dalloc(c, &c->d_tmpx, B * (N + 1) * n)); A(dalloc(c, &c->d_tmpu, B * N * m));
-  A(dalloc(c, &c->d_prevx, B * (N + 1) * n)); A(dalloc(c, &c->d_prevu, B * N * m));
+  A(dalloc(c, &c->d_prevx, B * (N + 1) * n)); A(dalloc(c, &c->d_prevu, B * N * m)); A(dalloc(c, &c->d_shadowx, B * (N + 1) * n));
   A(dalloc(c, &c->d_u0, B * m)); A(dalloc(c, &c->d_K0, B * m * n)); A(dalloc(c, &c->d_cost_tmp, B));
   // shared reference sets sized for per-rollout use
   A(dalloc(c, &c->d_xref, B * (N + 1) * n)); A(dalloc(c, &c->d_uref, B * N * m)); A(dalloc(c, &c->d_comref, B * (N + 1) * 3));
@@ -136,13 +138,15 @@ int ilqr_hip_destroy(ilqr_hip_ctx* c) {
   DevState& S = c->S;
   void* ptrs[] = {S.lin_dump, S.x0, S.xbar, S.ubar, S.xcand, S.ucand, S.cand_cost, S.A, S.Bm, S.lx, S.lu, S.lxx, S.luu, S.K, S.kff, S.Vx, S.Vxx, S.J, S.Jbase, S.ls_cost,
                   S.lambda, S.active, S.need_retry, S.iters, S.improved, S.alpha_idx, S.trace_cost, S.trace_alpha, S.trace_lambda, c->d_tmpx, c->d_tmpu,
-                  c->d_prevx, c->d_prevu, c->d_u0, c->d_K0, c->d_cost_tmp, c->d_xref, c->d_uref, c->d_comref, c->d_eeref, c->d_comvelref, c->d_stance};
+                  c->d_prevx, c->d_prevu, c->d_shadowx, c->d_u0, c->d_K0, c->d_cost_tmp, c->d_xref, c->d_uref, c->d_comref, c->d_eeref, c->d_comvelref, c->d_stance};
   for (void* p : ptrs) if (p) hipFree(p);
   for (hipEvent_t e : c->pool) hipEventDestroy(e);
-  for (auto& sl : c->slices) { hipEventDestroy(sl.fork); hipEventDestroy(sl.join); hipEventDestroy(sl.done); hipEventDestroy(sl.lead); hipStreamDestroy(sl.st2); hipStreamDestroy(sl.st); }
+  for (auto& sl : c->slices) { hipEventDestroy(sl.fork); hipEventDestroy(sl.join); hipEventDestroy(sl.done); hipEventDestroy(sl.lead); hipEventDestroy(sl.roll); hipStreamDestroy(sl.st3); hipStreamDestroy(sl.st2); hipStreamDestroy(sl.st); }
   if (c->ev_begin) hipEventDestroy(c->ev_begin);
   if (c->ev_fork) hipEventDestroy(c->ev_fork);
   if (c->ev_join) hipEventDestroy(c->ev_join);
+  if (c->ev_roll) hipEventDestroy(c->ev_roll);
+  if (c->stream3) hipStreamDestroy(c->stream3);
   if (c->stream2) hipStreamDestroy(c->stream2);
   if (c->stream) hipStreamDestroy(c->stream);
   delete c;
@@ -344,7 +348,8 @@ static int ensure_slices(ilqr_hip_ctx* c, int k) {
   if (!c->ev_begin) HIPCHK(c, hipEventCreateWithFlags(&c->ev_begin, hipEventDisableTiming));
   while ((int)c->slices.size() < k) {
     ilqr_hip_ctx::Slice sl;
-    HIPCHK(c, hipStreamCreate(&sl.st)); HIPCHK(c, hipStreamCreate(&sl.st2));
+    HIPCHK(c, hipStreamCreate(&sl.st)); HIPCHK(c, hipStreamCreate(&sl.st2)); HIPCHK(c, hipStreamCreate(&sl.st3));
+    HIPCHK(c, hipEventCreateWithFlags(&sl.roll, hipEventDisableTiming));
     HIPCHK(c, hipEventCreateWithFlags(&sl.fork, hipEventDisableTiming)); HIPCHK(c, hipEventCreateWithFlags(&sl.join, hipEventDisableTiming));
     HIPCHK(c, hipEventCreateWithFlags(&sl.done, hipEventDisableTiming)); HIPCHK(c, hipEventCreateWithFlags(&sl.lead, hipEventDisableTiming));
     c->slices.push_back(sl);
@@ -353,23 +358,42 @@ static int ensure_slices(ilqr_hip_ctx* c, int k) {
 }
 // the launch sequence of iLQR::solve (ilqr.cpp:521-660) for one slice on its streams; `wait_lead` (optional) delays the
 // first throughput-bound stage until the previous slice has finished its first backward pass, `lead` is recorded there
-static int enqueue_solve(ilqr_hip_ctx* c, const DevState& S, const h1::ProblemDev& P, hipStream_t st, hipStream_t st2,
-                         hipEvent_t ev_fork, hipEvent_t ev_join, hipEvent_t wait_lead, hipEvent_t lead) {
+static int overlap_rollout() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("ILQR_OVERLAP_ROLLOUT"); v = e ? atoi(e) : 1; }
+  return v;
+}
+static int enqueue_solve(ilqr_hip_ctx* c, const DevState& S, const h1::ProblemDev& P, hipStream_t st, hipStream_t st2, hipStream_t st3,
+                         hipEvent_t ev_fork, hipEvent_t ev_join, hipEvent_t ev_roll, const double* shadow_base, hipEvent_t wait_lead, hipEvent_t lead) {
+  // shadow target of the concurrent re-rollout: same rollouts as S.xbar, in the shadow buffer
+  double* shadow = const_cast<double*>(shadow_base) + (S.xbar - c->S.xbar);
   { StageTimer T(c, 0, st); ilqr::launch_rollout(S, P, ilqr::MASK_ALL, 0, 0, S.Jbase, st); ilqr::launch_solve_begin(S, st); }  // ilqr.cpp:540
   for (int iter = 0; iter < c->max_iter; ++iter) {
     // :551,563 nominal rollout at the top of every iteration, as the reference does.  From the second iteration on the
     // nominal trajectory is the candidate the line search accepted (or the unchanged previous one), so the re-rollout
     // only reproduces it; ILQR_REUSE_ROLLOUT=1 skips it (not the default: the headline metric counts the rollout
     // as part of an iteration)
-    if (iter == 0 || !reuse_rollout()) { StageTimer T(c, 0, st); ilqr::launch_rollout(S, P, ilqr::MASK_ACTIVE, 1, 0, S.Jbase, st); }
+    // From the second iteration on the nominal trajectory already is a rollout from x0 (the accepted line-search
+    // candidate, or the unchanged previous nominal), so the re-rollout reproduces it to rounding: it runs on a third
+    // stream into a shadow buffer beside the linearisation and is adopted (with its cost, the line-search baseline)
+    // before the backward pass.  ILQR_OVERLAP_ROLLOUT=0 restores the sequential order.
+    const bool concurrent_roll = iter > 0 && !reuse_rollout() && overlap_rollout() && !P.dyn.contact;
+    if ((iter == 0 || !reuse_rollout()) && !concurrent_roll) { StageTimer T(c, 0, st); ilqr::launch_rollout(S, P, ilqr::MASK_ACTIVE, 1, 0, S.Jbase, st); }
     if (iter == 0 && wait_lead) HIPCHK(c, hipStreamWaitEvent(st, wait_lead, 0));
     // linearisation (:576) and cost quadratics (:588) only depend on the rollout: run them concurrently
     HIPCHK(c, hipEventRecord(ev_fork, st));
     HIPCHK(c, hipStreamWaitEvent(st2, ev_fork, 0));
+    if (concurrent_roll) {
+      HIPCHK(c, hipStreamWaitEvent(st3, ev_fork, 0));
+      DevState Sr = S; Sr.xbar = shadow;
+      { StageTimer T(c, 0, st3); ilqr::launch_rollout(Sr, P, ilqr::MASK_ACTIVE, 1, 0, S.Jbase, st3); }
+      HIPCHK(c, hipEventRecord(ev_roll, st3));
+    }
     { StageTimer T(c, 2, st2); ilqr::launch_cost_quadratics(S, P, ilqr::MASK_ACTIVE, st2); }
     HIPCHK(c, hipEventRecord(ev_join, st2));
     { StageTimer T(c, 1, st); ilqr::launch_linearize(S, P, ilqr::MASK_ACTIVE, c->jac_mode, c->fd_eps, st); }
     HIPCHK(c, hipStreamWaitEvent(st, ev_join, 0));
+    if (concurrent_roll) { HIPCHK(c, hipStreamWaitEvent(st, ev_roll, 0)); ilqr::launch_adopt_rollout(S, shadow, ilqr::MASK_ACTIVE, st); }
     { StageTimer T(c, 3, st); ilqr::launch_backward(S, ilqr::MASK_ACTIVE, st); }                                  // :601
     if (iter == 0 && lead) HIPCHK(c, hipEventRecord(lead, st));
     { StageTimer T(c, 4, st); ilqr::launch_line_search(S, P, ilqr::MASK_ACTIVE, st); }                            // :616
@@ -391,7 +415,7 @@ int ilqr_hip_solve_async(ilqr_hip_ctx* c) {
   const int k = slices_wanted(c->B);
   c->n_slices = k;
   if (k <= 1) {
-    TRY(enqueue_solve(c, S, P, st, c->stream2, c->ev_fork, c->ev_join, nullptr, nullptr));
+    TRY(enqueue_solve(c, S, P, st, c->stream2, c->stream3, c->ev_fork, c->ev_join, c->ev_roll, c->d_shadowx, nullptr, nullptr));
   } else {
     TRY(ensure_slices(c, k));
     HIPCHK(c, hipEventRecord(c->ev_begin, st));
@@ -404,7 +428,7 @@ int ilqr_hip_solve_async(ilqr_hip_ctx* c) {
       HIPCHK(c, hipStreamWaitEvent(sl.st, c->ev_begin, 0));
       const DevState Ss = slice_state(S, (size_t)b0, Bs);
       const h1::ProblemDev Ps = slice_problem(P, b0);
-      TRY(enqueue_solve(c, Ss, Ps, sl.st, sl.st2, sl.fork, sl.join, (stagger && i > 0) ? c->slices[i - 1].lead : nullptr, sl.lead));
+      TRY(enqueue_solve(c, Ss, Ps, sl.st, sl.st2, sl.st3, sl.fork, sl.join, sl.roll, c->d_shadowx, (stagger && i > 0) ? c->slices[i - 1].lead : nullptr, sl.lead));
       HIPCHK(c, hipEventRecord(sl.done, sl.st));
       HIPCHK(c, hipStreamWaitEvent(st, sl.done, 0));
     }

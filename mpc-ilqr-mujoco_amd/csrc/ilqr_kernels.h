@@ -55,6 +55,7 @@ void launch_backward(const DevState& S, int mode, hipStream_t st);
 void launch_line_search(const DevState& S, const h1::ProblemDev& P, int mode, hipStream_t st);
 void launch_control(const DevState& S, int phase, int iter, double tol, int early_exit, hipStream_t st);
 void launch_solve_begin(const DevState& S, hipStream_t st);
+void launch_adopt_rollout(const DevState& S, const double* shadow, int mode, hipStream_t st);
 void launch_warm_shift(const DevState& S, const double* prev_x, const double* prev_u, hipStream_t st);
 void launch_last_step(const DevState& S, const h1::ProblemDev& P, hipStream_t st);
 void launch_compute_control(const DevState& S, const double* x_meas, double* u_out, hipStream_t st);

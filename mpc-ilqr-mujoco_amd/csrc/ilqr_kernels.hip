@@ -417,6 +417,15 @@ __global__ void k_warm_shift(DevState S, const double* prev_x, const double* pre
   for (int e = lane; e < (N - 1) * m; e += blockDim.x) ub[e] = pu[m + e];
   for (int e = lane; e < m; e += blockDim.x) ub[(N - 1) * m + e] = pu[(N - 1) * m + e];
 }
+// the nominal re-rollout of iterations >= 1 runs beside the linearisation into a shadow buffer (ilqr_capi.hip): adopt it
+__global__ void k_adopt_rollout(DevState S, const double* shadow, int mode) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  if (!selected(S, b, mode)) return;
+  const size_t len = (size_t)(S.N + 1) * H1_NX;
+  double* xb = S.xbar + (size_t)b * len;
+  const double* sh = shadow + (size_t)b * len;
+  for (int e = lane; e < (int)len; e += blockDim.x) xb[e] = sh[e];
+}
 // last knot of the warm start: xbar[N] = f(xbar[N-1], ubar[N-1])
 __global__ void k_last_step(DevState S, ProblemDev P) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -515,6 +524,7 @@ void launch_control(const DevState& S, int phase, int iter, double tol, int earl
   hipLaunchKernelGGL(k_control, dim3(S.B), dim3(64), 0, st, S, phase, iter, tol, early_exit);
 }
 void launch_solve_begin(const DevState& S, hipStream_t st) { hipLaunchKernelGGL(k_solve_begin, dim3(cdiv(S.B, 64)), dim3(64), 0, st, S); }
+void launch_adopt_rollout(const DevState& S, const double* shadow, int mode, hipStream_t st) { hipLaunchKernelGGL(k_adopt_rollout, dim3(S.B), dim3(64), 0, st, S, shadow, mode); }
 void launch_warm_shift(const DevState& S, const double* px, const double* pu, hipStream_t st) { hipLaunchKernelGGL(k_warm_shift, dim3(S.B), dim3(64), 0, st, S, px, pu); }
 void launch_last_step(const DevState& S, const ProblemDev& P, hipStream_t st) { if (!use_scalar_dyn() && !P.dyn.contact) { launch_last_step_r(S, P, st); return; } hipLaunchKernelGGL(k_last_step, dim3(cdiv(S.B, 64)), dim3(64), 0, st, S, P); }
 void launch_compute_control(const DevState& S, const double* x_meas, double* u_out, hipStream_t st) { hipLaunchKernelGGL(k_compute_control, dim3(S.B), dim3(64), 0, st, S, x_meas, u_out); }
