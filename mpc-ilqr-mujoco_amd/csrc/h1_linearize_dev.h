@@ -438,19 +438,51 @@ DEVFN void lin_minv_lane(LinShared& L, int lane) {
 }
 
 // d qacc / d direction = -Minv dT  (in place, one lane per direction)
+// dT <- -Minv dT (25 x 25 times 25 x 47) on v_mfma_f64_16x16x4_f64: 2 row tiles x 3 column tiles x 7 k-steps = 42 MFMA
+// (A operand lane (lr, lk) = Minv[16 I + lr][4 s + lk], B operand lane (lk, lr) = dT[4 s + lk][16 J + lr]; rows / k beyond
+// 25 are zero padding), instead of 625 broadcast LDS reads + 625 FMAs per lane.  All 64 lanes take part; every operand is
+// read before the first result is written back.
 DEVFN void lin_apply_minv_lane(LinShared& L, int lane) {
-  if (lane >= LIN_NDIR) return;
-  double col[H1_NV];
+  typedef double v4d_l __attribute__((ext_vector_type(4)));
+  const int lr = lane & 15, lk = lane >> 4;
+  double am[2][7], bd[3][7];
 #pragma unroll
-  for (int c = 0; c < H1_NV; ++c) col[c] = L.dT[c][lane];
+  for (int s = 0; s < 7; ++s) {
+    const int k = 4 * s + lk, kc = k < H1_NV ? k : H1_NV - 1;
 #pragma unroll
-  for (int r = 0; r < H1_NV; ++r) {
-    double s = 0.0;
+    for (int I = 0; I < 2; ++I) {
+      const int r = 16 * I + lr, rc = r < H1_NV ? r : H1_NV - 1;
+      const double v = L.Minv[rc][kc];
+      am[I][s] = (r < H1_NV && k < H1_NV) ? -v : 0.0;
+    }
 #pragma unroll
-    for (int c = 0; c < H1_NV; ++c) s -= L.Minv[r][c] * col[c];
-    L.dT[r][lane] = s;                   // this lane's column only: every input is already in registers
-    __builtin_amdgcn_sched_barrier(0);   // one row at a time (the scheduler otherwise hoists all 625 LDS operands)
+    for (int J = 0; J < 3; ++J) {
+      const double v = L.dT[kc][16 * J + lr];
+      bd[J][s] = (k < H1_NV) ? v : 0.0;
+    }
   }
+  __syncthreads();
+  v4d_l acc[2][3];
+#pragma unroll
+  for (int I = 0; I < 2; ++I)
+#pragma unroll
+    for (int J = 0; J < 3; ++J) acc[I][J] = (v4d_l){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int s = 0; s < 7; ++s)
+#pragma unroll
+    for (int I = 0; I < 2; ++I)
+#pragma unroll
+      for (int J = 0; J < 3; ++J) acc[I][J] = __builtin_amdgcn_mfma_f64_16x16x4f64(am[I][s], bd[J][s], acc[I][J], 0, 0, 0);
+#pragma unroll
+  for (int I = 0; I < 2; ++I)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = 16 * I + 4 * r + lk;
+      if (row < H1_NV) {
+#pragma unroll
+        for (int J = 0; J < 3; ++J) L.dT[row][16 * J + lr] = acc[I][J][r];
+      }
+    }
 }
 
 // cooperative load of the global dump into LDS (all lanes of one wave); rebuilds the joint rotations from
