@@ -310,10 +310,11 @@ static int reuse_rollout() {
 #ifndef SLICES_DEFAULT
 #define SLICES_DEFAULT 1
 #endif
-static int slices_wanted(int B) {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("ILQR_SLICES"); v = e ? atoi(e) : SLICES_DEFAULT; if (v < 1) v = 1; if (v > 32) v = 32; }
-  int k = v;
+static int slices_wanted(int B) {      // read at every solve: tests switch it within one process
+  const char* e = getenv("ILQR_SLICES");
+  int k = e ? atoi(e) : SLICES_DEFAULT;
+  if (k < 1) k = 1;
+  if (k > 32) k = 32;
   while (k > 1 && B / k < 64) --k;   // a slice is at least one wave of the widest kernels
   return k;
 }
@@ -358,11 +359,7 @@ static int ensure_slices(ilqr_hip_ctx* c, int k) {
 }
 // the launch sequence of iLQR::solve (ilqr.cpp:521-660) for one slice on its streams; `wait_lead` (optional) delays the
 // first throughput-bound stage until the previous slice has finished its first backward pass, `lead` is recorded there
-static int overlap_rollout() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("ILQR_OVERLAP_ROLLOUT"); v = e ? atoi(e) : 1; }
-  return v;
-}
+static int overlap_rollout() { const char* e = getenv("ILQR_OVERLAP_ROLLOUT"); return e ? atoi(e) : 1; }
 static int enqueue_solve(ilqr_hip_ctx* c, const DevState& S, const h1::ProblemDev& P, hipStream_t st, hipStream_t st2, hipStream_t st3,
                          hipEvent_t ev_fork, hipEvent_t ev_join, hipEvent_t ev_roll, const double* shadow_base, hipEvent_t wait_lead, hipEvent_t lead) {
   // shadow target of the concurrent re-rollout: same rollouts as S.xbar, in the shadow buffer

@@ -444,6 +444,33 @@ def test_closed_loop_standing_under_physical_gravity_needs_the_contact_row(tmp_p
     s.close()
 
 
+def test_launch_orchestration_variants_are_bitwise_equivalent():
+    """The solve may be enqueued as contiguous batch slices on separate streams (ILQR_SLICES) and the nominal re-rollout
+    of iterations >= 1 may run beside the linearisation into a shadow buffer (ILQR_OVERLAP_ROLLOUT): the kernels and the
+    data they see are the same, so costs, traces and gains must not change by a single bit -- except that with the
+    sequential rollout the linearisation reads the re-rolled trajectory instead of the accepted candidate (1e-12)."""
+    B = 200        # not a multiple of the slice count
+    prob, x0, ui = make(B, seed=12)
+    out = {}
+    for key, env in (("base", {}), ("slices", {"ILQR_SLICES": "3"}), ("seq", {"ILQR_OVERLAP_ROLLOUT": "0"})):
+        old = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        try:
+            s = _solver(B); s.set_problem(prob); s.set_max_iterations(4)
+            s.initialize(x0, ui)
+            cost = s.solve(x0)
+            out[key] = (cost, s.trace()[0], s.gains_K(), s.iterations())
+            s.close()
+        finally:
+            for k, v in old.items():
+                if v is None: os.environ.pop(k, None)
+                else: os.environ[k] = v
+    for a, b in zip(out["base"], out["slices"]):
+        assert np.array_equal(a, b, equal_nan=True)
+    assert np.array_equal(out["base"][3], out["seq"][3])
+    assert np.allclose(out["base"][0], out["seq"][0], rtol=1e-9) and rel(out["base"][2], out["seq"][2]) < 1e-6
+
+
 def test_per_rollout_reference_sets():
     B, N = 3, 25
     prob, x0, ui = make(B, seed=8)
