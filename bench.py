@@ -46,6 +46,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--gather-gains", action="store_true", help="include K0[19x51] in the per-step gather payload")
+    ap.add_argument("--contact", action="store_true",
+                    help="not the headline: contact row f4 (rigid stance on the scheduled feet, physical gravity, scalar kernels, forward-difference Jacobians)")
     return ap.parse_args()
 
 
@@ -93,13 +95,15 @@ def main():
     sc = pkg.scenario
     B, N, iters = args.batch, args.horizon, args.iters
 
-    prob = sc.make_problem(sv.reference_kinematics, N=N)
+    prob = sc.make_problem(sv.reference_kinematics, N=N, gravity=(0.0, 0.0, -9.81)) if args.contact else sc.make_problem(sv.reference_kinematics, N=N)
     ug = sv.gravity_compensation(sc.standing_state(), prob["gravity"])
     # every rank draws its own shard of the global batch (contiguous rollout ranges)
     x0, ui = sc.synthetic_batch(B, N, args.seed + rank, ug)
     s = sv.BatchedILQR(B, N=N, dt=prob["dt"], device=local_rank)
     s.set_problem(prob)
     s.set_max_iterations(iters)
+    if args.contact:
+        s.set_contact_mode(1)
     s.set_options(jacobian_mode=sv.JAC_ANALYTIC, early_exit=False)
     s.enable_profiling(True)
 
@@ -236,7 +240,7 @@ def main():
                                    "H1 standing balance, N=%d, dt=0.02, %d fixed iterations per rollout, shipped config.yaml weights, gravity %s"
                                    % (B, N, iters, list(prob["gravity"])),
                        "batch_per_gpu": B, "global_batch": B * world, "horizon": N, "iterations_per_solve": iters,
-                       "jacobians": "analytic", "batch_slices": n_slices, "gather": "u0+cost" + ("+K0" if args.gather_gains else "")},
+                       "jacobians": "forward differences (contact mode)" if args.contact else "analytic", "contact_mode": bool(args.contact), "batch_slices": n_slices, "gather": "u0+cost" + ("+K0" if args.gather_gains else "")},
             "roofline": roof,
             "kernels": {n: {k: (round(v, 6) if isinstance(v, float) else v) for k, v in t.items() if k in
                             ("total_ms_per_step", "avg_launch_ms", "frac_compute", "frac_hbm")} for n, t in table.items()},
