@@ -41,15 +41,17 @@ __device__ __forceinline__ double shfl_xor_f64(double v, int mask) {
 // plus base, torso and the base-only terms on the even lane; `com` = whole-body CoM (already summed over the pair)
 // (left / right hinge indices are compile-time constants and the operands wave-uniform, so every table value is a
 // scalar load or an immediate selected by the lane's side -- no per-lane indexed loads)
-DEVFN double knot_cost_half(const ProblemDev& P, int b, int t, bool side, const h1s::HalfX& h, const h1s::HalfU* u, const double* com) {
+// (the reference state / control of the knot arrive as this lane's half, fetched in one batch by the caller: fetched
+// element by element next to their use they cost ~50 k cycles per step, the loads of a 512-register kernel do not
+// get hoisted)
+DEVFN double knot_cost_half(const ProblemDev& P, int b, int t, bool side, const h1s::HalfX& h, const h1s::HalfU* u, const double* com,
+                            const h1s::HalfX& xr, const h1s::HalfU& ur) {
   const bool term = (t == P.N);
-  const double* xr = P.x_ref + b * P.x_ref_stride + t * H1_NX;
   const double* Qd = term ? P.Qf : P.Q;
   double a = 0.0, pen = 0.0;
-  auto sq1 = [&](int i, double v) { const double e = v - xr[i]; a += e * Qd[i] * e; };
-  // reference entries are per-rollout (one indexed load); weights and limits are wave-uniform: both sides' values are
-  // loaded unconditionally and selected (`side ? p[r] : p[l]` written inline would become a branch per use)
-  auto sq2 = [&](int il, int ir, double v) { const double ql = Qd[il], qr = Qd[ir]; const double e = v - xr[side ? ir : il]; a += e * (side ? qr : ql) * e; };
+  auto sq1 = [&](int i, double v, double r) { const double e = v - r; a += e * Qd[i] * e; };
+  // weights and limits are wave-uniform: both sides' values are loaded unconditionally and selected
+  auto sq2 = [&](int il, int ir, double v, double r) { const double ql = Qd[il], qr = Qd[ir]; const double e = v - r; a += e * (side ? qr : ql) * e; };
   auto jpen2 = [&](int jl, int jr, double q) {
     double lol, hil, lor, hir; limit_bounds(H1_JRANGE[jl], lol, hil); limit_bounds(H1_JRANGE[jr], lor, hir);
     const double lo = side ? lor : lol, hi = side ? hir : hil;
@@ -58,34 +60,33 @@ DEVFN double knot_cost_half(const ProblemDev& P, int b, int t, bool side, const 
   };
   if (!side) {
 #pragma unroll
-    for (int k = 0; k < 3; ++k) sq1(k, h.p[k]);
+    for (int k = 0; k < 3; ++k) sq1(k, h.p[k], xr.p[k]);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) sq1(3 + k, h.quat[k]);
+    for (int k = 0; k < 4; ++k) sq1(3 + k, h.quat[k], xr.quat[k]);
 #pragma unroll
-    for (int k = 0; k < 6; ++k) sq1(H1_NQ + k, h.vb[k]);
-    sq1(7 + 10, h.q.th11); sq1(H1_NQ + 6 + 10, h.q.qd11); jpen2(10, 10, h.q.th11);
+    for (int k = 0; k < 6; ++k) sq1(H1_NQ + k, h.vb[k], xr.vb[k]);
+    sq1(7 + 10, h.q.th11, xr.q.th11); sq1(H1_NQ + 6 + 10, h.q.qd11, xr.q.qd11); jpen2(10, 10, h.q.th11);
   }
 #pragma unroll
-  for (int k = 0; k < 5; ++k) { sq2(7 + k, 7 + 5 + k, h.q.thL[k]); sq2(H1_NQ + 6 + k, H1_NQ + 6 + 5 + k, h.q.qdL[k]); jpen2(k, 5 + k, h.q.thL[k]); }
+  for (int k = 0; k < 5; ++k) { sq2(7 + k, 7 + 5 + k, h.q.thL[k], xr.q.thL[k]); sq2(H1_NQ + 6 + k, H1_NQ + 6 + 5 + k, h.q.qdL[k], xr.q.qdL[k]); jpen2(k, 5 + k, h.q.thL[k]); }
 #pragma unroll
-  for (int k = 0; k < 4; ++k) { sq2(7 + 11 + k, 7 + 15 + k, h.q.thA[k]); sq2(H1_NQ + 6 + 11 + k, H1_NQ + 6 + 15 + k, h.q.qdA[k]); jpen2(11 + k, 15 + k, h.q.thA[k]); }
+  for (int k = 0; k < 4; ++k) { sq2(7 + 11 + k, 7 + 15 + k, h.q.thA[k], xr.q.thA[k]); sq2(H1_NQ + 6 + 11 + k, H1_NQ + 6 + 15 + k, h.q.qdA[k], xr.q.qdA[k]); jpen2(11 + k, 15 + k, h.q.thA[k]); }
   double c = 0.5 * a;
   if (!term) {
-    const double* ur = P.u_ref + b * P.u_ref_stride + t * H1_NU;
     double s = 0.0;
-    auto usq2 = [&](int jl, int jr, double v) {
+    auto usq2 = [&](int jl, int jr, double v, double r) {
       const double rl = P.R[jl], rr = P.R[jr];
-      const double e = v - ur[side ? jr : jl]; s += e * (side ? rr : rl) * e;
+      const double e = v - r; s += e * (side ? rr : rl) * e;
       double lol, hil, lor, hir; limit_bounds(H1_CTRLRANGE[jl], lol, hil); limit_bounds(H1_CTRLRANGE[jr], lor, hir);
       const double lo = side ? lor : lol, hi = side ? hir : hil;
       const double dh = fmax(v - hi, 0.0), dl = fmax(lo - v, 0.0);
       pen += P.w_ctrl * (dh * dh) + P.w_ctrl * (dl * dl);
     };
-    if (!side) usq2(10, 10, u->u11);
+    if (!side) usq2(10, 10, u->u11, ur.u11);
 #pragma unroll
-    for (int k = 0; k < 5; ++k) usq2(k, 5 + k, u->uL[k]);
+    for (int k = 0; k < 5; ++k) usq2(k, 5 + k, u->uL[k], ur.uL[k]);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) usq2(11 + k, 15 + k, u->uA[k]);
+    for (int k = 0; k < 4; ++k) usq2(11 + k, 15 + k, u->uA[k], ur.uA[k]);
     c += 0.5 * s;
   }
   if (!side) {
@@ -104,6 +105,13 @@ DEVFN double knot_cost_half(const ProblemDev& P, int b, int t, bool side, const 
     }
   }
   return c + pen;
+}
+DEVFN void load_half_u(bool side, const double* u, h1s::HalfU& o) {
+  o.u11 = u[10];
+#pragma unroll
+  for (int k = 0; k < 5; ++k) o.uL[k] = u[h1s::jleg(side, k)];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) o.uA[k] = u[h1s::jarm(side, k)];
 }
 __global__ void __launch_bounds__(64) k_line_search_s(DevState S, ProblemDev P, int mode) {
   extern __shared__ double lds[];
@@ -127,92 +135,92 @@ __global__ void __launch_bounds__(64) k_line_search_s(DevState S, ProblemDev P, 
 #ifdef LS_STAMP
   long long ph[8] = {0}; long long tl = clock64();
 #endif
-  double c = 0.0;
+  const int a8 = lane & ~15;                       // first lane of this rollout's 16
   for (int t = 0; t < N; ++t) {
     const double* xbt = xb + t * n;
+    // ---- everything this step reads from HBM for this lane's half, in one batch: nominal state (for x - xbar),
+    // nominal control and feedforward of the rows this side owns
+    h1s::HalfX xh; h1s::HalfU ubh, kfh;
+    h1s::load_half(side, xbt, xh);
+    load_half_u(side, ub + t * m, ubh);
+    load_half_u(side, kg + t * m, kfh);
     // ---- u = ubar + alpha k + K (x - xbar)   (ilqr.cpp:332-333)
     // state deviations of this candidate -> LDS slot j of the pair's column (even lane: shared coordinates + left)
     if (!side) {
 #pragma unroll
-      for (int k = 0; k < 3; ++k) lds[k * 64 + col] = h.p[k] - xbt[k];
+      for (int k = 0; k < 3; ++k) lds[k * 64 + col] = h.p[k] - xh.p[k];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) lds[(3 + k) * 64 + col] = h.quat[k] - xbt[3 + k];
+      for (int k = 0; k < 4; ++k) lds[(3 + k) * 64 + col] = h.quat[k] - xh.quat[k];
 #pragma unroll
-      for (int k = 0; k < 6; ++k) lds[(H1_NQ + k) * 64 + col] = h.vb[k] - xbt[H1_NQ + k];
-      lds[(7 + 10) * 64 + col] = h.q.th11 - xbt[7 + 10]; lds[(H1_NQ + 6 + 10) * 64 + col] = h.q.qd11 - xbt[H1_NQ + 6 + 10];
+      for (int k = 0; k < 6; ++k) lds[(H1_NQ + k) * 64 + col] = h.vb[k] - xh.vb[k];
+      lds[(7 + 10) * 64 + col] = h.q.th11 - xh.q.th11; lds[(H1_NQ + 6 + 10) * 64 + col] = h.q.qd11 - xh.q.qd11;
     }
     const int so = side ? 5 * 64 : 0, sa = side ? 4 * 64 : 0;   // LDS slot offset of this side's leg / arm hinges
 #pragma unroll
     for (int k = 0; k < 5; ++k) {
-      const int j = h1s::jleg(side, k);
-      lds[(7 + k) * 64 + so + col] = h.q.thL[k] - xbt[7 + j];
-      lds[(H1_NQ + 6 + k) * 64 + so + col] = h.q.qdL[k] - xbt[H1_NQ + 6 + j];
+      lds[(7 + k) * 64 + so + col] = h.q.thL[k] - xh.q.thL[k];
+      lds[(H1_NQ + 6 + k) * 64 + so + col] = h.q.qdL[k] - xh.q.qdL[k];
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const int j = h1s::jarm(side, k);
-      lds[(7 + 11 + k) * 64 + sa + col] = h.q.thA[k] - xbt[7 + j];
-      lds[(H1_NQ + 6 + 11 + k) * 64 + sa + col] = h.q.qdA[k] - xbt[H1_NQ + 6 + j];
+      lds[(7 + 11 + k) * 64 + sa + col] = h.q.thA[k] - xh.q.thA[k];
+      lds[(H1_NQ + 6 + 11 + k) * 64 + sa + col] = h.q.qdA[k] - xh.q.qdA[k];
     }
     __syncthreads();
-    double dxs[4][8];   // dx_{16 q + c16} of the 8 candidates of this rollout
+    // each side evaluates the controls it owns (left: leg 0..4, torso 10, arm 11..14; right: leg 5..9, arm 15..18): the 8
+    // lanes of a side split the columns of K_t (lane alpha owns j = alpha, alpha + 8, ...), multiply with the deviations of
+    // all 8 candidates and reduce-scatter over the alphas in three exchange steps -- nothing crosses the pair
+    double dxs[7][8];   // dx_{8 q + alpha} of the 8 candidates of this rollout
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int j = 16 * q + c16;
+    for (int q = 0; q < 7; ++q) {
+      const int j = 8 * q + ai;
 #pragma unroll
-      for (int a = 0; a < 8; ++a) dxs[q][a] = (j < H1_NX) ? lds[j * 64 + grp + 2 * a] : 0.0;
+      for (int a = 0; a < 8; ++a) dxs[q][a] = (j < H1_NX) ? lds[j * 64 + a8 + 2 * a] : 0.0;
     }
     __syncthreads();   // the dynamics step below reuses these LDS columns
     LSS(0)
     h1s::HalfU u;
-#pragma unroll LS_UNROLL
-    for (int i = 0; i < H1_NU; ++i) {
-      const double* Kr = Kg + ((size_t)t * m + i) * n;
-      double kv[4];
+    u.u11 = 0.0;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) { const int j = 16 * q + c16; kv[q] = (j < H1_NX) ? Kr[j] : 0.0; }
+    for (int k = 0; k < 10; ++k) {
+      // k = 0..4 leg, 5..8 arm, 9 torso (left side only; the right side repeats its last arm row and discards it)
+      const int row = k < 5 ? h1s::jleg(side, k) : (k < 9 ? h1s::jarm(side, k - 5) : (side ? 18 : 10));
+      const double* Kr = Kg + ((size_t)t * m + row) * n;
+      double kv[7];
+#pragma unroll
+      for (int q = 0; q < 7; ++q) { const int j = 8 * q + ai; kv[q] = (j < H1_NX) ? Kr[j] : 0.0; }
       double acc[8];
 #pragma unroll
       for (int a = 0; a < 8; ++a) acc[a] = 0.0;
 #pragma unroll
-      for (int q = 0; q < 4; ++q)
+      for (int q = 0; q < 7; ++q)
 #pragma unroll
         for (int a = 0; a < 8; ++a) acc[a] += kv[q] * dxs[q][a];
-      // reduce over the 16 lanes, scatter by alpha: both lanes of pair a end up with the sum of acc[a]
+      // reduce over the 8 same-side lanes, scatter by alpha (lane bits 3, 2, 1)
       double r1[4], r2[2];
 #pragma unroll
       for (int q = 0; q < 4; ++q) { const double keep = b8 ? acc[4 + q] : acc[q], send = b8 ? acc[q] : acc[4 + q]; r1[q] = keep + shfl_xor_f64(send, 8); }
 #pragma unroll
       for (int q = 0; q < 2; ++q) { const double keep = b4 ? r1[2 + q] : r1[q], send = b4 ? r1[q] : r1[2 + q]; r2[q] = keep + shfl_xor_f64(send, 4); }
       const double keep = b2 ? r2[1] : r2[0], send = b2 ? r2[0] : r2[1];
-      const double r3 = keep + shfl_xor_f64(send, 2);
-      const double s = h1s::pair_sum(r3);
-      const double ui = ub[t * m + i] + alpha * kg[t * m + i] + s;
-      // hand u_i to its owner: torso -> both lanes, hinge of this lane's side -> this lane
-      const int il = i - (side ? 5 : 0), ia = i - (side ? 15 : 11);
-      if (i == 10) u.u11 = ui;
-#pragma unroll
-      for (int k = 0; k < 5; ++k) if (il == k) u.uL[k] = ui;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) if (ia == k) u.uA[k] = ui;
-      const bool mine = (i == 10) ? !side : ((i < 10) ? ((i >= 5) == side) : ((i >= 15) == side));
-      if (mine) uc[t * m + i] = ui;
+      const double sfb = keep + shfl_xor_f64(send, 2);
+      const double ubase = k < 5 ? ubh.uL[k < 5 ? k : 0] : (k < 9 ? ubh.uA[k < 9 && k >= 5 ? k - 5 : 0] : ubh.u11);
+      const double kbase = k < 5 ? kfh.uL[k < 5 ? k : 0] : (k < 9 ? kfh.uA[k < 9 && k >= 5 ? k - 5 : 0] : kfh.u11);
+      const double ui = ubase + alpha * kbase + sfb;
+      if (k < 5) u.uL[k < 5 ? k : 0] = ui;
+      else if (k < 9) u.uA[(k >= 5 && k < 9) ? k - 5 : 0] = ui;
+      else u.u11 = side ? 0.0 : ui;
+      if (k < 9 || !side) uc[t * m + row] = ui;
     }
+    u.u11 = h1s::pair_sum(u.u11);     // torso control: from the left lane to both
     LSS(1)
-    double com[3] = {0.0, 0.0, 0.0};
-    if (P.w_balance > 0.0) h1s::com_mj(side, h, com);
-    c += knot_cost_half(P, b, t, side, h, &u, com);
     LSS(2)
     h1s::step(side, h, u, P.dyn.h, P.dyn.g, L);
     LSS(3)
     h1s::store_half(side, h, xc + (t + 1) * n);
     LSS(4)
   }
-  double com[3] = {0.0, 0.0, 0.0};
-  if (P.w_balance > 0.0) h1s::com_mj(side, h, com);
-  c += knot_cost_half(P, b, N, side, h, nullptr, com);
-  c = h1s::pair_sum(c);
-  if (!side) S.cand_cost[(size_t)b * 8 + ai] = c;
+  // the candidates' costs are evaluated afterwards, all knots in parallel (launch_cand_costs, dyn_kernels.hip)
 #ifdef LS_STAMP
   if (gid == 0) for (int q = 0; q < 8; ++q) S.J[q] = (double)ph[q];
 #endif
@@ -243,13 +251,27 @@ __global__ void __launch_bounds__(64) k_rollout_s(DevState S, ProblemDev P, int 
     for (int k = 0; k < 4; ++k) u.uA[k] = ub[t * H1_NU + h1s::jarm(side, k)];
     double com[3] = {0.0, 0.0, 0.0};
     if (P.w_balance > 0.0) h1s::com_mj(side, h, com);
-    c += knot_cost_half(P, b, t, side, h, &u, com);
+    {
+      h1s::HalfX xr; h1s::HalfU urf;
+      h1s::load_half(side, P.x_ref + b * P.x_ref_stride + t * H1_NX, xr);
+      load_half_u(side, P.u_ref + b * P.u_ref_stride + t * H1_NU, urf);
+      c += knot_cost_half(P, b, t, side, h, &u, com, xr, urf);
+    }
     if (do_roll) { h1s::step(side, h, u, P.dyn.h, P.dyn.g, L); h1s::store_half(side, h, xb + (t + 1) * H1_NX); }
     else h1s::load_half(side, xb + (t + 1) * H1_NX, h);
   }
   double com[3] = {0.0, 0.0, 0.0};
   if (P.w_balance > 0.0) h1s::com_mj(side, h, com);
-  c += knot_cost_half(P, b, N, side, h, nullptr, com);
+  {
+    h1s::HalfX xr; h1s::HalfU urf;
+    h1s::load_half(side, P.x_ref + b * P.x_ref_stride + N * H1_NX, xr);
+    urf.u11 = 0.0;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) urf.uL[k] = 0.0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) urf.uA[k] = 0.0;
+    c += knot_cost_half(P, b, N, side, h, nullptr, com, xr, urf);
+  }
   c = h1s::pair_sum(c);
   if (!side) cost_out[b] = c;
 }

@@ -98,7 +98,7 @@ int ilqr_hip_create(ilqr_hip_ctx** out, int device, int batch, int horizon, doub
   int rc = ILQR_OK;
   auto A = [&](int r) { if (rc == ILQR_OK) rc = r; };
   A(dalloc(c, &S.x0, B * n)); A(dalloc(c, &S.xbar, B * (N + 1) * n)); A(dalloc(c, &S.ubar, B * N * m));
-  A(dalloc(c, &S.xcand, B * 8 * (N + 1) * n)); A(dalloc(c, &S.ucand, B * 8 * N * m)); A(dalloc(c, &S.cand_cost, B * 8));
+  A(dalloc(c, &S.xcand, B * 8 * (N + 1) * n)); A(dalloc(c, &S.ucand, B * 8 * N * m)); A(dalloc(c, &S.cand_cost, B * 8)); A(dalloc(c, &S.cand_knot, B * 8 * (N + 1)));
   A(dalloc(c, &S.A, B * N * n * n + 32)); A(dalloc(c, &S.Bm, B * N * n * m + 32));   // slack: riccati_wave.hip stages 16-byte pairs that may straddle the end of the last row
   A(dalloc(c, &S.lx, B * (N + 1) * n)); A(dalloc(c, &S.lu, B * N * m)); A(dalloc(c, &S.lxx, B * (N + 1) * n * n)); A(dalloc(c, &S.luu, B * N * m));
   A(dalloc(c, &S.lin_dump, B * N * ilqr::lin_dump_doubles()));
@@ -136,7 +136,7 @@ int ilqr_hip_destroy(ilqr_hip_ctx* c) {
   if (!c) return ILQR_ERR_ARG;
   hipSetDevice(c->device);
   DevState& S = c->S;
-  void* ptrs[] = {S.lin_dump, S.x0, S.xbar, S.ubar, S.xcand, S.ucand, S.cand_cost, S.A, S.Bm, S.lx, S.lu, S.lxx, S.luu, S.K, S.kff, S.Vx, S.Vxx, S.J, S.Jbase, S.ls_cost,
+  void* ptrs[] = {S.cand_knot, S.lin_dump, S.x0, S.xbar, S.ubar, S.xcand, S.ucand, S.cand_cost, S.A, S.Bm, S.lx, S.lu, S.lxx, S.luu, S.K, S.kff, S.Vx, S.Vxx, S.J, S.Jbase, S.ls_cost,
                   S.lambda, S.active, S.need_retry, S.iters, S.improved, S.alpha_idx, S.trace_cost, S.trace_alpha, S.trace_lambda, c->d_tmpx, c->d_tmpu,
                   c->d_prevx, c->d_prevu, c->d_shadowx, c->d_u0, c->d_K0, c->d_cost_tmp, c->d_xref, c->d_uref, c->d_comref, c->d_eeref, c->d_comvelref, c->d_stance};
   for (void* p : ptrs) if (p) hipFree(p);
@@ -329,7 +329,7 @@ static DevState slice_state(const DevState& S, size_t b0, int Bs) {
   const size_t N = S.N, n = ILQR_NX, m = ILQR_NU, mi = S.max_iter;
   T.B = Bs;
   T.x0 += b0 * n; T.xbar += b0 * (N + 1) * n; T.ubar += b0 * N * m;
-  T.xcand += b0 * 8 * (N + 1) * n; T.ucand += b0 * 8 * N * m; T.cand_cost += b0 * 8;
+  T.xcand += b0 * 8 * (N + 1) * n; T.ucand += b0 * 8 * N * m; T.cand_cost += b0 * 8; T.cand_knot += b0 * 8 * (N + 1);
   T.A += b0 * N * n * n; T.Bm += b0 * N * n * m;
   T.lx += b0 * (N + 1) * n; T.lu += b0 * N * m; T.lxx += b0 * (N + 1) * n * n; T.luu += b0 * N * m;
   T.K += b0 * N * m * n; T.kff += b0 * N * m; T.lin_dump += b0 * N * ilqr::lin_dump_doubles();

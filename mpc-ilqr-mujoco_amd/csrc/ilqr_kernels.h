@@ -22,6 +22,7 @@ struct DevState {
   double* xcand;       // [B][8][N+1][51]   line-search candidates
   double* ucand;       // [B][8][N][19]
   double* cand_cost;   // [B][8]
+  double* cand_knot;   // [B][8][N+1]       per-knot costs of the line-search candidates (summed in knot order)
   double* A;           // [B][N][51][51]
   double* Bm;          // [B][N][51][19]
   double* lx;          // [B][N+1][51]
@@ -66,6 +67,7 @@ size_t lin_dump_doubles();
 void launch_rollout_r(const DevState& S, const h1::ProblemDev& P, int mode, int do_roll, int count_iter, double* cost_out, hipStream_t st);
 void launch_step_r(int count, const double* x, const double* u, const h1::DynParams& dyn, double* xn, hipStream_t st);
 void launch_last_step_r(const DevState& S, const h1::ProblemDev& P, hipStream_t st);
+void launch_cand_costs(const DevState& S, const h1::ProblemDev& P, int mode, hipStream_t st);
 void launch_line_search_r(const DevState& S, const h1::ProblemDev& P, int mode, hipStream_t st);
 void launch_lin_primal_r(const DevState& S, const h1::ProblemDev& P, int mode, hipStream_t st);
 int dyn_kernels_set_attr();

@@ -463,7 +463,7 @@ __global__ void k_pack_first_knot(DevState S, double* u0, double* K0) {
 #define ROLLOUT_SPLIT_DEFAULT 1
 #endif
 #ifndef LS_SPLIT_DEFAULT
-#define LS_SPLIT_DEFAULT 0
+#define LS_SPLIT_DEFAULT 1
 #endif
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
@@ -517,7 +517,11 @@ void launch_backward(const DevState& S, int mode, hipStream_t st) {
 }
 void launch_line_search(const DevState& S, const ProblemDev& P, int mode, hipStream_t st) {
   static const int split = use_split("ILQR_LS", LS_SPLIT_DEFAULT);
-  if (!use_scalar_dyn() && !P.dyn.contact) { if (split) launch_line_search_s(S, P, mode, st); else launch_line_search_r(S, P, mode, st); return; }
+  if (!use_scalar_dyn() && !P.dyn.contact) {
+    if (split) { launch_line_search_s(S, P, mode, st); launch_cand_costs(S, P, mode, st); }   // candidates' costs: all knots in parallel
+    else launch_line_search_r(S, P, mode, st);                                                  // (the one-lane kernel sums its own)
+    return;
+  }
   hipLaunchKernelGGL(k_line_search, dim3(cdiv((long)S.B * 8, 64)), dim3(64), 0, st, S, P, mode);
 }
 void launch_control(const DevState& S, int phase, int iter, double tol, int early_exit, hipStream_t st) {
