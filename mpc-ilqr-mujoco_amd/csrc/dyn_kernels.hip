@@ -197,45 +197,52 @@ __global__ void __launch_bounds__(64) k_line_search_r(DevState S, ProblemDev P, 
 // contiguous in HBM: fetched coalesced through LDS), a second tiny kernel adds them in knot order, i.e. in exactly the
 // order a sequential accumulation along the rollout would use (the accepted step size depends on cost < J - 1e-6).
 #define CK_LD 51
-__global__ void __launch_bounds__(64) k_cand_knot_cost(DevState S, ProblemDev P, int mode) {
+// rows = consecutive [N+1][51] trajectories in xsrc ([B][8] candidates: cshift = 3, oshift = 0; [B] nominal
+// trajectories: cshift = 0, oshift = 3 -- they use the slots of candidate 0 of their rollout in the knot buffer)
+__global__ void __launch_bounds__(64) k_traj_knot_cost(DevState S, ProblemDev P, int mode, const double* xsrc, const double* usrc, int cshift, int oshift) {
   __shared__ double xs[64 * CK_LD];
   const int N = S.N, lane = threadIdx.x;
-  const long total = (long)S.B * 8 * (N + 1);
+  const long total = ((long)S.B << cshift) * (N + 1);
   const long first = (long)blockIdx.x * 64;
-  // wave-uniform early exit when every rollout this wave touches is unselected
   const long idx = first + lane;
   const long idc = idx < total ? idx : total - 1;
   const int t = (int)(idc % (N + 1));
   const long cand = idc / (N + 1);
-  const int b = (int)(cand >> 3);
+  const int b = (int)(cand >> cshift);
   const bool act = idx < total && sel(S, b, mode);
-  if (!__any(act)) return;
+  if (!__any(act)) return;       // wave-uniform: every rollout this wave touches is unselected
   const long nrow = (first + 64 <= total) ? 64 : (total - first);
-  const double* src = S.xcand + first * H1_NX;
+  const double* src = xsrc + first * H1_NX;
   for (int e = lane; e < (int)nrow * H1_NX; e += 64) xs[e] = src[e];
   __syncthreads();
   double x[H1_NX], u[H1_NU];
 #pragma unroll
   for (int i = 0; i < H1_NX; ++i) x[i] = xs[(idx < total ? lane : 0) * CK_LD + i];
-  const double* ug = S.ucand + (cand * N + (t < N ? t : N - 1)) * H1_NU;
+  const double* ug = usrc + (cand * N + (t < N ? t : N - 1)) * H1_NU;
 #pragma unroll
   for (int i = 0; i < H1_NU; ++i) u[i] = ug[i];
   const double c = knot_cost_t(P, b, t, x, t < N ? u : (const double*)nullptr, ComReg());
-  if (act) S.cand_knot[idx] = c;
+  if (act) S.cand_knot[((cand << oshift) * (N + 1)) + t] = c;
 }
-__global__ void __launch_bounds__(64) k_cand_cost_sum(DevState S, int mode) {
-  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
-  const int b = gid >> 3;
+__global__ void __launch_bounds__(64) k_traj_cost_sum(DevState S, int mode, int cshift, int oshift, double* cost_out) {
+  const int cand = blockIdx.x * blockDim.x + threadIdx.x;
+  const int b = cand >> cshift;
   if (b >= S.B || !sel(S, b, mode)) return;
-  const double* ck = S.cand_knot + (size_t)gid * (S.N + 1);
+  const double* ck = S.cand_knot + ((size_t)cand << oshift) * (S.N + 1);
   double c = 0.0;
   for (int t = 0; t <= S.N; ++t) c += ck[t];
-  S.cand_cost[gid] = c;
+  cost_out[cand] = c;
 }
 void launch_cand_costs(const DevState& S, const ProblemDev& P, int mode, hipStream_t st) {
   const long total = (long)S.B * 8 * (S.N + 1);
-  hipLaunchKernelGGL(k_cand_knot_cost, dim3((unsigned)((total + 63) / 64)), dim3(64), 0, st, S, P, mode);
-  hipLaunchKernelGGL(k_cand_cost_sum, dim3((unsigned)(((long)S.B * 8 + 63) / 64)), dim3(64), 0, st, S, mode);
+  hipLaunchKernelGGL(k_traj_knot_cost, dim3((unsigned)((total + 63) / 64)), dim3(64), 0, st, S, P, mode, S.xcand, S.ucand, 3, 0);
+  hipLaunchKernelGGL(k_traj_cost_sum, dim3((unsigned)(((long)S.B * 8 + 63) / 64)), dim3(64), 0, st, S, mode, 3, 0, S.cand_cost);
+}
+// computeTotalCost of the nominal trajectories (S.xbar, S.ubar) into cost_out[B], same kernels, same summation order
+void launch_nominal_costs(const DevState& S, const ProblemDev& P, int mode, double* cost_out, hipStream_t st) {
+  const long total = (long)S.B * (S.N + 1);
+  hipLaunchKernelGGL(k_traj_knot_cost, dim3((unsigned)((total + 63) / 64)), dim3(64), 0, st, S, P, mode, S.xbar, S.ubar, 0, 3);
+  hipLaunchKernelGGL(k_traj_cost_sum, dim3((unsigned)((S.B + 63) / 64)), dim3(64), 0, st, S, mode, 0, 3, cost_out);
 }
 
 // primal dump of one knot per lane: see LinDumpG in h1_linearize_dev.h

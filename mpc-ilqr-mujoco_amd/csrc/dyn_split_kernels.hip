@@ -1,7 +1,8 @@
 // Dynamics kernels on TWO lanes per rollout / candidate (h1_aba_split.h): the even lane owns the left leg and arm,
 // the odd lane the right ones.  A separate translation unit from dyn_kernels.hip on purpose: with both variants in one
 // file the one-lane kernels came out 20 % slower (different inlining / register allocation).
-//   k_rollout_s      iLQR::forwardRolloutNominal + computeTotalCost   reference src/ilqr/ilqr.cpp:119-124, 363-518
+//   k_rollout_s      iLQR::forwardRolloutNominal                      reference src/ilqr/ilqr.cpp:119-124
+//   (computeTotalCost, ilqr.cpp:363-518, of the stored trajectories: k_traj_knot_cost / k_traj_cost_sum in dyn_kernels.hip)
 //   k_line_search_s  iLQR::forwardPassLineSearch, 8 alphas at once    reference src/ilqr/ilqr.cpp:311-361
 #include <hip/hip_runtime.h>
 
@@ -37,75 +38,6 @@ __device__ __forceinline__ double shfl_xor_f64(double v, int mask) {
 // a rollout adjacent (lane = 16 r + 2 alpha + side).  With one lane per candidate the 8 x B candidates fill only 2
 // waves per CU; two lanes each give every SIMD a wave.  Same cooperative feedback as k_line_search_r, over 16 lanes.
 #define DYN_LDS_BYTES_S (h1s::LDS_SLOTS * 64 * sizeof(double))
-// this lane's share of one knot of computeTotalCost (ilqr.cpp:370-443 / 447-510, penalties 512-515): its own hinges,
-// plus base, torso and the base-only terms on the even lane; `com` = whole-body CoM (already summed over the pair)
-// (left / right hinge indices are compile-time constants and the operands wave-uniform, so every table value is a
-// scalar load or an immediate selected by the lane's side -- no per-lane indexed loads)
-// (the reference state / control of the knot arrive as this lane's half, fetched in one batch by the caller: fetched
-// element by element next to their use they cost ~50 k cycles per step, the loads of a 512-register kernel do not
-// get hoisted)
-DEVFN double knot_cost_half(const ProblemDev& P, int b, int t, bool side, const h1s::HalfX& h, const h1s::HalfU* u, const double* com,
-                            const h1s::HalfX& xr, const h1s::HalfU& ur) {
-  const bool term = (t == P.N);
-  const double* Qd = term ? P.Qf : P.Q;
-  double a = 0.0, pen = 0.0;
-  auto sq1 = [&](int i, double v, double r) { const double e = v - r; a += e * Qd[i] * e; };
-  // weights and limits are wave-uniform: both sides' values are loaded unconditionally and selected
-  auto sq2 = [&](int il, int ir, double v, double r) { const double ql = Qd[il], qr = Qd[ir]; const double e = v - r; a += e * (side ? qr : ql) * e; };
-  auto jpen2 = [&](int jl, int jr, double q) {
-    double lol, hil, lor, hir; limit_bounds(H1_JRANGE[jl], lol, hil); limit_bounds(H1_JRANGE[jr], lor, hir);
-    const double lo = side ? lor : lol, hi = side ? hir : hil;
-    const double vh = fmax(q - hi, 0.0), vl = fmax(lo - q, 0.0);   // branch-free: a branch per hinge would serialise the loads
-    pen += P.w_joint * (vh * vh) + P.w_joint * (vl * vl);
-  };
-  if (!side) {
-#pragma unroll
-    for (int k = 0; k < 3; ++k) sq1(k, h.p[k], xr.p[k]);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) sq1(3 + k, h.quat[k], xr.quat[k]);
-#pragma unroll
-    for (int k = 0; k < 6; ++k) sq1(H1_NQ + k, h.vb[k], xr.vb[k]);
-    sq1(7 + 10, h.q.th11, xr.q.th11); sq1(H1_NQ + 6 + 10, h.q.qd11, xr.q.qd11); jpen2(10, 10, h.q.th11);
-  }
-#pragma unroll
-  for (int k = 0; k < 5; ++k) { sq2(7 + k, 7 + 5 + k, h.q.thL[k], xr.q.thL[k]); sq2(H1_NQ + 6 + k, H1_NQ + 6 + 5 + k, h.q.qdL[k], xr.q.qdL[k]); jpen2(k, 5 + k, h.q.thL[k]); }
-#pragma unroll
-  for (int k = 0; k < 4; ++k) { sq2(7 + 11 + k, 7 + 15 + k, h.q.thA[k], xr.q.thA[k]); sq2(H1_NQ + 6 + 11 + k, H1_NQ + 6 + 15 + k, h.q.qdA[k], xr.q.qdA[k]); jpen2(11 + k, 15 + k, h.q.thA[k]); }
-  double c = 0.5 * a;
-  if (!term) {
-    double s = 0.0;
-    auto usq2 = [&](int jl, int jr, double v, double r) {
-      const double rl = P.R[jl], rr = P.R[jr];
-      const double e = v - r; s += e * (side ? rr : rl) * e;
-      double lol, hil, lor, hir; limit_bounds(H1_CTRLRANGE[jl], lol, hil); limit_bounds(H1_CTRLRANGE[jr], lor, hir);
-      const double lo = side ? lor : lol, hi = side ? hir : hil;
-      const double dh = fmax(v - hi, 0.0), dl = fmax(lo - v, 0.0);
-      pen += P.w_ctrl * (dh * dh) + P.w_ctrl * (dl * dl);
-    };
-    if (!side) usq2(10, 10, u->u11, ur.u11);
-#pragma unroll
-    for (int k = 0; k < 5; ++k) usq2(k, 5 + k, u->uL[k], ur.uL[k]);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) usq2(11 + k, 15 + k, u->uA[k], ur.uA[k]);
-    c += 0.5 * s;
-  }
-  if (!side) {
-    if (P.w_upright > 0.0) {
-      const double qw = h.quat[0], qx = h.quat[1], qy = h.quat[2], qz = h.quat[3];
-      const double zx = 2.0 * (qx * qz + qw * qy), zy = 2.0 * (qy * qz - qw * qx), zz = 1.0 - 2.0 * (qx * qx + qy * qy);
-      c += 0.5 * P.w_upright * (zx * zx + zy * zy + (zz - 1.0) * (zz - 1.0));
-    }
-    if (P.w_balance > 0.0) {
-      double ps[2];
-      if (support_point(P, b, t, ps)) {
-        const double om = sqrt(com[2] / 9.81);
-        const double rx = com[0] + h.vb[0] * om - ps[0], ry = com[1] + h.vb[1] * om - ps[1];
-        c += 0.5 * P.w_balance * (rx * rx + ry * ry);
-      }
-    }
-  }
-  return c + pen;
-}
 DEVFN void load_half_u(bool side, const double* u, h1s::HalfU& o) {
   o.u11 = u[10];
 #pragma unroll
@@ -226,8 +158,9 @@ __global__ void __launch_bounds__(64) k_line_search_s(DevState S, ProblemDev P, 
 #endif
 }
 
-// thread per (rollout, side): nominal rollout + cost; mode / do_roll as k_rollout_r
-__global__ void __launch_bounds__(64) k_rollout_s(DevState S, ProblemDev P, int mode, int do_roll, int count_iter, double* cost_out) {
+// thread per (rollout, side): nominal rollout
+// (the cost of the trajectory is evaluated afterwards, all knots in parallel: launch_nominal_costs, dyn_kernels.hip)
+__global__ void __launch_bounds__(64) k_rollout_s(DevState S, ProblemDev P, int mode, int count_iter) {
   extern __shared__ double lds[];
   const int gid = blockIdx.x * blockDim.x + threadIdx.x;
   const int b = gid >> 1;
@@ -239,9 +172,7 @@ __global__ void __launch_bounds__(64) k_rollout_s(DevState S, ProblemDev P, int 
   const double* ub = S.ubar + (size_t)b * N * H1_NU;
   if (count_iter && !side) S.iters[b] += 1;
   h1s::HalfX h;
-  if (do_roll) { h1s::load_half(side, S.x0 + (size_t)b * H1_NX, h); h1s::store_half(side, h, xb); }
-  else h1s::load_half(side, xb, h);
-  double c = 0.0;
+  h1s::load_half(side, S.x0 + (size_t)b * H1_NX, h); h1s::store_half(side, h, xb);
   for (int t = 0; t < N; ++t) {
     h1s::HalfU u;
     u.u11 = ub[t * H1_NU + 10];
@@ -249,31 +180,13 @@ __global__ void __launch_bounds__(64) k_rollout_s(DevState S, ProblemDev P, int 
     for (int k = 0; k < 5; ++k) u.uL[k] = ub[t * H1_NU + h1s::jleg(side, k)];
 #pragma unroll
     for (int k = 0; k < 4; ++k) u.uA[k] = ub[t * H1_NU + h1s::jarm(side, k)];
-    double com[3] = {0.0, 0.0, 0.0};
-    if (P.w_balance > 0.0) h1s::com_mj(side, h, com);
-    {
-      h1s::HalfX xr; h1s::HalfU urf;
-      h1s::load_half(side, P.x_ref + b * P.x_ref_stride + t * H1_NX, xr);
-      load_half_u(side, P.u_ref + b * P.u_ref_stride + t * H1_NU, urf);
-      c += knot_cost_half(P, b, t, side, h, &u, com, xr, urf);
-    }
-    if (do_roll) { h1s::step(side, h, u, P.dyn.h, P.dyn.g, L); h1s::store_half(side, h, xb + (t + 1) * H1_NX); }
-    else h1s::load_half(side, xb + (t + 1) * H1_NX, h);
+    h1s::step(side, h, u, P.dyn.h, P.dyn.g, L);
+    h1s::store_half(side, h, xb + (t + 1) * H1_NX);
   }
-  double com[3] = {0.0, 0.0, 0.0};
-  if (P.w_balance > 0.0) h1s::com_mj(side, h, com);
-  {
-    h1s::HalfX xr; h1s::HalfU urf;
-    h1s::load_half(side, P.x_ref + b * P.x_ref_stride + N * H1_NX, xr);
-    urf.u11 = 0.0;
-#pragma unroll
-    for (int k = 0; k < 5; ++k) urf.uL[k] = 0.0;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) urf.uA[k] = 0.0;
-    c += knot_cost_half(P, b, N, side, h, nullptr, com, xr, urf);
-  }
-  c = h1s::pair_sum(c);
-  if (!side) cost_out[b] = c;
+}
+__global__ void __launch_bounds__(64) k_count_iter(DevState S, int mode) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < S.B && sel_s(S, b, mode)) S.iters[b] += 1;
 }
 
 static inline int cdiv_s(long a, long b) { return (int)((a + b - 1) / b); }
@@ -287,7 +200,9 @@ void launch_line_search_s(const DevState& S, const ProblemDev& P, int mode, hipS
   hipLaunchKernelGGL(k_line_search_s, dim3(cdiv_s((long)S.B * 16, 64)), dim3(64), DYN_LDS_BYTES_S, st, S, P, mode);
 }
 void launch_rollout_s(const DevState& S, const ProblemDev& P, int mode, int do_roll, int count_iter, double* cost_out, hipStream_t st) {
-  hipLaunchKernelGGL(k_rollout_s, dim3(cdiv_s((long)S.B * 2, 64)), dim3(64), DYN_LDS_BYTES_S, st, S, P, mode, do_roll, count_iter, cost_out);
+  if (do_roll) hipLaunchKernelGGL(k_rollout_s, dim3(cdiv_s((long)S.B * 2, 64)), dim3(64), DYN_LDS_BYTES_S, st, S, P, mode, count_iter);
+  else if (count_iter) hipLaunchKernelGGL(k_count_iter, dim3(cdiv_s(S.B, 64)), dim3(64), 0, st, S, mode);
+  launch_nominal_costs(S, P, mode, cost_out, st);
 }
 
 }  // namespace ilqr

@@ -68,6 +68,7 @@ void launch_rollout_r(const DevState& S, const h1::ProblemDev& P, int mode, int 
 void launch_step_r(int count, const double* x, const double* u, const h1::DynParams& dyn, double* xn, hipStream_t st);
 void launch_last_step_r(const DevState& S, const h1::ProblemDev& P, hipStream_t st);
 void launch_cand_costs(const DevState& S, const h1::ProblemDev& P, int mode, hipStream_t st);
+void launch_nominal_costs(const DevState& S, const h1::ProblemDev& P, int mode, double* cost_out, hipStream_t st);
 void launch_line_search_r(const DevState& S, const h1::ProblemDev& P, int mode, hipStream_t st);
 void launch_lin_primal_r(const DevState& S, const h1::ProblemDev& P, int mode, hipStream_t st);
 int dyn_kernels_set_attr();
