@@ -216,7 +216,17 @@ def main():
             table[name] = dict(total_ms_per_step=total / args.steps, avg_launch_ms=avg_ms, launches=stage_n.get(full, 0.0),
                                tflops=tf, frac_compute=tf / FP64_PEAK_TFLOPS, gbs=gbs, frac_hbm=gbs / HBM_PEAK_GBS,
                                compute_unit=k["unit"], algorithmic_flops_per_launch=k["flops"], algorithmic_bytes_per_launch=k["bytes"])
-        dom_kernel = max(table, key=lambda n: table[n]["total_ms_per_step"])
+        # The linearisation pair, the cost quadratics and the nominal re-rollout run on three streams at the same time: their
+        # spans overlap, so the sum of the three is more than the device time the region takes.  "Largest device time" is taken
+        # on exclusive-equivalent time: the spans of the concurrent groups are scaled by (longest span / sum of spans), i.e.
+        # the region is counted once and split in proportion (rocprofv3's per-kernel totals, profiles/, rank the same way
+        # once the contention-inflated durations of these kernels are set against their stand-alone times).
+        conc = [n for n in table if n.startswith("k_lin_") or n.startswith("k_cost_quadratics") or n.startswith("k_rollout")]
+        tot = sum(table[n]["total_ms_per_step"] for n in conc)
+        scale = (max(table[n]["total_ms_per_step"] for n in conc) / tot) if tot > 0 else 1.0
+        for n in table:
+            table[n]["exclusive_ms_per_step"] = table[n]["total_ms_per_step"] * (scale if n in conc else 1.0)
+        dom_kernel = max(table, key=lambda n: table[n]["exclusive_ms_per_step"])
         d = table[dom_kernel]
         # the roof the dominant kernel sits closer to: fp64 compute (78.6 TFLOP/s, vector == matrix peak) or HBM
         if d["frac_compute"] >= d["frac_hbm"]:
@@ -229,10 +239,11 @@ def main():
                      "algorithmic_flops_per_launch": d["algorithmic_flops_per_launch"],
                      "algorithmic_bytes_per_launch": d["algorithmic_bytes_per_launch"],
                      "frac_compute": d["frac_compute"], "frac_hbm": d["frac_hbm"],
-                     "kernel_total_ms_per_step": d["total_ms_per_step"],
+                     "kernel_total_ms_per_step": d["total_ms_per_step"], "kernel_exclusive_ms_per_step": d["exclusive_ms_per_step"],
                      "note": "full-batch launches only (HIP events on the launch stream); traffic = 2 x FETCH_SIZE + WRITE_SIZE of a full-batch launch (x 1 / batch_slices when the solve is sliced) from "
                              "separate rocprofv3 --pmc passes of this command (profiles/traffic_latest.json), null if not collected; "
-                             "cost quadratics and linearisation overlap on two streams, so their stage times include contention"})
+                             "linearisation, cost quadratics and nominal re-rollout overlap on three streams: their spans include contention, the dominant "
+                             "kernel is chosen on exclusive-equivalent time (kernels.*.exclusive_ms_per_step)"})
         out = {
             "metric": "iLQR iterations/sec (H1 nx=51 nu=19 N=%d)" % N, "value": value, "unit": "iterations/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
@@ -244,7 +255,7 @@ def main():
                        "jacobians": "forward differences (contact mode)" if args.contact else "analytic", "contact_mode": bool(args.contact), "batch_slices": n_slices, "gather": "u0+cost" + ("+K0" if args.gather_gains else "")},
             "roofline": roof,
             "kernels": {n: {k: (round(v, 6) if isinstance(v, float) else v) for k, v in t.items() if k in
-                            ("total_ms_per_step", "avg_launch_ms", "frac_compute", "frac_hbm")} for n, t in table.items()},
+                            ("total_ms_per_step", "exclusive_ms_per_step", "avg_launch_ms", "frac_compute", "frac_hbm")} for n, t in table.items()},
             "stage_ms_per_step": {k: stage_ms[k] / args.steps for k in stage_ms},
             "early_exit": {"value": ee_iters / ee_elapsed, "unit": "iterations/s", "mean_iterations_per_solve": ee_iters / (world * B * ee_steps),
                            "ms_per_step": 1e3 * ee_elapsed / ee_steps,
