@@ -31,19 +31,19 @@ for _ in range(reps):
 dt = (time.perf_counter() - t0) / reps
 print("%s: %.3f ms per call (host-timed, includes sync)  K checksum %.9e" % (stage, dt * 1e3, float(np.abs(s.gains_K()[::97]).sum())))
 if os.environ.get("ILQR_QSTAMPS"):
-    names = ["load x,u", "base_kin (lane 0)", "point sets (3 lanes)", "jac columns", "contexts (lane 0)", "gradient", "hessian"]
+    names = ["load x,u", "base kinematics (lane = body, level-synchronous)", "point sets (lane = set x body)", "jac columns", "contexts (lane = term x joint)", "gradient", "hessian"]
     st = s.cost()[:7]
     for nme, v in zip(names, st):
         print("  %-24s %10.0f cycles  %5.1f %%" % (nme, v, 100 * v / st.sum()))
     print("  total %.0f cycles" % st.sum())
 if os.environ.get("ILQR_SSTAMPS"):
-    names = ["dx exchange", "K dx + reduce", "cost (+CoM)", "dynamics step", "store x"]
+    names = ["loads + dx exchange", "K dx + reduce", "cost (+CoM; one-lane kernel only)", "dynamics step", "store x"]
     st = s.cost()[:5]
     for nme, v in zip(names, st):
         print("  %-28s %10.0f cycles/step  %5.1f %%" % (nme, v / 25, 100 * v / st.sum()))
     print("  total %.0f cycles per step" % (st.sum() / 25))
 if os.environ.get("ILQR_LSTAMPS"):
-    names = ["load dump", "accumulate forces (lane 0)", "prologue (lane 0)", "Minv sweeps (25 lanes)", "tangent RNEA (47 lanes)", "apply Minv", "columns + store"]
+    names = ["load dump", "accumulate forces (level-synchronous)", "prologue (one lane)", "Minv sweeps (25 lanes)", "tangent RNEA (47 lanes)", "apply Minv (MFMA)", "columns + store"]
     st = s.cost()[:7]
     for nme, v in zip(names, st):
         print("  %-28s %10.0f cycles  %5.1f %%" % (nme, v, 100 * v / st.sum()))
