@@ -120,6 +120,23 @@ __global__ void __launch_bounds__(64, LINT_WAVES) k_lin_tangent(DevState S, Prob
 
 // Reference-style forward differences (RobotUtils::linearizeDynamicsFD, robot_utils.cpp:120-160):
 // thread per (rollout, knot, column); columns 0..50 = d/dx, 51..69 = d/du.
+// The unperturbed step f(x_t, u_t) is evaluated once per knot (k_fd_base, thread per knot, into the first 51 slots of the
+// knot's lin_dump record, unused in this mode) -- as the reference does (robot_utils.cpp:126) -- not once per column.
+__global__ void __launch_bounds__(64) k_fd_base(DevState S, ProblemDev P, int mode) {
+  const long item = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (item >= (long)S.B * S.N) return;
+  const int t = (int)(item % S.N);
+  const int b = (int)(item / S.N);
+  if (!selected(S, b, mode)) return;
+  const double* xg = S.xbar + ((size_t)b * (S.N + 1) + t) * H1_NX;
+  const double* ug = S.ubar + ((size_t)b * S.N + t) * H1_NU;
+  double x[H1_NX], u[H1_NU], base[H1_NX];
+  for (int i = 0; i < H1_NX; ++i) x[i] = xg[i];
+  for (int i = 0; i < H1_NU; ++i) u[i] = ug[i];
+  step<double>(x, u, P.dyn, base, P.stance + b * P.stance_stride + 2 * t);
+  double* out = S.lin_dump + (size_t)item * LinDumpG_SIZE;
+  for (int i = 0; i < H1_NX; ++i) out[i] = base[i];
+}
 __global__ void __launch_bounds__(256) k_linearize_fd(DevState S, ProblemDev P, int mode, double eps) {
   const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const int NC = H1_NX + H1_NU;
@@ -132,13 +149,13 @@ __global__ void __launch_bounds__(256) k_linearize_fd(DevState S, ProblemDev P, 
   if (!selected(S, b, mode)) return;
   const double* xg = S.xbar + ((size_t)b * (S.N + 1) + t) * H1_NX;
   const double* ug = S.ubar + ((size_t)b * S.N + t) * H1_NU;
+  const double* base = S.lin_dump + (size_t)item * LinDumpG_SIZE;
   double* Ag = S.A + ((size_t)b * S.N + t) * H1_NX * H1_NX;
   double* Bg = S.Bm + ((size_t)b * S.N + t) * H1_NX * H1_NU;
-  double x[H1_NX], u[H1_NU], base[H1_NX], pert[H1_NX];
+  double x[H1_NX], u[H1_NU], pert[H1_NX];
   for (int i = 0; i < H1_NX; ++i) x[i] = xg[i];
   for (int i = 0; i < H1_NU; ++i) u[i] = ug[i];
   const int* stance = P.stance + b * P.stance_stride + 2 * t;
-  step<double>(x, u, P.dyn, base, stance);
   if (col < H1_NX) x[col] += eps; else u[col - H1_NX] += eps;
   step<double>(x, u, P.dyn, pert, stance);
   if (col < H1_NX) { for (int i = 0; i < H1_NX; ++i) Ag[i * H1_NX + col] = (pert[i] - base[i]) / eps; }
@@ -495,6 +512,7 @@ void launch_linearize(const DevState& S, const ProblemDev& P, int mode, int jac_
     if (phases & 2) hipLaunchKernelGGL(k_lin_tangent, dim3(S.N, S.B), dim3(64), 0, st, S, P, mode);
   } else if (phases & 2) {
     const long total = (long)S.B * S.N * (H1_NX + H1_NU);
+    hipLaunchKernelGGL(k_fd_base, dim3(cdiv((long)S.B * S.N, 64)), dim3(64), 0, st, S, P, mode);
     hipLaunchKernelGGL(k_linearize_fd, dim3(cdiv(total, 256)), dim3(256), 0, st, S, P, mode, eps);
   }
 }
