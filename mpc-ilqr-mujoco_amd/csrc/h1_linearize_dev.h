@@ -25,6 +25,8 @@ enum { LinDumpG_R0 = 0, LinDumpG_aL = 9, LinDumpG_qacc = 12, LinDumpG_sc = 37, L
 
 #define LIN_NDIR 47   // tangent directions: phi(3) theta(19) v_lin(3) omega(3) thetadot(19)
 #define LIN_LD 48     // padded lane stride of the direction arrays
+// packed index of the symmetric Minv (row r, column c in either order)
+#define MINV_IDX(r, c) ((r) >= (c) ? ((r) * ((r) + 1) / 2 + (c)) : ((c) * ((c) + 1) / 2 + (r)))
 
 // primal quantities of the knot every phase needs (subset of KnotDump)
 struct LinDump {
@@ -39,7 +41,7 @@ struct LinShared {
     struct { double U[H1_NB][6], Dinv[H1_NB], IA0inv[36]; } m;      // Minv sweeps only: articulated-body U_i, 1 / D_i, pelvis inverse
     struct { double part[4][6][19], part11[2][19]; } t;             // tangent sweeps only: pelvis / torso-hinge shares of the four
   } u;                                                              // chain groups (LL, RL, torso+LA, torso+RA) per group slot
-  double Minv[H1_NV][H1_NV];     // d qacc / d tau in MuJoCo coordinates
+  double Minv[H1_NV * (H1_NV + 1) / 2];   // d qacc / d tau in MuJoCo coordinates: symmetric, lower triangle packed (MINV)
   double dT[H1_NV][LIN_LD];      // tangent generalized forces, then d qacc / d direction
   double Iv[H1_NB][6];           // I_i v_i (momentum of body i), shared by every tangent direction
   double xa[H1_NB][6];           // X_i a_parent(i): the parent's acceleration in body i's frame
@@ -370,7 +372,7 @@ template <int FIRST, int LEN> struct MinvChainOut {
     for (int q = 0; q < 6; ++q) s -= L.u.m.U[I][q] * a[q];
     const double qdd = s * L.u.m.Dinv[I];
     a[ax] += qdd;
-    L.Minv[5 + I][lane] = qdd;
+    if (5 + I >= lane) L.Minv[MINV_IDX(5 + I, lane)] = qdd;
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (K + 1 < LEN) step<K + 1>(L, P, a, lane);
   }
@@ -417,8 +419,11 @@ DEVFN void lin_minv_lane(LinShared& L, int lane) {
     for (int k = 0; k < 6; ++k) s += L.u.m.IA0inv[6 * r + k] * rhs[k];
     a0[r] = s; }
   double lw[3]; mv3(L.D.R0, a0 + 3, lw);
-  L.Minv[0][lane] = lw[0]; L.Minv[1][lane] = lw[1]; L.Minv[2][lane] = lw[2];
-  L.Minv[3][lane] = a0[0]; L.Minv[4][lane] = a0[1]; L.Minv[5][lane] = a0[2];
+  // column `lane` of Minv: only the entries on and below the diagonal are kept (row r < lane is column r's entry)
+#pragma unroll
+  for (int r = 0; r < 3; ++r) if (r >= lane) L.Minv[MINV_IDX(r, lane)] = lw[r];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) if (3 + r >= lane) L.Minv[MINV_IDX(3 + r, lane)] = a0[r];
   double a11[6];
   {  // torso outward
     constexpr int I = 11, ax = h1c::C_AXIS[11];
@@ -429,7 +434,7 @@ DEVFN void lin_minv_lane(LinShared& L, int lane) {
     for (int q = 0; q < 6; ++q) s -= L.u.m.U[I][q] * a11[q];
     const double qdd = s * L.u.m.Dinv[I];
     a11[ax] += qdd;
-    L.Minv[5 + I][lane] = qdd;
+    if (5 + I >= lane) L.Minv[MINV_IDX(5 + I, lane)] = qdd;
   }
   MinvChainOut<12, 4>::step<0>(L, P, a11, lane);
   MinvChainOut<16, 4>::step<0>(L, P, a11, lane);
@@ -452,7 +457,7 @@ DEVFN void lin_apply_minv_lane(LinShared& L, int lane) {
 #pragma unroll
     for (int I = 0; I < 2; ++I) {
       const int r = 16 * I + lr, rc = r < H1_NV ? r : H1_NV - 1;
-      const double v = L.Minv[rc][kc];
+      const double v = L.Minv[MINV_IDX(rc, kc)];
       am[I][s] = (r < H1_NV && k < H1_NV) ? -v : 0.0;
     }
 #pragma unroll
@@ -597,7 +602,7 @@ DEVFN void lin_column(const LinShared& L, int is_u, int k, Out&& out) {
 #pragma unroll
   for (int r = 0; r < H1_NV; ++r) {
     double dq;
-    if (is_u) dq = L.Minv[r][6 + k] * fu;
+    if (is_u) dq = L.Minv[MINV_IDX(r, 6 + k)] * fu;
     else if (k < 3) dq = 0.0;
     else if (k < 7) dq = L.dT[r][0] * dphi[0] + L.dT[r][1] * dphi[1] + L.dT[r][2] * dphi[2];
     else dq = L.dT[r][src];

@@ -55,7 +55,7 @@ int main() {
       for (int r = 0; r < H1_NV; ++r) Mref[r][c] = y[r] - y0[r];
     }
     for (int lane = 0; lane < 64; ++lane) lin_minv_lane(L, lane);
-    { double em = 0; for (int r = 0; r < H1_NV; ++r) for (int c = 0; c < H1_NV; ++c) em = std::fmax(em, std::fabs(Mref[r][c] - L.Minv[r][c])); printf("  Minv sweep vs unit-force differences: %.3e\n", em); }
+    { double em = 0; for (int r = 0; r < H1_NV; ++r) for (int c = 0; c < H1_NV; ++c) em = std::fmax(em, std::fabs(Mref[r][c] - L.Minv[MINV_IDX(r, c)])); printf("  Minv sweep vs unit-force differences: %.3e\n", em); }
     lin_prologue(L);
     for (int lane = 0; lane < 64; ++lane) lin_tangent_zero(L, lane);
     for (int lane = 0; lane < 64; ++lane) lin_tangent_chains(L, lane);
