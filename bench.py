@@ -261,7 +261,7 @@ def main():
                            "ms_per_step": 1e3 * ee_elapsed / ee_steps,
                            "note": "same step with the reference's convergence exit (|dJ| < 1e-4) enabled: executed iterations per second; not the headline"},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # the CPU baseline is timed on rank 0 of the one-GPU run only
             try:
                 out["cpu_baseline"] = cpu_baseline(pkg, prob, x0, ui, iters, args.cpu_seconds)
             except Exception as e:  # the oracle is optional test infrastructure
