@@ -474,8 +474,9 @@ __global__ void k_pack_first_knot(DevState S, double* u0, double* K0) {
 }
 
 // ------------------------------------------------------------------ launchers
-// defaults measured on MI355X at B = 4096 (time per launch): rollout one lane 1.18 ms, two lanes 0.78 ms;
-// line search one lane per candidate 2.71 ms, two lanes 2.95 ms
+// defaults measured on MI355X at B = 4096 (time per full launch): rollout one lane 1.18 ms, two lanes 0.78 ms (0.4 ms
+// without the in-kernel cost); line search one lane per candidate 2.35 ms, two lanes per candidate with side-owned
+// feedback rows + parallel candidate costs 1.69 ms
 #ifndef ROLLOUT_SPLIT_DEFAULT
 #define ROLLOUT_SPLIT_DEFAULT 1
 #endif
