@@ -213,7 +213,9 @@ def main():
             avg_ms = stage_ms.get(full, 0.0) / max(stage_n.get(full, 0.0), 1.0)
             tf = k["flops"] / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
             gbs = k["bytes"] / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+            n_all = sum(stage_n.get(x, 0.0) for x in k["stages"])
             table[name] = dict(total_ms_per_step=total / args.steps, avg_launch_ms=avg_ms, launches=stage_n.get(full, 0.0),
+                               avg_launch_ms_all_passes=(total / n_all if n_all > 0 else 0.0),   # first + lambda-retry launches, as rocprofv3 --stats averages them
                                tflops=tf, frac_compute=tf / FP64_PEAK_TFLOPS, gbs=gbs, frac_hbm=gbs / HBM_PEAK_GBS,
                                compute_unit=k["unit"], algorithmic_flops_per_launch=k["flops"], algorithmic_bytes_per_launch=k["bytes"])
         # The linearisation pair, the cost quadratics and the nominal re-rollout run on three streams at the same time: their
@@ -236,6 +238,7 @@ def main():
         m = measured.get(dom_kernel.split("+")[-1])
         roof["traffic"] = None if m is None else (2.0 * 1024.0 * m["FETCH_SIZE_KiB"] + 1024.0 * m["WRITE_SIZE_KiB"]) / n_slices
         roof.update({"kernel": dom_kernel, "compute_unit": d["compute_unit"], "avg_launch_ms": d["avg_launch_ms"], "launches": d["launches"],
+                     "avg_launch_ms_all_passes": d["avg_launch_ms_all_passes"],
                      "algorithmic_flops_per_launch": d["algorithmic_flops_per_launch"],
                      "algorithmic_bytes_per_launch": d["algorithmic_bytes_per_launch"],
                      "frac_compute": d["frac_compute"], "frac_hbm": d["frac_hbm"],
