@@ -51,13 +51,17 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(pkg, prob, x0, ui, iters, budget_s):
+def cpu_baseline(pkg, prob, x0, ui, iters, budget_s, contact=False):
     """Oracle (CPU restatement, kind 'port') timed on the host cores on a bounded sample of the same batch."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as ol
     o = ol.Oracle(prob["N"], prob["dt"])
     o.set_problem(prob)
-    o.set_options(max_iter=iters, early_exit=0)
+    if contact:      # same plant and the same kind of Jacobians as the GPU's contact mode
+        o.set_contact_mode(1)
+        o.set_options(max_iter=iters, early_exit=0, jac_mode=1, fd_eps=1e-5)
+    else:
+        o.set_options(max_iter=iters, early_exit=0)
     cores = ol.max_threads()
     n0 = max(cores, 1)
     t0 = time.perf_counter()
@@ -69,7 +73,7 @@ def cpu_baseline(pkg, prob, x0, ui, iters, budget_s):
     tot1, *_ = o.batch_solve(x0[:n1], ui[:n1], nthreads=cores)
     dt1 = time.perf_counter() - t0
     return dict(value=tot1 / dt1, unit="iLQR iterations/s", cores=int(cores), kind="port",
-                sample="oracle (CPU restatement, analytic-AD Jacobians) on the first %d rollouts of the same batch, %d fixed iterations each, OpenMP over rollouts, %.1f s" % (n1, iters, dt1))
+                sample="oracle (CPU restatement, " + ("rigid-stance plant, forward-difference Jacobians" if contact else "analytic-AD Jacobians") + ") on the first %d rollouts of the same batch, %d fixed iterations each, OpenMP over rollouts, %.1f s" % (n1, iters, dt1))
 
 
 def main():
@@ -266,7 +270,7 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:   # the CPU baseline is timed on rank 0 of the one-GPU run only
             try:
-                out["cpu_baseline"] = cpu_baseline(pkg, prob, x0, ui, iters, args.cpu_seconds)
+                out["cpu_baseline"] = cpu_baseline(pkg, prob, x0, ui, iters, args.cpu_seconds, contact=args.contact)
             except Exception as e:  # the oracle is optional test infrastructure
                 out["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(out))
