@@ -60,8 +60,8 @@ def cpu_baseline(pkg, prob, x0, ui, iters, budget_s, contact=False):
     if contact:      # same plant and the same kind of Jacobians as the GPU's contact mode
         o.set_contact_mode(1)
         o.set_options(max_iter=iters, early_exit=0, jac_mode=1, fd_eps=1e-5)
-    else:
-        o.set_options(max_iter=iters, early_exit=0)
+    else:            # Jacobians by forward differences, eps 1e-5: the reference's own scheme (robot_utils.cpp:120-160) and the
+        o.set_options(max_iter=iters, early_exit=0, jac_mode=1, fd_eps=1e-5)   # faster of the oracle's two modes on a CPU
     cores = ol.max_threads()
     n0 = max(cores, 1)
     t0 = time.perf_counter()
@@ -73,7 +73,7 @@ def cpu_baseline(pkg, prob, x0, ui, iters, budget_s, contact=False):
     tot1, *_ = o.batch_solve(x0[:n1], ui[:n1], nthreads=cores)
     dt1 = time.perf_counter() - t0
     return dict(value=tot1 / dt1, unit="iLQR iterations/s", cores=int(cores), kind="port",
-                sample="oracle (CPU restatement, " + ("rigid-stance plant, forward-difference Jacobians" if contact else "analytic-AD Jacobians") + ") on the first %d rollouts of the same batch, %d fixed iterations each, OpenMP over rollouts, %.1f s" % (n1, iters, dt1))
+                sample="oracle (CPU restatement, " + ("rigid-stance plant, forward-difference Jacobians" if contact else "forward-difference Jacobians as in the reference; its forward-mode-AD variant is ~2x slower") + ") on the first %d rollouts of the same batch, %d fixed iterations each, OpenMP over rollouts, %.1f s" % (n1, iters, dt1))
 
 
 def main():
