@@ -45,7 +45,12 @@ def parse():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--print-signature", action="store_true", help="print the run signature tools/pmc_summary.py --stamp expects, and exit")
+    ap.add_argument("--rehearse-single-gpu", action="store_true",
+                    help="rehearsal of the N > 1 path on a one-GPU box: every rank uses device 0, gloo instead of RCCL, payload staged through the host")
     ap.add_argument("--gather-gains", action="store_true", help="include K0[19x51] in the per-step gather payload")
+    ap.add_argument("--stage", choices=["full", "rollout_jacobians"], default="full",
+                    help="full (headline) or BASELINE.json configs[1]: forward rollout + Jacobians only (use with --batch 1024)")
     ap.add_argument("--contact", action="store_true",
                     help="not the headline: contact row f4 (rigid stance on the scheduled feet, physical gravity, scalar kernels, forward-difference Jacobians)")
     return ap.parse_args()
@@ -76,8 +81,64 @@ def cpu_baseline(pkg, prob, x0, ui, iters, budget_s, contact=False):
                 sample="oracle (CPU restatement, " + ("rigid-stance plant, forward-difference Jacobians" if contact else "forward-difference Jacobians as in the reference; its forward-mode-AD variant is ~2x slower") + ") on the first %d rollouts of the same batch, %d fixed iterations each, OpenMP over rollouts, %.1f s" % (n1, iters, dt1))
 
 
+def run_signature(args, n_slices):
+    """What a PMC traffic record must have been collected on to describe this run (tools/pmc_summary.py --stamp)."""
+    return {"batch": args.batch, "horizon": args.horizon, "iters": args.iters, "contact": bool(args.contact), "slices": int(n_slices),
+            "backward": os.environ.get("ILQR_BACKWARD", "wave"), "ls": os.environ.get("ILQR_LS", "s"), "rollout": os.environ.get("ILQR_ROLLOUT", "s"),
+            "dyn": os.environ.get("ILQR_DYN", "")}
+
+
+def stage_bench(args, s, sv, x0_d, ui_d, B, N, world, rank, dev, prob):
+    """BASELINE.json configs[1]: forward rollout + Jacobians only (iLQR::forwardRolloutNominal + computeLinearization,
+    ilqr.cpp:119-131) over the batch; one step = cold-start rollout of every trajectory + A_t, B_t of every knot."""
+    import torch
+    import torch.distributed as dist
+
+    def one():
+        s.initialize_device(x0_d.data_ptr(), ui_d.data_ptr())     # N rollout steps per trajectory (enqueued on the handle's stream)
+        s.stage_linearize()                                       # A_t, B_t for all knots; synchronises the stream
+    for _ in range(max(1, args.warmup)):
+        one()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([el], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+    A, Bm = s.linearization()
+    assert np.all(np.isfinite(A)) and np.all(np.isfinite(Bm))
+    if rank == 0:
+        ms = 1e3 * el / args.steps
+        by = 8.0 * B * N * (70 + 493 + 493 + 70 + 2601 + 969)
+        fl = (JACOBIAN_FLOPS_PER_KNOT + STEP_FLOPS) * N * B
+        print(json.dumps({
+            "metric": "rollout + Jacobian passes/sec (H1 nx=51 nu=19 N=%d)" % N, "value": world * B * args.steps / el, "unit": "trajectories/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "BASELINE.json configs[1]: batch=%d H1 standing rollouts, N=%d, forward rollout + analytic Jacobians only, gravity %s" % (B, N, list(prob["gravity"])),
+                       "batch_per_gpu": B, "horizon": N},
+            "roofline": {"bound": "mfma", "achieved": fl / (ms * 1e-3) / 1e12, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": fl / (ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
+                         "frac_hbm": by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                         "note": "whole step (rollout + primal dump + tangent sweeps), host-timed; algorithmic flops = (12 k + 120 k) per knot (SURVEY 8(d) planning figures)"}}))
+    s.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
+    if args.print_signature:
+        slices = max(1, int(os.environ.get("ILQR_SLICES", "1")))
+        print(json.dumps(run_signature(args, slices), sort_keys=True))
+        return
     import torch
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -87,10 +148,15 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback in the product path)")
+    if args.rehearse_single_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.rehearse_single_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     import __graft_entry__ as ge
     pkg = ge._load_package()
@@ -101,8 +167,12 @@ def main():
 
     prob = sc.make_problem(sv.reference_kinematics, N=N, gravity=(0.0, 0.0, -9.81)) if args.contact else sc.make_problem(sv.reference_kinematics, N=N)
     ug = sv.gravity_compensation(sc.standing_state(), prob["gravity"])
-    # every rank draws its own shard of the global batch (contiguous rollout ranges)
-    x0, ui = sc.synthetic_batch(B, N, args.seed + rank, ug)
+    # ONE seeded global batch of world x B rollouts; rank r owns the contiguous range shard_range gives it,
+    # so a rollout's inputs -- and therefore its results -- do not depend on the number of GPUs
+    x0g, uig = sc.synthetic_batch(B * world, N, args.seed, ug)
+    lo, hi = sh.shard_range(B * world, rank, world)
+    x0, ui = np.ascontiguousarray(x0g[lo:hi]), np.ascontiguousarray(uig[lo:hi])
+    del x0g, uig
     s = sv.BatchedILQR(B, N=N, dt=prob["dt"], device=local_rank)
     s.set_problem(prob)
     s.set_max_iterations(iters)
@@ -122,18 +192,29 @@ def main():
 
     stage_ms, stage_n = {}, {}
 
+    if args.stage == "rollout_jacobians":
+        return stage_bench(args, s, sv, x0_d, ui_d, B, N, world, rank, dev, prob)
+
+    def record_stages():
+        ms, n = s.stage_ms()
+        for k in ms:
+            stage_ms[k] = stage_ms.get(k, 0.0) + ms[k]
+            stage_n[k] = stage_n.get(k, 0.0) + n[k]
+
     def one_step(timed):
+        # the previous step's payload copy / gather read u0_d, c_d, K0_d on torch's stream: let them finish before the
+        # library's own stream overwrites those buffers
+        torch.cuda.current_stream().synchronize()
         s.initialize_device(x0_d.data_ptr(), ui_d.data_ptr())
         s.solve_async()
         s.synchronize()
         s.pack_first_knot_device(u0_d.data_ptr(), None if K0_d is None else K0_d.data_ptr(), c_d.data_ptr())
         sh.pack_payload(payload, u0_d, c_d, K0_d)
-        sh.gather_first_knot(payload, dst=0)        # the ONE collective of an MPC step (RCCL over xGMI)
+        # the ONE collective of an MPC step (RCCL over xGMI; host-staged over gloo in the one-GPU rehearsal)
+        g = sh.gather_first_knot(payload.cpu() if args.rehearse_single_gpu else payload, dst=0)
         if timed:
-            ms, n = s.stage_ms()
-            for k in ms:
-                stage_ms[k] = stage_ms.get(k, 0.0) + ms[k]
-                stage_n[k] = stage_n.get(k, 0.0) + n[k]
+            record_stages()
+        return g
 
     for _ in range(args.warmup):
         one_step(False)
@@ -156,6 +237,14 @@ def main():
     assert np.all(it_done == iters), "fixed-iteration mode must run exactly --iters iterations per rollout"
     cost = s.cost()
     assert np.all(np.isfinite(cost))
+    # one more (untimed) step whose gathered payload is checked: rank 0 holds world x B rows in global rollout order
+    gathered = one_step(False)
+    gather_check = None
+    if rank == 0:
+        g = gathered.cpu().numpy()
+        assert g.shape == (world * B, sh.payload_width(args.gather_gains)) and np.all(np.isfinite(g))
+        assert np.array_equal(g[lo:hi, 19], s.cost()) and np.array_equal(g[lo:hi, :19], s.ubar()[:, 0])
+        gather_check = "rank 0 received %d rows in global rollout order" % g.shape[0]
 
     # second number: the same MPC step with the reference's convergence exit enabled -- iterations
     # actually executed per second; not the headline value
@@ -208,8 +297,17 @@ def main():
             "k_rollout_s": dict(stages=["iLQR_computeCost+forwardRollout"], unit="fp64 VALU",
                                 flops=STEP_FLOPS * N * Bl, bytes=D * Bl * N * (51 + 19 + 51)),
         }
+        # measured HBM traffic: a replay of the builder's own rocprofv3 --pmc passes (profiles/traffic_latest.json), valid
+        # only for the run it was collected on -- the file carries the signature of that run and is ignored otherwise
         traffic_file = os.path.join(ROOT, "profiles", "traffic_latest.json")
         measured = json.load(open(traffic_file)) if os.path.exists(traffic_file) else {}
+        sig = run_signature(args, n_slices)
+        stamp = measured.get("_stamp")
+        traffic_reason = None
+        if not measured:
+            traffic_reason = "profiles/traffic_latest.json not present"
+        elif stamp is None or any(stamp.get(k) != v for k, v in sig.items()):
+            traffic_reason = "profiles/traffic_latest.json was collected on another configuration (%s), this run is %s" % (json.dumps(stamp, sort_keys=True), json.dumps(sig, sort_keys=True))
         table = {}
         for name, k in kernels.items():
             total = sum(stage_ms.get(x, 0.0) for x in k["stages"])
@@ -239,16 +337,21 @@ def main():
             roof = {"bound": "mfma", "achieved": d["tflops"], "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": d["frac_compute"]}
         else:
             roof = {"bound": "hbm", "achieved": d["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": d["frac_hbm"]}
-        m = measured.get(dom_kernel.split("+")[-1])
-        roof["traffic"] = None if m is None else (2.0 * 1024.0 * m["FETCH_SIZE_KiB"] + 1024.0 * m["WRITE_SIZE_KiB"]) / n_slices
+        members = [measured.get(k) for k in dom_kernel.split("+")]     # a '+'-joined group: the sum of its member kernels
+        if traffic_reason is None and all(m is not None for m in members):
+            roof["traffic"] = sum(2.0 * 1024.0 * m["FETCH_SIZE_KiB"] + 1024.0 * m["WRITE_SIZE_KiB"] for m in members)
+            roof["traffic_source"] = "profiles/traffic_latest.json (builder's rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command: %s)" % json.dumps(stamp, sort_keys=True)
+        else:
+            roof["traffic"] = None
+            roof["traffic_source"] = traffic_reason or "no PMC record for %s" % dom_kernel
         roof.update({"kernel": dom_kernel, "compute_unit": d["compute_unit"], "avg_launch_ms": d["avg_launch_ms"], "launches": d["launches"],
                      "avg_launch_ms_all_passes": d["avg_launch_ms_all_passes"],
                      "algorithmic_flops_per_launch": d["algorithmic_flops_per_launch"],
                      "algorithmic_bytes_per_launch": d["algorithmic_bytes_per_launch"],
                      "frac_compute": d["frac_compute"], "frac_hbm": d["frac_hbm"],
                      "kernel_total_ms_per_step": d["total_ms_per_step"], "kernel_exclusive_ms_per_step": d["exclusive_ms_per_step"],
-                     "note": "full-batch launches only (HIP events on the launch stream); traffic = 2 x FETCH_SIZE + WRITE_SIZE of a full-batch launch (x 1 / batch_slices when the solve is sliced) from "
-                             "separate rocprofv3 --pmc passes of this command (profiles/traffic_latest.json), null if not collected; "
+                     "note": "full-batch launches only (HIP events on the launch stream); traffic = 2 x FETCH_SIZE + WRITE_SIZE of a full-batch launch from "
+                             "separate rocprofv3 --pmc passes of this command (see traffic_source), null when no record matches this run; "
                              "linearisation, cost quadratics and nominal re-rollout overlap on three streams: their spans include contention, the dominant "
                              "kernel is chosen on exclusive-equivalent time (kernels.*.exclusive_ms_per_step)"})
         out = {
@@ -259,7 +362,8 @@ def main():
                                    "H1 standing balance, N=%d, dt=0.02, %d fixed iterations per rollout, shipped config.yaml weights, gravity %s"
                                    % (B, N, iters, list(prob["gravity"])),
                        "batch_per_gpu": B, "global_batch": B * world, "horizon": N, "iterations_per_solve": iters,
-                       "jacobians": "forward differences (contact mode)" if args.contact else "analytic", "contact_mode": bool(args.contact), "batch_slices": n_slices, "gather": "u0+cost" + ("+K0" if args.gather_gains else "")},
+                       "jacobians": "forward differences (contact mode)" if args.contact else "analytic", "contact_mode": bool(args.contact), "batch_slices": n_slices, "gather": "u0+cost" + ("+K0" if args.gather_gains else ""), "gather_check": gather_check,
+                       "collective": ("none (one GPU)" if world == 1 else "gloo, host-staged (one-GPU rehearsal)" if args.rehearse_single_gpu else "RCCL gather to rank 0")},
             "roofline": roof,
             "kernels": {n: {k: (round(v, 6) if isinstance(v, float) else v) for k, v in t.items() if k in
                             ("total_ms_per_step", "exclusive_ms_per_step", "avg_launch_ms", "frac_compute", "frac_hbm")} for n, t in table.items()},

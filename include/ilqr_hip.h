@@ -117,6 +117,24 @@ int ilqr_hip_first_knot_device(ilqr_hip_ctx* ctx, const double** u0_device, cons
    u0_out[B][19], K0_out[B][19][51] (nullable), cost_out[B] (nullable); synchronises the handle's stream */
 int ilqr_hip_pack_first_knot_device(ilqr_hip_ctx* ctx, double* u0_out_device, double* K0_out_device, double* cost_out_device);
 
+/* ---- multi-GPU: one handle per GPU, one process or thread per handle.  The reference is single
+   process; its consumer of the result is MPC::stepOnce (src/ilqr/mpc.cpp:97-113: u_apply from ubar[0], K[0]).  The global
+   batch is cut into contiguous shards, rank r owning rollouts [r B, (r + 1) B); the only exchange is ONE gather per MPC
+   step of the first-knot payload row [u0(19) | cost | K0(19 x 51) if with_gains] of every rollout to `root`, in global
+   rollout order -- RCCL grouped send/recv over xGMI on the handle's stream.  librccl is opened on first use.
+     rank 0: ilqr_hip_comm_get_unique_id(id) -> hand the 128 bytes to every rank (file, socket, MPI, torch.distributed ...)
+     all   : ilqr_hip_comm_init(ctx, world, rank, id)        (world == 1: no RCCL, the gather is a device copy)
+     step  : solve ...; ilqr_hip_gather_first_knot(ctx, root, with_gains, recv); ilqr_hip_synchronize(ctx)
+   recv_device (root only, else NULL): device buffer [world * B][ilqr_hip_payload_width(with_gains)]. */
+#define ILQR_COMM_ID_BYTES 128
+int ilqr_hip_payload_width(int with_gains);
+int ilqr_hip_comm_get_unique_id(char* id /*[ILQR_COMM_ID_BYTES]*/);
+int ilqr_hip_comm_init(ilqr_hip_ctx* ctx, int world, int rank, const char* id /*[ILQR_COMM_ID_BYTES], may be NULL when world == 1*/);
+int ilqr_hip_comm_destroy(ilqr_hip_ctx* ctx);
+int ilqr_hip_comm_world(const ilqr_hip_ctx* ctx);
+int ilqr_hip_comm_rank(const ilqr_hip_ctx* ctx);
+int ilqr_hip_gather_first_knot(ilqr_hip_ctx* ctx, int root, int with_gains, double* recv_device);
+
 /* MPC::stepOnce control law u = ubar[0] + K[0](x_meas - xbar[0]) -- src/ilqr/mpc.cpp:97-101 */
 int ilqr_hip_compute_control(ilqr_hip_ctx* ctx, const double* x_measured /*[B][51]*/, double* u_apply /*[B][19]*/);
 
@@ -153,6 +171,10 @@ int ilqr_hip_step_stance(ilqr_hip_ctx* ctx, int count, const double* x, const do
    4 lineSearch, 5 control, 6 backwardPass (lambda-retry launch), 7 lineSearch (lambda-retry launch);
    requires ilqr_hip_enable_profiling(ctx, 1) before the solve */
 int ilqr_hip_enable_profiling(ilqr_hip_ctx* ctx, int on);
+/* Diagnostic of the concurrent nominal re-rollout (iterations >= 1 of a solve roll the nominal trajectory beside the
+   linearisation, ilqr.cpp:563 vs :576): number of trajectory elements of the last solve in which the re-rolled trajectory
+   differed bit-wise from the one the linearisation saw.  0 means the launch order is equivalent to the reference's. */
+int ilqr_hip_get_adopt_mismatches(ilqr_hip_ctx* ctx, unsigned long long* count);
 int ilqr_hip_get_stage_ms(ilqr_hip_ctx* ctx, double* ms /*[8]*/, double* launches /*[8]*/);
 
 /* ---- host-side model helpers (no GPU needed) ---- */

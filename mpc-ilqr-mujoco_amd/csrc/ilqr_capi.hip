@@ -2,6 +2,8 @@
 // host-side orchestration of iLQR::solve (reference src/ilqr/ilqr.cpp:521-660) as a fixed stream of
 // kernel launches with per-rollout masks on the device -- no host round trip inside a solve.
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>   // types and prototypes only: librccl is opened lazily (ilqr_hip_comm_*), never linked
+#include <dlfcn.h>
 #include <cstdlib>
 
 #include <cmath>
@@ -32,6 +34,14 @@ struct ilqr_hip_ctx {
   int n_xref = 0, n_stance = 0, n_ee = 0;
   // scratch
   double *d_tmpx = nullptr, *d_tmpu = nullptr, *d_prevx = nullptr, *d_prevu = nullptr, *d_u0 = nullptr, *d_K0 = nullptr, *d_cost_tmp = nullptr;
+  double *d_stepx = nullptr, *d_stepu = nullptr, *d_stepn = nullptr;   // ilqr_hip_step* scratch, grown on demand
+  size_t step_cap = 0;
+  unsigned long long* d_mismatch = nullptr;
+  // multi-GPU: RCCL communicator of this handle's rank and the packed first-knot payload it sends
+  ncclComm_t comm = nullptr;
+  int world = 1, rank = 0;
+  double* d_payload = nullptr;
+  size_t payload_cap = 0;   // elements in which a concurrent re-rollout differed from the trajectory it replaced
   int max_iter = 10;
   double tol = 1e-4;
   int jac_mode = ILQR_JAC_ANALYTIC;
@@ -72,14 +82,20 @@ template <class T> static int dalloc(ilqr_hip_ctx* c, T** p, size_t count) {
 #define TRY(x) do { int r_ = (x); if (r_ != ILQR_OK) return r_; } while (0)
 
 static hipEvent_t next_event(ilqr_hip_ctx* c) {
-  if (c->pool_next == c->pool.size()) { hipEvent_t e; hipEventCreate(&e); c->pool.push_back(e); }
+  if (c->pool_next == c->pool.size()) {
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) { c->err = "hipEventCreate failed (profiling events)"; return nullptr; }
+    c->pool.push_back(e);
+  }
   return c->pool[c->pool_next++];
 }
 struct StageTimer {
   ilqr_hip_ctx* c; int stage; hipStream_t st; hipEvent_t a{}, b{};
-  StageTimer(ilqr_hip_ctx* c_, int s, hipStream_t st_ = nullptr) : c(c_), stage(s), st(st_ ? st_ : c_->stream) { if (c->profiling) { a = next_event(c); b = next_event(c); hipEventRecord(a, st); } }
-  ~StageTimer() { if (c->profiling) { hipEventRecord(b, st); c->spans.push_back({stage, a, b}); } }
+  StageTimer(ilqr_hip_ctx* c_, int s, hipStream_t st_ = nullptr) : c(c_), stage(s), st(st_ ? st_ : c_->stream) { if (c->profiling) { a = next_event(c); b = next_event(c); if (a && b) hipEventRecord(a, st); } }
+  ~StageTimer() { if (c->profiling && a && b) { hipEventRecord(b, st); c->spans.push_back({stage, a, b}); } }
 };
+
+static inline void enter(const ilqr_hip_ctx* c) { hipSetDevice(c->device); ilqr::refresh_variants(); }
 
 extern "C" {
 
@@ -108,7 +124,7 @@ int ilqr_hip_create(ilqr_hip_ctx** out, int device, int batch, int horizon, doub
   A(dalloc(c, &S.trace_cost, B * (c->max_iter + 1))); A(dalloc(c, &S.trace_alpha, B * c->max_iter)); A(dalloc(c, &S.trace_lambda, B * c->max_iter));
   A(dalloc(c, &c->d_tmpx, B * (N + 1) * n)); A(dalloc(c, &c->d_tmpu, B * N * m));
   A(dalloc(c, &c->d_prevx, B * (N + 1) * n)); A(dalloc(c, &c->d_prevu, B * N * m)); A(dalloc(c, &c->d_shadowx, B * (N + 1) * n));
-  A(dalloc(c, &c->d_u0, B * m)); A(dalloc(c, &c->d_K0, B * m * n)); A(dalloc(c, &c->d_cost_tmp, B));
+  A(dalloc(c, &c->d_u0, B * m)); A(dalloc(c, &c->d_K0, B * m * n)); A(dalloc(c, &c->d_cost_tmp, B)); A(dalloc(c, &c->d_mismatch, 1));
   // shared reference sets sized for per-rollout use
   A(dalloc(c, &c->d_xref, B * (N + 1) * n)); A(dalloc(c, &c->d_uref, B * N * m)); A(dalloc(c, &c->d_comref, B * (N + 1) * 3));
   A(dalloc(c, &c->d_eeref, B * (N + 1) * 6)); A(dalloc(c, &c->d_comvelref, B * (N + 1) * 3)); A(dalloc(c, &c->d_stance, B * (N + 1) * 2));
@@ -134,12 +150,13 @@ int ilqr_hip_create(ilqr_hip_ctx** out, int device, int batch, int horizon, doub
 
 int ilqr_hip_destroy(ilqr_hip_ctx* c) {
   if (!c) return ILQR_ERR_ARG;
-  hipSetDevice(c->device);
+  enter(c);
   DevState& S = c->S;
   void* ptrs[] = {S.cand_knot, S.lin_dump, S.x0, S.xbar, S.ubar, S.xcand, S.ucand, S.cand_cost, S.A, S.Bm, S.lx, S.lu, S.lxx, S.luu, S.K, S.kff, S.Vx, S.Vxx, S.J, S.Jbase, S.ls_cost,
                   S.lambda, S.active, S.need_retry, S.iters, S.improved, S.alpha_idx, S.trace_cost, S.trace_alpha, S.trace_lambda, c->d_tmpx, c->d_tmpu,
-                  c->d_prevx, c->d_prevu, c->d_shadowx, c->d_u0, c->d_K0, c->d_cost_tmp, c->d_xref, c->d_uref, c->d_comref, c->d_eeref, c->d_comvelref, c->d_stance};
+                  c->d_prevx, c->d_prevu, c->d_shadowx, c->d_u0, c->d_K0, c->d_cost_tmp, c->d_stepx, c->d_stepu, c->d_stepn, c->d_mismatch, c->d_payload, c->d_xref, c->d_uref, c->d_comref, c->d_eeref, c->d_comvelref, c->d_stance};
   for (void* p : ptrs) if (p) hipFree(p);
+  if (c->comm) ilqr_hip_comm_destroy(c);
   for (hipEvent_t e : c->pool) hipEventDestroy(e);
   for (auto& sl : c->slices) { hipEventDestroy(sl.fork); hipEventDestroy(sl.join); hipEventDestroy(sl.done); hipEventDestroy(sl.lead); hipEventDestroy(sl.roll); hipStreamDestroy(sl.st3); hipStreamDestroy(sl.st2); hipStreamDestroy(sl.st); }
   if (c->ev_begin) hipEventDestroy(c->ev_begin);
@@ -174,7 +191,7 @@ static int check_sets(const ilqr_hip_ctx* c, int n_sets) { return (n_sets == 1 |
 
 int ilqr_hip_set_contact_schedule(ilqr_hip_ctx* c, const int* stance, int n_sets) {
   if (!c || !stance || check_sets(c, n_sets)) return ILQR_ERR_ARG;
-  hipSetDevice(c->device);
+  enter(c);
   const size_t per = (size_t)(c->N + 1) * 2;
   HIPCHK(c, hipMemcpyAsync(c->d_stance, stance, per * n_sets * sizeof(int), hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -183,7 +200,7 @@ int ilqr_hip_set_contact_schedule(ilqr_hip_ctx* c, const int* stance, int n_sets
 }
 int ilqr_hip_set_ee_references(ilqr_hip_ctx* c, const double* ee_ref, const double* com_vel_ref, int n_sets) {
   if (!c || !ee_ref || check_sets(c, n_sets)) return ILQR_ERR_ARG;
-  hipSetDevice(c->device);
+  enter(c);
   const size_t per = (size_t)(c->N + 1);
   HIPCHK(c, hipMemcpyAsync(c->d_eeref, ee_ref, per * 6 * n_sets * sizeof(double), hipMemcpyHostToDevice, c->stream));
   if (com_vel_ref) HIPCHK(c, hipMemcpyAsync(c->d_comvelref, com_vel_ref, per * 3 * n_sets * sizeof(double), hipMemcpyHostToDevice, c->stream));
@@ -195,7 +212,7 @@ int ilqr_hip_set_ee_references(ilqr_hip_ctx* c, const double* ee_ref, const doub
 }
 int ilqr_hip_set_references(ilqr_hip_ctx* c, const double* x_ref, const double* u_ref, const double* com_ref, int n_sets) {
   if (!c || !x_ref || !u_ref || !com_ref || check_sets(c, n_sets)) return ILQR_ERR_ARG;
-  hipSetDevice(c->device);
+  enter(c);
   const size_t N = c->N;
   HIPCHK(c, hipMemcpyAsync(c->d_xref, x_ref, (N + 1) * ILQR_NX * n_sets * sizeof(double), hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(c->d_uref, u_ref, N * ILQR_NU * n_sets * sizeof(double), hipMemcpyHostToDevice, c->stream));
@@ -210,7 +227,7 @@ int ilqr_hip_set_references(ilqr_hip_ctx* c, const double* x_ref, const double* 
 
 int ilqr_hip_set_regularization(ilqr_hip_ctx* c, double lambda) {
   if (!c) return ILQR_ERR_ARG;
-  hipSetDevice(c->device);
+  enter(c);
   std::vector<double> lam(c->B, lambda);
   HIPCHK(c, hipMemcpyAsync(c->S.lambda, lam.data(), c->B * sizeof(double), hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -218,7 +235,7 @@ int ilqr_hip_set_regularization(ilqr_hip_ctx* c, double lambda) {
 }
 int ilqr_hip_set_max_iterations(ilqr_hip_ctx* c, int max_iter) {
   if (!c || max_iter <= 0) return ILQR_ERR_ARG;
-  hipSetDevice(c->device);
+  enter(c);
   if (max_iter != c->max_iter) {
     hipFree(c->S.trace_cost); hipFree(c->S.trace_alpha); hipFree(c->S.trace_lambda);
     c->S.trace_cost = c->S.trace_alpha = c->S.trace_lambda = nullptr;
@@ -246,12 +263,12 @@ static int cold_start_device(ilqr_hip_ctx* c, const double* x0_dev, const double
 }
 int ilqr_hip_initialize_device(ilqr_hip_ctx* c, const double* x0_device, const double* u_init_device) {
   if (!c || !x0_device || !u_init_device) return ILQR_ERR_ARG;
-  hipSetDevice(c->device);
+  enter(c);
   return cold_start_device(c, x0_device, u_init_device);
 }
 int ilqr_hip_initialize(ilqr_hip_ctx* c, const double* x0, const double* u_init, const double* prev_xbar, const double* prev_ubar) {
   if (!c || !x0) return ILQR_ERR_ARG;
-  hipSetDevice(c->device);
+  enter(c);
   const size_t B = c->B, N = c->N;
   if (prev_xbar && prev_ubar) {
     HIPCHK(c, hipMemcpyAsync(c->S.x0, x0, B * ILQR_NX * sizeof(double), hipMemcpyHostToDevice, c->stream));
@@ -283,7 +300,7 @@ int ilqr_hip_initialize(ilqr_hip_ctx* c, const double* x0, const double* u_init,
 int ilqr_hip_initialize_warm_resident(ilqr_hip_ctx* c, const double* x0) {
   if (!c || !x0) return ILQR_ERR_ARG;
   if (!c->initialized) return ILQR_ERR_STATE;
-  hipSetDevice(c->device);
+  enter(c);
   const size_t B = c->B, N = c->N;
   HIPCHK(c, hipMemcpyAsync(c->S.x0, x0, B * ILQR_NX * sizeof(double), hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(c->d_prevx, c->S.xbar, B * (N + 1) * ILQR_NX * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
@@ -374,7 +391,9 @@ static int enqueue_solve(ilqr_hip_ctx* c, const DevState& S, const h1::ProblemDe
     // candidate, or the unchanged previous nominal), so the re-rollout reproduces it to rounding: it runs on a third
     // stream into a shadow buffer beside the linearisation and is adopted (with its cost, the line-search baseline)
     // before the backward pass.  ILQR_OVERLAP_ROLLOUT=0 restores the sequential order.
-    const bool concurrent_roll = iter > 0 && !reuse_rollout() && overlap_rollout() && !P.dyn.contact;
+    // (only while the line search and the rollout run the same step implementation: otherwise the re-rollout would differ in
+    // rounding from the trajectory the linearisation beside it sees)
+    const bool concurrent_roll = iter > 0 && !reuse_rollout() && overlap_rollout() && !P.dyn.contact && ilqr::variant_ls_split() == ilqr::variant_rollout_split();
     if ((iter == 0 || !reuse_rollout()) && !concurrent_roll) { StageTimer T(c, 0, st); ilqr::launch_rollout(S, P, ilqr::MASK_ACTIVE, 1, 0, S.Jbase, st); }
     if (iter == 0 && wait_lead) HIPCHK(c, hipStreamWaitEvent(st, wait_lead, 0));
     // linearisation (:576) and cost quadratics (:588) only depend on the rollout: run them concurrently
@@ -390,7 +409,7 @@ static int enqueue_solve(ilqr_hip_ctx* c, const DevState& S, const h1::ProblemDe
     HIPCHK(c, hipEventRecord(ev_join, st2));
     { StageTimer T(c, 1, st); ilqr::launch_linearize(S, P, ilqr::MASK_ACTIVE, c->jac_mode, c->fd_eps, st); }
     HIPCHK(c, hipStreamWaitEvent(st, ev_join, 0));
-    if (concurrent_roll) { HIPCHK(c, hipStreamWaitEvent(st, ev_roll, 0)); ilqr::launch_adopt_rollout(S, shadow, ilqr::MASK_ACTIVE, st); }
+    if (concurrent_roll) { HIPCHK(c, hipStreamWaitEvent(st, ev_roll, 0)); ilqr::launch_adopt_rollout(S, shadow, ilqr::MASK_ACTIVE, c->d_mismatch, st); }
     { StageTimer T(c, 3, st); ilqr::launch_backward(S, ilqr::MASK_ACTIVE, st); }                                  // :601
     if (iter == 0 && lead) HIPCHK(c, hipEventRecord(lead, st));
     { StageTimer T(c, 4, st); ilqr::launch_line_search(S, P, ilqr::MASK_ACTIVE, st); }                            // :616
@@ -405,10 +424,11 @@ int ilqr_hip_num_slices(const ilqr_hip_ctx* c) { return c ? slices_wanted(c->B) 
 int ilqr_hip_solve_async(ilqr_hip_ctx* c) {
   if (!c) return ILQR_ERR_ARG;
   if (!c->initialized || !c->refs_set) { c->err = "solve before initialize/set_references"; return ILQR_ERR_STATE; }
-  hipSetDevice(c->device);
+  enter(c);
   hipStream_t st = c->stream;
   const DevState& S = c->S; const h1::ProblemDev& P = c->P;
   c->spans.clear(); c->pool_next = 0;
+  HIPCHK(c, hipMemsetAsync(c->d_mismatch, 0, sizeof(unsigned long long), st));
   const int k = slices_wanted(c->B);
   c->n_slices = k;
   if (k <= 1) {
@@ -435,14 +455,14 @@ int ilqr_hip_solve_async(ilqr_hip_ctx* c) {
 }
 int ilqr_hip_synchronize(ilqr_hip_ctx* c) {
   if (!c) return ILQR_ERR_ARG;
-  hipSetDevice(c->device);
+  enter(c);
   HIPCHK(c, hipStreamSynchronize(c->stream));
   if (c->profiling) collect_profile(c);
   return ILQR_OK;
 }
 int ilqr_hip_solve(ilqr_hip_ctx* c, const double* x0, double* cost_out) {
   if (!c) return ILQR_ERR_ARG;
-  hipSetDevice(c->device);
+  enter(c);
   if (x0) HIPCHK(c, hipMemcpyAsync(c->S.x0, x0, (size_t)c->B * ILQR_NX * sizeof(double), hipMemcpyHostToDevice, c->stream));
   TRY(ilqr_hip_solve_async(c));
   TRY(ilqr_hip_synchronize(c));
@@ -454,7 +474,7 @@ int ilqr_hip_solve(ilqr_hip_ctx* c, const double* x0, double* cost_out) {
 #define GETTER(name, ptr, count, type)                                                                          \
   int name(ilqr_hip_ctx* c, type* out) {                                                                        \
     if (!c || !out) return ILQR_ERR_ARG;                                                                        \
-    hipSetDevice(c->device);                                                                                    \
+    enter(c);                                                                                    \
     HIPCHK(c, hipStreamSynchronize(c->stream));                                                                 \
     HIPCHK(c, hipMemcpy(out, c->S.ptr, (size_t)(count) * sizeof(type), hipMemcpyDeviceToHost));                 \
     return ILQR_OK;                                                                                             \
@@ -469,7 +489,7 @@ GETTER(ilqr_hip_get_lambda, lambda, c->B, double)
 
 int ilqr_hip_get_trace(ilqr_hip_ctx* c, double* cost, double* alpha, double* lambda) {
   if (!c) return ILQR_ERR_ARG;
-  hipSetDevice(c->device);
+  enter(c);
   HIPCHK(c, hipStreamSynchronize(c->stream));
   if (cost) HIPCHK(c, hipMemcpy(cost, c->S.trace_cost, (size_t)c->B * (c->max_iter + 1) * sizeof(double), hipMemcpyDeviceToHost));
   if (alpha) HIPCHK(c, hipMemcpy(alpha, c->S.trace_alpha, (size_t)c->B * c->max_iter * sizeof(double), hipMemcpyDeviceToHost));
@@ -478,7 +498,7 @@ int ilqr_hip_get_trace(ilqr_hip_ctx* c, double* cost, double* alpha, double* lam
 }
 int ilqr_hip_first_knot_device(ilqr_hip_ctx* c, const double** u0, const double** K0, const double** cost) {
   if (!c) return ILQR_ERR_ARG;
-  hipSetDevice(c->device);
+  enter(c);
   ilqr::launch_pack_first_knot(c->S, c->d_u0, c->d_K0, c->stream);
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -489,7 +509,7 @@ int ilqr_hip_first_knot_device(ilqr_hip_ctx* c, const double** u0, const double*
 }
 int ilqr_hip_pack_first_knot_device(ilqr_hip_ctx* c, double* u0_out, double* K0_out, double* cost_out) {
   if (!c || !u0_out) return ILQR_ERR_ARG;
-  hipSetDevice(c->device);
+  enter(c);
   ilqr::launch_pack_first_knot(c->S, u0_out, K0_out ? K0_out : c->d_K0, c->stream);
   HIPCHK(c, hipGetLastError());
   if (cost_out) HIPCHK(c, hipMemcpyAsync(cost_out, c->S.J, (size_t)c->B * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
@@ -498,7 +518,7 @@ int ilqr_hip_pack_first_knot_device(ilqr_hip_ctx* c, double* u0_out, double* K0_
 }
 int ilqr_hip_compute_control(ilqr_hip_ctx* c, const double* x_measured, double* u_apply) {
   if (!c || !x_measured || !u_apply) return ILQR_ERR_ARG;
-  hipSetDevice(c->device);
+  enter(c);
   HIPCHK(c, hipMemcpyAsync(c->d_tmpx, x_measured, (size_t)c->B * ILQR_NX * sizeof(double), hipMemcpyHostToDevice, c->stream));
   ilqr::launch_compute_control(c->S, c->d_tmpx, c->d_u0, c->stream);
   HIPCHK(c, hipGetLastError());
@@ -510,7 +530,7 @@ int ilqr_hip_compute_control(ilqr_hip_ctx* c, const double* x_measured, double* 
 // ---------------------------------------------------------------- stage entry points
 int ilqr_hip_set_trajectory(ilqr_hip_ctx* c, const double* xbar, const double* ubar) {
   if (!c || !xbar || !ubar) return ILQR_ERR_ARG;
-  hipSetDevice(c->device);
+  enter(c);
   const size_t B = c->B, N = c->N;
   HIPCHK(c, hipMemcpyAsync(c->S.xbar, xbar, B * (N + 1) * ILQR_NX * sizeof(double), hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(c->S.ubar, ubar, B * N * ILQR_NU * sizeof(double), hipMemcpyHostToDevice, c->stream));
@@ -519,7 +539,7 @@ int ilqr_hip_set_trajectory(ilqr_hip_ctx* c, const double* xbar, const double* u
   c->initialized = true;
   return ILQR_OK;
 }
-#define STAGE_PRE if (!c) return ILQR_ERR_ARG; if (!c->initialized) return ILQR_ERR_STATE; hipSetDevice(c->device)
+#define STAGE_PRE if (!c) return ILQR_ERR_ARG; if (!c->initialized) return ILQR_ERR_STATE; enter(c)
 #define STAGE_POST HIPCHK(c, hipGetLastError()); HIPCHK(c, hipStreamSynchronize(c->stream)); return ILQR_OK
 int ilqr_hip_stage_rollout(ilqr_hip_ctx* c) { STAGE_PRE; ilqr::launch_rollout(c->S, c->P, ilqr::MASK_ALL, 1, 0, c->S.Jbase, c->stream); STAGE_POST; }
 int ilqr_hip_stage_linearize(ilqr_hip_ctx* c) { STAGE_PRE; ilqr::launch_linearize(c->S, c->P, ilqr::MASK_ALL, c->jac_mode, c->fd_eps, c->stream); STAGE_POST; }
@@ -549,7 +569,7 @@ int ilqr_hip_stage_line_search(ilqr_hip_ctx* c, int* improved, double* new_cost,
   return ILQR_OK;
 }
 int ilqr_hip_get_linearization(ilqr_hip_ctx* c, double* A, double* Bm) {
-  if (!c) return ILQR_ERR_ARG; hipSetDevice(c->device);
+  if (!c) return ILQR_ERR_ARG; enter(c);
   const size_t B = c->B, N = c->N;
   HIPCHK(c, hipStreamSynchronize(c->stream));
   if (A) HIPCHK(c, hipMemcpy(A, c->S.A, B * N * ILQR_NX * ILQR_NX * sizeof(double), hipMemcpyDeviceToHost));
@@ -557,7 +577,7 @@ int ilqr_hip_get_linearization(ilqr_hip_ctx* c, double* A, double* Bm) {
   return ILQR_OK;
 }
 int ilqr_hip_set_linearization(ilqr_hip_ctx* c, const double* A, const double* Bm) {
-  if (!c || !A || !Bm) return ILQR_ERR_ARG; hipSetDevice(c->device);
+  if (!c || !A || !Bm) return ILQR_ERR_ARG; enter(c);
   const size_t B = c->B, N = c->N;
   HIPCHK(c, hipMemcpy(c->S.A, A, B * N * ILQR_NX * ILQR_NX * sizeof(double), hipMemcpyHostToDevice));
   HIPCHK(c, hipMemcpy(c->S.Bm, Bm, B * N * ILQR_NX * ILQR_NU * sizeof(double), hipMemcpyHostToDevice));
@@ -565,7 +585,7 @@ int ilqr_hip_set_linearization(ilqr_hip_ctx* c, const double* A, const double* B
   return ILQR_OK;
 }
 int ilqr_hip_get_quadratics(ilqr_hip_ctx* c, double* lx, double* lu, double* lxx, double* luu) {
-  if (!c) return ILQR_ERR_ARG; hipSetDevice(c->device);
+  if (!c) return ILQR_ERR_ARG; enter(c);
   const size_t B = c->B, N = c->N;
   HIPCHK(c, hipStreamSynchronize(c->stream));
   if (lx) HIPCHK(c, hipMemcpy(lx, c->S.lx, B * (N + 1) * ILQR_NX * sizeof(double), hipMemcpyDeviceToHost));
@@ -575,7 +595,7 @@ int ilqr_hip_get_quadratics(ilqr_hip_ctx* c, double* lx, double* lu, double* lxx
   return ILQR_OK;
 }
 int ilqr_hip_set_quadratics(ilqr_hip_ctx* c, const double* lx, const double* lu, const double* lxx, const double* luu) {
-  if (!c || !lx || !lu || !lxx || !luu) return ILQR_ERR_ARG; hipSetDevice(c->device);
+  if (!c || !lx || !lu || !lxx || !luu) return ILQR_ERR_ARG; enter(c);
   const size_t B = c->B, N = c->N;
   HIPCHK(c, hipMemcpy(c->S.lx, lx, B * (N + 1) * ILQR_NX * sizeof(double), hipMemcpyHostToDevice));
   HIPCHK(c, hipMemcpy(c->S.lu, lu, B * N * ILQR_NU * sizeof(double), hipMemcpyHostToDevice));
@@ -584,7 +604,7 @@ int ilqr_hip_set_quadratics(ilqr_hip_ctx* c, const double* lx, const double* lu,
   return ILQR_OK;
 }
 int ilqr_hip_get_value_function(ilqr_hip_ctx* c, double* Vx, double* Vxx) {
-  if (!c) return ILQR_ERR_ARG; hipSetDevice(c->device);
+  if (!c) return ILQR_ERR_ARG; enter(c);
   HIPCHK(c, hipStreamSynchronize(c->stream));
   if (Vx) HIPCHK(c, hipMemcpy(Vx, c->S.Vx, (size_t)c->B * ILQR_NX * sizeof(double), hipMemcpyDeviceToHost));
   if (Vxx) HIPCHK(c, hipMemcpy(Vxx, c->S.Vxx, (size_t)c->B * ILQR_NX * ILQR_NX * sizeof(double), hipMemcpyDeviceToHost));
@@ -602,19 +622,130 @@ int ilqr_hip_set_contact_mode(ilqr_hip_ctx* c, int mode, double softness) {
 }
 int ilqr_hip_step_stance(ilqr_hip_ctx* c, int count, const double* x, const double* u, int stance_left, int stance_right, double* x_next) {
   if (!c || count <= 0 || !x || !u || !x_next) return ILQR_ERR_ARG;
-  hipSetDevice(c->device);
-  double *dx = nullptr, *du = nullptr, *dn = nullptr;
-  HIPCHK(c, hipMalloc((void**)&dx, (size_t)count * ILQR_NX * sizeof(double)));
-  HIPCHK(c, hipMalloc((void**)&du, (size_t)count * ILQR_NU * sizeof(double)));
-  HIPCHK(c, hipMalloc((void**)&dn, (size_t)count * ILQR_NX * sizeof(double)));
-  hipMemcpy(dx, x, (size_t)count * ILQR_NX * sizeof(double), hipMemcpyHostToDevice);
-  hipMemcpy(du, u, (size_t)count * ILQR_NU * sizeof(double), hipMemcpyHostToDevice);
-  ilqr::launch_step(count, dx, du, c->P.dyn, dn, c->stream, stance_left, stance_right);
-  hipError_t e = hipStreamSynchronize(c->stream);
-  hipMemcpy(x_next, dn, (size_t)count * ILQR_NX * sizeof(double), hipMemcpyDeviceToHost);
-  hipFree(dx); hipFree(du); hipFree(dn);
-  HIPCHK(c, e);
+  enter(c);
+  if ((size_t)count > c->step_cap) {   // scratch owned by the context, grown on demand (the closed loop steps the plant every MPC step)
+    if (c->d_stepx) hipFree(c->d_stepx);
+    if (c->d_stepu) hipFree(c->d_stepu);
+    if (c->d_stepn) hipFree(c->d_stepn);
+    c->d_stepx = c->d_stepu = c->d_stepn = nullptr; c->step_cap = 0;
+    HIPCHK(c, hipMalloc((void**)&c->d_stepx, (size_t)count * ILQR_NX * sizeof(double)));
+    HIPCHK(c, hipMalloc((void**)&c->d_stepu, (size_t)count * ILQR_NU * sizeof(double)));
+    HIPCHK(c, hipMalloc((void**)&c->d_stepn, (size_t)count * ILQR_NX * sizeof(double)));
+    c->step_cap = (size_t)count;
+  }
+  HIPCHK(c, hipMemcpyAsync(c->d_stepx, x, (size_t)count * ILQR_NX * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->d_stepu, u, (size_t)count * ILQR_NU * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  ilqr::launch_step(count, c->d_stepx, c->d_stepu, c->P.dyn, c->d_stepn, c->stream, stance_left, stance_right);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipMemcpyAsync(x_next, c->d_stepn, (size_t)count * ILQR_NX * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
   return ILQR_OK;
+}
+int ilqr_hip_get_adopt_mismatches(ilqr_hip_ctx* c, unsigned long long* count) {
+  if (!c || !count) return ILQR_ERR_ARG;
+  enter(c);
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipMemcpy(count, c->d_mismatch, sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  return ILQR_OK;
+}
+
+// ---------------------------------------------------------------- multi-GPU: the ONE collective of an MPC step
+// RCCL (librccl.so.1) is opened on first use; a process that never shards never loads it.
+namespace {
+struct Rccl {
+  void* lib = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  std::string err;
+};
+Rccl g_rccl;
+bool rccl_load() {
+  Rccl& R = g_rccl;
+  if (R.lib) return true;
+  const char* names[] = {getenv("ILQR_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+  for (const char* n : names) { if (n && (R.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break; }
+  if (!R.lib) { R.err = std::string("cannot open librccl: ") + dlerror(); return false; }
+  bool ok = true;
+  auto sym = [&](const char* n) { void* p = dlsym(R.lib, n); if (!p) { ok = false; R.err = std::string("librccl lacks ") + n; } return p; };
+  R.GetUniqueId = (decltype(R.GetUniqueId))sym("ncclGetUniqueId");
+  R.CommInitRank = (decltype(R.CommInitRank))sym("ncclCommInitRank");
+  R.CommDestroy = (decltype(R.CommDestroy))sym("ncclCommDestroy");
+  R.Send = (decltype(R.Send))sym("ncclSend");
+  R.Recv = (decltype(R.Recv))sym("ncclRecv");
+  R.GroupStart = (decltype(R.GroupStart))sym("ncclGroupStart");
+  R.GroupEnd = (decltype(R.GroupEnd))sym("ncclGroupEnd");
+  R.GetErrorString = (decltype(R.GetErrorString))sym("ncclGetErrorString");
+  if (!ok) { dlclose(R.lib); R.lib = nullptr; }
+  return ok;
+}
+}  // namespace
+#define NCCLCHK(ctx, call)                                                                          \
+  do {                                                                                              \
+    ncclResult_t r_ = (call);                                                                       \
+    if (r_ != ncclSuccess) { (ctx)->err = std::string(#call) + ": " + g_rccl.GetErrorString(r_); return ILQR_ERR_HIP; } \
+  } while (0)
+
+int ilqr_hip_payload_width(int with_gains) { return ILQR_NU + 1 + (with_gains ? ILQR_NU * ILQR_NX : 0); }
+int ilqr_hip_comm_get_unique_id(char* id) {
+  if (!id) return ILQR_ERR_ARG;
+  if (!rccl_load()) return ILQR_ERR_UNSUPPORTED;
+  ncclUniqueId u;
+  if (g_rccl.GetUniqueId(&u) != ncclSuccess) return ILQR_ERR_HIP;
+  std::memcpy(id, u.internal, ILQR_COMM_ID_BYTES);
+  return ILQR_OK;
+}
+int ilqr_hip_comm_init(ilqr_hip_ctx* c, int world, int rank, const char* id) {
+  if (!c || world < 1 || rank < 0 || rank >= world || (world > 1 && !id)) return ILQR_ERR_ARG;
+  if (c->comm) { c->err = "communicator already initialised"; return ILQR_ERR_STATE; }
+  enter(c);
+  c->world = world; c->rank = rank;
+  if (world == 1) return ILQR_OK;           // one GPU: the gather degenerates to a device copy, RCCL is not needed
+  if (!rccl_load()) { c->err = g_rccl.err; return ILQR_ERR_UNSUPPORTED; }
+  ncclUniqueId u; std::memcpy(u.internal, id, ILQR_COMM_ID_BYTES);
+  NCCLCHK(c, g_rccl.CommInitRank(&c->comm, world, u, rank));
+  return ILQR_OK;
+}
+int ilqr_hip_comm_destroy(ilqr_hip_ctx* c) {
+  if (!c) return ILQR_ERR_ARG;
+  if (c->comm) { hipSetDevice(c->device); hipStreamSynchronize(c->stream); g_rccl.CommDestroy(c->comm); c->comm = nullptr; }
+  c->world = 1; c->rank = 0;
+  return ILQR_OK;
+}
+int ilqr_hip_comm_world(const ilqr_hip_ctx* c) { return c ? c->world : -1; }
+int ilqr_hip_comm_rank(const ilqr_hip_ctx* c) { return c ? c->rank : -1; }
+int ilqr_hip_gather_first_knot(ilqr_hip_ctx* c, int root, int with_gains, double* recv_device) {
+  if (!c || root < 0 || root >= c->world || (c->rank == root && !recv_device)) return ILQR_ERR_ARG;
+  if (!c->initialized) return ILQR_ERR_STATE;
+  enter(c);
+  const size_t W = (size_t)ilqr_hip_payload_width(with_gains), cnt = (size_t)c->B * W;
+  if (cnt > c->payload_cap) {
+    if (c->d_payload) hipFree(c->d_payload);
+    c->d_payload = nullptr; c->payload_cap = 0;
+    HIPCHK(c, hipMalloc((void**)&c->d_payload, cnt * sizeof(double)));
+    c->payload_cap = cnt;
+  }
+  // rank r's rollouts are rows [r B, (r + 1) B) of the gathered array: contiguous shards, global rollout order
+  double* mine = (c->rank == root) ? recv_device + (size_t)c->rank * cnt : c->d_payload;
+  ilqr::launch_pack_payload(c->S, with_gains, mine, c->stream);
+  HIPCHK(c, hipGetLastError());
+  if (c->world > 1) {
+    if (!c->comm) { c->err = "gather before ilqr_hip_comm_init"; return ILQR_ERR_STATE; }
+    // a gather as grouped point-to-point transfers: every peer sends to the root over its own xGMI link
+    NCCLCHK(c, g_rccl.GroupStart());
+    if (c->rank == root) {
+      for (int r = 0; r < c->world; ++r) if (r != root) NCCLCHK(c, g_rccl.Recv(recv_device + (size_t)r * cnt, cnt, ncclDouble, r, c->comm, c->stream));
+    } else {
+      NCCLCHK(c, g_rccl.Send(c->d_payload, cnt, ncclDouble, root, c->comm, c->stream));
+    }
+    NCCLCHK(c, g_rccl.GroupEnd());
+  }
+  return ILQR_OK;   // asynchronous on the handle's stream: ilqr_hip_synchronize before reading recv_device
 }
 
 int ilqr_hip_enable_profiling(ilqr_hip_ctx* c, int on) { if (!c) return ILQR_ERR_ARG; c->profiling = on ? 1 : 0; return ILQR_OK; }

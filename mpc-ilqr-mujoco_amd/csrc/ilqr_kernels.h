@@ -56,12 +56,18 @@ void launch_backward(const DevState& S, int mode, hipStream_t st);
 void launch_line_search(const DevState& S, const h1::ProblemDev& P, int mode, hipStream_t st);
 void launch_control(const DevState& S, int phase, int iter, double tol, int early_exit, hipStream_t st);
 void launch_solve_begin(const DevState& S, hipStream_t st);
-void launch_adopt_rollout(const DevState& S, const double* shadow, int mode, hipStream_t st);
+void launch_adopt_rollout(const DevState& S, const double* shadow, int mode, unsigned long long* mismatches, hipStream_t st);
 void launch_warm_shift(const DevState& S, const double* prev_x, const double* prev_u, hipStream_t st);
 void launch_last_step(const DevState& S, const h1::ProblemDev& P, hipStream_t st);
 void launch_compute_control(const DevState& S, const double* x_meas, double* u_out, hipStream_t st);
 void launch_pack_first_knot(const DevState& S, double* u0, double* K0, hipStream_t st);
+void launch_pack_payload(const DevState& S, int with_gains, double* out, hipStream_t st);
 int backward_needs_lds_attr();
+// kernel variants (ILQR_DYN / ILQR_ROLLOUT / ILQR_LS / ILQR_BACKWARD), re-read from the environment by refresh_variants()
+void refresh_variants();
+int variant_ls_split();
+int variant_rollout_split();
+int variant_backward();
 size_t backward_lds_bytes();
 size_t lin_dump_doubles();
 void launch_rollout_r(const DevState& S, const h1::ProblemDev& P, int mode, int do_roll, int count_iter, double* cost_out, hipStream_t st);

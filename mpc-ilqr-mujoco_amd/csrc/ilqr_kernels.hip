@@ -435,13 +435,18 @@ __global__ void k_warm_shift(DevState S, const double* prev_x, const double* pre
   for (int e = lane; e < m; e += blockDim.x) ub[(N - 1) * m + e] = pu[(N - 1) * m + e];
 }
 // the nominal re-rollout of iterations >= 1 runs beside the linearisation into a shadow buffer (ilqr_capi.hip): adopt it
-__global__ void k_adopt_rollout(DevState S, const double* shadow, int mode) {
+__global__ void k_adopt_rollout(DevState S, const double* shadow, int mode, unsigned long long* mismatches) {
   const int b = blockIdx.x, lane = threadIdx.x;
   if (!selected(S, b, mode)) return;
   const size_t len = (size_t)(S.N + 1) * H1_NX;
   double* xb = S.xbar + (size_t)b * len;
   const double* sh = shadow + (size_t)b * len;
-  for (int e = lane; e < (int)len; e += blockDim.x) xb[e] = sh[e];
+  // The linearisation and the cost quadratics that ran beside the re-rollout used the pre-adoption trajectory; the
+  // reference linearises the trajectory it has just rolled out (ilqr.cpp:563-588).  The two coincide only while the
+  // re-rollout reproduces the accepted candidate bit for bit: count every element that does not (checked by the GPU tests).
+  int bad = 0;
+  for (int e = lane; e < (int)len; e += blockDim.x) { const double v = sh[e]; bad += (__double_as_longlong(v) != __double_as_longlong(xb[e])); xb[e] = v; }
+  if (bad) atomicAdd(mismatches, (unsigned long long)bad);
 }
 // last knot of the warm start: xbar[N] = f(xbar[N-1], ubar[N-1])
 __global__ void k_last_step(DevState S, ProblemDev P) {
@@ -473,6 +478,17 @@ __global__ void k_pack_first_knot(DevState S, double* u0, double* K0) {
   for (int e = lane; e < m * n; e += blockDim.x) K0[(size_t)b * m * n + e] = S.K[(size_t)b * N * m * n + e];
 }
 
+// payload of the per-step gather: row b = [u0(19) | cost | K0(19 x 51) when with_gains]
+__global__ void k_pack_payload(DevState S, int with_gains, double* out) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const int N = S.N, n = H1_NX, m = H1_NU;
+  const int W = m + 1 + (with_gains ? m * n : 0);
+  double* row = out + (size_t)b * W;
+  for (int e = lane; e < m; e += blockDim.x) row[e] = S.ubar[(size_t)b * N * m + e];
+  if (lane == 0) row[m] = S.J[b];
+  if (with_gains) for (int e = lane; e < m * n; e += blockDim.x) row[m + 1 + e] = S.K[(size_t)b * N * m * n + e];
+}
+
 // ------------------------------------------------------------------ launchers
 // defaults measured on MI355X at B = 4096 (time per full launch): rollout one lane 1.18 ms, two lanes 0.78 ms (0.4 ms
 // without the in-kernel cost); line search one lane per candidate 2.35 ms, two lanes per candidate with side-owned
@@ -485,21 +501,33 @@ __global__ void k_pack_first_knot(DevState S, double* u0, double* K0) {
 #endif
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
-// ILQR_DYN=scalar selects the scratch-resident scalar ABA kernels (kept as an on-device cross-check)
-static int use_scalar_dyn() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("ILQR_DYN"); v = (e && e[0] == 's') ? 1 : 0; }
-  return v;
+// Kernel variants, selectable at run time (environment) and re-read at the start of every solve / stage call
+// (refresh_variants), so that a test can switch them within one process:
+//   ILQR_DYN=s        scratch-resident scalar ABA kernels for every dynamics stage (on-device cross-check; always in contact mode)
+//   ILQR_ROLLOUT=s|r  nominal rollout on two lanes (dyn_split_kernels.hip) or one lane per rollout
+//   ILQR_LS=s|r       line search on two lanes or one lane per candidate
+//   ILQR_BACKWARD=wave|wg|valu  one-wave MFMA (riccati_wave.hip) / four-wave MFMA (riccati_mfma.hip) / LDS + VALU cross-check
+struct Variants { int scalar_dyn, rollout_split, ls_split, backward; };
+static Variants g_var = {0, ROLLOUT_SPLIT_DEFAULT, LS_SPLIT_DEFAULT, -1};
+static int env_split(const char* var, int dflt) { const char* e = getenv(var); return !e ? dflt : (e[0] == 's' ? 1 : 0); }
+#ifndef BACKWARD_DEFAULT
+#define BACKWARD_DEFAULT 2
+#endif
+static int backward_kind() { return g_var.backward < 0 ? BACKWARD_DEFAULT : g_var.backward; }
+static int use_scalar_dyn() { return g_var.scalar_dyn; }
+void refresh_variants() {
+  const char* e = getenv("ILQR_DYN");
+  g_var.scalar_dyn = (e && e[0] == 's') ? 1 : 0;
+  g_var.rollout_split = env_split("ILQR_ROLLOUT", ROLLOUT_SPLIT_DEFAULT);
+  g_var.ls_split = env_split("ILQR_LS", LS_SPLIT_DEFAULT);
+  e = getenv("ILQR_BACKWARD");
+  g_var.backward = !e ? BACKWARD_DEFAULT : (e[0] == 'v') ? 1 : (e[0] == 'w' && e[1] == 'a') ? 2 : 0;
 }
-// ILQR_ROLLOUT=s / ILQR_LS=s select the two-lanes-per-rollout variants (dyn_split_kernels.hip)
-static int use_split(const char* var, int dflt) {
-  const char* e = getenv(var);
-  if (!e) return dflt;
-  return e[0] == 's' ? 1 : 0;
-}
+int variant_ls_split() { return g_var.ls_split; }
+int variant_rollout_split() { return g_var.rollout_split; }
+int variant_backward() { return backward_kind(); }
 void launch_rollout(const DevState& S, const ProblemDev& P, int mode, int do_roll, int count_iter, double* cost_out, hipStream_t st) {
-  static const int split = use_split("ILQR_ROLLOUT", ROLLOUT_SPLIT_DEFAULT);
-  if (!use_scalar_dyn() && !P.dyn.contact) { if (split) launch_rollout_s(S, P, mode, do_roll, count_iter, cost_out, st); else launch_rollout_r(S, P, mode, do_roll, count_iter, cost_out, st); return; }
+  if (!use_scalar_dyn() && !P.dyn.contact) { if (g_var.rollout_split) launch_rollout_s(S, P, mode, do_roll, count_iter, cost_out, st); else launch_rollout_r(S, P, mode, do_roll, count_iter, cost_out, st); return; }
   hipLaunchKernelGGL(k_rollout, dim3(cdiv(S.B, 64)), dim3(64), 0, st, S, P, mode, do_roll, count_iter, cost_out);
 }
 void launch_step(int count, const double* x, const double* u, const DynParams& dyn, double* xn, hipStream_t st, int stance_l, int stance_r) {
@@ -520,14 +548,6 @@ void launch_linearize(const DevState& S, const ProblemDev& P, int mode, int jac_
 size_t lin_dump_doubles() { return LinDumpG_SIZE; }
 // ILQR_BACKWARD=valu selects the LDS + VALU kernel (kept as an on-device cross-check), =wg the four-wave MFMA
 // kernel (riccati_mfma.hip), =wave the one-wave-per-rollout MFMA kernel (riccati_wave.hip)
-#ifndef BACKWARD_DEFAULT
-#define BACKWARD_DEFAULT 2
-#endif
-static int backward_kind() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("ILQR_BACKWARD"); v = !e ? BACKWARD_DEFAULT : (e[0] == 'v') ? 1 : (e[0] == 'w' && e[1] == 'a') ? 2 : 0; }
-  return v;
-}
 void launch_backward(const DevState& S, int mode, hipStream_t st) {
   const int kind = backward_kind();
   if (kind == 1) hipLaunchKernelGGL(k_backward, dim3(S.B), dim3(256), backward_lds_bytes(), st, S, mode);
@@ -535,9 +555,8 @@ void launch_backward(const DevState& S, int mode, hipStream_t st) {
   else launch_backward_mfma(S, mode, st);
 }
 void launch_line_search(const DevState& S, const ProblemDev& P, int mode, hipStream_t st) {
-  static const int split = use_split("ILQR_LS", LS_SPLIT_DEFAULT);
   if (!use_scalar_dyn() && !P.dyn.contact) {
-    if (split) { launch_line_search_s(S, P, mode, st); launch_cand_costs(S, P, mode, st); }   // candidates' costs: all knots in parallel
+    if (g_var.ls_split) { launch_line_search_s(S, P, mode, st); launch_cand_costs(S, P, mode, st); }   // candidates' costs: all knots in parallel
     else launch_line_search_r(S, P, mode, st);                                                  // (the one-lane kernel sums its own)
     return;
   }
@@ -547,11 +566,12 @@ void launch_control(const DevState& S, int phase, int iter, double tol, int earl
   hipLaunchKernelGGL(k_control, dim3(S.B), dim3(64), 0, st, S, phase, iter, tol, early_exit);
 }
 void launch_solve_begin(const DevState& S, hipStream_t st) { hipLaunchKernelGGL(k_solve_begin, dim3(cdiv(S.B, 64)), dim3(64), 0, st, S); }
-void launch_adopt_rollout(const DevState& S, const double* shadow, int mode, hipStream_t st) { hipLaunchKernelGGL(k_adopt_rollout, dim3(S.B), dim3(64), 0, st, S, shadow, mode); }
+void launch_adopt_rollout(const DevState& S, const double* shadow, int mode, unsigned long long* mismatches, hipStream_t st) { hipLaunchKernelGGL(k_adopt_rollout, dim3(S.B), dim3(64), 0, st, S, shadow, mode, mismatches); }
 void launch_warm_shift(const DevState& S, const double* px, const double* pu, hipStream_t st) { hipLaunchKernelGGL(k_warm_shift, dim3(S.B), dim3(64), 0, st, S, px, pu); }
 void launch_last_step(const DevState& S, const ProblemDev& P, hipStream_t st) { if (!use_scalar_dyn() && !P.dyn.contact) { launch_last_step_r(S, P, st); return; } hipLaunchKernelGGL(k_last_step, dim3(cdiv(S.B, 64)), dim3(64), 0, st, S, P); }
 void launch_compute_control(const DevState& S, const double* x_meas, double* u_out, hipStream_t st) { hipLaunchKernelGGL(k_compute_control, dim3(S.B), dim3(64), 0, st, S, x_meas, u_out); }
 void launch_pack_first_knot(const DevState& S, double* u0, double* K0, hipStream_t st) { hipLaunchKernelGGL(k_pack_first_knot, dim3(S.B), dim3(64), 0, st, S, u0, K0); }
+void launch_pack_payload(const DevState& S, int with_gains, double* out, hipStream_t st) { hipLaunchKernelGGL(k_pack_payload, dim3(S.B), dim3(64), 0, st, S, with_gains, out); }
 int backward_needs_lds_attr() {
   if (backward_mfma_set_attr() != 0) return 1;
   if (dyn_kernels_set_attr() != 0) return 1;

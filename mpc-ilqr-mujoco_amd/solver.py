@@ -34,7 +34,9 @@ EXPORTS = [
     "ilqr_hip_set_trajectory", "ilqr_hip_stage_rollout", "ilqr_hip_stage_linearize", "ilqr_hip_stage_cost_quadratics",
     "ilqr_hip_stage_backward_pass", "ilqr_hip_stage_line_search", "ilqr_hip_stage_total_cost",
     "ilqr_hip_get_linearization", "ilqr_hip_set_linearization", "ilqr_hip_get_quadratics", "ilqr_hip_set_quadratics",
-    "ilqr_hip_get_value_function", "ilqr_hip_step", "ilqr_hip_step_stance", "ilqr_hip_set_contact_mode", "ilqr_hip_enable_profiling", "ilqr_hip_get_stage_ms",
+    "ilqr_hip_get_value_function", "ilqr_hip_step", "ilqr_hip_step_stance", "ilqr_hip_set_contact_mode", "ilqr_hip_enable_profiling", "ilqr_hip_get_stage_ms", "ilqr_hip_get_adopt_mismatches",
+    "ilqr_hip_payload_width", "ilqr_hip_comm_get_unique_id", "ilqr_hip_comm_init", "ilqr_hip_comm_destroy", "ilqr_hip_comm_world", "ilqr_hip_comm_rank",
+    "ilqr_hip_gather_first_knot",
     "ilqr_hip_reference_kinematics", "ilqr_hip_reference_com_velocity", "ilqr_hip_foot_clearance", "ilqr_hip_gravity_compensation", "ilqr_hip_stream",
 ]
 
@@ -243,6 +245,27 @@ class BatchedILQR:
         """Write u0[B][19] (+ K0[B][19][51], cost[B]) into caller-owned device buffers (gather payload)."""
         self._chk(self.L.ilqr_hip_pack_first_knot_device(self.h, C.c_void_p(u0_ptr), C.c_void_p(K0_ptr), C.c_void_p(cost_ptr)))
 
+    # ---- multi-GPU: RCCL behind the C ABI (include/ilqr_hip.h "multi-GPU")
+    @staticmethod
+    def comm_unique_id():
+        """128-byte RCCL id (rank 0 creates it and hands it to every rank)."""
+        L = load_library()
+        buf = C.create_string_buffer(128)
+        rc = L.ilqr_hip_comm_get_unique_id(buf)
+        if rc:
+            raise ILQRError("ilqr_hip_comm_get_unique_id: %s" % STATUS.get(rc, rc))
+        return buf.raw
+
+    def comm_init(self, world, rank, unique_id=None):
+        self._chk(self.L.ilqr_hip_comm_init(self.h, int(world), int(rank), unique_id))
+
+    def comm_destroy(self):
+        self._chk(self.L.ilqr_hip_comm_destroy(self.h))
+
+    def gather_first_knot(self, recv_ptr, root=0, with_gains=False):
+        """Enqueue the per-step gather of [u0 | cost | (K0)] rows to `root` (recv_ptr: device buffer there, None elsewhere)."""
+        self._chk(self.L.ilqr_hip_gather_first_knot(self.h, int(root), int(bool(with_gains)), C.c_void_p(recv_ptr)))
+
     def compute_control(self, x_measured):
         u = np.zeros((self.B, NU))
         self._chk(self.L.ilqr_hip_compute_control(self.h, _p(_c64(x_measured)), _p(u)))
@@ -318,6 +341,12 @@ class BatchedILQR:
 
     def enable_profiling(self, on=True):
         self._chk(self.L.ilqr_hip_enable_profiling(self.h, int(bool(on))))
+
+    def adopt_mismatches(self):
+        """Elements in which the concurrent nominal re-rollouts of the last solve differed from the trajectory they replaced."""
+        n = C.c_ulonglong(0)
+        self._chk(self.L.ilqr_hip_get_adopt_mismatches(self.h, C.byref(n)))
+        return int(n.value)
 
     def num_slices(self):
         """Batch slices a solve is enqueued as (ILQR_SLICES)."""

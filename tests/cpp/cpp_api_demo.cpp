@@ -1,7 +1,9 @@
 // Drives the C++ mirror of the reference's classes (include/ilqr_hip.hpp: ilqr_hip::iLQR / ilqr_hip::MPC) the way
 // main/humanoid_mpc.cpp drives iLQR / MPC (setupSimulation :94-118, runSimulation :126-190): configure, two MPC steps
 // (cold start, then warm start), dump costs / first controls / first gain rows.  Test harness, not product code.
-//   usage: cpp_api_demo <input.bin> <output.bin>
+//   usage: cpp_api_demo <input.bin> <output.bin> [log_dir]
+//   with log_dir: mpc_log.csv, q_optimal.csv, u_optimal.csv in the reference's formats (mpc.cpp:181-355) and the profiling
+//   table (main/humanoid_mpc.cpp:195-226) on stdout
 //   input  (doubles): N, dt, Q[51], R[19], Qf[51], task w[6], constraint w[2], gravity[3], x0[51],
 //                     x_ref[(N+1)*51], com_ref[(N+1)*3], ee_ref[(N+1)*6], stance[(N+1)*2]
 //   output (doubles): per step: ok, cost, u_apply[19], ubar0[19], K0 row 0 [51]
@@ -34,6 +36,15 @@ int main(int argc, char** argv) {
     auto window = [&](int, std::vector<ilqr_hip::Vec>& xr, std::vector<ilqr_hip::Vec>& ur, std::vector<std::array<double, 3>>& cr) { xr = x_ref; ur = u_ref; cr = com_ref; };
     ilqr_hip::MPC<decltype(window)> mpc(N, dt, window);
     ilqr_hip::iLQR& s = mpc.solver();
+    {   // Config::buildCostMatrices with the shipped weights must reproduce the diagonals the harness was given
+      ilqr_hip::Vec q2, r2, qf2; ilqr_hip::buildCostMatrices(ilqr_hip::CostConfig(), q2, r2, qf2);
+      if (q2 != Q || r2 != R || qf2 != Qf) { std::fprintf(stderr, "buildCostMatrices differs from the shipped configuration\n"); return 4; }
+    }
+    if (argc > 3) {
+      mpc.enableCSVLogging(std::string(argv[3]) + "/mpc_log.csv");
+      mpc.enableOptimalTrajectoryLogging(argv[3]);
+      mpc.enableProfiling(true);
+    }
     s.setCostWeights(Q, R, Qf);
     s.setTaskWeights(tw[0], tw[1], tw[2], tw[3], tw[4], tw[5]);
     s.setConstraintWeights(cw[0], cw[1]);
@@ -55,6 +66,14 @@ int main(int argc, char** argv) {
       if (ilqr_hip_step(s.handle(), 1, x.data(), u.data(), xn.data()) != ILQR_OK) return 3;
       x = xn;
     }
+    {   // accessors of include/ilqr/mpc.hpp:27-28, 41-47
+      std::vector<ilqr_hip::Vec> xt, ut; mpc.getNominalTrajectory(xt, ut);
+      if (mpc.getTimeIndex() != 2 || xt.size() != (size_t)N + 1 || ut.size() != (size_t)N || mpc.gainsK().size() != (size_t)N || mpc.gainsK()[0].size() != 19u * 51u) return 5;
+      const ilqr_hip::Vec utv = mpc.computeTVLQRControl(xt[0]);
+      for (int i = 0; i < 19; ++i) if (utv[i] != ut[0][i]) return 6;          // zero state error: u = ubar[0]
+      mpc.setTimeIndex(7); if (mpc.getTimeIndex() != 7) return 7;
+    }
+    if (argc > 3) { mpc.finalizeCSVLog(); mpc.finalizeOptimalTrajectoryLog(); mpc.profiler().print(std::cout); }
     std::FILE* o = std::fopen(argv[2], "wb");
     std::fwrite(out.data(), sizeof(double), out.size(), o);
     std::fclose(o);

@@ -1,0 +1,366 @@
+"""GPU tests of the BASELINE.json configurations at their true per-GPU shapes, of every selectable kernel variant, and of the
+multi-rank shard / gather path as far as one GPU can execute it (two ranks on device 0)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+from conftest import load_package
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pkg = load_package()
+sc = pkg.scenario
+
+
+def _solver(*a, **k):
+    from mpc_ilqr_mujoco_amd import solver as sv
+    return sv.BatchedILQR(*a, **k)
+
+
+def rel(a, b):
+    return np.abs(a - b).max() / max(1e-300, np.abs(b).max())
+
+
+class env:
+    """Set environment variables for a block (the library re-reads its kernel-variant switches at every call)."""
+
+    def __init__(self, **kv):
+        self.kv = {k: v for k, v in kv.items() if v is not None}
+
+    def __enter__(self):
+        self.old = {k: os.environ.get(k) for k in self.kv}
+        os.environ.update(self.kv)
+
+    def __exit__(self, *exc):
+        for k, v in self.old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def standing(B, N=25, seed=0, gravity=None):
+    from mpc_ilqr_mujoco_amd import solver as sv
+    prob = sc.make_problem(sv.reference_kinematics, N=N, gravity=gravity)
+    ug = sv.gravity_compensation(sc.standing_state(), prob["gravity"])
+    x0, ui = sc.synthetic_batch(B, N, seed, ug)
+    return prob, x0, ui
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# kernel variants: every family that ships is exercised against the oracle / the NumPy golden
+VARIANTS = [
+    dict(ILQR_BACKWARD="wave", ILQR_LS="s", ILQR_ROLLOUT="s"),     # defaults
+    dict(ILQR_BACKWARD="wg", ILQR_LS="r", ILQR_ROLLOUT="r"),       # four-wave MFMA Riccati, one lane per trajectory
+    dict(ILQR_BACKWARD="valu", ILQR_LS="s", ILQR_ROLLOUT="r"),     # VALU Riccati; mixed line search / rollout -> sequential re-rollout
+    dict(ILQR_BACKWARD="wave", ILQR_DYN="s"),                      # scratch-resident scalar dynamics everywhere
+]
+
+
+@pytest.mark.parametrize("var", VARIANTS, ids=lambda v: ",".join("%s=%s" % (k[5:].lower(), x) for k, x in v.items()))
+def test_full_solve_parity_for_every_kernel_variant(var):
+    B = 4
+    prob, x0, ui = standing(B, seed=31)
+    with env(**var):
+        s = _solver(B); s.set_problem(prob); s.set_max_iterations(5)
+        s.initialize(x0, ui)
+        cost = s.solve(x0)
+        tc, ta, tl = s.trace()
+        K, it = s.gains_K(), s.iterations()
+        mism = s.adopt_mismatches()
+        s.close()
+    # wherever the re-rollout ran beside the linearisation it reproduced the accepted candidate bit for bit
+    assert mism == 0
+    for b in range(B):
+        o = ol.Oracle(prob["N"], prob["dt"]); o.set_problem(prob); o.set_options(max_iter=5)
+        o.initialize(x0[b], ui[b]); ok, c = o.solve(x0[b])
+        n, oc, oa, _ = o.trace()
+        assert n == it[b] and np.allclose(tc[b, : n + 1], oc[: n + 1], rtol=1e-5, atol=0) and np.array_equal(ta[b, :n], oa[:n])
+        assert abs(cost[b] - c) <= 1e-5 * abs(c) and rel(K[b], o.get("K")) < 1e-5
+
+
+@pytest.mark.parametrize("backward", ["wave", "wg", "valu"])
+def test_backward_kernels_vs_numpy_golden_and_indefinite_fallback(backward):
+    r = np.load(os.path.join(G, "riccati_golden.npz"))
+    with env(ILQR_BACKWARD=backward):
+        for case, tol in (("spd", 1e-9), ("bump", 1e-6)):
+            A, Bm = r[case + "_A"], r[case + "_B"]
+            s = _solver(2, N=A.shape[0]); s.set_regularization(float(r["lam"]))
+            rep = lambda a: np.stack([a, a])
+            s.set_linearization(rep(A), rep(Bm))
+            s.set_quadratics(rep(r[case + "_lx"]), rep(r[case + "_lu"]), rep(r[case + "_lxx"]), rep(r[case + "_luu"]))
+            s.stage_backward_pass()
+            Vx, Vxx = s.value_function()
+            for got, key in ((s.gains_K(), "K"), (s.gains_kff(), "k"), (Vx, "Vx"), (Vxx, "Vxx")):
+                want = r[case + "_" + key]
+                assert np.abs(got[1] - want).max() <= tol * max(1.0, np.abs(want).max()), (backward, case, key)
+            s.close()
+        # indefinite Quu even after the +1e-4 bump (ilqr.cpp:278-285): NumPy restatement of the long form
+        rng = np.random.default_rng(11)
+        N, n, m, lam = 4, 51, 19, 1e-6
+        A = np.eye(n)[None] + 0.05 * rng.standard_normal((N, n, n)); Bm = 0.1 * rng.standard_normal((N, n, m))
+        lx = rng.standard_normal((N + 1, n)); lu = rng.standard_normal((N, m))
+        lxx = np.stack([np.diag(rng.uniform(1.0, 3.0, n)) for _ in range(N + 1)]); luu = rng.uniform(0.5, 1.5, (N, m))
+        luu[2, 3] = -40.0; luu[1, 7] = -25.0
+        Vx, Vxx = lx[N].copy(), lxx[N].copy()
+        Kw = np.zeros((N, m, n))
+        for t in range(N - 1, -1, -1):
+            Qx = lx[t] + A[t].T @ Vx; Qu = lu[t] + Bm[t].T @ Vx
+            Qxx = lxx[t] + A[t].T @ Vxx @ A[t]; Quu = np.diag(luu[t]) + Bm[t].T @ Vxx @ Bm[t] + lam * np.eye(m); Qxu = A[t].T @ Vxx @ Bm[t]
+            if np.linalg.eigvalsh(Quu).min() <= 0:
+                Quu = Quu + 1e-4 * np.eye(m)
+            K = -np.linalg.solve(Quu, Qxu.T); k = -np.linalg.solve(Quu, Qu)
+            Vx = Qx + K.T @ Quu @ k + K.T @ Qu + Qxu @ k
+            Vxx = Qxx + K.T @ Quu @ K + K.T @ Qxu.T + Qxu @ K; Vxx = 0.5 * (Vxx + Vxx.T)
+            Kw[t] = K
+        s = _solver(2, N=N); s.set_regularization(lam)
+        rep = lambda a: np.stack([a] * 2)
+        s.set_linearization(rep(A), rep(Bm)); s.set_quadratics(rep(lx), rep(lu), rep(lxx), rep(luu))
+        s.stage_backward_pass()
+        gVx, gVxx = s.value_function()
+        assert rel(s.gains_K()[1], Kw) < 1e-7 and rel(gVx[1], Vx) < 1e-7 and rel(gVxx[0], Vxx) < 1e-7
+        s.close()
+
+
+@pytest.mark.parametrize("ls", ["s", "r"])
+def test_line_search_variants_match_oracle(ls):
+    prob, x0, ui = standing(3, seed=4)
+    with env(ILQR_LS=ls, ILQR_ROLLOUT=ls):
+        s = _solver(3); s.set_problem(prob)
+        s.initialize(x0, ui)
+        s.stage_linearize(); s.stage_cost_quadratics(); s.stage_backward_pass()
+        xb, ub = s.xbar(), s.ubar()
+        A, Bm = s.linearization(); lx, lu, lxx, luu = s.quadratics()
+        imp, cost, alpha = s.stage_line_search()
+        xn = s.xbar()
+        s.close()
+    for b in range(3):
+        o = ol.Oracle(prob["N"], prob["dt"]); o.set_problem(prob)
+        o.set_trajectory(xb[b], ub[b]); o.set_linearization(A[b], Bm[b]); o.set_quadratics(lx[b], lu[b], lxx[b], luu[b])
+        o.backward_pass()
+        ok, c, a = o.line_search(x0[b])
+        assert ok == bool(imp[b]) and a == alpha[b] and abs(c - cost[b]) < 1e-8 * abs(c) and rel(xn[b], o.get("xbar")) < 1e-8
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# BASELINE.json configs[1]: B = 1024 standing rollouts, N = 25, forward rollout + Jacobians only
+def test_config1_rollout_and_jacobians_at_1024():
+    B, N = 1024, 25
+    prob, x0, ui = standing(B, N, seed=1)
+    s = _solver(B, N=N); s.set_problem(prob)
+    s.initialize(x0, ui)
+    s.stage_linearize()
+    A, Bm = s.linearization()
+    xb, ub = s.xbar(), s.ubar()
+    assert np.all(np.isfinite(A)) and np.all(np.isfinite(Bm)) and np.array_equal(xb[:, 0], x0)
+    assert np.abs(np.linalg.norm(xb[:, :, 3:7], axis=2) - 1).max() < 1e-12
+    # structure of the semi-implicit Euler step: hinge positions q' = q + h v'  =>  dq'/du = h dv'/du, dq'/dq = I + h dv'/dq
+    h = prob["dt"]
+    assert np.abs(Bm[:, :, 7:26, :] - h * Bm[:, :, 32:51, :]).max() < 1e-12
+    assert np.abs(A[:, :, 0:3, 0:3] - np.eye(3) - h * A[:, :, 26:29, 0:3]).max() < 1e-12
+    # the trajectory satisfies the dynamics: x_{t+1} = f(x_t, u_t) (same step through the stage API)
+    for b in (0, 511, 1023):
+        assert np.array_equal(s.step(xb[b, :N], ub[b]), xb[b, 1:])
+    # oracle spot checks (forward-mode AD Jacobians) and a central-difference check through the GPU step itself
+    for b in (0, 333, 1023):
+        o = ol.Oracle(N, prob["dt"]); o.set_problem(prob); o.set_trajectory(xb[b], ub[b]); o.linearize()
+        assert np.abs(A[b] - o.get("A")).max() < 1e-9 and np.abs(Bm[b] - o.get("B")).max() < 1e-9
+        o2 = ol.Oracle(N, prob["dt"]); o2.set_problem(prob); o2.initialize(x0[b], ui[b])      # cold start = N rollout steps
+        assert rel(xb[b], o2.get("xbar")) < 1e-11
+    b, t, eps = 700, 12, 1e-6
+    xp = np.repeat(xb[b, t][None], 2 * 51, axis=0); up = np.repeat(ub[b, t][None], 2 * 51, axis=0)
+    for i in range(51):
+        xp[2 * i, i] += eps; xp[2 * i + 1, i] -= eps
+    f = s.step(xp, up)
+    Afd = ((f[0::2] - f[1::2]) / (2 * eps)).T
+    assert np.abs(Afd - A[b, t]).max() < 5e-7 * max(1.0, np.abs(A[b, t]).max())
+    s.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# BASELINE.json configs[4] at its per-GPU shape: B = 1024, N = 50, walking windows cut from the reference's walking file with
+# per-rollout start rows t0, contact-scheduled cost terms
+def walking_problem(B, N, seed):
+    from mpc_ilqr_mujoco_amd import references as rf
+    from mpc_ilqr_mujoco_amd import solver as sv
+    r = np.load(os.path.join(G, "refdata_golden.npz"))
+    # rows of data/h1_walking_pin.csv (Pinocchio quaternion order) -> MuJoCo order, velocities, stance flags: the offline
+    # preparation of references.prepare_reference, row for row
+    q_pin = r["walking_pin_rows"]
+    q_mj = rf.pinocchio_to_mujoco(q_pin)
+    v = rf.differentiate_positions(q_mj, float(r["dt"]))
+    flags = rf.contact_schedule(q_mj, sv.foot_clearance)
+    assert np.array_equal(flags, (r["walking_pin_clearance"] < 0).astype(np.int32))
+    rd = rf.ReferenceData(sv.reference_kinematics, sv.reference_com_velocity)
+    rd.set_states(np.concatenate([q_mj, v], axis=1)); rd.contact = flags
+    T = q_mj.shape[0]
+    base = sc.make_problem(sv.reference_kinematics, N=N, gravity=(0.0, 0.0, -1.0))
+    rng = np.random.default_rng(seed)
+    t0 = rng.integers(0, T - N - 1, size=B)
+    probs = {}
+    keys = ("x_ref", "u_ref", "com_ref", "stance", "ee_ref", "com_vel_ref")
+    stacks = {k: [] for k in keys}
+    for b in range(B):
+        if int(t0[b]) not in probs:
+            probs[int(t0[b])] = rd.problem_at(int(t0[b]), N, base, follow_schedule=True)
+        for k in keys:
+            stacks[k].append(probs[int(t0[b])][k][0])
+    prob = dict(base); prob["N"] = N
+    for k in keys:
+        prob[k] = np.stack(stacks[k])
+    x0 = rd.x_ref[t0].copy()
+    x0[:, 7:26] += rng.uniform(-0.02, 0.02, (B, 19)); x0[:, 0:3] += rng.uniform(-0.01, 0.01, (B, 3)); x0[:, 26:] *= 0.5
+    ug = sv.gravity_compensation(sc.standing_state(), prob["gravity"])
+    ui = np.tile(ug, (B, N, 1)) + rng.uniform(-0.5, 0.5, (B, N, 19))
+    return prob, x0, ui, t0
+
+
+def test_config4_walking_windows_at_per_gpu_shape():
+    B, N = 1024, 50
+    prob, x0, ui, t0 = walking_problem(B, N, seed=3)
+    assert prob["stance"].shape == (B, N + 1, 2) and prob["stance"].min() == 0 and len(set(t0.tolist())) > 50
+    s = _solver(B, N=N); s.set_problem(prob); s.set_max_iterations(4)
+    s.initialize(x0, ui)
+    cost = s.solve(x0)
+    tc = s.trace()[0]; it = s.iterations(); xb = s.xbar(); K = s.gains_K()
+    assert np.all(np.isfinite(cost)) and np.all(it >= 1) and np.all(it <= 4) and s.adopt_mismatches() == 0
+    for b in range(B):
+        assert np.all(np.diff(tc[b, : it[b] + 1]) <= 0)                   # accepted steps only ever decrease the cost
+    assert np.abs(np.linalg.norm(xb[:, :, 3:7], axis=2) - 1).max() < 1e-12 and np.array_equal(xb[:, 0], x0)
+    s.close()
+    # batch invariance: rollouts solved alone (their own reference sets) give bit-identical results
+    pick = [0, 500, 1023]
+    sub = dict(prob)
+    for k in ("x_ref", "u_ref", "com_ref", "stance", "ee_ref", "com_vel_ref"):
+        sub[k] = prob[k][pick]
+    s2 = _solver(len(pick), N=N); s2.set_problem(sub); s2.set_max_iterations(4)
+    s2.initialize(x0[pick], ui[pick]); c2 = s2.solve(x0[pick])
+    assert np.array_equal(c2, cost[pick]) and np.array_equal(s2.gains_K(), K[pick])
+    s2.close()
+    # oracle spot checks on the per-rollout reference sets
+    for b in (0, 777):
+        o = ol.Oracle(N, prob["dt"]); o.set_problem(prob, b); o.set_options(max_iter=4)
+        o.initialize(x0[b], ui[b]); ok, c = o.solve(x0[b])
+        n, oc, oa, _ = o.trace()
+        assert n == it[b] and np.allclose(tc[b, : n + 1], oc[: n + 1], rtol=1e-5) and rel(K[b], o.get("K")) < 1e-5
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# multi-rank: two ranks (both on device 0, payload staged through a gloo gather) vs one process solving the global batch
+_WORKER = r"""
+import os, sys
+import numpy as np
+import torch
+import torch.distributed as dist
+sys.path.insert(0, os.path.join(%(root)r, "tests"))
+from conftest import load_package
+pkg = load_package()
+from mpc_ilqr_mujoco_amd import sharding as sh, solver as sv
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+d = np.load(%(inp)r)
+G = d["x0"].shape[0]
+lo, hi = sh.shard_range(G, rank, world)
+prob = {k[2:]: d[k] for k in d.files if k.startswith("p_")}
+prob["task_weights"] = tuple(prob["task_weights"]); prob["gravity"] = tuple(prob["gravity"])
+for k in ("N", "dt", "w_joint", "w_ctrl"):
+    prob[k] = prob[k].item()
+s = sv.BatchedILQR(hi - lo, N=prob["N"], dt=prob["dt"], device=0)
+s.set_problem(prob); s.set_max_iterations(3)
+s.initialize(d["x0"][lo:hi], d["ui"][lo:hi]); s.solve(d["x0"][lo:hi])
+# the C ABI's own gather in its one-rank form packs the payload rows [u0 | cost | K0] on the device ...
+s.comm_init(1, 0)
+rows = torch.zeros(hi - lo, sh.payload_width(True), dtype=torch.float64, device="cuda:0")
+s.gather_first_knot(rows.data_ptr(), root=0, with_gains=True); s.synchronize()
+# ... and the exchange between the ranks is staged through the host here (two ranks share one GPU, which RCCL refuses)
+g = sh.gather_first_knot(rows.cpu(), dst=0)
+if rank == 0:
+    np.save(%(out)r, g.numpy())
+dist.barrier(); dist.destroy_process_group(); s.close()
+"""
+
+
+def test_two_rank_shard_gather_equals_single_process_bitwise(tmp_path):
+    from mpc_ilqr_mujoco_amd import sharding as sh
+    Gb = 16
+    prob, x0, ui = standing(Gb, seed=9)
+    inp, out = str(tmp_path / "in.npz"), str(tmp_path / "g.npy")
+    np.savez(inp, x0=x0, ui=ui, **{"p_" + k: np.asarray(v) for k, v in prob.items()})
+    script = str(tmp_path / "worker.py")
+    open(script, "w").write(_WORKER % dict(root=ROOT, inp=inp, out=out))
+    sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), script], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    g = np.load(out)
+    import torch
+    u0, cost, K0 = sh.unpack_payload(torch.from_numpy(g), True)
+    s = _solver(Gb); s.set_problem(prob); s.set_max_iterations(3)
+    s.initialize(x0, ui); c = s.solve(x0)
+    assert np.array_equal(cost.numpy(), c) and np.array_equal(u0.numpy(), s.ubar()[:, 0]) and np.array_equal(K0.numpy(), s.gains_K()[:, 0])
+    s.close()
+
+
+def test_bench_two_ranks_rehearsed_on_one_gpu():
+    """The world > 1 branch of bench.py (global batch sliced by shard_range, barrier, max-over-ranks timing, gather) executed
+    with two ranks on device 0 over gloo (--rehearse-single-gpu; on a multi-GPU node the same branch runs over RCCL)."""
+    sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--batch", "64", "--steps", "1", "--warmup", "0",
+                        "--rehearse-single-gpu"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 128 and d["value"] > 0 and "roofline" in d and "cpu_baseline" not in d
+    assert d["config"]["gather_check"] == "rank 0 received 128 rows in global rollout order"
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# C++ drop-in sharding without Python: the demo's one-rank form against the Python wrapper on the same rollouts
+def _demo_rollout(g, N):
+    M = (1 << 64) - 1
+    st = [(0x9E3779B97F4A7C15 * (g + 1)) & M]
+
+    def rnd():
+        s = st[0]
+        s ^= (s << 13) & M; s ^= s >> 7; s ^= (s << 17) & M
+        st[0] = s
+        return (s >> 11) / 9007199254740992.0 * 2.0 - 1.0
+    x0 = np.zeros(51); x0[2] = 1.0432
+    for i in range(3):
+        x0[i] += 0.02 * rnd()
+    w = np.array([0.05 * rnd(), 0.05 * rnd(), 0.05 * rnd()])
+    ang = float(np.sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2])); shf = np.sin(0.5 * ang) / ang if ang > 1e-12 else 0.5
+    x0[3] = np.cos(0.5 * ang); x0[4:7] = shf * w
+    for i in range(7, 26):
+        x0[i] = 0.05 * rnd()
+    for i in range(26, 51):
+        x0[i] = 0.1 * rnd()
+    u = np.array([[rnd() for _ in range(19)] for _ in range(N)])
+    return x0, u
+
+
+def test_cpp_multi_gpu_demo_one_rank(tmp_path):
+    from mpc_ilqr_mujoco_amd import solver as sv
+    exe = os.path.join(ROOT, "tests", "cpp", "build", "cpp_multi_gpu_demo")
+    assert os.path.exists(exe), "built by __graft_entry__.build()"
+    B, N = 6, 25
+    out = str(tmp_path / "rows.bin")
+    r = subprocess.run([exe, "1", str(B), "1", out], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    rows = np.fromfile(out).reshape(B, 20 + 19 * 51)
+    prob = sc.make_problem(sv.reference_kinematics, N=N)
+    xs, us = zip(*[_demo_rollout(g, N) for g in range(B)])
+    x0, ui = np.array(xs), np.array(us)
+    s = _solver(B); s.set_problem(prob); s.set_max_iterations(3)
+    s.initialize(x0, ui); c = s.solve(x0)
+    assert rel(rows[:, 19], c) < 1e-9 and rel(rows[:, :19], s.ubar()[:, 0]) < 1e-8 and rel(rows[:, 20:].reshape(B, 19, 51), s.gains_K()[:, 0]) < 1e-7
+    s.close()

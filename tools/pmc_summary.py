@@ -2,7 +2,8 @@
 """Per-kernel summary of rocprofv3 --pmc counter_collection.csv files.
 
   python tools/pmc_summary.py <counter_collection.csv> [...]            # table: n, mean, max per (kernel, counter)
-  python tools/pmc_summary.py --traffic-json OUT <fetch.csv> <write.csv>  # per kernel: FETCH_SIZE / WRITE_SIZE of the
+  python tools/pmc_summary.py --traffic-json OUT [--stamp "$(python bench.py --print-signature ...)"] <fetch.csv> <write.csv>
+      # per kernel: FETCH_SIZE / WRITE_SIZE of the
       largest launch (= the full-batch launch; the lambda-retry launches of the same kernel run a subset), in KiB as
       rocprofv3 reports them.  bench.py turns them into bytes: 2 x FETCH_SIZE (gfx950 counts 64 B per 128-B request,
       MI355X_MICROARCH.md "HBM"; re-checked for 8-byte-per-lane accesses with tools/probes/pmc_calib.hip) + WRITE_SIZE.
@@ -17,12 +18,24 @@ def load(paths):
     return acc
 
 if len(sys.argv) > 2 and sys.argv[1] == "--traffic-json":
-    acc = load(sys.argv[3:])
+    rest = sys.argv[3:]
+    stamp = None
+    if rest and rest[0] == "--stamp":      # signature of the bench run the counters were collected on (bench.py --print-signature)
+        stamp = json.loads(rest[1]); rest = rest[2:]
+    acc = load(rest)
     out = {}
     for (k, c), v in acc.items():
         if c in ("FETCH_SIZE", "WRITE_SIZE") and k.startswith("k_"):
             out.setdefault(k, {})[c + "_KiB"] = max(v)
     out = {k: v for k, v in out.items() if len(v) == 2}
+    if stamp is not None:
+        import subprocess, datetime
+        try:
+            stamp["head"] = subprocess.check_output(["git", "rev-parse", "--short", "HEAD"], text=True).strip()
+        except Exception:
+            stamp["head"] = "unknown"
+        stamp["date"] = datetime.date.today().isoformat()
+        out["_stamp"] = stamp
     json.dump(out, open(sys.argv[2], "w"), indent=1, sort_keys=True)
     print(json.dumps(out, indent=1, sort_keys=True))
 else:
