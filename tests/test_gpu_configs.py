@@ -167,7 +167,7 @@ def test_config1_rollout_and_jacobians_at_1024():
     assert np.abs(A[:, :, 0:3, 0:3] - np.eye(3) - h * A[:, :, 26:29, 0:3]).max() < 1e-12
     # the trajectory satisfies the dynamics: x_{t+1} = f(x_t, u_t) (same step through the stage API)
     for b in (0, 511, 1023):
-        assert np.array_equal(s.step(xb[b, :N], ub[b]), xb[b, 1:])
+        assert rel(s.step(xb[b, :N], ub[b]), xb[b, 1:]) < 1e-12        # (one-lane step kernel vs two-lane rollout kernel: rounding only)
     # oracle spot checks (forward-mode AD Jacobians) and a central-difference check through the GPU step itself
     for b in (0, 333, 1023):
         o = ol.Oracle(N, prob["dt"]); o.set_problem(prob); o.set_trajectory(xb[b], ub[b]); o.linearize()
@@ -233,7 +233,8 @@ def test_config4_walking_windows_at_per_gpu_shape():
     assert np.all(np.isfinite(cost)) and np.all(it >= 1) and np.all(it <= 4) and s.adopt_mismatches() == 0
     for b in range(B):
         assert np.all(np.diff(tc[b, : it[b] + 1]) <= 0)                   # accepted steps only ever decrease the cost
-    assert np.abs(np.linalg.norm(xb[:, :, 3:7], axis=2) - 1).max() < 1e-12 and np.array_equal(xb[:, 0], x0)
+    # (knot 0 is the measured state: rows of the 6-digit CSV, normalised by the step, not before it)
+    assert np.abs(np.linalg.norm(xb[:, 1:, 3:7], axis=2) - 1).max() < 1e-12 and np.array_equal(xb[:, 0], x0)
     s.close()
     # batch invariance: rollouts solved alone (their own reference sets) give bit-identical results
     pick = [0, 500, 1023]
