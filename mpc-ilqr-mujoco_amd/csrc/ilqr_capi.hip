@@ -118,7 +118,7 @@ int ilqr_hip_create(ilqr_hip_ctx** out, int device, int batch, int horizon, doub
   A(dalloc(c, &S.A, B * N * n * n + 32)); A(dalloc(c, &S.Bm, B * N * n * m + 32));   // slack: riccati_wave.hip stages 16-byte pairs that may straddle the end of the last row
   A(dalloc(c, &S.lx, B * (N + 1) * n)); A(dalloc(c, &S.lu, B * N * m)); A(dalloc(c, &S.lxx, B * (N + 1) * n * n)); A(dalloc(c, &S.luu, B * N * m));
   A(dalloc(c, &S.lin_dump, B * N * ilqr::lin_dump_doubles()));
-  A(dalloc(c, &S.K, B * N * m * n)); A(dalloc(c, &S.kff, B * N * m)); A(dalloc(c, &S.Vx, B * n)); A(dalloc(c, &S.Vxx, B * n * n));
+  A(dalloc(c, &S.K, B * N * m * n + 32)); /* slack: the line search stages K_t in 16-byte pairs, the last one ends one double past the knot */ A(dalloc(c, &S.kff, B * N * m)); A(dalloc(c, &S.Vx, B * n)); A(dalloc(c, &S.Vxx, B * n * n));
   A(dalloc(c, &S.J, B)); A(dalloc(c, &S.Jbase, B)); A(dalloc(c, &S.ls_cost, B)); A(dalloc(c, &S.lambda, B));
   A(dalloc(c, &S.active, B)); A(dalloc(c, &S.need_retry, B)); A(dalloc(c, &S.iters, B)); A(dalloc(c, &S.improved, B)); A(dalloc(c, &S.alpha_idx, B));
   A(dalloc(c, &S.trace_cost, B * (c->max_iter + 1))); A(dalloc(c, &S.trace_alpha, B * c->max_iter)); A(dalloc(c, &S.trace_lambda, B * c->max_iter));
@@ -144,6 +144,13 @@ int ilqr_hip_create(ilqr_hip_ctx** out, int device, int batch, int horizon, doub
   std::vector<double> lam(B, 1e-6);
   hipMemcpyAsync(S.lambda, lam.data(), B * sizeof(double), hipMemcpyHostToDevice, c->stream);
   if (hipStreamSynchronize(c->stream) != hipSuccess) { c->err = "stream sync failed in create"; *out = c; return ILQR_ERR_HIP; }
+  if (getenv("ILQR_DEBUG_PTRS")) {   // diagnostic: device address ranges, to place the address of a reported memory access fault
+    auto pr = [&](const char* name, const void* p, size_t bytes) { std::fprintf(stderr, "[ilqr_hip] %-10s %p .. %p\n", name, p, (const void*)((const char*)p + bytes)); };
+    pr("x0", S.x0, B * n * 8); pr("xbar", S.xbar, B * (N + 1) * n * 8); pr("ubar", S.ubar, B * N * m * 8);
+    pr("xcand", S.xcand, B * 8 * (N + 1) * n * 8); pr("ucand", S.ucand, B * 8 * N * m * 8); pr("K", S.K, (B * N * m * n + 32) * 8); pr("kff", S.kff, B * N * m * 8);
+    pr("A", S.A, (B * N * n * n + 32) * 8); pr("Bm", S.Bm, (B * N * n * m + 32) * 8); pr("lxx", S.lxx, B * (N + 1) * n * n * 8); pr("lin_dump", S.lin_dump, B * N * ilqr::lin_dump_doubles() * 8);
+    pr("active", S.active, B * 4); pr("cand_knot", S.cand_knot, B * 8 * (N + 1) * 8);
+  }
   *out = c;
   return ILQR_OK;
 }
