@@ -7,10 +7,13 @@
 //   3  Jacobian columns of c and cdot, lane = coordinate
 //   4  weighted functionals (one per active cost term) and their per-joint vectors til x z_j, P'_j, lane = (term, joint)
 //   5  gradient, lane = coordinate
-//   6  Hessian, upper-triangle entries distributed over the lanes block by block of the coordinate classes
-//      p | quat | theta | v_b | omega_b | thetadot, so that every lane of an iteration runs the same formula
-//      (the 2 w J^T J part is generic; the second-order part exists in 8 of the 21 class pairs only)
-// lxx is written twice per entry (a,b) and (b,a); the L2 merges the partial lines before they reach HBM.
+//   6  Hessian.  The first-order (Gauss-Newton) part -- sum_i scale_i J_i^T J_i over the <= 4 gradient-carrying functionals and
+//      the four dyads of the balance term -- is one 51 x 16 x 51 product on v_mfma_f64_16x16x4_f64 (4 k-steps x 16 tiles,
+//      operands straight from the Jacobian rows in LDS); the second-order part exists in 8 of the 21 pairs of coordinate
+//      classes p | quat | theta | v_b | omega_b | thetadot only: those entries are evaluated block by block (every lane of
+//      an iteration runs the same formula) into an LDS patch that the owner lanes of the accumulator tiles add before they
+//      store lxx row by row (128-byte runs; the version before this one evaluated 12 + 4 products per entry on the vector
+//      ALU behind 32 LDS reads and stored every entry twice at scattered addresses: 60 k of the kernel's 107 k cycles).
 #include <hip/hip_runtime.h>
 
 #include "h1_cost_dev.h"
@@ -42,21 +45,51 @@ constexpr QAncTable make_anc_table() {
 }
 __constant__ static const QAncTable QANC = make_anc_table();
 
+// (theta, theta) upper-triangle and (theta, thetadot) full-block entries with a second-order part: the pairs of joints one of
+// which is an ancestor of (or is) the other -- 59 + 99 of the 190 + 361 entries.  Packed: ja | jb << 5 | isd << 10.
+struct QRelTable { unsigned short e[192]; int n; };
+constexpr QRelTable make_rel_table() {
+  QRelTable T{};
+  int n = 0;
+  const QAncTable A = make_anc_table();
+  for (int ja = 1; ja < H1_NB; ++ja)
+    for (int jb = ja; jb < H1_NB; ++jb)
+      if ((A.m[ja] >> jb) & 1u) T.e[n++] = (unsigned short)(ja | (jb << 5));
+  for (int ja = 1; ja < H1_NB; ++ja)
+    for (int jb = 1; jb < H1_NB; ++jb)
+      if (((A.m[ja] >> jb) & 1u) || ((A.m[jb] >> ja) & 1u)) T.e[n++] = (unsigned short)(ja | (jb << 5) | (1 << 10));
+  T.n = n;
+  return T;
+}
+__constant__ static const QRelTable QREL = make_rel_table();
+static_assert(make_rel_table().n == 158, "related joint pairs of the H1 tree");
+
 #define QMAXC 6   // at most: CoM pos, CoM vel, one functional per foot (swing: position / stance: velocity), 2 balance
 struct QuadCtx { int set, is_vel; double scale; double vec[3], til[3], Dv[4][3]; };
 // 20,2xx B of LDS: 8 waves per CU.  Phase-1/2 temporaries share storage with the per-joint vectors of phase 4.
+#define QS2_R0 3            // second-order patch: rows quat | theta (3..25), columns 3..50, entry (a, b) with a <= b
+#define QS2_NR 23
+#define QS2_NC 48
 struct QuadLds {
-  double xp[H1_NX];                      // Pinocchio-ordered state (derivatives.cpp:12-24)
-  double R0[9], D[4][9];                 // base rotation (Eigen toRotationMatrix polynomial), dR/dquat_k
-  double zh[H1_NB][3], Om[H1_NB][3];     // joint axes and body angular velocities, pelvis frame
+  union {
+    struct {                               // phases 0..5 and the operand fetch of phase 6
+      double Jc[3][3][H1_NX], Jv[3][3][H1_NX];   // d c / d x_p, d cdot / d x_p per point set
+      double jr[2][H1_NX];                   // balance rows jr0, jr1 (jz, Jv0, Jv1 are rows of Jc[0] / Jv[0])
+      double xp[H1_NX];                      // Pinocchio-ordered state (derivatives.cpp:12-24)
+      double R0[9], D[4][9];                 // base rotation (Eigen toRotationMatrix polynomial), dR/dquat_k
+      double zh[H1_NB][3], Om[H1_NB][3];     // joint axes and body angular velocities, pelvis frame
+      double us[H1_NU];
+      double gsum[QMAXC][3];
+    };
+    double S2[QS2_NR][QS2_NC];             // phase 6: second-order part of the entries that have one
+  };
   double beta[3][3], gamma[3][3], mfrac[3];
   double w[3][H1_NB][3], dgam[3][H1_NB][3];
-  int on[3][H1_NB];
-  double Jc[3][3][H1_NX], Jv[3][3][H1_NX];   // d c / d x_p, d cdot / d x_p per point set
+  unsigned char on[3][H1_NB];
   QuadCtx ctx[QMAXC];
-  double jr[2][H1_NX];                   // balance rows jr0, jr1 (jz, Jv0, Jv1 are rows of Jc[0] / Jv[0])
-  double us[H1_NU];
-  double gsum[QMAXC][3]; int gset[QMAXC], gvel[QMAXC]; int nctx, ng, has_bal; double bal[8];
+  double dg[H1_NX];                      // diagonal additions: Q (or Qf) + soft joint-limit penalty
+  double gscale[QMAXC];                  // scale of the gradient-carrying functionals (first-order product)
+  unsigned char gset[8], gvel[8]; int nctx, ng, has_bal; double bal[8];
   double uJ[3][4], ur[3];                // upright pieces
   unsigned anc[H1_NB];                   // bit j of anc[i]: body i is an ancestor of (or is) body j
   union {
@@ -64,6 +97,7 @@ struct QuadLds {
     struct { double tz[QMAXC][H1_NJ][3], Pp[QMAXC][H1_NJ][3]; } j;                    // phases 4-6: til_c x z_j, P'_j
   } u;
 };
+static_assert(sizeof(double) * QS2_NR * QS2_NC <= sizeof(double) * (2 * 9 * H1_NX + 2 * H1_NX + H1_NX + 9 + 36 + 6 * H1_NB + H1_NU + 3 * QMAXC), "the patch fits the storage it aliases");
 static_assert(H1_NB * 3 >= H1_NX, "balance row m aliases Om");
 static_assert(sizeof(QuadLds) <= 20480, "QuadLds must fit 8 waves per CU");
 
@@ -256,7 +290,7 @@ __global__ void __launch_bounds__(64, QUAD_WAVES) k_cost_quadratics(DevState S, 
     auto push = [&](int set, int is_vel, double scale, const double* vec, bool grad) {
       L.ctx[n].set = set; L.ctx[n].is_vel = is_vel; L.ctx[n].scale = scale;
       for (int k = 0; k < 3; ++k) L.ctx[n].vec[k] = vec[k];
-      if (grad) { L.gset[g] = set; L.gvel[g] = is_vel; for (int k = 0; k < 3; ++k) L.gsum[g][k] = scale * vec[k]; ++g; }
+      if (grad) { L.gset[g] = (unsigned char)set; L.gvel[g] = (unsigned char)is_vel; L.gscale[g] = scale; for (int k = 0; k < 3; ++k) L.gsum[g][k] = scale * vec[k]; ++g; }
       ++n;
     };
     if (P.w_com > 0.0) {   // CoM position: w ||com - ref||^2
@@ -298,7 +332,18 @@ __global__ void __launch_bounds__(64, QUAD_WAVES) k_cost_quadratics(DevState S, 
       push(0, 0, P.w_balance, mu, false);
       push(0, 1, P.w_balance, nu, false);
     }
-    L.nctx = n; L.ng = g;
+    // the second-order part is linear in scale_c vec_c: contexts acting on the same point set with the same type merge
+    // (typically 6 -> 4: CoM position + balance, balance velocity part, one per foot); their scale becomes 1
+    int nm = 0;
+    for (int c = 0; c < n; ++c) {
+      int at = -1;
+      for (int q = 0; q < nm; ++q) if (L.ctx[q].set == L.ctx[c].set && L.ctx[q].is_vel == L.ctx[c].is_vel) at = q;
+      const double sc = L.ctx[c].scale;
+      const double v0 = sc * L.ctx[c].vec[0], v1 = sc * L.ctx[c].vec[1], v2 = sc * L.ctx[c].vec[2];
+      if (at < 0) { const int st_ = L.ctx[c].set, iv = L.ctx[c].is_vel; at = nm++; L.ctx[at].set = st_; L.ctx[at].is_vel = iv; L.ctx[at].scale = 1.0; L.ctx[at].vec[0] = v0; L.ctx[at].vec[1] = v1; L.ctx[at].vec[2] = v2; }
+      else { L.ctx[at].vec[0] += v0; L.ctx[at].vec[1] += v1; L.ctx[at].vec[2] += v2; }
+    }
+    L.nctx = nm; L.ng = g;
   }
   __syncthreads();
   const int nctx = L.nctx, ng = L.ng, has_bal = L.has_bal;
@@ -353,6 +398,13 @@ __global__ void __launch_bounds__(64, QUAD_WAVES) k_cost_quadratics(DevState S, 
       if (q < lo) g += -2.0 * P.w_joint * (lo - q);
     }
     S.lx[((size_t)b * (N + 1) + t) * H1_NX + a] = g;
+    double dgl = Qd[a];
+    if (a >= 7 && a < H1_NQ) {
+      double lo, hi; limit_bounds(H1_JRANGE[a - 7], lo, hi);
+      const double q = L.xp[a];
+      if (q > hi || q < lo) dgl += 2.0 * P.w_joint;
+    }
+    L.dg[a] = dgl;
   }
   if (!term && lane < H1_NU) {
     const double* ur_ = P.u_ref + b * P.u_ref_stride + t * H1_NU;
@@ -367,32 +419,43 @@ __global__ void __launch_bounds__(64, QUAD_WAVES) k_cost_quadratics(DevState S, 
   }
   QSTAMP(5)
 
-  // ---- phase 6: Hessian lxx, block by block of the coordinate classes
+  // ---- phase 6: Hessian lxx
   double* Hg = S.lxx + ((size_t)b * (N + 1) + t) * H1_NX * H1_NX;
-  // first-order (Gauss-Newton) part common to every entry: sum_i scale_i J_i^T J_i, then the balance rows
-  const double* Jrow[4]; double Jscale[4];   // at most 4 functionals carry a Gauss-Newton part (CoM pos / vel, one per foot)
+  typedef double v4d_q __attribute__((ext_vector_type(4)));
+  const int lr = lane & 15, lk = lane >> 4;
+  // 6a: operands of the first-order product H1[a][b] = sum_k sA_k RA_k[a] RB_k[b], k = 4 ks + lk:
+  //   lk < 3 : row lk of the Jacobian of gradient-carrying functional ks (RA = RB, sA = its scale)
+  //   lk = 3 : the balance dyads w (jr0 jr0' + jr1 jr1' + jz m' + m jz'): ks = 0 jr0, 1 jr1, 2 (jz, m), 3 (m, jz)
+  // operand of row tile I / column tile J = entry 16 I + lr of the row; everything beyond column 50 and every unused row is
+  // a true zero (junk operands slow the fp64 MFMA down tenfold)
+  double av[4][4], bv[4][4];
+  {
+    double* const balm_ = &L.Om[0][0];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int ii = i < ng ? i : 0;
-    Jrow[i] = L.gvel[ii] ? &L.Jv[L.gset[ii]][0][0] : &L.Jc[L.gset[ii]][0][0];
-    Jscale[i] = i < ng ? L.ctx[ii].scale : 0.0;
+    for (int ks = 0; ks < 4; ++ks) {
+      const int ii = ks < ng ? ks : 0;
+      const double* rowJ = (L.gvel[ii] ? &L.Jv[L.gset[ii]][0][0] : &L.Jc[L.gset[ii]][0][0]) + (lk < 3 ? lk : 0) * H1_NX;
+      const double* rowA = lk < 3 ? rowJ : (ks == 0 ? L.jr[0] : (ks == 1 ? L.jr[1] : (ks == 2 ? L.Jc[0][2] : balm_)));
+      const double* rowB = lk < 3 ? rowJ : (ks == 0 ? L.jr[0] : (ks == 1 ? L.jr[1] : (ks == 2 ? balm_ : L.Jc[0][2])));
+      const bool used = lk < 3 ? (ks < ng) : (has_bal != 0);
+      const double sA = lk < 3 ? L.gscale[ii] : P.w_balance;
+#pragma unroll
+      for (int T = 0; T < 4; ++T) {
+        const int e = 16 * T + lr, ec = e < H1_NX ? e : H1_NX - 1;
+        const double ra = rowA[ec], rb = rowB[ec];
+        const bool ok = used && e < H1_NX;
+        av[ks][T] = ok ? sA * ra : 0.0;
+        bv[ks][T] = ok ? rb : 0.0;
+      }
+    }
   }
-  auto dense = [&](int a, int bb) -> double {
-    double h = 0.0;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-      if (i < ng) { const double* J = Jrow[i]; h += Jscale[i] * (J[a] * J[bb] + J[H1_NX + a] * J[H1_NX + bb] + J[2 * H1_NX + a] * J[2 * H1_NX + bb]); }
-    return h;
-  };
-  // balance: jr0 jr0' + jr1 jr1' + om1 (r0 (Jv0 jz' + jz Jv0') + r1 (Jv1 jz' + jz Jv1')) + rv om2 jz jz' = ... + jz m' + m jz'
-  auto balance = [&](int a, int bb) -> double {
-    const double v = L.jr[0][a] * L.jr[0][bb] + L.jr[1][a] * L.jr[1][bb] + L.Jc[0][2][a] * balm[bb] + balm[a] * L.Jc[0][2][bb];
-    return P.w_balance * v;
-  };
-  auto store = [&](int a, int bb, double h) {
-    Hg[a * H1_NX + bb] = h;
-    if (a != bb) Hg[bb * H1_NX + a] = h;
-  };
+  QSTAMP(6)
+  __syncthreads();   // the Jacobian rows are in registers: their storage becomes the second-order patch
+  for (int e = lane; e < QS2_NR * QS2_NC; e += 64) (&L.S2[0][0])[e] = 0.0;
+  __syncthreads();
+  // 6b: second-order part, block by block of the coordinate classes (a <= bb in every block).  The (merged) contexts'
+  // set / type are wave-uniform: held in scalar registers, so the loops over them branch uniformly.
+  auto patch = [&](int a, int bb, double h) { L.S2[a - QS2_R0][bb - QS2_R0] = h; };
   // triangular index -> (i, j), i <= j < n
   auto tri = [](int idx, int n, int& i, int& j) {
     int a = (int)((2 * n + 1 - sqrtf((float)((2 * n + 1) * (2 * n + 1) - 8 * idx))) * 0.5f);   // exact integers in fp32; corrected below
@@ -401,40 +464,95 @@ __global__ void __launch_bounds__(64, QUAD_WAVES) k_cost_quadratics(DevState S, 
     i = a; j = a + (idx - (a * n - (a * (a - 1)) / 2));
   };
   const int Q0 = 3, T0 = 7, V0 = H1_NQ, W0 = H1_NQ + 3, D0 = H1_NQ + 6, NJ = H1_NJ;
-
-  // (p, *) rows 0..2 and (v_b | omega_b, v_b | omega_b | thetadot) rows 26..31: first-order part only
-  for (int idx = lane; idx < 150 + 135; idx += 64) {
-    int a, bb;
-    if (idx < 150) { a = idx < 51 ? 0 : (idx < 101 ? 1 : 2); bb = a + idx - (a == 0 ? 0 : (a == 1 ? 51 : 101)); }
-    else { int r, c; tri(idx - 150, 25, r, c); a = V0 + r; bb = V0 + c; }
-    double h = (a == bb) ? Qd[a] : 0.0;
-    h += dense(a, bb);
-    if (has_bal) h += balance(a, bb);
-    store(a, bb, h);
+  int cset[QMAXC], cvel[QMAXC];
+#pragma unroll
+  for (int c = 0; c < QMAXC; ++c) {
+    const int cc = c < nctx ? c : 0;
+    cset[c] = __builtin_amdgcn_readfirstlane(L.ctx[cc].set); cvel[c] = __builtin_amdgcn_readfirstlane(L.ctx[cc].is_vel);
   }
-  // (thetadot, thetadot) and (theta, v_b): first-order part only
-  for (int idx = lane; idx < 190 + 57; idx += 64) {
-    int a, bb;
-    if (idx < 190) { int r, c; tri(idx, NJ, r, c); a = D0 + r; bb = D0 + c; }
-    else { const int e = idx - 190; a = T0 + e / 3; bb = V0 + e % 3; }
-    double h = (a == bb) ? Qd[a] : 0.0;
-    h += dense(a, bb);
-    if (has_bal) h += balance(a, bb);
-    store(a, bb, h);
+  // (theta, theta) and (theta, thetadot), related joints only (compile-time list): three passes of 64 entries
+  for (int e = lane; e < 158; e += 64) {
+    const unsigned pk = QREL.e[e];
+    const int ja = pk & 31, jb = (pk >> 5) & 31;
+    const bool isd = (pk >> 10) != 0;
+    const int lo = ja < jb ? ja : jb, hi = ja < jb ? jb : ja;     // parents precede their children in the body numbering
+    double h = 0.0;
+#pragma unroll
+    for (int c = 0; c < QMAXC; ++c) {
+      if (c >= nctx) break;
+      const int st_ = cset[c];
+      const double f = (L.on[st_][ja] & L.on[st_][jb]) ? 1.0 : 0.0;
+      const double* tz = L.u.j.tz[c][lo - 1];
+      const double* wh = L.w[st_][hi];
+      const double t1 = dot3(tz, wh);
+      double v;
+      if (cvel[c]) { const double t2 = dot3(L.u.j.Pp[c][lo - 1], wh) + dot3(tz, L.dgam[st_][hi]); v = isd ? t1 : t2; }
+      else v = isd ? 0.0 : t1;
+      h += f * v;                                  // (the merged contexts carry their weight in vec: scale = 1)
+    }
+    patch(T0 + ja - 1, (isd ? D0 : T0) + jb - 1, h);
   }
-  // (quat, quat): d2R/dq2 terms + upright
-  if (lane < 10) {
-    int ka, kb; tri(lane, 4, ka, kb);
-    const int a = Q0 + ka, bb = Q0 + kb;
-    double h = (a == bb) ? Qd[a] : 0.0;
-    h += dense(a, bb);
+  // (quat, theta) and (quat, thetadot): Dv . w / Dv . dgam
+  for (int idx = lane; idx < 2 * 4 * NJ; idx += 64) {
+    const bool isd = idx >= 4 * NJ;
+    const int e = isd ? idx - 4 * NJ : idx;
+    const int k = e / NJ, j = 1 + e % NJ;
+    double h = 0.0;
+#pragma unroll
+    for (int c = 0; c < QMAXC; ++c) {
+      if (c >= nctx) break;
+      const int st_ = cset[c];
+      const double f = L.on[st_][j] ? 1.0 : 0.0;
+      const double* Dv = L.ctx[c].Dv[k];
+      double v;
+      if (cvel[c]) v = dot3(Dv, isd ? L.w[st_][j] : L.dgam[st_][j]);
+      else v = isd ? 0.0 : dot3(Dv, L.w[st_][j]);
+      h += f * v;
+    }
+    patch(Q0 + k, (isd ? D0 : T0) + j - 1, h);
+  }
+  // (theta, omega_b): (w_j x til)_c on lanes 0..56; (quat, v_b), (quat, omega_b) and (quat, quat) on lanes 0..33 of a second pass
+  if (lane < 3 * NJ) {
+    const int ja = 1 + lane / 3, cc = lane % 3;
+    double h = 0.0;
+#pragma unroll
+    for (int c = 0; c < QMAXC; ++c) {
+      if (c >= nctx) break;
+      if (!cvel[c]) continue;
+      const int st_ = cset[c];
+      const double f = L.on[st_][ja] ? 1.0 : 0.0;
+      double tv[3]; cross(L.w[st_][ja], L.ctx[c].til, tv);
+      h += f * sel3(tv, cc);
+    }
+    patch(T0 + ja - 1, W0 + cc, h);
+  }
+  if (lane < 24) {
+    const bool isw = lane >= 12;
+    const int e = isw ? lane - 12 : lane;
+    const int k = e / 3, cc = e % 3;
+    double h = 0.0;
+#pragma unroll
+    for (int c = 0; c < QMAXC; ++c) {
+      if (c >= nctx) break;
+      if (!cvel[c]) continue;
+      const QuadCtx& C = L.ctx[c];
+      const int st_ = cset[c];
+      if (!isw) h += C.Dv[k][cc] * L.mfrac[st_];
+      else { double tv[3]; cross(L.beta[st_], C.Dv[k], tv); h += sel3(tv, cc); }   // Dv . (-[beta]x e_c) = (beta x Dv)_c
+    }
+    patch(Q0 + k, (isw ? W0 : V0) + cc, h);
+  } else if (lane >= 32 && lane < 42) {
+    // (quat, quat): d2R/dq2 terms + upright
+    int ka, kb; tri(lane - 32, 4, ka, kb);
+    double h = 0.0;
     double D2[9]; d2R_sel(ka, kb, D2);
 #pragma unroll
     for (int c = 0; c < QMAXC; ++c) {
       if (c >= nctx) break;
       const QuadCtx& C = L.ctx[c];
-      double tv[3]; mv3(D2, C.is_vel ? L.gamma[C.set] : L.beta[C.set], tv);
-      h += C.scale * dot3(C.vec, tv);
+      const int st_ = cset[c];
+      double tv[3]; mv3(D2, cvel[c] ? L.gamma[st_] : L.beta[st_], tv);
+      h += dot3(C.vec, tv);
     }
     if (P.w_upright > 0.0) {
       const int i = ka, j = kb;
@@ -445,92 +563,38 @@ __global__ void __launch_bounds__(64, QUAD_WAVES) k_cost_quadratics(DevState S, 
       if ((i == 1 && j == 1) || (i == 2 && j == 2)) v += -4.0 * L.ur[2];
       h += P.w_upright * v;
     }
-    if (has_bal) h += balance(a, bb);
-    store(a, bb, h);
+    patch(Q0 + ka, Q0 + kb, h);
   }
-  // (quat, theta) and (quat, thetadot): Dv . w / Dv . dgam
-  for (int idx = lane; idx < 2 * 4 * NJ; idx += 64) {
-    const bool isd = idx >= 4 * NJ;
-    const int e = isd ? idx - 4 * NJ : idx;
-    const int k = e / NJ, j = 1 + e % NJ;
-    const int a = Q0 + k, bb = (isd ? D0 : T0) + j - 1;
-    double h = dense(a, bb);
+  __syncthreads();
+  QSTAMP(7)
+  // 6c: first-order product row tile by row tile; the owner lane of an accumulator element (row 16 I + 4 r + lk, column
+  // 16 J + lr) adds the diagonal terms and the patch entry of its (unordered) index pair and stores it: for a fixed
+  // register the wave writes four rows x 16 consecutive columns
 #pragma unroll
-    for (int c = 0; c < QMAXC; ++c) {
-      if (c >= nctx) break;
-      const QuadCtx& C = L.ctx[c];
-      if (!L.on[C.set][j]) continue;
-      if (!isd) h += C.scale * dot3(C.Dv[k], C.is_vel ? L.dgam[C.set][j] : L.w[C.set][j]);
-      else if (C.is_vel) h += C.scale * dot3(C.Dv[k], L.w[C.set][j]);
-    }
-    if (has_bal) h += balance(a, bb);
-    store(a, bb, h);
-  }
-  // (quat, v_b) and (quat, omega_b)
-  if (lane < 24) {
-    const bool isw = lane >= 12;
-    const int e = isw ? lane - 12 : lane;
-    const int k = e / 3, cc = e % 3;
-    const int a = Q0 + k, bb = (isw ? W0 : V0) + cc;
-    double h = dense(a, bb);
+  for (int I = 0; I < 4; ++I) {
+    v4d_q acc[4];
 #pragma unroll
-    for (int c = 0; c < QMAXC; ++c) {
-      if (c >= nctx) break;
-      const QuadCtx& C = L.ctx[c];
-      if (!C.is_vel) continue;
-      if (!isw) h += C.scale * C.Dv[k][cc] * L.mfrac[C.set];
-      else { double tv[3]; cross(L.beta[C.set], C.Dv[k], tv); h += C.scale * sel3(tv, cc); }   // Dv . (-[beta]x e_c) = (beta x Dv)_c
-    }
-    if (has_bal) h += balance(a, bb);
-    store(a, bb, h);
-  }
-  // (theta, theta) upper triangle and (theta, thetadot) full block: related joints only
-  for (int idx = lane; idx < 190 + NJ * NJ; idx += 64) {
-    const bool isd = idx >= 190;
-    int ja, jb;
-    if (!isd) { int r, c; tri(idx, NJ, r, c); ja = 1 + r; jb = 1 + c; }
-    else { const int e = idx - 190; ja = 1 + e / NJ; jb = 1 + e % NJ; }
-    const int a = T0 + ja - 1, bb = (isd ? D0 : T0) + jb - 1;
-    double h = (a == bb) ? Qd[a] : 0.0;
-    h += dense(a, bb);
-    int lo, hi;
-    if (related_mask(L.anc, ja, jb, lo, hi)) {
+    for (int J = 0; J < 4; ++J) acc[J] = (v4d_q){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-      for (int c = 0; c < QMAXC; ++c) {
-        if (c >= nctx) break;
-        const QuadCtx& C = L.ctx[c];
-        if (!L.on[C.set][ja] || !L.on[C.set][jb]) continue;
-        if (isd && !C.is_vel) continue;
-        double v = dot3(L.u.j.tz[c][lo - 1], L.w[C.set][hi]);
-        if (!isd && C.is_vel) v = dot3(L.u.j.Pp[c][lo - 1], L.w[C.set][hi]) + dot3(L.u.j.tz[c][lo - 1], L.dgam[C.set][hi]);
-        h += C.scale * v;
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int J = 0; J < 4; ++J) acc[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ks][I], bv[ks][J], acc[J], 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int a = 16 * I + 4 * r + lk;
+      if (16 * I + 4 * r >= H1_NX) continue;           // compile-time: rows beyond 50 do not exist
+#pragma unroll
+      for (int J = 0; J < 4; ++J) {
+        const int bb = 16 * J + lr;
+        double h = acc[J][r];
+        if (a == bb) h += L.dg[a < H1_NX ? a : 0];
+        const int lo2 = a < bb ? a : bb, hi2 = a < bb ? bb : a;
+        if (lo2 >= QS2_R0 && lo2 < QS2_R0 + QS2_NR && hi2 < H1_NX) h += L.S2[lo2 - QS2_R0][hi2 - QS2_R0];
+        if (a < H1_NX && bb < H1_NX) Hg[a * H1_NX + bb] = h;
       }
     }
-    if (has_bal) h += balance(a, bb);
-    if (a == bb) {
-      double lo_, hi_; limit_bounds(H1_JRANGE[a - 7], lo_, hi_);
-      const double q = L.xp[a];
-      if (q > hi_ || q < lo_) h += 2.0 * P.w_joint;
-    }
-    store(a, bb, h);
   }
-  // (theta, omega_b): (w_j x til)_c
-  if (lane < 3 * NJ) {
-    const int ja = 1 + lane / 3, cc = lane % 3;
-    const int a = T0 + ja - 1, bb = W0 + cc;
-    double h = dense(a, bb);
-#pragma unroll
-    for (int c = 0; c < QMAXC; ++c) {
-      if (c >= nctx) break;
-      const QuadCtx& C = L.ctx[c];
-      if (!C.is_vel || !L.on[C.set][ja]) continue;
-      double tv[3]; cross(L.w[C.set][ja], C.til, tv);
-      h += C.scale * sel3(tv, cc);
-    }
-    if (has_bal) h += balance(a, bb);
-    store(a, bb, h);
-  }
-  QSTAMP(6)
+  QSTAMP(8)
 }
 
 void launch_cost_quadratics(const DevState& S, const ProblemDev& P, int mode, hipStream_t st) {

@@ -31,8 +31,8 @@ for _ in range(reps):
 dt = (time.perf_counter() - t0) / reps
 print("%s: %.3f ms per call (host-timed, includes sync)  K checksum %.9e" % (stage, dt * 1e3, float(np.abs(s.gains_K()[::97]).sum())))
 if os.environ.get("ILQR_QSTAMPS"):
-    names = ["load x,u", "base kinematics (lane = body, level-synchronous)", "point sets (lane = set x body)", "jac columns", "contexts (lane = term x joint)", "gradient", "hessian"]
-    st = s.cost()[:7]
+    names = ["load x,u", "base kinematics (lane = body, level-synchronous)", "point sets (lane = set x body)", "jac columns", "contexts (lane = term x joint)", "gradient", "hessian: operand fetch", "hessian: second-order patch", "hessian: MFMA + store"]
+    st = s.cost()[:9]
     for nme, v in zip(names, st):
         print("  %-24s %10.0f cycles  %5.1f %%" % (nme, v, 100 * v / st.sum()))
     print("  total %.0f cycles" % st.sum())
