@@ -276,10 +276,9 @@ DEVFN void lin_tangent_zero(LinShared& L, int lane) {
   for (int e = lane; e < (H1_NV - 6) * LIN_LD; e += 64) (&L.dT[6][0])[e] = 0.0;
 }
 // step 2: 2 x 19 lanes sweep the two legs, then torso + the two arms; shares of the pelvis / torso hinge -> L.u.t
-DEVFN void lin_tangent_chains(LinShared& L, int lane) {
+DEVFN void lin_tangent_legs(LinShared& L, int lane) {
   const int grp = lane / 19, q = lane - 19 * grp;
   const bool side = grp == 1;
-  // ---- pass 1: the two legs
   if (grp < 2) {
     int kind, idx; slot_direction(false, side, q, kind, idx);
     const int col = dir_lane(kind, idx);
@@ -289,7 +288,10 @@ DEVFN void lin_tangent_chains(LinShared& L, int lane) {
 #pragma unroll
     for (int k = 0; k < 6; ++k) L.u.t.part[grp][k][q] = dFj[k];
   }
-  // ---- pass 2: torso + the two arms
+}
+DEVFN void lin_tangent_arms(LinShared& L, int lane) {
+  const int grp = lane / 19, q = lane - 19 * grp;
+  const bool side = grp == 1;
   if (grp < 2) {
     int kind, idx; slot_direction(true, side, q, kind, idx);
     const int col = dir_lane(kind, idx);
@@ -307,6 +309,12 @@ DEVFN void lin_tangent_chains(LinShared& L, int lane) {
 #pragma unroll
     for (int k = 0; k < 6; ++k) L.u.t.part[2 + grp][k][q] = dFj[k];
   }
+}
+// step 2: 2 x 19 lanes sweep the two legs, then torso + the two arms; shares of the pelvis / torso hinge -> L.u.t
+// (k_lin_tangent runs the two passes on its two waves at the same time)
+DEVFN void lin_tangent_chains(LinShared& L, int lane) {
+  lin_tangent_legs(L, lane);
+  lin_tangent_arms(L, lane);
 }
 // step 3: pelvis: own force tangent + the four chain shares, per direction (lane = direction, fixed order)
 DEVFN void lin_tangent_pelvis(LinShared& L, int lane) {
@@ -544,6 +552,100 @@ DEVFN void lin_accumulate_forces(LinShared& L, int lane) {
       for (int k = 0; k < 6; ++k) L.D.F[i][k] = acc[k];
     }
     __syncthreads();
+  }
+}
+
+// ---- two waves per knot (k_lin_tangent): the knot's LDS record is shared, the phases are split between the waves ----------
+// wave-local ordering of LDS accesses (one wave executes its LDS instructions in order; this only stops the compiler)
+DEVFN void wave_sync() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
+// cooperative load by 128 threads; wave 0 rebuilds the joint rotations / parent accelerations, wave 1 the body forces
+DEVFN void lin_load_dump2(LinShared& L, const double* g, int tid) {
+  LinDump& D = L.D;
+  const int wv = tid >> 6, lane = tid & 63;
+  for (int e = tid; e < 9; e += 128) D.R0[e] = g[LinDumpG_R0 + e];
+  for (int e = tid; e < 3; e += 128) D.aL[e] = g[LinDumpG_aL + e];
+  for (int e = tid; e < H1_NV; e += 128) D.qacc[e] = g[LinDumpG_qacc + e];
+  for (int e = tid; e < H1_NB * 6; e += 128) { (&D.v[0][0])[e] = g[LinDumpG_v + e]; (&L.u.m.U[0][0])[e] = g[LinDumpG_U + e]; }
+  for (int e = tid; e < H1_NB; e += 128) L.u.m.Dinv[e] = g[LinDumpG_Dinv + e];
+  for (int e = tid; e < 36; e += 128) L.u.m.IA0inv[e] = g[LinDumpG_IA0inv + e];
+  if (wv == 0 && lane >= 1 && lane < H1_NB) {
+    const int i = lane, a = H1_AXIS[i], b = (a + 1) % 3, d = (a + 2) % 3;
+    const double s = g[LinDumpG_sc + 2 * i], c = g[LinDumpG_sc + 2 * i + 1];
+    for (int r = 0; r < 3; ++r) {
+      const double fa = H1_RFIX[i][r][a], fb = H1_RFIX[i][r][b], fd = H1_RFIX[i][r][d];
+      D.Rj[i][3 * r + a] = fa; D.Rj[i][3 * r + b] = fb * c + fd * s; D.Rj[i][3 * r + d] = fd * c - fb * s;
+    }
+    double ap[6], xa[6];
+    for (int k = 0; k < 6; ++k) ap[k] = g[LinDumpG_a + 6 * H1_PARENT[i] + k];
+    xf_motion(D.Rj[i], H1_POS[i], ap, xa);
+    for (int k = 0; k < 6; ++k) L.xa[i][k] = xa[k];
+  }
+  if (wv == 1 && lane < H1_NB) {
+    const int i = lane;
+    double v[6], a[6], Iv[6], Ia[6], vIv[6];
+    for (int k = 0; k < 6; ++k) { v[k] = g[LinDumpG_v + 6 * i + k]; a[k] = g[LinDumpG_a + 6 * i + k]; }
+    inertia_mul(i, v, Iv); inertia_mul(i, a, Ia); crf(v, Iv, vIv);
+    for (int k = 0; k < 6; ++k) { D.F[i][k] = Ia[k] + vIv[k]; L.Iv[i][k] = Iv[k]; }
+  }
+}
+// lin_accumulate_forces on ONE wave (the other one runs the Minv sweeps meanwhile): wave-local ordering, no workgroup barrier
+DEVFN void lin_accumulate_forces_w(LinShared& L, int lane) {
+  const int i = lane;
+  int dep = -1, c0 = 0, c1 = 0, c2 = 0;
+  if (i < H1_NB) {
+    dep = H1_DEPTH[i];
+    if (i == 0) { c0 = 1; c1 = 6; c2 = 11; }
+    else if (i == 11) { c0 = 12; c1 = 16; }
+    else if (i != 5 && i != 10 && i != 15 && i != 19) c0 = i + 1;
+  }
+  for (int d = 4; d >= 0; --d) {
+    if (dep == d && c0) {
+      double acc[6];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) acc[k] = L.D.F[i][k];
+      xf_force_acc(L.D.Rj[c0], H1_POS[c0], L.D.F[c0], acc);
+      if (c1) xf_force_acc(L.D.Rj[c1], H1_POS[c1], L.D.F[c1], acc);
+      if (c2) xf_force_acc(L.D.Rj[c2], H1_POS[c2], L.D.F[c2], acc);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) L.D.F[i][k] = acc[k];
+    }
+    wave_sync();
+  }
+}
+// dT <- -Minv dT on the MFMA, row tile I = wave index (21 MFMA per wave); contains a workgroup barrier between the operand
+// reads and the write-back (in place)
+DEVFN void lin_apply_minv_2(LinShared& L, int tid) {
+  typedef double v4d_l __attribute__((ext_vector_type(4)));
+  const int I = tid >> 6, lane = tid & 63;
+  const int lr = lane & 15, lk = lane >> 4;
+  double am[7], bd[3][7];
+#pragma unroll
+  for (int s = 0; s < 7; ++s) {
+    const int k = 4 * s + lk, kc = k < H1_NV ? k : H1_NV - 1;
+    const int r = 16 * I + lr, rc = r < H1_NV ? r : H1_NV - 1;
+    const double v = L.Minv[MINV_IDX(rc, kc)];
+    am[s] = (r < H1_NV && k < H1_NV) ? -v : 0.0;
+#pragma unroll
+    for (int J = 0; J < 3; ++J) {
+      const double w = L.dT[kc][16 * J + lr];
+      bd[J][s] = (k < H1_NV) ? w : 0.0;
+    }
+  }
+  __syncthreads();
+  v4d_l acc[3];
+#pragma unroll
+  for (int J = 0; J < 3; ++J) acc[J] = (v4d_l){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int s = 0; s < 7; ++s)
+#pragma unroll
+    for (int J = 0; J < 3; ++J) acc[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(am[s], bd[J][s], acc[J], 0, 0, 0);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = 16 * I + 4 * r + lk;
+    if (row < H1_NV) {
+#pragma unroll
+      for (int J = 0; J < 3; ++J) L.dT[row][16 * J + lr] = acc[J][r];
+    }
   }
 }
 

@@ -79,42 +79,52 @@ __global__ void __launch_bounds__(64) k_step(int count, const double* x, const d
 //                  (tangent RNEA sweeps), then lanes = Jacobian columns.
 // -DLIN_STAMP: diagnostic build only -- per-phase cycle counts of workgroup (0, 0) land in S.J[0..7]
 #ifdef LIN_STAMP
-#define LSTAMP(k) { const long long tn_ = clock64(); if (t == 0 && b == 0 && lane == 0) S.J[k] = (double)(tn_ - qlast); qlast = tn_; }
+#define LSTAMP(k) { const long long tn_ = clock64(); if (t == 0 && b == 0 && tid == 0) S.J[k] = (double)(tn_ - qlast); qlast = tn_; }
 #else
 #define LSTAMP(k)
 #endif
-__global__ void __launch_bounds__(64, LINT_WAVES) k_lin_tangent(DevState S, ProblemDev P, int mode) {
-  const int t = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+// Two waves per knot share the knot's LDS record (22.7 KB: the LDS, not the registers, bounds the occupancy -- 7 one-wave
+// workgroups per CU before, now 6 x 2 waves): wave 0 accumulates the inverse-dynamics forces and sweeps the legs, wave 1 runs
+// the Minv sweeps and sweeps torso + arms; the Minv product is split by row tile, the 51 columns of A go to wave 0 and the 19
+// of B to wave 1.  A knot's critical path drops from ~107 k to ~65 k cycles and twice as many waves hide each other's latencies.
+__global__ void __launch_bounds__(128, 3) k_lin_tangent(DevState S, ProblemDev P, int mode) {
+  const int t = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
   if (!selected(S, b, mode)) return;
   __shared__ LinShared L;
 #ifdef LIN_STAMP
   long long qlast = clock64();
 #endif
   const size_t knot = (size_t)b * S.N + t;
-  lin_load_dump(L, S.lin_dump + knot * LinDumpG_SIZE, lane);
-  if (lane < H1_NX) L.x[lane] = S.xbar[((size_t)b * (S.N + 1) + t) * H1_NX + lane];
-  if (lane < H1_NU) L.u_[lane] = S.ubar[((size_t)b * S.N + t) * H1_NU + lane];
-  if (lane == 0) L.h = P.dyn.h;
+  lin_load_dump2(L, S.lin_dump + knot * LinDumpG_SIZE, tid);
+  if (tid < H1_NX) L.x[tid] = S.xbar[((size_t)b * (S.N + 1) + t) * H1_NX + tid];
+  if (tid >= 64 && tid < 64 + H1_NU) L.u_[tid - 64] = S.ubar[((size_t)b * S.N + t) * H1_NU + tid - 64];
+  if (tid == 127) L.h = P.dyn.h;
+  for (int e = tid; e < (H1_NV - 6) * LIN_LD; e += 128) (&L.dT[6][0])[e] = 0.0;     // lin_tangent_zero
   __syncthreads();
   LSTAMP(0)
-  lin_accumulate_forces(L, lane);
-  LSTAMP(1)
-  if (lane == 0) lin_prologue(L);
-  LSTAMP(2)
-  lin_minv_lane(L, lane);       // lanes 0..24: columns of Minv
-  LSTAMP(3)
+  if (wv == 0) {
+    lin_accumulate_forces_w(L, lane);
+    LSTAMP(1)
+    if (lane == 32) lin_prologue(L);
+    LSTAMP(2)
+  } else {
+    lin_minv_lane(L, lane);       // lanes 0..24: columns of Minv
+  }
   __syncthreads();
-  lin_tangent_all(L, lane);     // chain-grouped tangent sweeps -> tangent generalized forces of the 47 directions
+  LSTAMP(3)
+  if (wv == 0) lin_tangent_legs(L, lane); else lin_tangent_arms(L, lane);
+  __syncthreads();
+  if (wv == 0) lin_tangent_pelvis(L, lane);
   __syncthreads();
   LSTAMP(4)
-  lin_apply_minv_lane(L, lane);
+  lin_apply_minv_2(L, tid);
   __syncthreads();
   LSTAMP(5)
   double* Ag = S.A + knot * H1_NX * H1_NX;
   double* Bg = S.Bm + knot * H1_NX * H1_NU;
   // each lane streams one column; for a fixed row the lanes write consecutive addresses
-  if (lane < H1_NX) lin_column(L, 0, lane, [&](int r, double v) { Ag[r * H1_NX + lane] = v; });
-  if (lane < H1_NU) lin_column(L, 1, lane, [&](int r, double v) { Bg[r * H1_NU + lane] = v; });
+  if (wv == 0 && lane < H1_NX) lin_column(L, 0, lane, [&](int r, double v) { Ag[r * H1_NX + lane] = v; });
+  if (wv == 1 && lane < H1_NU) lin_column(L, 1, lane, [&](int r, double v) { Bg[r * H1_NU + lane] = v; });
   LSTAMP(6)
 }
 
@@ -538,7 +548,7 @@ void launch_step(int count, const double* x, const double* u, const DynParams& d
 void launch_linearize(const DevState& S, const ProblemDev& P, int mode, int jac_mode, double eps, hipStream_t st, int phases) {
   if (jac_mode == 0 && !P.dyn.contact) {   // contact mode (f4): the stance-constrained step is differentiated by forward differences
     if (phases & 1) launch_lin_primal_r(S, P, mode, st);
-    if (phases & 2) hipLaunchKernelGGL(k_lin_tangent, dim3(S.N, S.B), dim3(64), 0, st, S, P, mode);
+    if (phases & 2) hipLaunchKernelGGL(k_lin_tangent, dim3(S.N, S.B), dim3(128), 0, st, S, P, mode);
   } else if (phases & 2) {
     const long total = (long)S.B * S.N * (H1_NX + H1_NU);
     hipLaunchKernelGGL(k_fd_base, dim3(cdiv((long)S.B * S.N, 64)), dim3(64), 0, st, S, P, mode);
