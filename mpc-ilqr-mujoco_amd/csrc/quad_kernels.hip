@@ -1,6 +1,6 @@
 // K3: cost quadratics -- iLQR::computeCostQuadratics (reference src/ilqr/ilqr.cpp:133-244) with the exact task-term
 // Hessians of add{CoM,CoMVel,EEPos,EEVel,Upright,Balance}CostDerivatives (ilqr.cpp:662-800; closed forms of
-// derivatives.cpp:525-707, see h1_cost_dev.h).  One wave per (knot, rollout); every phase is lane-parallel:
+// derivatives.cpp:525-707, see h1_cost_dev.h).  One two-wave workgroup per (knot, rollout); every phase is lane-parallel:
 //   1  pelvis-frame kinematics of the URDF tree, lane = body, one barrier per tree level (5 levels)
 //   2  point sets (whole-body CoM, left / right ankle origin), lane = (set, body): subtree aggregates are direct
 //      sums over the ancestor bitmask instead of an inward sweep, so there is no sequential dependency
@@ -26,7 +26,7 @@ using namespace h1;
 namespace ilqr {
 
 #ifndef QUAD_WAVES
-#define QUAD_WAVES 2   // waves per SIMD requested from the register allocator
+#define QUAD_WAVES 4   // waves per SIMD requested from the register allocator (8 two-wave workgroups per CU)
 #endif
 // -DQUAD_STAMP: diagnostic build only -- per-phase cycle counts of workgroup (0, 0) land in S.J[0..7]
 #ifdef QUAD_STAMP
@@ -118,8 +118,11 @@ DEVFN void d2R_sel(int k, int l, double* D) {
   dR_dquat(k, q, D);
 }
 
-__global__ void __launch_bounds__(64, QUAD_WAVES) k_cost_quadratics(DevState S, ProblemDev P, int mode) {
-  const int t = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+// Two waves per knot share the knot's LDS record (20.4 KB bound the occupancy at 8 one-wave workgroups per CU).  `lane` runs
+// over 0..127: the lane-parallel phases 1-5 have at most 64 work items and stay on wave 0 (wave 1 waits at the barriers),
+// the Hessian -- half of the kernel -- is split: patch entries over 128 lanes, two accumulator row tiles per wave.
+__global__ void __launch_bounds__(128, QUAD_WAVES) k_cost_quadratics(DevState S, ProblemDev P, int mode) {
+  const int t = blockIdx.x, b = blockIdx.y, lane = threadIdx.x, wv = lane >> 6;
   if (!quad_selected(S, b, mode)) return;
   const int N = S.N;
   const bool term = (t == N);
@@ -360,7 +363,7 @@ __global__ void __launch_bounds__(64, QUAD_WAVES) k_cost_quadratics(DevState S, 
     L.jr[1][a] = L.Jc[0][1][a] + om * L.Jv[0][1][a] + L.bal[6] * om1 * jz;
   }
   __syncthreads();   // (also: the phase-1/2 temporaries are dead, their storage becomes tz / Pp)
-  for (int e = lane; e < nctx * H1_NJ; e += 64) {
+  for (int e = lane; e < nctx * H1_NJ; e += 128) {
     const int c = e / H1_NJ, j = 1 + e - c * H1_NJ;
     const QuadCtx& C = L.ctx[c];
     double tz[3]; cross(C.til, L.zh[j], tz);
@@ -422,13 +425,13 @@ __global__ void __launch_bounds__(64, QUAD_WAVES) k_cost_quadratics(DevState S, 
   // ---- phase 6: Hessian lxx
   double* Hg = S.lxx + ((size_t)b * (N + 1) + t) * H1_NX * H1_NX;
   typedef double v4d_q __attribute__((ext_vector_type(4)));
-  const int lr = lane & 15, lk = lane >> 4;
+  const int lr = lane & 15, lk = (lane >> 4) & 3;
   // 6a: operands of the first-order product H1[a][b] = sum_k sA_k RA_k[a] RB_k[b], k = 4 ks + lk:
   //   lk < 3 : row lk of the Jacobian of gradient-carrying functional ks (RA = RB, sA = its scale)
   //   lk = 3 : the balance dyads w (jr0 jr0' + jr1 jr1' + jz m' + m jz'): ks = 0 jr0, 1 jr1, 2 (jz, m), 3 (m, jz)
   // operand of row tile I / column tile J = entry 16 I + lr of the row; everything beyond column 50 and every unused row is
   // a true zero (junk operands slow the fp64 MFMA down tenfold)
-  double av[4][4], bv[4][4];
+  double av[4][2], bv[4][4];            // this wave's two row tiles 2 wv, 2 wv + 1; all four column tiles
   {
     double* const balm_ = &L.Om[0][0];
 #pragma unroll
@@ -444,14 +447,18 @@ __global__ void __launch_bounds__(64, QUAD_WAVES) k_cost_quadratics(DevState S, 
         const int e = 16 * T + lr, ec = e < H1_NX ? e : H1_NX - 1;
         const double ra = rowA[ec], rb = rowB[ec];
         const bool ok = used && e < H1_NX;
-        av[ks][T] = ok ? sA * ra : 0.0;
         bv[ks][T] = ok ? rb : 0.0;
+        const double avv = ok ? sA * ra : 0.0;
+        if (T == 0) { if (wv == 0) av[ks][0] = avv; }
+        else if (T == 1) { if (wv == 0) av[ks][1] = avv; }
+        else if (T == 2) { if (wv == 1) av[ks][0] = avv; }
+        else { if (wv == 1) av[ks][1] = avv; }
       }
     }
   }
   QSTAMP(6)
   __syncthreads();   // the Jacobian rows are in registers: their storage becomes the second-order patch
-  for (int e = lane; e < QS2_NR * QS2_NC; e += 64) (&L.S2[0][0])[e] = 0.0;
+  for (int e = lane; e < QS2_NR * QS2_NC; e += 128) (&L.S2[0][0])[e] = 0.0;
   __syncthreads();
   // 6b: second-order part, block by block of the coordinate classes (a <= bb in every block).  The (merged) contexts'
   // set / type are wave-uniform: held in scalar registers, so the loops over them branch uniformly.
@@ -471,7 +478,7 @@ __global__ void __launch_bounds__(64, QUAD_WAVES) k_cost_quadratics(DevState S, 
     cset[c] = __builtin_amdgcn_readfirstlane(L.ctx[cc].set); cvel[c] = __builtin_amdgcn_readfirstlane(L.ctx[cc].is_vel);
   }
   // (theta, theta) and (theta, thetadot), related joints only (compile-time list): three passes of 64 entries
-  for (int e = lane; e < 158; e += 64) {
+  for (int e = lane; e < 158; e += 128) {
     const unsigned pk = QREL.e[e];
     const int ja = pk & 31, jb = (pk >> 5) & 31;
     const bool isd = (pk >> 10) != 0;
@@ -493,7 +500,7 @@ __global__ void __launch_bounds__(64, QUAD_WAVES) k_cost_quadratics(DevState S, 
     patch(T0 + ja - 1, (isd ? D0 : T0) + jb - 1, h);
   }
   // (quat, theta) and (quat, thetadot): Dv . w / Dv . dgam
-  for (int idx = lane; idx < 2 * 4 * NJ; idx += 64) {
+  for (int idx = lane; idx < 2 * 4 * NJ; idx += 128) {
     const bool isd = idx >= 4 * NJ;
     const int e = isd ? idx - 4 * NJ : idx;
     const int k = e / NJ, j = 1 + e % NJ;
@@ -511,7 +518,7 @@ __global__ void __launch_bounds__(64, QUAD_WAVES) k_cost_quadratics(DevState S, 
     }
     patch(Q0 + k, (isd ? D0 : T0) + j - 1, h);
   }
-  // (theta, omega_b): (w_j x til)_c on lanes 0..56; (quat, v_b), (quat, omega_b) and (quat, quat) on lanes 0..33 of a second pass
+  // (theta, omega_b): (w_j x til)_c on wave 0; (quat, v_b), (quat, omega_b) and (quat, quat) on wave 1
   if (lane < 3 * NJ) {
     const int ja = 1 + lane / 3, cc = lane % 3;
     double h = 0.0;
@@ -526,9 +533,9 @@ __global__ void __launch_bounds__(64, QUAD_WAVES) k_cost_quadratics(DevState S, 
     }
     patch(T0 + ja - 1, W0 + cc, h);
   }
-  if (lane < 24) {
-    const bool isw = lane >= 12;
-    const int e = isw ? lane - 12 : lane;
+  if (lane >= 64 && lane < 64 + 24) {
+    const bool isw = lane >= 64 + 12;
+    const int e = isw ? lane - 64 - 12 : lane - 64;
     const int k = e / 3, cc = e % 3;
     double h = 0.0;
 #pragma unroll
@@ -541,9 +548,9 @@ __global__ void __launch_bounds__(64, QUAD_WAVES) k_cost_quadratics(DevState S, 
       else { double tv[3]; cross(L.beta[st_], C.Dv[k], tv); h += sel3(tv, cc); }   // Dv . (-[beta]x e_c) = (beta x Dv)_c
     }
     patch(Q0 + k, (isw ? W0 : V0) + cc, h);
-  } else if (lane >= 32 && lane < 42) {
+  } else if (lane >= 96 && lane < 106) {
     // (quat, quat): d2R/dq2 terms + upright
-    int ka, kb; tri(lane - 32, 4, ka, kb);
+    int ka, kb; tri(lane - 96, 4, ka, kb);
     double h = 0.0;
     double D2[9]; d2R_sel(ka, kb, D2);
 #pragma unroll
@@ -571,26 +578,27 @@ __global__ void __launch_bounds__(64, QUAD_WAVES) k_cost_quadratics(DevState S, 
   // 16 J + lr) adds the diagonal terms and the patch entry of its (unordered) index pair and stores it: for a fixed
   // register the wave writes four rows x 16 consecutive columns
 #pragma unroll
-  for (int I = 0; I < 4; ++I) {
+  for (int Ii = 0; Ii < 2; ++Ii) {
+    const int I = 2 * wv + Ii;
     v4d_q acc[4];
 #pragma unroll
     for (int J = 0; J < 4; ++J) acc[J] = (v4d_q){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-      for (int J = 0; J < 4; ++J) acc[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ks][I], bv[ks][J], acc[J], 0, 0, 0);
+      for (int J = 0; J < 4; ++J) acc[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ks][Ii], bv[ks][J], acc[J], 0, 0, 0);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int a = 16 * I + 4 * r + lk;
-      if (16 * I + 4 * r >= H1_NX) continue;           // compile-time: rows beyond 50 do not exist
+      if (a >= H1_NX) continue;                        // rows beyond 50 do not exist (last row tile)
 #pragma unroll
       for (int J = 0; J < 4; ++J) {
         const int bb = 16 * J + lr;
         double h = acc[J][r];
-        if (a == bb) h += L.dg[a < H1_NX ? a : 0];
+        if (a == bb) h += L.dg[a];
         const int lo2 = a < bb ? a : bb, hi2 = a < bb ? bb : a;
         if (lo2 >= QS2_R0 && lo2 < QS2_R0 + QS2_NR && hi2 < H1_NX) h += L.S2[lo2 - QS2_R0][hi2 - QS2_R0];
-        if (a < H1_NX && bb < H1_NX) Hg[a * H1_NX + bb] = h;
+        if (bb < H1_NX) Hg[a * H1_NX + bb] = h;
       }
     }
   }
@@ -598,7 +606,7 @@ __global__ void __launch_bounds__(64, QUAD_WAVES) k_cost_quadratics(DevState S, 
 }
 
 void launch_cost_quadratics(const DevState& S, const ProblemDev& P, int mode, hipStream_t st) {
-  hipLaunchKernelGGL(k_cost_quadratics, dim3(S.N + 1, S.B), dim3(64), 0, st, S, P, mode);
+  hipLaunchKernelGGL(k_cost_quadratics, dim3(S.N + 1, S.B), dim3(128), 0, st, S, P, mode);
 }
 
 }  // namespace ilqr
