@@ -161,8 +161,10 @@ int ilqr_hip_step(ilqr_hip_ctx* ctx, int count, const double* x /*[count][51]*/,
    quantities; `softness` (> 0: set, <= 0: keep, default 1e-5 / kg) regularises the constraint-space inertia.  In this
    mode the rollout, line search and warm-start step run on the scalar kernels and the Jacobians are the reference's
    forward differences (robot_utils.cpp:120-160), whatever ilqr_hip_set_options selected.
-   ilqr_hip_step_stance: one step with explicit stance flags (the flags only matter in contact mode). */
-enum ilqr_contact_mode { ILQR_CONTACT_NONE = 0, ILQR_CONTACT_RIGID_STANCE = 1 };
+   ilqr_hip_step_stance: one step with explicit stance flags (the flags only matter in contact mode).
+   ILQR_CONTACT_UNILATERAL_STANCE: the same constraint, but the floor only pushes: a scheduled stance foot whose constraint
+   force has a negative component along the world up axis is released for that step and the remaining set solved again. */
+enum ilqr_contact_mode { ILQR_CONTACT_NONE = 0, ILQR_CONTACT_RIGID_STANCE = 1, ILQR_CONTACT_UNILATERAL_STANCE = 2 };
 int ilqr_hip_set_contact_mode(ilqr_hip_ctx* ctx, int mode, double softness);
 int ilqr_hip_step_stance(ilqr_hip_ctx* ctx, int count, const double* x, const double* u, int stance_left, int stance_right, double* x_next);
 

@@ -34,6 +34,29 @@ __device__ __forceinline__ double shfl_xor_f64(double v, int mask) {
   return __hiloint2double(hi, lo);
 }
 
+// ---- contact row f4 on the two-lane kernels -------------------------------------------------------------------------
+// One compiled copy of the stance-constrained step (h1s::step_stance) shared by every kernel of this file: the constraint
+// solve (twelve unit-wrench propagations, a 12 x 12 Cholesky) wants the register file to itself, and one machine code for
+// the rollout and the line search makes the nominal re-rollout reproduce the accepted candidate bit for bit.
+// The constraint-free path (contact mode 0, the headline) keeps its inlined step and is not touched by this.
+extern __shared__ double dyn_lds_c[];
+__device__ __attribute__((noinline)) void step_stance_shared(h1s::HalfX* hp, const h1s::HalfU* up, double dt, double gx, double gy, double gz,
+                                                             double soft, int mode, int st_left, int st_right) {
+  const int lane = threadIdx.x;
+  const bool side = (lane & 1) != 0;
+  const h1s::LaneLds L{dyn_lds_c, 64, lane};
+  const double grav[3] = {gx, gy, gz};
+  h1s::HalfX h = *hp;
+  const h1s::HalfU u = *up;
+  h1s::step_stance(side, h, u, dt, grav, L, soft, mode, (side ? st_right : st_left) == 1, (side ? st_left : st_right) == 1);
+  *hp = h;
+}
+// one step of either kind; `st` = stance flags (left, right) of the knot being stepped
+DEVFN void step_any(bool side, h1s::HalfX& h, const h1s::HalfU& u, const DynParams& dyn, const int* st, const h1s::LaneLds& L) {
+  if (dyn.contact) step_stance_shared(&h, &u, dyn.h, dyn.g[0], dyn.g[1], dyn.g[2], dyn.soft, dyn.contact, st[0], st[1]);
+  else h1s::step(side, h, u, dyn.h, dyn.g, L);
+}
+
 // ---- line search on two lanes per candidate (h1_aba_split.h): thread per (rollout, alpha, side), the 16 lanes of
 // a rollout adjacent (lane = 16 r + 2 alpha + side).  With one lane per candidate the 8 x B candidates fill only 2
 // waves per CU; two lanes each give every SIMD a wave.  Same cooperative feedback as k_line_search_r, over 16 lanes.
@@ -147,7 +170,7 @@ __global__ void __launch_bounds__(64) k_line_search_s(DevState S, ProblemDev P, 
     u.u11 = h1s::pair_sum(u.u11);     // torso control: from the left lane to both
     LSS(1)
     LSS(2)
-    h1s::step(side, h, u, P.dyn.h, P.dyn.g, L);
+    step_any(side, h, u, P.dyn, P.stance + b * P.stance_stride + 2 * t, L);
     LSS(3)
     h1s::store_half(side, h, xc + (t + 1) * n);
     LSS(4)
@@ -180,7 +203,7 @@ __global__ void __launch_bounds__(64) k_rollout_s(DevState S, ProblemDev P, int 
     for (int k = 0; k < 5; ++k) u.uL[k] = ub[t * H1_NU + h1s::jleg(side, k)];
 #pragma unroll
     for (int k = 0; k < 4; ++k) u.uA[k] = ub[t * H1_NU + h1s::jarm(side, k)];
-    h1s::step(side, h, u, P.dyn.h, P.dyn.g, L);
+    step_any(side, h, u, P.dyn, P.stance + b * P.stance_stride + 2 * t, L);
     h1s::store_half(side, h, xb + (t + 1) * H1_NX);
   }
 }
@@ -189,15 +212,129 @@ __global__ void __launch_bounds__(64) k_count_iter(DevState S, int mode) {
   if (b < S.B && sel_s(S, b, mode)) S.iters[b] += 1;
 }
 
+// two lanes per item: plain batched step with explicit stance flags (stage API / plant of the closed loop)
+__global__ void __launch_bounds__(64) k_step_s(int count, const double* x, const double* u, DynParams dyn, double* xn, int st_l, int st_r) {
+  extern __shared__ double lds[];
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = gid >> 1;
+  const bool side = (gid & 1) != 0;
+  if (i >= count) return;
+  const h1s::LaneLds L{lds, 64, (int)threadIdx.x};
+  h1s::HalfX h; h1s::load_half(side, x + (size_t)i * H1_NX, h);
+  h1s::HalfU uu; load_half_u(side, u + (size_t)i * H1_NU, uu);
+  const int st[2] = {st_l, st_r};
+  step_any(side, h, uu, dyn, st, L);
+  h1s::store_half(side, h, xn + (size_t)i * H1_NX);
+}
+// last knot of the warm start: xbar[N] = f(xbar[N-1], ubar[N-1])  (ilqr.cpp:72-80)
+__global__ void __launch_bounds__(64) k_last_step_s(DevState S, ProblemDev P) {
+  extern __shared__ double lds[];
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  const int b = gid >> 1;
+  const bool side = (gid & 1) != 0;
+  if (b >= S.B) return;
+  const h1s::LaneLds L{lds, 64, (int)threadIdx.x};
+  const int N = S.N;
+  h1s::HalfX h; h1s::load_half(side, S.xbar + ((size_t)b * (N + 1) + N - 1) * H1_NX, h);
+  h1s::HalfU uu; load_half_u(side, S.ubar + ((size_t)b * N + N - 1) * H1_NU, uu);
+  step_any(side, h, uu, P.dyn, P.stance + b * P.stance_stride + 2 * (N - 1), L);
+  h1s::store_half(side, h, S.xbar + ((size_t)b * (N + 1) + N) * H1_NX);
+}
+// Reference-style forward differences (RobotUtils::linearizeDynamicsFD, robot_utils.cpp:120-160) on the two-lane step:
+// a lane pair per (knot, column); columns 0..50 perturb x, 51..69 perturb u, column 70 is the unperturbed step (evaluated
+// once per knot, as the reference does).  The stepped states land in A / B / the knot's lin_dump record; k_fd_finish turns
+// them into difference quotients.
+DEVFN void perturb_half(bool side, h1s::HalfX& h, h1s::HalfU& u, int col, double eps) {
+#pragma unroll
+  for (int k = 0; k < 3; ++k) h.p[k] += (col == k) ? eps : 0.0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) h.quat[k] += (col == 3 + k) ? eps : 0.0;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) h.vb[k] += (col == H1_NQ + k) ? eps : 0.0;
+  h.q.th11 += (col == 7 + 10) ? eps : 0.0; h.q.qd11 += (col == H1_NQ + 6 + 10) ? eps : 0.0;
+#pragma unroll
+  for (int k = 0; k < 5; ++k) { const int j = h1s::jleg(side, k); h.q.thL[k] += (col == 7 + j) ? eps : 0.0; h.q.qdL[k] += (col == H1_NQ + 6 + j) ? eps : 0.0; u.uL[k] += (col == H1_NX + j) ? eps : 0.0; }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { const int j = h1s::jarm(side, k); h.q.thA[k] += (col == 7 + j) ? eps : 0.0; h.q.qdA[k] += (col == H1_NQ + 6 + j) ? eps : 0.0; u.uA[k] += (col == H1_NX + j) ? eps : 0.0; }
+  u.u11 += (col == H1_NX + 10) ? eps : 0.0;
+}
+// store this lane's half of a state as column `col` (stride ld) of a row-major matrix
+DEVFN void store_half_col(bool side, const h1s::HalfX& h, double* M, int ld, int col) {
+  if (!side) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) M[k * ld + col] = h.p[k];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) M[(3 + k) * ld + col] = h.quat[k];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) M[(H1_NQ + k) * ld + col] = h.vb[k];
+    M[(7 + 10) * ld + col] = h.q.th11; M[(H1_NQ + 6 + 10) * ld + col] = h.q.qd11;
+  }
+#pragma unroll
+  for (int k = 0; k < 5; ++k) { M[(7 + h1s::jleg(side, k)) * ld + col] = h.q.thL[k]; M[(H1_NQ + 6 + h1s::jleg(side, k)) * ld + col] = h.q.qdL[k]; }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { M[(7 + h1s::jarm(side, k)) * ld + col] = h.q.thA[k]; M[(H1_NQ + 6 + h1s::jarm(side, k)) * ld + col] = h.q.qdA[k]; }
+}
+#define FD_NCOL (H1_NX + H1_NU + 1)
+__global__ void __launch_bounds__(64) k_fd_steps_s(DevState S, ProblemDev P, int mode, double eps, int dump_doubles) {
+  extern __shared__ double lds[];
+  const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long pr = gid >> 1;
+  const bool side = (gid & 1) != 0;
+  const long total = (long)S.B * S.N * FD_NCOL;
+  const long prc = pr < total ? pr : total - 1;
+  const int col = (int)(prc % FD_NCOL);
+  const long item = prc / FD_NCOL;
+  const int t = (int)(item % S.N), b = (int)(item / S.N);
+  const bool act = pr < total && sel_s(S, b, mode);
+  if (!__any(act)) return;
+  const h1s::LaneLds L{lds, 64, (int)threadIdx.x};
+  h1s::HalfX h; h1s::load_half(side, S.xbar + ((size_t)b * (S.N + 1) + t) * H1_NX, h);
+  h1s::HalfU uu; load_half_u(side, S.ubar + ((size_t)b * S.N + t) * H1_NU, uu);
+  perturb_half(side, h, uu, col, eps);
+  step_any(side, h, uu, P.dyn, P.stance + b * P.stance_stride + 2 * t, L);
+  if (!act) return;
+  if (col < H1_NX) store_half_col(side, h, S.A + (size_t)item * H1_NX * H1_NX, H1_NX, col);
+  else if (col < H1_NX + H1_NU) store_half_col(side, h, S.Bm + (size_t)item * H1_NX * H1_NU, H1_NU, col - H1_NX);
+  else h1s::store_half(side, h, S.lin_dump + (size_t)item * dump_doubles);
+}
+__global__ void __launch_bounds__(256) k_fd_finish(DevState S, int mode, double eps, int dump_doubles) {
+  const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int NC = H1_NX + H1_NU;
+  const long total = (long)S.B * S.N * H1_NX * NC;
+  if (gid >= total) return;
+  const int c = (int)(gid % NC);
+  const int i = (int)((gid / NC) % H1_NX);
+  const long item = gid / ((long)NC * H1_NX);
+  const int b = (int)(item / S.N);
+  if (!sel_s(S, b, mode)) return;
+  const double base = S.lin_dump[(size_t)item * dump_doubles + i];
+  double* e = c < H1_NX ? S.A + ((size_t)item * H1_NX + i) * H1_NX + c : S.Bm + ((size_t)item * H1_NX + i) * H1_NU + (c - H1_NX);
+  *e = (*e - base) / eps;
+}
+
 static inline int cdiv_s(long a, long b) { return (int)((a + b - 1) / b); }
 int dyn_split_kernels_set_attr() {
   int rc = 0;
   rc |= hipFuncSetAttribute((const void*)k_line_search_s, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DYN_LDS_BYTES_S) != hipSuccess;
   rc |= hipFuncSetAttribute((const void*)k_rollout_s, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DYN_LDS_BYTES_S) != hipSuccess;
+  rc |= hipFuncSetAttribute((const void*)k_step_s, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DYN_LDS_BYTES_S) != hipSuccess;
+  rc |= hipFuncSetAttribute((const void*)k_last_step_s, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DYN_LDS_BYTES_S) != hipSuccess;
+  rc |= hipFuncSetAttribute((const void*)k_fd_steps_s, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DYN_LDS_BYTES_S) != hipSuccess;
   return rc;
 }
 void launch_line_search_s(const DevState& S, const ProblemDev& P, int mode, hipStream_t st) {
   hipLaunchKernelGGL(k_line_search_s, dim3(cdiv_s((long)S.B * 16, 64)), dim3(64), DYN_LDS_BYTES_S, st, S, P, mode);
+}
+void launch_step_s(int count, const double* x, const double* u, const DynParams& dyn, double* xn, hipStream_t st, int stance_l, int stance_r) {
+  hipLaunchKernelGGL(k_step_s, dim3(cdiv_s((long)count * 2, 64)), dim3(64), DYN_LDS_BYTES_S, st, count, x, u, dyn, xn, stance_l, stance_r);
+}
+void launch_last_step_s(const DevState& S, const ProblemDev& P, hipStream_t st) {
+  hipLaunchKernelGGL(k_last_step_s, dim3(cdiv_s((long)S.B * 2, 64)), dim3(64), DYN_LDS_BYTES_S, st, S, P);
+}
+void launch_linearize_fd_s(const DevState& S, const ProblemDev& P, int mode, double eps, hipStream_t st) {
+  const int dd = (int)lin_dump_doubles();
+  hipLaunchKernelGGL(k_fd_steps_s, dim3(cdiv_s((long)S.B * S.N * FD_NCOL * 2, 64)), dim3(64), DYN_LDS_BYTES_S, st, S, P, mode, eps, dd);
+  hipLaunchKernelGGL(k_fd_finish, dim3(cdiv_s((long)S.B * S.N * H1_NX * (H1_NX + H1_NU), 256)), dim3(256), 0, st, S, mode, eps, dd);
 }
 void launch_rollout_s(const DevState& S, const ProblemDev& P, int mode, int do_roll, int count_iter, double* cost_out, hipStream_t st) {
   if (do_roll) hipLaunchKernelGGL(k_rollout_s, dim3(cdiv_s((long)S.B * 2, 64)), dim3(64), DYN_LDS_BYTES_S, st, S, P, mode, count_iter);

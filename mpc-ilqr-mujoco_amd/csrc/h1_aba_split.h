@@ -365,7 +365,7 @@ typedef Chain<12, 16, 4, 48> ArmChain;   // bodies 12..15 / 16..19, LDS slots 48
 // Forward dynamics in MuJoCo coordinates.  R0: base rotation from the unit quaternion; vb = qvel[0..5];
 // qbase[6] (identical on both lanes) and this lane's hinge accelerations out.
 DEVFN void forward_dynamics(bool side, const double* R0, const double* vb, const HalfState& q, const HalfTau& tau, double arm_eff,
-                            const double* grav, const LaneLds& L, double* qbase, HalfAcc& qacc) {
+                            const double* grav, const LaneLds& L, double* qbase, HalfAcc& qacc, Art* Y0_out = nullptr, double* a0_out = nullptr) {
   double v0[6] = {vb[3], vb[4], vb[5], 0, 0, 0};
   v0[3] = R0[0] * vb[0] + R0[3] * vb[1] + R0[6] * vb[2];
   v0[4] = R0[1] * vb[0] + R0[4] * vb[1] + R0[7] * vb[2];
@@ -404,6 +404,11 @@ DEVFN void forward_dynamics(bool side, const double* R0, const double* vb, const
   // pelvis
   double rhs[6] = {-p0[0], -p0[1], -p0[2], -p0[3], -p0[4], -p0[5]}, a0[6];
   solve6(Y0, rhs, a0);
+  if (Y0_out) *Y0_out = Y0;
+  if (a0_out) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) a0_out[k] = a0[k];
+  }
   const double mg[3] = {-grav[0], -grav[1], -grav[2]};
   const double a0p[3] = {R0[0] * mg[0] + R0[3] * mg[1] + R0[6] * mg[2], R0[1] * mg[0] + R0[4] * mg[1] + R0[7] * mg[2], R0[2] * mg[0] + R0[5] * mg[1] + R0[8] * mg[2]};
   double wxv[3]; cross(v0, v0 + 3, wxv);
@@ -423,6 +428,271 @@ DEVFN void quat_R(double w, double x, double y, double z, double* R) {
   R[0] = 1.0 - 2.0 * (y * y + z * z); R[1] = 2.0 * (x * y - w * z); R[2] = 2.0 * (x * z + w * y);
   R[3] = 2.0 * (x * y + w * z); R[4] = 1.0 - 2.0 * (x * x + z * z); R[5] = 2.0 * (y * z - w * x);
   R[6] = 2.0 * (x * z - w * y); R[7] = 2.0 * (y * z + w * x); R[8] = 1.0 - 2.0 * (x * x + y * y);
+}
+
+// ---- schedule-driven rigid stance constraints on two lanes per rollout -------------------------------
+// Same algorithm as h1_dynamics_dev.h forward_dynamics_stance / oracle forward_dynamics_mj_stance (reference plant:
+// RobotUtils::rolloutOneStep with MuJoCo's floor contacts, robot_utils.cpp:106-117): velocity-level constraint v_f + h a_f = 0
+// on the ankle link of every scheduled stance foot, a_f = a_f,free + C lambda, C = J Mhat^-1 J^T built by propagating unit
+// wrenches through the articulated-body quantities of the free solve (U_i, 1/D_i in LDS, the pelvis inverse).  Each lane
+// owns its side's foot: it propagates the six unit wrenches of its own foot inward, the pelvis shares are exchanged with the
+// partner (DPP), and every lane sweeps its own leg outward for all twelve columns -- i.e. it computes the six rows of C of
+// its own foot; the two 6 x 12 row blocks are exchanged, so both lanes factor the same 12 x 12 matrix and obtain bitwise
+// identical multipliers.  Feet that are not in stance keep their rows / columns as identity (no lane-divergent sizes).
+struct LegTrig { double sn[5], cs[5]; };
+// LDL^T of the (pair-identical) pelvis articulated inertia, kept for the 13 pelvis solves of a constrained step
+struct Ldl6 { double Lm[15], d[6]; };   // strict lower triangle row by row: (1,0) (2,0) (2,1) (3,0) ...
+DEVFN constexpr int lidx(int i, int j) { return i * (i - 1) / 2 + j; }
+DEVFN void ldl6_factor(const Art& Y, Ldl6& F) {
+  double M[36];
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { M[6 * r + c] = Y.A[sidx(r, c)]; M[6 * r + 3 + c] = Y.B[3 * r + c]; M[6 * (3 + r) + c] = Y.B[3 * c + r]; M[6 * (3 + r) + 3 + c] = Y.C[sidx(r, c)]; }
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    double s = M[6 * j + j];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) if (k < j) s -= F.Lm[lidx(j, k)] * F.Lm[lidx(j, k)] * F.d[k];
+    F.d[j] = s;
+    const double inv = 1.0 / s;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) if (i > j) {
+      double t = M[6 * i + j];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) if (k < j) t -= F.Lm[lidx(i, k)] * F.Lm[lidx(j, k)] * F.d[k];
+      F.Lm[lidx(i, j)] = t * inv;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 6; ++j) F.d[j] = 1.0 / F.d[j];
+}
+DEVFN void ldl6_solve(const Ldl6& F, const double* rhs, double* out) {
+  double z[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) { double s = rhs[i];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) if (k < i) s -= F.Lm[lidx(i, k)] * z[k];
+    z[i] = s; }
+#pragma unroll
+  for (int i = 0; i < 6; ++i) z[i] *= F.d[i];
+#pragma unroll
+  for (int i = 5; i >= 0; --i) { double s = z[i];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) if (k > i) s -= F.Lm[lidx(k, i)] * out[k];
+    out[i] = s; }
+}
+// sweeps of a force / acceleration increment along a mirrored chain whose U_i, 1/D_i sit in LDS (slot blocks from SLOT0)
+template <int FL, int FR, int LEN, int SLOT0> struct ChainResp {
+  // inward from the chain's last body: dp = bias-force increment there; du[K] = joint-force increments; returns the root share
+  template <int K> static DEVFN void in(bool side, const double* sn, const double* cs, const LaneLds& L, double* dp, double* du, double* root) {
+    constexpr int AX = C_AXIS[FL + K];
+    du[K] = -dp[AX];
+    const double sc = du[K] * L[SLOT0 + 8 * K + 6];
+    double dpa[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) dpa[k] = dp[k] + L[SLOT0 + 8 * K + k] * sc;
+    double par[6] = {0, 0, 0, 0, 0, 0};
+    xf_force_acc<FL + K, FR + K>(side, dpa, sn[K], cs[K], par);
+    if constexpr (K > 0) in<K - 1>(side, sn, cs, L, par, du, root);
+    else {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) root[k] = par[k];
+    }
+  }
+  // outward from the root acceleration increment ap; du may be nullptr (no joint-force increments on this chain)
+  template <int K> static DEVFN void out(bool side, const double* sn, const double* cs, const LaneLds& L, const double* ap, const double* du, double* dq, double* alast) {
+    constexpr int AX = C_AXIS[FL + K];
+    double a[6]; xf_motion<FL + K, FR + K>(side, ap, sn[K], cs[K], a);
+    double s = du ? du[K] : 0.0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) s -= L[SLOT0 + 8 * K + k] * a[k];
+    const double qdd = s * L[SLOT0 + 8 * K + 6];
+    a[AX] += qdd;
+    if (dq) dq[K] = qdd;
+    if constexpr (K + 1 < LEN) out<K + 1>(side, sn, cs, L, a, du, dq, alast);
+    else if (alast) {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) alast[k] = a[k];
+    }
+  }
+  // velocity, gravity-offset acceleration and two pure-rotation images (linear 3-vectors) at the chain's last body
+  template <int K> static DEVFN void kin(bool side, const double* sn, const double* cs, const double* th_unused, const double* qd, const double* qdd,
+                                         const double* vp, const double* ap, const double* o1p, const double* o2p, double* v, double* a, double* o1, double* o2) {
+    constexpr int AX = C_AXIS[FL + K];
+    double vv[6], aa[6];
+    xf_motion<FL + K, FR + K>(side, vp, sn[K], cs[K], vv); vv[AX] += qd[K];
+    xf_motion<FL + K, FR + K>(side, ap, sn[K], cs[K], aa);
+    double ca[3], cl[3]; cross_axis<AX>(vv, ca); cross_axis<AX>(vv + 3, cl);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { aa[k] += qd[K] * ca[k]; aa[3 + k] += qd[K] * cl[k]; }
+    aa[AX] += qdd[K];
+    double q1[3], q2[3];
+    rotT<FL + K, FR + K>(side, o1p, sn[K], cs[K], q1); rotT<FL + K, FR + K>(side, o2p, sn[K], cs[K], q2);
+    if constexpr (K + 1 < LEN) kin<K + 1>(side, sn, cs, th_unused, qd, qdd, vv, aa, q1, q2, v, a, o1, o2);
+    else {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) { v[k] = vv[k]; a[k] = aa[k]; }
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { o1[k] = q1[k]; o2[k] = q2[k]; }
+    }
+  }
+};
+typedef ChainResp<1, 6, 5, 8> LegResp;
+typedef ChainResp<12, 16, 4, 48> ArmResp;
+
+// symmetric n x n in packed lower storage (row i: i (i + 1) / 2 + j, j <= i)
+DEVFN constexpr int pidx(int i, int j) { return i >= j ? i * (i + 1) / 2 + j : j * (j + 1) / 2 + i; }
+// in-place Cholesky of the packed SPD 12 x 12 and solution of C x = b (b overwritten)
+DEVFN void chol12_solve(double* C, double* b) {
+#pragma unroll
+  for (int j = 0; j < 12; ++j) {
+    double d = C[pidx(j, j)];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) if (k < j) d -= C[pidx(j, k)] * C[pidx(j, k)];
+    const double r = sqrt(d), ri = 1.0 / r;
+    C[pidx(j, j)] = ri;                       // the reciprocal of the pivot is kept
+#pragma unroll
+    for (int i = 0; i < 12; ++i) if (i > j) {
+      double t = C[pidx(i, j)];
+#pragma unroll
+      for (int k = 0; k < 12; ++k) if (k < j) t -= C[pidx(i, k)] * C[pidx(j, k)];
+      C[pidx(i, j)] = t * ri;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 12; ++i) { double t = b[i];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) if (k < i) t -= C[pidx(i, k)] * b[k];
+    b[i] = t * C[pidx(i, i)]; }
+#pragma unroll
+  for (int i = 11; i >= 0; --i) { double t = b[i];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) if (k > i) t -= C[pidx(k, i)] * b[k];
+    b[i] = t * C[pidx(i, i)]; }
+}
+
+// Corrects the accelerations of the free solve (qbase, qacc; U_i, 1/D_i of it still in LDS) for the stance constraints.
+// st_own / st_par: stance flags of this lane's / the partner's foot; mode 2 = unilateral.  Y0, a0: pelvis articulated inertia
+// and raw (gravity-offset, body-frame) pelvis acceleration of the free solve.
+DEVFN void stance_correct(bool side, const double* R0, const double* vb, const HalfState& q, double h, double soft, int mode, bool st_own, bool st_par,
+                          const double* grav, const LaneLds& L, const Art& Y0, const double* a0, double* qbase, HalfAcc& qacc) {
+  LegTrig T;
+#pragma unroll
+  for (int k = 0; k < 5; ++k) h1f::sincos_fast(q.thL[k], &T.sn[k], &T.cs[k]);
+  Ldl6 F; ldl6_factor(Y0, F);
+  // own foot: velocity, acceleration of the free solve, gravity offset and world up axis in link coordinates
+  double v0[6] = {vb[3], vb[4], vb[5], 0, 0, 0};
+  v0[3] = R0[0] * vb[0] + R0[3] * vb[1] + R0[6] * vb[2];
+  v0[4] = R0[1] * vb[0] + R0[4] * vb[1] + R0[7] * vb[2];
+  v0[5] = R0[2] * vb[0] + R0[5] * vb[1] + R0[8] * vb[2];
+  const double mg[3] = {-grav[0], -grav[1], -grav[2]};
+  const double a0p[3] = {R0[0] * mg[0] + R0[3] * mg[1] + R0[6] * mg[2], R0[1] * mg[0] + R0[4] * mg[1] + R0[7] * mg[2], R0[2] * mg[0] + R0[5] * mg[1] + R0[8] * mg[2]};
+  const double zb[3] = {R0[6], R0[7], R0[8]};        // R0^T e_z
+  double vf[6], af[6], off[3], zl[3];
+  LegResp::kin<0>(side, T.sn, T.cs, nullptr, q.qdL, qacc.qL, v0, a0, a0p, zb, vf, af, off, zl);
+  double bown[6];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { bown[k] = -vf[k] / h - af[k]; bown[3 + k] = -vf[3 + k] / h - (af[3 + k] - off[k]); }
+  // unit wrenches on the own foot: inward shares at the pelvis and joint-force increments
+  double p0[6][6], du[6][5];
+#pragma unroll
+  for (int c = 0; c < 6; ++c) {
+    double dp[6] = {0, 0, 0, 0, 0, 0}; dp[c] = -1.0;
+    LegResp::in<4>(side, T.sn, T.cs, L, dp, du[c], p0[c]);
+  }
+  // rows of C that belong to the own foot: columns 0..5 = left foot's wrench components, 6..11 = right foot's
+  double Crow[6][12];
+#pragma unroll
+  for (int j = 0; j < 12; ++j) {
+    const bool own = (j >= 6) == side;              // column j is a wrench on this lane's own foot
+    const int c = j % 6;
+    double pj[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) { const double mine = p0[c][k], theirs = xch(mine); pj[k] = -(own ? mine : theirs); }
+    double a0j[6]; ldl6_solve(F, pj, a0j);
+    double dz[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) dz[k] = own ? du[c][k] : 0.0;
+    double afj[6];
+    LegResp::out<0>(side, T.sn, T.cs, L, a0j, dz, nullptr, afj);
+#pragma unroll
+    for (int r = 0; r < 6; ++r) Crow[r][j] = afj[r];
+  }
+  // both lanes assemble the same 12 x 12 system: rows 0..5 from the left lane, 6..11 from the right lane
+  double C[78], b[12];
+#pragma unroll
+  for (int r = 0; r < 6; ++r) {
+    const double bo = bown[r], bp = xch(bo);
+    b[r] = side ? bp : bo; b[6 + r] = side ? bo : bp;
+#pragma unroll
+    for (int j = 0; j < 12; ++j) {
+      const double mine = Crow[r][j], theirs = xch(mine);
+      const double left = side ? theirs : mine, right = side ? mine : theirs;
+      if (j <= r) C[pidx(r, j)] = left;             // lower triangle of the left foot's rows
+      if (j <= 6 + r) C[pidx(6 + r, j)] = right;    // lower triangle of the right foot's rows
+    }
+  }
+  bool actL = side ? st_par : st_own, actR = side ? st_own : st_par;
+  double lam[12];
+  double Cw[78];
+  auto solve_masked = [&]() {
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+      const bool ai = i < 6 ? actL : actR;
+      lam[i] = ai ? b[i] : 0.0;
+#pragma unroll
+      for (int j = 0; j < 12; ++j) if (j <= i) {
+        const bool aj = j < 6 ? actL : actR;
+        Cw[pidx(i, j)] = (ai && aj) ? C[pidx(i, j)] + (i == j ? soft : 0.0) : (i == j ? 1.0 : 0.0);
+      }
+    }
+    chol12_solve(Cw, lam);
+  };
+  solve_masked();
+  if (mode == 2) {
+    // unilateral: normal force on a foot = (world up axis in link coordinates) . (force part of its multiplier)
+    const double* lo = lam + (side ? 6 : 0);
+    const double fz_own = zl[0] * lo[3] + zl[1] * lo[4] + zl[2] * lo[5], fz_par = xch(fz_own);
+    const double fzL = side ? fz_par : fz_own, fzR = side ? fz_own : fz_par;
+    const bool relL = actL && fzL < 0.0, relR = actR && fzR < 0.0;
+    if (relL || relR) { actL = actL && !relL; actR = actR && !relR; solve_masked(); }
+  }
+  // propagate the multipliers: own wrench inward, pelvis, outward along every chain of this lane
+  {
+    const double* lo = lam + (side ? 6 : 0);
+    double dp[6], duo[5], pown[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) dp[k] = -lo[k];
+    LegResp::in<4>(side, T.sn, T.cs, L, dp, duo, pown);
+    double ptot[6], da0[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) ptot[k] = -pair_sum(pown[k]);
+    ldl6_solve(F, ptot, da0);
+    double dqL[5];
+    LegResp::out<0>(side, T.sn, T.cs, L, da0, duo, dqL, nullptr);
+#pragma unroll
+    for (int k = 0; k < 5; ++k) qacc.qL[k] += dqL[k];
+    // torso (slot block 0) and arm: no joint-force increments, only the pelvis acceleration travels outward
+    double s11, c11; h1f::sincos_fast(q.th11, &s11, &c11);
+    double a11[6]; xf_motion<11, 11>(side, da0, s11, c11, a11);
+    double sacc = 0.0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) sacc -= L[k] * a11[k];
+    const double dq11 = sacc * L[6];
+    a11[C_AXIS[11]] += dq11;
+    qacc.q11 += dq11;
+    double snA[4], csA[4], dqA[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) h1f::sincos_fast(q.thA[k], &snA[k], &csA[k]);
+    ArmResp::out<0>(side, snA, csA, L, a11, nullptr, dqA, nullptr);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) qacc.qA[k] += dqA[k];
+    qbase[0] += R0[0] * da0[3] + R0[1] * da0[4] + R0[2] * da0[5];
+    qbase[1] += R0[3] * da0[3] + R0[4] * da0[4] + R0[5] * da0[5];
+    qbase[2] += R0[6] * da0[3] + R0[7] * da0[4] + R0[8] * da0[5];
+    qbase[3] += da0[0]; qbase[4] += da0[1]; qbase[5] += da0[2];
+  }
 }
 
 // this lane's view of one state x = [qpos(26), qvel(25)]: the floating base (both lanes) + its HalfState
@@ -485,6 +755,50 @@ DEVFN void step(bool side, HalfX& h, const HalfU& u, double dt, const double* gr
   double qb[6]; HalfAcc qa;
   forward_dynamics(side, R0, h.vb, h.q, tau, ARMATURE + dt * DAMPING, grav, L, qb, qa);
   // semi-implicit Euler: v' = v + h qacc, q' = q (+) h v'
+#pragma unroll
+  for (int k = 0; k < 6; ++k) h.vb[k] += dt * qb[k];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) h.p[k] += dt * h.vb[k];
+  h.q.qd11 += dt * qa.q11; h.q.th11 += dt * h.q.qd11;
+#pragma unroll
+  for (int k = 0; k < 5; ++k) { h.q.qdL[k] += dt * qa.qL[k]; h.q.thL[k] += dt * h.q.qdL[k]; }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { h.q.qdA[k] += dt * qa.qA[k]; h.q.thA[k] += dt * h.q.qdA[k]; }
+  const double s = (h.vb[3] * h.vb[3] + h.vb[4] * h.vb[4] + h.vb[5] * h.vb[5]) * (dt * dt);
+  double c, so;
+  if (s < 1e-6) { c = 1.0 - s / 8.0 + s * s / 384.0 - s * s * s / 46080.0; so = 0.5 - s / 48.0 + s * s / 3840.0 - s * s * s / 645120.0; }
+  else { const double a = sqrt(s); double sn, cn; h1f::sincos_fast(0.5 * a, &sn, &cn); c = cn; so = sn / a; }
+  const double ew = c, ex = so * dt * h.vb[3], ey = so * dt * h.vb[4], ez = so * dt * h.vb[5];
+  const double rw = qh[0] * ew - qh[1] * ex - qh[2] * ey - qh[3] * ez;
+  const double rx = qh[0] * ex + qh[1] * ew + qh[2] * ez - qh[3] * ey;
+  const double ry = qh[0] * ey - qh[1] * ez + qh[2] * ew + qh[3] * ex;
+  const double rz = qh[0] * ez + qh[1] * ey - qh[2] * ex + qh[3] * ew;
+  const double rn = sqrt(rw * rw + rx * rx + ry * ry + rz * rz);
+  h.quat[0] = rw / rn; h.quat[1] = rx / rn; h.quat[2] = ry / rn; h.quat[3] = rz / rn;
+}
+
+// x <- f(x, u) with the stance constraints of the scheduled feet (contact mode 1 / 2)
+DEVFN void step_stance(bool side, HalfX& h, const HalfU& u, double dt, const double* grav, const LaneLds& L, double soft, int mode, bool st_own, bool st_par) {
+  const double qn = sqrt(h.quat[0] * h.quat[0] + h.quat[1] * h.quat[1] + h.quat[2] * h.quat[2] + h.quat[3] * h.quat[3]);
+  const double qh[4] = {h.quat[0] / qn, h.quat[1] / qn, h.quat[2] / qn, h.quat[3] / qn};
+  double R0[9]; quat_R(qh[0], qh[1], qh[2], qh[3], R0);
+  HalfTau tau;
+  tau.t11 = clampu(u.u11, C_CTRLRANGE[10]) - DAMPING * h.q.qd11;
+#pragma unroll
+  for (int k = 0; k < 5; ++k) {
+    const double lo = side ? C_CTRLRANGE[5 + k][0] : C_CTRLRANGE[k][0], hi = side ? C_CTRLRANGE[5 + k][1] : C_CTRLRANGE[k][1];
+    const double uc = u.uL[k] < lo ? lo : (u.uL[k] > hi ? hi : u.uL[k]);
+    tau.tL[k] = uc - DAMPING * h.q.qdL[k];
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const double lo = side ? C_CTRLRANGE[15 + k][0] : C_CTRLRANGE[11 + k][0], hi = side ? C_CTRLRANGE[15 + k][1] : C_CTRLRANGE[11 + k][1];
+    const double uc = u.uA[k] < lo ? lo : (u.uA[k] > hi ? hi : u.uA[k]);
+    tau.tA[k] = uc - DAMPING * h.q.qdA[k];
+  }
+  double qb[6]; HalfAcc qa; Art Y0; double a0[6];
+  forward_dynamics(side, R0, h.vb, h.q, tau, ARMATURE + dt * DAMPING, grav, L, qb, qa, &Y0, a0);
+  if (st_own || st_par) stance_correct(side, R0, h.vb, h.q, dt, soft, mode, st_own, st_par, grav, L, Y0, a0, qb, qa);
 #pragma unroll
   for (int k = 0; k < 6; ++k) h.vb[k] += dt * qb[k];
 #pragma unroll

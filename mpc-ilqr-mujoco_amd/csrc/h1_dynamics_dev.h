@@ -54,7 +54,8 @@ DEVFN double val(Dual a) { return a.v; }
 struct DynParams {
   double h;
   double g[3];
-  int contact;      // 0: constraint-free step; 1: rigid stance constraints on the scheduled feet
+  int contact;      // 0: constraint-free step; 1: rigid stance constraints on the scheduled feet;
+                    // 2: the same, unilateral (a stance foot the floor would have to pull on is released)
   double soft;      // diagonal softness of the stance constraint (1 / kg)
 };
 
@@ -423,33 +424,50 @@ __device__ inline void stance_respond(const KnotDump& Dm, int nf, const int* fb,
   if (full) for (int k = 0; k < 6; ++k) dbase[k] = da[0][k];
 }
 __device__ inline void forward_dynamics_stance(const double* quat_hat, const double* theta, const double* v, const double* tau, double arm_eff,
-                                               const double* grav, double h, double soft, const int* stance, double* qacc) {
+                                               const double* grav, double h, double soft, const int* stance, double* qacc, int contact_mode = 1) {
   KnotDump Dm;
   forward_dynamics<double, true>(quat_hat, theta, v, tau, arm_eff, grav, qacc, nullptr, &Dm);
   int nf = 0, fb[2];
   if (stance[0] == 1) fb[nf++] = 5;      // left ankle link
   if (stance[1] == 1) fb[nf++] = 10;     // right ankle link
   if (nf == 0) return;
-  const int nc = 6 * nf;
-  double C[144], b[12];
-  for (int g = 0; g < nf; ++g)
-    for (int c = 0; c < 6; ++c) {
-      double fext[2][6], daf[2][6];
-      for (int g2 = 0; g2 < 2; ++g2) for (int k = 0; k < 6; ++k) fext[g2][k] = 0.0;
-      fext[g][c] = 1.0;
-      stance_respond(Dm, nf, fb, fext, daf, false, nullptr, nullptr);
-      for (int g2 = 0; g2 < nf; ++g2) for (int k = 0; k < 6; ++k) C[(6 * g2 + k) * nc + 6 * g + c] = daf[g2][k];
-    }
-  for (int i = 0; i < nc; ++i) C[i * nc + i] += soft;
   // true (not gravity-offset) spatial acceleration of the foot: a_f - X_{f<-0} (0, R0^T(-g))
   const double mg[3] = {-grav[0], -grav[1], -grav[2]};
   double a0p[3]; mtv3(Dm.R0, mg, a0p);
-  for (int g = 0; g < nf; ++g) {
-    double off[6] = {0.0, 0.0, 0.0, a0p[0], a0p[1], a0p[2]};
-    for (int i = fb[g] - 4; i <= fb[g]; ++i) { double o2[6]; xf_motion(Dm.Rj[i], H1_POS[i], off, o2); for (int k = 0; k < 6; ++k) off[k] = o2[k]; }
-    for (int k = 0; k < 6; ++k) b[6 * g + k] = -Dm.v[fb[g]][k] / h - (Dm.a[fb[g]][k] - off[k]);
+  double b[12];
+  auto solve_set = [&]() {          // (C + soft I) lambda = b for the current stance set fb[0..nf)
+    const int nc = 6 * nf;
+    double C[144];
+    for (int g = 0; g < nf; ++g)
+      for (int c = 0; c < 6; ++c) {
+        double fext[2][6], daf[2][6];
+        for (int g2 = 0; g2 < 2; ++g2) for (int k = 0; k < 6; ++k) fext[g2][k] = 0.0;
+        fext[g][c] = 1.0;
+        stance_respond(Dm, nf, fb, fext, daf, false, nullptr, nullptr);
+        for (int g2 = 0; g2 < nf; ++g2) for (int k = 0; k < 6; ++k) C[(6 * g2 + k) * nc + 6 * g + c] = daf[g2][k];
+      }
+    for (int i = 0; i < nc; ++i) C[i * nc + i] += soft;
+    for (int g = 0; g < nf; ++g) {
+      double off[6] = {0.0, 0.0, 0.0, a0p[0], a0p[1], a0p[2]};
+      for (int i = fb[g] - 4; i <= fb[g]; ++i) { double o2[6]; xf_motion(Dm.Rj[i], H1_POS[i], off, o2); for (int k = 0; k < 6; ++k) off[k] = o2[k]; }
+      for (int k = 0; k < 6; ++k) b[6 * g + k] = -Dm.v[fb[g]][k] / h - (Dm.a[fb[g]][k] - off[k]);
+    }
+    chol_solve_small(C, b, nc);
+  };
+  solve_set();
+  if (contact_mode == 2) {
+    // unilateral: normal force on foot g = (world up axis in link coordinates) . (force part of lambda_g); feet with a
+    // negative one are released and the remaining set is solved again (once)
+    int keep[2], nk = 0;
+    for (int g = 0; g < nf; ++g) {
+      double zl[6] = {0.0, 0.0, 0.0, Dm.R0[6], Dm.R0[7], Dm.R0[8]};
+      for (int i = fb[g] - 4; i <= fb[g]; ++i) { double o2[6]; xf_motion(Dm.Rj[i], H1_POS[i], zl, o2); for (int k = 0; k < 6; ++k) zl[k] = o2[k]; }
+      const double fz = zl[3] * b[6 * g + 3] + zl[4] * b[6 * g + 4] + zl[5] * b[6 * g + 5];
+      if (!(fz < 0.0)) keep[nk++] = fb[g];
+    }
+    if (nk < nf) { nf = nk; for (int g = 0; g < nk; ++g) fb[g] = keep[g]; if (nf > 0) solve_set(); }
   }
-  chol_solve_small(C, b, nc);
+  if (nf == 0) return;
   double fext[2][6], daf[2][6], dq[H1_NB], da0[6];
   for (int g = 0; g < 2; ++g) for (int k = 0; k < 6; ++k) fext[g][k] = g < nf ? b[6 * g + k] : 0.0;
   stance_respond(Dm, nf, fb, fext, daf, true, dq, da0);
@@ -486,7 +504,7 @@ DEVFN void step(const T* x, const T* u, const DynParams& P, T* xn, const int* st
   T qacc[H1_NV];
   bool done = false;
   if constexpr (std::is_same<T, double>::value) {
-    if (P.contact && stance) { forward_dynamics_stance(qh, x + 7, x + H1_NQ, tau, H1_ARMATURE + h * H1_DAMPING, P.g, h, P.soft, stance, qacc); done = true; }
+    if (P.contact && stance) { forward_dynamics_stance(qh, x + 7, x + H1_NQ, tau, H1_ARMATURE + h * H1_DAMPING, P.g, h, P.soft, stance, qacc, P.contact); done = true; }
   }
   if (!done) forward_dynamics(qh, x + 7, x + H1_NQ, tau, H1_ARMATURE + h * H1_DAMPING, P.g, qacc);
   T vn[H1_NV];

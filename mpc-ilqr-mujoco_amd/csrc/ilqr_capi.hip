@@ -400,7 +400,7 @@ static int enqueue_solve(ilqr_hip_ctx* c, const DevState& S, const h1::ProblemDe
     // before the backward pass.  ILQR_OVERLAP_ROLLOUT=0 restores the sequential order.
     // (only while the line search and the rollout run the same step implementation: otherwise the re-rollout would differ in
     // rounding from the trajectory the linearisation beside it sees)
-    const bool concurrent_roll = iter > 0 && !reuse_rollout() && overlap_rollout() && !P.dyn.contact && ilqr::variant_ls_split() == ilqr::variant_rollout_split();
+    const bool concurrent_roll = iter > 0 && !reuse_rollout() && overlap_rollout() && (P.dyn.contact || ilqr::variant_ls_split() == ilqr::variant_rollout_split());   // (contact mode: both on the two-lane kernels)
     if ((iter == 0 || !reuse_rollout()) && !concurrent_roll) { StageTimer T(c, 0, st); ilqr::launch_rollout(S, P, ilqr::MASK_ACTIVE, 1, 0, S.Jbase, st); }
     if (iter == 0 && wait_lead) HIPCHK(c, hipStreamWaitEvent(st, wait_lead, 0));
     // linearisation (:576) and cost quadratics (:588) only depend on the rollout: run them concurrently
@@ -622,7 +622,7 @@ int ilqr_hip_step(ilqr_hip_ctx* c, int count, const double* x, const double* u, 
   return ilqr_hip_step_stance(c, count, x, u, 1, 1, x_next);
 }
 int ilqr_hip_set_contact_mode(ilqr_hip_ctx* c, int mode, double softness) {
-  if (!c || (mode != ILQR_CONTACT_NONE && mode != ILQR_CONTACT_RIGID_STANCE)) return ILQR_ERR_ARG;
+  if (!c || (mode != ILQR_CONTACT_NONE && mode != ILQR_CONTACT_RIGID_STANCE && mode != ILQR_CONTACT_UNILATERAL_STANCE)) return ILQR_ERR_ARG;
   c->P.dyn.contact = mode;
   if (softness > 0.0) c->P.dyn.soft = softness;
   return ILQR_OK;

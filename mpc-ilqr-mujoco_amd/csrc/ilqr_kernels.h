@@ -82,6 +82,9 @@ int dyn_kernels_set_attr();
 void launch_rollout_s(const DevState& S, const h1::ProblemDev& P, int mode, int do_roll, int count_iter, double* cost_out, hipStream_t st);
 void launch_line_search_s(const DevState& S, const h1::ProblemDev& P, int mode, hipStream_t st);
 int dyn_split_kernels_set_attr();
+void launch_step_s(int count, const double* x, const double* u, const h1::DynParams& dyn, double* xn, hipStream_t st, int stance_l, int stance_r);
+void launch_last_step_s(const DevState& S, const h1::ProblemDev& P, hipStream_t st);
+void launch_linearize_fd_s(const DevState& S, const h1::ProblemDev& P, int mode, double eps, hipStream_t st);
 void launch_backward_mfma(const DevState& S, int mode, hipStream_t st);
 int backward_mfma_set_attr();
 void launch_backward_wave(const DevState& S, int mode, hipStream_t st);

@@ -537,11 +537,12 @@ int variant_ls_split() { return g_var.ls_split; }
 int variant_rollout_split() { return g_var.rollout_split; }
 int variant_backward() { return backward_kind(); }
 void launch_rollout(const DevState& S, const ProblemDev& P, int mode, int do_roll, int count_iter, double* cost_out, hipStream_t st) {
-  if (!use_scalar_dyn() && !P.dyn.contact) { if (g_var.rollout_split) launch_rollout_s(S, P, mode, do_roll, count_iter, cost_out, st); else launch_rollout_r(S, P, mode, do_roll, count_iter, cost_out, st); return; }
+  // contact mode (f4) runs on the two-lane kernels (the one-lane register kernels are constraint-free only)
+  if (!use_scalar_dyn()) { if (g_var.rollout_split || P.dyn.contact) launch_rollout_s(S, P, mode, do_roll, count_iter, cost_out, st); else launch_rollout_r(S, P, mode, do_roll, count_iter, cost_out, st); return; }
   hipLaunchKernelGGL(k_rollout, dim3(cdiv(S.B, 64)), dim3(64), 0, st, S, P, mode, do_roll, count_iter, cost_out);
 }
 void launch_step(int count, const double* x, const double* u, const DynParams& dyn, double* xn, hipStream_t st, int stance_l, int stance_r) {
-  if (!use_scalar_dyn() && !dyn.contact) { launch_step_r(count, x, u, dyn, xn, st); return; }
+  if (!use_scalar_dyn()) { if (dyn.contact) launch_step_s(count, x, u, dyn, xn, st, stance_l, stance_r); else launch_step_r(count, x, u, dyn, xn, st); return; }
   hipLaunchKernelGGL(k_step, dim3(cdiv(count, 64)), dim3(64), 0, st, count, x, u, dyn, xn, stance_l, stance_r);
 }
 // phases: 1 = primal dump only, 2 = tangent sweeps / FD only, 3 = both
@@ -549,6 +550,8 @@ void launch_linearize(const DevState& S, const ProblemDev& P, int mode, int jac_
   if (jac_mode == 0 && !P.dyn.contact) {   // contact mode (f4): the stance-constrained step is differentiated by forward differences
     if (phases & 1) launch_lin_primal_r(S, P, mode, st);
     if (phases & 2) hipLaunchKernelGGL(k_lin_tangent, dim3(S.N, S.B), dim3(128), 0, st, S, P, mode);
+  } else if ((phases & 2) && !use_scalar_dyn()) {
+    launch_linearize_fd_s(S, P, mode, eps, st);       // forward differences on the two-lane step (any contact mode)
   } else if (phases & 2) {
     const long total = (long)S.B * S.N * (H1_NX + H1_NU);
     hipLaunchKernelGGL(k_fd_base, dim3(cdiv((long)S.B * S.N, 64)), dim3(64), 0, st, S, P, mode);
@@ -565,8 +568,8 @@ void launch_backward(const DevState& S, int mode, hipStream_t st) {
   else launch_backward_mfma(S, mode, st);
 }
 void launch_line_search(const DevState& S, const ProblemDev& P, int mode, hipStream_t st) {
-  if (!use_scalar_dyn() && !P.dyn.contact) {
-    if (g_var.ls_split) { launch_line_search_s(S, P, mode, st); launch_cand_costs(S, P, mode, st); }   // candidates' costs: all knots in parallel
+  if (!use_scalar_dyn()) {
+    if (g_var.ls_split || P.dyn.contact) { launch_line_search_s(S, P, mode, st); launch_cand_costs(S, P, mode, st); }   // candidates' costs: all knots in parallel
     else launch_line_search_r(S, P, mode, st);                                                  // (the one-lane kernel sums its own)
     return;
   }
@@ -578,7 +581,7 @@ void launch_control(const DevState& S, int phase, int iter, double tol, int earl
 void launch_solve_begin(const DevState& S, hipStream_t st) { hipLaunchKernelGGL(k_solve_begin, dim3(cdiv(S.B, 64)), dim3(64), 0, st, S); }
 void launch_adopt_rollout(const DevState& S, const double* shadow, int mode, unsigned long long* mismatches, hipStream_t st) { hipLaunchKernelGGL(k_adopt_rollout, dim3(S.B), dim3(64), 0, st, S, shadow, mode, mismatches); }
 void launch_warm_shift(const DevState& S, const double* px, const double* pu, hipStream_t st) { hipLaunchKernelGGL(k_warm_shift, dim3(S.B), dim3(64), 0, st, S, px, pu); }
-void launch_last_step(const DevState& S, const ProblemDev& P, hipStream_t st) { if (!use_scalar_dyn() && !P.dyn.contact) { launch_last_step_r(S, P, st); return; } hipLaunchKernelGGL(k_last_step, dim3(cdiv(S.B, 64)), dim3(64), 0, st, S, P); }
+void launch_last_step(const DevState& S, const ProblemDev& P, hipStream_t st) { if (!use_scalar_dyn()) { if (P.dyn.contact) launch_last_step_s(S, P, st); else launch_last_step_r(S, P, st); return; } hipLaunchKernelGGL(k_last_step, dim3(cdiv(S.B, 64)), dim3(64), 0, st, S, P); }
 void launch_compute_control(const DevState& S, const double* x_meas, double* u_out, hipStream_t st) { hipLaunchKernelGGL(k_compute_control, dim3(S.B), dim3(64), 0, st, S, x_meas, u_out); }
 void launch_pack_first_knot(const DevState& S, double* u0, double* K0, hipStream_t st) { hipLaunchKernelGGL(k_pack_first_knot, dim3(S.B), dim3(64), 0, st, S, u0, K0); }
 void launch_pack_payload(const DevState& S, int with_gains, double* out, hipStream_t st) { hipLaunchKernelGGL(k_pack_payload, dim3(S.B), dim3(64), 0, st, S, with_gains, out); }

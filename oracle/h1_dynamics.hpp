@@ -27,7 +27,8 @@ using std::sqrt;
 struct DynParams {
   double h;     // timestep
   double g[3];  // world gravity vector
-  int contact = 0;       // 0: constraint-free step; 1: rigid stance constraints on the scheduled feet
+  int contact = 0;       // 0: constraint-free step; 1: rigid stance constraints on the scheduled feet;
+                         // 2: the same, unilateral: a stance foot the floor would have to pull on is released
   double soft = 1e-5;    // diagonal softness of the stance constraint (1 / kg), keeps J Minv J^T invertible with straight knees
 };
 
@@ -267,7 +268,7 @@ constexpr int H1_FOOT_BODY[2] = {5, 10};   // left / right ankle link (leaf of e
 
 template <class T>
 inline void forward_dynamics_mj_stance(const T* quat_hat, const T* theta, const T* v, const T* tau, double arm_eff,
-                                       const double* grav, double h, double soft, const int* stance, T* qacc) {
+                                       const double* grav, double h, double soft, const int* stance, T* qacc, int contact_mode = 1) {
   double Isp[H1_NB][36];
   for (int i = 0; i < H1_NB; ++i) spatial_inertia(H1_MASS[i], H1_COM[i], H1_INERTIA[i], Isp[i]);
   T R0[9]; quat_wxyz_to_R(quat_hat[0], quat_hat[1], quat_hat[2], quat_hat[3], R0);
@@ -326,7 +327,6 @@ inline void forward_dynamics_mj_stance(const T* quat_hat, const T* theta, const 
   for (int f = 0; f < 2; ++f) if (stance[f] == 1) fb[nf++] = H1_FOOT_BODY[f];
   T da0[6]; for (int k = 0; k < 6; ++k) da0[k] = T(0.0);
   if (nf > 0) {
-    const int nc = 6 * nf;
     // response to wrenches fext[g] (link coordinates, acting on stance foot g): accelerations of the stance feet,
     // and (full = true) of the pelvis and every hinge
     auto respond = [&](const T (*fext)[6], T (*da_feet)[6], bool full, T* dqdd, T* dbase) {
@@ -354,28 +354,48 @@ inline void forward_dynamics_mj_stance(const T* quat_hat, const T* theta, const 
       for (int g = 0; g < nf; ++g) for (int k = 0; k < 6; ++k) da_feet[g][k] = da[fb[g]][k];
       if (full) for (int k = 0; k < 6; ++k) dbase[k] = da[0][k];
     };
-    T C[144], b[12];
-    for (int g = 0; g < nf; ++g)
-      for (int c = 0; c < 6; ++c) {
-        T fext[2][6], daf[2][6];
-        for (int g2 = 0; g2 < 2; ++g2) for (int k = 0; k < 6; ++k) fext[g2][k] = T(0.0);
-        fext[g][c] = T(1.0);
-        respond(fext, daf, false, nullptr, nullptr);
-        for (int g2 = 0; g2 < nf; ++g2) for (int k = 0; k < 6; ++k) C[(6 * g2 + k) * nc + 6 * g + c] = daf[g2][k];
+    // (C + soft I) lambda = b for the current stance set fb[0..nf)
+    T lam[12];
+    auto solve_set = [&]() {
+      const int nc = 6 * nf;
+      T C[144];
+      for (int g = 0; g < nf; ++g)
+        for (int c = 0; c < 6; ++c) {
+          T fext[2][6], daf[2][6];
+          for (int g2 = 0; g2 < 2; ++g2) for (int k = 0; k < 6; ++k) fext[g2][k] = T(0.0);
+          fext[g][c] = T(1.0);
+          respond(fext, daf, false, nullptr, nullptr);
+          for (int g2 = 0; g2 < nf; ++g2) for (int k = 0; k < 6; ++k) C[(6 * g2 + k) * nc + 6 * g + c] = daf[g2][k];
+        }
+      for (int i = 0; i < nc; ++i) C[i * nc + i] += soft;
+      // true (not gravity-offset) spatial acceleration of a leg body: acc_i - X_{i<-0} (0, R0^T(-g))
+      for (int g = 0; g < nf; ++g) {
+        T off[6]; for (int k = 0; k < 6; ++k) off[k] = a0p[k];
+        const int first = fb[g] - 4;
+        for (int i = first; i <= fb[g]; ++i) { T o2[6]; xf_motion(Rj[i], H1_POS[i], off, o2); for (int k = 0; k < 6; ++k) off[k] = o2[k]; }
+        for (int k = 0; k < 6; ++k) lam[6 * g + k] = -vel[fb[g]][k] / h - (acc[fb[g]][k] - off[k]);
       }
-    for (int i = 0; i < nc; ++i) C[i * nc + i] += soft;
-    // true (not gravity-offset) spatial acceleration of a leg body: acc_i - X_{i<-0} (0, R0^T(-g))
-    for (int g = 0; g < nf; ++g) {
-      T off[6]; for (int k = 0; k < 6; ++k) off[k] = a0p[k];
-      const int first = fb[g] - 4;
-      for (int i = first; i <= fb[g]; ++i) { T o2[6]; xf_motion(Rj[i], H1_POS[i], off, o2); for (int k = 0; k < 6; ++k) off[k] = o2[k]; }
-      for (int k = 0; k < 6; ++k) b[6 * g + k] = -vel[fb[g]][k] / h - (acc[fb[g]][k] - off[k]);
+      chol_solve_inplace(C, lam, nc);
+    };
+    solve_set();
+    if (contact_mode == 2) {
+      // unilateral: the floor pushes, it does not pull.  Normal force on foot g = (world up axis in link coordinates) . (force part
+      // of lambda_g); feet with a negative one are released and the remaining set is solved again (once).
+      int keep[2], nk = 0;
+      for (int g = 0; g < nf; ++g) {
+        T zl[6] = {T(0.0), T(0.0), T(0.0), R0[6], R0[7], R0[8]};       // R0^T e_z
+        for (int i = fb[g] - 4; i <= fb[g]; ++i) { T o2[6]; xf_motion(Rj[i], H1_POS[i], zl, o2); for (int k = 0; k < 6; ++k) zl[k] = o2[k]; }
+        const T fz = zl[3] * lam[6 * g + 3] + zl[4] * lam[6 * g + 4] + zl[5] * lam[6 * g + 5];
+        if (!(val(fz) < 0.0)) keep[nk++] = fb[g];
+      }
+      if (nk < nf) { nf = nk; for (int g = 0; g < nk; ++g) fb[g] = keep[g]; if (nf > 0) solve_set(); }
     }
-    chol_solve_inplace(C, b, nc);
-    T fext[2][6], daf[2][6], dq[H1_NB];
-    for (int g = 0; g < 2; ++g) for (int k = 0; k < 6; ++k) fext[g][k] = g < nf ? b[6 * g + k] : T(0.0);
-    respond(fext, daf, true, dq, da0);
-    for (int i = 1; i < H1_NB; ++i) qdd[i] += dq[i];
+    if (nf > 0) {
+      T fext[2][6], daf[2][6], dq[H1_NB];
+      for (int g = 0; g < 2; ++g) for (int k = 0; k < 6; ++k) fext[g][k] = g < nf ? lam[6 * g + k] : T(0.0);
+      respond(fext, daf, true, dq, da0);
+      for (int i = 1; i < H1_NB; ++i) qdd[i] += dq[i];
+    }
   }
   for (int i = 1; i < H1_NB; ++i) qacc[6 + i - 1] = qdd[i];
   T nudot[6]; for (int k = 0; k < 6; ++k) nudot[k] = acc[0][k] - a0p[k] + da0[k];
@@ -410,7 +430,7 @@ inline void h1_step(const T* x, const T* u, const DynParams& P, T* xn, const int
     tau[i] = ui - H1_DAMPING * x[H1_NQ + 6 + i];
   }
   T qacc[H1_NV];
-  if (P.contact && stance) forward_dynamics_mj_stance(qh, x + 7, x + H1_NQ, tau, H1_ARMATURE + h * H1_DAMPING, P.g, h, P.soft, stance, qacc);
+  if (P.contact && stance) forward_dynamics_mj_stance(qh, x + 7, x + H1_NQ, tau, H1_ARMATURE + h * H1_DAMPING, P.g, h, P.soft, stance, qacc, P.contact);
   else forward_dynamics_mj(qh, x + 7, x + H1_NQ, tau, H1_ARMATURE + h * H1_DAMPING, P.g, qacc);
   T vn[H1_NV];
   for (int i = 0; i < H1_NV; ++i) { vn[i] = x[H1_NQ + i] + h * qacc[i]; xn[H1_NQ + i] = vn[i]; }

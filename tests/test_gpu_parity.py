@@ -280,6 +280,68 @@ def test_contact_mode_step_and_solve_match_oracle():
     s.close()
 
 
+def test_unilateral_contact_mode_releases_pulled_feet_and_matches_oracle():
+    """Contact mode 2 (ILQR_CONTACT_UNILATERAL_STANCE): the floor pushes, it does not pull.  (i) step parity GPU (two-lane
+    kernels) <-> oracle for states where a scheduled stance foot is pulled off the ground (that foot is released) and where it
+    is not (identical to mode 1); (ii) a full solve in mode 2 against the oracle; (iii) the nominal re-rollout reproduces the
+    accepted candidates bit for bit in contact mode too."""
+    B = 4
+    prob, x0, ui = make(B, seed=18, gravity=[0.0, 0.0, -9.81], walking=True)
+    s = _solver(B); s.set_problem(prob)
+    o = oracle_for(prob)
+    rng = np.random.default_rng(7)
+    xs = x0.copy(); xs[:, 26:] += rng.uniform(-0.2, 0.2, (B, 25)); xs[:, 7 + 3] += 0.3; xs[:, 7 + 8] += 0.3
+    xs[0, 28] = 3.0                               # pelvis moving up fast: both feet would have to be pulled along
+    xs[1, 26 + 6 + 3] = -6.0                      # left knee flexing fast: the left foot lifts
+    us = ui[:, 0, :]
+    released = 0
+    for sl, sr in ((1, 1), (1, 0), (0, 1)):
+        s.set_contact_mode(1); got1 = s.step_stance(xs, us, sl, sr)
+        s.set_contact_mode(2); got2 = s.step_stance(xs, us, sl, sr)
+        for b in range(B):
+            o.set_contact_mode(2); want2 = o.step_stance(xs[b], us[b], [sl, sr])
+            o.set_contact_mode(1); want1 = o.step_stance(xs[b], us[b], [sl, sr])
+            assert np.abs(got2[b] - want2).max() < 1e-9 * max(1.0, np.abs(want2).max()), (sl, sr, b, np.abs(got2[b] - want2).max())
+            assert np.abs(got1[b] - want1).max() < 1e-9 * max(1.0, np.abs(want1).max())
+            released += int(np.abs(want2 - want1).max() > 1e-6)
+    assert released >= 2                           # the unilateral rule actually fired
+    assert np.abs(got2[3] - got1[3]).max() < 1e-12   # an unperturbed standing rollout keeps both feet
+    s.set_contact_mode(2)
+    s.set_options(jacobian_mode=1, fd_eps=1e-5, early_exit=False); s.set_max_iterations(3)
+    s.initialize(x0, ui)
+    cost = s.solve(x0)
+    tc, ta, tl = s.trace()
+    assert s.adopt_mismatches() == 0
+    for b in range(B):
+        ob = oracle_for(prob, jac_mode=1, fd_eps=1e-5, early_exit=0, max_iter=3); ob.set_contact_mode(2)
+        ob.initialize(x0[b], ui[b]); ok, c = ob.solve(x0[b])
+        n, oc, oa, ol_ = ob.trace()
+        assert n == 3 and np.allclose(tc[b], oc, rtol=1e-5) and np.array_equal(ta[b], oa), (tc[b], oc, ta[b], oa)
+        assert abs(cost[b] - c) <= 1e-5 * abs(c) and rel(s.gains_K()[b], ob.get("K")) < 1e-4 and rel(s.xbar()[b], ob.get("xbar")) < 1e-5
+    s.close()
+
+
+def test_forward_difference_jacobians_two_lane_vs_scalar_kernels():
+    """The forward-difference Jacobians (the reference's scheme, robot_utils.cpp:120-160) on the two-lane step kernels equal the
+    scalar kernels' (ILQR_DYN=s) to rounding / eps, with and without stance constraints."""
+    B = 3
+    for contact in (0, 2):
+        prob, x0, ui = make(B, seed=19, gravity=[0.0, 0.0, -9.81] if contact else None, walking=True)
+        out = []
+        for dyn in (None, "s"):
+            old = os.environ.get("ILQR_DYN")
+            if dyn: os.environ["ILQR_DYN"] = dyn
+            try:
+                s = _solver(B); s.set_problem(prob); s.set_contact_mode(contact); s.set_options(jacobian_mode=1, fd_eps=1e-5)
+                s.initialize(x0, ui); s.stage_linearize()
+                out.append(s.linearization()); s.close()
+            finally:
+                if dyn:
+                    if old is None: os.environ.pop("ILQR_DYN", None)
+                    else: os.environ["ILQR_DYN"] = old
+        assert np.abs(out[0][0] - out[1][0]).max() < 2e-5 and np.abs(out[0][1] - out[1][1]).max() < 2e-5
+
+
 def test_warm_start_mpc_step_and_control_law():
     from mpc_ilqr_mujoco_amd import solver as sv
     B = 2
