@@ -52,7 +52,8 @@ def parse():
     ap.add_argument("--stage", choices=["full", "rollout_jacobians"], default="full",
                     help="full (headline) or BASELINE.json configs[1]: forward rollout + Jacobians only (use with --batch 1024)")
     ap.add_argument("--contact", action="store_true",
-                    help="not the headline: contact row f4 (rigid stance on the scheduled feet, physical gravity, scalar kernels, forward-difference Jacobians)")
+                    help="not the headline: contact row f4 (unilateral rigid stance on the scheduled feet, physical gravity -9.81, two-lane kernels, forward-difference Jacobians)")
+    ap.add_argument("--no-contact-line", action="store_true", help="skip the short contact-mode measurement added to the default line")
     return ap.parse_args()
 
 
@@ -63,7 +64,7 @@ def cpu_baseline(pkg, prob, x0, ui, iters, budget_s, contact=False):
     o = ol.Oracle(prob["N"], prob["dt"])
     o.set_problem(prob)
     if contact:      # same plant and the same kind of Jacobians as the GPU's contact mode
-        o.set_contact_mode(1)
+        o.set_contact_mode(2)
         o.set_options(max_iter=iters, early_exit=0, jac_mode=1, fd_eps=1e-5)
     else:            # Jacobians by forward differences, eps 1e-5: the reference's own scheme (robot_utils.cpp:120-160) and the
         o.set_options(max_iter=iters, early_exit=0, jac_mode=1, fd_eps=1e-5)   # faster of the oracle's two modes on a CPU
@@ -177,7 +178,7 @@ def main():
     s.set_problem(prob)
     s.set_max_iterations(iters)
     if args.contact:
-        s.set_contact_mode(1)
+        s.set_contact_mode(2)
     s.set_options(jacobian_mode=sv.JAC_ANALYTIC, early_exit=False)
     s.enable_profiling(True)
 
@@ -267,6 +268,30 @@ def main():
         dist.all_reduce(t2, op=dist.ReduceOp.SUM)
         ee_iters = float(t2.item())
     ee_steps = max(1, args.steps // 2)
+
+    # third number (not the headline): the same batch under physical gravity with the scheduled feet held in
+    # stance (unilateral rigid stance constraints, forward-difference Jacobians as the reference takes them), fixed iterations
+    contact_line = None
+    if not args.contact and not args.no_contact_line and world == 1:
+        probc = sc.make_problem(sv.reference_kinematics, N=N, gravity=(0.0, 0.0, -9.81))
+        ugc = sv.gravity_compensation(sc.standing_state(), probc["gravity"])
+        x0c, uic = sc.synthetic_batch(B, N, args.seed, ugc)
+        s.set_problem(probc); s.set_contact_mode(2); s.set_options(jacobian_mode=sv.JAC_FD_FORWARD, early_exit=False)
+        x0c_d, uic_d = torch.from_numpy(x0c).to(dev), torch.from_numpy(uic).to(dev)
+
+        def cstep():
+            s.initialize_device(x0c_d.data_ptr(), uic_d.data_ptr()); s.solve_async(); s.synchronize()
+        cstep()
+        torch.cuda.synchronize(); tc0 = time.perf_counter()
+        csteps = 2
+        for _ in range(csteps):
+            cstep()
+        torch.cuda.synchronize(); tc = time.perf_counter() - tc0
+        assert np.all(s.iterations() == iters) and np.all(np.isfinite(s.cost()))
+        contact_line = {"value": B * iters * csteps / tc, "unit": "iterations/s", "ms_per_step": 1e3 * tc / csteps,
+                        "workload": "same batch, gravity [0, 0, -9.81], both feet scheduled in stance: unilateral rigid stance constraints in rollout / line search, "
+                                    "forward-difference Jacobians (eps 1e-5, the reference's scheme) on the two-lane step kernels, %d fixed iterations" % iters}
+        s.set_contact_mode(0)
 
     if rank == 0:
         total_iters = float(world) * B * iters * args.steps
@@ -372,6 +397,8 @@ def main():
                            "ms_per_step": 1e3 * ee_elapsed / ee_steps,
                            "note": "same step with the reference's convergence exit (|dJ| < 1e-4) enabled: executed iterations per second; not the headline"},
         }
+        if contact_line is not None:
+            out["contact"] = contact_line
         if not args.no_cpu_baseline and world == 1:   # the CPU baseline is timed on rank 0 of the one-GPU run only
             try:
                 out["cpu_baseline"] = cpu_baseline(pkg, prob, x0, ui, iters, args.cpu_seconds, contact=args.contact)

@@ -52,8 +52,11 @@ __device__ __attribute__((noinline)) void step_stance_shared(h1s::HalfX* hp, con
   *hp = h;
 }
 // one step of either kind; `st` = stance flags (left, right) of the knot being stepped
+// (compile-time switch: the constraint-free instantiation of a kernel contains no call and no address-taken state -- with a
+// run-time branch the mere presence of the call cost the headline's line search 20 %)
+template <bool CONTACT>
 DEVFN void step_any(bool side, h1s::HalfX& h, const h1s::HalfU& u, const DynParams& dyn, const int* st, const h1s::LaneLds& L) {
-  if (dyn.contact) step_stance_shared(&h, &u, dyn.h, dyn.g[0], dyn.g[1], dyn.g[2], dyn.soft, dyn.contact, st[0], st[1]);
+  if constexpr (CONTACT) step_stance_shared(&h, &u, dyn.h, dyn.g[0], dyn.g[1], dyn.g[2], dyn.soft, dyn.contact, st[0], st[1]);
   else h1s::step(side, h, u, dyn.h, dyn.g, L);
 }
 
@@ -68,6 +71,7 @@ DEVFN void load_half_u(bool side, const double* u, h1s::HalfU& o) {
 #pragma unroll
   for (int k = 0; k < 4; ++k) o.uA[k] = u[h1s::jarm(side, k)];
 }
+template <bool CONTACT>
 __global__ void __launch_bounds__(64) k_line_search_s(DevState S, ProblemDev P, int mode) {
   extern __shared__ double lds[];
   const int gid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -170,7 +174,7 @@ __global__ void __launch_bounds__(64) k_line_search_s(DevState S, ProblemDev P, 
     u.u11 = h1s::pair_sum(u.u11);     // torso control: from the left lane to both
     LSS(1)
     LSS(2)
-    step_any(side, h, u, P.dyn, P.stance + b * P.stance_stride + 2 * t, L);
+    step_any<CONTACT>(side, h, u, P.dyn, P.stance + b * P.stance_stride + 2 * t, L);
     LSS(3)
     h1s::store_half(side, h, xc + (t + 1) * n);
     LSS(4)
@@ -183,6 +187,7 @@ __global__ void __launch_bounds__(64) k_line_search_s(DevState S, ProblemDev P, 
 
 // thread per (rollout, side): nominal rollout
 // (the cost of the trajectory is evaluated afterwards, all knots in parallel: launch_nominal_costs, dyn_kernels.hip)
+template <bool CONTACT>
 __global__ void __launch_bounds__(64) k_rollout_s(DevState S, ProblemDev P, int mode, int count_iter) {
   extern __shared__ double lds[];
   const int gid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -203,7 +208,7 @@ __global__ void __launch_bounds__(64) k_rollout_s(DevState S, ProblemDev P, int 
     for (int k = 0; k < 5; ++k) u.uL[k] = ub[t * H1_NU + h1s::jleg(side, k)];
 #pragma unroll
     for (int k = 0; k < 4; ++k) u.uA[k] = ub[t * H1_NU + h1s::jarm(side, k)];
-    step_any(side, h, u, P.dyn, P.stance + b * P.stance_stride + 2 * t, L);
+    step_any<CONTACT>(side, h, u, P.dyn, P.stance + b * P.stance_stride + 2 * t, L);
     h1s::store_half(side, h, xb + (t + 1) * H1_NX);
   }
 }
@@ -223,7 +228,7 @@ __global__ void __launch_bounds__(64) k_step_s(int count, const double* x, const
   h1s::HalfX h; h1s::load_half(side, x + (size_t)i * H1_NX, h);
   h1s::HalfU uu; load_half_u(side, u + (size_t)i * H1_NU, uu);
   const int st[2] = {st_l, st_r};
-  step_any(side, h, uu, dyn, st, L);
+  if (dyn.contact) step_any<true>(side, h, uu, dyn, st, L); else step_any<false>(side, h, uu, dyn, st, L);
   h1s::store_half(side, h, xn + (size_t)i * H1_NX);
 }
 // last knot of the warm start: xbar[N] = f(xbar[N-1], ubar[N-1])  (ilqr.cpp:72-80)
@@ -237,7 +242,7 @@ __global__ void __launch_bounds__(64) k_last_step_s(DevState S, ProblemDev P) {
   const int N = S.N;
   h1s::HalfX h; h1s::load_half(side, S.xbar + ((size_t)b * (N + 1) + N - 1) * H1_NX, h);
   h1s::HalfU uu; load_half_u(side, S.ubar + ((size_t)b * N + N - 1) * H1_NU, uu);
-  step_any(side, h, uu, P.dyn, P.stance + b * P.stance_stride + 2 * (N - 1), L);
+  if (P.dyn.contact) step_any<true>(side, h, uu, P.dyn, P.stance + b * P.stance_stride + 2 * (N - 1), L); else step_any<false>(side, h, uu, P.dyn, P.stance + b * P.stance_stride + 2 * (N - 1), L);
   h1s::store_half(side, h, S.xbar + ((size_t)b * (N + 1) + N) * H1_NX);
 }
 // Reference-style forward differences (RobotUtils::linearizeDynamicsFD, robot_utils.cpp:120-160) on the two-lane step:
@@ -291,7 +296,7 @@ __global__ void __launch_bounds__(64) k_fd_steps_s(DevState S, ProblemDev P, int
   h1s::HalfX h; h1s::load_half(side, S.xbar + ((size_t)b * (S.N + 1) + t) * H1_NX, h);
   h1s::HalfU uu; load_half_u(side, S.ubar + ((size_t)b * S.N + t) * H1_NU, uu);
   perturb_half(side, h, uu, col, eps);
-  step_any(side, h, uu, P.dyn, P.stance + b * P.stance_stride + 2 * t, L);
+  if (P.dyn.contact) step_any<true>(side, h, uu, P.dyn, P.stance + b * P.stance_stride + 2 * t, L); else step_any<false>(side, h, uu, P.dyn, P.stance + b * P.stance_stride + 2 * t, L);
   if (!act) return;
   if (col < H1_NX) store_half_col(side, h, S.A + (size_t)item * H1_NX * H1_NX, H1_NX, col);
   else if (col < H1_NX + H1_NU) store_half_col(side, h, S.Bm + (size_t)item * H1_NX * H1_NU, H1_NU, col - H1_NX);
@@ -315,15 +320,18 @@ __global__ void __launch_bounds__(256) k_fd_finish(DevState S, int mode, double 
 static inline int cdiv_s(long a, long b) { return (int)((a + b - 1) / b); }
 int dyn_split_kernels_set_attr() {
   int rc = 0;
-  rc |= hipFuncSetAttribute((const void*)k_line_search_s, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DYN_LDS_BYTES_S) != hipSuccess;
-  rc |= hipFuncSetAttribute((const void*)k_rollout_s, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DYN_LDS_BYTES_S) != hipSuccess;
+  rc |= hipFuncSetAttribute((const void*)k_line_search_s<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DYN_LDS_BYTES_S) != hipSuccess;
+  rc |= hipFuncSetAttribute((const void*)k_line_search_s<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DYN_LDS_BYTES_S) != hipSuccess;
+  rc |= hipFuncSetAttribute((const void*)k_rollout_s<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DYN_LDS_BYTES_S) != hipSuccess;
+  rc |= hipFuncSetAttribute((const void*)k_rollout_s<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DYN_LDS_BYTES_S) != hipSuccess;
   rc |= hipFuncSetAttribute((const void*)k_step_s, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DYN_LDS_BYTES_S) != hipSuccess;
   rc |= hipFuncSetAttribute((const void*)k_last_step_s, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DYN_LDS_BYTES_S) != hipSuccess;
   rc |= hipFuncSetAttribute((const void*)k_fd_steps_s, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DYN_LDS_BYTES_S) != hipSuccess;
   return rc;
 }
 void launch_line_search_s(const DevState& S, const ProblemDev& P, int mode, hipStream_t st) {
-  hipLaunchKernelGGL(k_line_search_s, dim3(cdiv_s((long)S.B * 16, 64)), dim3(64), DYN_LDS_BYTES_S, st, S, P, mode);
+  if (P.dyn.contact) hipLaunchKernelGGL(k_line_search_s<true>, dim3(cdiv_s((long)S.B * 16, 64)), dim3(64), DYN_LDS_BYTES_S, st, S, P, mode);
+  else hipLaunchKernelGGL(k_line_search_s<false>, dim3(cdiv_s((long)S.B * 16, 64)), dim3(64), DYN_LDS_BYTES_S, st, S, P, mode);
 }
 void launch_step_s(int count, const double* x, const double* u, const DynParams& dyn, double* xn, hipStream_t st, int stance_l, int stance_r) {
   hipLaunchKernelGGL(k_step_s, dim3(cdiv_s((long)count * 2, 64)), dim3(64), DYN_LDS_BYTES_S, st, count, x, u, dyn, xn, stance_l, stance_r);
@@ -337,7 +345,8 @@ void launch_linearize_fd_s(const DevState& S, const ProblemDev& P, int mode, dou
   hipLaunchKernelGGL(k_fd_finish, dim3(cdiv_s((long)S.B * S.N * H1_NX * (H1_NX + H1_NU), 256)), dim3(256), 0, st, S, mode, eps, dd);
 }
 void launch_rollout_s(const DevState& S, const ProblemDev& P, int mode, int do_roll, int count_iter, double* cost_out, hipStream_t st) {
-  if (do_roll) hipLaunchKernelGGL(k_rollout_s, dim3(cdiv_s((long)S.B * 2, 64)), dim3(64), DYN_LDS_BYTES_S, st, S, P, mode, count_iter);
+  if (do_roll && P.dyn.contact) hipLaunchKernelGGL(k_rollout_s<true>, dim3(cdiv_s((long)S.B * 2, 64)), dim3(64), DYN_LDS_BYTES_S, st, S, P, mode, count_iter);
+  else if (do_roll) hipLaunchKernelGGL(k_rollout_s<false>, dim3(cdiv_s((long)S.B * 2, 64)), dim3(64), DYN_LDS_BYTES_S, st, S, P, mode, count_iter);
   else if (count_iter) hipLaunchKernelGGL(k_count_iter, dim3(cdiv_s(S.B, 64)), dim3(64), 0, st, S, mode);
   launch_nominal_costs(S, P, mode, cost_out, st);
 }
