@@ -13,6 +13,8 @@ written differently from oracle/ (which they pin), plus excerpts of the referenc
                         line-search cost (computeTotalCost) and the soft-limit penalties.
   riccati_golden.npz  : NumPy restatement of iLQR::backwardPass (ilqr.cpp:250-309) on synthetic inputs
                         incl. the LLT-failure branch.
+  solve_golden.npz    : the WHOLE solve loop (ilqr.cpp:521-660) restated with the pieces above on a 6-knot horizon: Kane-step
+                        rollout, central-difference Jacobians of it, torch-autograd cost quadratics, NumPy Riccati, line search.
   refdata_golden.npz  : rows of data/q_ref2_mj.csv, data/v_ref2.csv (reference data files) used as a
                         known-answer test of the state conventions.
 """
@@ -400,12 +402,233 @@ def gen_refdata():
     print("refdata rows", q[rows].shape, v[rows].shape, "contact flags reproduced:", cw.shape, "walking_pin stance counts", (clrw < 0).sum(0), "min |clr|", np.abs(clrw).min(), np.abs(clr2).min())
 
 
+# ----------------------------------------------------------------------------- whole solve loop (numpy / torch)
+def gen_solve():
+    """NumPy / torch float64 restatement of the WHOLE iLQR::solve loop (ilqr.cpp:521-660) on a short horizon, glued from the
+    independent pieces above: rollout through the Kane step, Jacobians by central differences of that step (eps 1e-4: a
+    numerical stand-in for the exact derivatives the HIP path computes analytically), cost quadratics from the
+    torch-autograd task terms (Pinocchio conventions, permutation quirk), NumPy Riccati, 8-alpha line search with the
+    reference's lambda / retry / exit rules.  Pins the glue between the individually pinned stages (cost trace, accepted
+    step sizes, gains) for the oracle (CPU test) and the HIP path (-m gpu)."""
+    bodies, ctrl = load_mjcf()
+    pin = PinTorch()
+    N, h = 6, 0.02
+    grav = np.array([0.0, 0.0, -1.0])
+    nq, nx, nu = 26, 51, 19
+    Q = np.ones(nx); Q[0], Q[1], Q[2] = 200.0, 50.0, 200.0; Q[3] = 50.0; Q[4:7] = 50.0; Q[7:nq] = 50.0
+    Q[nq], Q[nq + 1], Q[nq + 2] = 150.0, 50.0, 150.0; Q[nq + 3:nq + 6] = 75.0; Q[nq + 6:] = 75.0
+    R = np.ones(nu) * 0.001
+    Qf = Q * 2.0; Qf[0] *= 5.0; Qf[1] *= 2.0; Qf[2] *= 5.0; Qf[nq + 2] *= 4.0
+    w = dict(com=100.0, comvel=0.0, eepos=400.0, eevel=400.0, upright=20.0, balance=30.0, joint=1500.0, ctrl=1500.0)
+    jr = np.array([b["rng"] for b in bodies[1:]])
+    stance = np.ones((N + 1, 2), dtype=np.int32); stance[2:4, 0] = 0        # the left foot swings at knots 2, 3
+    xs = np.zeros(nx); xs[2] = 1.0432; xs[3] = 1.0
+    x_ref = np.tile(xs, (N + 1, 1)); u_ref = np.zeros((N, nu))
+
+    def fk_mj(x):
+        nb = len(bodies); Rw = [None] * nb; p = [None] * nb
+        Rw[0] = q2R(x[3:7]); p[0] = x[0:3]
+        for i in range(1, nb):
+            b = bodies[i]; pa = b["parent"]
+            Rw[i] = Rw[pa] @ b["R"] @ axis_rot(b["axis"], x[7 + i - 1]); p[i] = p[pa] + Rw[pa] @ b["pos"]
+        M = sum(b["m"] for b in bodies)
+        return sum(b["m"] * (p[i] + Rw[i] @ b["c"]) for i, b in enumerate(bodies)) / M, np.stack([p[5], p[10]])
+
+    com_ref = np.zeros((N + 1, 3)); ee_ref = np.zeros((N + 1, 2, 3))
+    for t in range(N + 1):
+        com_ref[t], ee_ref[t] = fk_mj(x_ref[t])
+    ee_ref[2:4, 0, 2] += 0.03                                                # swing-foot target above the ground
+
+    def f(x, u):
+        return kane_step(bodies, ctrl, x, u, h, grav)[0]
+
+    def limits(rng):
+        m = 0.1 * (rng[:, 1] - rng[:, 0])
+        return rng[:, 0] + m, rng[:, 1] - m
+
+    jlo, jhi = limits(jr); ulo, uhi = limits(ctrl)
+
+    def support(t):
+        L, Rt = stance[t, 0] == 1, stance[t, 1] == 1
+        if L and Rt:
+            return 0.5 * (ee_ref[t, 0, :2] + ee_ref[t, 1, :2])
+        if L:
+            return ee_ref[t, 0, :2]
+        if Rt:
+            return ee_ref[t, 1, :2]
+        return None
+
+    def knot_cost(t, x, u):          # ilqr.cpp:363-518
+        Qd = Qf if t == N else Q
+        e = x - x_ref[t]
+        c = 0.5 * e @ (Qd * e)
+        if u is not None:
+            eu = u - u_ref[t]; c += 0.5 * eu @ (R * eu)
+        qw, qx, qy, qz = x[3:7]
+        r = np.array([2 * (qx * qz + qw * qy), 2 * (qy * qz - qw * qx), 1 - 2 * (qx * qx + qy * qy) - 1.0])
+        c += 0.5 * w["upright"] * r @ r
+        ps = support(t)
+        if ps is not None:
+            com, _ = fk_mj(x)
+            om = math.sqrt(com[2] / 9.81)
+            rb = com[:2] + x[nq:nq + 2] * om - ps
+            c += 0.5 * w["balance"] * rb @ rb
+        uu = np.zeros(nu) if u is None else u
+        c += w["ctrl"] * (np.maximum(uu - uhi, 0) ** 2 + np.maximum(ulo - uu, 0) ** 2).sum()
+        q = x[7:nq]
+        c += w["joint"] * (np.maximum(q - jhi, 0) ** 2 + np.maximum(jlo - q, 0) ** 2).sum()
+        return c
+
+    def total_cost(X, U):
+        return sum(knot_cost(t, X[t], U[t]) for t in range(N)) + knot_cost(N, X[N], None)
+
+    def perm(x):
+        xp = x.clone(); xp[3], xp[4], xp[5], xp[6] = x[4], x[5], x[6], x[3]
+        return xp
+
+    def task_terms(t):
+        terms = [lambda xp: w["com"] * ((pin.com(xp) - torch.tensor(com_ref[t])) ** 2).sum()]
+        for ee, idx in ((0, 5), (1, 10)):
+            if stance[t, ee] != 1:
+                terms.append(lambda xp, ee=ee, idx=idx: w["eepos"] * ((pin.frame(xp, idx)[0] - torch.tensor(ee_ref[t, ee])) ** 2).sum())
+            else:
+                terms.append(lambda xp, idx=idx: w["eevel"] * (pin.frame(xp, idx)[1] ** 2).sum())
+
+        def upright(xp):
+            qw, qx, qy, qz = xp[3], xp[4], xp[5], xp[6]
+            r = torch.stack([2 * (qx * qz + qw * qy), 2 * (qy * qz - qw * qx), (1 - 2 * (qx * qx + qy * qy)) - 1.0])
+            return 0.5 * w["upright"] * (r ** 2).sum()
+        terms.append(upright)
+        ps = support(t)
+        if ps is not None:
+            def balance(xp):
+                c, vc = pin.com(xp, True)
+                om = torch.sqrt(c[2] / 9.81)
+                r = c[0:2] + vc[0:2] * om - torch.tensor(ps)
+                return 0.5 * w["balance"] * (r ** 2).sum()
+            terms.append(balance)
+        return terms
+
+    def quadratics(X, U):            # ilqr.cpp:133-244
+        lx = np.zeros((N + 1, nx)); lu = np.zeros((N, nu)); lxx = np.zeros((N + 1, nx, nx)); luu = np.zeros((N, nu))
+        for t in range(N + 1):
+            Qd = Qf if t == N else Q
+            lx[t] = Qd * (X[t] - x_ref[t]); lxx[t] = np.diag(Qd)
+            fsum = lambda xp: sum(term(xp) for term in task_terms(t))
+            xp0 = perm(torch.tensor(X[t]))
+            g = torch.autograd.grad(fsum(xp0.clone().requires_grad_(True)), None) if False else None
+            xpr = xp0.clone().requires_grad_(True)
+            lx[t] += torch.autograd.grad(fsum(xpr), xpr)[0].numpy()          # slots of the permuted state, added as they are
+            lxx[t] += torch.autograd.functional.hessian(fsum, xp0).numpy()
+            q = X[t, 7:nq]
+            lx[t, 7:nq] += 2 * w["joint"] * (np.maximum(q - jhi, 0) - np.maximum(jlo - q, 0))
+            lxx[t][np.arange(7, nq), np.arange(7, nq)] += 2 * w["joint"] * ((q > jhi) | (q < jlo))
+            if t < N:
+                lu[t] = R * (U[t] - u_ref[t]) + 2 * w["ctrl"] * (np.maximum(U[t] - uhi, 0) - np.maximum(ulo - U[t], 0))
+                luu[t] = R + 2 * w["ctrl"] * ((U[t] > uhi) | (U[t] < ulo))
+        return lx, lu, lxx, luu
+
+    def linearize(X, U, eps=1e-4):
+        A = np.zeros((N, nx, nx)); B = np.zeros((N, nx, nu))
+        for t in range(N):
+            for i in range(nx):
+                d = np.zeros(nx); d[i] = eps
+                A[t][:, i] = (f(X[t] + d, U[t]) - f(X[t] - d, U[t])) / (2 * eps)
+            for i in range(nu):
+                d = np.zeros(nu); d[i] = eps
+                B[t][:, i] = (f(X[t], U[t] + d) - f(X[t], U[t] - d)) / (2 * eps)
+        return A, B
+
+    alphas = [1.0, 0.8, 0.6, 0.4, 0.2, 0.1, 0.05, 0.01]
+
+    def line_search(x0, X, U, K, k):
+        J0 = total_cost(X, U)
+        for a in alphas:
+            Xn = [x0.copy()]; Un = []
+            for t in range(N):
+                u = U[t] + a * k[t] + K[t] @ (Xn[t] - X[t])
+                Un.append(u); Xn.append(f(Xn[t], u))
+            Jn = total_cost(np.array(Xn), np.array(Un))
+            if Jn < J0 - 1e-6:
+                return True, np.array(Xn), np.array(Un), Jn, a
+        return False, X, U, J0, 0.0
+
+    out = {}
+    max_iter, tol = 3, 1e-4
+    rng = np.random.default_rng(2024)
+    for seed in range(2):
+        x0 = xs.copy()
+        x0[0:3] += rng.uniform(-0.02, 0.02, 3)
+        wv = rng.uniform(-0.05, 0.05, 3); ang = np.linalg.norm(wv)
+        x0[3:7] = np.concatenate([[math.cos(ang / 2)], math.sin(ang / 2) * wv / ang])
+        x0[7:nq] += rng.uniform(-0.05, 0.05, 19); x0[nq:] += rng.uniform(-0.1, 0.1, 25)
+        U = rng.uniform(-1.0, 1.0, (N, nu))
+        X = [x0.copy()]
+        for t in range(N):
+            X.append(f(X[t], U[t]))
+        X = np.array(X)
+        lam = 1e-6
+        J = total_cost(X, U)
+        trace_c, trace_a, trace_l = [J], [], []
+        Ks = None
+        it = 0
+        for it_ in range(max_iter):
+            it = it_ + 1
+            Jprev = J
+            X[0] = x0
+            for t in range(N):
+                X[t + 1] = f(X[t], U[t])
+            A, B = linearize(X, U)
+            lx, lu, lxx, luu = quadratics(X, U)
+            lam_used = lam
+            K, k, _, _, _ = riccati_numpy(A, B, lx, lu, lxx, luu, lam)
+            ok, Xn, Un, Jn, a = line_search(x0, X, U, K, k)
+            if not ok:
+                lam = min(lam * 10.0, 1e-3); lam_used = lam
+                K, k, _, _, _ = riccati_numpy(A, B, lx, lu, lxx, luu, lam)
+                ok, Xn, Un, Jn, a = line_search(x0, X, U, K, k)
+                if not ok:
+                    trace_c.append(J); trace_a.append(0.0); trace_l.append(lam_used); Ks = K
+                    if it_ > 1:
+                        break
+                    continue
+            X, U, J = Xn, Un, Jn
+            Ks = K
+            trace_c.append(J); trace_a.append(a); trace_l.append(lam_used)
+            lam = max(lam / 2.0, 1e-6)
+            if abs(J - Jprev) < tol or J > 1e6:
+                break
+        print("solve golden seed", seed, "iterations", it, "costs", trace_c, "alphas", trace_a)
+        out["x0_%d" % seed] = x0; out["u_init_%d" % seed] = Un * 0 + 0 if False else None
+        out["x0_%d" % seed] = x0
+        out["iters_%d" % seed] = it
+        out["trace_cost_%d" % seed] = np.array(trace_c); out["trace_alpha_%d" % seed] = np.array(trace_a); out["trace_lambda_%d" % seed] = np.array(trace_l)
+        out["K_%d" % seed] = Ks; out["xbar_%d" % seed] = X; out["ubar_%d" % seed] = U
+    out = {k_: v for k_, v in out.items() if v is not None}
+    # the inputs that are not a function of the seed
+    rng = np.random.default_rng(2024)
+    uin = []
+    for seed in range(2):
+        rng.uniform(-0.02, 0.02, 3); rng.uniform(-0.05, 0.05, 3); rng.uniform(-0.05, 0.05, 19); rng.uniform(-0.1, 0.1, 25)
+        uin.append(rng.uniform(-1.0, 1.0, (N, nu)))
+    out["u_init"] = np.array(uin)
+    out.update(N=N, h=h, gravity=grav, Q=Q, R=R, Qf=Qf, stance=stance, x_ref=x_ref, u_ref=u_ref, com_ref=com_ref, ee_ref=ee_ref,
+               task_weights=np.array([w["com"], w["comvel"], w["eepos"], w["eevel"], w["upright"], w["balance"]]), w_joint=w["joint"], w_ctrl=w["ctrl"],
+               max_iter=max_iter, tol=tol)
+    np.savez(os.path.join(HERE, "solve_golden.npz"), **out)
+    print("solve golden written")
+
+
 if __name__ == "__main__":
     import sys
     if len(sys.argv) > 1 and sys.argv[1] == "refdata":
         gen_refdata()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "solve":
+        gen_solve()
+        sys.exit(0)
     gen_dynamics()
     gen_costs()
     gen_riccati()
     gen_refdata()
+    gen_solve()
