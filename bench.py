@@ -65,7 +65,7 @@ def cpu_baseline(pkg, prob, x0, ui, iters, budget_s, contact=False):
     o.set_problem(prob)
     if contact:      # same plant and the same kind of Jacobians as the GPU's contact mode
         o.set_contact_mode(2)
-        o.set_options(max_iter=iters, early_exit=0, jac_mode=1, fd_eps=1e-5)
+        o.set_options(max_iter=iters, early_exit=0, jac_mode=1, fd_eps=1e-5)     # (forward differences: the faster of the oracle's two modes)
     else:            # Jacobians by forward differences, eps 1e-5: the reference's own scheme (robot_utils.cpp:120-160) and the
         o.set_options(max_iter=iters, early_exit=0, jac_mode=1, fd_eps=1e-5)   # faster of the oracle's two modes on a CPU
     cores = ol.max_threads()
@@ -276,7 +276,7 @@ def main():
         probc = sc.make_problem(sv.reference_kinematics, N=N, gravity=(0.0, 0.0, -9.81))
         ugc = sv.gravity_compensation(sc.standing_state(), probc["gravity"])
         x0c, uic = sc.synthetic_batch(B, N, args.seed, ugc)
-        s.set_problem(probc); s.set_contact_mode(2); s.set_options(jacobian_mode=sv.JAC_FD_FORWARD, early_exit=False)
+        s.set_problem(probc); s.set_contact_mode(2); s.set_options(jacobian_mode=sv.JAC_ANALYTIC, early_exit=False)
         x0c_d, uic_d = torch.from_numpy(x0c).to(dev), torch.from_numpy(uic).to(dev)
 
         def cstep():
@@ -290,7 +290,7 @@ def main():
         assert np.all(s.iterations() == iters) and np.all(np.isfinite(s.cost()))
         contact_line = {"value": B * iters * csteps / tc, "unit": "iterations/s", "ms_per_step": 1e3 * tc / csteps,
                         "workload": "same batch, gravity [0, 0, -9.81], both feet scheduled in stance: unilateral rigid stance constraints in rollout / line search, "
-                                    "forward-difference Jacobians (eps 1e-5, the reference's scheme) on the two-lane step kernels, %d fixed iterations" % iters}
+                                    "analytic Jacobians of the constrained step, %d fixed iterations" % iters}
         s.set_contact_mode(0)
 
     if rank == 0:
@@ -387,7 +387,7 @@ def main():
                                    "H1 standing balance, N=%d, dt=0.02, %d fixed iterations per rollout, shipped config.yaml weights, gravity %s"
                                    % (B, N, iters, list(prob["gravity"])),
                        "batch_per_gpu": B, "global_batch": B * world, "horizon": N, "iterations_per_solve": iters,
-                       "jacobians": "forward differences (contact mode)" if args.contact else "analytic", "contact_mode": bool(args.contact), "batch_slices": n_slices, "gather": "u0+cost" + ("+K0" if args.gather_gains else ""), "gather_check": gather_check,
+                       "jacobians": "analytic (constrained step)" if args.contact else "analytic", "contact_mode": bool(args.contact), "batch_slices": n_slices, "gather": "u0+cost" + ("+K0" if args.gather_gains else ""), "gather_check": gather_check,
                        "collective": ("none (one GPU)" if world == 1 else "gloo, host-staged (one-GPU rehearsal)" if args.rehearse_single_gpu else "RCCL gather to rank 0")},
             "roofline": roof,
             "kernels": {n: {k: (round(v, 6) if isinstance(v, float) else v) for k, v in t.items() if k in

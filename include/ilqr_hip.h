@@ -158,9 +158,10 @@ int ilqr_hip_step(ilqr_hip_ctx* ctx, int count, const double* x /*[count][51]*/,
    RobotUtils::rolloutOneStep, src/common/robot_utils.cpp:106-117).  ILQR_CONTACT_RIGID_STANCE restates the regime its
    scenarios run in: a foot the contact schedule (ilqr_hip_set_contact_schedule, horizon-local rows) marks as stance does
    not move -- velocity-level constraint on the ankle link over one step, solved through the articulated-body
-   quantities; `softness` (> 0: set, <= 0: keep, default 1e-5 / kg) regularises the constraint-space inertia.  In this
-   mode the rollout, line search and warm-start step run on the scalar kernels and the Jacobians are the reference's
-   forward differences (robot_utils.cpp:120-160), whatever ilqr_hip_set_options selected.
+   quantities; `softness` (> 0: set, <= 0: keep, default 1e-5 / kg) regularises the constraint-space inertia.  Rollout, line
+   search, warm-start step and plant run on the two-lane register / LDS kernels with the constraint solve in them; the
+   Jacobians are analytic (ILQR_JAC_ANALYTIC: derivative of the constrained step with the active set held fixed) or the
+   reference's forward differences (ILQR_JAC_FD_FORWARD, robot_utils.cpp:120-160), as ilqr_hip_set_options selects.
    ilqr_hip_step_stance: one step with explicit stance flags (the flags only matter in contact mode).
    ILQR_CONTACT_UNILATERAL_STANCE: the same constraint, but the floor only pushes: a scheduled stance foot whose constraint
    force has a negative component along the world up axis is released for that step and the remaining set solved again. */

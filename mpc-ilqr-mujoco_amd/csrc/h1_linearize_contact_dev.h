@@ -1,0 +1,425 @@
+// Analytic Jacobians of the STANCE-CONSTRAINED step (contact row f4): A_t = df/dx, B_t = df/du of
+//   Mhat qacc + bias(q, v) - J^T lambda = tau,      J qacc + gamma(q, v) + v_f / h + soft lambda = 0
+// (h1_dynamics_dev.h forward_dynamics_stance; reference plant: RobotUtils::rolloutOneStep with MuJoCo's floor contacts,
+// robot_utils.cpp:106-117, which the reference differentiates by forward differences, robot_utils.cpp:120-160).
+// Differentiating the two equations with qacc, lambda as the dependent variables (active set fixed):
+//   Mhat dqacc - J^T dlambda = -dT,   J dqacc + soft dlambda = -dR
+//   dT = tangent of the inverse dynamics WITH the contact wrench as an external force fixed in link coordinates
+//        (the tangent-RNEA sweeps of h1_linearize_dev.h, with -lambda added to the foot bodies' forces),
+//   dR = tangent of (true foot acceleration + v_f / h) with qacc fixed (foot body's dv, da of the same sweeps, minus the
+//        tangent of the rotated gravity offset),
+//   => dlambda = (C + soft)^-1 (G^T dT - dR),  dqacc = -Mhat^-1 dT + G dlambda,   G = Mhat^-1 J^T,  C = J G.
+// G and C come from twelve unit-wrench responses of the articulated-body recursion (lanes 25..36 beside the 25 Minv lanes);
+// controls: dqacc/du_i = (Minv[:, 6+i] - G (C + soft)^-1 G[6+i, :]^T) free_u.
+// The primal dump is the FREE solve (k_lin_primal_r); lambda, the constrained qacc and body accelerations are rebuilt here.
+#pragma once
+#include "h1_linearize_dev.h"
+
+namespace h1 {
+
+struct LinContact {
+  double a[H1_NB][6];        // body accelerations (gravity-offset form): free solve, then constrained
+  double G[H1_NV][12];       // Mhat^-1 J^T, columns = wrench components (left foot 0..5, right foot 6..11)
+  double C[12][12];          // J Mhat^-1 J^T
+  double F[12][12];          // Cholesky factor of the masked C + soft I: lower, reciprocal pivots on the diagonal
+  double b[12], lam[12];
+  double dq[H1_NV];          // G lambda
+  double da[H1_NB][6];       // body acceleration increments
+  double offb[11][3];        // gravity offset R_i^T R0^T (-g) at the leg bodies 1..10 ([0]: pelvis)
+  double zl[2][3];           // world up axis in the feet's link coordinates
+  double dR[2][6][19];       // tangent of (a_f,true + v_f / h) of foot g per chain-group slot
+  double W[12][LIN_LD];      // dlambda per direction
+  double WU[12][20];         // dlambda per control column
+  int act[2];                // active stance feet after the unilateral check
+};
+
+// columns of Minv (lanes 0..24, as lin_minv_lane) and of G = Mhat^-1 J^T (lanes 25..36: unit wrench component c on foot g);
+// the feet's accelerations of the wrench columns are the rows of C
+template <int FIRST, int LEN> struct MinvChainOutC {
+  template <int K> static DEVFN void step(LinShared& L, LinContact& Cc, const MinvPath& P, const double* ap, int lane) {
+    constexpr int I = FIRST + K, ax = h1c::C_AXIS[I], dep = h1c::C_DEPTH[I];
+    const double r[3] = {h1c::C_POS[I][0], h1c::C_POS[I][1], h1c::C_POS[I][2]};
+    double a[6]; xf_motion(L.D.Rj[I], r, ap, a);
+    double s = (P.body[dep] == I) ? P.du[dep] : 0.0;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) s -= L.u.m.U[I][q] * a[q];
+    const double qdd = s * L.u.m.Dinv[I];
+    a[ax] += qdd;
+    if (lane < H1_NV) { if (5 + I >= lane) L.Minv[MINV_IDX(5 + I, lane)] = qdd; }
+    else {
+      Cc.G[5 + I][lane - H1_NV] = qdd;
+      if constexpr (I == 5 || I == 10) {
+#pragma unroll
+        for (int q = 0; q < 6; ++q) Cc.C[(I == 5 ? 0 : 6) + q][lane - H1_NV] = a[q];
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (K + 1 < LEN) step<K + 1>(L, Cc, P, a, lane);
+  }
+};
+DEVFN void lin_minv_lane_c(LinShared& L, LinContact& Cc, int lane) {
+  if (lane >= H1_NV + 12) return;
+  const int c = lane;
+  const bool wrench = c >= H1_NV;
+  const int wc = c - H1_NV;                 // wrench column: foot wc / 6, component wc % 6
+  double p0[6] = {0, 0, 0, 0, 0, 0};
+  MinvPath P;
+#pragma unroll
+  for (int d = 0; d < 6; ++d) { P.body[d] = -1; P.du[d] = 0.0; }
+  {
+    int i = wrench ? (wc < 6 ? 5 : 10) : ((c >= 6) ? c - 5 : 0);        // first body on the path (0: none)
+    double acc[6] = {0, 0, 0, 0, 0, 0};
+    if (wrench) {
+      const int k = wc % 6;
+#pragma unroll
+      for (int q = 0; q < 6; ++q) acc[q] = (q == k) ? -1.0 : 0.0;      // bias-force increment of a unit wrench on the foot
+    }
+    bool first = !wrench;
+#pragma unroll
+    for (int d = 5; d >= 1; --d) {
+      if (i > 0 && H1_DEPTH[i] == d) {
+        const int ax = H1_AXIS[i];
+        const double du = (first ? 1.0 : 0.0) - (ax == 0 ? acc[0] : (ax == 1 ? acc[1] : acc[2]));
+        first = false;
+        P.body[d] = i; P.du[d] = du;
+        const double s = du * L.u.m.Dinv[i];
+        double pa[6];
+#pragma unroll
+        for (int r = 0; r < 6; ++r) { pa[r] = acc[r] + L.u.m.U[i][r] * s; acc[r] = 0.0; }
+        xf_force_acc(L.D.Rj[i], H1_POS[i], pa, acc);
+        i = H1_PARENT[i];
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 6; ++r) p0[r] = acc[r];
+  }
+  double rhs[6] = {-p0[0], -p0[1], -p0[2], -p0[3], -p0[4], -p0[5]};
+  if (!wrench) {
+    if (c < 3) { rhs[3] += L.D.R0[3 * c]; rhs[4] += L.D.R0[3 * c + 1]; rhs[5] += L.D.R0[3 * c + 2]; }
+    else if (c < 6) rhs[c - 3] += 1.0;
+  }
+  double a0[6];
+#pragma unroll
+  for (int r = 0; r < 6; ++r) { double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) s += L.u.m.IA0inv[6 * r + k] * rhs[k];
+    a0[r] = s; }
+  double lw[3]; mv3(L.D.R0, a0 + 3, lw);
+  if (!wrench) {
+#pragma unroll
+    for (int r = 0; r < 3; ++r) if (r >= lane) L.Minv[MINV_IDX(r, lane)] = lw[r];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) if (3 + r >= lane) L.Minv[MINV_IDX(3 + r, lane)] = a0[r];
+  } else {
+#pragma unroll
+    for (int r = 0; r < 3; ++r) { Cc.G[r][wc] = lw[r]; Cc.G[3 + r][wc] = a0[r]; }
+  }
+  double a11[6];
+  {
+    constexpr int I = 11, ax = h1c::C_AXIS[11];
+    const double r[3] = {h1c::C_POS[I][0], h1c::C_POS[I][1], h1c::C_POS[I][2]};
+    xf_motion(L.D.Rj[I], r, a0, a11);
+    double s = (P.body[1] == I) ? P.du[1] : 0.0;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) s -= L.u.m.U[I][q] * a11[q];
+    const double qdd = s * L.u.m.Dinv[I];
+    a11[ax] += qdd;
+    if (!wrench) { if (5 + I >= lane) L.Minv[MINV_IDX(5 + I, lane)] = qdd; }
+    else Cc.G[5 + I][wc] = qdd;
+  }
+  MinvChainOutC<12, 4>::step<0>(L, Cc, P, a11, lane);
+  MinvChainOutC<16, 4>::step<0>(L, Cc, P, a11, lane);
+  MinvChainOutC<1, 5>::step<0>(L, Cc, P, a0, lane);
+  MinvChainOutC<6, 5>::step<0>(L, Cc, P, a0, lane);
+}
+
+// load by 128 threads: as lin_load_dump2, but the body accelerations are kept (they are corrected for the constraint before
+// X a_parent and the body forces are formed)
+DEVFN void lin_load_dump2c(LinShared& L, LinContact& Cc, const double* g, int tid) {
+  LinDump& D = L.D;
+  const int wv = tid >> 6, lane = tid & 63;
+  for (int e = tid; e < 9; e += 128) D.R0[e] = g[LinDumpG_R0 + e];
+  for (int e = tid; e < 3; e += 128) D.aL[e] = g[LinDumpG_aL + e];
+  for (int e = tid; e < H1_NV; e += 128) D.qacc[e] = g[LinDumpG_qacc + e];
+  for (int e = tid; e < H1_NB * 6; e += 128) { (&D.v[0][0])[e] = g[LinDumpG_v + e]; (&L.u.m.U[0][0])[e] = g[LinDumpG_U + e]; (&Cc.a[0][0])[e] = g[LinDumpG_a + e]; }
+  for (int e = tid; e < H1_NB; e += 128) L.u.m.Dinv[e] = g[LinDumpG_Dinv + e];
+  for (int e = tid; e < 36; e += 128) L.u.m.IA0inv[e] = g[LinDumpG_IA0inv + e];
+  if (wv == 0 && lane >= 1 && lane < H1_NB) {
+    const int i = lane, a = H1_AXIS[i], b = (a + 1) % 3, d = (a + 2) % 3;
+    const double s = g[LinDumpG_sc + 2 * i], c = g[LinDumpG_sc + 2 * i + 1];
+    for (int r = 0; r < 3; ++r) {
+      const double fa = H1_RFIX[i][r][a], fb = H1_RFIX[i][r][b], fd = H1_RFIX[i][r][d];
+      D.Rj[i][3 * r + a] = fa; D.Rj[i][3 * r + b] = fb * c + fd * s; D.Rj[i][3 * r + d] = fd * c - fb * s;
+    }
+  }
+  if (wv == 1 && lane < H1_NB) {
+    const int i = lane;
+    double v[6], Iv[6];
+    for (int k = 0; k < 6; ++k) v[k] = g[LinDumpG_v + 6 * i + k];
+    inertia_mul(i, v, Iv);
+    for (int k = 0; k < 6; ++k) L.Iv[i][k] = Iv[k];
+  }
+}
+
+// one lane per foot: gravity offset and world up axis rotated down the leg, right-hand side of the constraint
+DEVFN void lin_contact_rhs(LinShared& L, LinContact& Cc, const double* grav, int g) {
+  const LinDump& D = L.D;
+  const double mg[3] = {-grav[0], -grav[1], -grav[2]};
+  double off[3]; mtv3(D.R0, mg, off);
+  double zl[3] = {D.R0[6], D.R0[7], D.R0[8]};
+  if (g == 0) { Cc.offb[0][0] = off[0]; Cc.offb[0][1] = off[1]; Cc.offb[0][2] = off[2]; }
+  const int first = g == 0 ? 1 : 6;
+  for (int i = first; i < first + 5; ++i) {
+    double o2[3], z2[3]; mtv3(D.Rj[i], off, o2); mtv3(D.Rj[i], zl, z2);
+    for (int k = 0; k < 3; ++k) { off[k] = o2[k]; zl[k] = z2[k]; Cc.offb[i][k] = o2[k]; }
+  }
+  const int fbody = first + 4;
+  for (int k = 0; k < 3; ++k) {
+    Cc.zl[g][k] = zl[k];
+    Cc.b[6 * g + k] = -D.v[fbody][k] / L.h - Cc.a[fbody][k];
+    Cc.b[6 * g + 3 + k] = -D.v[fbody][3 + k] / L.h - (Cc.a[fbody][3 + k] - off[k]);
+  }
+}
+// x <- (C + soft)^-1 x with the factor left by lin_contact_solve_w (wave-uniform LDS reads; inactive rows are identity)
+DEVFN void lin_contact_backsolve(const LinContact& Cc, double* x) {
+  // (a scheduling fence per row: left alone the compiler hoists all 78 factor entries into registers first and spills)
+#pragma unroll
+  for (int i = 0; i < 12; ++i) { double t = x[i];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) if (k < i) t -= Cc.F[i][k] * x[k];
+    x[i] = t * Cc.F[i][i];
+    __builtin_amdgcn_sched_barrier(0); }
+#pragma unroll
+  for (int i = 11; i >= 0; --i) { double t = x[i];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) if (k > i) t -= Cc.F[k][i] * x[k];
+    x[i] = t * Cc.F[i][i];
+    __builtin_amdgcn_sched_barrier(0); }
+}
+// wave 0: masked Cholesky of C + soft I (left-looking, lane = row, one column per step, operands in LDS -- a one-lane version
+// with local arrays lived in scratch and made the kernel five times slower), multipliers, unilateral release.
+// Leaves the factor in Cc.F (lower, reciprocal pivots on the diagonal), the multipliers in Cc.lam, the active set in Cc.act.
+DEVFN void lin_contact_solve_w(LinContact& Cc, const int* stance, double soft, int mode, int lane) {
+  if (lane < 2) Cc.act[lane] = stance[lane] == 1 ? 1 : 0;
+  wave_sync();
+  for (int pass = 0; pass < 2; ++pass) {
+    if (lane < 12) {
+      const int i = lane;
+      const bool ai = Cc.act[i / 6] != 0;
+#pragma unroll
+      for (int j = 0; j < 12; ++j) {
+        const bool aj = Cc.act[j / 6] != 0;
+        if (j <= i) Cc.F[i][j] = (ai && aj) ? Cc.C[i][j] + (i == j ? soft : 0.0) : (i == j ? 1.0 : 0.0);
+      }
+    }
+    wave_sync();
+#pragma unroll
+    for (int j = 0; j < 12; ++j) {
+      if (lane == j) {
+        double d = Cc.F[j][j];
+#pragma unroll
+        for (int k = 0; k < 12; ++k) if (k < j) d -= Cc.F[j][k] * Cc.F[j][k];
+        Cc.F[j][j] = 1.0 / sqrt(d);
+      }
+      wave_sync();
+      if (lane > j && lane < 12) {
+        double t = Cc.F[lane][j];
+#pragma unroll
+        for (int k = 0; k < 12; ++k) if (k < j) t -= Cc.F[lane][k] * Cc.F[j][k];
+        Cc.F[lane][j] = t * Cc.F[j][j];
+      }
+      wave_sync();
+    }
+    int again = 0;
+    if (lane == 0) {
+      double x[12];
+#pragma unroll
+      for (int i = 0; i < 12; ++i) x[i] = Cc.act[i / 6] ? Cc.b[i] : 0.0;
+      lin_contact_backsolve(Cc, x);
+#pragma unroll
+      for (int i = 0; i < 12; ++i) Cc.lam[i] = x[i];
+      if (mode == 2 && pass == 0) {
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+          const double fz = Cc.zl[g][0] * x[6 * g + 3] + Cc.zl[g][1] * x[6 * g + 4] + Cc.zl[g][2] * x[6 * g + 5];
+          if (Cc.act[g] && fz < 0.0) { Cc.act[g] = 0; again = 1; }
+        }
+      }
+    }
+    again = __builtin_amdgcn_readfirstlane(again);
+    wave_sync();
+    if (!again) break;
+  }
+}
+// wave 0: constrained accelerations.  dq = G lambda, qacc += dq, aL += R0^T dq_lin, body accelerations a += da (level by
+// level), then X a_parent and the body forces with the contact wrenches as external forces.  Wave-local ordering only.
+DEVFN void lin_contact_correct(LinShared& L, LinContact& Cc, int lane) {
+  LinDump& D = L.D;
+  if (lane < H1_NV) {
+    double s = 0.0;
+#pragma unroll
+    for (int j = 0; j < 12; ++j) s += Cc.G[lane][j] * Cc.lam[j];
+    Cc.dq[lane] = s;
+    D.qacc[lane] += s;
+  }
+  wave_sync();
+  if (lane == 0) {
+    double dl[3]; mtv3(D.R0, Cc.dq, dl);
+    for (int k = 0; k < 3; ++k) { Cc.da[0][k] = Cc.dq[3 + k]; Cc.da[0][3 + k] = dl[k]; D.aL[k] += dl[k]; }
+  }
+  wave_sync();
+  const int i = lane;
+  const int dep = (i >= 1 && i < H1_NB) ? H1_DEPTH[i] : -1;
+  for (int d = 1; d <= 5; ++d) {
+    if (dep == d) {
+      double a[6]; xf_motion(D.Rj[i], H1_POS[i], Cc.da[H1_PARENT[i]], a);
+      a[H1_AXIS[i]] += Cc.dq[5 + i];
+      for (int k = 0; k < 6; ++k) Cc.da[i][k] = a[k];
+    }
+    wave_sync();
+  }
+  if (i < H1_NB) { for (int k = 0; k < 6; ++k) Cc.a[i][k] += Cc.da[i][k]; }
+  wave_sync();
+  if (i >= 1 && i < H1_NB) {
+    double xa[6]; xf_motion(D.Rj[i], H1_POS[i], Cc.a[H1_PARENT[i]], xa);
+    for (int k = 0; k < 6; ++k) L.xa[i][k] = xa[k];
+  }
+  if (i < H1_NB) {
+    double Ia[6], vIv[6], Iv[6];
+    for (int k = 0; k < 6; ++k) Iv[k] = L.Iv[i][k];
+    inertia_mul(i, Cc.a[i], Ia); crf(D.v[i], Iv, vIv);
+    const int g = (i == 5) ? 0 : ((i == 10) ? 1 : -1);
+    for (int k = 0; k < 6; ++k) D.F[i][k] = Ia[k] + vIv[k] - (g >= 0 ? Cc.lam[6 * (g < 0 ? 0 : g) + k] : 0.0);
+  }
+}
+
+// leg sweeps of the tangent RNEA with the foot's constraint-row tangent: as lin_tangent_legs / TanChain2<1, 6, 5>, plus the
+// tangent of the rotated gravity offset carried down the leg; dR = da_foot - (0, dgl) + dv_foot / h per group slot
+template <int K> DEVFN void tan_leg_fwd_c(const LinShared& L, const LinContact& Cc, bool side, int kind, int idx, const double* pv, const double* pa, const double* pg,
+                                          double (*df)[6], double* dv_f, double* da_f, double* dg_f) {
+  constexpr int IL = 1 + K, IR = 6 + K, ax = h1c::C_AXIS[IL];
+  double nv[6], na[6], ng[3];
+  tan_body_fwd2<IL, IR>(L, side, kind, idx, pv, pa, nv, na, df[K]);
+  const int i = side ? IR : IL;
+  mtv3(L.D.Rj[i], pg, ng);
+  {   // d(R_i^T u)/d theta_i = (R_i^T u) x e_ax, own hinge only
+    const double mt = (kind == DIR_THETA && idx == i) ? 1.0 : 0.0;
+    double t[3]; h1r::cross_axis<ax>(Cc.offb[i], t);
+    ng[0] += mt * t[0]; ng[1] += mt * t[1]; ng[2] += mt * t[2];
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  if constexpr (K + 1 < 5) tan_leg_fwd_c<K + 1>(L, Cc, side, kind, idx, nv, na, ng, df, dv_f, da_f, dg_f);
+  else {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) { dv_f[k] = nv[k]; da_f[k] = na[k]; }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) dg_f[k] = ng[k];
+  }
+}
+DEVFN void lin_tangent_legs_c(LinShared& L, LinContact& Cc, int lane) {
+  const int grp = lane / 19, q = lane - 19 * grp;
+  const bool side = grp == 1;
+  if (grp < 2) {
+    int kind, idx; slot_direction(false, side, q, kind, idx);
+    const int col = dir_lane(kind, idx);
+    double dv0[6], da0[6]; tan_base(L, kind, idx, dv0, da0);
+    double dg0[3] = {0.0, 0.0, 0.0};
+    if (kind == DIR_PHI) cross_axis(Cc.offb[0], idx, dg0);        // d(R0^T u) = (R0^T u) x dphi
+    double df[5][6], dvf[6], daf[6], dgf[3];
+    tan_leg_fwd_c<0>(L, Cc, side, kind, idx, dv0, da0, dg0, df, dvf, daf, dgf);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      Cc.dR[grp][k][q] = daf[k] + dvf[k] / L.h;
+      Cc.dR[grp][3 + k][q] = daf[3 + k] - dgf[k] + dvf[3 + k] / L.h;
+    }
+    double dFj[6] = {0, 0, 0, 0, 0, 0};
+    double acc[6] = {0, 0, 0, 0, 0, 0};
+    TanChain2<1, 6, 5>::bwd<4>(L, side, kind, idx, df, acc, dFj, col);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) L.u.t.part[grp][k][q] = dFj[k];
+  }
+}
+// multiplier tangents: wave 0 lane = direction (47), wave 1 lane = control column (19)
+DEVFN void lin_contact_multipliers(const LinShared& L, LinContact& Cc, int wv, int lane) {
+  if (wv == 0 && lane < LIN_NDIR) {
+    int kind, idx; lane_direction(lane, kind, idx);
+    double w[12];
+#pragma unroll
+    for (int j = 0; j < 12; ++j) w[j] = 0.0;
+#pragma unroll 1
+    for (int r = 0; r < H1_NV; ++r) {      // (not unrolled: the 300 entries of G would be hoisted into registers and spill)
+      const double t = L.dT[r][lane];
+#pragma unroll
+      for (int j = 0; j < 12; ++j) w[j] += Cc.G[r][j] * t;
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      const int sl = slot_in_group(g, kind, idx);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        const double dr = sl >= 0 ? Cc.dR[g][k][sl < 0 ? 0 : sl] : 0.0;
+        w[6 * g + k] = Cc.act[g] ? w[6 * g + k] - dr : 0.0;
+      }
+    }
+    lin_contact_backsolve(Cc, w);
+#pragma unroll
+    for (int j = 0; j < 12; ++j) Cc.W[j][lane] = w[j];
+  } else if (wv == 0 && lane < LIN_LD) {
+#pragma unroll
+    for (int j = 0; j < 12; ++j) Cc.W[j][lane] = 0.0;            // padding column of the MFMA operand
+  }
+  if (wv == 1 && lane < H1_NU) {
+    double w[12];
+#pragma unroll
+    for (int j = 0; j < 12; ++j) w[j] = Cc.act[j / 6] ? -Cc.G[6 + lane][j] : 0.0;
+    lin_contact_backsolve(Cc, w);
+#pragma unroll
+    for (int j = 0; j < 12; ++j) Cc.WU[j][lane] = w[j];
+  }
+}
+// dT <- -Minv dT + G W on the MFMA (row tile I = wave index): the 7 k-steps of the Minv product + 3 of the G product
+DEVFN void lin_apply_minv_2c(LinShared& L, const LinContact& Cc, int tid) {
+  typedef double v4d_l __attribute__((ext_vector_type(4)));
+  const int I = tid >> 6, lane = tid & 63;
+  const int lr = lane & 15, lk = lane >> 4;
+  double am[10], bd[3][10];
+  const int r = 16 * I + lr, rc = r < H1_NV ? r : H1_NV - 1;
+#pragma unroll
+  for (int s = 0; s < 7; ++s) {
+    const int k = 4 * s + lk, kc = k < H1_NV ? k : H1_NV - 1;
+    const double v = L.Minv[MINV_IDX(rc, kc)];
+    am[s] = (r < H1_NV && k < H1_NV) ? -v : 0.0;
+#pragma unroll
+    for (int J = 0; J < 3; ++J) {
+      const double w = L.dT[kc][16 * J + lr];
+      bd[J][s] = (k < H1_NV) ? w : 0.0;
+    }
+  }
+#pragma unroll
+  for (int s = 0; s < 3; ++s) {
+    const int k = 4 * s + lk;
+    const double v = Cc.G[rc][k];
+    am[7 + s] = (r < H1_NV) ? v : 0.0;
+#pragma unroll
+    for (int J = 0; J < 3; ++J) bd[J][7 + s] = Cc.W[k][16 * J + lr];
+  }
+  __syncthreads();
+  v4d_l acc[3];
+#pragma unroll
+  for (int J = 0; J < 3; ++J) acc[J] = (v4d_l){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int s = 0; s < 10; ++s)
+#pragma unroll
+    for (int J = 0; J < 3; ++J) acc[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(am[s], bd[J][s], acc[J], 0, 0, 0);
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr) {
+    const int row = 16 * I + 4 * rr + lk;
+    if (row < H1_NV) {
+#pragma unroll
+      for (int J = 0; J < 3; ++J) L.dT[row][16 * J + lr] = acc[J][rr];
+    }
+  }
+}
+
+}  // namespace h1

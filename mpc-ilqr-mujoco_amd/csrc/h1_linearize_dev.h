@@ -690,8 +690,9 @@ DEVFN void quat_mul(const double* a, const double* b, double* r) {
 
 // column k of A (is_u = 0, k in 0..50) or of B (is_u = 1, k in 0..18), streamed row by row into out(row, value):
 // nothing but the three angular rows of d v' survives between rows
+// (contact mode: Gc = Mhat^-1 J^T and WUc = the multiplier tangents of the control columns, h1_linearize_contact_dev.h)
 template <class Out>
-DEVFN void lin_column(const LinShared& L, int is_u, int k, Out&& out) {
+DEVFN void lin_column(const LinShared& L, int is_u, int k, Out&& out, const double (*Gc)[12] = nullptr, const double (*WUc)[20] = nullptr) {
   const double h = L.h;
   double dphi[3] = {0.0, 0.0, 0.0};
   int src = -1;                 // lane of dT holding d qacc / d direction for this column (theta, velocity columns)
@@ -704,7 +705,14 @@ DEVFN void lin_column(const LinShared& L, int is_u, int k, Out&& out) {
 #pragma unroll
   for (int r = 0; r < H1_NV; ++r) {
     double dq;
-    if (is_u) dq = L.Minv[MINV_IDX(r, 6 + k)] * fu;
+    if (is_u) {
+      dq = L.Minv[MINV_IDX(r, 6 + k)];
+      if (Gc) {
+#pragma unroll
+        for (int j = 0; j < 12; ++j) dq += Gc[r][j] * WUc[j][k];
+      }
+      dq *= fu;
+    }
     else if (k < 3) dq = 0.0;
     else if (k < 7) dq = L.dT[r][0] * dphi[0] + L.dT[r][1] * dphi[1] + L.dT[r][2] * dphi[2];
     else dq = L.dT[r][src];

@@ -16,6 +16,8 @@
 
 #include "h1_cost_dev.h"
 #include "h1_linearize_dev.h"
+#include "h1_linearize_contact_dev.h"
+#include <type_traits>
 #include "ilqr_kernels.h"
 
 using namespace h1;
@@ -126,6 +128,48 @@ __global__ void __launch_bounds__(128, 3) k_lin_tangent(DevState S, ProblemDev P
   if (wv == 0 && lane < H1_NX) lin_column(L, 0, lane, [&](int r, double v) { Ag[r * H1_NX + lane] = v; });
   if (wv == 1 && lane < H1_NU) lin_column(L, 1, lane, [&](int r, double v) { Bg[r * H1_NU + lane] = v; });
   LSTAMP(6)
+}
+
+// Contact row f4: analytic Jacobians of the stance-constrained step (h1_linearize_contact_dev.h).  Same two-wave layout; the
+// primal dump is the free solve, the multipliers and the constrained accelerations are rebuilt here (twelve unit-wrench
+// lanes beside the 25 Minv lanes), the tangent sweeps carry the contact wrench as an external force and collect the
+// constraint-row tangents, and the final product is -Minv dT + G dlambda.
+__global__ void __launch_bounds__(128, 2) k_lin_tangent_c(DevState S, ProblemDev P, int mode) {
+  const int t = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+  if (!selected(S, b, mode)) return;
+  __shared__ LinShared L;
+  __shared__ LinContact Cc;
+  const size_t knot = (size_t)b * S.N + t;
+  lin_load_dump2c(L, Cc, S.lin_dump + knot * LinDumpG_SIZE, tid);
+  if (tid < H1_NX) L.x[tid] = S.xbar[((size_t)b * (S.N + 1) + t) * H1_NX + tid];
+  if (tid >= 64 && tid < 64 + H1_NU) L.u_[tid - 64] = S.ubar[((size_t)b * S.N + t) * H1_NU + tid - 64];
+  if (tid == 127) L.h = P.dyn.h;
+  for (int e = tid; e < (H1_NV - 6) * LIN_LD; e += 128) (&L.dT[6][0])[e] = 0.0;
+  __syncthreads();
+  if (wv == 1) lin_minv_lane_c(L, Cc, lane);                 // lanes 0..24: Minv, 25..36: G and C
+  else if (lane < 2) lin_contact_rhs(L, Cc, P.dyn.g, lane);
+  __syncthreads();
+  if (wv == 0) lin_contact_solve_w(Cc, P.stance + b * P.stance_stride + 2 * t, P.dyn.soft, P.dyn.contact, lane);
+  __syncthreads();
+  if (wv == 0) {
+    lin_contact_correct(L, Cc, lane);
+    wave_sync();
+    lin_accumulate_forces_w(L, lane);
+    if (lane == 32) lin_prologue(L);
+  }
+  __syncthreads();
+  if (wv == 0) lin_tangent_legs_c(L, Cc, lane); else lin_tangent_arms(L, lane);
+  __syncthreads();
+  if (wv == 0) lin_tangent_pelvis(L, lane);
+  __syncthreads();
+  lin_contact_multipliers(L, Cc, wv, lane);
+  __syncthreads();
+  lin_apply_minv_2c(L, Cc, tid);
+  __syncthreads();
+  double* Ag = S.A + knot * H1_NX * H1_NX;
+  double* Bg = S.Bm + knot * H1_NX * H1_NU;
+  if (wv == 0 && lane < H1_NX) lin_column(L, 0, lane, [&](int r, double v) { Ag[r * H1_NX + lane] = v; });
+  if (wv == 1 && lane < H1_NU) lin_column(L, 1, lane, [&](int r, double v) { Bg[r * H1_NU + lane] = v; }, Cc.G, Cc.WU);
 }
 
 // Reference-style forward differences (RobotUtils::linearizeDynamicsFD, robot_utils.cpp:120-160):
@@ -547,7 +591,11 @@ void launch_step(int count, const double* x, const double* u, const DynParams& d
 }
 // phases: 1 = primal dump only, 2 = tangent sweeps / FD only, 3 = both
 void launch_linearize(const DevState& S, const ProblemDev& P, int mode, int jac_mode, double eps, hipStream_t st, int phases) {
-  if (jac_mode == 0 && !P.dyn.contact) {   // contact mode (f4): the stance-constrained step is differentiated by forward differences
+  if (jac_mode == 0 && !use_scalar_dyn()) {
+    if (phases & 1) launch_lin_primal_r(S, P, mode, st);       // (contact mode: the dump is the free solve, see k_lin_tangent_c)
+    if ((phases & 2) && P.dyn.contact) hipLaunchKernelGGL(k_lin_tangent_c, dim3(S.N, S.B), dim3(128), 0, st, S, P, mode);
+    else if (phases & 2) hipLaunchKernelGGL(k_lin_tangent, dim3(S.N, S.B), dim3(128), 0, st, S, P, mode);
+  } else if (jac_mode == 0 && !P.dyn.contact) {               // ILQR_DYN=s: the analytic kernels are constraint-free only
     if (phases & 1) launch_lin_primal_r(S, P, mode, st);
     if (phases & 2) hipLaunchKernelGGL(k_lin_tangent, dim3(S.N, S.B), dim3(128), 0, st, S, P, mode);
   } else if ((phases & 2) && !use_scalar_dyn()) {

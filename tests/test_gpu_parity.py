@@ -321,6 +321,42 @@ def test_unilateral_contact_mode_releases_pulled_feet_and_matches_oracle():
     s.close()
 
 
+@pytest.mark.parametrize("mode", [1, 2])
+def test_contact_analytic_jacobians_match_oracle_ad(mode):
+    """Contact row f4: analytic Jacobians of the stance-constrained step (k_lin_tangent_c: KKT differentiation with the contact
+    wrench as an external force in the tangent sweeps, unit-wrench columns G = Mhat^-1 J^T, constraint-row tangents) against
+    the oracle's forward-mode AD through its constrained step -- exact derivatives on both sides, not finite differences --
+    on a schedule with double support, single support and flight knots, under physical gravity."""
+    B = 3
+    prob, x0, ui = make(B, seed=23, gravity=[0.0, 0.0, -9.81], walking=True)
+    prob["stance"] = prob["stance"].copy(); prob["stance"][0, 10:12, :] = 0          # two flight knots
+    s = _solver(B); s.set_problem(prob); s.set_contact_mode(mode); s.set_options(jacobian_mode=0)
+    if mode == 2:
+        x0 = x0.copy(); x0[1, 28] = 2.5                                               # pelvis moving up: feet released at the first knots
+    s.initialize(x0, ui)
+    s.stage_linearize()
+    A, Bm = s.linearization()
+    xb, ub = s.xbar(), s.ubar()
+    for b in range(B):
+        o = oracle_for(prob, jac_mode=0); o.set_contact_mode(mode)
+        o.set_trajectory(xb[b], ub[b]); o.linearize()
+        Ao, Bo = o.get("A"), o.get("B")
+        assert np.abs(A[b] - Ao).max() < 1e-8 * max(1.0, np.abs(Ao).max()), (b, np.abs(A[b] - Ao).max(), np.unravel_index(np.abs(A[b] - Ao).argmax(), Ao.shape))
+        assert np.abs(Bm[b] - Bo).max() < 1e-8 * max(1.0, np.abs(Bo).max()), (b, np.abs(Bm[b] - Bo).max())
+    # and a full solve with these Jacobians against the oracle (AD Jacobians, same contact mode)
+    s.set_options(jacobian_mode=0, early_exit=False); s.set_max_iterations(3)
+    s.initialize(x0, ui); cost = s.solve(x0)
+    tc, ta, tl = s.trace()
+    assert s.adopt_mismatches() == 0
+    for b in range(B):
+        ob = oracle_for(prob, jac_mode=0, early_exit=0, max_iter=3); ob.set_contact_mode(mode)
+        ob.initialize(x0[b], ui[b]); ok, c = ob.solve(x0[b])
+        n, oc, oa, ol_ = ob.trace()
+        assert n == 3 and np.allclose(tc[b], oc, rtol=1e-5) and np.array_equal(ta[b], oa), (tc[b], oc, ta[b], oa)
+        assert abs(cost[b] - c) <= 1e-5 * abs(c) and rel(s.gains_K()[b], ob.get("K")) < 1e-5 and rel(s.xbar()[b], ob.get("xbar")) < 1e-5
+    s.close()
+
+
 def test_forward_difference_jacobians_two_lane_vs_scalar_kernels():
     """The forward-difference Jacobians (the reference's scheme, robot_utils.cpp:120-160) on the two-lane step kernels equal the
     scalar kernels' (ILQR_DYN=s) to rounding / eps, with and without stance constraints."""

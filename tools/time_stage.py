@@ -11,11 +11,14 @@ sc = pkg.scenario
 stage = sys.argv[1] if len(sys.argv) > 1 else "backward"
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 B, N = int(os.environ.get("ILQR_B", "4096")), int(os.environ.get("ILQR_N", "25"))
-prob = sc.make_problem(sv.reference_kinematics, N=N)
+CONTACT = int(os.environ.get("ILQR_CONTACT", "0"))      # 1 / 2: contact row f4 under physical gravity
+prob = sc.make_problem(sv.reference_kinematics, N=N, gravity=(0.0, 0.0, -9.81)) if CONTACT else sc.make_problem(sv.reference_kinematics, N=N)
 ug = sv.gravity_compensation(sc.standing_state(), prob["gravity"])
 x0, ui = sc.synthetic_batch(B, N, 0, ug)
 s = sv.BatchedILQR(B, N=N)
 s.set_problem(prob)
+if CONTACT:
+    s.set_contact_mode(CONTACT)
 if os.environ.get("ILQR_LAMBDA"):
     s.set_regularization(float(os.environ["ILQR_LAMBDA"]))
 s.initialize(x0, ui)
