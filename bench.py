@@ -309,7 +309,7 @@ def main():
             bk_name: dict(stages=["iLQR_backwardPass", "iLQR_backwardPass_retry"], unit="fp64 MFMA",
                                     flops=RICCATI_FLOPS_PER_KNOT * N * Bl,
                                     bytes=D * Bl * (N * (2601 + 969 + 2601 + 51 + 19 + 19 + 969 + 19) + 2 * (2601 + 51))),
-            ("k_line_search_r" if os.environ.get("ILQR_LS", "s")[:1] == "r" else "k_line_search_s+k_cand_knot_cost"):
+            ("k_line_search_r" if os.environ.get("ILQR_LS", "s")[:1] == "r" else "k_line_search_s+k_traj_knot_cost"):
                                     dict(stages=["iLQR_lineSearch", "iLQR_lineSearch_retry"], unit="fp64 VALU",
                                     flops=STEP_FLOPS * N * Bl,      # the accepted alpha's rollout is the algorithmic work
                                     bytes=D * Bl * N * ((969 + 19 + 51 + 19) + 8 * (51 + 19))),

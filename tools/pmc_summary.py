@@ -14,7 +14,11 @@ def load(paths):
     acc = collections.defaultdict(list)
     for path in paths:
         for r in csv.DictReader(open(path)):
-            acc[(r["Kernel_Name"].split("(")[0].replace("ilqr::", ""), r["Counter_Name"])].append(float(r["Counter_Value"]))
+            name = r["Kernel_Name"].split("(")[0].replace("ilqr::", "")
+            if name.startswith("void "):
+                name = name[5:]
+            name = name.split("<")[0]          # template instantiations (k_line_search_s<false>) under their plain name
+            acc[(name, r["Counter_Name"])].append(float(r["Counter_Value"]))
     return acc
 
 if len(sys.argv) > 2 and sys.argv[1] == "--traffic-json":
