@@ -196,60 +196,79 @@ DEVFN void lin_contact_backsolve(const LinContact& Cc, double* x) {
     x[i] = t * Cc.F[i][i];
     __builtin_amdgcn_sched_barrier(0); }
 }
-// wave 0: masked Cholesky of C + soft I (left-looking, lane = row, one column per step, operands in LDS -- a one-lane version
-// with local arrays lived in scratch and made the kernel five times slower), multipliers, unilateral release.
+// wave 0: masked Cholesky of C + soft I with lane i holding ROW i in twelve registers (right-looking, fully unrolled): the
+// pivot and the column below it travel by v_readlane, no LDS round trip and no synchronisation inside the factorisation.
+// By symmetry lane i also ends up with column i of L (its registers k > i), so the back substitution needs broadcasts of
+// the solution only.  (A lane-per-row version through LDS took 30 k cycles, a one-lane unrolled one 49 k with 200 spills.)
 // Leaves the factor in Cc.F (lower, reciprocal pivots on the diagonal), the multipliers in Cc.lam, the active set in Cc.act.
+DEVFN double bcast_lane(double x, int src) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(x), src), hi = __builtin_amdgcn_readlane(__double2hiint(x), src);
+  return __hiloint2double(hi, lo);
+}
 DEVFN void lin_contact_solve_w(LinContact& Cc, const int* stance, double soft, int mode, int lane) {
-  if (lane < 2) Cc.act[lane] = stance[lane] == 1 ? 1 : 0;
-  wave_sync();
+  const int i = lane < 12 ? lane : 11;
+  int actL = stance[0] == 1, actR = stance[1] == 1;
+#pragma unroll 1
   for (int pass = 0; pass < 2; ++pass) {
-    if (lane < 12) {
-      const int i = lane;
-      const bool ai = Cc.act[i / 6] != 0;
-#pragma unroll
-      for (int j = 0; j < 12; ++j) {
-        const bool aj = Cc.act[j / 6] != 0;
-        if (j <= i) Cc.F[i][j] = (ai && aj) ? Cc.C[i][j] + (i == j ? soft : 0.0) : (i == j ? 1.0 : 0.0);
-      }
-    }
-    wave_sync();
+    const bool ai = (i < 6) ? actL : actR;
+    double F[12];
 #pragma unroll
     for (int j = 0; j < 12; ++j) {
-      if (lane == j) {
-        double d = Cc.F[j][j];
+      const bool aj = (j < 6) ? actL : actR;
+      const double c = Cc.C[i > j ? i : j][i > j ? j : i];          // lower triangle, mirrored
+      F[j] = (ai && aj) ? c + (i == j ? soft : 0.0) : (i == j ? 1.0 : 0.0);
+    }
+    double rinv = 1.0;                                               // 1 / L_ii of this lane's row
 #pragma unroll
-        for (int k = 0; k < 12; ++k) if (k < j) d -= Cc.F[j][k] * Cc.F[j][k];
-        Cc.F[j][j] = 1.0 / sqrt(d);
-      }
-      wave_sync();
-      if (lane > j && lane < 12) {
-        double t = Cc.F[lane][j];
+    for (int j = 0; j < 12; ++j) {
+      const double d = bcast_lane(F[j], j);                          // pivot: element (j, j), held by lane j
+      const double ri = 1.0 / sqrt(d);
+      if (i == j) rinv = ri;
+      const double lij = F[j] * ri;                                  // lane i > j: L_ij; lane j itself: sqrt(d)
 #pragma unroll
-        for (int k = 0; k < 12; ++k) if (k < j) t -= Cc.F[lane][k] * Cc.F[j][k];
-        Cc.F[lane][j] = t * Cc.F[j][j];
+      for (int k = 0; k < 12; ++k) if (k > j) {
+        const double lkj = bcast_lane(lij, k);                       // L_kj, held by lane k
+        if (i > j) F[k] -= lij * lkj;
       }
-      wave_sync();
+      if (i > j) F[j] = lij;
+      else if (i == j) {                                             // row j is final: its registers k > j become column j of L
+#pragma unroll
+        for (int k = 0; k < 12; ++k) if (k > j) F[k] *= ri;
+      }
+    }
+    // forward substitution L y = b, then L^T x = y; x_k broadcast from lane k
+    double y = ai ? Cc.b[i] : 0.0;
+#pragma unroll
+    for (int k = 0; k < 12; ++k) {
+      const double yk = bcast_lane(y * rinv, k);                     // y_k final once all k' < k have been subtracted
+      if (i == k) y = yk;
+      else if (i > k) y -= F[k] * yk;
+    }
+    double x = y;
+#pragma unroll
+    for (int k = 11; k >= 0; --k) {
+      const double xk = bcast_lane(x * rinv, k);
+      if (i == k) x = xk;
+      else if (i < k) x -= F[k] * xk;                                // F[k], k > i: L_ki
     }
     int again = 0;
-    if (lane == 0) {
-      double x[12];
-#pragma unroll
-      for (int i = 0; i < 12; ++i) x[i] = Cc.act[i / 6] ? Cc.b[i] : 0.0;
-      lin_contact_backsolve(Cc, x);
-#pragma unroll
-      for (int i = 0; i < 12; ++i) Cc.lam[i] = x[i];
-      if (mode == 2 && pass == 0) {
-#pragma unroll
-        for (int g = 0; g < 2; ++g) {
-          const double fz = Cc.zl[g][0] * x[6 * g + 3] + Cc.zl[g][1] * x[6 * g + 4] + Cc.zl[g][2] * x[6 * g + 5];
-          if (Cc.act[g] && fz < 0.0) { Cc.act[g] = 0; again = 1; }
-        }
-      }
+    if (mode == 2 && pass == 0) {
+      const double lx3 = bcast_lane(x, 3), lx4 = bcast_lane(x, 4), lx5 = bcast_lane(x, 5), rx3 = bcast_lane(x, 9), rx4 = bcast_lane(x, 10), rx5 = bcast_lane(x, 11);
+      const double fzL = Cc.zl[0][0] * lx3 + Cc.zl[0][1] * lx4 + Cc.zl[0][2] * lx5, fzR = Cc.zl[1][0] * rx3 + Cc.zl[1][1] * rx4 + Cc.zl[1][2] * rx5;
+      if (actL && fzL < 0.0) { actL = 0; again = 1; }
+      if (actR && fzR < 0.0) { actR = 0; again = 1; }
     }
-    again = __builtin_amdgcn_readfirstlane(again);
-    wave_sync();
-    if (!again) break;
+    if (!again) {
+      if (lane < 12) {
+        Cc.lam[i] = x;
+#pragma unroll
+        for (int j = 0; j < 12; ++j) if (j < i) Cc.F[i][j] = F[j];
+        Cc.F[i][i] = rinv;
+      }
+      break;
+    }
   }
+  if (lane == 0) { Cc.act[0] = actL; Cc.act[1] = actR; }
 }
 // wave 0: constrained accelerations.  dq = G lambda, qacc += dq, aL += R0^T dq_lin, body accelerations a += da (level by
 // level), then X a_parent and the body forces with the contact wrenches as external forces.  Wave-local ordering only.
@@ -293,28 +312,18 @@ DEVFN void lin_contact_correct(LinShared& L, LinContact& Cc, int lane) {
   }
 }
 
-// leg sweeps of the tangent RNEA with the foot's constraint-row tangent: as lin_tangent_legs / TanChain2<1, 6, 5>, plus the
-// tangent of the rotated gravity offset carried down the leg; dR = da_foot - (0, dgl) + dv_foot / h per group slot
-template <int K> DEVFN void tan_leg_fwd_c(const LinShared& L, const LinContact& Cc, bool side, int kind, int idx, const double* pv, const double* pa, const double* pg,
-                                          double (*df)[6], double* dv_f, double* da_f, double* dg_f) {
+// leg sweeps of the tangent RNEA with the foot's constraint-row tangent: lin_tangent_legs + the foot body's dv, da, and the
+// tangent of the rotated gravity offset carried down the leg (a 3-vector: d(R_i^T u) = R_i^T du + [own hinge] (R_i^T u) x e);
+// dR = da_foot - (0, dgl) + dv_foot / h per group slot
+template <int K> DEVFN void tan_leg_gravity(const LinShared& L, const LinContact& Cc, bool side, int kind, int idx, const double* pg, double* dg_f) {
   constexpr int IL = 1 + K, IR = 6 + K, ax = h1c::C_AXIS[IL];
-  double nv[6], na[6], ng[3];
-  tan_body_fwd2<IL, IR>(L, side, kind, idx, pv, pa, nv, na, df[K]);
   const int i = side ? IR : IL;
-  mtv3(L.D.Rj[i], pg, ng);
-  {   // d(R_i^T u)/d theta_i = (R_i^T u) x e_ax, own hinge only
-    const double mt = (kind == DIR_THETA && idx == i) ? 1.0 : 0.0;
-    double t[3]; h1r::cross_axis<ax>(Cc.offb[i], t);
-    ng[0] += mt * t[0]; ng[1] += mt * t[1]; ng[2] += mt * t[2];
-  }
-  __builtin_amdgcn_sched_barrier(0);
-  if constexpr (K + 1 < 5) tan_leg_fwd_c<K + 1>(L, Cc, side, kind, idx, nv, na, ng, df, dv_f, da_f, dg_f);
-  else {
-#pragma unroll
-    for (int k = 0; k < 6; ++k) { dv_f[k] = nv[k]; da_f[k] = na[k]; }
-#pragma unroll
-    for (int k = 0; k < 3; ++k) dg_f[k] = ng[k];
-  }
+  double ng[3]; mtv3(L.D.Rj[i], pg, ng);
+  const double mt = (kind == DIR_THETA && idx == i) ? 1.0 : 0.0;
+  double t[3]; h1r::cross_axis<ax>(Cc.offb[i], t);
+  ng[0] += mt * t[0]; ng[1] += mt * t[1]; ng[2] += mt * t[2];
+  if constexpr (K + 1 < 5) tan_leg_gravity<K + 1>(L, Cc, side, kind, idx, ng, dg_f);
+  else { dg_f[0] = ng[0]; dg_f[1] = ng[1]; dg_f[2] = ng[2]; }
 }
 DEVFN void lin_tangent_legs_c(LinShared& L, LinContact& Cc, int lane) {
   const int grp = lane / 19, q = lane - 19 * grp;
@@ -323,14 +332,20 @@ DEVFN void lin_tangent_legs_c(LinShared& L, LinContact& Cc, int lane) {
     int kind, idx; slot_direction(false, side, q, kind, idx);
     const int col = dir_lane(kind, idx);
     double dv0[6], da0[6]; tan_base(L, kind, idx, dv0, da0);
-    double dg0[3] = {0.0, 0.0, 0.0};
-    if (kind == DIR_PHI) cross_axis(Cc.offb[0], idx, dg0);        // d(R0^T u) = (R0^T u) x dphi
-    double df[5][6], dvf[6], daf[6], dgf[3];
-    tan_leg_fwd_c<0>(L, Cc, side, kind, idx, dv0, da0, dg0, df, dvf, daf, dgf);
+    {
+      double dg0[3] = {0.0, 0.0, 0.0}, dgf[3];
+      if (kind == DIR_PHI) cross_axis(Cc.offb[0], idx, dg0);        // d(R0^T u) = (R0^T u) x dphi
+      tan_leg_gravity<0>(L, Cc, side, kind, idx, dg0, dgf);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) Cc.dR[grp][3 + k][q] = -dgf[k];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    double df[5][6], dvf[6], daf[6];
+    TanChain2<1, 6, 5>::fwd<0>(L, side, kind, idx, dv0, da0, df, dvf, daf);
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
       Cc.dR[grp][k][q] = daf[k] + dvf[k] / L.h;
-      Cc.dR[grp][3 + k][q] = daf[3 + k] - dgf[k] + dvf[3 + k] / L.h;
+      Cc.dR[grp][3 + k][q] += daf[3 + k] + dvf[3 + k] / L.h;
     }
     double dFj[6] = {0, 0, 0, 0, 0, 0};
     double acc[6] = {0, 0, 0, 0, 0, 0};
@@ -339,35 +354,52 @@ DEVFN void lin_tangent_legs_c(LinShared& L, LinContact& Cc, int lane) {
     for (int k = 0; k < 6; ++k) L.u.t.part[grp][k][q] = dFj[k];
   }
 }
-// multiplier tangents: wave 0 lane = direction (47), wave 1 lane = control column (19)
+// multiplier tangents.  wave 0: W = G^T dT (12 x 25 times 25 x 47) on the MFMA -- 7 k-steps x 3 column tiles, A operand lane
+// (lr = j, lk) = G[4 s + lk][j], B operand = dT[4 s + lk][16 J + lr] -- written to Cc.W, then lane = direction subtracts the
+// constraint-row tangents and back-substitutes; wave 1: lane = control column (19)
 DEVFN void lin_contact_multipliers(const LinShared& L, LinContact& Cc, int wv, int lane) {
-  if (wv == 0 && lane < LIN_NDIR) {
-    int kind, idx; lane_direction(lane, kind, idx);
-    double w[12];
+  typedef double v4d_c __attribute__((ext_vector_type(4)));
+  if (wv == 0) {
+    const int lr = lane & 15, lk = lane >> 4;
+    v4d_c acc[3];
 #pragma unroll
-    for (int j = 0; j < 12; ++j) w[j] = 0.0;
-#pragma unroll 1
-    for (int r = 0; r < H1_NV; ++r) {      // (not unrolled: the 300 entries of G would be hoisted into registers and spill)
-      const double t = L.dT[r][lane];
+    for (int J = 0; J < 3; ++J) acc[J] = (v4d_c){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-      for (int j = 0; j < 12; ++j) w[j] += Cc.G[r][j] * t;
-      __builtin_amdgcn_sched_barrier(0);
-    }
+    for (int sx = 0; sx < 7; ++sx) {
+      const int k = 4 * sx + lk, kc = k < H1_NV ? k : H1_NV - 1;
+      const double gv = Cc.G[kc][lr < 12 ? lr : 0];
+      const double am = (k < H1_NV && lr < 12) ? gv : 0.0;
 #pragma unroll
-    for (int g = 0; g < 2; ++g) {
-      const int sl = slot_in_group(g, kind, idx);
-#pragma unroll
-      for (int k = 0; k < 6; ++k) {
-        const double dr = sl >= 0 ? Cc.dR[g][k][sl < 0 ? 0 : sl] : 0.0;
-        w[6 * g + k] = Cc.act[g] ? w[6 * g + k] - dr : 0.0;
+      for (int J = 0; J < 3; ++J) {
+        const double tv = L.dT[kc][16 * J + lr];
+        acc[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(am, (k < H1_NV) ? tv : 0.0, acc[J], 0, 0, 0);
       }
     }
-    lin_contact_backsolve(Cc, w);
 #pragma unroll
-    for (int j = 0; j < 12; ++j) Cc.W[j][lane] = w[j];
-  } else if (wv == 0 && lane < LIN_LD) {
+    for (int r = 0; r < 3; ++r) {                 // rows j = 4 r + lk < 12
 #pragma unroll
-    for (int j = 0; j < 12; ++j) Cc.W[j][lane] = 0.0;            // padding column of the MFMA operand
+      for (int J = 0; J < 3; ++J) Cc.W[4 * r + lk][16 * J + lr] = acc[J][r];
+    }
+    wave_sync();
+    if (lane < LIN_NDIR) {
+      int kind, idx; lane_direction(lane, kind, idx);
+      double w[12];
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        const int sl = slot_in_group(g, kind, idx);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+          const double dr = sl >= 0 ? Cc.dR[g][k][sl < 0 ? 0 : sl] : 0.0;
+          w[6 * g + k] = Cc.act[g] ? Cc.W[6 * g + k][lane] - dr : 0.0;
+        }
+      }
+      lin_contact_backsolve(Cc, w);
+#pragma unroll
+      for (int j = 0; j < 12; ++j) Cc.W[j][lane] = w[j];
+    } else if (lane < LIN_LD) {
+#pragma unroll
+      for (int j = 0; j < 12; ++j) Cc.W[j][lane] = 0.0;            // padding column of the MFMA operand
+    }
   }
   if (wv == 1 && lane < H1_NU) {
     double w[12];

@@ -246,11 +246,17 @@ DEVFN double tan_body_bwd2(const LinShared& L, bool side, int kind, int idx, con
   return tot[ax];
 }
 template <int FL, int FR, int LEN> struct TanChain2 {
-  template <int K> static DEVFN void fwd(const LinShared& L, bool side, int kind, int idx, const double* pv, const double* pa, double (*df)[6]) {
+  // (dv_last / da_last: optional copy of the LAST body's velocity / acceleration tangents -- the foot's, for the contact row)
+  template <int K> static DEVFN void fwd(const LinShared& L, bool side, int kind, int idx, const double* pv, const double* pa, double (*df)[6],
+                                         double* dv_last = nullptr, double* da_last = nullptr) {
     double nv[6], na[6];
     tan_body_fwd2<FL + K, FR + K>(L, side, kind, idx, pv, pa, nv, na, df[K]);
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (K + 1 < LEN) fwd<K + 1>(L, side, kind, idx, nv, na, df);
+    if constexpr (K + 1 < LEN) fwd<K + 1>(L, side, kind, idx, nv, na, df, dv_last, da_last);
+    else if (dv_last) {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) { dv_last[k] = nv[k]; da_last[k] = na[k]; }
+    }
   }
   template <int K> static DEVFN void bwd(LinShared& L, bool side, int kind, int idx, double (*df)[6], double* acc, double* dFj, int col) {
     double tot[6];

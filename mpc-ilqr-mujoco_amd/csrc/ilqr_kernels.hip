@@ -139,6 +139,9 @@ __global__ void __launch_bounds__(128, 2) k_lin_tangent_c(DevState S, ProblemDev
   if (!selected(S, b, mode)) return;
   __shared__ LinShared L;
   __shared__ LinContact Cc;
+#ifdef LIN_STAMP
+  long long qlast = clock64();
+#endif
   const size_t knot = (size_t)b * S.N + t;
   lin_load_dump2c(L, Cc, S.lin_dump + knot * LinDumpG_SIZE, tid);
   if (tid < H1_NX) L.x[tid] = S.xbar[((size_t)b * (S.N + 1) + t) * H1_NX + tid];
@@ -146,11 +149,14 @@ __global__ void __launch_bounds__(128, 2) k_lin_tangent_c(DevState S, ProblemDev
   if (tid == 127) L.h = P.dyn.h;
   for (int e = tid; e < (H1_NV - 6) * LIN_LD; e += 128) (&L.dT[6][0])[e] = 0.0;
   __syncthreads();
+  LSTAMP(0)
   if (wv == 1) lin_minv_lane_c(L, Cc, lane);                 // lanes 0..24: Minv, 25..36: G and C
   else if (lane < 2) lin_contact_rhs(L, Cc, P.dyn.g, lane);
   __syncthreads();
+  LSTAMP(1)
   if (wv == 0) lin_contact_solve_w(Cc, P.stance + b * P.stance_stride + 2 * t, P.dyn.soft, P.dyn.contact, lane);
   __syncthreads();
+  LSTAMP(2)
   if (wv == 0) {
     lin_contact_correct(L, Cc, lane);
     wave_sync();
@@ -158,18 +164,23 @@ __global__ void __launch_bounds__(128, 2) k_lin_tangent_c(DevState S, ProblemDev
     if (lane == 32) lin_prologue(L);
   }
   __syncthreads();
+  LSTAMP(3)
   if (wv == 0) lin_tangent_legs_c(L, Cc, lane); else lin_tangent_arms(L, lane);
   __syncthreads();
   if (wv == 0) lin_tangent_pelvis(L, lane);
   __syncthreads();
+  LSTAMP(4)
   lin_contact_multipliers(L, Cc, wv, lane);
   __syncthreads();
+  LSTAMP(5)
   lin_apply_minv_2c(L, Cc, tid);
   __syncthreads();
+  LSTAMP(6)
   double* Ag = S.A + knot * H1_NX * H1_NX;
   double* Bg = S.Bm + knot * H1_NX * H1_NU;
   if (wv == 0 && lane < H1_NX) lin_column(L, 0, lane, [&](int r, double v) { Ag[r * H1_NX + lane] = v; });
   if (wv == 1 && lane < H1_NU) lin_column(L, 1, lane, [&](int r, double v) { Bg[r * H1_NU + lane] = v; }, Cc.G, Cc.WU);
+  LSTAMP(7)
 }
 
 // Reference-style forward differences (RobotUtils::linearizeDynamicsFD, robot_utils.cpp:120-160):

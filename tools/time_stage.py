@@ -45,7 +45,14 @@ if os.environ.get("ILQR_SSTAMPS"):
     for nme, v in zip(names, st):
         print("  %-28s %10.0f cycles/step  %5.1f %%" % (nme, v / 25, 100 * v / st.sum()))
     print("  total %.0f cycles per step" % (st.sum() / 25))
-if os.environ.get("ILQR_LSTAMPS"):
+if os.environ.get("ILQR_LSTAMPS") and CONTACT:
+    names = ["load dump", "Minv + wrench sweeps || constraint rhs", "constraint solve (wave 0)", "correction, forces, prologue (wave 0)", "tangent sweeps + pelvis",
+             "multiplier tangents", "apply Minv + G (MFMA)", "columns + store"]
+    st = s.cost()[:8]
+    for nme, v in zip(names, st):
+        print("  %-44s %10.0f cycles  %5.1f %%" % (nme, v, 100 * v / st.sum()))
+    print("  total %.0f cycles" % st.sum())
+elif os.environ.get("ILQR_LSTAMPS"):
     names = ["load dump", "accumulate forces (level-synchronous)", "prologue (one lane)", "Minv sweeps (25 lanes)", "tangent RNEA (47 lanes)", "apply Minv (MFMA)", "columns + store"]
     st = s.cost()[:7]
     for nme, v in zip(names, st):
