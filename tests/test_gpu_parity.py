@@ -499,11 +499,15 @@ def test_closed_loop_runner_with_logs(tmp_path):
     B, N = 3, 25
     base = sc.make_problem(sv.reference_kinematics, N=N, gravity=(0.0, 0.0, -2.0))
     s = _solver(B); s.set_max_iterations(2)
-    run = ml.MPCRunner(s, rd, base, log_dir=str(tmp_path), log_rollouts=(0, 2))
+    run = ml.MPCRunner(s, rd, base, log_dir=str(tmp_path), log_rollouts=(0, 2), profile_stages=True)
     x0 = np.repeat(rd.x_ref[:1], B, axis=0); x0[:, 26:] *= 0.1
     ug = sv.gravity_compensation(sc.standing_state(), base["gravity"])
     xs, us = run.run(x0, 3, u_init=np.repeat(np.tile(ug, (N, 1))[None], B, axis=0))
     run.close()
+    table = run.profiling_table()      # the reference's profiler keys and table layout (main/humanoid_mpc.cpp:195-226)
+    for key in ("MPC_stepOnce", "MPC_extractReference", "MPC_warmStart", "MPC_iLQR_solve", "MPC_computeControl", "iLQR_backwardPass", "iLQR_lineSearch", "iLQR_linearization"):
+        row = [l for l in table.splitlines() if l.startswith(key)]
+        assert len(row) == 1 and int(row[0].split()[1]) == 3, key
     assert xs.shape == (4, B, 51) and us.shape == (3, B, 19) and np.all(np.isfinite(xs))
     assert np.allclose(xs[1], s.step(xs[0], us[0]), rtol=0, atol=1e-12)        # the plant is the model's own step
     for b in (0, 2):
