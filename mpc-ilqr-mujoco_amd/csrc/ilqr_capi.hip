@@ -48,6 +48,7 @@ struct ilqr_hip_ctx {
   double fd_eps = 1e-5;
   int early_exit = 1;
   bool initialized = false, refs_set = false;
+  double lin_fold_h = 0.0;   // step size h while S.A / S.Bm hold the analytic Jacobians (folded backward kernel), else 0
   std::string err;
   // profiling
   int profiling = 0;
@@ -388,6 +389,7 @@ static int enqueue_solve(ilqr_hip_ctx* c, const DevState& S, const h1::ProblemDe
                          hipEvent_t ev_fork, hipEvent_t ev_join, hipEvent_t ev_roll, const double* shadow_base, hipEvent_t wait_lead, hipEvent_t lead) {
   // shadow target of the concurrent re-rollout: same rollouts as S.xbar, in the shadow buffer
   double* shadow = const_cast<double*>(shadow_base) + (S.xbar - c->S.xbar);
+  const double fold_h = ilqr::linearize_fold_h(P, c->jac_mode);
   { StageTimer T(c, 0, st); ilqr::launch_rollout(S, P, ilqr::MASK_ALL, 0, 0, S.Jbase, st); ilqr::launch_solve_begin(S, st); }  // ilqr.cpp:540
   for (int iter = 0; iter < c->max_iter; ++iter) {
     // :551,563 nominal rollout at the top of every iteration, as the reference does.  From the second iteration on the
@@ -417,11 +419,11 @@ static int enqueue_solve(ilqr_hip_ctx* c, const DevState& S, const h1::ProblemDe
     { StageTimer T(c, 1, st); ilqr::launch_linearize(S, P, ilqr::MASK_ACTIVE, c->jac_mode, c->fd_eps, st); }
     HIPCHK(c, hipStreamWaitEvent(st, ev_join, 0));
     if (concurrent_roll) { HIPCHK(c, hipStreamWaitEvent(st, ev_roll, 0)); ilqr::launch_adopt_rollout(S, shadow, ilqr::MASK_ACTIVE, c->d_mismatch, st); }
-    { StageTimer T(c, 3, st); ilqr::launch_backward(S, ilqr::MASK_ACTIVE, st); }                                  // :601
+    { StageTimer T(c, 3, st); ilqr::launch_backward(S, ilqr::MASK_ACTIVE, st, fold_h); }                                  // :601
     if (iter == 0 && lead) HIPCHK(c, hipEventRecord(lead, st));
     { StageTimer T(c, 4, st); ilqr::launch_line_search(S, P, ilqr::MASK_ACTIVE, st); }                            // :616
     { StageTimer T(c, 5, st); ilqr::launch_control(S, 0, iter, c->tol, c->early_exit, st); }                      // :619-620,645-655
-    { StageTimer T(c, 6, st); ilqr::launch_backward(S, ilqr::MASK_RETRY, st); }                                   // :637
+    { StageTimer T(c, 6, st); ilqr::launch_backward(S, ilqr::MASK_RETRY, st, fold_h); }                                  // :637
     { StageTimer T(c, 7, st); ilqr::launch_line_search(S, P, ilqr::MASK_RETRY, st); }                             // :638
     { StageTimer T(c, 5, st); ilqr::launch_control(S, 1, iter, c->tol, c->early_exit, st); }                      // :640-646
   }
@@ -438,6 +440,7 @@ int ilqr_hip_solve_async(ilqr_hip_ctx* c) {
   HIPCHK(c, hipMemsetAsync(c->d_mismatch, 0, sizeof(unsigned long long), st));
   const int k = slices_wanted(c->B);
   c->n_slices = k;
+  c->lin_fold_h = ilqr::linearize_fold_h(P, c->jac_mode);   // what S.A / S.Bm hold after this solve
   if (k <= 1) {
     TRY(enqueue_solve(c, S, P, st, c->stream2, c->stream3, c->ev_fork, c->ev_join, c->ev_roll, c->d_shadowx, nullptr, nullptr));
   } else {
@@ -549,9 +552,9 @@ int ilqr_hip_set_trajectory(ilqr_hip_ctx* c, const double* xbar, const double* u
 #define STAGE_PRE if (!c) return ILQR_ERR_ARG; if (!c->initialized) return ILQR_ERR_STATE; enter(c)
 #define STAGE_POST HIPCHK(c, hipGetLastError()); HIPCHK(c, hipStreamSynchronize(c->stream)); return ILQR_OK
 int ilqr_hip_stage_rollout(ilqr_hip_ctx* c) { STAGE_PRE; ilqr::launch_rollout(c->S, c->P, ilqr::MASK_ALL, 1, 0, c->S.Jbase, c->stream); STAGE_POST; }
-int ilqr_hip_stage_linearize(ilqr_hip_ctx* c) { STAGE_PRE; ilqr::launch_linearize(c->S, c->P, ilqr::MASK_ALL, c->jac_mode, c->fd_eps, c->stream); STAGE_POST; }
+int ilqr_hip_stage_linearize(ilqr_hip_ctx* c) { STAGE_PRE; ilqr::launch_linearize(c->S, c->P, ilqr::MASK_ALL, c->jac_mode, c->fd_eps, c->stream); c->lin_fold_h = ilqr::linearize_fold_h(c->P, c->jac_mode); STAGE_POST; }
 int ilqr_hip_stage_cost_quadratics(ilqr_hip_ctx* c) { STAGE_PRE; if (!c->refs_set) return ILQR_ERR_STATE; ilqr::launch_cost_quadratics(c->S, c->P, ilqr::MASK_ALL, c->stream); STAGE_POST; }
-int ilqr_hip_stage_backward_pass(ilqr_hip_ctx* c) { STAGE_PRE; ilqr::launch_backward(c->S, ilqr::MASK_ALL, c->stream); STAGE_POST; }
+int ilqr_hip_stage_backward_pass(ilqr_hip_ctx* c) { STAGE_PRE; ilqr::launch_backward(c->S, ilqr::MASK_ALL, c->stream, c->lin_fold_h); STAGE_POST; }
 int ilqr_hip_stage_total_cost(ilqr_hip_ctx* c, double* cost) {
   STAGE_PRE; if (!cost || !c->refs_set) return ILQR_ERR_ARG;
   ilqr::launch_rollout(c->S, c->P, ilqr::MASK_ALL, 0, 0, c->d_cost_tmp, c->stream);
@@ -589,6 +592,7 @@ int ilqr_hip_set_linearization(ilqr_hip_ctx* c, const double* A, const double* B
   HIPCHK(c, hipMemcpy(c->S.A, A, B * N * ILQR_NX * ILQR_NX * sizeof(double), hipMemcpyHostToDevice));
   HIPCHK(c, hipMemcpy(c->S.Bm, Bm, B * N * ILQR_NX * ILQR_NU * sizeof(double), hipMemcpyHostToDevice));
   c->initialized = true;
+  c->lin_fold_h = 0.0;      // Jacobians of unknown origin: generic backward kernel
   return ILQR_OK;
 }
 int ilqr_hip_get_quadratics(ilqr_hip_ctx* c, double* lx, double* lu, double* lxx, double* luu) {

@@ -52,7 +52,8 @@ void launch_rollout(const DevState& S, const h1::ProblemDev& P, int mode, int do
 void launch_step(int count, const double* x, const double* u, const h1::DynParams& dyn, double* xn, hipStream_t st, int stance_l = 1, int stance_r = 1);
 void launch_linearize(const DevState& S, const h1::ProblemDev& P, int mode, int jac_mode, double eps, hipStream_t st, int phases = 3);
 void launch_cost_quadratics(const DevState& S, const h1::ProblemDev& P, int mode, hipStream_t st);
-void launch_backward(const DevState& S, int mode, hipStream_t st);
+void launch_backward(const DevState& S, int mode, hipStream_t st, double fold_h = 0.0);
+double linearize_fold_h(const h1::ProblemDev& P, int jac_mode);
 void launch_line_search(const DevState& S, const h1::ProblemDev& P, int mode, hipStream_t st);
 void launch_control(const DevState& S, int phase, int iter, double tol, int early_exit, hipStream_t st);
 void launch_solve_begin(const DevState& S, hipStream_t st);
@@ -87,7 +88,7 @@ void launch_last_step_s(const DevState& S, const h1::ProblemDev& P, hipStream_t 
 void launch_linearize_fd_s(const DevState& S, const h1::ProblemDev& P, int mode, double eps, hipStream_t st);
 void launch_backward_mfma(const DevState& S, int mode, hipStream_t st);
 int backward_mfma_set_attr();
-void launch_backward_wave(const DevState& S, int mode, hipStream_t st);
+void launch_backward_wave(const DevState& S, int mode, hipStream_t st, double fold_h);
 size_t backward_mfma_lds_bytes();
 
 }  // namespace ilqr

@@ -12,6 +12,8 @@
 // item (thread, wave or workgroup, per kernel) owns one rollout / knot and streams its own slab.
 #include <hip/hip_runtime.h>
 
+#include <cstring>
+
 #include <cstdlib>
 
 #include "h1_cost_dev.h"
@@ -571,9 +573,10 @@ static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 //   ILQR_DYN=s        scratch-resident scalar ABA kernels for every dynamics stage (on-device cross-check; always in contact mode)
 //   ILQR_ROLLOUT=s|r  nominal rollout on two lanes (dyn_split_kernels.hip) or one lane per rollout
 //   ILQR_LS=s|r       line search on two lanes or one lane per candidate
-//   ILQR_BACKWARD=wave|wg|valu  one-wave MFMA (riccati_wave.hip) / four-wave MFMA (riccati_mfma.hip) / LDS + VALU cross-check
-struct Variants { int scalar_dyn, rollout_split, ls_split, backward; };
-static Variants g_var = {0, ROLLOUT_SPLIT_DEFAULT, LS_SPLIT_DEFAULT, -1};
+//   ILQR_BACKWARD=wave|wave-generic|wg|valu  one-wave MFMA (riccati_wave.hip; "wave-generic" = never the folded variant) /
+//                     four-wave MFMA (riccati_mfma.hip) / LDS + VALU cross-check
+struct Variants { int scalar_dyn, rollout_split, ls_split, backward, fold; };
+static Variants g_var = {0, ROLLOUT_SPLIT_DEFAULT, LS_SPLIT_DEFAULT, -1, 1};
 static int env_split(const char* var, int dflt) { const char* e = getenv(var); return !e ? dflt : (e[0] == 's' ? 1 : 0); }
 #ifndef BACKWARD_DEFAULT
 #define BACKWARD_DEFAULT 2
@@ -587,6 +590,7 @@ void refresh_variants() {
   g_var.ls_split = env_split("ILQR_LS", LS_SPLIT_DEFAULT);
   e = getenv("ILQR_BACKWARD");
   g_var.backward = !e ? BACKWARD_DEFAULT : (e[0] == 'v') ? 1 : (e[0] == 'w' && e[1] == 'a') ? 2 : 0;
+  g_var.fold = !(e && strstr(e, "generic"));
 }
 int variant_ls_split() { return g_var.ls_split; }
 int variant_rollout_split() { return g_var.rollout_split; }
@@ -618,12 +622,18 @@ void launch_linearize(const DevState& S, const ProblemDev& P, int mode, int jac_
   }
 }
 size_t lin_dump_doubles() { return LinDumpG_SIZE; }
+// Step size h if launch_linearize(jac_mode) writes Jacobians whose hinge-position rows are exactly e_k + h * the hinge-velocity
+// rows (the analytic tangent kernels, lin_column) and the backward kernel can use that (riccati_wave.hip fold_rows); else 0.
+double linearize_fold_h(const ProblemDev& P, int jac_mode) {
+  const bool analytic = jac_mode == 0 && (!use_scalar_dyn() || !P.dyn.contact);
+  return (analytic && g_var.fold && backward_kind() == 2) ? P.dyn.h : 0.0;
+}
 // ILQR_BACKWARD=valu selects the LDS + VALU kernel (kept as an on-device cross-check), =wg the four-wave MFMA
 // kernel (riccati_mfma.hip), =wave the one-wave-per-rollout MFMA kernel (riccati_wave.hip)
-void launch_backward(const DevState& S, int mode, hipStream_t st) {
+void launch_backward(const DevState& S, int mode, hipStream_t st, double fold_h) {
   const int kind = backward_kind();
   if (kind == 1) hipLaunchKernelGGL(k_backward, dim3(S.B), dim3(256), backward_lds_bytes(), st, S, mode);
-  else if (kind == 2) launch_backward_wave(S, mode, st);
+  else if (kind == 2) launch_backward_wave(S, mode, st, g_var.fold ? fold_h : 0.0);
   else launch_backward_mfma(S, mode, st);
 }
 void launch_line_search(const DevState& S, const ProblemDev& P, int mode, hipStream_t st) {

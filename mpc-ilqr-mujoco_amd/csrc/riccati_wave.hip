@@ -19,12 +19,15 @@
 //                                                                  columns 52..54 = Quu[0..15, 16..18]
 //   P5   Quu[0..15, 0..15] = B0^T G0                (13)
 //   P1   W = M A~                                   (208)          row / column 51 of W = A^T Vx / Vx
-//   P3   Q = lxx~ + A~^T W                          (208)          lxx~ = lxx with lx in row and column 51, straight
+//   P3   Q = lxx~ + A~^T W                          (130)          lxx~ = lxx with lx in row and column 51, straight
 //        from HBM into the accumulators; row / column 51 of Q = Qx; rows 52..54 = B_t[:,16..18]^T W =
 //        Qux[16..18, :] (column 51: Qu[16..18] - lu, columns 52..54: Quu[16..18, 16..18]) for free
 //   --   Quu -> LDS (1.5 KB), Cholesky + L^-1 on the same wave (row of Quu / column of L^-1 per lane)
-//   P6a  Y = L^-1 Qux~ (40), P6b [K | k] = -L^-T Y (40, straight to HBM), P7 M <- Q - Y^T Y (80)
-// 693 MFMA per knot (732 in the four-wave kernel), ~400 live registers at the peak (one wave per SIMD).
+//   P6a  Y = L^-1 Qux~ (40), P6b [K | k] = -L^-T Y (24: rows 16..18 only need k >= 16; straight to HBM),
+//   P7   M <- Q - Y^T Y (50, tiles I >= J)
+// 569 MFMA per knot with P3 / P7 on the lower tiles only (732 in the four-wave kernel); 429 in the folded variant
+// (template parameter FOLD, see fold_rows below) that the analytic Jacobians select.  ~400 live registers at the peak
+// (one wave per SIMD).
 // LDS holds Quu, L^-1 in the two operand layouts and the scratch of the indefinite-Quu fallback only.
 #include <hip/hip_runtime.h>
 
@@ -72,6 +75,38 @@ __device__ __forceinline__ double wbcast(double x, int lane) {
   const int hi = __builtin_amdgcn_readlane(__double2hiint(x), lane);
   return __hiloint2double(hi, lo);
 }
+
+// Folded knots (template parameter FOLD of the kernel).  The semi-implicit Euler step makes the hinge-position rows of the
+// analytic Jacobians exact copies of the hinge-velocity rows: A_t[7 + j][:] = e_(7+j)^T + h A_t[32 + j][:] and
+// B_t[7 + j][:] = h B_t[32 + j][:] (h1_linearize_dev.h lin_column).  For the sixteen rows k = 8..23 -- k-steps 2..5 of
+// every product that contracts over the rows of A~ or B_t -- the contribution  X[:, k] A~[k][:]  is therefore
+// X[:, k] e_k^T + h X[:, k] A~[k + 25][:]: fold h X[:, k] into X[:, k + 25] once (rows 33..48 of the operand += h * rows
+// 8..23, a rotation by 16 lanes plus a register shift in C layout), add the identity part X[:, 8..23] to columns 8..23
+// of the result, and drop the four k-steps.  140 of the 585 MFMA of a knot go away (P1 64, P3 40, P2 16, P4 16, P5 4)
+// together with 16 of the 51 rows of A_t and of B_t[:, 0..15] that no longer have to be fetched.
+// wrot16: value of lane - 16 (mod 64), i.e. of the same column one lk earlier.
+__device__ __forceinline__ double wrot16(double x, int raddr) {
+  const int lo = __builtin_amdgcn_ds_bpermute(raddr, __double2loint(x));
+  const int hi = __builtin_amdgcn_ds_bpermute(raddr, __double2hiint(x));
+  return __hiloint2double(hi, lo);
+}
+// One column of tiles t0..t3 (rows 0..63 of 16 columns, register r of tile I = row 16 I + 4 r + lk): rows 33..48 += h * rows
+// 8..23.  Row k = 4 s + lk takes row k - 25 = 4 (s - 6) + lk - 1: the lane one lk earlier, register s - 6 (lk >= 1) or,
+// wrapping to lk = 3, register s - 7.
+__device__ __forceinline__ void fold_rows(const v4d& t0, const v4d& t1, v4d& t2, v4d& t3, int lk, int raddr, double h) {
+  const bool top = lk == 3;
+  const double r8 = wrot16(top ? t0[1] : t0[2], raddr);
+  const double r9 = wrot16(top ? t0[2] : t0[3], raddr);
+  const double r10 = wrot16(top ? t0[3] : t1[0], raddr);
+  const double r11 = wrot16(top ? t1[0] : t1[1], raddr);
+  const double r12 = wrot16(t1[1], raddr);
+  t2[0] = (lk >= 1) ? __builtin_fma(h, r8, t2[0]) : t2[0];      // row 32 stays
+  t2[1] = __builtin_fma(h, r9, t2[1]);
+  t2[2] = __builtin_fma(h, r10, t2[2]);
+  t2[3] = __builtin_fma(h, r11, t2[3]);
+  t3[0] = (lk == 0) ? __builtin_fma(h, r12, t3[0]) : t3[0];     // row 48 only
+}
+#define WFOLD_SKIP(s) (FOLD && (s) >= 2 && (s) <= 5)
 
 // Augmented cost Hessian of one knot in C layout: lxx inside, lx in row 51 and column 51, zeros beyond.  Every load is
 // unconditional from an in-range address and masked afterwards (no branches: the 64 loads issue back to back).
@@ -167,6 +202,7 @@ __device__ __forceinline__ int chol_linv(double (&v)[WM], double (&col)[2][64], 
 // (T, 2j) and (T, 2j + 1): lane = (h, lk, p) fetches the pair A~[4 (2j + h) + lk][16 T + 2p .. 2p + 1].  Column tile 3
 // gathers columns 48..50 of A_t (+ one junk double), columns 16..18 of B_t (+ junk); fix_A masks the junk and sets
 // the unit entry.  Row 51 does not exist in A_t: those lanes fetch row 50 and are masked as well.
+template <bool FOLD>
 __device__ __forceinline__ void stage_A(WaveLds& L, const double* Ap, const double* Bp, int lane) {
   typedef const __attribute__((address_space(1))) void* gptr;
   typedef __attribute__((address_space(3))) void* lptr;
@@ -185,20 +221,23 @@ __device__ __forceinline__ void stage_A(WaveLds& L, const double* Ap, const doub
   for (int T = 0; T < 3; ++T) {
 #pragma unroll
     for (int j = 0; j < 6; ++j)
-      __builtin_amdgcn_global_load_lds((gptr)(b012 + 8 * j * WN + 16 * T), (lptr)&L.Aop[(T * 13 + 2 * j) * 64], 16, 0, 0);
+      if (!(FOLD && (j == 1 || j == 2)))     // folded: rows 8..23 are never used
+        __builtin_amdgcn_global_load_lds((gptr)(b012 + 8 * j * WN + 16 * T), (lptr)&L.Aop[(T * 13 + 2 * j) * 64], 16, 0, 0);
     if (lane < 32) __builtin_amdgcn_global_load_lds((gptr)(b012_6 + 16 * T), (lptr)&L.Aop[(T * 13 + 12) * 64], 16, 0, 0);
   }
 #pragma unroll
   for (int j = 0; j < 6; ++j)
-    __builtin_amdgcn_global_load_lds((gptr)(b3 + j * st3), (lptr)&L.Aop[(39 + 2 * j) * 64], 16, 0, 0);
+    if (!(FOLD && (j == 1 || j == 2)))
+      __builtin_amdgcn_global_load_lds((gptr)(b3 + j * st3), (lptr)&L.Aop[(39 + 2 * j) * 64], 16, 0, 0);
   if (lane < 32) __builtin_amdgcn_global_load_lds((gptr)b3_6, (lptr)&L.Aop[(39 + 12) * 64], 16, 0, 0);
 }
 
 // B_t[:, 0..15] in B-operand layout; row 51 does not exist (clamped to row 50, zeroed)
+template <bool FOLD>
 __device__ __forceinline__ void load_b0(double (&b0)[WKS], const double* Bp, int lk, int lr) {
   const unsigned off = (unsigned)(lk * WM + lr);
 #pragma unroll
-  for (int s = 0; s < WKS - 1; ++s) b0[s] = (Bp + 4 * s * WM)[off];
+  for (int s = 0; s < WKS - 1; ++s) if (!WFOLD_SKIP(s)) b0[s] = (Bp + 4 * s * WM)[off];
   const int lkc = lk < 3 ? lk : 2;
   const double v = (Bp + 48 * WM)[(unsigned)(lkc * WM + lr)];
   b0[WKS - 1] = (lk < 3) ? v : 0.0;
@@ -206,11 +245,13 @@ __device__ __forceinline__ void load_b0(double (&b0)[WKS], const double* Bp, int
 
 // After the staged data has landed: zero row 51 (k-step 12, lk = 3) of every column tile, and in column tile 3 keep
 // columns 48..50 (A_t) and 52..54 (B_t[:, 16..18]), set A~[51][51] = 1, zero the rest.
+template <bool FOLD>
 __device__ __forceinline__ void fix_A(WaveLds& L, int lane) {
   const int lr = lane & 15, lk = lane >> 4;
   const bool keep = (lr < 3) || (lr >= 4 && lr < 7);
 #pragma unroll
   for (int s = 0; s < WKS; ++s) {
+    if (WFOLD_SKIP(s)) continue;
     const double v = L.Aop[(39 + s) * 64 + lane];
     double w = keep ? v : 0.0;
     if (s == WKS - 1 && lk == 3) w = (lr == 3) ? 1.0 : 0.0;
@@ -270,7 +311,8 @@ __device__ __forceinline__ void gauss_jordan_inverse(WaveLds& L, int lane) {
   __syncthreads();
 }
 
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) k_backward_wave(DevState S, int mode) {
+template <bool FOLD>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) k_backward_wave(DevState S, int mode, double fh) {
   const int b = blockIdx.x;
   if (mode == MASK_ACTIVE && !S.active[b]) return;
   if (mode == MASK_RETRY && !(S.active[b] && S.need_retry[b])) return;
@@ -289,8 +331,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
   {
     const double* Ap = S.A + ((size_t)b * N + (N - 1)) * n * n;
     const double* Bp = S.Bm + ((size_t)b * N + (N - 1)) * n * m;
-    stage_A(L, Ap, Bp, lane0);
-    load_b0(b0, Bp, lane0 >> 4, lane0 & 15);
+    stage_A<FOLD>(L, Ap, Bp, lane0);
+    load_b0<FOLD>(b0, Bp, lane0 >> 4, lane0 & 15);
   }
 
 #ifdef WAVE_STAMP
@@ -311,7 +353,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 #ifndef WAVE_SKIP_FIX
-    fix_A(L, lane);
+    fix_A<FOLD>(L, lane);
     __syncthreads();
 #endif
 #define AOP(T, s) L.Aop[((T) * 13 + (s)) * 64 + lane]
@@ -324,6 +366,21 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
     const int lkc3 = lk < 3 ? lk : 2;
     const double lu16 = lug[16 + lkc3], luu16 = luug[16 + lkc3];
     WSTAMP(0)
+    // ---- folded: keep the identity part M[:, 8..23] of W for the rows about to change (row tiles 2, 3; rows 52.. of W are
+    // never used), then rows 33..48 of M += h * rows 8..23 for every product that has M on the left (P2, P1)
+    const int raddr = ((lane - 16) & 63) << 2;
+    double wid[2][5];
+    if (FOLD) {
+#pragma unroll
+      for (int J = 0; J < 2; ++J) {
+        const bool in = J == 0 ? lr >= 8 : lr < 8;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) wid[J][r] = in ? M[2][J][r] : 0.0;
+        wid[J][4] = in ? M[3][J][0] : 0.0;
+      }
+#pragma unroll
+      for (int I = 0; I < 4; ++I) fold_rows(M[0][I], M[1][I], M[2][I], M[3][I], lk, raddr, fh);
+    }
     // ---- P2: G0 = M B0 (row 51: B0^T Vx)
     v4d g0[4];
 #pragma unroll
@@ -331,20 +388,39 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
 #pragma unroll
     for (int s = 0; s < WKS; ++s)
 #pragma unroll
-      for (int I = 0; I < 4; ++I) g0[I] = wmfma(M[s >> 2][I][s & 3], b0[s], g0[I]);
+      for (int I = 0; I < 4; ++I) if (!WFOLD_SKIP(s)) g0[I] = wmfma(M[s >> 2][I][s & 3], b0[s], g0[I]);
+    if (FOLD) {
+      // identity part of P4: Qux~[u][k] += G0[k][u] for k = 8..23, the transposes of two tiles of G0 through LDS
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) L.T[q][(4 * r + lk) * WLDT + lr] = g0[q][r];
+      // rows 33..48 of G0 += h * rows 8..23 for the products that contract over its rows (P4, P5)
+      fold_rows(g0[0], g0[1], g0[2], g0[3], lk, raddr, fh);
+      __syncthreads();
+    }
     WSTAMP(1)
     // ---- P4: Qux~[0..15, :] = G0^T A~
     v4d qux0[4];
 #pragma unroll
     for (int J = 0; J < 4; ++J) qux0[J] = (v4d){0.0, 0.0, 0.0, 0.0};
+    if (FOLD) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const double t0 = L.T[0][lr * WLDT + 4 * r + lk], t1 = L.T[1][lr * WLDT + 4 * r + lk];
+        qux0[0][r] = lr >= 8 ? t0 : 0.0;
+        qux0[1][r] = lr < 8 ? t1 : 0.0;
+      }
+    }
 #pragma unroll
     for (int s = 0; s < WKS; ++s)
 #pragma unroll
-      for (int J = 0; J < 4; ++J) qux0[J] = wmfma(g0[s >> 2][s & 3], AOP(J, s), qux0[J]);
+      for (int J = 0; J < 4; ++J) if (!WFOLD_SKIP(s)) qux0[J] = wmfma(g0[s >> 2][s & 3], AOP(J, s), qux0[J]);
     // ---- P5: Quu[0..15, 0..15] = B0^T G0 (two interleaved accumulators)
     v4d quu0 = (v4d){0.0, 0.0, 0.0, 0.0}, quu1 = (v4d){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int s = 0; s < WKS; ++s) {
+      if (WFOLD_SKIP(s)) continue;
       if (s & 1) quu1 = wmfma(b0[s], g0[s >> 2][s & 3], quu1);
       else quu0 = wmfma(b0[s], g0[s >> 2][s & 3], quu0);
     }
@@ -355,17 +431,30 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
     for (int I = 0; I < 4; ++I)
 #pragma unroll
       for (int J = 0; J < 4; ++J) W[I][J] = (v4d){0.0, 0.0, 0.0, 0.0};
+    if (FOLD) {
+      // identity part of P1: W[:, 8..23] starts from M[:, 8..23] (row tiles 0, 1 of M are untouched by the fold)
+#pragma unroll
+      for (int J = 0; J < 2; ++J) {
+        const bool in = J == 0 ? lr >= 8 : lr < 8;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { W[0][J][r] = in ? M[0][J][r] : 0.0; W[1][J][r] = in ? M[1][J][r] : 0.0; W[2][J][r] = wid[J][r]; }
+        W[3][J][0] = wid[J][4];
+      }
+    }
 #pragma unroll
     for (int s = 0; s < WKS; ++s) {
+      if (WFOLD_SKIP(s)) continue;
       const double a3 = AOP(3, s);
 #pragma unroll
       for (int I = 0; I < 4; ++I) W[I][3] = wmfma(M[s >> 2][I][s & 3], a3, W[I][3]);
     }
+    if (FOLD) fold_rows(W[0][3], W[1][3], W[2][3], W[3][3], lk, raddr, fh);
     // ---- P3, tile (3, 3): rows / columns 52..54 = Quu[16..18, 16..18], column 51 = Qu[16..18] - lu (two accumulators)
     {
       v4d q1 = (v4d){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
       for (int s = 0; s < WKS; ++s) {
+        if (WFOLD_SKIP(s)) continue;
         const double a3 = AOP(3, s);
         if (s & 1) q1 = wmfma(a3, W[s >> 2][3][s & 3], q1);
         else Q[3][3] = wmfma(a3, W[s >> 2][3][s & 3], Q[3][3]);
@@ -396,6 +485,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
     // vector ALU (it is not an XDL op), so nothing can be hidden behind it -- the factorisation below simply follows
 #pragma unroll
     for (int s = 0; s < WKS; ++s) {
+      if (WFOLD_SKIP(s)) continue;
       double aj[3];
 #pragma unroll
       for (int J = 0; J < 3; ++J) aj[J] = AOP(J, s);
@@ -404,10 +494,18 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
 #pragma unroll
         for (int J = 0; J < 3; ++J) W[I][J] = wmfma(M[s >> 2][I][s & 3], aj[J], W[I][J]);
     }
+    if (FOLD) {
+      // identity part of P3: rows 8..23 of Q += rows 8..23 of W (as computed), then rows 33..48 of W += h * rows 8..23
+#pragma unroll
+      for (int r = 0; r < 2; ++r) { Q[0][0][2 + r] += W[0][0][2 + r]; Q[1][0][r] += W[1][0][r]; Q[1][1][r] += W[1][1][r]; }
+#pragma unroll
+      for (int J = 0; J < 3; ++J) fold_rows(W[0][J], W[1][J], W[2][J], W[3][J], lk, raddr, fh);
+    }
 #pragma unroll
     for (int s = 0; s < WKS; ++s)
 #pragma unroll
       for (int I = 0; I < 4; ++I) {
+        if (WFOLD_SKIP(s)) continue;
         const double ai = AOP(I, s);
 #pragma unroll
         for (int J = 0; J <= I && J < 3; ++J) Q[I][J] = wmfma(ai, W[s >> 2][J][s & 3], Q[I][J]);
@@ -459,8 +557,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
 #ifndef WAVE_SKIP_STAGE
     if (t > 0) {
       asm volatile("" ::: "memory");
-      stage_A(L, Ag - n * n, Bg - n * m, lane);
-      load_b0(b0, Bg - n * m, lk, lr);
+      stage_A<FOLD>(L, Ag - n * n, Bg - n * m, lane);
+      load_b0<FOLD>(b0, Bg - n * m, lk, lr);
     }
 #endif
     {
@@ -502,7 +600,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
           for (int J = 0; J < 4; ++J) {
             const double yb = y[s >> 2][J][s & 3];
             kk[0][J] = wmfma(lb0, yb, kk[0][J]);
-            kk[1][J] = wmfma(lb1, yb, kk[1][J]);
+            if (s == 4) kk[1][J] = wmfma(lb1, yb, kk[1][J]);      // Linv is lower triangular: Linv[k][16..18] = 0 for k < 16
           }
         }
       } else {
@@ -596,8 +694,11 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
       }
 }
 
-void launch_backward_wave(const DevState& S, int mode, hipStream_t st) {
-  hipLaunchKernelGGL(k_backward_wave, dim3(S.B), dim3(64), 0, st, S, mode);
+// fold_h: the step size h when A_t, B_t come from the analytic linearisation kernels (their hinge-position rows are then
+// exactly e_k + h * the hinge-velocity rows, see fold_rows), 0 for Jacobians of any other origin (generic kernel)
+void launch_backward_wave(const DevState& S, int mode, hipStream_t st, double fold_h) {
+  if (fold_h != 0.0) hipLaunchKernelGGL(k_backward_wave<true>, dim3(S.B), dim3(64), 0, st, S, mode, fold_h);
+  else hipLaunchKernelGGL(k_backward_wave<false>, dim3(S.B), dim3(64), 0, st, S, mode, 0.0);
 }
 
 }  // namespace ilqr

@@ -129,6 +129,60 @@ def test_backward_kernels_vs_numpy_golden_and_indefinite_fallback(backward):
         s.close()
 
 
+def _riccati_numpy(A, Bm, lx, lu, lxx, luu, lam):
+    """ilqr.cpp:250-309 for one rollout (positive definite Quu: no bump)."""
+    N, n, m = A.shape[0], A.shape[1], Bm.shape[2]
+    Vx, Vxx = lx[N].copy(), lxx[N].copy()
+    K, k = np.zeros((N, m, n)), np.zeros((N, m))
+    for t in range(N - 1, -1, -1):
+        Qx = lx[t] + A[t].T @ Vx; Qu = lu[t] + Bm[t].T @ Vx
+        Qxx = lxx[t] + A[t].T @ Vxx @ A[t]; Quu = np.diag(luu[t]) + Bm[t].T @ Vxx @ Bm[t] + lam * np.eye(m); Qxu = A[t].T @ Vxx @ Bm[t]
+        if np.linalg.eigvalsh(Quu).min() <= 0:
+            Quu = Quu + 1e-4 * np.eye(m)
+        K[t] = -np.linalg.solve(Quu, Qxu.T); k[t] = -np.linalg.solve(Quu, Qu)
+        Vx = Qx + K[t].T @ Quu @ k[t] + K[t].T @ Qu + Qxu @ k[t]
+        Vxx = Qxx + K[t].T @ Quu @ K[t] + K[t].T @ Qxu.T + Qxu @ K[t]; Vxx = 0.5 * (Vxx + Vxx.T)
+    return K, k, Vx, Vxx
+
+
+@pytest.mark.parametrize("contact", [0, 2])
+def test_folded_backward_pass_equals_generic_kernel_and_numpy(contact):
+    """The one-wave Riccati kernel drops the k-steps of the hinge-position rows when the Jacobians come from the analytic
+    linearisation (riccati_wave.hip fold_rows: A[7+j] = e + h A[32+j], B[7+j] = h B[32+j]).  Same Jacobians and quadratics
+    through the folded kernel, the generic kernel (ILQR_BACKWARD=wave-generic) and NumPy; then with an indefinite Quu, where
+    the folded products feed the Gauss-Jordan fallback."""
+    B = 3
+    prob, x0, ui = standing(B, seed=17, gravity=[0.0, 0.0, -9.81] if contact else None)
+    s = _solver(B); s.set_problem(prob); s.set_contact_mode(contact); s.set_options(jacobian_mode=0); s.set_regularization(1e-6)
+    s.initialize(x0, ui)
+    s.stage_linearize(); s.stage_cost_quadratics()
+    A, Bm = s.linearization()
+    # the structure the fold relies on: exact off the diagonal, one rounding of 1 + h a on it (the kernel may fuse it)
+    h = prob["dt"]
+    for j in range(19):
+        e = np.zeros(51); e[7 + j] = 1.0
+        assert np.abs(A[:, :, 7 + j, :] - (e + h * A[:, :, 32 + j, :])).max() <= 2.3e-16 and np.array_equal(Bm[:, :, 7 + j, :], h * Bm[:, :, 32 + j, :])
+    lx, lu, lxx, luu = s.quadratics()
+    for indefinite in (False, True):
+        if indefinite:
+            luu = luu.copy(); luu[:, 7, 3] = -4e4; luu[:, 20, 11] = -2.5e4
+            s.set_quadratics(lx, lu, lxx, luu)
+        out = {}
+        for kind in ("wave", "wave-generic"):
+            with env(ILQR_BACKWARD=kind):
+                s.stage_backward_pass()
+                out[kind] = (s.gains_K(), s.gains_kff()) + tuple(s.value_function())
+        tol = 1e-6 if indefinite else 1e-9
+        for got, want in zip(out["wave"], out["wave-generic"]):
+            assert rel(got, want) < tol, (contact, indefinite, rel(got, want))
+        assert any(not np.array_equal(g, w) for g, w in zip(out["wave"], out["wave-generic"]))     # two different kernels did run
+        for b in range(B):
+            ref = _riccati_numpy(A[b], Bm[b], lx[b], lu[b], lxx[b], luu[b], 1e-6)
+            for got, want in zip(out["wave"], ref):
+                assert rel(got[b], want) < 10 * tol, (contact, indefinite, b, rel(got[b], want))
+    s.close()
+
+
 @pytest.mark.parametrize("ls", ["s", "r"])
 def test_line_search_variants_match_oracle(ls):
     prob, x0, ui = standing(3, seed=4)
