@@ -156,22 +156,23 @@ __device__ __forceinline__ double scale_rsqrt(double v, double x) {
 // v_readlane; the rest of the column goes through LDS (published by the row lanes, read back by every lane at
 // wave-uniform addresses, one 16-byte broadcast read per two entries) and feeds the bulk of the updates, which are
 // pinned in right-looking order so that they fill the gaps of the chain instead of extending it.
-__device__ __forceinline__ int chol_linv(double (&v)[WM], double (&col)[2][64], int lane) {
-  int fail = 0;
+struct CholSweep {
+  int fail;
   double vj, c1;
-  {
+  double c[WM];
+  __device__ __forceinline__ void begin(double (&v)[WM], double (&col)[2][64], int lane) {
+    fail = 0;
     const double piv = wbcast(v[0], 0);
     if (!(piv > 0.0)) fail = 1;
     vj = scale_rsqrt(v[0], piv > 0.0 ? piv : 1.0);
     v[0] = vj;
     col[0][lane] = vj;   // every lane stores (no exec change); entries 0..18 are the column of L
     c1 = wbcast(vj, 1);
+#pragma unroll
+    for (int k = 2; k < WM; ++k) c[k] = col[0][k];
   }
-  double c[WM];
-#pragma unroll
-  for (int k = 2; k < WM; ++k) c[k] = col[0][k];
-#pragma unroll
-  for (int j = 0; j < WM - 1; ++j) {
+  // step j = 0..17 (compile-time constant after unrolling)
+  __device__ __forceinline__ void step(int j, double (&v)[WM], double (&col)[2][64], int lane) {
     // critical chain: finish register j + 1, pivot, scale, publish, broadcast the entry the next step starts with
     v[j + 1] = __builtin_fma(-vj, c1, v[j + 1]);
     const double piv = wbcast(v[j + 1], j + 1);
@@ -194,7 +195,13 @@ __device__ __forceinline__ int chol_linv(double (&v)[WM], double (&col)[2][64], 
     vj = vn;
     c1 = c1n;
   }
-  return fail;
+};
+__device__ __forceinline__ int chol_linv(double (&v)[WM], double (&col)[2][64], int lane) {
+  CholSweep cs;
+  cs.begin(v, col, lane);
+#pragma unroll
+  for (int j = 0; j < WM - 1; ++j) cs.step(j, v, col, lane);
+  return cs.fail;
 }
 
 // HBM -> LDS staging of A~ of one knot without passing through registers (global_load_lds_dwordx4: every lane
@@ -501,27 +508,103 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
 #pragma unroll
       for (int J = 0; J < 3; ++J) fold_rows(W[0][J], W[1][J], W[2][J], W[3][J], lk, raddr, fh);
     }
+    // The factorisation of Quu (below) is a latency chain of 18 short steps on the same wave (pivot broadcast, rsqrt, scale,
+    // column through LDS); Quu has been in LDS since before P1, so the sweep is woven into the MFMA of the rest of P3: the
+    // 9 products of a k-step form a flat list, and every point of the sweep where the next instruction would wait (after
+    // the rsqrt, after the column has been published and requested back, after the bulk update) is followed by the next
+    // one or two of them.  Scheduling fences keep the compiler from regrouping either stream.
+    int fail = 0;
+    double v[WM];
+    const int xl = lane - 32;
+#ifndef WAVE_NO_INTERLEAVE
+    {
+      constexpr int NS = FOLD ? 9 : WKS, NMF = 9 * NS;
+#define WACT(si) (FOLD ? ((si) < 2 ? (si) : (si) + 4) : (si))
+#define WFENCE __builtin_amdgcn_sched_barrier(0)
+      double ai[4], an[4];
 #pragma unroll
-    for (int s = 0; s < WKS; ++s)
+      for (int I = 0; I < 4; ++I) an[I] = AOP(I, WACT(0));
+      int nm = 0;
+      auto mf = [&]() {
+        if (nm < NMF) {
+          const int si = nm / 9, q = nm % 9, ks = WACT(si);
+          if (q == 0) {
+#pragma unroll
+            for (int I = 0; I < 4; ++I) ai[I] = an[I];
+            if (si + 1 < NS) {
+#pragma unroll
+              for (int I = 0; I < 4; ++I) an[I] = AOP(I, WACT(si + 1));
+            }
+          }
+          const int I = q < 1 ? 0 : q < 3 ? 1 : q < 6 ? 2 : 3, J = q - (I == 0 ? 0 : I == 1 ? 1 : I == 2 ? 3 : 6);
+          Q[I][J] = wmfma(ai[I], W[ks >> 2][J][ks & 3], Q[I][J]);
+          ++nm;
+        }
+      };
+      CholSweep cs;
+#pragma unroll
+      for (int c = 0; c < WM; ++c) v[c] = (lane < m) ? L.QL[lane * WLDQ + c] : ((c == xl) ? 1.0 : 0.0);
+      WFENCE; mf(); mf(); WFENCE;
+      cs.begin(v, L.col, lane);
+      WFENCE; mf(); mf(); WFENCE;
+#pragma unroll
+      for (int j = 0; j < WM - 1; ++j) {
+        v[j + 1] = __builtin_fma(-cs.vj, cs.c1, v[j + 1]);
+        const double piv = wbcast(v[j + 1], j + 1);
+        if (!(piv > 0.0)) cs.fail = 1;
+        const double x = piv > 0.0 ? piv : 1.0;
+        const double y = __builtin_amdgcn_rsq(x);
+        WFENCE; mf(); WFENCE;
+        const double a = v[j + 1] * y, tt = x * y;
+        const double e = __builtin_fma(-tt, y, 1.0);
+        const double vn = __builtin_fma(0.5 * a, e, a);
+        v[j + 1] = vn;
+        double cn[WM];
+        double c1n = 0.0;
+        if (j + 2 < WM) {
+          L.col[(j + 1) & 1][lane] = vn;
+          c1n = wbcast(vn, j + 2);
+#pragma unroll
+          for (int k = j + 3; k < WM; ++k) cn[k] = L.col[(j + 1) & 1][k];
+        }
+        WFENCE; mf(); mf(); WFENCE;
+#pragma unroll
+        for (int k = j + 2; k < WM; ++k) v[k] = __builtin_fma(-cs.vj, cs.c[k], v[k]);
+#pragma unroll
+        for (int k = j + 3; k < WM; ++k) cs.c[k] = cn[k];
+        cs.vj = vn;
+        cs.c1 = c1n;
+        WFENCE; mf(); if (j & 1) mf(); WFENCE;
+      }
+#pragma unroll
+      for (int r = 0; r < NMF; ++r) mf();
+      fail = cs.fail;
+#undef WACT
+#undef WFENCE
+    }
+#else
+#pragma unroll
+    for (int s = 0; s < WKS; ++s) {
+      if (WFOLD_SKIP(s)) continue;
 #pragma unroll
       for (int I = 0; I < 4; ++I) {
-        if (WFOLD_SKIP(s)) continue;
         const double ai = AOP(I, s);
 #pragma unroll
         for (int J = 0; J <= I && J < 3; ++J) Q[I][J] = wmfma(ai, W[s >> 2][J][s & 3], Q[I][J]);
       }
+    }
+#endif
     WSTAMP(5)
     // ---- right-looking Cholesky Quu = L L^T fused with Linv = L^-1.  Lanes 0..18 hold a row of Quu, lanes 32..50 a
     // column of Linv, in the same 19 registers: step j scales register j by 1 / L[j][j] (-> L[i][j] on the row lanes,
     // Linv[j][c] on the column lanes) and every later register k loses v[j] * L[k][j] (one broadcast, one FMA for
     // both halves; the broadcasts of a step are independent of its FMAs, so they issue back to back).
-    int fail = 0;
     {
-      double v[WM];
-      const int xl = lane - 32;
+#ifdef WAVE_NO_INTERLEAVE
 #pragma unroll
       for (int c = 0; c < WM; ++c) v[c] = (lane < m) ? L.QL[lane * WLDQ + c] : ((c == xl) ? 1.0 : 0.0);
       fail = chol_linv(v, L.col, lane);
+#endif
 #ifndef WAVE_NO_FALLBACK
       if (fail) {
         // ilqr.cpp:278-281: one retry with Quu + 1e-4 I
