@@ -200,7 +200,7 @@ __global__ void __launch_bounds__(64) k_line_search_r(DevState S, ProblemDev P, 
 // rows = consecutive [N+1][51] trajectories in xsrc ([B][8] candidates: cshift = 3, oshift = 0; [B] nominal
 // trajectories: cshift = 0, oshift = 3 -- they use the slots of candidate 0 of their rollout in the knot buffer)
 __global__ void __launch_bounds__(64) k_traj_knot_cost(DevState S, ProblemDev P, int mode, const double* xsrc, const double* usrc, int cshift, int oshift) {
-  __shared__ double xs[64 * CK_LD];
+  __shared__ double xs[32 * CK_LD];     // half a wave's rows at a time: 13 KB, so that the registers (two waves per SIMD), not the LDS, set the occupancy
   const int N = S.N, lane = threadIdx.x;
   const long total = ((long)S.B << cshift) * (N + 1);
   const long first = (long)blockIdx.x * 64;
@@ -213,11 +213,19 @@ __global__ void __launch_bounds__(64) k_traj_knot_cost(DevState S, ProblemDev P,
   if (!__any(act)) return;       // wave-uniform: every rollout this wave touches is unselected
   const long nrow = (first + 64 <= total) ? 64 : (total - first);
   const double* src = xsrc + first * H1_NX;
-  for (int e = lane; e < (int)nrow * H1_NX; e += 64) xs[e] = src[e];
-  __syncthreads();
   double x[H1_NX], u[H1_NU];
 #pragma unroll
-  for (int i = 0; i < H1_NX; ++i) x[i] = xs[(idx < total ? lane : 0) * CK_LD + i];
+  for (int half = 0; half < 2; ++half) {
+    const int r0 = 32 * half, nr = (int)nrow - r0 < 32 ? (int)nrow - r0 : 32;      // rows r0 .. r0 + nr of this wave
+    if (half) __syncthreads();
+    for (int e = lane; e < nr * H1_NX; e += 64) xs[e] = src[r0 * H1_NX + e];
+    __syncthreads();
+    if ((lane >> 5) == half) {
+      const int row = (idx < total ? lane : (int)nrow - 1) - r0;
+#pragma unroll
+      for (int i = 0; i < H1_NX; ++i) x[i] = xs[(row >= 0 ? row : 0) * CK_LD + i];
+    }
+  }
   const double* ug = usrc + (cand * N + (t < N ? t : N - 1)) * H1_NU;
 #pragma unroll
   for (int i = 0; i < H1_NU; ++i) u[i] = ug[i];
