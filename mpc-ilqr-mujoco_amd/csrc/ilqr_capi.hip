@@ -123,6 +123,7 @@ int ilqr_hip_create(ilqr_hip_ctx** out, int device, int batch, int horizon, doub
   A(dalloc(c, &S.J, B)); A(dalloc(c, &S.Jbase, B)); A(dalloc(c, &S.ls_cost, B)); A(dalloc(c, &S.lambda, B));
   A(dalloc(c, &S.active, B)); A(dalloc(c, &S.need_retry, B)); A(dalloc(c, &S.iters, B)); A(dalloc(c, &S.improved, B)); A(dalloc(c, &S.alpha_idx, B));
   A(dalloc(c, &S.trace_cost, B * (c->max_iter + 1))); A(dalloc(c, &S.trace_alpha, B * c->max_iter)); A(dalloc(c, &S.trace_lambda, B * c->max_iter));
+  A(dalloc(c, &S.order, B * 2 * (c->max_iter + 1))); A(dalloc(c, &S.order_n, 2 * (size_t)(c->max_iter + 1)));
   A(dalloc(c, &c->d_tmpx, B * (N + 1) * n)); A(dalloc(c, &c->d_tmpu, B * N * m));
   A(dalloc(c, &c->d_prevx, B * (N + 1) * n)); A(dalloc(c, &c->d_prevu, B * N * m)); A(dalloc(c, &c->d_shadowx, B * (N + 1) * n));
   A(dalloc(c, &c->d_u0, B * m)); A(dalloc(c, &c->d_K0, B * m * n)); A(dalloc(c, &c->d_cost_tmp, B)); A(dalloc(c, &c->d_mismatch, 1));
@@ -161,7 +162,7 @@ int ilqr_hip_destroy(ilqr_hip_ctx* c) {
   enter(c);
   DevState& S = c->S;
   void* ptrs[] = {S.cand_knot, S.lin_dump, S.x0, S.xbar, S.ubar, S.xcand, S.ucand, S.cand_cost, S.A, S.Bm, S.lx, S.lu, S.lxx, S.luu, S.K, S.kff, S.Vx, S.Vxx, S.J, S.Jbase, S.ls_cost,
-                  S.lambda, S.active, S.need_retry, S.iters, S.improved, S.alpha_idx, S.trace_cost, S.trace_alpha, S.trace_lambda, c->d_tmpx, c->d_tmpu,
+                  S.lambda, S.active, S.need_retry, S.iters, S.improved, S.alpha_idx, S.trace_cost, S.trace_alpha, S.trace_lambda, S.order, S.order_n, c->d_tmpx, c->d_tmpu,
                   c->d_prevx, c->d_prevu, c->d_shadowx, c->d_u0, c->d_K0, c->d_cost_tmp, c->d_stepx, c->d_stepu, c->d_stepn, c->d_mismatch, c->d_payload, c->d_xref, c->d_uref, c->d_comref, c->d_eeref, c->d_comvelref, c->d_stance};
   for (void* p : ptrs) if (p) hipFree(p);
   if (c->comm) ilqr_hip_comm_destroy(c);
@@ -245,10 +246,11 @@ int ilqr_hip_set_max_iterations(ilqr_hip_ctx* c, int max_iter) {
   if (!c || max_iter <= 0) return ILQR_ERR_ARG;
   enter(c);
   if (max_iter != c->max_iter) {
-    hipFree(c->S.trace_cost); hipFree(c->S.trace_alpha); hipFree(c->S.trace_lambda);
-    c->S.trace_cost = c->S.trace_alpha = c->S.trace_lambda = nullptr;
+    hipFree(c->S.trace_cost); hipFree(c->S.trace_alpha); hipFree(c->S.trace_lambda); hipFree(c->S.order); hipFree(c->S.order_n);
+    c->S.trace_cost = c->S.trace_alpha = c->S.trace_lambda = nullptr; c->S.order = c->S.order_n = nullptr;
     c->max_iter = max_iter; c->S.max_iter = max_iter;
     TRY(dalloc(c, &c->S.trace_cost, (size_t)c->B * (max_iter + 1))); TRY(dalloc(c, &c->S.trace_alpha, (size_t)c->B * max_iter)); TRY(dalloc(c, &c->S.trace_lambda, (size_t)c->B * max_iter));
+    TRY(dalloc(c, &c->S.order, (size_t)c->B * 2 * (max_iter + 1))); TRY(dalloc(c, &c->S.order_n, 2 * (size_t)(max_iter + 1)));
   }
   return ILQR_OK;
 }
@@ -362,6 +364,7 @@ static DevState slice_state(const DevState& S, size_t b0, int Bs) {
   T.J += b0; T.Jbase += b0; T.ls_cost += b0; T.lambda += b0;
   T.active += b0; T.need_retry += b0; T.iters += b0; T.improved += b0; T.alpha_idx += b0;
   T.trace_cost += b0 * (mi + 1); T.trace_alpha += b0 * mi; T.trace_lambda += b0 * mi;
+  T.order = nullptr; T.order_n = nullptr;      // the compacted lists index the whole batch: not used by slices
   return T;
 }
 static h1::ProblemDev slice_problem(const h1::ProblemDev& P, long b0) {
@@ -419,11 +422,11 @@ static int enqueue_solve(ilqr_hip_ctx* c, const DevState& S, const h1::ProblemDe
     { StageTimer T(c, 1, st); ilqr::launch_linearize(S, P, ilqr::MASK_ACTIVE, c->jac_mode, c->fd_eps, st); }
     HIPCHK(c, hipStreamWaitEvent(st, ev_join, 0));
     if (concurrent_roll) { HIPCHK(c, hipStreamWaitEvent(st, ev_roll, 0)); ilqr::launch_adopt_rollout(S, shadow, ilqr::MASK_ACTIVE, c->d_mismatch, st); }
-    { StageTimer T(c, 3, st); ilqr::launch_backward(S, ilqr::MASK_ACTIVE, st, fold_h); }                                  // :601
+    { StageTimer T(c, 3, st); ilqr::launch_backward(S, ilqr::MASK_ACTIVE, st, fold_h, iter); }                                  // :601
     if (iter == 0 && lead) HIPCHK(c, hipEventRecord(lead, st));
     { StageTimer T(c, 4, st); ilqr::launch_line_search(S, P, ilqr::MASK_ACTIVE, st); }                            // :616
     { StageTimer T(c, 5, st); ilqr::launch_control(S, 0, iter, c->tol, c->early_exit, st); }                      // :619-620,645-655
-    { StageTimer T(c, 6, st); ilqr::launch_backward(S, ilqr::MASK_RETRY, st, fold_h); }                                  // :637
+    { StageTimer T(c, 6, st); ilqr::launch_backward(S, ilqr::MASK_RETRY, st, fold_h, iter); }                                  // :637
     { StageTimer T(c, 7, st); ilqr::launch_line_search(S, P, ilqr::MASK_RETRY, st); }                             // :638
     { StageTimer T(c, 5, st); ilqr::launch_control(S, 1, iter, c->tol, c->early_exit, st); }                      // :640-646
   }

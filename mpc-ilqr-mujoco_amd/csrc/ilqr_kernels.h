@@ -46,13 +46,20 @@ struct DevState {
   double* trace_cost;  // [B][max_iter+1]
   double* trace_alpha; // [B][max_iter]
   double* trace_lambda;// [B][max_iter]
+  // Compacted work lists, rebuilt on the device by k_control (null: not in use, e.g. batch slices): list (it, 0) = rollouts
+  // active at the start of iteration it, list (it, 1) = rollouts that take the lambda retry of iteration it.  A launch whose
+  // blocks are one rollout each (k_backward_wave) takes rollout order[...][blockIdx] for blockIdx < order_n[...]: the selected
+  // rollouts then occupy the FIRST blocks of the grid and spread evenly over the shader engines (workgroups are dealt to them
+  // round-robin by index: with a scattered selection one engine needs an extra 0.5 ms round of the one-wave-per-SIMD kernel).
+  int* order;          // [2 (max_iter + 1)][B]
+  int* order_n;        // [2 (max_iter + 1)]
 };
 
 void launch_rollout(const DevState& S, const h1::ProblemDev& P, int mode, int do_roll, int count_iter, double* cost_out, hipStream_t st);
 void launch_step(int count, const double* x, const double* u, const h1::DynParams& dyn, double* xn, hipStream_t st, int stance_l = 1, int stance_r = 1);
 void launch_linearize(const DevState& S, const h1::ProblemDev& P, int mode, int jac_mode, double eps, hipStream_t st, int phases = 3);
 void launch_cost_quadratics(const DevState& S, const h1::ProblemDev& P, int mode, hipStream_t st);
-void launch_backward(const DevState& S, int mode, hipStream_t st, double fold_h = 0.0);
+void launch_backward(const DevState& S, int mode, hipStream_t st, double fold_h = 0.0, int iter = -1);
 double linearize_fold_h(const h1::ProblemDev& P, int jac_mode);
 void launch_line_search(const DevState& S, const h1::ProblemDev& P, int mode, hipStream_t st);
 void launch_control(const DevState& S, int phase, int iter, double tol, int early_exit, hipStream_t st);
@@ -88,7 +95,7 @@ void launch_last_step_s(const DevState& S, const h1::ProblemDev& P, hipStream_t 
 void launch_linearize_fd_s(const DevState& S, const h1::ProblemDev& P, int mode, double eps, hipStream_t st);
 void launch_backward_mfma(const DevState& S, int mode, hipStream_t st);
 int backward_mfma_set_attr();
-void launch_backward_wave(const DevState& S, int mode, hipStream_t st, double fold_h);
+void launch_backward_wave(const DevState& S, int mode, hipStream_t st, double fold_h, const int* list, const int* count);
 size_t backward_mfma_lds_bytes();
 
 }  // namespace ilqr

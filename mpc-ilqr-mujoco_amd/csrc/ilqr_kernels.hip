@@ -421,21 +421,25 @@ __global__ void __launch_bounds__(64) k_line_search(DevState S, ProblemDev P, in
 }
 
 // ------------------------------------------------------------------ K6: iteration control
-// one wave per rollout: lane 0 decides (ilqr.cpp:619-655), all lanes copy the accepted candidate.
+// one wave per rollout, 16 rollouts per workgroup: lane 0 decides (ilqr.cpp:619-655), all lanes copy the accepted candidate.
 // phase 0: after the first line search of an iteration; phase 1: after the retry line search;
 // phase 2: stage API (report only, accept if improved, no lambda / activity bookkeeping).
-__global__ void __launch_bounds__(64) k_control(DevState S, int phase, int iter, double tol, int early_exit) {
-  const int b = blockIdx.x, lane = threadIdx.x;
-  __shared__ int s_accept;
+#define CTRL_WAVES 16
+__global__ void __launch_bounds__(64 * CTRL_WAVES) k_control(DevState S, int phase, int iter, double tol, int early_exit) {
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int b = blockIdx.x * CTRL_WAVES + wv;
+  __shared__ int s_accept[CTRL_WAVES], s_slot[CTRL_WAVES], s_base[2];
   const int N = S.N;
-  if (phase == 0 && !S.active[b]) return;
-  if (phase == 1 && !(S.active[b] && S.need_retry[b])) return;
-  if (lane == 0) {
+  bool run = b < S.B;
+  if (run && phase == 0 && !S.active[b]) run = false;
+  if (run && phase == 1 && !(S.active[b] && S.need_retry[b])) run = false;
+  if (lane == 0) { s_accept[wv] = -1; s_slot[wv] = -1; }
+  if (run && lane == 0) {
     if (phase == 0) S.iters[b] += 1;
     const double base = S.Jbase[b];
     int acc = -1;
     for (int a = 0; a < 8; ++a) { const double c = S.cand_cost[(size_t)b * 8 + a]; if (c < base - 1e-6) { acc = a; break; } }
-    s_accept = acc;
+    s_accept[wv] = acc;
     S.improved[b] = acc >= 0;
     S.alpha_idx[b] = acc;
     if (phase == 2) {
@@ -464,10 +468,33 @@ __global__ void __launch_bounds__(64) k_control(DevState S, int phase, int iter,
         S.trace_lambda[(size_t)b * S.max_iter + tr] = lam_used;
         if (early_exit && iter > 1) S.active[b] = 0;
       }
+      // compacted work lists (DevState::order): this rollout goes into the retry pass of this iteration (kind 1) or, its
+      // iteration being over, among the rollouts still active in the next one (kind 0)
+      if (S.order) {
+        const int retry = phase == 0 && S.need_retry[b];
+        if (retry || S.active[b]) s_slot[wv] = retry ? 1 : 0;
+      }
     }
   }
   __syncthreads();
-  const int acc = s_accept;
+  if (S.order && phase != 2) {
+    // one atomic per list and workgroup (16 rollouts), positions within the workgroup in rollout order
+    if (threadIdx.x < 2) {
+      int cnt = 0;
+      for (int w = 0; w < CTRL_WAVES; ++w) cnt += s_slot[w] == (int)threadIdx.x;
+      const int slot = threadIdx.x ? 2 * iter + 1 : 2 * (iter + 1);
+      s_base[threadIdx.x] = cnt ? atomicAdd(&S.order_n[slot], cnt) : 0;
+    }
+    __syncthreads();
+    if (lane == 0 && s_slot[wv] >= 0) {
+      const int kind = s_slot[wv];
+      int pos = s_base[kind];
+      for (int w = 0; w < wv; ++w) pos += s_slot[w] == kind;
+      const int slot = kind ? 2 * iter + 1 : 2 * (iter + 1);
+      S.order[(size_t)slot * S.B + pos] = b;
+    }
+  }
+  const int acc = s_accept[wv];
   if (acc < 0) return;
   const double* xc = S.xcand + ((size_t)b * 8 + acc) * (N + 1) * H1_NX;
   const double* uc = S.ucand + ((size_t)b * 8 + acc) * N * H1_NU;
@@ -482,6 +509,10 @@ __global__ void k_solve_begin(DevState S) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= S.B) return;
   S.active[b] = 1; S.need_retry[b] = 0; S.iters[b] = 0;
+  if (S.order) {       // iteration 0: every rollout, in order; the other lists are filled by k_control
+    S.order[b] = b;
+    if (b == 0) { S.order_n[0] = S.B; for (int i = 1; i < 2 * (S.max_iter + 1); ++i) S.order_n[i] = 0; }
+  }
   const double J0 = S.Jbase[b];
   S.J[b] = J0;
   for (int i = 0; i <= S.max_iter; ++i) S.trace_cost[(size_t)b * (S.max_iter + 1) + i] = (i == 0) ? J0 : __builtin_nan("");
@@ -630,10 +661,14 @@ double linearize_fold_h(const ProblemDev& P, int jac_mode) {
 }
 // ILQR_BACKWARD=valu selects the LDS + VALU kernel (kept as an on-device cross-check), =wg the four-wave MFMA
 // kernel (riccati_mfma.hip), =wave the one-wave-per-rollout MFMA kernel (riccati_wave.hip)
-void launch_backward(const DevState& S, int mode, hipStream_t st, double fold_h) {
+void launch_backward(const DevState& S, int mode, hipStream_t st, double fold_h, int iter) {
   const int kind = backward_kind();
   if (kind == 1) hipLaunchKernelGGL(k_backward, dim3(S.B), dim3(256), backward_lds_bytes(), st, S, mode);
-  else if (kind == 2) launch_backward_wave(S, mode, st, g_var.fold ? fold_h : 0.0);
+  else if (kind == 2) {
+    // inside a solve (iter >= 0) the selected rollouts come from the compacted list of this pass
+    const int slot = (S.order && iter >= 0 && mode != MASK_ALL) ? 2 * iter + (mode == MASK_RETRY ? 1 : 0) : -1;
+    launch_backward_wave(S, mode, st, g_var.fold ? fold_h : 0.0, slot >= 0 ? S.order + (size_t)slot * S.B : nullptr, slot >= 0 ? S.order_n + slot : nullptr);
+  }
   else launch_backward_mfma(S, mode, st);
 }
 void launch_line_search(const DevState& S, const ProblemDev& P, int mode, hipStream_t st) {
@@ -645,7 +680,7 @@ void launch_line_search(const DevState& S, const ProblemDev& P, int mode, hipStr
   hipLaunchKernelGGL(k_line_search, dim3(cdiv((long)S.B * 8, 64)), dim3(64), 0, st, S, P, mode);
 }
 void launch_control(const DevState& S, int phase, int iter, double tol, int early_exit, hipStream_t st) {
-  hipLaunchKernelGGL(k_control, dim3(S.B), dim3(64), 0, st, S, phase, iter, tol, early_exit);
+  hipLaunchKernelGGL(k_control, dim3(cdiv(S.B, CTRL_WAVES)), dim3(64 * CTRL_WAVES), 0, st, S, phase, iter, tol, early_exit);
 }
 void launch_solve_begin(const DevState& S, hipStream_t st) { hipLaunchKernelGGL(k_solve_begin, dim3(cdiv(S.B, 64)), dim3(64), 0, st, S); }
 void launch_adopt_rollout(const DevState& S, const double* shadow, int mode, unsigned long long* mismatches, hipStream_t st) { hipLaunchKernelGGL(k_adopt_rollout, dim3(S.B), dim3(64), 0, st, S, shadow, mode, mismatches); }

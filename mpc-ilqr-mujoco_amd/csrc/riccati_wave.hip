@@ -319,10 +319,15 @@ __device__ __forceinline__ void gauss_jordan_inverse(WaveLds& L, int lane) {
 }
 
 template <bool FOLD>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) k_backward_wave(DevState S, int mode, double fh) {
-  const int b = blockIdx.x;
-  if (mode == MASK_ACTIVE && !S.active[b]) return;
-  if (mode == MASK_RETRY && !(S.active[b] && S.need_retry[b])) return;
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) k_backward_wave(DevState S, int mode, double fh, const int* list, const int* count) {
+  int b = blockIdx.x;
+  if (list) {                       // compacted selection (DevState::order): the first *count blocks take the listed rollouts
+    if (b >= *count) return;
+    b = list[b];
+  } else {
+    if (mode == MASK_ACTIVE && !S.active[b]) return;
+    if (mode == MASK_RETRY && !(S.active[b] && S.need_retry[b])) return;
+  }
   __shared__ WaveLds L;
   const int lane0 = threadIdx.x;
   const int N = S.N;
@@ -779,9 +784,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
 
 // fold_h: the step size h when A_t, B_t come from the analytic linearisation kernels (their hinge-position rows are then
 // exactly e_k + h * the hinge-velocity rows, see fold_rows), 0 for Jacobians of any other origin (generic kernel)
-void launch_backward_wave(const DevState& S, int mode, hipStream_t st, double fold_h) {
-  if (fold_h != 0.0) hipLaunchKernelGGL(k_backward_wave<true>, dim3(S.B), dim3(64), 0, st, S, mode, fold_h);
-  else hipLaunchKernelGGL(k_backward_wave<false>, dim3(S.B), dim3(64), 0, st, S, mode, 0.0);
+void launch_backward_wave(const DevState& S, int mode, hipStream_t st, double fold_h, const int* list, const int* count) {
+  if (fold_h != 0.0) hipLaunchKernelGGL(k_backward_wave<true>, dim3(S.B), dim3(64), 0, st, S, mode, fold_h, list, count);
+  else hipLaunchKernelGGL(k_backward_wave<false>, dim3(S.B), dim3(64), 0, st, S, mode, 0.0, list, count);
 }
 
 }  // namespace ilqr

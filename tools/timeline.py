@@ -32,3 +32,23 @@ for r in rows[lo:hi]:
     else: busy += cur_e - cur_s; cur_s, cur_e = s, e
 busy += cur_e - cur_s
 print("iteration span %.1f us, union of kernel time %.1f us, idle %.1f us" % ((last_end - t0) / 1e3, busy / 1e3, (last_end - t0 - busy) / 1e3))
+if len(sys.argv) > 3 and sys.argv[3] == "all":
+    # one line per iteration: span and the duration of each full-batch kernel in it
+    print()
+    print("%4s %9s  %s" % ("iter", "span_us", "kernel durations (us)"))
+    for k in range(len(marks) - 1):
+        lo, hi = marks[k], marks[k + 1]
+        while lo > 0 and "k_control" not in rows[lo - 1]["Kernel_Name"] and "k_solve_begin" not in rows[lo - 1]["Kernel_Name"]:
+            lo -= 1
+        while hi > lo and "k_control" not in rows[hi - 1]["Kernel_Name"]:
+            hi -= 1
+        seg = rows[lo:hi]
+        if not seg:
+            continue
+        a, b = int(seg[0]["Start_Timestamp"]), max(int(r["End_Timestamp"]) for r in seg)
+        parts = []
+        for r in seg:
+            nm = r["Kernel_Name"].replace("void ", "").replace("ilqr::", "").split("(")[0].split("<")[0]
+            if nm in ("k_lin_primal_r", "k_lin_tangent", "k_cost_quadratics", "k_backward_wave", "k_line_search_s", "k_rollout_s"):
+                parts.append("%s %.0f" % (nm[2:9], (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3))
+        print("%4d %9.1f  %s" % (k, (b - a) / 1e3, "  ".join(parts)))
