@@ -72,12 +72,16 @@ DEVFN void load_half_u(bool side, const double* u, h1s::HalfU& o) {
   for (int k = 0; k < 4; ++k) o.uA[k] = u[h1s::jarm(side, k)];
 }
 template <bool CONTACT>
-__global__ void __launch_bounds__(64) k_line_search_s(DevState S, ProblemDev P, int mode) {
+__global__ void __launch_bounds__(64) k_line_search_s(DevState S, ProblemDev P, int mode, const int* list, const int* count) {
   extern __shared__ double lds[];
   const int gid = blockIdx.x * blockDim.x + threadIdx.x;
-  const int b = gid >> 4, ai = (gid >> 1) & 7;
+  const int ai = (gid >> 1) & 7;
   const bool side = (gid & 1) != 0;
-  if (b >= S.B || !sel_s(S, b, mode)) return;
+  int b = gid >> 4;
+  if (list) {                          // compacted selection (DevState::order): the selected rollouts fill the first waves
+    if (b >= *count) return;
+    b = list[b];
+  } else if (b >= S.B || !sel_s(S, b, mode)) return;
   const int lane = threadIdx.x, grp = lane & ~15, c16 = lane & 15, col = lane & ~1;
   const h1s::LaneLds L{lds, 64, lane};
   const int N = S.N, n = H1_NX, m = H1_NU;
@@ -329,9 +333,9 @@ int dyn_split_kernels_set_attr() {
   rc |= hipFuncSetAttribute((const void*)k_fd_steps_s, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DYN_LDS_BYTES_S) != hipSuccess;
   return rc;
 }
-void launch_line_search_s(const DevState& S, const ProblemDev& P, int mode, hipStream_t st) {
-  if (P.dyn.contact) hipLaunchKernelGGL(k_line_search_s<true>, dim3(cdiv_s((long)S.B * 16, 64)), dim3(64), DYN_LDS_BYTES_S, st, S, P, mode);
-  else hipLaunchKernelGGL(k_line_search_s<false>, dim3(cdiv_s((long)S.B * 16, 64)), dim3(64), DYN_LDS_BYTES_S, st, S, P, mode);
+void launch_line_search_s(const DevState& S, const ProblemDev& P, int mode, hipStream_t st, const int* list, const int* count) {
+  if (P.dyn.contact) hipLaunchKernelGGL(k_line_search_s<true>, dim3(cdiv_s((long)S.B * 16, 64)), dim3(64), DYN_LDS_BYTES_S, st, S, P, mode, list, count);
+  else hipLaunchKernelGGL(k_line_search_s<false>, dim3(cdiv_s((long)S.B * 16, 64)), dim3(64), DYN_LDS_BYTES_S, st, S, P, mode, list, count);
 }
 void launch_step_s(int count, const double* x, const double* u, const DynParams& dyn, double* xn, hipStream_t st, int stance_l, int stance_r) {
   hipLaunchKernelGGL(k_step_s, dim3(cdiv_s((long)count * 2, 64)), dim3(64), DYN_LDS_BYTES_S, st, count, x, u, dyn, xn, stance_l, stance_r);

@@ -671,9 +671,13 @@ void launch_backward(const DevState& S, int mode, hipStream_t st, double fold_h,
   }
   else launch_backward_mfma(S, mode, st);
 }
-void launch_line_search(const DevState& S, const ProblemDev& P, int mode, hipStream_t st) {
+void launch_line_search(const DevState& S, const ProblemDev& P, int mode, hipStream_t st, int iter) {
   if (!use_scalar_dyn()) {
-    if (g_var.ls_split || P.dyn.contact) { launch_line_search_s(S, P, mode, st); launch_cand_costs(S, P, mode, st); }   // candidates' costs: all knots in parallel
+    if (g_var.ls_split || P.dyn.contact) {
+      const int slot = (S.order && iter >= 0 && mode != MASK_ALL) ? 2 * iter + (mode == MASK_RETRY ? 1 : 0) : -1;      // as launch_backward
+      launch_line_search_s(S, P, mode, st, slot >= 0 ? S.order + (size_t)slot * S.B : nullptr, slot >= 0 ? S.order_n + slot : nullptr);
+      launch_cand_costs(S, P, mode, st);
+    }   // candidates' costs: all knots in parallel
     else launch_line_search_r(S, P, mode, st);                                                  // (the one-lane kernel sums its own)
     return;
   }
