@@ -179,6 +179,11 @@ int ilqr_hip_enable_profiling(ilqr_hip_ctx* ctx, int on);
    differed bit-wise from the one the linearisation saw.  0 means the launch order is equivalent to the reference's. */
 int ilqr_hip_get_adopt_mismatches(ilqr_hip_ctx* ctx, unsigned long long* count);
 int ilqr_hip_get_stage_ms(ilqr_hip_ctx* ctx, double* ms /*[8]*/, double* launches /*[8]*/);
+/* Iterations whose kernels the last solve enqueued: max_iterations, or fewer when the convergence exit (ilqr.cpp:645-655,
+   ilqr_hip_set_options early_exit) is on and every rollout of the batch had left the loop -- the host follows the device-side
+   count of active rollouts one iteration behind and stops launching (environment ILQR_EE_GATE=0 turns that off).
+   Returns the count, or -1 for a null handle. */
+int ilqr_hip_get_iterations_enqueued(const ilqr_hip_ctx* ctx);
 
 /* ---- host-side model helpers (no GPU needed) ---- */
 /* reference construction as RobotUtils::loadReferences does it (src/common/robot_utils.cpp:369-403):

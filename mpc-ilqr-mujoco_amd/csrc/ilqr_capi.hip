@@ -48,6 +48,11 @@ struct ilqr_hip_ctx {
   double fd_eps = 1e-5;
   int early_exit = 1;
   bool initialized = false, refs_set = false;
+  // early-exit gate: the number of rollouts still active after each iteration travels to this pinned array behind the
+  // iteration; the host stays one iteration ahead of the device and stops enqueuing once the batch has converged
+  int* h_active = nullptr;
+  std::vector<hipEvent_t> ev_active;
+  int iterations_enqueued = 0;
   double lin_fold_h = 0.0;   // step size h while S.A / S.Bm hold the analytic Jacobians (folded backward kernel), else 0
   std::string err;
   // profiling
@@ -167,6 +172,8 @@ int ilqr_hip_destroy(ilqr_hip_ctx* c) {
   for (void* p : ptrs) if (p) hipFree(p);
   if (c->comm) ilqr_hip_comm_destroy(c);
   for (hipEvent_t e : c->pool) hipEventDestroy(e);
+  for (hipEvent_t e : c->ev_active) hipEventDestroy(e);
+  if (c->h_active) (void)hipHostFree(c->h_active);
   for (auto& sl : c->slices) { hipEventDestroy(sl.fork); hipEventDestroy(sl.join); hipEventDestroy(sl.done); hipEventDestroy(sl.lead); hipEventDestroy(sl.roll); hipStreamDestroy(sl.st3); hipStreamDestroy(sl.st2); hipStreamDestroy(sl.st); }
   if (c->ev_begin) hipEventDestroy(c->ev_begin);
   if (c->ev_fork) hipEventDestroy(c->ev_fork);
@@ -388,13 +395,32 @@ static int ensure_slices(ilqr_hip_ctx* c, int k) {
 // the launch sequence of iLQR::solve (ilqr.cpp:521-660) for one slice on its streams; `wait_lead` (optional) delays the
 // first throughput-bound stage until the previous slice has finished its first backward pass, `lead` is recorded there
 static int overlap_rollout() { const char* e = getenv("ILQR_OVERLAP_ROLLOUT"); return e ? atoi(e) : 1; }
+static int early_exit_gate() { const char* e = getenv("ILQR_EE_GATE"); return e ? atoi(e) : 1; }
+static int ensure_gate(ilqr_hip_ctx* c) {
+  if ((int)c->ev_active.size() >= c->max_iter + 2 && c->h_active) return ILQR_OK;
+  if (c->h_active) { (void)hipHostFree(c->h_active); c->h_active = nullptr; }
+  HIPCHK(c, hipHostMalloc((void**)&c->h_active, sizeof(int) * (size_t)(c->max_iter + 2), hipHostMallocDefault));
+  while ((int)c->ev_active.size() < c->max_iter + 2) { hipEvent_t e; HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming)); c->ev_active.push_back(e); }
+  return ILQR_OK;
+}
 static int enqueue_solve(ilqr_hip_ctx* c, const DevState& S, const h1::ProblemDev& P, hipStream_t st, hipStream_t st2, hipStream_t st3,
                          hipEvent_t ev_fork, hipEvent_t ev_join, hipEvent_t ev_roll, const double* shadow_base, hipEvent_t wait_lead, hipEvent_t lead) {
   // shadow target of the concurrent re-rollout: same rollouts as S.xbar, in the shadow buffer
   double* shadow = const_cast<double*>(shadow_base) + (S.xbar - c->S.xbar);
   const double fold_h = ilqr::linearize_fold_h(P, c->jac_mode);
   { StageTimer T(c, 0, st); ilqr::launch_rollout(S, P, ilqr::MASK_ALL, 0, 0, S.Jbase, st); ilqr::launch_solve_begin(S, st); }  // ilqr.cpp:540
+  // With the convergence exit on, the launches of an iteration nobody needs are pure latency (17 launches that find nothing to
+  // do): the count of rollouts active after iteration i (DevState::order_n, maintained by k_control) follows iteration i to the
+  // host, which enqueues iteration i only after it has seen the count left by iteration i - 2 -- one full iteration stays
+  // queued on the device meanwhile, so the device never waits for the host.  (ILQR_EE_GATE=0: always enqueue max_iter.)
+  const bool gate = c->early_exit && S.order && early_exit_gate();
+  if (gate) TRY(ensure_gate(c));
+  c->iterations_enqueued = c->max_iter;
   for (int iter = 0; iter < c->max_iter; ++iter) {
+    if (gate && iter >= 2) {
+      HIPCHK(c, hipEventSynchronize(c->ev_active[iter - 2]));
+      if (c->h_active[iter - 1] == 0) { c->iterations_enqueued = iter; break; }     // nobody was active in iteration iter - 1
+    }
     // :551,563 nominal rollout at the top of every iteration, as the reference does.  From the second iteration on the
     // nominal trajectory is the candidate the line search accepted (or the unchanged previous one), so the re-rollout
     // only reproduces it; ILQR_REUSE_ROLLOUT=1 skips it (not the default: the headline metric counts the rollout
@@ -429,6 +455,10 @@ static int enqueue_solve(ilqr_hip_ctx* c, const DevState& S, const h1::ProblemDe
     { StageTimer T(c, 6, st); ilqr::launch_backward(S, ilqr::MASK_RETRY, st, fold_h, iter); }                                  // :637
     { StageTimer T(c, 7, st); ilqr::launch_line_search(S, P, ilqr::MASK_RETRY, st, iter); }                             // :638
     { StageTimer T(c, 5, st); ilqr::launch_control(S, 1, iter, c->tol, c->early_exit, st); }                      // :640-646
+    if (gate) {
+      HIPCHK(c, hipMemcpyAsync(&c->h_active[iter + 1], S.order_n + 2 * (iter + 1), sizeof(int), hipMemcpyDeviceToHost, st));
+      HIPCHK(c, hipEventRecord(c->ev_active[iter], st));
+    }
   }
   return ILQR_OK;
 }
@@ -655,6 +685,7 @@ int ilqr_hip_step_stance(ilqr_hip_ctx* c, int count, const double* x, const doub
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return ILQR_OK;
 }
+int ilqr_hip_get_iterations_enqueued(const ilqr_hip_ctx* c) { return c ? c->iterations_enqueued : -1; }
 int ilqr_hip_get_adopt_mismatches(ilqr_hip_ctx* c, unsigned long long* count) {
   if (!c || !count) return ILQR_ERR_ARG;
   enter(c);

@@ -183,6 +183,31 @@ def test_folded_backward_pass_equals_generic_kernel_and_numpy(contact):
     s.close()
 
 
+def test_early_exit_gate_stops_launching_and_changes_nothing():
+    """With the convergence exit on, the host follows the device-side count of active rollouts and stops enqueuing iterations
+    once the batch is done (ilqr_capi.hip enqueue_solve); the compacted work lists (DevState::order) feed the Riccati and
+    line-search launches.  Same traces, iteration counts, gains and trajectories with the gate off, and against the oracle."""
+    B = 6
+    prob, x0, ui = standing(B, seed=41)
+    out = {}
+    for gate in ("1", "0"):
+        with env(ILQR_EE_GATE=gate):
+            s = _solver(B); s.set_problem(prob); s.set_options(early_exit=True); s.set_max_iterations(10)
+            s.initialize(x0, ui); cost = s.solve(x0)
+            # warm re-solve from the converged solution: every rollout leaves after a few iterations
+            s.initialize_warm_resident(x0); cost2 = s.solve(x0)
+            out[gate] = (cost, cost2, s.iterations(), s.gains_K(), s.xbar(), s.trace()[0], s.iterations_enqueued())
+            s.close()
+    for a, b_ in zip(out["1"][:6], out["0"][:6]):
+        assert np.array_equal(a, b_, equal_nan=True)
+    its = out["1"][2]
+    assert out["0"][6] == 10 and out["1"][6] < 10 and out["1"][6] >= its.max()      # launched no more than one or two idle iterations
+    for b in range(B):
+        o = ol.Oracle(prob["N"], prob["dt"]); o.set_problem(prob); o.set_options(max_iter=10, early_exit=1)
+        o.initialize(x0[b], ui[b]); ok, c = o.solve(x0[b])
+        assert abs(out["1"][0][b] - c) <= 1e-5 * abs(c)
+
+
 @pytest.mark.parametrize("ls", ["s", "r"])
 def test_line_search_variants_match_oracle(ls):
     prob, x0, ui = standing(3, seed=4)
