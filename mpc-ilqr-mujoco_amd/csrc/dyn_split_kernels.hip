@@ -57,7 +57,12 @@ __device__ __attribute__((noinline)) void step_stance_shared(h1s::HalfX* hp, con
 template <bool CONTACT>
 DEVFN void step_any(bool side, h1s::HalfX& h, const h1s::HalfU& u, const DynParams& dyn, const int* st, const h1s::LaneLds& L) {
   if constexpr (CONTACT) step_stance_shared(&h, &u, dyn.h, dyn.g[0], dyn.g[1], dyn.g[2], dyn.soft, dyn.contact, st[0], st[1]);
-  else h1s::step(side, h, u, dyn.h, dyn.g, L);
+  else {
+    // (the step size behind an opaque barrier as well: with h a loop invariant the articulated quantities of the chains' leaf
+    // bodies -- constants plus the armature term h * damping -- are hoisted out of the knot loop, spilled and reloaded per step)
+    double dt = dyn.h; asm volatile("" : "+s"(dt));
+    h1s::step(side, h, u, dt, dyn.g, L);
+  }
 }
 
 // ---- line search on two lanes per candidate (h1_aba_split.h): thread per (rollout, alpha, side), the 16 lanes of
@@ -178,7 +183,9 @@ __global__ void __launch_bounds__(64) k_line_search_s(DevState S, ProblemDev P, 
     u.u11 = h1s::pair_sum(u.u11);     // torso control: from the left lane to both
     LSS(1)
     LSS(2)
-    step_any<CONTACT>(side, h, u, P.dyn, P.stance + b * P.stance_stride + 2 * t, L);
+    int sd = side; asm volatile("" : "+v"(sd));          // (see k_rollout_s)
+    const bool side_t = sd != 0;
+    step_any<CONTACT>(side_t, h, u, P.dyn, P.stance + b * P.stance_stride + 2 * t, L);
     LSS(3)
     h1s::store_half(side, h, xc + (t + 1) * n);
     LSS(4)
@@ -212,7 +219,11 @@ __global__ void __launch_bounds__(64) k_rollout_s(DevState S, ProblemDev P, int 
     for (int k = 0; k < 5; ++k) u.uL[k] = ub[t * H1_NU + h1s::jleg(side, k)];
 #pragma unroll
     for (int k = 0; k < 4; ++k) u.uA[k] = ub[t * H1_NU + h1s::jarm(side, k)];
-    step_any<CONTACT>(side, h, u, P.dyn, P.stance + b * P.stance_stride + 2 * t, L);
+    // the side is re-derived behind an opaque barrier every step: otherwise the ~120 per-lane body constants `side ? right : left`
+    // are hoisted out of the knot loop as loop invariants, spilled, and fetched back from scratch every step
+    int sd = side; asm volatile("" : "+v"(sd));
+    const bool side_t = sd != 0;
+    step_any<CONTACT>(side_t, h, u, P.dyn, P.stance + b * P.stance_stride + 2 * t, L);
     h1s::store_half(side, h, xb + (t + 1) * H1_NX);
   }
 }
