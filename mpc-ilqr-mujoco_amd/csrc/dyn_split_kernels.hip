@@ -87,24 +87,29 @@ __global__ void __launch_bounds__(64) k_line_search_s(DevState S, ProblemDev P, 
     if (b >= *count) return;
     b = list[b];
   } else if (b >= S.B || !sel_s(S, b, mode)) return;
-  const int lane = threadIdx.x, grp = lane & ~15, c16 = lane & 15, col = lane & ~1;
-  const h1s::LaneLds L{lds, 64, lane};
+  const int lane0 = threadIdx.x;
   const int N = S.N, n = H1_NX, m = H1_NU;
   const double alpha = ALPHAS_S[ai];
-  const double* xb = S.xbar + (size_t)b * (N + 1) * n;
-  const double* ub = S.ubar + (size_t)b * N * m;
-  const double* Kg = S.K + (size_t)b * N * m * n;
-  const double* kg = S.kff + (size_t)b * N * m;
-  double* xc = S.xcand + ((size_t)b * 8 + ai) * (N + 1) * n;
-  double* uc = S.ucand + ((size_t)b * 8 + ai) * N * m;
   const bool b8 = (ai & 4) != 0, b4 = (ai & 2) != 0, b2 = (ai & 1) != 0;
   h1s::HalfX h; h1s::load_half(side, S.x0 + (size_t)b * n, h);
-  h1s::store_half(side, h, xc);
+  h1s::store_half(side, h, S.xcand + ((size_t)b * 8 + ai) * (N + 1) * n);
 #ifdef LS_STAMP
   long long ph[8] = {0}; long long tl = clock64();
 #endif
-  const int a8 = lane & ~15;                       // first lane of this rollout's 16
   for (int t = 0; t < N; ++t) {
+    // rollout and lane indices re-derived behind an opaque barrier every step: the dozens of per-lane addresses and LDS
+    // offsets derived from them are then recomputed (a few integer operations) instead of being hoisted out of the knot loop
+    // as loop invariants, spilled, and fetched back from scratch
+    int bt = b, lane = lane0;
+    asm volatile("" : "+v"(bt), "+v"(lane));
+    const int col = lane & ~1, a8 = lane & ~15;     // the pair's LDS column; first lane of this rollout's 16
+    const h1s::LaneLds L{lds, 64, lane};
+    const double* xb = S.xbar + (size_t)bt * (N + 1) * n;
+    const double* ub = S.ubar + (size_t)bt * N * m;
+    const double* Kg = S.K + (size_t)bt * N * m * n;
+    const double* kg = S.kff + (size_t)bt * N * m;
+    double* xc = S.xcand + ((size_t)bt * 8 + ai) * (N + 1) * n;
+    double* uc = S.ucand + ((size_t)bt * 8 + ai) * N * m;
     const double* xbt = xb + t * n;
     // ---- everything this step reads from HBM for this lane's half, in one batch: nominal state (for x - xbar),
     // nominal control and feedforward of the rows this side owns
