@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include "h1_cost_dev.h"
+#define ABA_FENCE          // scheduling fences between the sweeps of the articulated-body algorithm (h1_aba_split.h)
 #include "h1_aba_split.h"
 #include "ilqr_kernels.h"
 

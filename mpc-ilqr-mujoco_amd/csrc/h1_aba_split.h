@@ -387,6 +387,9 @@ DEVFN void forward_dynamics(bool side, const double* R0, const double* vb, const
     for (int k = 0; k < 6; ++k) p0[k] = 0.0;
     body_in<11, 11>(side, Y, T11, tau.t11, q.qd11, arm_eff, L, 0, Y0, p0);   // torso's share of the pelvis (both lanes)
   }
+#ifdef ABA_FENCE   // scheduling fence between the independent sweeps (arms | legs | pelvis solve | outward passes): left free, the
+  __builtin_amdgcn_sched_barrier(0);   // scheduler interleaves them and a third more temporaries live (and spill) at once
+#endif
   {
     Art Yl; art_zero(Yl); double pl[6] = {0, 0, 0, 0, 0, 0};
     LegChain::in(side, v0, q.thL, q.qdL, tau.tL, arm_eff, L, Yl, pl);
@@ -401,6 +404,9 @@ DEVFN void forward_dynamics(bool side, const double* R0, const double* vb, const
 #pragma unroll
     for (int k = 0; k < 6; ++k) p0[k] += pv[k];
   }
+#ifdef ABA_FENCE
+  __builtin_amdgcn_sched_barrier(0);
+#endif
   // pelvis
   double rhs[6] = {-p0[0], -p0[1], -p0[2], -p0[3], -p0[4], -p0[5]}, a0[6];
   solve6(Y0, rhs, a0);
@@ -421,6 +427,9 @@ DEVFN void forward_dynamics(bool side, const double* R0, const double* vb, const
   double v11[6], a11[6];
   qacc.q11 = body_acc<11, 11>(side, v0, a0, q.th11, q.qd11, L, 0, v11, a11);
   ArmChain::acc<0>(side, v11, a11, q.thA, q.qdA, L, qacc.qA);
+#ifdef ABA_FENCE
+  __builtin_amdgcn_sched_barrier(0);
+#endif
   LegChain::acc<0>(side, v0, a0, q.thL, q.qdL, L, qacc.qL);
 }
 
