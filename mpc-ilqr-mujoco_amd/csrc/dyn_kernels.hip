@@ -8,6 +8,7 @@
 
 #include "h1_cost_dev.h"
 #include "h1_linearize_dev.h"
+#define ABA_FENCE          // scheduling fences between the sweeps of the articulated-body algorithm (h1_aba_reg.h): k_lin_primal_r spills 532 instead of 1152 B
 #include "h1_aba_reg.h"
 #include "ilqr_kernels.h"
 

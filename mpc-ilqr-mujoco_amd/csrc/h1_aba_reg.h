@@ -348,7 +348,13 @@ DEVFN void forward_dynamics(const double* R0, const double* theta, const double*
   BodyState T11; body_out<11>(v0, theta[10], v[6 + 10], T11);
   Art Yt; art_zero(Yt); double pt[6] = {0, 0, 0, 0, 0, 0};
   Chain<12, 4>::in(T11.v, theta, v, tau, arm_eff, L, nullptr, nullptr, Yt, pt);
+#ifdef ABA_FENCE   // scheduling fence between the independent sweeps: left free, the scheduler interleaves the chains and
+  __builtin_amdgcn_sched_barrier(0);   // many more temporaries live (and spill) at once
+#endif
   Chain<16, 4>::in(T11.v, theta, v, tau, arm_eff, L, nullptr, nullptr, Yt, pt);
+#ifdef ABA_FENCE
+  __builtin_amdgcn_sched_barrier(0);
+#endif
   Art Y0; body_inertia<0>(Y0);
   double p0[6];
   { double Iv[6]; inertia_mul<0>(v0, Iv); crf(v0, Iv, p0); }
@@ -358,8 +364,17 @@ DEVFN void forward_dynamics(const double* R0, const double* theta, const double*
     for (int k = 0; k < 6; ++k) T11.pA[k] += pt[k];
     body_in<11>(Y, T11, tau[10], v[6 + 10], arm_eff, L, Y0, p0);
   }
+#ifdef ABA_FENCE
+  __builtin_amdgcn_sched_barrier(0);
+#endif
   Chain<1, 5>::in(v0, theta, v, tau, arm_eff, L, nullptr, nullptr, Y0, p0);
+#ifdef ABA_FENCE
+  __builtin_amdgcn_sched_barrier(0);
+#endif
   Chain<6, 5>::in(v0, theta, v, tau, arm_eff, L, nullptr, nullptr, Y0, p0);
+#ifdef ABA_FENCE
+  __builtin_amdgcn_sched_barrier(0);
+#endif
   // pelvis
   double rhs[6] = {-p0[0], -p0[1], -p0[2], -p0[3], -p0[4], -p0[5]}, a0[6];
   solve6(Y0, rhs, a0, IA0inv);
@@ -376,9 +391,21 @@ DEVFN void forward_dynamics(const double* R0, const double* theta, const double*
   // outward accelerations
   double v11[6], a11[6];
   Chain<11, 1>::template acc<0>(v0, a0, theta, v, L, qacc, v11, a11, sink);
+#ifdef ABA_FENCE
+  __builtin_amdgcn_sched_barrier(0);
+#endif
   Chain<12, 4>::template acc<0>(v11, a11, theta, v, L, qacc, nullptr, nullptr, sink);
+#ifdef ABA_FENCE
+  __builtin_amdgcn_sched_barrier(0);
+#endif
   Chain<16, 4>::template acc<0>(v11, a11, theta, v, L, qacc, nullptr, nullptr, sink);
+#ifdef ABA_FENCE
+  __builtin_amdgcn_sched_barrier(0);
+#endif
   Chain<1, 5>::template acc<0>(v0, a0, theta, v, L, qacc, nullptr, nullptr, sink);
+#ifdef ABA_FENCE
+  __builtin_amdgcn_sched_barrier(0);
+#endif
   Chain<6, 5>::template acc<0>(v0, a0, theta, v, L, qacc, nullptr, nullptr, sink);
 }
 
