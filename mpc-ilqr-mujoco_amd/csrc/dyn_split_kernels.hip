@@ -9,6 +9,7 @@
 #include "h1_cost_dev.h"
 #define ABA_FENCE          // scheduling fences between the sweeps of the articulated-body algorithm (h1_aba_split.h)
 #include "h1_aba_split.h"
+#include "h1_linearize_dev.h"      // LinDumpG: what k_lin_tangent reads of the nominal knot
 #include "ilqr_kernels.h"
 
 using namespace h1;
@@ -233,6 +234,76 @@ __global__ void __launch_bounds__(64) k_rollout_s(DevState S, ProblemDev P, int 
     h1s::store_half(side, h, xb + (t + 1) * H1_NX);
   }
 }
+// ---- primal dump of the analytic linearisation on two lanes per knot (replaces k_lin_primal_r, dyn_kernels.hip, wherever the
+// two-lane kernels run): forward dynamics of the nominal knot, every body's velocity / acceleration / sin, cos / U / 1/D, the base
+// rotation, the joint accelerations and the inverse of the pelvis' articulated inertia -> LinDumpG (h1_linearize_dev.h)
+struct DumpSinkS {
+  double* g;
+  DEVFN void operator()(int i, const double* v, const double* a, double s, double c) const {
+    double* sc = g + LinDumpG_sc + 2 * i; sc[0] = s; sc[1] = c;
+    double* vv = g + LinDumpG_v + 6 * i; double* aa = g + LinDumpG_a + 6 * i;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) { vv[k] = v[k]; aa[k] = a[k]; }
+  }
+};
+__global__ void __launch_bounds__(64) k_lin_primal_s(DevState S, ProblemDev P, int mode) {
+  extern __shared__ double lds[];
+  const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long knot = gid >> 1;
+  const bool side = (gid & 1) != 0;
+  if (knot >= (long)S.B * S.N) return;
+  const int t = (int)(knot % S.N), b = (int)(knot / S.N);
+  if (!sel_s(S, b, mode)) return;
+  const h1s::LaneLds L{lds, 64, (int)threadIdx.x};
+  h1s::HalfX h; h1s::load_half(side, S.xbar + ((size_t)b * (S.N + 1) + t) * H1_NX, h);
+  h1s::HalfU u; load_half_u(side, S.ubar + ((size_t)b * S.N + t) * H1_NU, u);
+  const double dt = P.dyn.h;
+  const double qn = sqrt(h.quat[0] * h.quat[0] + h.quat[1] * h.quat[1] + h.quat[2] * h.quat[2] + h.quat[3] * h.quat[3]);
+  double R0[9]; h1s::quat_R(h.quat[0] / qn, h.quat[1] / qn, h.quat[2] / qn, h.quat[3] / qn, R0);
+  h1s::HalfTau tau;
+  tau.t11 = h1s::clampu(u.u11, h1s::C_CTRLRANGE[10]) - h1s::DAMPING * h.q.qd11;
+#pragma unroll
+  for (int k = 0; k < 5; ++k) tau.tL[k] = h1s::clampu(u.uL[k], h1s::C_CTRLRANGE[h1s::jleg(side, k)]) - h1s::DAMPING * h.q.qdL[k];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) tau.tA[k] = h1s::clampu(u.uA[k], h1s::C_CTRLRANGE[h1s::jarm(side, k)]) - h1s::DAMPING * h.q.qdA[k];
+  double* g = S.lin_dump + (size_t)knot * LinDumpG_SIZE;
+  DumpSinkS all{g};
+  // pelvis and torso are computed on both lanes: only the left one stores them
+  auto sink = [&](int i, const double* v, const double* a, double s, double c) { if (!side || (i != 0 && i != 11)) all(i, v, a, s, c); };
+  double qb[6], inv36[36], aL[3]; h1s::HalfAcc qa;
+  h1s::forward_dynamics_dump(side, R0, h.vb, h.q, tau, h1s::ARMATURE + dt * h1s::DAMPING, P.dyn.g, L, qb, qa, sink, inv36, aL);
+  if (!side) {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) g[LinDumpG_R0 + k] = R0[k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) g[LinDumpG_aL + k] = aL[k];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) { g[LinDumpG_qacc + k] = qb[k]; g[LinDumpG_U + k] = 0.0; }
+    g[LinDumpG_Dinv] = 0.0;
+    g[LinDumpG_qacc + 6 + 10] = qa.q11;
+#pragma unroll
+    for (int k = 0; k < 36; ++k) g[LinDumpG_IA0inv + k] = inv36[k];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) g[LinDumpG_U + 6 * 11 + k] = L[k];
+    g[LinDumpG_Dinv + 11] = L[6];
+  }
+#pragma unroll
+  for (int K = 0; K < 5; ++K) {
+    const int i = (side ? 6 : 1) + K;             // body of leg hinge K on this side
+    g[LinDumpG_qacc + 6 + i - 1] = qa.qL[K];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) g[LinDumpG_U + 6 * i + k] = L[8 + 8 * K + k];
+    g[LinDumpG_Dinv + i] = L[8 + 8 * K + 6];
+  }
+#pragma unroll
+  for (int K = 0; K < 4; ++K) {
+    const int i = (side ? 16 : 12) + K;
+    g[LinDumpG_qacc + 6 + i - 1] = qa.qA[K];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) g[LinDumpG_U + 6 * i + k] = L[48 + 8 * K + k];
+    g[LinDumpG_Dinv + i] = L[48 + 8 * K + 6];
+  }
+}
 __global__ void __launch_bounds__(64) k_count_iter(DevState S, int mode) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b < S.B && sel_s(S, b, mode)) S.iters[b] += 1;
@@ -346,6 +417,7 @@ int dyn_split_kernels_set_attr() {
   rc |= hipFuncSetAttribute((const void*)k_rollout_s<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DYN_LDS_BYTES_S) != hipSuccess;
   rc |= hipFuncSetAttribute((const void*)k_rollout_s<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DYN_LDS_BYTES_S) != hipSuccess;
   rc |= hipFuncSetAttribute((const void*)k_step_s, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DYN_LDS_BYTES_S) != hipSuccess;
+  rc |= hipFuncSetAttribute((const void*)k_lin_primal_s, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DYN_LDS_BYTES_S) != hipSuccess;
   rc |= hipFuncSetAttribute((const void*)k_last_step_s, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DYN_LDS_BYTES_S) != hipSuccess;
   rc |= hipFuncSetAttribute((const void*)k_fd_steps_s, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DYN_LDS_BYTES_S) != hipSuccess;
   return rc;
@@ -353,6 +425,9 @@ int dyn_split_kernels_set_attr() {
 void launch_line_search_s(const DevState& S, const ProblemDev& P, int mode, hipStream_t st, const int* list, const int* count) {
   if (P.dyn.contact) hipLaunchKernelGGL(k_line_search_s<true>, dim3(cdiv_s((long)S.B * 16, 64)), dim3(64), DYN_LDS_BYTES_S, st, S, P, mode, list, count);
   else hipLaunchKernelGGL(k_line_search_s<false>, dim3(cdiv_s((long)S.B * 16, 64)), dim3(64), DYN_LDS_BYTES_S, st, S, P, mode, list, count);
+}
+void launch_lin_primal_s(const DevState& S, const ProblemDev& P, int mode, hipStream_t st) {
+  hipLaunchKernelGGL(k_lin_primal_s, dim3(cdiv_s((long)S.B * S.N * 2, 64)), dim3(64), DYN_LDS_BYTES_S, st, S, P, mode);
 }
 void launch_step_s(int count, const double* x, const double* u, const DynParams& dyn, double* xn, hipStream_t st, int stance_l, int stance_r) {
   hipLaunchKernelGGL(k_step_s, dim3(cdiv_s((long)count * 2, 64)), dim3(64), DYN_LDS_BYTES_S, st, count, x, u, dyn, xn, stance_l, stance_r);

@@ -238,9 +238,11 @@ template <int IL, int IR> DEVFN void body_in(bool side, Art& Y, BodyState& S, do
   xf_force_acc<IL, IR>(side, pa, S.s, S.c, pAp);
 }
 // outward acceleration step: in (vp, ap) of the parent, out (v, a) of the body and its joint acceleration
-template <int IL, int IR> DEVFN double body_acc(bool side, const double* vp, const double* ap, double theta, double qd, const LaneLds& L, int slot, double* v, double* a) {
+template <int IL, int IR> DEVFN double body_acc(bool side, const double* vp, const double* ap, double theta, double qd, const LaneLds& L, int slot, double* v, double* a,
+                                                double* sc = nullptr) {
   constexpr int AX = C_AXIS[IL];
   double s, c; h1f::sincos_fast(theta, &s, &c);
+  if (sc) { sc[0] = s; sc[1] = c; }
   xf_motion<IL, IR>(side, vp, s, c, v); v[AX] += qd;
   xf_motion<IL, IR>(side, ap, s, c, a);
   double ca[3], cl[3]; cross_axis<AX>(v, ca); cross_axis<AX>(v + 3, cl);
@@ -306,6 +308,13 @@ template <int FL, int FR, int LEN, int SLOT0> struct Chain {
     } else {
       body_in<FL + K, FR + K>(side, Y, S, tau[K], qd[K], arm_eff, L, SLOT0 + 8 * K, Yj, pAj);
     }
+  }
+  // the same sweep reporting every body: sink(body index of this lane's side, v, a, sin, cos)
+  template <int K, class Sink> static DEVFN void acc_dump(bool side, const double* vp, const double* ap, const double* th, const double* qd, const LaneLds& L, double* qdd, Sink& sink) {
+    double v[6], a[6], sc[2];
+    qdd[K] = body_acc<FL + K, FR + K>(side, vp, ap, th[K], qd[K], L, SLOT0 + 8 * K, v, a, sc);
+    sink(side ? FR + K : FL + K, v, a, sc[0], sc[1]);
+    if constexpr (K + 1 < LEN) acc_dump<K + 1>(side, v, a, th, qd, L, qdd, sink);
   }
   template <int K> static DEVFN void acc(bool side, const double* vp, const double* ap, const double* th, const double* qd, const LaneLds& L, double* qdd) {
     double v[6], a[6];
@@ -491,6 +500,80 @@ DEVFN void ldl6_solve(const Ldl6& F, const double* rhs, double* out) {
     for (int k = 0; k < 6; ++k) if (k > i) s -= F.Lm[lidx(k, i)] * out[k];
     out[i] = s; }
 }
+
+// The same forward dynamics reporting what the analytic linearisation needs of the nominal knot (LinDumpG, h1_linearize_dev.h):
+// sink(body, v, a, sin, cos) for every body of this lane's side (pelvis and torso: both lanes report them), the explicit
+// inverse of the pelvis' articulated inertia and the pelvis' linear acceleration without the gravity term.  U, 1/D stay in
+// this lane's LDS slots (torso: slot block 0, leg hinge K: 8 + 8 K, arm hinge K: 48 + 8 K).
+template <class Sink>
+DEVFN void forward_dynamics_dump(bool side, const double* R0, const double* vb, const HalfState& q, const HalfTau& tau, double arm_eff, const double* grav,
+                                 const LaneLds& L, double* qbase, HalfAcc& qacc, Sink& sink, double* inv36, double* aL) {
+  double v0[6] = {vb[3], vb[4], vb[5], 0, 0, 0};
+  v0[3] = R0[0] * vb[0] + R0[3] * vb[1] + R0[6] * vb[2];
+  v0[4] = R0[1] * vb[0] + R0[4] * vb[1] + R0[7] * vb[2];
+  v0[5] = R0[2] * vb[0] + R0[5] * vb[1] + R0[8] * vb[2];
+  BodyState T11; body_out<11, 11>(side, v0, q.th11, q.qd11, T11);
+  Art Y0; double p0[6];
+  {
+    Art Yt; art_zero(Yt); double pt[6] = {0, 0, 0, 0, 0, 0};
+    ArmChain::in(side, T11.v, q.thA, q.qdA, tau.tA, arm_eff, L, Yt, pt);
+    art_pair_sum(Yt);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) pt[k] = pair_sum(pt[k]);
+    Art Y; body_inertia<11, 11>(side, Y); art_add(Y, Yt);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) T11.pA[k] += pt[k];
+    art_zero(Y0);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) p0[k] = 0.0;
+    body_in<11, 11>(side, Y, T11, tau.t11, q.qd11, arm_eff, L, 0, Y0, p0);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  {
+    Art Yl; art_zero(Yl); double pl[6] = {0, 0, 0, 0, 0, 0};
+    LegChain::in(side, v0, q.thL, q.qdL, tau.tL, arm_eff, L, Yl, pl);
+    art_pair_sum(Yl);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) pl[k] = pair_sum(pl[k]);
+    art_add(Y0, Yl);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) p0[k] += pl[k];
+    Art Yb; body_inertia<0, 0>(side, Yb); art_add(Y0, Yb);
+    double Iv[6], pv[6]; inertia_mul<0, 0>(side, v0, Iv); crf(v0, Iv, pv);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) p0[k] += pv[k];
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  // pelvis: one factorisation, the solve and (left lane's job to store) the explicit inverse column by column
+  double rhs[6] = {-p0[0], -p0[1], -p0[2], -p0[3], -p0[4], -p0[5]}, a0[6];
+  Ldl6 F; ldl6_factor(Y0, F);
+  ldl6_solve(F, rhs, a0);
+#pragma unroll
+  for (int c = 0; c < 6; ++c) {
+    double e[6] = {0, 0, 0, 0, 0, 0}, col[6]; e[c] = 1.0;
+    ldl6_solve(F, e, col);
+#pragma unroll
+    for (int r = 0; r < 6; ++r) inv36[6 * r + c] = col[r];
+  }
+  const double mg[3] = {-grav[0], -grav[1], -grav[2]};
+  const double a0p[3] = {R0[0] * mg[0] + R0[3] * mg[1] + R0[6] * mg[2], R0[1] * mg[0] + R0[4] * mg[1] + R0[7] * mg[2], R0[2] * mg[0] + R0[5] * mg[1] + R0[8] * mg[2]};
+  double wxv[3]; cross(v0, v0 + 3, wxv);
+  const double lin[3] = {a0[3] - a0p[0] + wxv[0], a0[4] - a0p[1] + wxv[1], a0[5] - a0p[2] + wxv[2]};
+  qbase[0] = R0[0] * lin[0] + R0[1] * lin[1] + R0[2] * lin[2];
+  qbase[1] = R0[3] * lin[0] + R0[4] * lin[1] + R0[5] * lin[2];
+  qbase[2] = R0[6] * lin[0] + R0[7] * lin[1] + R0[8] * lin[2];
+  qbase[3] = a0[0]; qbase[4] = a0[1]; qbase[5] = a0[2];
+  aL[0] = a0[3] + wxv[0]; aL[1] = a0[4] + wxv[1]; aL[2] = a0[5] + wxv[2];
+  sink(0, v0, a0, 0.0, 1.0);
+  __builtin_amdgcn_sched_barrier(0);
+  double v11[6], a11[6], sc11[2];
+  qacc.q11 = body_acc<11, 11>(side, v0, a0, q.th11, q.qd11, L, 0, v11, a11, sc11);
+  sink(11, v11, a11, sc11[0], sc11[1]);
+  ArmChain::acc_dump<0>(side, v11, a11, q.thA, q.qdA, L, qacc.qA, sink);
+  __builtin_amdgcn_sched_barrier(0);
+  LegChain::acc_dump<0>(side, v0, a0, q.thL, q.qdL, L, qacc.qL, sink);
+}
+
 // sweeps of a force / acceleration increment along a mirrored chain whose U_i, 1/D_i sit in LDS (slot blocks from SLOT0)
 template <int FL, int FR, int LEN, int SLOT0> struct ChainResp {
   // inward from the chain's last body: dp = bias-force increment there; du[K] = joint-force increments; returns the root share

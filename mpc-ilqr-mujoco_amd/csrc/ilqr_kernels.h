@@ -88,6 +88,7 @@ void launch_lin_primal_r(const DevState& S, const h1::ProblemDev& P, int mode, h
 int dyn_kernels_set_attr();
 // dyn_split_kernels.hip: two lanes per rollout / candidate
 void launch_rollout_s(const DevState& S, const h1::ProblemDev& P, int mode, int do_roll, int count_iter, double* cost_out, hipStream_t st);
+void launch_lin_primal_s(const DevState& S, const h1::ProblemDev& P, int mode, hipStream_t st);
 void launch_line_search_s(const DevState& S, const h1::ProblemDev& P, int mode, hipStream_t st, const int* list = nullptr, const int* count = nullptr);
 int dyn_split_kernels_set_attr();
 void launch_step_s(int count, const double* x, const double* u, const h1::DynParams& dyn, double* xn, hipStream_t st, int stance_l, int stance_r);

@@ -638,7 +638,8 @@ void launch_step(int count, const double* x, const double* u, const DynParams& d
 // phases: 1 = primal dump only, 2 = tangent sweeps / FD only, 3 = both
 void launch_linearize(const DevState& S, const ProblemDev& P, int mode, int jac_mode, double eps, hipStream_t st, int phases) {
   if (jac_mode == 0 && !use_scalar_dyn()) {
-    if (phases & 1) launch_lin_primal_r(S, P, mode, st);       // (contact mode: the dump is the free solve, see k_lin_tangent_c)
+    // primal dump: on two lanes per knot beside the two-lane rollout kernels, one lane per knot with ILQR_ROLLOUT=r
+    if (phases & 1) { if (g_var.rollout_split || P.dyn.contact) launch_lin_primal_s(S, P, mode, st); else launch_lin_primal_r(S, P, mode, st); }   // (contact mode: the dump is the free solve, see k_lin_tangent_c)
     if ((phases & 2) && P.dyn.contact) hipLaunchKernelGGL(k_lin_tangent_c, dim3(S.N, S.B), dim3(128), 0, st, S, P, mode);
     else if (phases & 2) hipLaunchKernelGGL(k_lin_tangent, dim3(S.N, S.B), dim3(128), 0, st, S, P, mode);
   } else if (jac_mode == 0 && !P.dyn.contact) {               // ILQR_DYN=s: the analytic kernels are constraint-free only
