@@ -219,7 +219,17 @@ __global__ void __launch_bounds__(64) k_traj_knot_cost(DevState S, ProblemDev P,
   for (int half = 0; half < 2; ++half) {
     const int r0 = 32 * half, nr = (int)nrow - r0 < 32 ? (int)nrow - r0 : 32;      // rows r0 .. r0 + nr of this wave
     if (half) __syncthreads();
-    for (int e = lane; e < nr * H1_NX; e += 64) xs[e] = src[r0 * H1_NX + e];
+    {
+      // all the loads of the half first, then the LDS writes: as a plain copy loop the compiler waits for every load before it
+      // issues the next one (26 exposed HBM round trips per half; this was most of the kernel's time)
+      const int cnt = nr * H1_NX;
+      constexpr int NIT = (32 * H1_NX + 63) / 64;
+      double tmp[NIT];
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) { const int e = lane + 64 * it; tmp[it] = src[r0 * H1_NX + (e < cnt ? e : 0)]; }
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) { const int e = lane + 64 * it; if (e < cnt) xs[e] = tmp[it]; }
+    }
     __syncthreads();
     if ((lane >> 5) == half) {
       const int row = (idx < total ? lane : (int)nrow - 1) - r0;
