@@ -565,34 +565,58 @@ DEVFN void lin_accumulate_forces(LinShared& L, int lane) {
 // wave-local ordering of LDS accesses (one wave executes its LDS instructions in order; this only stops the compiler)
 DEVFN void wave_sync() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
 // cooperative load by 128 threads; wave 0 rebuilds the joint rotations / parent accelerations, wave 1 the body forces
-DEVFN void lin_load_dump2(LinShared& L, const double* g, int tid) {
+// xg / ug: the knot's state and control (into L.x, L.u_); returns false, before anything is written, when *flag (if given) is 0
+DEVFN bool lin_load_dump2(LinShared& L, const double* g, int tid, const double* xg = nullptr, const double* ug = nullptr, const int* flag = nullptr,
+                          const int* flag2 = nullptr) {
   LinDump& D = L.D;
   const int wv = tid >> 6, lane = tid & 63;
-  for (int e = tid; e < 9; e += 128) D.R0[e] = g[LinDumpG_R0 + e];
-  for (int e = tid; e < 3; e += 128) D.aL[e] = g[LinDumpG_aL + e];
-  for (int e = tid; e < H1_NV; e += 128) D.qacc[e] = g[LinDumpG_qacc + e];
-  for (int e = tid; e < H1_NB * 6; e += 128) { (&D.v[0][0])[e] = g[LinDumpG_v + e]; (&L.u.m.U[0][0])[e] = g[LinDumpG_U + e]; }
-  for (int e = tid; e < H1_NB; e += 128) L.u.m.Dinv[e] = g[LinDumpG_Dinv + e];
-  for (int e = tid; e < 36; e += 128) L.u.m.IA0inv[e] = g[LinDumpG_IA0inv + e];
+  const int f1 = flag ? *flag : 1, f2 = flag2 ? *flag2 : 1;       // (requested together with everything else)
+  // Every value this thread needs from the knot's record is requested before the first one is used (indices clamped into the
+  // record instead of predicated): written group by group -- load, LDS store, next group -- each group waits out its own HBM
+  // round trip, seven of them in a row (this phase was 14 k of the kernel's 68 k cycles).
+  const double r0 = g[LinDumpG_R0 + (tid < 9 ? tid : 0)];
+  const double al = g[LinDumpG_aL + (tid < 3 ? tid : 0)];
+  const double qa = g[LinDumpG_qacc + (tid < H1_NV ? tid : 0)];
+  const int ev = tid < H1_NB * 6 ? tid : 0;
+  const double vv = g[LinDumpG_v + ev], uu = g[LinDumpG_U + ev];
+  const double di = g[LinDumpG_Dinv + (tid < H1_NB ? tid : 0)];
+  const double ia = g[LinDumpG_IA0inv + (tid < 36 ? tid : 0)];
+  // wave 0, lanes 1..19: sin / cos of the body's joint and the parent's acceleration; wave 1, lanes 0..19: the body's v and a
+  const int i0 = (lane >= 1 && lane < H1_NB) ? lane : 1, i1 = lane < H1_NB ? lane : 0;
+  const int ib = wv == 0 ? i0 : i1;
+  const int par0 = (i0 == 1 || i0 == 6 || i0 == 11) ? 0 : ((i0 == 12 || i0 == 16) ? 11 : i0 - 1);     // H1_PARENT without the table's round trip
+  const double* p6 = g + (wv == 0 ? LinDumpG_a + 6 * par0 : LinDumpG_v + 6 * i1);
+  double w6[6], a6[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) { w6[k] = p6[k]; a6[k] = g[LinDumpG_a + 6 * ib + k]; }
+  const double s = g[LinDumpG_sc + 2 * i0], c = g[LinDumpG_sc + 2 * i0 + 1];
+  double xu = 0.0;
+  if (xg) xu = (tid < 64) ? xg[tid < H1_NX ? tid : 0] : ug[(tid - 64) < H1_NU ? tid - 64 : 0];
+  if (!(f1 && f2)) return false;
+  if (xg) { if (tid < H1_NX) L.x[tid] = xu; if (tid >= 64 && tid < 64 + H1_NU) L.u_[tid - 64] = xu; }
+  if (tid < 9) D.R0[tid] = r0;
+  if (tid < 3) D.aL[tid] = al;
+  if (tid < H1_NV) D.qacc[tid] = qa;
+  if (tid < H1_NB * 6) { (&D.v[0][0])[tid] = vv; (&L.u.m.U[0][0])[tid] = uu; }
+  if (tid < H1_NB) L.u.m.Dinv[tid] = di;
+  if (tid < 36) L.u.m.IA0inv[tid] = ia;
   if (wv == 0 && lane >= 1 && lane < H1_NB) {
     const int i = lane, a = H1_AXIS[i], b = (a + 1) % 3, d = (a + 2) % 3;
-    const double s = g[LinDumpG_sc + 2 * i], c = g[LinDumpG_sc + 2 * i + 1];
     for (int r = 0; r < 3; ++r) {
       const double fa = H1_RFIX[i][r][a], fb = H1_RFIX[i][r][b], fd = H1_RFIX[i][r][d];
       D.Rj[i][3 * r + a] = fa; D.Rj[i][3 * r + b] = fb * c + fd * s; D.Rj[i][3 * r + d] = fd * c - fb * s;
     }
-    double ap[6], xa[6];
-    for (int k = 0; k < 6; ++k) ap[k] = g[LinDumpG_a + 6 * H1_PARENT[i] + k];
-    xf_motion(D.Rj[i], H1_POS[i], ap, xa);
+    double xa[6];
+    xf_motion(D.Rj[i], H1_POS[i], w6, xa);
     for (int k = 0; k < 6; ++k) L.xa[i][k] = xa[k];
   }
   if (wv == 1 && lane < H1_NB) {
     const int i = lane;
-    double v[6], a[6], Iv[6], Ia[6], vIv[6];
-    for (int k = 0; k < 6; ++k) { v[k] = g[LinDumpG_v + 6 * i + k]; a[k] = g[LinDumpG_a + 6 * i + k]; }
-    inertia_mul(i, v, Iv); inertia_mul(i, a, Ia); crf(v, Iv, vIv);
+    double Iv[6], Ia[6], vIv[6];
+    inertia_mul(i, w6, Iv); inertia_mul(i, a6, Ia); crf(w6, Iv, vIv);
     for (int k = 0; k < 6; ++k) { D.F[i][k] = Ia[k] + vIv[k]; L.Iv[i][k] = Iv[k]; }
   }
+  return true;
 }
 // lin_accumulate_forces on ONE wave (the other one runs the Minv sweeps meanwhile): wave-local ordering, no workgroup barrier
 DEVFN void lin_accumulate_forces_w(LinShared& L, int lane) {
