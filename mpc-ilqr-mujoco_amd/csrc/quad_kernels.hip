@@ -123,7 +123,6 @@ DEVFN void d2R_sel(int k, int l, double* D) {
 // the Hessian -- half of the kernel -- is split: patch entries over 128 lanes, two accumulator row tiles per wave.
 __global__ void __launch_bounds__(128, QUAD_WAVES) k_cost_quadratics(DevState S, ProblemDev P, int mode) {
   const int t = blockIdx.x, b = blockIdx.y, lane = threadIdx.x, wv = lane >> 6;
-  if (!quad_selected(S, b, mode)) return;
   const int N = S.N;
   const bool term = (t == N);
   __shared__ QuadLds L;
@@ -132,13 +131,22 @@ __global__ void __launch_bounds__(128, QUAD_WAVES) k_cost_quadratics(DevState S,
 #endif
   const double* xg = S.xbar + ((size_t)b * (N + 1) + t) * H1_NX;
 
-  // ---- phase 0: state (Pinocchio slot order of the quaternion), ancestor masks
-  if (lane < H1_NX) {
-    const int src = (lane == 3) ? 4 : (lane == 4) ? 5 : (lane == 5) ? 6 : (lane == 6) ? 3 : lane;
-    L.xp[lane] = xg[src];
+  // ---- phase 0: state (Pinocchio slot order of the quaternion), ancestor masks.  The rollout's selection flags are requested
+  // together with the knot's data (indices clamped instead of predicated) and tested before anything is written: flag, state,
+  // control and table one after the other were four serial HBM round trips at the top of every workgroup
+  {
+    const int f1 = mode == MASK_ALL ? 1 : S.active[b], f2 = mode == MASK_RETRY ? S.need_retry[b] : 1;
+    const int lx = lane < H1_NX ? lane : 0;
+    const int src = (lx == 3) ? 4 : (lx == 4) ? 5 : (lx == 5) ? 6 : (lx == 6) ? 3 : lx;
+    const double xv = xg[src];
+    const int tu = term ? N - 1 : t;
+    const double uv = S.ubar[((size_t)b * N + tu) * H1_NU + (lane < H1_NU ? lane : 0)];
+    const unsigned an = QANC.m[lane < H1_NB ? lane : 0];
+    if (!(f1 && f2)) return;
+    if (lane < H1_NX) L.xp[lane] = xv;
+    if (!term && lane < H1_NU) L.us[lane] = uv;
+    if (lane < H1_NB) L.anc[lane] = an;
   }
-  if (!term && lane < H1_NU) L.us[lane] = S.ubar[((size_t)b * N + t) * H1_NU + lane];
-  if (lane < H1_NB) L.anc[lane] = QANC.m[lane];
   __syncthreads();
   QSTAMP(0)
 
