@@ -253,10 +253,11 @@ __global__ void __launch_bounds__(64) k_lin_primal_s(DevState S, ProblemDev P, i
   const bool side = (gid & 1) != 0;
   if (knot >= (long)S.B * S.N) return;
   const int t = (int)(knot % S.N), b = (int)(knot / S.N);
-  if (!sel_s(S, b, mode)) return;
+  const int f1 = mode == MASK_ALL ? 1 : S.active[b], f2 = mode == MASK_RETRY ? S.need_retry[b] : 1;   // requested with the knot's data, tested after
   const h1s::LaneLds L{lds, 64, (int)threadIdx.x};
   h1s::HalfX h; h1s::load_half(side, S.xbar + ((size_t)b * (S.N + 1) + t) * H1_NX, h);
   h1s::HalfU u; load_half_u(side, S.ubar + ((size_t)b * S.N + t) * H1_NU, u);
+  if (!(f1 && f2)) return;
   const double dt = P.dyn.h;
   const double qn = sqrt(h.quat[0] * h.quat[0] + h.quat[1] * h.quat[1] + h.quat[2] * h.quat[2] + h.quat[3] * h.quat[3]);
   double R0[9]; h1s::quat_R(h.quat[0] / qn, h.quat[1] / qn, h.quat[2] / qn, h.quat[3] / qn, R0);

@@ -423,6 +423,17 @@ __global__ void __launch_bounds__(64) k_line_search(DevState S, ProblemDev P, in
 // one wave per rollout, 16 rollouts per workgroup: lane 0 decides (ilqr.cpp:619-655), all lanes copy the accepted candidate.
 // phase 0: after the first line search of an iteration; phase 1: after the retry line search;
 // phase 2: stage API (report only, accept if improved, no lambda / activity bookkeeping).
+// dst[0..len) = src[0..len) by the 64 lanes of a wave, eight loads in flight per lane (a plain copy loop waits for every load
+// before it issues the next one: source and destination might alias as far as the compiler knows)
+__device__ __forceinline__ void wave_copy(double* dst, const double* src, int len, int lane) {
+  for (int base = 0; base < len; base += 64 * 8) {
+    double v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const int e = base + 64 * j + lane; v[j] = src[e < len ? e : 0]; }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const int e = base + 64 * j + lane; if (e < len) dst[e] = v[j]; }
+  }
+}
 #define CTRL_WAVES 16
 __global__ void __launch_bounds__(64 * CTRL_WAVES) k_control(DevState S, int phase, int iter, double tol, int early_exit) {
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -437,7 +448,11 @@ __global__ void __launch_bounds__(64 * CTRL_WAVES) k_control(DevState S, int pha
     if (phase == 0) S.iters[b] += 1;
     const double base = S.Jbase[b];
     int acc = -1;
-    for (int a = 0; a < 8; ++a) { const double c = S.cand_cost[(size_t)b * 8 + a]; if (c < base - 1e-6) { acc = a; break; } }
+    double cc[8];
+#pragma unroll
+    for (int a = 0; a < 8; ++a) cc[a] = S.cand_cost[(size_t)b * 8 + a];       // (one batch; inside the scan each load would wait for the previous test)
+#pragma unroll
+    for (int a = 7; a >= 0; --a) if (cc[a] < base - 1e-6) acc = a;            // the first (largest) alpha that improves
     s_accept[wv] = acc;
     S.improved[b] = acc >= 0;
     S.alpha_idx[b] = acc;
@@ -499,8 +514,8 @@ __global__ void __launch_bounds__(64 * CTRL_WAVES) k_control(DevState S, int pha
   const double* uc = S.ucand + ((size_t)b * 8 + acc) * N * H1_NU;
   double* xb = S.xbar + (size_t)b * (N + 1) * H1_NX;
   double* ub = S.ubar + (size_t)b * N * H1_NU;
-  for (int e = lane; e < (N + 1) * H1_NX; e += 64) xb[e] = xc[e];
-  for (int e = lane; e < N * H1_NU; e += 64) ub[e] = uc[e];
+  wave_copy(xb, xc, (N + 1) * H1_NX, lane);
+  wave_copy(ub, uc, N * H1_NU, lane);
 }
 
 // solve prologue: J = initial cost, trace[0], counters
@@ -542,7 +557,16 @@ __global__ void k_adopt_rollout(DevState S, const double* shadow, int mode, unsi
   // reference linearises the trajectory it has just rolled out (ilqr.cpp:563-588).  The two coincide only while the
   // re-rollout reproduces the accepted candidate bit for bit: count every element that does not (checked by the GPU tests).
   int bad = 0;
-  for (int e = lane; e < (int)len; e += blockDim.x) { const double v = sh[e]; bad += (__double_as_longlong(v) != __double_as_longlong(xb[e])); xb[e] = v; }
+  for (int base = 0; base < (int)len; base += 64 * 8) {       // (blockDim.x == 64; eight elements in flight per lane, see wave_copy)
+    double v[8], o[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const int e = base + 64 * j + lane, ec = e < (int)len ? e : 0; v[j] = sh[ec]; o[j] = xb[ec]; }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int e = base + 64 * j + lane;
+      if (e < (int)len) { bad += (__double_as_longlong(v[j]) != __double_as_longlong(o[j])); xb[e] = v[j]; }
+    }
+  }
   if (bad) atomicAdd(mismatches, (unsigned long long)bad);
 }
 // last knot of the warm start: xbar[N] = f(xbar[N-1], ubar[N-1])
