@@ -135,18 +135,35 @@ DEVFN void lin_minv_lane_c(LinShared& L, LinContact& Cc, int lane) {
 
 // load by 128 threads: as lin_load_dump2, but the body accelerations are kept (they are corrected for the constraint before
 // X a_parent and the body forces are formed)
-DEVFN void lin_load_dump2c(LinShared& L, LinContact& Cc, const double* g, int tid) {
+// (every load requested before the first use, selection flags included, as in lin_load_dump2; false = rollout not selected)
+DEVFN bool lin_load_dump2c(LinShared& L, LinContact& Cc, const double* g, int tid, const double* xg, const double* ug, const int* flag, const int* flag2) {
   LinDump& D = L.D;
   const int wv = tid >> 6, lane = tid & 63;
-  for (int e = tid; e < 9; e += 128) D.R0[e] = g[LinDumpG_R0 + e];
-  for (int e = tid; e < 3; e += 128) D.aL[e] = g[LinDumpG_aL + e];
-  for (int e = tid; e < H1_NV; e += 128) D.qacc[e] = g[LinDumpG_qacc + e];
-  for (int e = tid; e < H1_NB * 6; e += 128) { (&D.v[0][0])[e] = g[LinDumpG_v + e]; (&L.u.m.U[0][0])[e] = g[LinDumpG_U + e]; (&Cc.a[0][0])[e] = g[LinDumpG_a + e]; }
-  for (int e = tid; e < H1_NB; e += 128) L.u.m.Dinv[e] = g[LinDumpG_Dinv + e];
-  for (int e = tid; e < 36; e += 128) L.u.m.IA0inv[e] = g[LinDumpG_IA0inv + e];
+  const int f1 = flag ? *flag : 1, f2 = flag2 ? *flag2 : 1;
+  const double r0 = g[LinDumpG_R0 + (tid < 9 ? tid : 0)];
+  const double al = g[LinDumpG_aL + (tid < 3 ? tid : 0)];
+  const double qa = g[LinDumpG_qacc + (tid < H1_NV ? tid : 0)];
+  const int ev = tid < H1_NB * 6 ? tid : 0;
+  const double vv = g[LinDumpG_v + ev], uu = g[LinDumpG_U + ev], aa = g[LinDumpG_a + ev];
+  const double di = g[LinDumpG_Dinv + (tid < H1_NB ? tid : 0)];
+  const double ia = g[LinDumpG_IA0inv + (tid < 36 ? tid : 0)];
+  const int i0 = (lane >= 1 && lane < H1_NB) ? lane : 1, i1 = lane < H1_NB ? lane : 0;
+  const double s = g[LinDumpG_sc + 2 * i0], c = g[LinDumpG_sc + 2 * i0 + 1];
+  double v6[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) v6[k] = g[LinDumpG_v + 6 * i1 + k];
+  const double xu = (tid < 64) ? xg[tid < H1_NX ? tid : 0] : ug[(tid - 64) < H1_NU ? tid - 64 : 0];
+  if (!(f1 && f2)) return false;
+  if (tid < H1_NX) L.x[tid] = xu;
+  if (tid >= 64 && tid < 64 + H1_NU) L.u_[tid - 64] = xu;
+  if (tid < 9) D.R0[tid] = r0;
+  if (tid < 3) D.aL[tid] = al;
+  if (tid < H1_NV) D.qacc[tid] = qa;
+  if (tid < H1_NB * 6) { (&D.v[0][0])[tid] = vv; (&L.u.m.U[0][0])[tid] = uu; (&Cc.a[0][0])[tid] = aa; }
+  if (tid < H1_NB) L.u.m.Dinv[tid] = di;
+  if (tid < 36) L.u.m.IA0inv[tid] = ia;
   if (wv == 0 && lane >= 1 && lane < H1_NB) {
     const int i = lane, a = H1_AXIS[i], b = (a + 1) % 3, d = (a + 2) % 3;
-    const double s = g[LinDumpG_sc + 2 * i], c = g[LinDumpG_sc + 2 * i + 1];
     for (int r = 0; r < 3; ++r) {
       const double fa = H1_RFIX[i][r][a], fb = H1_RFIX[i][r][b], fd = H1_RFIX[i][r][d];
       D.Rj[i][3 * r + a] = fa; D.Rj[i][3 * r + b] = fb * c + fd * s; D.Rj[i][3 * r + d] = fd * c - fb * s;
@@ -154,11 +171,11 @@ DEVFN void lin_load_dump2c(LinShared& L, LinContact& Cc, const double* g, int ti
   }
   if (wv == 1 && lane < H1_NB) {
     const int i = lane;
-    double v[6], Iv[6];
-    for (int k = 0; k < 6; ++k) v[k] = g[LinDumpG_v + 6 * i + k];
-    inertia_mul(i, v, Iv);
+    double Iv[6];
+    inertia_mul(i, v6, Iv);
     for (int k = 0; k < 6; ++k) L.Iv[i][k] = Iv[k];
   }
+  return true;
 }
 
 // one lane per foot: gravity offset and world up axis rotated down the leg, right-hand side of the constraint

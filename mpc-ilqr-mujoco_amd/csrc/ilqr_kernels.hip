@@ -137,16 +137,14 @@ __global__ void __launch_bounds__(128, 3) k_lin_tangent(DevState S, ProblemDev P
 // constraint-row tangents, and the final product is -Minv dT + G dlambda.
 __global__ void __launch_bounds__(128, 2) k_lin_tangent_c(DevState S, ProblemDev P, int mode) {
   const int t = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
-  if (!selected(S, b, mode)) return;
   __shared__ LinShared L;
   __shared__ LinContact Cc;
 #ifdef LIN_STAMP
   long long qlast = clock64();
 #endif
   const size_t knot = (size_t)b * S.N + t;
-  lin_load_dump2c(L, Cc, S.lin_dump + knot * LinDumpG_SIZE, tid);
-  if (tid < H1_NX) L.x[tid] = S.xbar[((size_t)b * (S.N + 1) + t) * H1_NX + tid];
-  if (tid >= 64 && tid < 64 + H1_NU) L.u_[tid - 64] = S.ubar[((size_t)b * S.N + t) * H1_NU + tid - 64];
+  if (!lin_load_dump2c(L, Cc, S.lin_dump + knot * LinDumpG_SIZE, tid, S.xbar + ((size_t)b * (S.N + 1) + t) * H1_NX, S.ubar + ((size_t)b * S.N + t) * H1_NU,
+                       mode == MASK_ALL ? nullptr : S.active + b, mode == MASK_RETRY ? S.need_retry + b : nullptr)) return;
   if (tid == 127) L.h = P.dyn.h;
   for (int e = tid; e < (H1_NV - 6) * LIN_LD; e += 128) (&L.dT[6][0])[e] = 0.0;
   __syncthreads();
