@@ -246,13 +246,19 @@ struct DumpSinkS {
     for (int k = 0; k < 6; ++k) { vv[k] = v[k]; aa[k] = a[k]; }
   }
 };
-__global__ void __launch_bounds__(64) k_lin_primal_s(DevState S, ProblemDev P, int mode) {
+__global__ void __launch_bounds__(64) k_lin_primal_s(DevState S, ProblemDev P, int mode, const int* list, const int* count) {
   extern __shared__ double lds[];
   const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const long knot = gid >> 1;
   const bool side = (gid & 1) != 0;
   if (knot >= (long)S.B * S.N) return;
-  const int t = (int)(knot % S.N), b = (int)(knot / S.N);
+  const int t = (int)(knot % S.N);
+  int b = (int)(knot / S.N);
+  if (list) {                        // compacted selection (DevState::order): position -> rollout
+    if (b >= *count) return;
+    b = list[b];
+    mode = MASK_ALL;
+  }
   const int f1 = mode == MASK_ALL ? 1 : S.active[b], f2 = mode == MASK_RETRY ? S.need_retry[b] : 1;   // requested with the knot's data, tested after
   const h1s::LaneLds L{lds, 64, (int)threadIdx.x};
   h1s::HalfX h; h1s::load_half(side, S.xbar + ((size_t)b * (S.N + 1) + t) * H1_NX, h);
@@ -267,7 +273,7 @@ __global__ void __launch_bounds__(64) k_lin_primal_s(DevState S, ProblemDev P, i
   for (int k = 0; k < 5; ++k) tau.tL[k] = h1s::clampu(u.uL[k], h1s::C_CTRLRANGE[h1s::jleg(side, k)]) - h1s::DAMPING * h.q.qdL[k];
 #pragma unroll
   for (int k = 0; k < 4; ++k) tau.tA[k] = h1s::clampu(u.uA[k], h1s::C_CTRLRANGE[h1s::jarm(side, k)]) - h1s::DAMPING * h.q.qdA[k];
-  double* g = S.lin_dump + (size_t)knot * LinDumpG_SIZE;
+  double* g = S.lin_dump + ((size_t)b * S.N + t) * LinDumpG_SIZE;
   DumpSinkS all{g};
   // pelvis and torso are computed on both lanes: only the left one stores them
   auto sink = [&](int i, const double* v, const double* a, double s, double c) { if (!side || (i != 0 && i != 11)) all(i, v, a, s, c); };
@@ -427,8 +433,8 @@ void launch_line_search_s(const DevState& S, const ProblemDev& P, int mode, hipS
   if (P.dyn.contact) hipLaunchKernelGGL(k_line_search_s<true>, dim3(cdiv_s((long)S.B * 16, 64)), dim3(64), DYN_LDS_BYTES_S, st, S, P, mode, list, count);
   else hipLaunchKernelGGL(k_line_search_s<false>, dim3(cdiv_s((long)S.B * 16, 64)), dim3(64), DYN_LDS_BYTES_S, st, S, P, mode, list, count);
 }
-void launch_lin_primal_s(const DevState& S, const ProblemDev& P, int mode, hipStream_t st) {
-  hipLaunchKernelGGL(k_lin_primal_s, dim3(cdiv_s((long)S.B * S.N * 2, 64)), dim3(64), DYN_LDS_BYTES_S, st, S, P, mode);
+void launch_lin_primal_s(const DevState& S, const ProblemDev& P, int mode, hipStream_t st, const int* list, const int* count) {
+  hipLaunchKernelGGL(k_lin_primal_s, dim3(cdiv_s((long)S.B * S.N * 2, 64)), dim3(64), DYN_LDS_BYTES_S, st, S, P, mode, list, count);
 }
 void launch_step_s(int count, const double* x, const double* u, const DynParams& dyn, double* xn, hipStream_t st, int stance_l, int stance_r) {
   hipLaunchKernelGGL(k_step_s, dim3(cdiv_s((long)count * 2, 64)), dim3(64), DYN_LDS_BYTES_S, st, count, x, u, dyn, xn, stance_l, stance_r);

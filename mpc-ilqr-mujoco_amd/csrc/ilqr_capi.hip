@@ -413,6 +413,8 @@ static int enqueue_solve(ilqr_hip_ctx* c, const DevState& S, const h1::ProblemDe
   // do): the count of rollouts active after iteration i (DevState::order_n, maintained by k_control) follows iteration i to the
   // host, which enqueues iteration i only after it has seen the count left by iteration i - 2 -- one full iteration stays
   // queued on the device meanwhile, so the device never waits for the host.  (ILQR_EE_GATE=0: always enqueue max_iter.)
+  // without the convergence exit every rollout stays active: the per-knot kernels then skip the selection altogether
+  const int sel_mode = c->early_exit ? ilqr::MASK_ACTIVE : ilqr::MASK_ALL;
   const bool gate = c->early_exit && S.order && early_exit_gate();
   if (gate) TRY(ensure_gate(c));
   c->iterations_enqueued = c->max_iter;
@@ -443,9 +445,9 @@ static int enqueue_solve(ilqr_hip_ctx* c, const DevState& S, const h1::ProblemDe
       { StageTimer T(c, 0, st3); ilqr::launch_rollout(Sr, P, ilqr::MASK_ACTIVE, 1, 0, S.Jbase, st3); }
       HIPCHK(c, hipEventRecord(ev_roll, st3));
     }
-    { StageTimer T(c, 2, st2); ilqr::launch_cost_quadratics(S, P, ilqr::MASK_ACTIVE, st2); }
+    { StageTimer T(c, 2, st2); ilqr::launch_cost_quadratics(S, P, sel_mode, st2, iter); }
     HIPCHK(c, hipEventRecord(ev_join, st2));
-    { StageTimer T(c, 1, st); ilqr::launch_linearize(S, P, ilqr::MASK_ACTIVE, c->jac_mode, c->fd_eps, st); }
+    { StageTimer T(c, 1, st); ilqr::launch_linearize(S, P, sel_mode, c->jac_mode, c->fd_eps, st, 3, iter); }
     HIPCHK(c, hipStreamWaitEvent(st, ev_join, 0));
     if (concurrent_roll) { HIPCHK(c, hipStreamWaitEvent(st, ev_roll, 0)); ilqr::launch_adopt_rollout(S, shadow, ilqr::MASK_ACTIVE, c->d_mismatch, st); }
     { StageTimer T(c, 3, st); ilqr::launch_backward(S, ilqr::MASK_ACTIVE, st, fold_h, iter); }                                  // :601

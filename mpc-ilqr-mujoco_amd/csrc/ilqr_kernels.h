@@ -57,8 +57,15 @@ struct DevState {
 
 void launch_rollout(const DevState& S, const h1::ProblemDev& P, int mode, int do_roll, int count_iter, double* cost_out, hipStream_t st);
 void launch_step(int count, const double* x, const double* u, const h1::DynParams& dyn, double* xn, hipStream_t st, int stance_l = 1, int stance_r = 1);
-void launch_linearize(const DevState& S, const h1::ProblemDev& P, int mode, int jac_mode, double eps, hipStream_t st, int phases = 3);
-void launch_cost_quadratics(const DevState& S, const h1::ProblemDev& P, int mode, hipStream_t st);
+void launch_linearize(const DevState& S, const h1::ProblemDev& P, int mode, int jac_mode, double eps, hipStream_t st, int phases = 3, int iter = -1);
+void launch_cost_quadratics(const DevState& S, const h1::ProblemDev& P, int mode, hipStream_t st, int iter = -1);
+// compacted list of the rollouts of a pass inside a solve (DevState::order), or nulls: MASK_ACTIVE at iteration iter -> list (iter, 0), MASK_RETRY -> (iter, 1)
+struct WorkList { const int* list; const int* count; };
+inline WorkList work_list(const DevState& S, int mode, int iter) {
+  if (!S.order || iter < 0 || mode == MASK_ALL) return WorkList{nullptr, nullptr};
+  const int slot = 2 * iter + (mode == MASK_RETRY ? 1 : 0);
+  return WorkList{S.order + (size_t)slot * S.B, S.order_n + slot};
+}
 void launch_backward(const DevState& S, int mode, hipStream_t st, double fold_h = 0.0, int iter = -1);
 double linearize_fold_h(const h1::ProblemDev& P, int jac_mode);
 void launch_line_search(const DevState& S, const h1::ProblemDev& P, int mode, hipStream_t st, int iter = -1);
@@ -88,7 +95,7 @@ void launch_lin_primal_r(const DevState& S, const h1::ProblemDev& P, int mode, h
 int dyn_kernels_set_attr();
 // dyn_split_kernels.hip: two lanes per rollout / candidate
 void launch_rollout_s(const DevState& S, const h1::ProblemDev& P, int mode, int do_roll, int count_iter, double* cost_out, hipStream_t st);
-void launch_lin_primal_s(const DevState& S, const h1::ProblemDev& P, int mode, hipStream_t st);
+void launch_lin_primal_s(const DevState& S, const h1::ProblemDev& P, int mode, hipStream_t st, const int* list = nullptr, const int* count = nullptr);
 void launch_line_search_s(const DevState& S, const h1::ProblemDev& P, int mode, hipStream_t st, const int* list = nullptr, const int* count = nullptr);
 int dyn_split_kernels_set_attr();
 void launch_step_s(int count, const double* x, const double* u, const h1::DynParams& dyn, double* xn, hipStream_t st, int stance_l, int stance_r);

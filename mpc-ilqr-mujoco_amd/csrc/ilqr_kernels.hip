@@ -91,8 +91,14 @@ __global__ void __launch_bounds__(64) k_step(int count, const double* x, const d
 // workgroups per CU before, now 6 x 2 waves): wave 0 accumulates the inverse-dynamics forces and sweeps the legs, wave 1 runs
 // the Minv sweeps and sweeps torso + arms; the Minv product is split by row tile, the 51 columns of A go to wave 0 and the 19
 // of B to wave 1.  A knot's critical path drops from ~107 k to ~65 k cycles and twice as many waves hide each other's latencies.
-__global__ void __launch_bounds__(128, 3) k_lin_tangent(DevState S, ProblemDev P, int mode) {
-  const int t = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+__global__ void __launch_bounds__(128, 3) k_lin_tangent(DevState S, ProblemDev P, int mode, const int* list, const int* count) {
+  const int t = blockIdx.x, tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+  int b = blockIdx.y;
+  if (list) {                        // compacted selection (DevState::order)
+    if (b >= *count) return;
+    b = list[b];
+    mode = MASK_ALL;
+  }
   __shared__ LinShared L;
 #ifdef LIN_STAMP
   long long qlast = clock64();
@@ -135,8 +141,14 @@ __global__ void __launch_bounds__(128, 3) k_lin_tangent(DevState S, ProblemDev P
 // primal dump is the free solve, the multipliers and the constrained accelerations are rebuilt here (twelve unit-wrench
 // lanes beside the 25 Minv lanes), the tangent sweeps carry the contact wrench as an external force and collect the
 // constraint-row tangents, and the final product is -Minv dT + G dlambda.
-__global__ void __launch_bounds__(128, 2) k_lin_tangent_c(DevState S, ProblemDev P, int mode) {
-  const int t = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+__global__ void __launch_bounds__(128, 2) k_lin_tangent_c(DevState S, ProblemDev P, int mode, const int* list, const int* count) {
+  const int t = blockIdx.x, tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+  int b = blockIdx.y;
+  if (list) {                        // compacted selection (DevState::order)
+    if (b >= *count) return;
+    b = list[b];
+    mode = MASK_ALL;
+  }
   __shared__ LinShared L;
   __shared__ LinContact Cc;
 #ifdef LIN_STAMP
@@ -657,15 +669,16 @@ void launch_step(int count, const double* x, const double* u, const DynParams& d
   hipLaunchKernelGGL(k_step, dim3(cdiv(count, 64)), dim3(64), 0, st, count, x, u, dyn, xn, stance_l, stance_r);
 }
 // phases: 1 = primal dump only, 2 = tangent sweeps / FD only, 3 = both
-void launch_linearize(const DevState& S, const ProblemDev& P, int mode, int jac_mode, double eps, hipStream_t st, int phases) {
+void launch_linearize(const DevState& S, const ProblemDev& P, int mode, int jac_mode, double eps, hipStream_t st, int phases, int iter) {
+  const WorkList w = work_list(S, mode, iter);
   if (jac_mode == 0 && !use_scalar_dyn()) {
     // primal dump: on two lanes per knot beside the two-lane rollout kernels, one lane per knot with ILQR_ROLLOUT=r
-    if (phases & 1) { if (g_var.rollout_split || P.dyn.contact) launch_lin_primal_s(S, P, mode, st); else launch_lin_primal_r(S, P, mode, st); }   // (contact mode: the dump is the free solve, see k_lin_tangent_c)
-    if ((phases & 2) && P.dyn.contact) hipLaunchKernelGGL(k_lin_tangent_c, dim3(S.N, S.B), dim3(128), 0, st, S, P, mode);
-    else if (phases & 2) hipLaunchKernelGGL(k_lin_tangent, dim3(S.N, S.B), dim3(128), 0, st, S, P, mode);
+    if (phases & 1) { if (g_var.rollout_split || P.dyn.contact) launch_lin_primal_s(S, P, mode, st, w.list, w.count); else launch_lin_primal_r(S, P, mode, st); }   // (contact mode: the dump is the free solve, see k_lin_tangent_c)
+    if ((phases & 2) && P.dyn.contact) hipLaunchKernelGGL(k_lin_tangent_c, dim3(S.N, S.B), dim3(128), 0, st, S, P, mode, w.list, w.count);
+    else if (phases & 2) hipLaunchKernelGGL(k_lin_tangent, dim3(S.N, S.B), dim3(128), 0, st, S, P, mode, w.list, w.count);
   } else if (jac_mode == 0 && !P.dyn.contact) {               // ILQR_DYN=s: the analytic kernels are constraint-free only
     if (phases & 1) launch_lin_primal_r(S, P, mode, st);
-    if (phases & 2) hipLaunchKernelGGL(k_lin_tangent, dim3(S.N, S.B), dim3(128), 0, st, S, P, mode);
+    if (phases & 2) hipLaunchKernelGGL(k_lin_tangent, dim3(S.N, S.B), dim3(128), 0, st, S, P, mode, w.list, w.count);
   } else if ((phases & 2) && !use_scalar_dyn()) {
     launch_linearize_fd_s(S, P, mode, eps, st);       // forward differences on the two-lane step (any contact mode)
   } else if (phases & 2) {

@@ -121,8 +121,14 @@ DEVFN void d2R_sel(int k, int l, double* D) {
 // Two waves per knot share the knot's LDS record (20.4 KB bound the occupancy at 8 one-wave workgroups per CU).  `lane` runs
 // over 0..127: the lane-parallel phases 1-5 have at most 64 work items and stay on wave 0 (wave 1 waits at the barriers),
 // the Hessian -- half of the kernel -- is split: patch entries over 128 lanes, two accumulator row tiles per wave.
-__global__ void __launch_bounds__(128, QUAD_WAVES) k_cost_quadratics(DevState S, ProblemDev P, int mode) {
-  const int t = blockIdx.x, b = blockIdx.y, lane = threadIdx.x, wv = lane >> 6;
+__global__ void __launch_bounds__(128, QUAD_WAVES) k_cost_quadratics(DevState S, ProblemDev P, int mode, const int* list, const int* count) {
+  const int t = blockIdx.x, lane = threadIdx.x, wv = lane >> 6;
+  int b = blockIdx.y;
+  if (list) {                        // compacted selection (DevState::order): no per-rollout flags to fetch, unselected workgroups leave on one cached scalar
+    if (b >= *count) return;
+    b = list[b];
+    mode = MASK_ALL;
+  }
   const int N = S.N;
   const bool term = (t == N);
   __shared__ QuadLds L;
@@ -613,8 +619,9 @@ __global__ void __launch_bounds__(128, QUAD_WAVES) k_cost_quadratics(DevState S,
   QSTAMP(8)
 }
 
-void launch_cost_quadratics(const DevState& S, const ProblemDev& P, int mode, hipStream_t st) {
-  hipLaunchKernelGGL(k_cost_quadratics, dim3(S.N + 1, S.B), dim3(128), 0, st, S, P, mode);
+void launch_cost_quadratics(const DevState& S, const ProblemDev& P, int mode, hipStream_t st, int iter) {
+  const WorkList w = work_list(S, mode, iter);
+  hipLaunchKernelGGL(k_cost_quadratics, dim3(S.N + 1, S.B), dim3(128), 0, st, S, P, mode, w.list, w.count);
 }
 
 }  // namespace ilqr
