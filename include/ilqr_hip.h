@@ -174,6 +174,9 @@ int ilqr_hip_step_stance(ilqr_hip_ctx* ctx, int count, const double* x, const do
    4 lineSearch, 5 control, 6 backwardPass (lambda-retry launch), 7 lineSearch (lambda-retry launch);
    requires ilqr_hip_enable_profiling(ctx, 1) before the solve */
 int ilqr_hip_enable_profiling(ilqr_hip_ctx* ctx, int on);
+/* Restrict the event pairs to the stages whose bit (stage index as above) is set in `mask` (default 0xFF: all).  Every timed
+   launch costs two event records on its stream: all eight stages together add 1.3 ms to a 95 ms solve at B = 4096. */
+int ilqr_hip_set_profiled_stages(ilqr_hip_ctx* ctx, unsigned mask);
 /* Diagnostic of the concurrent nominal re-rollout (iterations >= 1 of a solve roll the nominal trajectory beside the
    linearisation, ilqr.cpp:563 vs :576): number of trajectory elements of the last solve in which the re-rolled trajectory
    differed bit-wise from the one the linearisation saw.  0 means the launch order is equivalent to the reference's. */

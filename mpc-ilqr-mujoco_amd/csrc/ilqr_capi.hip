@@ -57,6 +57,7 @@ struct ilqr_hip_ctx {
   std::string err;
   // profiling
   int profiling = 0;
+  unsigned prof_mask = 0xFFu;             // stages that get event pairs while profiling is on (ilqr_hip_set_profiled_stages)
   struct Span { int stage; hipEvent_t a, b; };
   std::vector<Span> spans;
   std::vector<hipEvent_t> pool;
@@ -97,8 +98,8 @@ static hipEvent_t next_event(ilqr_hip_ctx* c) {
 }
 struct StageTimer {
   ilqr_hip_ctx* c; int stage; hipStream_t st; hipEvent_t a{}, b{};
-  StageTimer(ilqr_hip_ctx* c_, int s, hipStream_t st_ = nullptr) : c(c_), stage(s), st(st_ ? st_ : c_->stream) { if (c->profiling) { a = next_event(c); b = next_event(c); if (a && b) hipEventRecord(a, st); } }
-  ~StageTimer() { if (c->profiling && a && b) { hipEventRecord(b, st); c->spans.push_back({stage, a, b}); } }
+  StageTimer(ilqr_hip_ctx* c_, int s, hipStream_t st_ = nullptr) : c(c_), stage(s), st(st_ ? st_ : c_->stream) { if (c->profiling && ((c->prof_mask >> s) & 1u)) { a = next_event(c); b = next_event(c); if (a && b) hipEventRecord(a, st); } }
+  ~StageTimer() { if (a && b) { hipEventRecord(b, st); c->spans.push_back({stage, a, b}); } }
 };
 
 static inline void enter(const ilqr_hip_ctx* c) { hipSetDevice(c->device); ilqr::refresh_variants(); }
@@ -796,6 +797,7 @@ int ilqr_hip_gather_first_knot(ilqr_hip_ctx* c, int root, int with_gains, double
 }
 
 int ilqr_hip_enable_profiling(ilqr_hip_ctx* c, int on) { if (!c) return ILQR_ERR_ARG; c->profiling = on ? 1 : 0; return ILQR_OK; }
+int ilqr_hip_set_profiled_stages(ilqr_hip_ctx* c, unsigned mask) { if (!c) return ILQR_ERR_ARG; c->prof_mask = mask & 0xFFu; return ILQR_OK; }
 int ilqr_hip_get_stage_ms(ilqr_hip_ctx* c, double* ms, double* launches) {
   if (!c || !ms) return ILQR_ERR_ARG;
   for (int i = 0; i < 8; ++i) { ms[i] = c->stage_ms[i]; if (launches) launches[i] = c->stage_launches[i]; }

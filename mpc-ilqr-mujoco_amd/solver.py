@@ -34,7 +34,7 @@ EXPORTS = [
     "ilqr_hip_set_trajectory", "ilqr_hip_stage_rollout", "ilqr_hip_stage_linearize", "ilqr_hip_stage_cost_quadratics",
     "ilqr_hip_stage_backward_pass", "ilqr_hip_stage_line_search", "ilqr_hip_stage_total_cost",
     "ilqr_hip_get_linearization", "ilqr_hip_set_linearization", "ilqr_hip_get_quadratics", "ilqr_hip_set_quadratics",
-    "ilqr_hip_get_value_function", "ilqr_hip_step", "ilqr_hip_step_stance", "ilqr_hip_set_contact_mode", "ilqr_hip_enable_profiling", "ilqr_hip_get_stage_ms", "ilqr_hip_get_adopt_mismatches", "ilqr_hip_get_iterations_enqueued",
+    "ilqr_hip_get_value_function", "ilqr_hip_step", "ilqr_hip_step_stance", "ilqr_hip_set_contact_mode", "ilqr_hip_enable_profiling", "ilqr_hip_get_stage_ms", "ilqr_hip_get_adopt_mismatches", "ilqr_hip_get_iterations_enqueued", "ilqr_hip_set_profiled_stages",
     "ilqr_hip_payload_width", "ilqr_hip_comm_get_unique_id", "ilqr_hip_comm_init", "ilqr_hip_comm_destroy", "ilqr_hip_comm_world", "ilqr_hip_comm_rank",
     "ilqr_hip_gather_first_knot",
     "ilqr_hip_reference_kinematics", "ilqr_hip_reference_com_velocity", "ilqr_hip_foot_clearance", "ilqr_hip_gravity_compensation", "ilqr_hip_stream",
@@ -341,6 +341,14 @@ class BatchedILQR:
 
     def enable_profiling(self, on=True):
         self._chk(self.L.ilqr_hip_enable_profiling(self.h, int(bool(on))))
+
+    STAGE_KEYS = ["iLQR_computeCost+forwardRollout", "iLQR_linearization", "iLQR_costQuadratics", "iLQR_backwardPass", "iLQR_lineSearch", "iLQR_control",
+                  "iLQR_backwardPass_retry", "iLQR_lineSearch_retry"]
+
+    def set_profiled_stages(self, keys=None):
+        """Time only the given stages (keys of stage_ms()) while profiling is on; None = all."""
+        mask = 0xFF if keys is None else sum(1 << self.STAGE_KEYS.index(k) for k in keys)
+        self._chk(self.L.ilqr_hip_set_profiled_stages(self.h, C.c_uint(mask)))
 
     def adopt_mismatches(self):
         """Elements in which the concurrent nominal re-rollouts of the last solve differed from the trajectory they replaced."""

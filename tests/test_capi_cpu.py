@@ -76,6 +76,7 @@ def test_multi_gpu_entry_points_validate_their_arguments():
     assert L.ilqr_hip_comm_world(None) == -1 and L.ilqr_hip_comm_rank(None) == -1
     assert L.ilqr_hip_get_adopt_mismatches(None, None) == 1
     assert L.ilqr_hip_get_iterations_enqueued(None) == -1
+    assert L.ilqr_hip_set_profiled_stages(None, 0xFF) == 1
 
 
 def test_cpp_multi_gpu_demo_builds():
