@@ -252,10 +252,10 @@ __global__ void __launch_bounds__(64) k_traj_cost_sum(DevState S, int mode, int 
   for (int t = 0; t <= S.N; ++t) c += ck[t];
   cost_out[cand] = c;
 }
-void launch_cand_costs(const DevState& S, const ProblemDev& P, int mode, hipStream_t st) {
+void launch_cand_costs(const DevState& S, const ProblemDev& P, int mode, hipStream_t st, bool with_sum) {
   const long total = (long)S.B * 8 * (S.N + 1);
   hipLaunchKernelGGL(k_traj_knot_cost, dim3((unsigned)((total + 63) / 64)), dim3(64), 0, st, S, P, mode, S.xcand, S.ucand, 3, 0);
-  hipLaunchKernelGGL(k_traj_cost_sum, dim3((unsigned)(((long)S.B * 8 + 63) / 64)), dim3(64), 0, st, S, mode, 3, 0, S.cand_cost);
+  if (with_sum) hipLaunchKernelGGL(k_traj_cost_sum, dim3((unsigned)(((long)S.B * 8 + 63) / 64)), dim3(64), 0, st, S, mode, 3, 0, S.cand_cost);
 }
 // computeTotalCost of the nominal trajectories (S.xbar, S.ubar) into cost_out[B], same kernels, same summation order
 void launch_nominal_costs(const DevState& S, const ProblemDev& P, int mode, double* cost_out, hipStream_t st) {

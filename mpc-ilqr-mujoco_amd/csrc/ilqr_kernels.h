@@ -69,7 +69,8 @@ inline WorkList work_list(const DevState& S, int mode, int iter) {
 void launch_backward(const DevState& S, int mode, hipStream_t st, double fold_h = 0.0, int iter = -1);
 double linearize_fold_h(const h1::ProblemDev& P, int jac_mode);
 void launch_line_search(const DevState& S, const h1::ProblemDev& P, int mode, hipStream_t st, int iter = -1);
-void launch_control(const DevState& S, int phase, int iter, double tol, int early_exit, hipStream_t st);
+void launch_control(const DevState& S, int phase, int iter, double tol, int early_exit, hipStream_t st, int sum_knots = 0);
+bool ls_costs_per_knot(const h1::ProblemDev& P);
 void launch_solve_begin(const DevState& S, hipStream_t st);
 void launch_adopt_rollout(const DevState& S, const double* shadow, int mode, unsigned long long* mismatches, hipStream_t st);
 void launch_warm_shift(const DevState& S, const double* prev_x, const double* prev_u, hipStream_t st);
@@ -88,7 +89,7 @@ size_t lin_dump_doubles();
 void launch_rollout_r(const DevState& S, const h1::ProblemDev& P, int mode, int do_roll, int count_iter, double* cost_out, hipStream_t st);
 void launch_step_r(int count, const double* x, const double* u, const h1::DynParams& dyn, double* xn, hipStream_t st);
 void launch_last_step_r(const DevState& S, const h1::ProblemDev& P, hipStream_t st);
-void launch_cand_costs(const DevState& S, const h1::ProblemDev& P, int mode, hipStream_t st);
+void launch_cand_costs(const DevState& S, const h1::ProblemDev& P, int mode, hipStream_t st, bool with_sum = true);
 void launch_nominal_costs(const DevState& S, const h1::ProblemDev& P, int mode, double* cost_out, hipStream_t st);
 void launch_line_search_r(const DevState& S, const h1::ProblemDev& P, int mode, hipStream_t st);
 void launch_lin_primal_r(const DevState& S, const h1::ProblemDev& P, int mode, hipStream_t st);

@@ -445,7 +445,7 @@ __device__ __forceinline__ void wave_copy(double* dst, const double* src, int le
   }
 }
 #define CTRL_WAVES 16
-__global__ void __launch_bounds__(64 * CTRL_WAVES) k_control(DevState S, int phase, int iter, double tol, int early_exit) {
+__global__ void __launch_bounds__(64 * CTRL_WAVES) k_control(DevState S, int phase, int iter, double tol, int early_exit, int sum_knots) {
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int b = blockIdx.x * CTRL_WAVES + wv;
   __shared__ int s_accept[CTRL_WAVES], s_slot[CTRL_WAVES], s_base[2];
@@ -454,26 +454,41 @@ __global__ void __launch_bounds__(64 * CTRL_WAVES) k_control(DevState S, int pha
   if (run && phase == 0 && !S.active[b]) run = false;
   if (run && phase == 1 && !(S.active[b] && S.need_retry[b])) run = false;
   if (lane == 0) { s_accept[wv] = -1; s_slot[wv] = -1; }
+  // sum_knots: the candidates' costs arrive as per-knot costs (k_traj_knot_cost); lane a adds candidate a's in knot order -- the
+  // order of a sequential accumulation along the rollout, as k_traj_cost_sum does (one launch and one launch gap less per pass)
+  double csum = 0.0;
+  if (run && sum_knots && lane < 8) {
+    const double* ck = S.cand_knot + ((size_t)b * 8 + lane) * (N + 1);
+    for (int t = 0; t <= N; ++t) csum += ck[t];
+    S.cand_cost[(size_t)b * 8 + lane] = csum;
+  }
+  double cc[8];
+#pragma unroll
+  for (int a = 0; a < 8; ++a) {
+    const int lo = __shfl(__double2loint(csum), a), hi = __shfl(__double2hiint(csum), a);
+    cc[a] = __hiloint2double(hi, lo);
+  }
   if (run && lane == 0) {
     if (phase == 0) S.iters[b] += 1;
     const double base = S.Jbase[b];
     int acc = -1;
-    double cc[8];
+    if (!sum_knots) {
 #pragma unroll
-    for (int a = 0; a < 8; ++a) cc[a] = S.cand_cost[(size_t)b * 8 + a];       // (one batch; inside the scan each load would wait for the previous test)
+      for (int a = 0; a < 8; ++a) cc[a] = S.cand_cost[(size_t)b * 8 + a];     // (one batch; inside the scan each load would wait for the previous test)
+    }
 #pragma unroll
     for (int a = 7; a >= 0; --a) if (cc[a] < base - 1e-6) acc = a;            // the first (largest) alpha that improves
     s_accept[wv] = acc;
     S.improved[b] = acc >= 0;
     S.alpha_idx[b] = acc;
     if (phase == 2) {
-      S.ls_cost[b] = acc >= 0 ? S.cand_cost[(size_t)b * 8 + acc] : base;
+      S.ls_cost[b] = acc >= 0 ? cc[acc < 0 ? 0 : acc] : base;
     } else {
       const double lam_used = S.lambda[b];
       const int tr = iter;  // trace slot
       if (acc >= 0) {
         const double Jprev = S.J[b];
-        const double Jn = S.cand_cost[(size_t)b * 8 + acc];
+        const double Jn = cc[acc];
         S.J[b] = Jn;
         S.Jbase[b] = Jn;   // the accepted candidate is the next nominal trajectory: its cost is the next baseline
         S.lambda[b] = fmax(lam_used / 2.0, 1e-6);
@@ -711,15 +726,17 @@ void launch_line_search(const DevState& S, const ProblemDev& P, int mode, hipStr
     if (g_var.ls_split || P.dyn.contact) {
       const int slot = (S.order && iter >= 0 && mode != MASK_ALL) ? 2 * iter + (mode == MASK_RETRY ? 1 : 0) : -1;      // as launch_backward
       launch_line_search_s(S, P, mode, st, slot >= 0 ? S.order + (size_t)slot * S.B : nullptr, slot >= 0 ? S.order_n + slot : nullptr);
-      launch_cand_costs(S, P, mode, st);
+      launch_cand_costs(S, P, mode, st, iter < 0);      // (inside a solve k_control adds the knot costs up)
     }   // candidates' costs: all knots in parallel
     else launch_line_search_r(S, P, mode, st);                                                  // (the one-lane kernel sums its own)
     return;
   }
   hipLaunchKernelGGL(k_line_search, dim3(cdiv((long)S.B * 8, 64)), dim3(64), 0, st, S, P, mode);
 }
-void launch_control(const DevState& S, int phase, int iter, double tol, int early_exit, hipStream_t st) {
-  hipLaunchKernelGGL(k_control, dim3(cdiv(S.B, CTRL_WAVES)), dim3(64 * CTRL_WAVES), 0, st, S, phase, iter, tol, early_exit);
+// inside a solve the two-lane line search leaves per-knot costs behind and k_control sums them itself (ls_costs_per_knot)
+bool ls_costs_per_knot(const ProblemDev& P) { return !use_scalar_dyn() && (g_var.ls_split || P.dyn.contact); }
+void launch_control(const DevState& S, int phase, int iter, double tol, int early_exit, hipStream_t st, int sum_knots) {
+  hipLaunchKernelGGL(k_control, dim3(cdiv(S.B, CTRL_WAVES)), dim3(64 * CTRL_WAVES), 0, st, S, phase, iter, tol, early_exit, sum_knots);
 }
 void launch_solve_begin(const DevState& S, hipStream_t st) { hipLaunchKernelGGL(k_solve_begin, dim3(cdiv(S.B, 64)), dim3(64), 0, st, S); }
 void launch_adopt_rollout(const DevState& S, const double* shadow, int mode, unsigned long long* mismatches, hipStream_t st) { hipLaunchKernelGGL(k_adopt_rollout, dim3(S.B), dim3(64), 0, st, S, shadow, mode, mismatches); }
