@@ -56,6 +56,27 @@ __device__ __attribute__((noinline)) void step_stance_shared(h1s::HalfX* hp, con
 // one step of either kind; `st` = stance flags (left, right) of the knot being stepped
 // (compile-time switch: the constraint-free instantiation of a kernel contains no call and no address-taken state -- with a
 // run-time branch the mere presence of the call cost the headline's line search 20 %)
+DEVFN void pin(double& v) { asm volatile("" : "+v"(v)); }
+DEVFN void pin_half(h1s::HalfX& h) {
+#pragma unroll
+  for (int k = 0; k < 3; ++k) pin(h.p[k]);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) pin(h.quat[k]);
+#pragma unroll
+  for (int k = 0; k < 6; ++k) pin(h.vb[k]);
+  pin(h.q.th11); pin(h.q.qd11);
+#pragma unroll
+  for (int k = 0; k < 5; ++k) { pin(h.q.thL[k]); pin(h.q.qdL[k]); }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { pin(h.q.thA[k]); pin(h.q.qdA[k]); }
+}
+DEVFN void pin_half_u(h1s::HalfU& u) {
+  pin(u.u11);
+#pragma unroll
+  for (int k = 0; k < 5; ++k) pin(u.uL[k]);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) pin(u.uA[k]);
+}
 template <bool CONTACT>
 DEVFN void step_any(bool side, h1s::HalfX& h, const h1s::HalfU& u, const DynParams& dyn, const int* st, const h1s::LaneLds& L) {
   if constexpr (CONTACT) step_stance_shared(&h, &u, dyn.h, dyn.g[0], dyn.g[1], dyn.g[2], dyn.soft, dyn.contact, st[0], st[1]);
@@ -63,7 +84,14 @@ DEVFN void step_any(bool side, h1s::HalfX& h, const h1s::HalfU& u, const DynPara
     // (the step size behind an opaque barrier as well: with h a loop invariant the articulated quantities of the chains' leaf
     // bodies -- constants plus the armature term h * damping -- are hoisted out of the knot loop, spilled and reloaded per step)
     double dt = dyn.h; asm volatile("" : "+s"(dt));
-    h1s::step(side, h, u, dt, dyn.g, L);
+    // Opaque boundary around the step: inlined into different kernels the same source is otherwise fused / scheduled together
+    // with whatever surrounds it (the feedback law in the line search, plain loads in the rollout), and the re-rollout of an
+    // accepted candidate can differ from it in the last bit of a few entries.  With every input and output pinned the step is
+    // the same expression graph in every kernel (ilqr_hip_get_adopt_mismatches stays 0; GPU tests).
+    h1s::HalfU uo = u;
+    pin_half(h); pin_half_u(uo);
+    h1s::step(side, h, uo, dt, dyn.g, L);
+    pin_half(h);
   }
 }
 
@@ -84,17 +112,29 @@ __global__ void __launch_bounds__(64) k_line_search_s(DevState S, ProblemDev P, 
   const int gid = blockIdx.x * blockDim.x + threadIdx.x;
   const int ai = (gid >> 1) & 7;
   const bool side = (gid & 1) != 0;
+  // No lane leaves early: the feedback below is an MFMA product over the whole wave (every lane supplies operands of every
+  // rollout of the wave), so the 16 lanes of a rollout that is not selected run along on a valid rollout and skip their stores.
   int b = gid >> 4;
+  bool live;
   if (list) {                          // compacted selection (DevState::order): the selected rollouts fill the first waves
-    if (b >= *count) return;
-    b = list[b];
-  } else if (b >= S.B || !sel_s(S, b, mode)) return;
+    const int cnt = *count;
+    live = b < cnt;
+    b = list[live ? b : 0];
+  } else {
+    live = b < S.B;
+    b = live ? b : S.B - 1;
+    live = live && sel_s(S, b, mode);
+  }
+  if (!__any(live)) return;
   const int lane0 = threadIdx.x;
   const int N = S.N, n = H1_NX, m = H1_NU;
   const double alpha = ALPHAS_S[ai];
-  const bool b8 = (ai & 4) != 0, b4 = (ai & 2) != 0, b2 = (ai & 1) != 0;
   h1s::HalfX h; h1s::load_half(side, S.x0 + (size_t)b * n, h);
-  h1s::store_half(side, h, S.xcand + ((size_t)b * 8 + ai) * (N + 1) * n);
+  if (live) h1s::store_half(side, h, S.xcand + ((size_t)b * 8 + ai) * (N + 1) * n);
+  // rollouts of the wave's four 16-lane groups (for the K_t operands every lane fetches for every group)
+  int bw[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) bw[r] = __shfl(b, 16 * r);
 #ifdef LS_STAMP
   long long ph[8] = {0}; long long tl = clock64();
 #endif
@@ -142,51 +182,65 @@ __global__ void __launch_bounds__(64) k_line_search_s(DevState S, ProblemDev P, 
       lds[(H1_NQ + 6 + 11 + k) * 64 + sa + col] = h.q.qdA[k] - xh.q.qdA[k];
     }
     __syncthreads();
-    // each side evaluates the controls it owns (left: leg 0..4, torso 10, arm 11..14; right: leg 5..9, arm 15..18): the 8
-    // lanes of a side split the columns of K_t (lane alpha owns j = alpha, alpha + 8, ...), multiply with the deviations of
-    // all 8 candidates and reduce-scatter over the alphas in three exchange steps -- nothing crosses the pair
-    double dxs[7][8];   // dx_{8 q + alpha} of the 8 candidates of this rollout
+    // ---- U_r = K_t,r dX_r on v_mfma_f64_16x16x4_f64, one product per rollout r of the wave (19 x 51 x 8, padded 32 x 52 x 16):
+    //   A (16 x 4 per k-step s, row tile I): lane l = K_t[16 I + (l & 15)][4 s + (l >> 4)]  straight from HBM (rows past 18 clamped)
+    //   B (4 x 16):                          lane l = dx_{4 s + (l >> 4)} of candidate l & 7   from the exchange rows in LDS
+    //   D lane l register q = U[16 I + 4 q + (l >> 4)][candidate l & 15]                       -> LDS rows 52.. -> the owning lanes
+    // 104 MFMA per step instead of ~1900 VALU instructions (a lone wave pays 8 cycles for each of those, 64 for an MFMA); the
+    // operands of rollout r + 2 are requested before the products of rollout r start.
+    {
+      typedef double v4d_s __attribute__((ext_vector_type(4)));
+      const int lk = lane >> 4, lr = lane & 15;
+      const int rowA1 = (16 + lr) < m ? (16 + lr) : (m - 1);
+      const unsigned offA0 = (unsigned)(lr * n + lk), offA1 = (unsigned)(rowA1 * n + lk);
+      const int offB = lk * 64 + 2 * (lr & 7);
+      constexpr int UROW = 52;                        // LDS rows 52..70: the 19 feedback terms, column = the pair's
+      double ka[3][2][13];
 #pragma unroll
-    for (int q = 0; q < 7; ++q) {
-      const int j = 8 * q + ai;
+      for (int r = 0; r < 2; ++r) {
+        const double* Kt = S.K + ((size_t)bw[r] * N + t) * m * n;
 #pragma unroll
-      for (int a = 0; a < 8; ++a) dxs[q][a] = (j < H1_NX) ? lds[j * 64 + a8 + 2 * a] : 0.0;
+        for (int sk = 0; sk < 13; ++sk) { ka[r][0][sk] = (Kt + 4 * sk)[offA0]; ka[r][1][sk] = (Kt + 4 * sk)[offA1]; }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (r + 2 < 4) {
+          const double* Kt = S.K + ((size_t)bw[r + 2] * N + t) * m * n;
+#pragma unroll
+          for (int sk = 0; sk < 13; ++sk) { ka[(r + 2) % 3][0][sk] = (Kt + 4 * sk)[offA0]; ka[(r + 2) % 3][1][sk] = (Kt + 4 * sk)[offA1]; }
+        }
+        v4d_s d0 = {0.0, 0.0, 0.0, 0.0}, d1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int sk = 0; sk < 13; ++sk) {
+          double bv = lds[4 * sk * 64 + 16 * r + offB];
+          if (sk == 12) bv = lk == 3 ? 0.0 : bv;              // column 51 does not exist
+          d0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ka[r % 3][0][sk], bv, d0, 0, 0, 0);
+          d1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ka[r % 3][1][sk], bv, d1, 0, 0, 0);
+        }
+        if (lr < 8) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) lds[(UROW + 4 * q + lk) * 64 + 16 * r + 2 * lr] = d0[q];
+          if (lk < 3) lds[(UROW + 16 + lk) * 64 + 16 * r + 2 * lr] = d1[0];
+        }
+      }
+      __syncthreads();
+      LSS(0)
     }
-    __syncthreads();   // the dynamics step below reuses these LDS columns
-    LSS(0)
     h1s::HalfU u;
-    u.u11 = 0.0;
 #pragma unroll
     for (int k = 0; k < 10; ++k) {
       // k = 0..4 leg, 5..8 arm, 9 torso (left side only; the right side repeats its last arm row and discards it)
       const int row = k < 5 ? h1s::jleg(side, k) : (k < 9 ? h1s::jarm(side, k - 5) : (side ? 18 : 10));
-      const double* Kr = Kg + ((size_t)t * m + row) * n;
-      double kv[7];
-#pragma unroll
-      for (int q = 0; q < 7; ++q) { const int j = 8 * q + ai; kv[q] = (j < H1_NX) ? Kr[j] : 0.0; }
-      double acc[8];
-#pragma unroll
-      for (int a = 0; a < 8; ++a) acc[a] = 0.0;
-#pragma unroll
-      for (int q = 0; q < 7; ++q)
-#pragma unroll
-        for (int a = 0; a < 8; ++a) acc[a] += kv[q] * dxs[q][a];
-      // reduce over the 8 same-side lanes, scatter by alpha (lane bits 3, 2, 1)
-      double r1[4], r2[2];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) { const double keep = b8 ? acc[4 + q] : acc[q], send = b8 ? acc[q] : acc[4 + q]; r1[q] = keep + shfl_xor_f64(send, 8); }
-#pragma unroll
-      for (int q = 0; q < 2; ++q) { const double keep = b4 ? r1[2 + q] : r1[q], send = b4 ? r1[q] : r1[2 + q]; r2[q] = keep + shfl_xor_f64(send, 4); }
-      const double keep = b2 ? r2[1] : r2[0], send = b2 ? r2[0] : r2[1];
-      const double sfb = keep + shfl_xor_f64(send, 2);
+      const double sfb = lds[(52 + row) * 64 + col];
       const double ubase = k < 5 ? ubh.uL[k < 5 ? k : 0] : (k < 9 ? ubh.uA[k < 9 && k >= 5 ? k - 5 : 0] : ubh.u11);
       const double kbase = k < 5 ? kfh.uL[k < 5 ? k : 0] : (k < 9 ? kfh.uA[k < 9 && k >= 5 ? k - 5 : 0] : kfh.u11);
       const double ui = ubase + alpha * kbase + sfb;
       if (k < 5) u.uL[k < 5 ? k : 0] = ui;
       else if (k < 9) u.uA[(k >= 5 && k < 9) ? k - 5 : 0] = ui;
       else u.u11 = side ? 0.0 : ui;
-      if (k < 9 || !side) uc[t * m + row] = ui;
+      if (live && (k < 9 || !side)) uc[t * m + row] = ui;
     }
+    __syncthreads();   // the dynamics step below reuses these LDS rows
     u.u11 = h1s::pair_sum(u.u11);     // torso control: from the left lane to both
     LSS(1)
     LSS(2)
@@ -194,7 +248,7 @@ __global__ void __launch_bounds__(64) k_line_search_s(DevState S, ProblemDev P, 
     const bool side_t = sd != 0;
     step_any<CONTACT>(side_t, h, u, P.dyn, P.stance + b * P.stance_stride + 2 * t, L);
     LSS(3)
-    h1s::store_half(side, h, xc + (t + 1) * n);
+    if (live) h1s::store_half(side, h, xc + (t + 1) * n);
     LSS(4)
   }
   // the candidates' costs are evaluated afterwards, all knots in parallel (launch_cand_costs, dyn_kernels.hip)
