@@ -62,6 +62,45 @@ template <int I> constexpr bool rfix_identity() {
 #define CM(k) SD(IL, IR, C_COM[IL][k], C_COM[IR][k])
 #define IN(r, c) SD(IL, IR, C_INERTIA[IL][r][c], C_INERTIA[IR][r][c])
 #define MS SD(IL, IR, C_MASS[IL], C_MASS[IR])
+// The model's constant matrices are full of exact zeros (axis-aligned frame rotations, offsets along one axis, diagonal
+// inertia tensors) and IEEE semantics forbid the compiler to drop `0 * x` or `x + 0` (x could be NaN / Inf, the zero signed):
+// 15 % of the fp64 instructions of a dynamics step carried a literal 0.  The primitives below leave those terms out at compile
+// time (a term is dropped only where the constant is zero on BOTH sides of the mirror pair); what remains is evaluated in the
+// same order as before.
+#define ZP(k) (C_POS[IL][k] == 0.0 && C_POS[IR][k] == 0.0)
+#define ZC(k) (C_COM[IL][k] == 0.0 && C_COM[IR][k] == 0.0)
+#define ZR(r, c) (C_RFIX[IL][r][c] == 0.0 && C_RFIX[IR][r][c] == 0.0)
+#define ZI(r, c) (C_INERTIA[IL][r][c] == 0.0 && C_INERTIA[IR][r][c] == 0.0)
+// c0 x0 + c1 x1 + c2 x2 without the terms whose constant is zero
+template <bool Z0, bool Z1, bool Z2> DEVFN double dot3z(double c0, double c1, double c2, double x0, double x1, double x2) {
+  if constexpr (Z0 && Z1 && Z2) return 0.0;
+  else if constexpr (Z1 && Z2) return c0 * x0;
+  else if constexpr (Z0 && Z2) return c1 * x1;
+  else if constexpr (Z0 && Z1) return c2 * x2;
+  else if constexpr (Z2) return c0 * x0 + c1 * x1;
+  else if constexpr (Z1) return c0 * x0 + c2 * x2;
+  else if constexpr (Z0) return c1 * x1 + c2 * x2;
+  else return c0 * x0 + c1 * x1 + c2 * x2;
+}
+// a x - b y without the products whose constant (a, b) is zero
+template <bool ZA, bool ZB> DEVFN double diffz(double a, double x, double b, double y) {
+  if constexpr (ZA && ZB) return 0.0;
+  else if constexpr (ZB) return a * x;
+  else if constexpr (ZA) return -(b * y);
+  else return a * x - b * y;
+}
+template <bool Z> DEVFN double addz(double x, double t) { if constexpr (Z) return x; else return x + t; }
+template <bool Z> DEVFN double subz(double x, double t) { if constexpr (Z) return x; else return x - t; }
+// o = r x v and o = v x r for a constant r whose zero components are known (ZX, ZY, ZZ); component k of either is identically
+// zero when the two OTHER components of r are
+template <bool ZX, bool ZY, bool ZZ> DEVFN void cross_cv(double rx, double ry, double rz, const double* v, double* o) {
+  const double o0 = diffz<ZY, ZZ>(ry, v[2], rz, v[1]), o1 = diffz<ZZ, ZX>(rz, v[0], rx, v[2]), o2 = diffz<ZX, ZY>(rx, v[1], ry, v[0]);
+  o[0] = o0; o[1] = o1; o[2] = o2;
+}
+template <bool ZX, bool ZY, bool ZZ> DEVFN void cross_vc(double rx, double ry, double rz, const double* v, double* o) {
+  const double o0 = diffz<ZZ, ZY>(rz, v[1], ry, v[2]), o1 = diffz<ZX, ZZ>(rx, v[2], rz, v[0]), o2 = diffz<ZY, ZX>(ry, v[0], rx, v[1]);
+  o[0] = o0; o[1] = o1; o[2] = o2;
+}
 
 // y = Rj x with Rj = Rfix * Rot(AX, theta) (child -> parent coordinates)
 template <int IL, int IR> DEVFN void rot(bool side, const double* x, double s, double c, double* y) {
@@ -71,9 +110,9 @@ template <int IL, int IR> DEVFN void rot(bool side, const double* x, double s, d
   t[a] = x[a]; t[b] = c * x[b] - s * x[d]; t[d] = s * x[b] + c * x[d];
   if constexpr (rfix_identity<IL>()) { y[0] = t[0]; y[1] = t[1]; y[2] = t[2]; }
   else {
-    y[0] = RF(0, 0) * t[0] + RF(0, 1) * t[1] + RF(0, 2) * t[2];
-    y[1] = RF(1, 0) * t[0] + RF(1, 1) * t[1] + RF(1, 2) * t[2];
-    y[2] = RF(2, 0) * t[0] + RF(2, 1) * t[1] + RF(2, 2) * t[2];
+    y[0] = dot3z<ZR(0, 0), ZR(0, 1), ZR(0, 2)>(RF(0, 0), RF(0, 1), RF(0, 2), t[0], t[1], t[2]);
+    y[1] = dot3z<ZR(1, 0), ZR(1, 1), ZR(1, 2)>(RF(1, 0), RF(1, 1), RF(1, 2), t[0], t[1], t[2]);
+    y[2] = dot3z<ZR(2, 0), ZR(2, 1), ZR(2, 2)>(RF(2, 0), RF(2, 1), RF(2, 2), t[0], t[1], t[2]);
   }
 }
 // y = Rj^T x
@@ -82,46 +121,45 @@ template <int IL, int IR> DEVFN void rotT(bool side, const double* x, double s, 
   double t[3];
   if constexpr (rfix_identity<IL>()) { t[0] = x[0]; t[1] = x[1]; t[2] = x[2]; }
   else {
-    t[0] = RF(0, 0) * x[0] + RF(1, 0) * x[1] + RF(2, 0) * x[2];
-    t[1] = RF(0, 1) * x[0] + RF(1, 1) * x[1] + RF(2, 1) * x[2];
-    t[2] = RF(0, 2) * x[0] + RF(1, 2) * x[1] + RF(2, 2) * x[2];
+    t[0] = dot3z<ZR(0, 0), ZR(1, 0), ZR(2, 0)>(RF(0, 0), RF(1, 0), RF(2, 0), x[0], x[1], x[2]);
+    t[1] = dot3z<ZR(0, 1), ZR(1, 1), ZR(2, 1)>(RF(0, 1), RF(1, 1), RF(2, 1), x[0], x[1], x[2]);
+    t[2] = dot3z<ZR(0, 2), ZR(1, 2), ZR(2, 2)>(RF(0, 2), RF(1, 2), RF(2, 2), x[0], x[1], x[2]);
   }
   y[a] = t[a]; y[b] = c * t[b] + s * t[d]; y[d] = -s * t[b] + c * t[d];
 }
 // motion transform parent -> child
 template <int IL, int IR> DEVFN void xf_motion(bool side, const double* vp, double s, double c, double* vc) {
-  const double r[3] = {PS(0), PS(1), PS(2)};
-  double t[3]; cross(vp, r, t);
-  const double lin[3] = {vp[3] + t[0], vp[4] + t[1], vp[5] + t[2]};
+  double t[3]; cross_vc<ZP(0), ZP(1), ZP(2)>(PS(0), PS(1), PS(2), vp, t);
+  const double lin[3] = {addz<ZP(1) && ZP(2)>(vp[3], t[0]), addz<ZP(2) && ZP(0)>(vp[4], t[1]), addz<ZP(0) && ZP(1)>(vp[5], t[2])};
   rotT<IL, IR>(side, vp, s, c, vc); rotT<IL, IR>(side, lin, s, c, vc + 3);
 }
 // inverse motion transform child -> parent: vp = X^-1 vc
 template <int IL, int IR> DEVFN void xf_motion_inv(bool side, const double* vc, double s, double c, double* vp) {
-  const double r[3] = {PS(0), PS(1), PS(2)};
   double lin[3], t[3];
   rot<IL, IR>(side, vc, s, c, vp); rot<IL, IR>(side, vc + 3, s, c, lin);
-  cross(vp, r, t);
-  vp[3] = lin[0] - t[0]; vp[4] = lin[1] - t[1]; vp[5] = lin[2] - t[2];
+  cross_vc<ZP(0), ZP(1), ZP(2)>(PS(0), PS(1), PS(2), vp, t);
+  vp[3] = subz<ZP(1) && ZP(2)>(lin[0], t[0]); vp[4] = subz<ZP(2) && ZP(0)>(lin[1], t[1]); vp[5] = subz<ZP(0) && ZP(1)>(lin[2], t[2]);
 }
-// force transform child -> parent, accumulating
-template <int IL, int IR> DEVFN void xf_force_acc(bool side, const double* fc, double s, double c, double* fp) {
-  const double r[3] = {PS(0), PS(1), PS(2)};
-  double n[3], f[3], rf[3]; rot<IL, IR>(side, fc, s, c, n); rot<IL, IR>(side, fc + 3, s, c, f); cross(r, f, rf);
-  fp[0] += n[0] + rf[0]; fp[1] += n[1] + rf[1]; fp[2] += n[2] + rf[2];
-  fp[3] += f[0]; fp[4] += f[1]; fp[5] += f[2];
+// force transform child -> parent, accumulating (ACC) or assigning (the target is known to be zero)
+template <int IL, int IR, bool ACC = true> DEVFN void xf_force_acc(bool side, const double* fc, double s, double c, double* fp) {
+  double n[3], f[3], rf[3]; rot<IL, IR>(side, fc, s, c, n); rot<IL, IR>(side, fc + 3, s, c, f);
+  cross_cv<ZP(0), ZP(1), ZP(2)>(PS(0), PS(1), PS(2), f, rf);
+  const double m0 = addz<ZP(1) && ZP(2)>(n[0], rf[0]), m1 = addz<ZP(2) && ZP(0)>(n[1], rf[1]), m2 = addz<ZP(0) && ZP(1)>(n[2], rf[2]);
+  if constexpr (ACC) { fp[0] += m0; fp[1] += m1; fp[2] += m2; fp[3] += f[0]; fp[4] += f[1]; fp[5] += f[2]; }
+  else { fp[0] = m0; fp[1] = m1; fp[2] = m2; fp[3] = f[0]; fp[4] = f[1]; fp[5] = f[2]; }
 }
 // spatial inertia (about the body frame origin) times a motion vector
 template <int IL, int IR> DEVFN void inertia_mul(bool side, const double* a, double* f) {
   const double m = MS;
-  const double c[3] = {CM(0), CM(1), CM(2)};
-  const double Iw0 = IN(0, 0) * a[0] + IN(0, 1) * a[1] + IN(0, 2) * a[2];
-  const double Iw1 = IN(1, 0) * a[0] + IN(1, 1) * a[1] + IN(1, 2) * a[2];
-  const double Iw2 = IN(2, 0) * a[0] + IN(2, 1) * a[1] + IN(2, 2) * a[2];
-  const double wc[3] = {a[1] * c[2] - a[2] * c[1], a[2] * c[0] - a[0] * c[2], a[0] * c[1] - a[1] * c[0]};
-  const double fl[3] = {m * (a[3] + wc[0]), m * (a[4] + wc[1]), m * (a[5] + wc[2])};
-  f[0] = Iw0 + (c[1] * fl[2] - c[2] * fl[1]);
-  f[1] = Iw1 + (c[2] * fl[0] - c[0] * fl[2]);
-  f[2] = Iw2 + (c[0] * fl[1] - c[1] * fl[0]);
+  const double Iw0 = dot3z<ZI(0, 0), ZI(0, 1), ZI(0, 2)>(IN(0, 0), IN(0, 1), IN(0, 2), a[0], a[1], a[2]);
+  const double Iw1 = dot3z<ZI(1, 0), ZI(1, 1), ZI(1, 2)>(IN(1, 0), IN(1, 1), IN(1, 2), a[0], a[1], a[2]);
+  const double Iw2 = dot3z<ZI(2, 0), ZI(2, 1), ZI(2, 2)>(IN(2, 0), IN(2, 1), IN(2, 2), a[0], a[1], a[2]);
+  double wc[3]; cross_vc<ZC(0), ZC(1), ZC(2)>(CM(0), CM(1), CM(2), a, wc);            // w x c
+  const double fl[3] = {m * addz<ZC(1) && ZC(2)>(a[3], wc[0]), m * addz<ZC(2) && ZC(0)>(a[4], wc[1]), m * addz<ZC(0) && ZC(1)>(a[5], wc[2])};
+  double cf[3]; cross_cv<ZC(0), ZC(1), ZC(2)>(CM(0), CM(1), CM(2), fl, cf);           // c x f_lin
+  f[0] = addz<ZC(1) && ZC(2)>(Iw0, cf[0]);
+  f[1] = addz<ZC(2) && ZC(0)>(Iw1, cf[1]);
+  f[2] = addz<ZC(0) && ZC(1)>(Iw2, cf[2]);
   f[3] = fl[0]; f[4] = fl[1]; f[5] = fl[2];
 }
 // v x* f
@@ -165,33 +203,50 @@ template <int IL, int IR> DEVFN void rot_congruence(bool side, double* M, double
   for (int row = 0; row < 3; ++row) { double y[3]; rot<IL, IR>(side, T + 3 * row, s, c, y); M[3 * row] = y[0]; M[3 * row + 1] = y[1]; M[3 * row + 2] = y[2]; }
 }
 DEVFN void sym_to_full(const double* S, double* M) { M[0] = S[0]; M[1] = S[1]; M[2] = S[2]; M[3] = S[1]; M[4] = S[3]; M[5] = S[4]; M[6] = S[2]; M[7] = S[4]; M[8] = S[5]; }
-// Yp += X^T Ya X for the joint transform (rotation Rj, then translation by r = pos)
-template <int IL, int IR> DEVFN void fold_art(bool side, const Art& Ya, double s, double c, Art& Yp) {
+// Yp (+)= X^T Ya X for the joint transform (rotation Rj, then translation by r = pos); ACC = false assigns (Yp known to be zero).
+// With [r]x the cross-product matrix: C' = C, B' = B + [r]x C, A' = A + [r]x B^T + B' [r]x^T -- column j of [r]x C is r x C[:, j],
+// column j of [r]x B^T is r x (row j of B), row i of B' [r]x^T is r x (row i of B'); components of r that are zero drop out.
+template <int IL, int IR, bool ACC = true> DEVFN void fold_art(bool side, const Art& Ya, double s, double c, Art& Yp) {
   double A[9], B[9], C[9];
   sym_to_full(Ya.A, A); sym_to_full(Ya.C, C);
 #pragma unroll
   for (int k = 0; k < 9; ++k) B[k] = Ya.B[k];
   rot_congruence<IL, IR>(side, A, s, c); rot_congruence<IL, IR>(side, B, s, c); rot_congruence<IL, IR>(side, C, s, c);
+  constexpr bool zx = ZP(0), zy = ZP(1), zz = ZP(2);
+  constexpr bool z0 = zy && zz, z1 = zz && zx, z2 = zx && zy;      // component k of r x (.) vanishes identically
   const double rx = PS(0), ry = PS(1), rz = PS(2);
-  const double R[9] = {0.0, -rz, ry, rz, 0.0, -rx, -ry, rx, 0.0};
-  double RC[9], Bp[9];
+  double Bp[9], Ap[9];
 #pragma unroll
-  for (int i = 0; i < 3; ++i)
+  for (int j = 0; j < 3; ++j) {
+    const double cj[3] = {C[j], C[3 + j], C[6 + j]};
+    double rc[3]; cross_cv<zx, zy, zz>(rx, ry, rz, cj, rc);
+    Bp[j] = addz<z0>(B[j], rc[0]); Bp[3 + j] = addz<z1>(B[3 + j], rc[1]); Bp[6 + j] = addz<z2>(B[6 + j], rc[2]);
+  }
+  double rbt[9], bprt[9];
 #pragma unroll
-    for (int j = 0; j < 3; ++j) { RC[3 * i + j] = R[3 * i] * C[j] + R[3 * i + 1] * C[3 + j] + R[3 * i + 2] * C[6 + j]; Bp[3 * i + j] = B[3 * i + j] + RC[3 * i + j]; }
-  double Ap[9];
+  for (int j = 0; j < 3; ++j) {
+    double o[3]; cross_cv<zx, zy, zz>(rx, ry, rz, B + 3 * j, o);      // column j of [r]x B^T
+    rbt[j] = o[0]; rbt[3 + j] = o[1]; rbt[6 + j] = o[2];
+  }
 #pragma unroll
-  for (int i = 0; i < 3; ++i)
+  for (int i = 0; i < 3; ++i) cross_cv<zx, zy, zz>(rx, ry, rz, Bp + 3 * i, bprt + 3 * i);   // row i of B' [r]x^T
+  // Ap[i][j] = A[i][j] + rbt[i][j] + bprt[i][j]; rbt[i][j] vanishes with z_i, bprt[i][j] with z_j
+  Ap[0] = addz<z0>(addz<z0>(A[0], rbt[0]), bprt[0]); Ap[1] = addz<z1>(addz<z0>(A[1], rbt[1]), bprt[1]); Ap[2] = addz<z2>(addz<z0>(A[2], rbt[2]), bprt[2]);
+  Ap[3] = addz<z0>(addz<z1>(A[3], rbt[3]), bprt[3]); Ap[4] = addz<z1>(addz<z1>(A[4], rbt[4]), bprt[4]); Ap[5] = addz<z2>(addz<z1>(A[5], rbt[5]), bprt[5]);
+  Ap[6] = addz<z0>(addz<z2>(A[6], rbt[6]), bprt[6]); Ap[7] = addz<z1>(addz<z2>(A[7], rbt[7]), bprt[7]); Ap[8] = addz<z2>(addz<z2>(A[8], rbt[8]), bprt[8]);
+  const double a1 = 0.5 * (Ap[1] + Ap[3]), a2 = 0.5 * (Ap[2] + Ap[6]), a4 = 0.5 * (Ap[5] + Ap[7]);
+  const double c1 = 0.5 * (C[1] + C[3]), c2 = 0.5 * (C[2] + C[6]), c4 = 0.5 * (C[5] + C[7]);
+  if constexpr (ACC) {
+    Yp.A[0] += Ap[0]; Yp.A[1] += a1; Yp.A[2] += a2; Yp.A[3] += Ap[4]; Yp.A[4] += a4; Yp.A[5] += Ap[8];
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      const double rbt = R[3 * i] * B[3 * j] + R[3 * i + 1] * B[3 * j + 1] + R[3 * i + 2] * B[3 * j + 2];
-      const double bprt = Bp[3 * i] * R[3 * j] + Bp[3 * i + 1] * R[3 * j + 1] + Bp[3 * i + 2] * R[3 * j + 2];
-      Ap[3 * i + j] = A[3 * i + j] + rbt + bprt;
-    }
-  Yp.A[0] += Ap[0]; Yp.A[1] += 0.5 * (Ap[1] + Ap[3]); Yp.A[2] += 0.5 * (Ap[2] + Ap[6]); Yp.A[3] += Ap[4]; Yp.A[4] += 0.5 * (Ap[5] + Ap[7]); Yp.A[5] += Ap[8];
+    for (int k = 0; k < 9; ++k) Yp.B[k] += Bp[k];
+    Yp.C[0] += C[0]; Yp.C[1] += c1; Yp.C[2] += c2; Yp.C[3] += C[4]; Yp.C[4] += c4; Yp.C[5] += C[8];
+  } else {
+    Yp.A[0] = Ap[0]; Yp.A[1] = a1; Yp.A[2] = a2; Yp.A[3] = Ap[4]; Yp.A[4] = a4; Yp.A[5] = Ap[8];
 #pragma unroll
-  for (int k = 0; k < 9; ++k) Yp.B[k] += Bp[k];
-  Yp.C[0] += C[0]; Yp.C[1] += 0.5 * (C[1] + C[3]); Yp.C[2] += 0.5 * (C[2] + C[6]); Yp.C[3] += C[4]; Yp.C[4] += 0.5 * (C[5] + C[7]); Yp.C[5] += C[8];
+    for (int k = 0; k < 9; ++k) Yp.B[k] = Bp[k];
+    Yp.C[0] = C[0]; Yp.C[1] = c1; Yp.C[2] = c2; Yp.C[3] = C[4]; Yp.C[4] = c4; Yp.C[5] = C[8];
+  }
 }
 
 // ---- per-body sweeps -------------------------------------------------------------------------------
@@ -207,7 +262,7 @@ template <int IL, int IR> DEVFN void body_out(bool side, const double* vp, doubl
 }
 // inward step of a hinge body: Y = its articulated inertia (own + children), S.pA = bias (own + children).
 // Writes U, 1/D, u to LDS slot block `slot`, folds the projected inertia / bias into the parent's accumulators.
-template <int IL, int IR> DEVFN void body_in(bool side, Art& Y, BodyState& S, double tau, double qd, double arm_eff, const LaneLds& L, int slot, Art& Yp, double* pAp) {
+template <int IL, int IR, bool ACC = true> DEVFN void body_in(bool side, Art& Y, BodyState& S, double tau, double qd, double arm_eff, const LaneLds& L, int slot, Art& Yp, double* pAp) {
   constexpr int AX = C_AXIS[IL];
   double Ua[3], Ul[3];
 #pragma unroll
@@ -234,8 +289,8 @@ template <int IL, int IR> DEVFN void body_in(bool side, Art& Y, BodyState& S, do
     pa[r] = S.pA[r] + Ua[r] * ud + Y.A[sidx(r, 0)] * ca[0] + Y.A[sidx(r, 1)] * ca[1] + Y.A[sidx(r, 2)] * ca[2] + Y.B[3 * r] * cl[0] + Y.B[3 * r + 1] * cl[1] + Y.B[3 * r + 2] * cl[2];
     pa[3 + r] = S.pA[3 + r] + Ul[r] * ud + Y.B[r] * ca[0] + Y.B[3 + r] * ca[1] + Y.B[6 + r] * ca[2] + Y.C[sidx(r, 0)] * cl[0] + Y.C[sidx(r, 1)] * cl[1] + Y.C[sidx(r, 2)] * cl[2];
   }
-  fold_art<IL, IR>(side, Y, S.s, S.c, Yp);
-  xf_force_acc<IL, IR>(side, pa, S.s, S.c, pAp);
+  fold_art<IL, IR, ACC>(side, Y, S.s, S.c, Yp);
+  xf_force_acc<IL, IR, ACC>(side, pa, S.s, S.c, pAp);
 }
 // outward acceleration step: in (vp, ap) of the parent, out (v, a) of the body and its joint acceleration
 template <int IL, int IR> DEVFN double body_acc(bool side, const double* vp, const double* ap, double theta, double qd, const LaneLds& L, int slot, double* v, double* a,
@@ -296,10 +351,7 @@ template <int FL, int FR, int LEN, int SLOT0> struct Chain {
       for (int k = 0; k < 6; ++k) S.pA[k] += pc[k];
     }
     if constexpr (K > 0) {
-      art_zero(carry);
-#pragma unroll
-      for (int k = 0; k < 6; ++k) pc[k] = 0.0;
-      body_in<FL + K, FR + K>(side, Y, S, tau[K], qd[K], arm_eff, L, SLOT0 + 8 * K, carry, pc);
+      body_in<FL + K, FR + K, false>(side, Y, S, tau[K], qd[K], arm_eff, L, SLOT0 + 8 * K, carry, pc);     // carry, pc <- (assigned)
       // parent's velocity for the next inward step
       double vc[6] = {v[0], v[1], v[2], v[3], v[4], v[5]};
       vc[AX] -= qd[K];
