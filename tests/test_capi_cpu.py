@@ -89,3 +89,20 @@ def test_cpp_multi_gpu_demo_builds():
     if not torch.cuda.is_available():
         r = subprocess.run([exe, "1", "2", "0", "/tmp/never_written.bin"], capture_output=True, text=True)
         assert r.returncode == 1 and "ilqr_hip_create" in r.stderr        # fails loudly without a GPU
+
+
+def test_bench_picks_the_dominant_kernel_group_on_exclusive_equivalent_time():
+    """bench.py: the linearisation pair, the cost quadratics and the nominal re-rollout overlap on three streams -- their spans are
+    scaled by (longest / sum) before the groups are ranked; the group's stage keys are what the timed region keeps event pairs for."""
+    import importlib.util, types
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
+    args = types.SimpleNamespace(contact=False)
+    groups = bench.kernel_groups(args, 4096, 25, 1)
+    stage = {"iLQR_backwardPass": 20.0, "iLQR_backwardPass_retry": 15.0, "iLQR_lineSearch": 9.0, "iLQR_lineSearch_retry": 7.0,
+             "iLQR_linearization": 37.0, "iLQR_costQuadratics": 19.0, "iLQR_computeCost+forwardRollout": 9.0}
+    name, keys = bench.dominant_group(groups, stage)
+    assert name == "k_backward_wave" and keys == ["iLQR_backwardPass", "iLQR_backwardPass_retry"]      # 35 ms against 37 * 37 / 65 = 21 ms
+    stage["iLQR_backwardPass"] = 2.0; stage["iLQR_backwardPass_retry"] = 1.0
+    name, keys = bench.dominant_group(groups, stage)
+    assert name == "k_lin_primal_s+k_lin_tangent" and keys == ["iLQR_linearization"]

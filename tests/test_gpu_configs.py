@@ -208,6 +208,26 @@ def test_early_exit_gate_stops_launching_and_changes_nothing():
         assert abs(out["1"][0][b] - c) <= 1e-5 * abs(c)
 
 
+def test_profiled_stage_mask_times_only_the_chosen_stages():
+    """bench.py keeps event pairs only around the roofline kernel group inside its timed region (ilqr_hip_set_profiled_stages)."""
+    B = 4
+    prob, x0, ui = standing(B, seed=3)
+    s = _solver(B); s.set_problem(prob); s.set_max_iterations(3); s.set_options(early_exit=False)
+    s.enable_profiling(True)
+    s.initialize(x0, ui); s.solve(x0)
+    ms_all, n_all = s.stage_ms()
+    assert all(n_all[k] > 0 and ms_all[k] > 0 for k in ("iLQR_backwardPass", "iLQR_lineSearch", "iLQR_linearization", "iLQR_costQuadratics"))
+    s.set_profiled_stages(["iLQR_backwardPass", "iLQR_backwardPass_retry"])
+    s.set_regularization(1e-6); s.initialize(x0, ui); cost = s.solve(x0)       # (lambda is state that survives a solve, as in the reference)
+    ms, n = s.stage_ms()
+    assert n["iLQR_backwardPass"] == 3 and n["iLQR_backwardPass_retry"] == 3 and ms["iLQR_backwardPass"] > 0
+    assert all(n[k] == 0 and ms[k] == 0 for k in ms if not k.startswith("iLQR_backwardPass"))
+    s.set_profiled_stages(None)
+    s.set_regularization(1e-6); s.initialize(x0, ui); cost2 = s.solve(x0)
+    assert np.array_equal(cost, cost2) and s.stage_ms()[1]["iLQR_lineSearch"] == 3
+    s.close()
+
+
 @pytest.mark.parametrize("ls", ["s", "r"])
 def test_line_search_variants_match_oracle(ls):
     prob, x0, ui = standing(3, seed=4)
