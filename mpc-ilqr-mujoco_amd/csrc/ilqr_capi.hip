@@ -25,6 +25,7 @@ struct ilqr_hip_ctx {
   hipStream_t stream2 = nullptr;          // cost quadratics run here, concurrently with the linearisation
   hipStream_t stream3 = nullptr;          // nominal re-rollout of iterations >= 1, concurrently with both
   hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_roll = nullptr;
+  hipEvent_t ev_lin = nullptr, ev_adopt = nullptr;   // adoption of the re-rolled trajectory beside the backward pass (enqueue_solve)
   double* d_shadowx = nullptr;            // [B][N+1][51] target of the concurrent re-rollout
   DevState S{};
   h1::ProblemDev P{};
@@ -114,7 +115,8 @@ int ilqr_hip_create(ilqr_hip_ctx** out, int device, int batch, int horizon, doub
   ilqr_hip_ctx* c = new ilqr_hip_ctx();
   c->device = device; c->B = batch; c->N = horizon;
   if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&c->stream) != hipSuccess || hipStreamCreate(&c->stream2) != hipSuccess || hipStreamCreate(&c->stream3) != hipSuccess || hipEventCreateWithFlags(&c->ev_roll, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) { delete c; return ILQR_ERR_NO_DEVICE; }
+      hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_lin, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_adopt, hipEventDisableTiming) != hipSuccess) { delete c; return ILQR_ERR_NO_DEVICE; }
   const size_t B = batch, N = horizon, n = ILQR_NX, m = ILQR_NU;
   DevState& S = c->S;
   S.B = batch; S.N = horizon; S.max_iter = c->max_iter;
@@ -180,6 +182,8 @@ int ilqr_hip_destroy(ilqr_hip_ctx* c) {
   if (c->ev_fork) hipEventDestroy(c->ev_fork);
   if (c->ev_join) hipEventDestroy(c->ev_join);
   if (c->ev_roll) hipEventDestroy(c->ev_roll);
+  if (c->ev_lin) hipEventDestroy(c->ev_lin);
+  if (c->ev_adopt) hipEventDestroy(c->ev_adopt);
   if (c->stream3) hipStreamDestroy(c->stream3);
   if (c->stream2) hipStreamDestroy(c->stream2);
   if (c->stream) hipStreamDestroy(c->stream);
@@ -405,7 +409,8 @@ static int ensure_gate(ilqr_hip_ctx* c) {
   return ILQR_OK;
 }
 static int enqueue_solve(ilqr_hip_ctx* c, const DevState& S, const h1::ProblemDev& P, hipStream_t st, hipStream_t st2, hipStream_t st3,
-                         hipEvent_t ev_fork, hipEvent_t ev_join, hipEvent_t ev_roll, const double* shadow_base, hipEvent_t wait_lead, hipEvent_t lead) {
+                         hipEvent_t ev_fork, hipEvent_t ev_join, hipEvent_t ev_roll, const double* shadow_base, hipEvent_t wait_lead, hipEvent_t lead,
+                         hipEvent_t ev_lin = nullptr, hipEvent_t ev_adopt = nullptr) {
   // shadow target of the concurrent re-rollout: same rollouts as S.xbar, in the shadow buffer
   double* shadow = const_cast<double*>(shadow_base) + (S.xbar - c->S.xbar);
   const double fold_h = ilqr::linearize_fold_h(P, c->jac_mode);
@@ -449,9 +454,19 @@ static int enqueue_solve(ilqr_hip_ctx* c, const DevState& S, const h1::ProblemDe
     { StageTimer T(c, 2, st2); ilqr::launch_cost_quadratics(S, P, sel_mode, st2, iter); }
     HIPCHK(c, hipEventRecord(ev_join, st2));
     { StageTimer T(c, 1, st); ilqr::launch_linearize(S, P, sel_mode, c->jac_mode, c->fd_eps, st, 3, iter); }
+    // The re-rolled trajectory replaces xbar once the linearisation and the cost quadratics have read the old one.  The backward
+    // pass reads neither: with the extra events the adoption runs on the rollout's stream beside it and only the line search waits.
+    const bool adopt_aside = concurrent_roll && ev_lin && ev_adopt;
+    if (adopt_aside) {
+      HIPCHK(c, hipEventRecord(ev_lin, st));
+      HIPCHK(c, hipStreamWaitEvent(st3, ev_lin, 0)); HIPCHK(c, hipStreamWaitEvent(st3, ev_join, 0));
+      ilqr::launch_adopt_rollout(S, shadow, ilqr::MASK_ACTIVE, c->d_mismatch, st3);
+      HIPCHK(c, hipEventRecord(ev_adopt, st3));
+    }
     HIPCHK(c, hipStreamWaitEvent(st, ev_join, 0));
-    if (concurrent_roll) { HIPCHK(c, hipStreamWaitEvent(st, ev_roll, 0)); ilqr::launch_adopt_rollout(S, shadow, ilqr::MASK_ACTIVE, c->d_mismatch, st); }
+    if (concurrent_roll && !adopt_aside) { HIPCHK(c, hipStreamWaitEvent(st, ev_roll, 0)); ilqr::launch_adopt_rollout(S, shadow, ilqr::MASK_ACTIVE, c->d_mismatch, st); }
     { StageTimer T(c, 3, st); ilqr::launch_backward(S, ilqr::MASK_ACTIVE, st, fold_h, iter); }                                  // :601
+    if (adopt_aside) HIPCHK(c, hipStreamWaitEvent(st, ev_adopt, 0));
     if (iter == 0 && lead) HIPCHK(c, hipEventRecord(lead, st));
     { StageTimer T(c, 4, st); ilqr::launch_line_search(S, P, ilqr::MASK_ACTIVE, st, iter); }                            // :616
     { StageTimer T(c, 5, st); ilqr::launch_control(S, 0, iter, c->tol, c->early_exit, st, ilqr::ls_costs_per_knot(P)); }                      // :619-620,645-655
@@ -478,7 +493,7 @@ int ilqr_hip_solve_async(ilqr_hip_ctx* c) {
   c->n_slices = k;
   c->lin_fold_h = ilqr::linearize_fold_h(P, c->jac_mode);   // what S.A / S.Bm hold after this solve
   if (k <= 1) {
-    TRY(enqueue_solve(c, S, P, st, c->stream2, c->stream3, c->ev_fork, c->ev_join, c->ev_roll, c->d_shadowx, nullptr, nullptr));
+    TRY(enqueue_solve(c, S, P, st, c->stream2, c->stream3, c->ev_fork, c->ev_join, c->ev_roll, c->d_shadowx, nullptr, nullptr, c->ev_lin, c->ev_adopt));
   } else {
     TRY(ensure_slices(c, k));
     HIPCHK(c, hipEventRecord(c->ev_begin, st));
