@@ -7,7 +7,8 @@
 One "step" = one MPC step of the hot path over the whole batch with inputs resident in HBM:
 cold-start initializeWithReference (gravity-comp + noise controls, N rollouts) followed by
 iLQR::solve with exactly `--iters` iterations per rollout (early exit disabled, the headline mode of
-BASELINE.md section 3) and the per-step pack of {u0, cost} (plus one RCCL gather to rank 0 when N > 1).
+BASELINE.md section 3) and the per-step gather of {u0, cost} rows to rank 0 through the product's own collective
+(ilqr_hip_gather_first_knot: RCCL grouped send/recv behind the C ABI when N > 1, a device copy when N = 1).
 Workload: BASELINE.json configs[2] "Batch=4096 full iLQR, N=25, 1xMI355X" (the config the metric
 "iLQR iterations/sec" is quoted on); weak scaling: 4096 rollouts per GPU (configs[3] at 8 GPUs).
 Prints ONE JSON line on rank 0.
@@ -32,6 +33,26 @@ RICCATI_FLOPS_PER_KNOT = 914786.0
 JACOBIAN_FLOPS_PER_KNOT = 120000.0
 STEP_FLOPS = 12000.0      # one ABA dynamics step
 QUAD_FLOPS_PER_KNOT = 50000.0
+FLOP_SOURCE = "Riccati: exact count of the minimal-reuse formulation (SURVEY.md 8(d)); dynamics step / Jacobians / cost quadratics: planning estimates of SURVEY.md 8(d)"
+# whole-iteration budget of SURVEY.md 8(d) at N = 25 (scaled by N / 25 for other horizons): 27.8 MFLOP and 2.43 MB per rollout-iteration
+ITER_FLOPS_N25, ITER_BYTES_N25 = 27.8e6, 2.43e6
+# v_mfma_f64_16x16x4_f64 per knot issued by the one-wave Riccati kernel (riccati_wave.hip): folded / generic variant, 2048 flops each
+MFMA_PER_KNOT = {"folded": 429, "generic": 569}
+
+
+def workload_label(args, B, N, iters, world, gravity):
+    """Names a BASELINE.json config only when (batch, horizon, stage, contact, iterations) IS that config; else 'custom: ...'."""
+    body = ("batch=%d/GPU full iLQR (rollout+Jacobians+cost quadratics+Riccati+8-alpha line search), H1 standing balance, N=%d, dt=0.02, "
+            "%d fixed iterations per rollout, shipped config.yaml weights, gravity %s" % (B, N, iters, list(gravity)))
+    if args.contact:
+        return "custom (contact row f4: unilateral rigid stance on the scheduled feet): " + body
+    if B == 4096 and N == 25 and iters == 10:
+        if world == 1:
+            return "BASELINE.json configs[2]: " + body
+        if world == 8:
+            return "BASELINE.json configs[3] (32768 rollouts = 4096 per GPU x 8): " + body
+        return "per-GPU shape of BASELINE.json configs[2]/[3] on %d GPUs (configs[3] is the 8-GPU point of this weak-scaling series): " % world + body
+    return "custom: " + body
 
 
 def parse():
@@ -52,7 +73,7 @@ def parse():
     ap.add_argument("--stage", choices=["full", "rollout_jacobians"], default="full",
                     help="full (headline) or BASELINE.json configs[1]: forward rollout + Jacobians only (use with --batch 1024)")
     ap.add_argument("--contact", action="store_true",
-                    help="not the headline: contact row f4 (unilateral rigid stance on the scheduled feet, physical gravity -9.81, two-lane kernels, forward-difference Jacobians)")
+                    help="not the headline: contact row f4 (unilateral rigid stance on the scheduled feet, physical gravity -9.81, two-lane kernels, analytic Jacobians of the constrained step)")
     ap.add_argument("--no-contact-line", action="store_true", help="skip the short contact-mode measurement added to the default line")
     return ap.parse_args()
 
@@ -63,9 +84,9 @@ def cpu_baseline(pkg, prob, x0, ui, iters, budget_s, contact=False):
     import oracle_lib as ol
     o = ol.Oracle(prob["N"], prob["dt"])
     o.set_problem(prob)
-    if contact:      # same plant and the same kind of Jacobians as the GPU's contact mode
+    if contact:      # same plant and the same kind of Jacobians as the GPU's contact mode: exact derivatives of the constrained step
         o.set_contact_mode(2)
-        o.set_options(max_iter=iters, early_exit=0, jac_mode=1, fd_eps=1e-5)     # (forward differences: the faster of the oracle's two modes)
+        o.set_options(max_iter=iters, early_exit=0, jac_mode=0)     # (the oracle takes them by forward-mode AD)
     else:            # Jacobians by forward differences, eps 1e-5: the reference's own scheme (robot_utils.cpp:120-160) and the
         o.set_options(max_iter=iters, early_exit=0, jac_mode=1, fd_eps=1e-5)   # faster of the oracle's two modes on a CPU
     cores = ol.max_threads()
@@ -79,12 +100,24 @@ def cpu_baseline(pkg, prob, x0, ui, iters, budget_s, contact=False):
     tot1, *_ = o.batch_solve(x0[:n1], ui[:n1], nthreads=cores)
     dt1 = time.perf_counter() - t0
     return dict(value=tot1 / dt1, unit="iLQR iterations/s", cores=int(cores), kind="port",
-                sample="oracle (CPU restatement, " + ("rigid-stance plant, forward-difference Jacobians" if contact else "forward-difference Jacobians as in the reference; its forward-mode-AD variant is ~2x slower") + ") on the first %d rollouts of the same batch, %d fixed iterations each, OpenMP over rollouts, %.1f s" % (n1, iters, dt1))
+                sample="oracle (CPU restatement, " + ("rigid-stance plant, exact (forward-mode AD) Jacobians of the constrained step as on the GPU" if contact else "forward-difference Jacobians as in the reference; its forward-mode-AD variant is ~2x slower") + ") on the first %d rollouts of the same batch, %d fixed iterations each, OpenMP over rollouts, %.1f s" % (n1, iters, dt1))
+
+
+def csrc_hash():
+    """sha256 over the kernel sources (csrc/*.hip, *.h, Makefile): a PMC traffic record describes THIS build only."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "mpc-ilqr-mujoco_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(d, "*.hip")) + glob.glob(os.path.join(d, "*.h")) + glob.glob(os.path.join(d, "*.cpp")) + [os.path.join(d, "Makefile")]):
+        h.update(os.path.basename(f).encode()); h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
 
 
 def run_signature(args, n_slices):
-    """What a PMC traffic record must have been collected on to describe this run (tools/pmc_summary.py --stamp)."""
-    return {"batch": args.batch, "horizon": args.horizon, "iters": args.iters, "contact": bool(args.contact), "slices": int(n_slices),
+    """What a PMC traffic record must have been collected on to describe this run (tools/pmc_summary.py --stamp): the
+    configuration AND the kernel sources (a kernel change without a re-collection must not inherit the old traffic figure)."""
+    return {"csrc_sha": csrc_hash(), "batch": args.batch, "horizon": args.horizon, "iters": args.iters, "contact": bool(args.contact), "slices": int(n_slices),
             "backward": os.environ.get("ILQR_BACKWARD", "wave"), "ls": os.environ.get("ILQR_LS", "s"), "rollout": os.environ.get("ILQR_ROLLOUT", "s"),
             "dyn": os.environ.get("ILQR_DYN", "")}
 
@@ -159,15 +192,22 @@ def stage_bench(args, s, sv, x0_d, ui_d, B, N, world, rank, dev, prob):
         ms = 1e3 * el / args.steps
         by = 8.0 * B * N * (70 + 493 + 493 + 70 + 2601 + 969)
         fl = (JACOBIAN_FLOPS_PER_KNOT + STEP_FLOPS) * N * B
+        tf, gbs = fl / (ms * 1e-3) / 1e12, by / (ms * 1e-3) / 1e9
+        # the roof this pass sits closer to, as the main path picks it
+        roof = ({"bound": "mfma", "achieved": tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP64_PEAK_TFLOPS} if tf / FP64_PEAK_TFLOPS >= gbs / HBM_PEAK_GBS
+                else {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS})
+        roof.update({"frac_compute": tf / FP64_PEAK_TFLOPS, "frac_hbm": gbs / HBM_PEAK_GBS, "traffic": None,
+                     "note": "whole step (rollout + primal dump + tangent sweeps), host-timed; algorithmic flops = one dynamics step + one analytic (A_t, B_t) "
+                             "per knot (FLOP_SOURCE below), algorithmic bytes = trajectory + primal dump round trip + A_t + B_t"})
+        is_cfg1 = (B == 1024 and N == 25)
         print(json.dumps({
             "metric": "rollout + Jacobian passes/sec (H1 nx=51 nu=19 N=%d)" % N, "value": world * B * args.steps / el, "unit": "trajectories/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "BASELINE.json configs[1]: batch=%d H1 standing rollouts, N=%d, forward rollout + analytic Jacobians only, gravity %s" % (B, N, list(prob["gravity"])),
-                       "batch_per_gpu": B, "horizon": N},
-            "roofline": {"bound": "mfma", "achieved": fl / (ms * 1e-3) / 1e12, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": fl / (ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
-                         "frac_hbm": by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
-                         "note": "whole step (rollout + primal dump + tangent sweeps), host-timed; algorithmic flops = (12 k + 120 k) per knot (SURVEY 8(d) planning figures)"}}))
+            "config": {"workload": ("BASELINE.json configs[1]: " if is_cfg1 else "custom (shape of BASELINE.json configs[1] at another size): ") +
+                                   "batch=%d H1 standing rollouts, N=%d, forward rollout + analytic Jacobians only, gravity %s" % (B, N, list(prob["gravity"])),
+                       "batch_per_gpu": B, "horizon": N, "flop_source": FLOP_SOURCE},
+            "roofline": roof}))
     s.close()
     if world > 1:
         dist.destroy_process_group()
@@ -224,10 +264,23 @@ def main():
     dev = torch.device("cuda", local_rank)
     x0_d = torch.from_numpy(x0).to(dev)
     ui_d = torch.from_numpy(ui).to(dev)
-    payload = torch.zeros(B, sh.payload_width(args.gather_gains), dtype=torch.float64, device=dev)   # [u0 | cost | (K0)] per rollout
-    u0_d = torch.zeros(B, 19, dtype=torch.float64, device=dev)
-    c_d = torch.zeros(B, dtype=torch.float64, device=dev)
-    K0_d = torch.zeros(B, 19 * 51, dtype=torch.float64, device=dev) if args.gather_gains else None
+    # The ONE collective of an MPC step is the product's own: ilqr_hip_gather_first_knot packs the rows
+    # [u0 | cost | (K0)] on the device and gathers them on rank 0 as grouped RCCL send/recv behind the C ABI.  The process group
+    # the driver's launcher set up only carries the 128-byte RCCL id from rank 0 to the other ranks (and the barrier / timing
+    # reduction).  One GPU: the same entry point degenerates to a device copy.  --rehearse-single-gpu (two ranks on ONE device,
+    # which RCCL refuses): every rank runs the one-rank form and the rows are staged through the host over gloo.
+    W = sh.payload_width(args.gather_gains)
+    rccl = world > 1 and not args.rehearse_single_gpu
+    if rccl:
+        idt = torch.zeros(128, dtype=torch.uint8, device=dev)
+        if rank == 0:
+            idt.copy_(torch.frombuffer(bytearray(sv.BatchedILQR.comm_unique_id()), dtype=torch.uint8))
+        dist.broadcast(idt, src=0)
+        s.comm_init(world, rank, bytes(idt.cpu().numpy().tobytes()))
+        recv = torch.zeros(world * B, W, dtype=torch.float64, device=dev) if rank == 0 else None
+    else:
+        s.comm_init(1, 0)
+        recv = torch.zeros(B, W, dtype=torch.float64, device=dev)
     torch.cuda.synchronize()
 
     stage_ms, stage_n = {}, {}          # every stage, from ONE untimed step after the timed region (all event pairs on)
@@ -243,16 +296,14 @@ def main():
             n_acc[k] = n_acc.get(k, 0.0) + n[k]
 
     def one_step(timed):
-        # the previous step's payload copy / gather read u0_d, c_d, K0_d on torch's stream: let them finish before the
-        # library's own stream overwrites those buffers
-        torch.cuda.current_stream().synchronize()
         s.initialize_device(x0_d.data_ptr(), ui_d.data_ptr())
         s.solve_async()
+        # the gather follows the solve on the handle's own stream: one host synchronisation per MPC step
+        s.gather_first_knot(None if recv is None else recv.data_ptr(), root=0, with_gains=args.gather_gains)
         s.synchronize()
-        s.pack_first_knot_device(u0_d.data_ptr(), None if K0_d is None else K0_d.data_ptr(), c_d.data_ptr())
-        sh.pack_payload(payload, u0_d, c_d, K0_d)
-        # the ONE collective of an MPC step (RCCL over xGMI; host-staged over gloo in the one-GPU rehearsal)
-        g = sh.gather_first_knot(payload.cpu() if args.rehearse_single_gpu else payload, dst=0)
+        g = recv
+        if args.rehearse_single_gpu and world > 1:
+            g = sh.gather_first_knot(recv.cpu(), dst=0)
         if timed:
             record_stages(timed_ms, timed_n)
         return g
@@ -321,7 +372,7 @@ def main():
     ee_steps = max(1, args.steps // 2)
 
     # third number (not the headline): the same batch under physical gravity with the scheduled feet held in
-    # stance (unilateral rigid stance constraints, forward-difference Jacobians as the reference takes them), fixed iterations
+    # stance (unilateral rigid stance constraints, analytic Jacobians of the constrained step), fixed iterations
     contact_line = None
     if not args.contact and not args.no_contact_line and world == 1:
         probc = sc.make_problem(sv.reference_kinematics, N=N, gravity=(0.0, 0.0, -9.81))
@@ -403,13 +454,28 @@ def main():
         else:
             roof["traffic"] = None
             roof["traffic_source"] = traffic_reason or "no PMC record for %s" % dom_kernel
+        # whole-iteration view (SURVEY.md 8(d) budget per rollout-iteration x iterations/s, against the roofs of `world` GPUs)
+        it_scale = N / 25.0
+        roof["whole_iteration_frac"] = value * ITER_FLOPS_N25 * it_scale / (FP64_PEAK_TFLOPS * 1e12 * world)
+        roof["whole_iteration_frac_hbm"] = value * ITER_BYTES_N25 * it_scale / (HBM_PEAK_GBS * 1e9 * world)
+        if dom_kernel == "k_backward_wave" and d["avg_launch_ms"] > 0:
+            # `achieved` / `frac` are ALGORITHMIC-equivalent rates (914 786 flop per knot, the dense minimal-reuse count); the kernel
+            # issues fewer, padded products: MFMA count x 2048 flops is what the hardware executes
+            variant = "folded" if (os.environ.get("ILQR_BACKWARD", "wave") == "wave") else "generic"
+            ex = MFMA_PER_KNOT[variant] * 2048.0 * N * (B / n_slices)
+            roof["executed_mfma_flops_per_launch"] = ex
+            roof["frac_executed_mfma"] = ex / (d["avg_launch_ms"] * 1e-3) / 1e12 / FP64_PEAK_TFLOPS
+            roof["riccati_variant"] = variant
         roof.update({"kernel": dom_kernel, "compute_unit": d["compute_unit"], "avg_launch_ms": d["avg_launch_ms"], "launches": d["launches"],
                      "avg_launch_ms_all_passes": d["avg_launch_ms_all_passes"],
                      "algorithmic_flops_per_launch": d["algorithmic_flops_per_launch"],
                      "algorithmic_bytes_per_launch": d["algorithmic_bytes_per_launch"],
                      "frac_compute": d["frac_compute"], "frac_hbm": d["frac_hbm"],
                      "kernel_total_ms_per_step": d["total_ms_per_step"], "kernel_exclusive_ms_per_step": d["exclusive_ms_per_step"],
-                     "note": "full-batch launches of the timed steps only (HIP events on the launch stream; this kernel group was picked on an untimed probe "
+                     "note": "achieved / frac = ALGORITHMIC flops (or bytes) of one launch / its average duration -- an algorithmic-equivalent rate, not a count of issued "
+                             "instructions (executed_mfma_flops_per_launch / frac_executed_mfma give the issued MFMA flops of the Riccati kernel); "
+                             "whole_iteration_frac = iterations/s x SURVEY 8(d)'s 27.8 MFLOP (2.43 MB) per rollout-iteration against the fp64 (HBM) roof; "
+                             "full-batch launches of the timed steps only (HIP events on the launch stream; this kernel group was picked on an untimed probe "
                              "step with every stage timed, and is the only one that carries event pairs inside the timed region); traffic = 2 x FETCH_SIZE + WRITE_SIZE of a full-batch launch from "
                              "separate rocprofv3 --pmc passes of this command (see traffic_source), null when no record matches this run; "
                              "linearisation, cost quadratics and nominal re-rollout overlap on three streams: their spans include contention, the dominant "
@@ -418,12 +484,13 @@ def main():
             "metric": "iLQR iterations/sec (H1 nx=51 nu=19 N=%d)" % N, "value": value, "unit": "iterations/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "BASELINE.json configs[2]: batch=%d/GPU full iLQR (rollout+Jacobians+cost quadratics+Riccati+8-alpha line search), "
-                                   "H1 standing balance, N=%d, dt=0.02, %d fixed iterations per rollout, shipped config.yaml weights, gravity %s"
-                                   % (B, N, iters, list(prob["gravity"])),
+            "config": {"workload": workload_label(args, B, N, iters, world, prob["gravity"]),
+                       "flop_source": FLOP_SOURCE,
                        "batch_per_gpu": B, "global_batch": B * world, "horizon": N, "iterations_per_solve": iters,
                        "jacobians": "analytic (constrained step)" if args.contact else "analytic", "contact_mode": bool(args.contact), "batch_slices": n_slices, "gather": "u0+cost" + ("+K0" if args.gather_gains else ""), "gather_check": gather_check,
-                       "collective": ("none (one GPU)" if world == 1 else "gloo, host-staged (one-GPU rehearsal)" if args.rehearse_single_gpu else "RCCL gather to rank 0")},
+                       "collective": ("ilqr_hip_gather_first_knot, one rank: device copy (no RCCL)" if world == 1 else
+                                      "ilqr_hip_gather_first_knot per rank + gloo, host-staged (one-GPU rehearsal)" if args.rehearse_single_gpu else
+                                      "RCCL grouped send/recv behind the C ABI (ilqr_hip_gather_first_knot)")},
             "roofline": roof,
             "kernels": {n: {k: (round(v, 6) if isinstance(v, float) else v) for k, v in t.items() if k in
                             ("total_ms_per_step", "exclusive_ms_per_step", "avg_launch_ms", "frac_compute", "frac_hbm")} for n, t in table.items()},

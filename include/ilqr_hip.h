@@ -96,8 +96,17 @@ int ilqr_hip_initialize_device(ilqr_hip_ctx* ctx, const double* x0_device, const
    with ilqr_hip_set_references; x0[B][51] (host) or NULL to reuse the x0 given to initialize.
    cost_out[B] may be NULL.  Runs asynchronously on the handle's stream and synchronises before returning. */
 int ilqr_hip_solve(ilqr_hip_ctx* ctx, const double* x0, double* cost_out);
-/* enqueue only (no host synchronisation, nothing copied back); pair with ilqr_hip_synchronize */
+/* enqueue only (nothing copied back); pair with ilqr_hip_synchronize.
+   With the reference's convergence exit on (ilqr_hip_set_options early_exit = 1, the default; ilqr.cpp:645-655) AND the
+   early-exit gate on (ilqr_hip_set_early_exit_gate, default on) this call BLOCKS the host while it enqueues: it launches
+   iteration i only after it has seen how many rollouts were still active after iteration i - 2, and stops once that count is
+   zero.  The device never waits (one full iteration stays queued), but a host thread that drives several handles, or overlaps
+   its own work with the solve, should turn the gate off for a handle: the call then enqueues all max_iter iterations and
+   returns at once (converged rollouts are masked out on the device, results are identical). */
 int ilqr_hip_solve_async(ilqr_hip_ctx* ctx);
+/* per-handle switch of the early-exit gate described above (1 = on, the default).  The environment variable ILQR_EE_GATE,
+   when set, overrides it for every handle of the process (diagnostics). */
+int ilqr_hip_set_early_exit_gate(ilqr_hip_ctx* ctx, int on);
 int ilqr_hip_synchronize(ilqr_hip_ctx* ctx);
 
 /* accessors: iLQR::xbar/ubar/gainsK/gainsKff -- include/ilqr/ilqr.hpp:34-37 */
@@ -184,7 +193,7 @@ int ilqr_hip_get_adopt_mismatches(ilqr_hip_ctx* ctx, unsigned long long* count);
 int ilqr_hip_get_stage_ms(ilqr_hip_ctx* ctx, double* ms /*[8]*/, double* launches /*[8]*/);
 /* Iterations whose kernels the last solve enqueued: max_iterations, or fewer when the convergence exit (ilqr.cpp:645-655,
    ilqr_hip_set_options early_exit) is on and every rollout of the batch had left the loop -- the host follows the device-side
-   count of active rollouts one iteration behind and stops launching (environment ILQR_EE_GATE=0 turns that off).
+   count of active rollouts one iteration behind and stops launching (ilqr_hip_set_early_exit_gate(ctx, 0) turns that off).
    Returns the count, or -1 for a null handle. */
 int ilqr_hip_get_iterations_enqueued(const ilqr_hip_ctx* ctx);
 

@@ -103,6 +103,8 @@ class iLQR {
   // build-specific: analytic Jacobians (default) or the reference's forward differences (robot_utils.cpp:120-160);
   // early_exit = false runs exactly max_iterations iterations
   void setOptions(int jacobian_mode, double fd_eps = 1e-5, bool early_exit = true) { chk(ilqr_hip_set_options(ctx_, jacobian_mode, fd_eps, early_exit ? 1 : 0)); }
+  // off: solveAsync enqueues every iteration at once and never blocks the host (see ilqr_hip_solve_async in ilqr_hip.h)
+  void setEarlyExitGate(bool on) { chk(ilqr_hip_set_early_exit_gate(ctx_, on ? 1 : 0)); }
   void enableProfiling(bool on) { chk(ilqr_hip_enable_profiling(ctx_, on ? 1 : 0)); }
   // device time per stage of the last solve, keyed like the reference's profiler (ilqr.cpp:537-639)
   std::map<std::string, double> stageMs() {

@@ -226,7 +226,8 @@ __global__ void __launch_bounds__(64) k_traj_knot_cost(DevState S, ProblemDev P,
       constexpr int NIT = (32 * H1_NX + 63) / 64;
       double tmp[NIT];
 #pragma unroll
-      for (int it = 0; it < NIT; ++it) { const int e = lane + 64 * it; tmp[it] = src[r0 * H1_NX + (e < cnt ? e : 0)]; }
+      // (lanes past the block's rows fall back to its FIRST row, which always exists: with <= 32 rows left the second half has none)
+      for (int it = 0; it < NIT; ++it) { const int e = lane + 64 * it; tmp[it] = src[e < cnt ? r0 * H1_NX + e : 0]; }
 #pragma unroll
       for (int it = 0; it < NIT; ++it) { const int e = lane + 64 * it; if (e < cnt) xs[e] = tmp[it]; }
     }

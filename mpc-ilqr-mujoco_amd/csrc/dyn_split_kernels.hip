@@ -213,9 +213,13 @@ __global__ void __launch_bounds__(64) k_line_search_s(DevState S, ProblemDev P, 
 #pragma unroll
         for (int sk = 0; sk < 13; ++sk) {
           double bv = lds[4 * sk * 64 + 16 * r + offB];
-          if (sk == 12) bv = lk == 3 ? 0.0 : bv;              // column 51 does not exist
-          d0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ka[r % 3][0][sk], bv, d0, 0, 0, 0);
-          d1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ka[r % 3][1][sk], bv, d1, 0, 0, 0);
+          double a0 = ka[r % 3][0][sk], a1 = ka[r % 3][1][sk];
+          // column 51 does not exist: BOTH operands of the phantom k-step are zeroed.  The A operand fetched there is the first
+          // entry of the next row of K (row 18 of the last knot: of the NEXT rollout's gains), and 0 * NaN = NaN -- a diverged
+          // neighbour would otherwise poison u[18] of a healthy rollout (rollouts are independent; GPU test)
+          if (sk == 12) { bv = lk == 3 ? 0.0 : bv; a0 = lk == 3 ? 0.0 : a0; a1 = lk == 3 ? 0.0 : a1; }
+          d0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, bv, d0, 0, 0, 0);
+          d1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, bv, d1, 0, 0, 0);
         }
         if (lr < 8) {
 #pragma unroll

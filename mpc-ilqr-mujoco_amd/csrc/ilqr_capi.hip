@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -48,6 +49,7 @@ struct ilqr_hip_ctx {
   int jac_mode = ILQR_JAC_ANALYTIC;
   double fd_eps = 1e-5;
   int early_exit = 1;
+  int ee_gate = 1;            // early-exit gate (ilqr_hip_set_early_exit_gate): solve_async waits for iteration i - 2 before it enqueues iteration i
   bool initialized = false, refs_set = false;
   // early-exit gate: the number of rollouts still active after each iteration travels to this pinned array behind the
   // iteration; the host stays one iteration ahead of the device and stops enqueuing once the batch has converged
@@ -272,6 +274,7 @@ int ilqr_hip_set_options(ilqr_hip_ctx* c, int jacobian_mode, double fd_eps, int 
   c->jac_mode = jacobian_mode; c->fd_eps = fd_eps; c->early_exit = early_exit ? 1 : 0;
   return ILQR_OK;
 }
+int ilqr_hip_set_early_exit_gate(ilqr_hip_ctx* c, int on) { if (!c) return ILQR_ERR_ARG; c->ee_gate = on ? 1 : 0; return ILQR_OK; }
 
 // ---------------------------------------------------------------- initializeWithReference
 static int cold_start_device(ilqr_hip_ctx* c, const double* x0_dev, const double* uinit_dev) {
@@ -341,11 +344,7 @@ static void collect_profile(ilqr_hip_ctx* c) {
   c->spans.clear(); c->pool_next = 0;
 }
 
-static int reuse_rollout() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("ILQR_REUSE_ROLLOUT"); v = (e && e[0] == '1') ? 1 : 0; }
-  return v;
-}
+static int reuse_rollout() { const char* e = getenv("ILQR_REUSE_ROLLOUT"); return (e && e[0] == '1') ? 1 : 0; }   // read at every solve, like every other switch
 #ifndef SLICES_DEFAULT
 #define SLICES_DEFAULT 1
 #endif
@@ -357,11 +356,7 @@ static int slices_wanted(int B) {      // read at every solve: tests switch it w
   while (k > 1 && B / k < 64) --k;   // a slice is at least one wave of the widest kernels
   return k;
 }
-static int stagger_wanted() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("ILQR_STAGGER"); v = e ? atoi(e) : 1; }
-  return v;
-}
+static int stagger_wanted() { const char* e = getenv("ILQR_STAGGER"); return e ? atoi(e) : 1; }
 // view of rollouts [b0, b0 + Bs) of the batch (every array is rollout-major)
 static DevState slice_state(const DevState& S, size_t b0, int Bs) {
   DevState T = S;
@@ -400,7 +395,8 @@ static int ensure_slices(ilqr_hip_ctx* c, int k) {
 // the launch sequence of iLQR::solve (ilqr.cpp:521-660) for one slice on its streams; `wait_lead` (optional) delays the
 // first throughput-bound stage until the previous slice has finished its first backward pass, `lead` is recorded there
 static int overlap_rollout() { const char* e = getenv("ILQR_OVERLAP_ROLLOUT"); return e ? atoi(e) : 1; }
-static int early_exit_gate() { const char* e = getenv("ILQR_EE_GATE"); return e ? atoi(e) : 1; }
+// the handle's own setting (ilqr_hip_set_early_exit_gate); the environment, when set, overrides it (diagnostics, tests)
+static int early_exit_gate(const ilqr_hip_ctx* c) { const char* e = getenv("ILQR_EE_GATE"); return e ? atoi(e) : c->ee_gate; }
 static int ensure_gate(ilqr_hip_ctx* c) {
   if ((int)c->ev_active.size() >= c->max_iter + 2 && c->h_active) return ILQR_OK;
   if (c->h_active) { (void)hipHostFree(c->h_active); c->h_active = nullptr; }
@@ -421,7 +417,7 @@ static int enqueue_solve(ilqr_hip_ctx* c, const DevState& S, const h1::ProblemDe
   // queued on the device meanwhile, so the device never waits for the host.  (ILQR_EE_GATE=0: always enqueue max_iter.)
   // without the convergence exit every rollout stays active: the per-knot kernels then skip the selection altogether
   const int sel_mode = c->early_exit ? ilqr::MASK_ACTIVE : ilqr::MASK_ALL;
-  const bool gate = c->early_exit && S.order && early_exit_gate();
+  const bool gate = c->early_exit && S.order && early_exit_gate(c);
   if (gate) TRY(ensure_gate(c));
   c->iterations_enqueued = c->max_iter;
   for (int iter = 0; iter < c->max_iter; ++iter) {
@@ -728,24 +724,33 @@ struct Rccl {
   std::string err;
 };
 Rccl g_rccl;
+std::once_flag g_rccl_once;
+bool g_rccl_ok = false;
+// Opened and resolved exactly once per process, whichever host thread gets there first (the multi-GPU C++ model is one thread
+// and one handle per GPU, tests/cpp/cpp_multi_gpu_demo.cpp); the table is published only after every symbol has resolved.
 bool rccl_load() {
-  Rccl& R = g_rccl;
-  if (R.lib) return true;
-  const char* names[] = {getenv("ILQR_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-  for (const char* n : names) { if (n && (R.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break; }
-  if (!R.lib) { R.err = std::string("cannot open librccl: ") + dlerror(); return false; }
-  bool ok = true;
-  auto sym = [&](const char* n) { void* p = dlsym(R.lib, n); if (!p) { ok = false; R.err = std::string("librccl lacks ") + n; } return p; };
-  R.GetUniqueId = (decltype(R.GetUniqueId))sym("ncclGetUniqueId");
-  R.CommInitRank = (decltype(R.CommInitRank))sym("ncclCommInitRank");
-  R.CommDestroy = (decltype(R.CommDestroy))sym("ncclCommDestroy");
-  R.Send = (decltype(R.Send))sym("ncclSend");
-  R.Recv = (decltype(R.Recv))sym("ncclRecv");
-  R.GroupStart = (decltype(R.GroupStart))sym("ncclGroupStart");
-  R.GroupEnd = (decltype(R.GroupEnd))sym("ncclGroupEnd");
-  R.GetErrorString = (decltype(R.GetErrorString))sym("ncclGetErrorString");
-  if (!ok) { dlclose(R.lib); R.lib = nullptr; }
-  return ok;
+  std::call_once(g_rccl_once, [] {
+    Rccl R;
+    const char* names[] = {getenv("ILQR_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    void* lib = nullptr;
+    for (const char* n : names) { if (n && (lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break; }
+    if (!lib) { const char* de = dlerror(); g_rccl.err = std::string("cannot open librccl: ") + (de ? de : "?"); return; }
+    bool ok = true;
+    auto sym = [&](const char* n) { void* p = dlsym(lib, n); if (!p) { ok = false; g_rccl.err = std::string("librccl lacks ") + n; } return p; };
+    R.GetUniqueId = (decltype(R.GetUniqueId))sym("ncclGetUniqueId");
+    R.CommInitRank = (decltype(R.CommInitRank))sym("ncclCommInitRank");
+    R.CommDestroy = (decltype(R.CommDestroy))sym("ncclCommDestroy");
+    R.Send = (decltype(R.Send))sym("ncclSend");
+    R.Recv = (decltype(R.Recv))sym("ncclRecv");
+    R.GroupStart = (decltype(R.GroupStart))sym("ncclGroupStart");
+    R.GroupEnd = (decltype(R.GroupEnd))sym("ncclGroupEnd");
+    R.GetErrorString = (decltype(R.GetErrorString))sym("ncclGetErrorString");
+    if (!ok) { dlclose(lib); return; }
+    R.lib = lib;
+    g_rccl = R;
+    g_rccl_ok = true;
+  });
+  return g_rccl_ok;
 }
 }  // namespace
 #define NCCLCHK(ctx, call)                                                                          \
@@ -801,12 +806,14 @@ int ilqr_hip_gather_first_knot(ilqr_hip_ctx* c, int root, int with_gains, double
     if (!c->comm) { c->err = "gather before ilqr_hip_comm_init"; return ILQR_ERR_STATE; }
     // a gather as grouped point-to-point transfers: every peer sends to the root over its own xGMI link
     NCCLCHK(c, g_rccl.GroupStart());
+    ncclResult_t gr = ncclSuccess;      // an error inside the group still closes it before the call returns
     if (c->rank == root) {
-      for (int r = 0; r < c->world; ++r) if (r != root) NCCLCHK(c, g_rccl.Recv(recv_device + (size_t)r * cnt, cnt, ncclDouble, r, c->comm, c->stream));
+      for (int r = 0; r < c->world && gr == ncclSuccess; ++r) if (r != root) gr = g_rccl.Recv(recv_device + (size_t)r * cnt, cnt, ncclDouble, r, c->comm, c->stream);
     } else {
-      NCCLCHK(c, g_rccl.Send(c->d_payload, cnt, ncclDouble, root, c->comm, c->stream));
+      gr = g_rccl.Send(c->d_payload, cnt, ncclDouble, root, c->comm, c->stream);
     }
-    NCCLCHK(c, g_rccl.GroupEnd());
+    const ncclResult_t ge = g_rccl.GroupEnd();
+    if (gr != ncclSuccess || ge != ncclSuccess) { c->err = std::string("RCCL gather (grouped send/recv): ") + g_rccl.GetErrorString(gr != ncclSuccess ? gr : ge); return ILQR_ERR_HIP; }
   }
   return ILQR_OK;   // asynchronous on the handle's stream: ilqr_hip_synchronize before reading recv_device
 }

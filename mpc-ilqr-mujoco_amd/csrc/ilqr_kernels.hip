@@ -654,8 +654,11 @@ static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 //   ILQR_LS=s|r       line search on two lanes or one lane per candidate
 //   ILQR_BACKWARD=wave|wave-generic|wg|valu  one-wave MFMA (riccati_wave.hip; "wave-generic" = never the folded variant) /
 //                     four-wave MFMA (riccati_mfma.hip) / LDS + VALU cross-check
+// One copy per host thread: every C-ABI call refreshes the calling thread's copy on entry (ilqr_capi.hip enter()) and the
+// launchers it then calls read that same copy, so handles driven from different host threads (one thread and one handle per
+// GPU, tests/cpp/cpp_multi_gpu_demo.cpp) never write to shared state.
 struct Variants { int scalar_dyn, rollout_split, ls_split, backward, fold; };
-static Variants g_var = {0, ROLLOUT_SPLIT_DEFAULT, LS_SPLIT_DEFAULT, -1, 1};
+static thread_local Variants g_var = {0, ROLLOUT_SPLIT_DEFAULT, LS_SPLIT_DEFAULT, -1, 1};
 static int env_split(const char* var, int dflt) { const char* e = getenv(var); return !e ? dflt : (e[0] == 's' ? 1 : 0); }
 #ifndef BACKWARD_DEFAULT
 #define BACKWARD_DEFAULT 2

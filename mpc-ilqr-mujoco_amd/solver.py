@@ -25,7 +25,7 @@ EXPORTS = [
     "ilqr_hip_create", "ilqr_hip_destroy", "ilqr_hip_last_error", "ilqr_hip_batch", "ilqr_hip_horizon", "ilqr_hip_num_slices",
     "ilqr_hip_set_cost_weights", "ilqr_hip_set_task_weights", "ilqr_hip_set_constraint_weights", "ilqr_hip_set_gravity",
     "ilqr_hip_set_contact_schedule", "ilqr_hip_set_ee_references", "ilqr_hip_set_references",
-    "ilqr_hip_set_regularization", "ilqr_hip_set_max_iterations", "ilqr_hip_set_tolerance", "ilqr_hip_set_options",
+    "ilqr_hip_set_regularization", "ilqr_hip_set_max_iterations", "ilqr_hip_set_tolerance", "ilqr_hip_set_options", "ilqr_hip_set_early_exit_gate",
     "ilqr_hip_initialize", "ilqr_hip_initialize_warm_resident", "ilqr_hip_initialize_device",
     "ilqr_hip_solve", "ilqr_hip_solve_async", "ilqr_hip_synchronize",
     "ilqr_hip_get_xbar", "ilqr_hip_get_ubar", "ilqr_hip_get_gains_K", "ilqr_hip_get_gains_kff", "ilqr_hip_get_cost",
@@ -176,6 +176,10 @@ class BatchedILQR:
 
     def set_options(self, jacobian_mode=JAC_ANALYTIC, fd_eps=1e-5, early_exit=True):
         self._chk(self.L.ilqr_hip_set_options(self.h, int(jacobian_mode), C.c_double(fd_eps), int(bool(early_exit))))
+
+    def set_early_exit_gate(self, on=True):
+        """Per-handle switch of the early-exit gate: off = solve_async enqueues all iterations at once and never blocks the host."""
+        self._chk(self.L.ilqr_hip_set_early_exit_gate(self.h, int(bool(on))))
 
     # ---- initializeWithReference / solve
     def initialize(self, x0, u_init=None, prev_xbar=None, prev_ubar=None):

@@ -106,3 +106,22 @@ def test_bench_picks_the_dominant_kernel_group_on_exclusive_equivalent_time():
     stage["iLQR_backwardPass"] = 2.0; stage["iLQR_backwardPass_retry"] = 1.0
     name, keys = bench.dominant_group(groups, stage)
     assert name == "k_lin_primal_s+k_lin_tangent" and keys == ["iLQR_linearization"]
+
+
+def test_bench_names_a_baseline_config_only_when_it_runs_one_and_stamps_the_kernel_sources():
+    """bench.py: config.workload says 'BASELINE.json configs[k]' only when (batch, horizon, iterations, contact, world) is that
+    config; the PMC traffic record (profiles/traffic_latest.json) is attached only to the build it was collected on -- the run
+    signature carries a hash of the kernel sources."""
+    import importlib.util, types
+    spec = importlib.util.spec_from_file_location("bench_mod2", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
+    a = types.SimpleNamespace(contact=False, batch=4096, horizon=25, iters=10)
+    g = (0.0, 0.0, -1.0)
+    assert bench.workload_label(a, 4096, 25, 10, 1, g).startswith("BASELINE.json configs[2]:")
+    assert bench.workload_label(a, 4096, 25, 10, 8, g).startswith("BASELINE.json configs[3]")
+    assert bench.workload_label(a, 4096, 25, 10, 2, g).startswith("per-GPU shape of BASELINE.json configs[2]/[3] on 2 GPUs")
+    for B, N, it in ((1024, 50, 10), (1024, 25, 10), (4096, 25, 5), (1, 25, 10)):
+        assert bench.workload_label(a, B, N, it, 1, g).startswith("custom:")
+    assert bench.workload_label(types.SimpleNamespace(contact=True), 4096, 25, 10, 1, (0, 0, -9.81)).startswith("custom (contact row f4")
+    sig = bench.run_signature(a, 1)
+    assert len(sig["csrc_sha"]) == 16 and sig["csrc_sha"] == bench.csrc_hash() and sig["batch"] == 4096

@@ -198,7 +198,16 @@ def test_early_exit_gate_stops_launching_and_changes_nothing():
             s.initialize_warm_resident(x0); cost2 = s.solve(x0)
             out[gate] = (cost, cost2, s.iterations(), s.gains_K(), s.xbar(), s.trace()[0], s.iterations_enqueued())
             s.close()
+    # the per-handle switch (ilqr_hip_set_early_exit_gate) does what the process-wide environment variable does
+    s = _solver(B); s.set_problem(prob); s.set_options(early_exit=True); s.set_max_iterations(10); s.set_early_exit_gate(False)
+    s.initialize(x0, ui); cost = s.solve(x0)
+    s.initialize_warm_resident(x0); cost2 = s.solve(x0)
+    out["handle-off"] = (cost, cost2, s.iterations(), s.gains_K(), s.xbar(), s.trace()[0], s.iterations_enqueued())
+    s.close()
+    assert out["handle-off"][6] == 10
     for a, b_ in zip(out["1"][:6], out["0"][:6]):
+        assert np.array_equal(a, b_, equal_nan=True)
+    for a, b_ in zip(out["1"][:6], out["handle-off"][:6]):
         assert np.array_equal(a, b_, equal_nan=True)
     its = out["1"][2]
     assert out["0"][6] == 10 and out["1"][6] < 10 and out["1"][6] >= its.max()      # launched no more than one or two idle iterations
@@ -246,6 +255,36 @@ def test_line_search_variants_match_oracle(ls):
         o.backward_pass()
         ok, c, a = o.line_search(x0[b])
         assert ok == bool(imp[b]) and a == alpha[b] and abs(c - cost[b]) < 1e-8 * abs(c) and rel(xn[b], o.get("xbar")) < 1e-8
+
+
+def test_diverged_neighbour_does_not_poison_a_healthy_rollout():
+    """Rollouts are independent (no cross-rollout term anywhere in ilqr.cpp).  The MFMA feedback of the two-lane line search pads
+    K_t to 52 columns; the A operand of the phantom column is the first entry of the NEXT row of K -- at row 18 of the last knot
+    that is the next ROLLOUT's K_0[0][0] -- so both operands are zeroed (0 * NaN would be NaN).  One rollout of the batch gets
+    NaN gains (through NaN quadratics); every other rollout's line search must be bit-identical to the all-healthy run."""
+    B = 8
+    prob, x0, ui = standing(B, seed=23)
+    s = _solver(B); s.set_problem(prob)
+    s.initialize(x0, ui)
+    s.stage_linearize(); s.stage_cost_quadratics()
+    xb, ub = s.xbar(), s.ubar()
+    lx, lu, lxx, luu = s.quadratics()
+    s.stage_backward_pass()
+    imp0, cost0, alpha0 = s.stage_line_search()
+    xn0, un0 = s.xbar(), s.ubar()
+    for bad in (1, 5):                      # bad - 1 is the rollout whose last-knot feedback reads past its own gains
+        s.set_trajectory(xb, ub)
+        lxx_bad = lxx.copy(); lxx_bad[bad, -1] = np.nan
+        s.set_quadratics(lx, lu, lxx_bad, luu)
+        s.stage_backward_pass()
+        assert np.all(np.isnan(s.gains_K()[bad]))
+        imp, cost, alpha = s.stage_line_search()
+        xn, un = s.xbar(), s.ubar()
+        ok = [b for b in range(B) if b != bad]
+        assert not imp[bad]
+        assert np.array_equal(imp[ok], imp0[ok]) and np.array_equal(cost[ok], cost0[ok]) and np.array_equal(alpha[ok], alpha0[ok])
+        assert np.array_equal(xn[ok], xn0[ok]) and np.array_equal(un[ok], un0[ok])
+    s.close()
 
 
 # ---------------------------------------------------------------------------------------------------------------------
