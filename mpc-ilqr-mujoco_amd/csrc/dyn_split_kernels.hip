@@ -153,12 +153,41 @@ __global__ void __launch_bounds__(64) k_line_search_s(DevState S, ProblemDev P, 
     double* xc = S.xcand + ((size_t)bt * 8 + ai) * (N + 1) * n;
     double* uc = S.ucand + ((size_t)bt * 8 + ai) * N * m;
     const double* xbt = xb + t * n;
-    // ---- everything this step reads from HBM for this lane's half, in one batch: nominal state (for x - xbar),
-    // nominal control and feedforward of the rows this side owns
+    // ---- everything this step reads from HBM, requested in ONE batch at the very top: the K_t operands of the wave's first two
+    // rollouts (MFMA feedback below; left to itself the scheduler sinks these 52 loads down to their first use, behind the state
+    // exchange and its barrier -- a second exposed HBM round trip per step), then this lane's half of the nominal state (for
+    // x - xbar), nominal control and feedforward.  The scheduling fence keeps the order of issue.
+    typedef double v4d_s __attribute__((ext_vector_type(4)));
+    typedef double v2d_s __attribute__((ext_vector_type(2)));
+    const int lk = lane >> 4, lr = lane & 15;
+    const int rowA1 = (16 + lr) < m ? (16 + lr) : (m - 1);
+    // K_t operands of the MFMA feedback, fetched sector by sector.  The 51 contraction indices can be dealt to the (k-step,
+    // lk) slots in any order as long as both operands agree: instruction j = 0..5 takes 16 bytes per lane at
+    // K_t[row][8 j + 2 lk], i.e. indices 8 j + 2 lk + h (h = 0, 1) for the k-steps 2 j + h, so the four lk lanes of a row
+    // fetch ONE contiguous 64-byte sector and every sector of K_t is requested exactly once (with the plain mapping 4 sk + lk
+    // a lane fetched 8 bytes and every sector was requested by two to four instructions, out of an L1 the four waves of a
+    // CU thrash: the line search waited on its own re-fetches); k-step 12 takes the last three columns 48 + lk as before.
+    const unsigned offA0 = (unsigned)(lr * n + 2 * lk), offA1 = (unsigned)(rowA1 * n + 2 * lk);
+    const unsigned offT0 = (unsigned)(lr * n + 48 + lk), offT1 = (unsigned)(rowA1 * n + 48 + lk);
+    v2d_s ka[3][2][6];
+    double kt[3][2];
+    auto fetchK = [&](int slot, int r) {
+      const double* Kt = S.K + ((size_t)bw[r] * N + t) * m * n;
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        ka[slot][0][j] = *reinterpret_cast<const v2d_s*>(Kt + 8 * j + offA0);
+        ka[slot][1][j] = *reinterpret_cast<const v2d_s*>(Kt + 8 * j + offA1);
+      }
+      kt[slot][0] = Kt[offT0]; kt[slot][1] = Kt[offT1];
+    };
+    fetchK(0, 0); fetchK(1, 1);
     h1s::HalfX xh; h1s::HalfU ubh, kfh;
     h1s::load_half(side, xbt, xh);
     load_half_u(side, ub + t * m, ubh);
     load_half_u(side, kg + t * m, kfh);
+#ifndef LS_NO_HOIST
+    __builtin_amdgcn_sched_barrier(0);
+#endif
     // ---- u = ubar + alpha k + K (x - xbar)   (ilqr.cpp:332-333)
     // state deviations of this candidate -> LDS slot j of the pair's column (even lane: shared coordinates + left)
     if (!side) {
@@ -183,41 +212,33 @@ __global__ void __launch_bounds__(64) k_line_search_s(DevState S, ProblemDev P, 
     }
     __syncthreads();
     // ---- U_r = K_t,r dX_r on v_mfma_f64_16x16x4_f64, one product per rollout r of the wave (19 x 51 x 8, padded 32 x 52 x 16):
-    //   A (16 x 4 per k-step s, row tile I): lane l = K_t[16 I + (l & 15)][4 s + (l >> 4)]  straight from HBM (rows past 18 clamped)
-    //   B (4 x 16):                          lane l = dx_{4 s + (l >> 4)} of candidate l & 7   from the exchange rows in LDS
+    //   A (16 x 4 per k-step s, row tile I): lane l = K_t[16 I + (l & 15)][kappa(s, l >> 4)]  straight from HBM (rows past 18 clamped)
+    //   B (4 x 16):                          lane l = dx_{kappa(s, l >> 4)} of candidate l & 7   from the exchange rows in LDS
+    //   (kappa: the dealing of the contraction indices to the slots, see the fetch at the top of the step)
     //   D lane l register q = U[16 I + 4 q + (l >> 4)][candidate l & 15]                       -> LDS rows 52.. -> the owning lanes
     // 104 MFMA per step instead of ~1900 VALU instructions (a lone wave pays 8 cycles for each of those, 64 for an MFMA); the
     // operands of rollout r + 2 are requested before the products of rollout r start.
     {
-      typedef double v4d_s __attribute__((ext_vector_type(4)));
-      const int lk = lane >> 4, lr = lane & 15;
-      const int rowA1 = (16 + lr) < m ? (16 + lr) : (m - 1);
-      const unsigned offA0 = (unsigned)(lr * n + lk), offA1 = (unsigned)(rowA1 * n + lk);
-      const int offB = lk * 64 + 2 * (lr & 7);
+      const int offB = 2 * lk * 64 + 2 * (lr & 7), offBt = (48 + lk) * 64 + 2 * (lr & 7);
       constexpr int UROW = 52;                        // LDS rows 52..70: the 19 feedback terms, column = the pair's
-      double ka[3][2][13];
-#pragma unroll
-      for (int r = 0; r < 2; ++r) {
-        const double* Kt = S.K + ((size_t)bw[r] * N + t) * m * n;
-#pragma unroll
-        for (int sk = 0; sk < 13; ++sk) { ka[r][0][sk] = (Kt + 4 * sk)[offA0]; ka[r][1][sk] = (Kt + 4 * sk)[offA1]; }
-      }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        if (r + 2 < 4) {
-          const double* Kt = S.K + ((size_t)bw[r + 2] * N + t) * m * n;
-#pragma unroll
-          for (int sk = 0; sk < 13; ++sk) { ka[(r + 2) % 3][0][sk] = (Kt + 4 * sk)[offA0]; ka[(r + 2) % 3][1][sk] = (Kt + 4 * sk)[offA1]; }
-        }
+        if (r + 2 < 4) fetchK((r + 2) % 3, r + 2);
         v4d_s d0 = {0.0, 0.0, 0.0, 0.0}, d1 = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int sk = 0; sk < 13; ++sk) {
-          double bv = lds[4 * sk * 64 + 16 * r + offB];
-          double a0 = ka[r % 3][0][sk], a1 = ka[r % 3][1][sk];
-          // column 51 does not exist: BOTH operands of the phantom k-step are zeroed.  The A operand fetched there is the first
-          // entry of the next row of K (row 18 of the last knot: of the NEXT rollout's gains), and 0 * NaN = NaN -- a diverged
-          // neighbour would otherwise poison u[18] of a healthy rollout (rollouts are independent; GPU test)
-          if (sk == 12) { bv = lk == 3 ? 0.0 : bv; a0 = lk == 3 ? 0.0 : a0; a1 = lk == 3 ? 0.0 : a1; }
+        for (int j = 0; j < 6; ++j)
+#pragma unroll
+          for (int hh = 0; hh < 2; ++hh) {
+            const double bv = lds[(8 * j + hh) * 64 + 16 * r + offB];      // dx of index 8 j + 2 lk + hh
+            d0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ka[r % 3][0][j][hh], bv, d0, 0, 0, 0);
+            d1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ka[r % 3][1][j][hh], bv, d1, 0, 0, 0);
+          }
+        {
+          // k-step 12: indices 48 + lk; column 51 does not exist: BOTH operands of the phantom slot are zeroed.  The A operand
+          // fetched there is the first entry of the next row of K (row 18 of the last knot: of the NEXT rollout's gains), and
+          // 0 * NaN = NaN -- a diverged neighbour would otherwise poison u[18] of a healthy rollout (GPU test)
+          double bv = lds[16 * r + offBt], a0 = kt[r % 3][0], a1 = kt[r % 3][1];
+          bv = lk == 3 ? 0.0 : bv; a0 = lk == 3 ? 0.0 : a0; a1 = lk == 3 ? 0.0 : a1;
           d0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, bv, d0, 0, 0, 0);
           d1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, bv, d1, 0, 0, 0);
         }

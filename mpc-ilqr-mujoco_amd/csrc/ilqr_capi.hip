@@ -56,6 +56,7 @@ struct ilqr_hip_ctx {
   int* h_active = nullptr;
   std::vector<hipEvent_t> ev_active;
   int iterations_enqueued = 0;
+  bool lxx_lower = false;    // S.lxx of the knots t < N holds the tiles I >= J only (last written inside a solve): getters mirror them
   double lin_fold_h = 0.0;   // step size h while S.A / S.Bm hold the analytic Jacobians (folded backward kernel), else 0
   std::string err;
   // profiling
@@ -418,6 +419,9 @@ static int enqueue_solve(ilqr_hip_ctx* c, const DevState& S, const h1::ProblemDe
   // without the convergence exit every rollout stays active: the per-knot kernels then skip the selection altogether
   const int sel_mode = c->early_exit ? ilqr::MASK_ACTIVE : ilqr::MASK_ALL;
   const bool gate = c->early_exit && S.order && early_exit_gate(c);
+  // the one-wave Riccati kernel reads only the tiles I >= J of lxx_t (t < N): the cost quadratics then leave the others unwritten
+  const int lxx_lower = ilqr::variant_backward() == 2 ? 1 : 0;
+  if (lxx_lower) c->lxx_lower = true;
   if (gate) TRY(ensure_gate(c));
   c->iterations_enqueued = c->max_iter;
   for (int iter = 0; iter < c->max_iter; ++iter) {
@@ -447,7 +451,7 @@ static int enqueue_solve(ilqr_hip_ctx* c, const DevState& S, const h1::ProblemDe
       { StageTimer T(c, 0, st3); ilqr::launch_rollout(Sr, P, ilqr::MASK_ACTIVE, 1, 0, S.Jbase, st3); }
       HIPCHK(c, hipEventRecord(ev_roll, st3));
     }
-    { StageTimer T(c, 2, st2); ilqr::launch_cost_quadratics(S, P, sel_mode, st2, iter); }
+    { StageTimer T(c, 2, st2); ilqr::launch_cost_quadratics(S, P, sel_mode, st2, iter, lxx_lower); }
     HIPCHK(c, hipEventRecord(ev_join, st2));
     { StageTimer T(c, 1, st); ilqr::launch_linearize(S, P, sel_mode, c->jac_mode, c->fd_eps, st, 3, iter); }
     // The re-rolled trajectory replaces xbar once the linearisation and the cost quadratics have read the old one.  The backward
@@ -600,7 +604,7 @@ int ilqr_hip_set_trajectory(ilqr_hip_ctx* c, const double* xbar, const double* u
 #define STAGE_POST HIPCHK(c, hipGetLastError()); HIPCHK(c, hipStreamSynchronize(c->stream)); return ILQR_OK
 int ilqr_hip_stage_rollout(ilqr_hip_ctx* c) { STAGE_PRE; ilqr::launch_rollout(c->S, c->P, ilqr::MASK_ALL, 1, 0, c->S.Jbase, c->stream); STAGE_POST; }
 int ilqr_hip_stage_linearize(ilqr_hip_ctx* c) { STAGE_PRE; ilqr::launch_linearize(c->S, c->P, ilqr::MASK_ALL, c->jac_mode, c->fd_eps, c->stream); c->lin_fold_h = ilqr::linearize_fold_h(c->P, c->jac_mode); STAGE_POST; }
-int ilqr_hip_stage_cost_quadratics(ilqr_hip_ctx* c) { STAGE_PRE; if (!c->refs_set) return ILQR_ERR_STATE; ilqr::launch_cost_quadratics(c->S, c->P, ilqr::MASK_ALL, c->stream); STAGE_POST; }
+int ilqr_hip_stage_cost_quadratics(ilqr_hip_ctx* c) { STAGE_PRE; if (!c->refs_set) return ILQR_ERR_STATE; ilqr::launch_cost_quadratics(c->S, c->P, ilqr::MASK_ALL, c->stream); c->lxx_lower = false; STAGE_POST; }
 int ilqr_hip_stage_backward_pass(ilqr_hip_ctx* c) { STAGE_PRE; ilqr::launch_backward(c->S, ilqr::MASK_ALL, c->stream, c->lin_fold_h); STAGE_POST; }
 int ilqr_hip_stage_total_cost(ilqr_hip_ctx* c, double* cost) {
   STAGE_PRE; if (!cost || !c->refs_set) return ILQR_ERR_ARG;
@@ -648,7 +652,16 @@ int ilqr_hip_get_quadratics(ilqr_hip_ctx* c, double* lx, double* lu, double* lxx
   HIPCHK(c, hipStreamSynchronize(c->stream));
   if (lx) HIPCHK(c, hipMemcpy(lx, c->S.lx, B * (N + 1) * ILQR_NX * sizeof(double), hipMemcpyDeviceToHost));
   if (lu) HIPCHK(c, hipMemcpy(lu, c->S.lu, B * N * ILQR_NU * sizeof(double), hipMemcpyDeviceToHost));
-  if (lxx) HIPCHK(c, hipMemcpy(lxx, c->S.lxx, B * (N + 1) * ILQR_NX * ILQR_NX * sizeof(double), hipMemcpyDeviceToHost));
+  if (lxx) {
+    HIPCHK(c, hipMemcpy(lxx, c->S.lxx, B * (N + 1) * ILQR_NX * ILQR_NX * sizeof(double), hipMemcpyDeviceToHost));
+    if (c->lxx_lower) {   // the last solve stored the tiles I >= J of the knots t < N only (quad_kernels.hip): lxx is symmetric
+      for (size_t k = 0; k < B * (N + 1); ++k) {
+        if (k % (N + 1) == N) continue;
+        double* H = lxx + k * ILQR_NX * ILQR_NX;
+        for (int i = 0; i < ILQR_NX; ++i) for (int j = 16 * (i / 16 + 1); j < ILQR_NX; ++j) H[i * ILQR_NX + j] = H[j * ILQR_NX + i];
+      }
+    }
+  }
   if (luu) HIPCHK(c, hipMemcpy(luu, c->S.luu, B * N * ILQR_NU * sizeof(double), hipMemcpyDeviceToHost));
   return ILQR_OK;
 }
@@ -658,6 +671,7 @@ int ilqr_hip_set_quadratics(ilqr_hip_ctx* c, const double* lx, const double* lu,
   HIPCHK(c, hipMemcpy(c->S.lx, lx, B * (N + 1) * ILQR_NX * sizeof(double), hipMemcpyHostToDevice));
   HIPCHK(c, hipMemcpy(c->S.lu, lu, B * N * ILQR_NU * sizeof(double), hipMemcpyHostToDevice));
   HIPCHK(c, hipMemcpy(c->S.lxx, lxx, B * (N + 1) * ILQR_NX * ILQR_NX * sizeof(double), hipMemcpyHostToDevice));
+  c->lxx_lower = false;
   HIPCHK(c, hipMemcpy(c->S.luu, luu, B * N * ILQR_NU * sizeof(double), hipMemcpyHostToDevice));
   return ILQR_OK;
 }

@@ -121,7 +121,11 @@ DEVFN void d2R_sel(int k, int l, double* D) {
 // Two waves per knot share the knot's LDS record (20.4 KB bound the occupancy at 8 one-wave workgroups per CU).  `lane` runs
 // over 0..127: the lane-parallel phases 1-5 have at most 64 work items and stay on wave 0 (wave 1 waits at the barriers),
 // the Hessian -- half of the kernel -- is split: patch entries over 128 lanes, two accumulator row tiles per wave.
-__global__ void __launch_bounds__(128, QUAD_WAVES) k_cost_quadratics(DevState S, ProblemDev P, int mode, const int* list, const int* count) {
+// `lower` (inside a solve whose backward pass is the one-wave Riccati kernel): for the knots t < N only the tiles I >= J of lxx are
+// computed and stored -- exactly the ones k_backward_wave loads (load_aug<true>, riccati_wave.hip); lxx is symmetric, the six
+// strictly upper 16 x 16 tiles (35 % of its entries, 0.85 GB per launch at B = 4096) were written for nobody.  The terminal knot,
+// which that kernel loads whole, and every stage-API call keep the full matrix (ilqr_hip_get_quadratics mirrors the tiles back).
+__global__ void __launch_bounds__(128, QUAD_WAVES) k_cost_quadratics(DevState S, ProblemDev P, int mode, const int* list, const int* count, int lower) {
   const int t = blockIdx.x, lane = threadIdx.x, wv = lane >> 6;
   int b = blockIdx.y;
   if (list) {                        // compacted selection (DevState::order): no per-rollout flags to fetch, unselected workgroups leave on one cached scalar
@@ -445,7 +449,7 @@ __global__ void __launch_bounds__(128, QUAD_WAVES) k_cost_quadratics(DevState S,
   //   lk = 3 : the balance dyads w (jr0 jr0' + jr1 jr1' + jz m' + m jz'): ks = 0 jr0, 1 jr1, 2 (jz, m), 3 (m, jz)
   // operand of row tile I / column tile J = entry 16 I + lr of the row; everything beyond column 50 and every unused row is
   // a true zero (junk operands slow the fp64 MFMA down tenfold)
-  double av[4][2], bv[4][4];            // this wave's two row tiles 2 wv, 2 wv + 1; all four column tiles
+  double av[4][2], bv[4][4];            // this wave's two row tiles wv, wv + 2 (balanced when only the tiles I >= J are wanted); all four column tiles
   {
     double* const balm_ = &L.Om[0][0];
 #pragma unroll
@@ -463,10 +467,7 @@ __global__ void __launch_bounds__(128, QUAD_WAVES) k_cost_quadratics(DevState S,
         const bool ok = used && e < H1_NX;
         bv[ks][T] = ok ? rb : 0.0;
         const double avv = ok ? sA * ra : 0.0;
-        if (T == 0) { if (wv == 0) av[ks][0] = avv; }
-        else if (T == 1) { if (wv == 0) av[ks][1] = avv; }
-        else if (T == 2) { if (wv == 1) av[ks][0] = avv; }
-        else { if (wv == 1) av[ks][1] = avv; }
+        if ((T & 1) == wv) av[ks][T >> 1] = avv;          // row tile T belongs to wave T & 1, slot T >> 1
       }
     }
   }
@@ -591,22 +592,25 @@ __global__ void __launch_bounds__(128, QUAD_WAVES) k_cost_quadratics(DevState S,
   // 6c: first-order product row tile by row tile; the owner lane of an accumulator element (row 16 I + 4 r + lk, column
   // 16 J + lr) adds the diagonal terms and the patch entry of its (unordered) index pair and stores it: for a fixed
   // register the wave writes four rows x 16 consecutive columns
+  const bool low = lower && !term;
 #pragma unroll
   for (int Ii = 0; Ii < 2; ++Ii) {
-    const int I = 2 * wv + Ii;
+    const int I = wv + 2 * Ii;
     v4d_q acc[4];
 #pragma unroll
     for (int J = 0; J < 4; ++J) acc[J] = (v4d_q){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-      for (int J = 0; J < 4; ++J) acc[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ks][Ii], bv[ks][J], acc[J], 0, 0, 0);
+      for (int J = 0; J < 4; ++J)
+        if (!(low && J > I)) acc[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ks][Ii], bv[ks][J], acc[J], 0, 0, 0);      // (wave-uniform)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int a = 16 * I + 4 * r + lk;
       if (a >= H1_NX) continue;                        // rows beyond 50 do not exist (last row tile)
 #pragma unroll
       for (int J = 0; J < 4; ++J) {
+        if (low && J > I) continue;
         const int bb = 16 * J + lr;
         double h = acc[J][r];
         if (a == bb) h += L.dg[a];
@@ -619,9 +623,9 @@ __global__ void __launch_bounds__(128, QUAD_WAVES) k_cost_quadratics(DevState S,
   QSTAMP(8)
 }
 
-void launch_cost_quadratics(const DevState& S, const ProblemDev& P, int mode, hipStream_t st, int iter) {
+void launch_cost_quadratics(const DevState& S, const ProblemDev& P, int mode, hipStream_t st, int iter, int lower) {
   const WorkList w = work_list(S, mode, iter);
-  hipLaunchKernelGGL(k_cost_quadratics, dim3(S.N + 1, S.B), dim3(128), 0, st, S, P, mode, w.list, w.count);
+  hipLaunchKernelGGL(k_cost_quadratics, dim3(S.N + 1, S.B), dim3(128), 0, st, S, P, mode, w.list, w.count, lower);
 }
 
 }  // namespace ilqr
