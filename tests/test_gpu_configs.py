@@ -392,6 +392,92 @@ def test_config4_walking_windows_at_per_gpu_shape():
 
 
 # ---------------------------------------------------------------------------------------------------------------------
+# The GLOBAL sizes of the two 8-GPU configurations on ONE device (288 GB of HBM hold them: DESIGN section 2): what needs eight
+# physical GPUs is only the placement of the shards -- a rollout's results do not depend on it (next section).
+def _first_knot_rows(s, with_gains=True):
+    """[u0 | cost | K0] rows through the product's own pack (the gather payload), without pulling K for the whole batch."""
+    import torch
+    from mpc_ilqr_mujoco_amd import sharding as sh
+    rows = torch.zeros(s.B, sh.payload_width(with_gains), dtype=torch.float64, device="cuda:0")
+    s.comm_init(1, 0)
+    s.gather_first_knot(rows.data_ptr(), root=0, with_gains=with_gains); s.synchronize()
+    s.comm_destroy()
+    return rows.cpu().numpy()
+
+
+def test_config3_global_batch_of_32768_on_one_device():
+    """BASELINE.json configs[3]: 32768 rollouts, N = 25, full iLQR -- its whole global batch on one GPU (57 GB).  Properties
+    at full size (finite, monotone cost traces, unit quaternions, iteration counts), batch invariance against the same rollouts
+    solved in a small handle (bit for bit, first-knot payload rows), oracle spot checks."""
+    B, N, iters = 32768, 25, 4
+    prob, x0, ui = standing(B, N, seed=0)
+    s = _solver(B, N=N); s.set_problem(prob); s.set_max_iterations(iters)
+    s.initialize(x0, ui)
+    cost = s.solve(x0)
+    tc, ta, _ = s.trace(); it = s.iterations()
+    assert cost.shape == (B,) and np.all(np.isfinite(cost)) and np.all(it >= 1) and np.all(it <= iters) and s.adopt_mismatches() == 0
+    idx = np.arange(iters + 1)[None, :] <= it[:, None]
+    d = np.diff(tc, axis=1)                                            # (NaN beyond the executed iterations: masked below)
+    assert np.all(d[idx[:, 1:]] <= 0)                                 # accepted steps only ever decrease the cost
+    stuck = np.where(~(cost < tc[:, 0]))[0]                             # a handful of cold starts never find an improving step:
+    assert np.all(cost <= tc[:, 0]) and len(stuck) < B // 1000          # fail -> retry -> continue -> fail -> break (ilqr.cpp:619-644)
+    assert len(stuck) >= 1 and np.all(it[stuck] == 3) and np.all(ta[stuck, :3] == 0.0)
+    rows = _first_knot_rows(s)
+    assert np.array_equal(rows[:, 19], cost) and np.all(np.isfinite(rows))
+    xb_pick = None
+    pick = [0, int(stuck[0]), 4095, 4096, 17000, 32767]                # a stuck rollout; first / last rollout of a rank's shard at 8 ranks; the batch's ends
+    s.close()
+    s2 = _solver(len(pick), N=N); s2.set_problem(prob); s2.set_max_iterations(iters)
+    s2.initialize(x0[pick], ui[pick]); c2 = s2.solve(x0[pick])
+    r2 = _first_knot_rows(s2)
+    assert np.array_equal(c2, cost[pick]) and np.array_equal(r2, rows[pick])
+    xb = s2.xbar(); K = s2.gains_K(); tc2 = s2.trace()[0]; it2 = s2.iterations()
+    assert np.abs(np.linalg.norm(xb[:, :, 3:7], axis=2) - 1).max() < 1e-12
+    s2.close()
+    for j, b in enumerate(pick[:2]):
+        o = ol.Oracle(N, prob["dt"]); o.set_problem(prob); o.set_options(max_iter=iters)
+        o.initialize(x0[b], ui[b]); ok, c = o.solve(x0[b])
+        n, oc, oa, _ = o.trace()
+        assert n == it2[j] and np.allclose(tc2[j, : n + 1], oc[: n + 1], rtol=1e-5) and rel(K[j], o.get("K")) < 1e-5
+
+
+def test_config4_global_batch_of_8192_walking_windows_contact_scheduled():
+    """BASELINE.json configs[4]: 8192 rollouts, N = 50, reference windows cut from the reference's walking file with per-rollout
+    start rows, contact-scheduled cost terms AND the schedule-driven unilateral stance constraints in the dynamics
+    (set_contact_mode(2), row f4) -- the whole global batch on one GPU (28 GB)."""
+    B, N, iters = 8192, 50, 3
+    prob, x0, ui, t0 = walking_problem(B, N, seed=7)
+    assert prob["stance"].shape == (B, N + 1, 2) and prob["stance"].min() == 0
+    s = _solver(B, N=N); s.set_problem(prob); s.set_contact_mode(2); s.set_max_iterations(iters)
+    s.initialize(x0, ui)
+    cost = s.solve(x0)
+    tc = s.trace()[0]; it = s.iterations()
+    assert np.all(np.isfinite(cost)) and np.all(it >= 1) and np.all(it <= iters) and s.adopt_mismatches() == 0
+    idx = np.arange(iters + 1)[None, :] <= it[:, None]
+    d = np.diff(tc, axis=1)                                            # (NaN beyond the executed iterations: masked below)
+    assert np.all(d[idx[:, 1:]] <= 0)
+    rows = _first_knot_rows(s)
+    assert np.array_equal(rows[:, 19], cost) and np.all(np.isfinite(rows))
+    s.close()
+    pick = [0, 1023, 1024, 8191]
+    sub = dict(prob)
+    for k in ("x_ref", "u_ref", "com_ref", "stance", "ee_ref", "com_vel_ref"):
+        sub[k] = prob[k][pick]
+    s2 = _solver(len(pick), N=N); s2.set_problem(sub); s2.set_contact_mode(2); s2.set_max_iterations(iters)
+    s2.initialize(x0[pick], ui[pick]); c2 = s2.solve(x0[pick])
+    r2 = _first_knot_rows(s2)
+    assert np.array_equal(c2, cost[pick]) and np.array_equal(r2, rows[pick])
+    K = s2.gains_K(); tc2 = s2.trace()[0]; it2 = s2.iterations(); xb = s2.xbar()
+    assert np.abs(np.linalg.norm(xb[:, 1:, 3:7], axis=2) - 1).max() < 1e-12
+    s2.close()
+    b = pick[2]
+    o = ol.Oracle(N, prob["dt"]); o.set_problem(prob, b); o.set_contact_mode(2); o.set_options(max_iter=iters)
+    o.initialize(x0[b], ui[b]); ok, c = o.solve(x0[b])
+    n, oc, oa, _ = o.trace()
+    assert n == it2[2] and np.allclose(tc2[2, : n + 1], oc[: n + 1], rtol=1e-5) and rel(K[2], o.get("K")) < 1e-5
+
+
+# ---------------------------------------------------------------------------------------------------------------------
 # multi-rank: two ranks (both on device 0, payload staged through a gloo gather) vs one process solving the global batch
 _WORKER = r"""
 import os, sys
