@@ -27,15 +27,21 @@ sys.path.insert(0, ROOT)
 
 FP64_PEAK_TFLOPS = 78.6   # MI355X FP64 vector == matrix peak (AMD spec; the microarch guide lists no fp64 row)
 HBM_PEAK_GBS = 8000.0
-# algorithmic work per rollout: Riccati backward pass, minimal-reuse formulation
+# algorithmic work per rollout: Riccati backward pass, minimal-reuse formulation (exact count)
 RICCATI_FLOPS_PER_KNOT = 914786.0
-# dynamics Jacobians: planning estimate of SURVEY.md 8(d) (analytic A_t, B_t of one knot)
-JACOBIAN_FLOPS_PER_KNOT = 120000.0
-STEP_FLOPS = 12000.0      # one ABA dynamics step
-QUAD_FLOPS_PER_KNOT = 50000.0
-FLOP_SOURCE = "Riccati: exact count of the minimal-reuse formulation (SURVEY.md 8(d)); dynamics step / Jacobians / cost quadratics: planning estimates of SURVEY.md 8(d)"
+# Dynamics step, analytic (A_t, B_t), cost quadratics and one line-search trial: COUNTED on the oracle's restatement by its
+# op counter (oracle/opcount.cpp; add / sub / mul / div / sqrt / sin / cos = 1 flop each, nothing fused), at knot 7 of rollout 0
+# of the seed-0 standing batch under the shipped weights -- tests/test_oracle_golden.py pins these four numbers to the counter.
+STEP_FLOPS = 27167.0                 # one dynamics step (h1_step)
+JACOBIAN_FLOPS_PER_KNOT = 203199.0   # tangent scheme: 1 forward dynamics + 48 inverse-dynamics tangents + Mhat + 67 solves + integrator
+QUAD_FLOPS_PER_KNOT = 135167.0       # closed-form gradient and Hessian of the six task terms + limits (stance knot)
+ALPHA_TRIAL_FLOPS_PER_KNOT = 32366.0 # u = ubar + alpha k + K dx, the step, 1/N of computeTotalCost
+FLOP_SOURCE = ("Riccati: exact count of the minimal-reuse formulation (SURVEY.md 8(d)); dynamics step / analytic Jacobians / cost quadratics / line-search "
+               "trial: counted by the oracle's op counter (oracle/opcount.cpp), pinned by tests/test_oracle_golden.py")
 # whole-iteration budget of SURVEY.md 8(d) at N = 25 (scaled by N / 25 for other horizons): 27.8 MFLOP and 2.43 MB per rollout-iteration
 ITER_FLOPS_N25, ITER_BYTES_N25 = 27.8e6, 2.43e6
+# the same total from the counted figures: Riccati + N x (nominal step + Jacobians + line-search trial) + (N + 1) x quadratics
+ITER_FLOPS_COUNTED_N25 = 25 * (RICCATI_FLOPS_PER_KNOT + STEP_FLOPS + JACOBIAN_FLOPS_PER_KNOT + ALPHA_TRIAL_FLOPS_PER_KNOT) + 26 * QUAD_FLOPS_PER_KNOT
 # v_mfma_f64_16x16x4_f64 per knot issued by the one-wave Riccati kernel (riccati_wave.hip): folded / generic variant, 2048 flops each
 MFMA_PER_KNOT = {"folded": 429, "generic": 569}
 
@@ -135,7 +141,7 @@ def kernel_groups(args, B, N, n_slices):
                       bytes=D * Bl * (N * (2601 + 969 + 2601 + 51 + 19 + 19 + 969 + 19) + 2 * (2601 + 51))),
         ("k_line_search_r" if os.environ.get("ILQR_LS", "s")[:1] == "r" else "k_line_search_s+k_traj_knot_cost"):
                       dict(stages=["iLQR_lineSearch", "iLQR_lineSearch_retry"], unit="fp64 VALU",
-                      flops=STEP_FLOPS * N * Bl,      # the accepted alpha's rollout is the algorithmic work
+                      flops=ALPHA_TRIAL_FLOPS_PER_KNOT * N * Bl,      # the accepted alpha's trial is the algorithmic work
                       bytes=D * Bl * N * ((969 + 19 + 51 + 19) + 8 * (51 + 19))),
         primal + "+k_lin_tangent": dict(stages=["iLQR_linearization"], unit="fp64 VALU",
                                         flops=JACOBIAN_FLOPS_PER_KNOT * N * Bl,
@@ -458,6 +464,7 @@ def main():
         it_scale = N / 25.0
         roof["whole_iteration_frac"] = value * ITER_FLOPS_N25 * it_scale / (FP64_PEAK_TFLOPS * 1e12 * world)
         roof["whole_iteration_frac_hbm"] = value * ITER_BYTES_N25 * it_scale / (HBM_PEAK_GBS * 1e9 * world)
+        roof["whole_iteration_frac_counted_flops"] = value * ITER_FLOPS_COUNTED_N25 * it_scale / (FP64_PEAK_TFLOPS * 1e12 * world)
         if dom_kernel == "k_backward_wave" and d["avg_launch_ms"] > 0:
             # `achieved` / `frac` are ALGORITHMIC-equivalent rates (914 786 flop per knot, the dense minimal-reuse count); the kernel
             # issues fewer, padded products: MFMA count x 2048 flops is what the hardware executes
@@ -474,7 +481,8 @@ def main():
                      "kernel_total_ms_per_step": d["total_ms_per_step"], "kernel_exclusive_ms_per_step": d["exclusive_ms_per_step"],
                      "note": "achieved / frac = ALGORITHMIC flops (or bytes) of one launch / its average duration -- an algorithmic-equivalent rate, not a count of issued "
                              "instructions (executed_mfma_flops_per_launch / frac_executed_mfma give the issued MFMA flops of the Riccati kernel); "
-                             "whole_iteration_frac = iterations/s x SURVEY 8(d)'s 27.8 MFLOP (2.43 MB) per rollout-iteration against the fp64 (HBM) roof; "
+                             "whole_iteration_frac = iterations/s x SURVEY 8(d)'s 27.8 MFLOP (2.43 MB) per rollout-iteration against the fp64 (HBM) roof, "
+                             "whole_iteration_frac_counted_flops the same with the op-counted per-stage figures (config.flop_source: 33.0 MFLOP at N = 25); "
                              "full-batch launches of the timed steps only (HIP events on the launch stream; this kernel group was picked on an untimed probe "
                              "step with every stage timed, and is the only one that carries event pairs inside the timed region); traffic = 2 x FETCH_SIZE + WRITE_SIZE of a full-batch launch from "
                              "separate rocprofv3 --pmc passes of this command (see traffic_source), null when no record matches this run; "

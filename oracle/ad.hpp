@@ -9,6 +9,8 @@
 
 namespace orc {
 
+inline double val(double a) { return a; }   // (declared first: DD<double> resolves val(a.v) at its definition)
+
 template <int N>
 struct D1 {
   double v;
@@ -68,7 +70,5 @@ template <class S> inline DD<S> sin(const DD<S>& a) { using std::sin; using std:
 template <class S> inline DD<S> cos(const DD<S>& a) { using std::sin; using std::cos; return DD<S>(cos(a.v), -(sin(a.v) * a.d)); }
 template <class S> inline DD<S> sqrt(const DD<S>& a) { using std::sqrt; S r = sqrt(a.v); return DD<S>(r, a.d / (r * 2.0)); }
 template <class S> inline double val(const DD<S>& a) { return val(a.v); }
-
-inline double val(double a) { return a; }
 
 }  // namespace orc

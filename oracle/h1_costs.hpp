@@ -39,7 +39,7 @@ struct Problem {
 };
 
 // ---------------- RobotUtils::constraintCost / Gradients / Hessians ----------------
-inline void limit_bounds(const double* range, double& lo, double& hi) {
+template <class R> inline void limit_bounds(const R* range, double& lo, double& hi) {   // (R: the model table's scalar)
   double margin = 0.1 * (range[1] - range[0]);
   lo = range[0] + margin; hi = range[1] - margin;
 }
@@ -221,6 +221,7 @@ inline void to_pin_order(const double* x, double* xp) {  // derivatives.cpp:12-2
   xp[3] = x[4]; xp[4] = x[5]; xp[5] = x[6]; xp[6] = x[3];
 }
 
+#ifndef ORC_COUNTING   // (the op-counting build, opcount.cpp, re-reads this file with the scalar type replaced: closed forms only)
 // exact gradient + Hessian of a templated scalar by forward-over-forward AD; ADDS into g/H
 template <class F> inline void ad_grad_hess(const double* xp, F f, double* g, double* H) {
   typedef D1<H1_NX> In; typedef DD<In> Out;
@@ -232,6 +233,7 @@ template <class F> inline void ad_grad_hess(const double* xp, F f, double* g, do
     for (int l = 0; l < H1_NX; ++l) H[k * H1_NX + l] += r.d.g[l];
   }
 }
+#endif
 
 // ---------------- closed forms ----------------
 struct BaseKin {
@@ -264,7 +266,7 @@ inline void base_kin(const double* xp, BaseKin& B) {
   for (int i = 0; i < H1_NB; ++i) for (int k = 0; k < 9; ++k) B.Rh[i][k] = K.Rh[i][k];
 }
 // mu[i]: mass of the point attached to body i at local offset c[i]; Mtot: normalisation
-inline void point_set(const BaseKin& B, const double* mu, const double (*c)[3], double Mtot, PointSet& S) {
+template <class MU, class CC> inline void point_set(const BaseKin& B, const MU* mu, const CC (*c)[3], double Mtot, PointSet& S) {
   double msub[H1_NB], hsub[H1_NB][3], sw[H1_NB][3];
   for (int i = 0; i < H1_NB; ++i) { msub[i] = 0; for (int k = 0; k < 3; ++k) { hsub[i][k] = 0; sw[i][k] = 0; } }
   double mall = 0;
@@ -462,7 +464,9 @@ inline void cost_quadratics_knot(const Problem& P, int t, const double* x, const
     if (P.w_ee_vel > 0.0) for (int e = 0; e < 2; ++e) if (P.stance[2 * t + e] == 1) add_vel_term(Z.B, Z.ee[e], zero3, P.w_ee_vel, lx, lxx);
     if (P.w_upright > 0.0) add_upright_term(xp, P.w_upright, lx, lxx);
     if (P.w_balance > 0.0 && has_support) add_balance_term(Z.B, Z.com, ps, P.w_balance, lx, lxx);
-  } else {
+  }
+#ifndef ORC_COUNTING
+  else {
     if (P.w_com > 0.0) { const double* ref = &P.com_ref[t * 3]; double w = P.w_com; ad_grad_hess(xp, [&](const DD<D1<H1_NX>>* z) { return sym_com_pos(z, ref, w); }, lx, lxx); }
     if (!term && P.w_com_vel > 0.0) { const double* ref = &P.com_vel_ref[t * 3]; double w = P.w_com_vel; ad_grad_hess(xp, [&](const DD<D1<H1_NX>>* z) { return sym_com_vel(z, ref, w); }, lx, lxx); }
     if (P.w_ee_pos > 0.0) for (int e = 0; e < 2; ++e) if (P.stance[2 * t + e] != 1) { const double* ref = &P.ee_ref[(t * 2 + e) * 3]; double w = P.w_ee_pos; int body = e == 0 ? H1_EE_LEFT : H1_EE_RIGHT; ad_grad_hess(xp, [&](const DD<D1<H1_NX>>* z) { return sym_ee_pos(z, body, ref, w); }, lx, lxx); }
@@ -478,6 +482,7 @@ inline void cost_quadratics_knot(const Problem& P, int t, const double* x, const
       for (int i = 0; i < H1_NX; ++i) { lx[i] += g[i]; for (int j = 0; j < H1_NX; ++j) lxx[i * H1_NX + j] += 0.5 * (Hh[i * H1_NX + j] + Hh[j * H1_NX + i]); }  // derivatives.cpp:796
     }
   }
+#endif
   double zero_u[H1_NU] = {0}, dummy_lu[H1_NU] = {0}, dummy_luu[H1_NU] = {0};
   if (!term) constraint_derivs(P, x, u, lx, lu, lxx, luu_diag);
   else constraint_derivs(P, x, zero_u, lx, dummy_lu, lxx, dummy_luu);

@@ -381,6 +381,9 @@ long orc_batch_solve(void* tmpl, int Bn, const double* x0, const double* u_init,
   }
   return total;
 }
+// algorithmic flop counts of SURVEY.md 8(d) on the oracle's own code (opcount.cpp)
+void orc_op_counts_impl(const orc::Problem& P, int t, const double* x, const double* u, double* out);
+void orc_op_counts(void* s, int t, const double* x, const double* u, double* out /*[8]*/) { orc_op_counts_impl(((Solver*)s)->P, t, x, u, out); }
 int orc_max_threads() {
 #ifdef _OPENMP
   return omp_get_max_threads();

@@ -179,6 +179,16 @@ class Oracle:
         getattr(self.L, "orc_get_" + name)(self.h, _p(out))
         return out
 
+    def op_counts(self, t, x, u):
+        """Algorithmic flop counts of SURVEY.md 8(d) on the oracle's own code (oracle/opcount.cpp): dict with the flops of one
+        dynamics step, one knot of one line-search trial, the cost quadratics of knot t and one analytic (A_t, B_t), plus the
+        sin / cos evaluations among them."""
+        out = np.zeros(8)
+        x, u = c64(x), c64(u)
+        self.L.orc_op_counts(self.h, int(t), _p(x), _p(u), _p(out))
+        keys = ("step", "alpha_trial_knot", "quadratics_knot", "jacobians")
+        return {k: int(round(v)) for k, v in zip(keys, out[:4])}, {k: int(round(v)) for k, v in zip(keys, out[4:])}
+
     def batch_solve(self, x0, u_init, nthreads=0, want_gains=False):
         x0 = c64(x0)
         B = x0.shape[0]
@@ -209,6 +219,15 @@ def inverse_dynamics(x, qacc, arm, grav):
     tau = np.zeros(NV)
     lib().orc_inverse_dynamics(_p(x), _p(qacc), C.c_double(arm), _p(grav), _p(tau))
     return tau
+
+
+def tangent_scheme_jacobians(x, u, h, gravity):
+    """(A, B) of the constraint-free step by the scheme whose flops opcount.cpp counts (same code on plain doubles)."""
+    L = lib()
+    x, u, g = c64(x), c64(u), c64(gravity)
+    A, B = np.zeros((NX, NX)), np.zeros((NX, NU))
+    L.orc_tangent_scheme_jacobians(_p(x), _p(u), C.c_double(h), _p(g), _p(A), _p(B))
+    return A, B
 
 
 def max_threads():

@@ -313,3 +313,37 @@ def test_stance_constrained_step_identities():
         xp, xm = x.copy(), x.copy(); xp[j] += eps; xm[j] -= eps
         col = (o2.step_stance(xp, u, [1, 1]) - o2.step_stance(xm, u, [1, 1])) / (2 * eps)
         assert np.abs(A[:, j] - col).max() < 1e-5 * max(1.0, np.abs(col).max()), (j, np.abs(A[:, j] - col).max())
+
+
+def test_op_counter_pins_the_algorithmic_flop_figures_of_the_bench():
+    """'flops of dynamics + analytic Jacobians + cost quadratics + one line-search alpha: to be taken from the CPU
+    restatement's op counter'.  The counter (oracle/opcount.cpp) runs the oracle's own code on a counting scalar; bench.py's
+    per-stage constants are these numbers, at knot 7 of rollout 0 of the seed-0 standing batch under the shipped weights.  The
+    Jacobian scheme that is counted is first checked to BE a correct algorithm: on plain doubles it reproduces the oracle's
+    forward-mode AD Jacobians."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod3", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
+    N = 25
+    prob = sc.make_problem(ol.reference_kinematics, N=N)
+    o = ol.Oracle(N, prob["dt"]); o.set_problem(prob)
+    ug = o.grav_comp(sc.standing_state())
+    x0, ui = sc.synthetic_batch(2, N, 0, ug)
+    o.initialize(x0[0], ui[0]); o.linearize()
+    xb, ub = o.get("xbar"), o.get("ubar")
+    for t in (0, 7, 24):
+        A, B = ol.tangent_scheme_jacobians(xb[t], ub[t], prob["dt"], prob["gravity"])
+        assert np.abs(A - o.get("A")[t]).max() < 1e-12 and np.abs(B - o.get("B")[t]).max() < 1e-12
+    flops, trig = o.op_counts(7, xb[7], ub[7])
+    assert (flops["step"], flops["alpha_trial_knot"], flops["quadratics_knot"]) == (int(bench.STEP_FLOPS), int(bench.ALPHA_TRIAL_FLOPS_PER_KNOT), int(bench.QUAD_FLOPS_PER_KNOT)), flops
+    # (the zero-aware part of the Jacobian count sees the occasional exact zero of the data: a few hundred flops in 200 k)
+    assert abs(flops["jacobians"] - bench.JACOBIAN_FLOPS_PER_KNOT) < 1e-3 * bench.JACOBIAN_FLOPS_PER_KNOT, flops
+    # the counts are properties of the algorithm, not of the knot: another state of the trajectory gives the same step / trial
+    # counts, the quadratics of the terminal knot lose the control terms, the Jacobian count moves only with exact zeros in the data
+    f2, _ = o.op_counts(N, xb[N], ub[N - 1])
+    assert f2["step"] == flops["step"] and abs(f2["jacobians"] - flops["jacobians"]) < 0.01 * flops["jacobians"]
+    assert 0 < flops["quadratics_knot"] - f2["quadratics_knot"] < 200
+    assert trig["step"] == 40          # 19 hinges + the quaternion's half angle, sine and cosine each
+    # the whole-iteration total bench.py reports beside SURVEY's planning budget of 27.8 MFLOP
+    assert abs(bench.ITER_FLOPS_COUNTED_N25 - 32952292.0) < 1.0
