@@ -239,7 +239,11 @@ DEVFN void lin_contact_solve_w(LinContact& Cc, const int* stance, double soft, i
 #pragma unroll
     for (int j = 0; j < 12; ++j) {
       const double d = bcast_lane(F[j], j);                          // pivot: element (j, j), held by lane j
-      const double ri = 1.0 / sqrt(d);
+      // 1 / sqrt(d): hardware estimate (v_rsq_f64, ~2^-26) + two Newton steps (the library's sqrt followed by a division is
+      // ~70 instructions of a dependent chain, at every one of the twelve pivots)
+      double ri = __builtin_amdgcn_rsq(d);
+      ri = ri * __builtin_fma(-0.5 * d * ri, ri, 1.5);
+      ri = ri * __builtin_fma(-0.5 * d * ri, ri, 1.5);
       if (i == j) rinv = ri;
       const double lij = F[j] * ri;                                  // lane i > j: L_ij; lane j itself: sqrt(d)
 #pragma unroll

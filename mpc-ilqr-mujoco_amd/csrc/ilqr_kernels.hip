@@ -165,15 +165,16 @@ __global__ void __launch_bounds__(128, 2) k_lin_tangent_c(DevState S, ProblemDev
   else if (lane < 2) lin_contact_rhs(L, Cc, P.dyn.g, lane);
   __syncthreads();
   LSTAMP(1)
+  // wave 0: the constraint solve; wave 1, idle here otherwise: the integrator's uniform quantities except what depends on the
+  // constrained accelerations -- lin_prologue reads qacc, so it follows the correction below, but on wave 1 (one lane, 7 k
+  // cycles) beside wave 0's force accumulation instead of after it
   if (wv == 0) lin_contact_solve_w(Cc, P.stance + b * P.stance_stride + 2 * t, P.dyn.soft, P.dyn.contact, lane);
   __syncthreads();
   LSTAMP(2)
-  if (wv == 0) {
-    lin_contact_correct(L, Cc, lane);
-    wave_sync();
-    lin_accumulate_forces_w(L, lane);
-    if (lane == 32) lin_prologue(L);
-  }
+  if (wv == 0) lin_contact_correct(L, Cc, lane);
+  __syncthreads();
+  if (wv == 0) lin_accumulate_forces_w(L, lane);
+  else if (lane == 32) lin_prologue(L);
   __syncthreads();
   LSTAMP(3)
   if (wv == 0) lin_tangent_legs_c(L, Cc, lane); else lin_tangent_arms(L, lane);
