@@ -106,7 +106,11 @@ DEVFN void load_half_u(bool side, const double* u, h1s::HalfU& o) {
 #pragma unroll
   for (int k = 0; k < 4; ++k) o.uA[k] = u[h1s::jarm(side, k)];
 }
-template <bool CONTACT>
+// RPW = rollouts per wave: 4 (the 64 lanes are four rollouts' 16) or 1 -- for batches of at most 1024 rollouts, where four per wave
+// would leave SIMDs empty: the wave's lanes 16..63 then mirror lanes 0..15 (same rollout, same candidates, no stores), a step
+// fetches one rollout's K_t and runs one feedback product instead of four, and every rollout has a SIMD to itself.  The per-rollout
+// arithmetic is the same instruction sequence in both: results are bit-identical (batch invariance, GPU tests).
+template <bool CONTACT, int RPW>
 __global__ void __launch_bounds__(64) k_line_search_s(DevState S, ProblemDev P, int mode, const int* list, const int* count) {
   extern __shared__ double lds[];
   const int gid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -114,7 +118,8 @@ __global__ void __launch_bounds__(64) k_line_search_s(DevState S, ProblemDev P, 
   const bool side = (gid & 1) != 0;
   // No lane leaves early: the feedback below is an MFMA product over the whole wave (every lane supplies operands of every
   // rollout of the wave), so the 16 lanes of a rollout that is not selected run along on a valid rollout and skip their stores.
-  int b = gid >> 4;
+  int b = RPW == 4 ? gid >> 4 : (int)blockIdx.x;
+  const bool owner = RPW == 4 || threadIdx.x < 16;          // RPW = 1: lanes 16..63 are mirrors
   bool live;
   if (list) {                          // compacted selection (DevState::order): the selected rollouts fill the first waves
     const int cnt = *count;
@@ -126,15 +131,16 @@ __global__ void __launch_bounds__(64) k_line_search_s(DevState S, ProblemDev P, 
     live = live && sel_s(S, b, mode);
   }
   if (!__any(live)) return;
+  live = live && owner;
   const int lane0 = threadIdx.x;
   const int N = S.N, n = H1_NX, m = H1_NU;
   const double alpha = ALPHAS_S[ai];
   h1s::HalfX h; h1s::load_half(side, S.x0 + (size_t)b * n, h);
   if (live) h1s::store_half(side, h, S.xcand + ((size_t)b * 8 + ai) * (N + 1) * n);
   // rollouts of the wave's four 16-lane groups (for the K_t operands every lane fetches for every group)
-  int bw[4];
+  int bw[RPW];
 #pragma unroll
-  for (int r = 0; r < 4; ++r) bw[r] = __shfl(b, 16 * r);
+  for (int r = 0; r < RPW; ++r) bw[r] = __shfl(b, 16 * r);
 #ifdef LS_STAMP
   long long ph[8] = {0}; long long tl = clock64();
 #endif
@@ -180,7 +186,8 @@ __global__ void __launch_bounds__(64) k_line_search_s(DevState S, ProblemDev P, 
       }
       kt[slot][0] = Kt[offT0]; kt[slot][1] = Kt[offT1];
     };
-    fetchK(0, 0); fetchK(1, 1);
+    fetchK(0, 0);
+    if (RPW > 1) fetchK(1, 1);
     h1s::HalfX xh; h1s::HalfU ubh, kfh;
     h1s::load_half(side, xbt, xh);
     load_half_u(side, ub + t * m, ubh);
@@ -222,8 +229,8 @@ __global__ void __launch_bounds__(64) k_line_search_s(DevState S, ProblemDev P, 
       const int offB = 2 * lk * 64 + 2 * (lr & 7), offBt = (48 + lk) * 64 + 2 * (lr & 7);
       constexpr int UROW = 52;                        // LDS rows 52..70: the 19 feedback terms, column = the pair's
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        if (r + 2 < 4) fetchK((r + 2) % 3, r + 2);
+      for (int r = 0; r < RPW; ++r) {
+        if (r + 2 < RPW) fetchK((r + 2) % 3, r + 2);
         v4d_s d0 = {0.0, 0.0, 0.0, 0.0}, d1 = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int j = 0; j < 6; ++j)
@@ -256,7 +263,7 @@ __global__ void __launch_bounds__(64) k_line_search_s(DevState S, ProblemDev P, 
     for (int k = 0; k < 10; ++k) {
       // k = 0..4 leg, 5..8 arm, 9 torso (left side only; the right side repeats its last arm row and discards it)
       const int row = k < 5 ? h1s::jleg(side, k) : (k < 9 ? h1s::jarm(side, k - 5) : (side ? 18 : 10));
-      const double sfb = lds[(52 + row) * 64 + col];
+      const double sfb = lds[(52 + row) * 64 + (RPW == 4 ? col : (col & 15))];      // (RPW = 1: the mirrors read the owners' columns)
       const double ubase = k < 5 ? ubh.uL[k < 5 ? k : 0] : (k < 9 ? ubh.uA[k < 9 && k >= 5 ? k - 5 : 0] : ubh.u11);
       const double kbase = k < 5 ? kfh.uL[k < 5 ? k : 0] : (k < 9 ? kfh.uA[k < 9 && k >= 5 ? k - 5 : 0] : kfh.u11);
       const double ui = ubase + alpha * kbase + sfb;
@@ -498,8 +505,10 @@ __global__ void __launch_bounds__(256) k_fd_finish(DevState S, int mode, double 
 static inline int cdiv_s(long a, long b) { return (int)((a + b - 1) / b); }
 int dyn_split_kernels_set_attr() {
   int rc = 0;
-  rc |= hipFuncSetAttribute((const void*)k_line_search_s<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DYN_LDS_BYTES_S) != hipSuccess;
-  rc |= hipFuncSetAttribute((const void*)k_line_search_s<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DYN_LDS_BYTES_S) != hipSuccess;
+  rc |= hipFuncSetAttribute((const void*)k_line_search_s<false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DYN_LDS_BYTES_S) != hipSuccess;
+  rc |= hipFuncSetAttribute((const void*)k_line_search_s<true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DYN_LDS_BYTES_S) != hipSuccess;
+  rc |= hipFuncSetAttribute((const void*)k_line_search_s<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DYN_LDS_BYTES_S) != hipSuccess;
+  rc |= hipFuncSetAttribute((const void*)k_line_search_s<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DYN_LDS_BYTES_S) != hipSuccess;
   rc |= hipFuncSetAttribute((const void*)k_rollout_s<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DYN_LDS_BYTES_S) != hipSuccess;
   rc |= hipFuncSetAttribute((const void*)k_rollout_s<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DYN_LDS_BYTES_S) != hipSuccess;
   rc |= hipFuncSetAttribute((const void*)k_step_s, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DYN_LDS_BYTES_S) != hipSuccess;
@@ -508,9 +517,17 @@ int dyn_split_kernels_set_attr() {
   rc |= hipFuncSetAttribute((const void*)k_fd_steps_s, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DYN_LDS_BYTES_S) != hipSuccess;
   return rc;
 }
+#ifndef LS_RPW1_MAX_BATCH
+#define LS_RPW1_MAX_BATCH 1024      // one wave per SIMD on the 1024 SIMDs of an MI355X
+#endif
 void launch_line_search_s(const DevState& S, const ProblemDev& P, int mode, hipStream_t st, const int* list, const int* count) {
-  if (P.dyn.contact) hipLaunchKernelGGL(k_line_search_s<true>, dim3(cdiv_s((long)S.B * 16, 64)), dim3(64), DYN_LDS_BYTES_S, st, S, P, mode, list, count);
-  else hipLaunchKernelGGL(k_line_search_s<false>, dim3(cdiv_s((long)S.B * 16, 64)), dim3(64), DYN_LDS_BYTES_S, st, S, P, mode, list, count);
+  if (S.B <= LS_RPW1_MAX_BATCH) {        // a rollout per wave (see the kernel)
+    if (P.dyn.contact) hipLaunchKernelGGL((k_line_search_s<true, 1>), dim3(S.B), dim3(64), DYN_LDS_BYTES_S, st, S, P, mode, list, count);
+    else hipLaunchKernelGGL((k_line_search_s<false, 1>), dim3(S.B), dim3(64), DYN_LDS_BYTES_S, st, S, P, mode, list, count);
+    return;
+  }
+  if (P.dyn.contact) hipLaunchKernelGGL((k_line_search_s<true, 4>), dim3(cdiv_s((long)S.B * 16, 64)), dim3(64), DYN_LDS_BYTES_S, st, S, P, mode, list, count);
+  else hipLaunchKernelGGL((k_line_search_s<false, 4>), dim3(cdiv_s((long)S.B * 16, 64)), dim3(64), DYN_LDS_BYTES_S, st, S, P, mode, list, count);
 }
 void launch_lin_primal_s(const DevState& S, const ProblemDev& P, int mode, hipStream_t st, const int* list, const int* count) {
   hipLaunchKernelGGL(k_lin_primal_s, dim3(cdiv_s((long)S.B * S.N * 2, 64)), dim3(64), DYN_LDS_BYTES_S, st, S, P, mode, list, count);

@@ -149,6 +149,184 @@ def kane_step(bodies, ctrlrange, x, u, h, grav, damping=1.0, armature=0.1):
     return np.concatenate([qn, vn]), qacc, M, bias
 
 
+# ----------------------------------------------------------------------------- complex-safe Kane dynamics (round 3)
+# The same world-frame Kane restatement, written so that it accepts complex arguments: exact Jacobians by complex-step
+# differentiation (imag f(x + i eps e_k) / eps, eps = 1e-30: no subtraction, no truncation error), and the stance-constrained
+# step of the contact row as a plain KKT system -- independent of the oracle's / the kernels'
+# articulated-body formulation (unit-wrench propagation, C = J Mhat^-1 J^T, Cholesky).
+def cnorm(a):
+    return np.sqrt((a * a).sum())
+
+
+def q2R_c(q):
+    w, x, y, z = q / cnorm(q)
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
+                     [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                     [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+
+
+def axis_rot_c(axis, th):
+    K = skew(axis)
+    return np.eye(3) + np.sin(th) * K + (1 - np.cos(th)) * (K @ K)
+
+
+FEET = (5, 10)      # left_ankle_link, right_ankle_link (robot_utils.cpp:44-47)
+
+
+def kane_eval_c(bodies, q, v, qacc, grav, armature):
+    """F = M qacc + bias in MuJoCo coordinates (as kane_residual) and, per foot, the spatial velocity and acceleration of
+    the ankle link in LINK coordinates, Featherstone convention: [omega; v_O] and [alpha; a_O - omega x v_O], plus the world
+    up axis in link coordinates."""
+    nb = len(bodies)
+    dt = np.result_type(q.dtype, v.dtype, qacc.dtype)
+    R = [None] * nb; p = [None] * nb; om = [None] * nb; al = [None] * nb; acc = [None] * nb; z = [None] * nb; vo = [None] * nb
+    R[0] = q2R_c(q[3:7]); p[0] = q[0:3].astype(dt)
+    om[0] = R[0] @ v[3:6]; al[0] = R[0] @ qacc[3:6]; acc[0] = qacc[0:3].astype(dt); vo[0] = v[0:3].astype(dt)
+    for i in range(1, nb):
+        b = bodies[i]; pa = b["parent"]
+        R[i] = R[pa] @ (b["R"] @ axis_rot_c(b["axis"], q[7 + i - 1]))
+        d = R[pa] @ b["pos"]
+        p[i] = p[pa] + d
+        z[i] = R[i] @ b["axis"]
+        qd, qdd = v[6 + i - 1], qacc[6 + i - 1]
+        om[i] = om[pa] + z[i] * qd
+        al[i] = al[pa] + np.cross(om[pa], z[i]) * qd + z[i] * qdd
+        acc[i] = acc[pa] + np.cross(al[pa], d) + np.cross(om[pa], np.cross(om[pa], d))
+        vo[i] = vo[pa] + np.cross(om[pa], d)
+    F = np.zeros(25, dtype=dt)
+    for i in range(nb):
+        b = bodies[i]
+        e = R[i] @ b["c"]
+        ci = p[i] + e
+        ac = acc[i] + np.cross(al[i], e) + np.cross(om[i], np.cross(om[i], e))
+        Iw = R[i] @ b["I"] @ R[i].T
+        fl_ = b["m"] * (ac - grav)
+        tq = Iw @ al[i] + np.cross(om[i], Iw @ om[i])
+        F[0:3] += fl_
+        F[3:6] += R[0].T @ (np.cross(ci - p[0], fl_) + tq)
+        a = i
+        while a > 0:
+            F[6 + a - 1] += z[a] @ (np.cross(ci - p[a], fl_) + tq)
+            a = bodies[a]["parent"]
+    F[6:] += armature * qacc[6:]
+    feet = []
+    for f in FEET:
+        wl, vl = R[f].T @ om[f], R[f].T @ vo[f]
+        feet.append(dict(vel=np.concatenate([wl, vl]), acc=np.concatenate([R[f].T @ al[f], R[f].T @ acc[f] - np.cross(wl, vl)]), up=R[f].T @ np.array([0.0, 0.0, 1.0])))
+    return F, feet
+
+
+def integrate_c(q, v, qacc, h):
+    vn = v + h * qacc
+    qn = q.astype(vn.dtype).copy()
+    qn[0:3] += h * vn[0:3]
+    qn[7:] += h * vn[6:]
+    quat = q[3:7] / cnorm(q[3:7])
+    w = vn[3:6]
+    s = (w * w).sum() * h * h                       # (angle)^2
+    if abs(s.real if np.iscomplexobj(s) else s) < 1e-12:
+        c, so = 1 - s / 8 + s * s / 384, 0.5 - s / 48 + s * s / 3840       # cos(a/2), sin(a/2)/a
+    else:
+        a_ = np.sqrt(s); c, so = np.cos(a_ / 2), np.sin(a_ / 2) / a_
+    e = np.concatenate([[c], so * h * w])
+    a, b = quat, e
+    r = np.array([a[0] * b[0] - a[1:] @ b[1:], *(a[0] * b[1:] + b[0] * a[1:] + np.cross(a[1:], b[1:]))])
+    qn[3:7] = r / cnorm(r)
+    return np.concatenate([qn, vn])
+
+
+def kane_step_c(bodies, ctrlrange, x, u, h, grav, stance=(1, 1), contact=0, soft=1e-5, damping=1.0, armature=0.1, want=False):
+    """One MuJoCo-semantics step of the constraint-free plant (contact = 0) or with the feet the schedule
+    marks as stance held by velocity-level rigid constraints over the step (contact = 1 bilateral, 2 unilateral: a foot whose
+    normal force would pull is released and the rest solved again, once):
+        Mhat qacc - J^T lambda = tau - D v - bias ,   J qacc + gamma + v_f / h + soft lambda = 0 ,   Mhat = M + armature + h D
+    with J, gamma from a_f(qacc) = gamma + J qacc (spatial acceleration of the ankle link in link coordinates)."""
+    q, v = x[:26], x[26:]
+    z25 = np.zeros(25)
+    bias, feet0 = kane_eval_c(bodies, q, v, z25, grav, armature)
+    cols = [kane_eval_c(bodies, q, v, np.eye(25)[k], grav, armature) for k in range(25)]
+    M = np.stack([c[0] - bias for c in cols], axis=1)
+    D = np.concatenate([np.zeros(6), damping * np.ones(19)])
+    ur = u.real if np.iscomplexobj(u) else u
+    uc = np.where(ur < ctrlrange[:, 0], ctrlrange[:, 0], np.where(ur > ctrlrange[:, 1], ctrlrange[:, 1], u))
+    tau = np.concatenate([np.zeros(6), uc])
+    Mh = M + h * np.diag(D)
+    rhs = tau - D * v - bias
+    act = [bool(contact) and stance[0] == 1, bool(contact) and stance[1] == 1]
+    lam = np.zeros(12, dtype=rhs.dtype)
+    for _pass in range(2):
+        rows = [f for f in range(2) if act[f]]
+        if not rows:
+            qacc = np.linalg.solve(Mh, rhs); lam[:] = 0
+            break
+        J = np.concatenate([np.stack([cols[k][1][f]["acc"] - feet0[f]["acc"] for k in range(25)], axis=1) for f in rows], axis=0)
+        b = np.concatenate([-feet0[f]["vel"] / h - feet0[f]["acc"] for f in rows])
+        nc = J.shape[0]
+        KKT = np.block([[Mh, -J.T], [J, soft * np.eye(nc)]])
+        sol = np.linalg.solve(KKT, np.concatenate([rhs, b]))
+        qacc = sol[:25]
+        lam[:] = 0
+        for j, f in enumerate(rows):
+            lam[6 * f:6 * f + 6] = sol[25 + 6 * j:25 + 6 * j + 6]
+        again = False
+        if contact == 2 and _pass == 0:
+            for f in rows:
+                fz = feet0[f]["up"] @ lam[6 * f + 3:6 * f + 6]
+                if (fz.real if np.iscomplexobj(fz) else fz) < 0.0:
+                    act[f] = False; again = True
+        if not again:
+            break
+    xn = integrate_c(q, v, qacc, h)
+    if want:
+        return xn, qacc, Mh, lam, act
+    return xn
+
+
+def jacobians_complex_step(f, x, u, eps=1e-30):
+    """A = df/dx, B = df/du of a complex-safe step f(x, u) by complex-step differentiation (exact to rounding)."""
+    nx, nu = x.shape[0], u.shape[0]
+    A = np.zeros((nx, nx)); B = np.zeros((nx, nu))
+    for i in range(nx):
+        xp = x.astype(complex); xp[i] += 1j * eps
+        A[:, i] = f(xp, u.astype(complex)).imag / eps
+    for i in range(nu):
+        up = u.astype(complex); up[i] += 1j * eps
+        B[:, i] = f(x.astype(complex), up).imag / eps
+    return A, B
+
+
+def jacobians_tangent_free(bodies, ctrlrange, x, u, h, grav, damping=1.0, armature=0.1, eps=1e-30):
+    """The same Jacobians for the constraint-free step at 1/25 of the cost: d qacc / d z = -Mhat^-1 d r / d z with the residual
+    r = F(q, v, qacc) + D v - tau differentiated at fixed qacc (ONE complex residual evaluation per state coordinate instead of
+    a whole step with its 26), then the integrator by complex step."""
+    q, v = x[:26], x[26:]
+    xn, qacc, Mh, _, _ = kane_step_c(bodies, ctrlrange, x, u, h, grav, want=True)
+    D = np.concatenate([np.zeros(6), damping * np.ones(19)])
+    free_u = ((u >= ctrlrange[:, 0]) & (u <= ctrlrange[:, 1])).astype(float)
+    Mi = np.linalg.inv(Mh)
+    nx, nu = 51, 19
+    A = np.zeros((nx, nx)); B = np.zeros((nx, nu))
+    for col in range(nx + nu):
+        dq = np.zeros(25)
+        if 3 <= col < nx:
+            xp = x.astype(complex); xp[col] += 1j * eps
+            dr = kane_eval_c(bodies, xp[:26], xp[26:], qacc.astype(complex), grav, armature)[0].imag / eps
+            if col >= 26:
+                dr[col - 26] += D[col - 26]
+            dq = -Mi @ dr
+        elif col >= nx:
+            dq = Mi[:, 6 + col - nx] * free_u[col - nx]
+        xp = x.astype(complex)
+        if col < nx:
+            xp[col] += 1j * eps
+        d = integrate_c(xp[:26], xp[26:], qacc + 1j * eps * dq, h).imag / eps
+        if col < nx:
+            A[:, col] = d
+        else:
+            B[:, col - nx] = d
+    return A, B
+
+
 def gen_dynamics():
     bodies, ctrl = load_mjcf()
     rng = np.random.default_rng(123)
@@ -403,8 +581,12 @@ def gen_refdata():
 
 
 # ----------------------------------------------------------------------------- whole solve loop (numpy / torch)
-def gen_solve():
-    """NumPy / torch float64 restatement of the WHOLE iLQR::solve loop (ilqr.cpp:521-660) on a short horizon, glued from the
+def gen_solve(N=6, out_name="solve_golden.npz", n_seeds=2, max_iter=3, jac="central", contact=0, grav=(0.0, 0.0, -1.0), rng_seed=2024,
+              swing=(2, 4), u_scale=1.0, u_bias=None):
+    """(Defaults = the round-2 golden, file for file.  Round 3 adds: jac = "tangent" -- exact Jacobians of the constraint-free
+    Kane step by complex-step differentiation, N = 25 -- and contact = 2 with jac = "complex": the stance-constrained step as a
+    NumPy KKT system with complex-step Jacobians of the whole constrained step.)
+    NumPy / torch float64 restatement of the WHOLE iLQR::solve loop (ilqr.cpp:521-660) on a short horizon, glued from the
     independent pieces above: rollout through the Kane step, Jacobians by central differences of that step (eps 1e-4: a
     numerical stand-in for the exact derivatives the HIP path computes analytically), cost quadratics from the
     torch-autograd task terms (Pinocchio conventions, permutation quirk), NumPy Riccati, 8-alpha line search with the
@@ -412,8 +594,8 @@ def gen_solve():
     step sizes, gains) for the oracle (CPU test) and the HIP path (-m gpu)."""
     bodies, ctrl = load_mjcf()
     pin = PinTorch()
-    N, h = 6, 0.02
-    grav = np.array([0.0, 0.0, -1.0])
+    h = 0.02
+    grav = np.array(grav, dtype=float)
     nq, nx, nu = 26, 51, 19
     Q = np.ones(nx); Q[0], Q[1], Q[2] = 200.0, 50.0, 200.0; Q[3] = 50.0; Q[4:7] = 50.0; Q[7:nq] = 50.0
     Q[nq], Q[nq + 1], Q[nq + 2] = 150.0, 50.0, 150.0; Q[nq + 3:nq + 6] = 75.0; Q[nq + 6:] = 75.0
@@ -421,7 +603,9 @@ def gen_solve():
     Qf = Q * 2.0; Qf[0] *= 5.0; Qf[1] *= 2.0; Qf[2] *= 5.0; Qf[nq + 2] *= 4.0
     w = dict(com=100.0, comvel=0.0, eepos=400.0, eevel=400.0, upright=20.0, balance=30.0, joint=1500.0, ctrl=1500.0)
     jr = np.array([b["rng"] for b in bodies[1:]])
-    stance = np.ones((N + 1, 2), dtype=np.int32); stance[2:4, 0] = 0        # the left foot swings at knots 2, 3
+    stance = np.ones((N + 1, 2), dtype=np.int32)
+    if swing is not None:
+        stance[swing[0]:swing[1], 0] = 0                                     # the left foot swings at these knots (default: 2, 3)
     xs = np.zeros(nx); xs[2] = 1.0432; xs[3] = 1.0
     x_ref = np.tile(xs, (N + 1, 1)); u_ref = np.zeros((N, nu))
 
@@ -437,9 +621,12 @@ def gen_solve():
     com_ref = np.zeros((N + 1, 3)); ee_ref = np.zeros((N + 1, 2, 3))
     for t in range(N + 1):
         com_ref[t], ee_ref[t] = fk_mj(x_ref[t])
-    ee_ref[2:4, 0, 2] += 0.03                                                # swing-foot target above the ground
+    if swing is not None:
+        ee_ref[swing[0]:swing[1], 0, 2] += 0.03                              # swing-foot target above the ground
 
-    def f(x, u):
+    def f(x, u, t=0):
+        if contact or jac != "central":
+            return kane_step_c(bodies, ctrl, x, u, h, grav, stance=stance[t], contact=contact)
         return kane_step(bodies, ctrl, x, u, h, grav)[0]
 
     def limits(rng):
@@ -530,6 +717,14 @@ def gen_solve():
 
     def linearize(X, U, eps=1e-4):
         A = np.zeros((N, nx, nx)); B = np.zeros((N, nx, nu))
+        if jac == "tangent":
+            for t in range(N):
+                A[t], B[t] = jacobians_tangent_free(bodies, ctrl, X[t], U[t], h, grav)
+            return A, B
+        if jac == "complex":
+            for t in range(N):
+                A[t], B[t] = jacobians_complex_step(lambda xx, uu: f(xx, uu, t), X[t], U[t])
+            return A, B
         for t in range(N):
             for i in range(nx):
                 d = np.zeros(nx); d[i] = eps
@@ -547,25 +742,28 @@ def gen_solve():
             Xn = [x0.copy()]; Un = []
             for t in range(N):
                 u = U[t] + a * k[t] + K[t] @ (Xn[t] - X[t])
-                Un.append(u); Xn.append(f(Xn[t], u))
+                Un.append(u); Xn.append(f(Xn[t], u, t))
             Jn = total_cost(np.array(Xn), np.array(Un))
             if Jn < J0 - 1e-6:
                 return True, np.array(Xn), np.array(Un), Jn, a
         return False, X, U, J0, 0.0
 
     out = {}
-    max_iter, tol = 3, 1e-4
-    rng = np.random.default_rng(2024)
-    for seed in range(2):
+    tol = 1e-4
+    rng = np.random.default_rng(rng_seed)
+    ub = np.zeros(nu) if u_bias is None else np.asarray(u_bias, dtype=float)
+    uin = []
+    for seed in range(n_seeds):
         x0 = xs.copy()
         x0[0:3] += rng.uniform(-0.02, 0.02, 3)
         wv = rng.uniform(-0.05, 0.05, 3); ang = np.linalg.norm(wv)
         x0[3:7] = np.concatenate([[math.cos(ang / 2)], math.sin(ang / 2) * wv / ang])
         x0[7:nq] += rng.uniform(-0.05, 0.05, 19); x0[nq:] += rng.uniform(-0.1, 0.1, 25)
-        U = rng.uniform(-1.0, 1.0, (N, nu))
+        U = ub + u_scale * rng.uniform(-1.0, 1.0, (N, nu))
+        uin.append(U.copy())
         X = [x0.copy()]
         for t in range(N):
-            X.append(f(X[t], U[t]))
+            X.append(f(X[t], U[t], t))
         X = np.array(X)
         lam = 1e-6
         J = total_cost(X, U)
@@ -577,7 +775,7 @@ def gen_solve():
             Jprev = J
             X[0] = x0
             for t in range(N):
-                X[t + 1] = f(X[t], U[t])
+                X[t + 1] = f(X[t], U[t], t)
             A, B = linearize(X, U)
             lx, lu, lxx, luu = quadratics(X, U)
             lam_used = lam
@@ -605,18 +803,27 @@ def gen_solve():
         out["trace_cost_%d" % seed] = np.array(trace_c); out["trace_alpha_%d" % seed] = np.array(trace_a); out["trace_lambda_%d" % seed] = np.array(trace_l)
         out["K_%d" % seed] = Ks; out["xbar_%d" % seed] = X; out["ubar_%d" % seed] = U
     out = {k_: v for k_, v in out.items() if v is not None}
-    # the inputs that are not a function of the seed
-    rng = np.random.default_rng(2024)
-    uin = []
-    for seed in range(2):
-        rng.uniform(-0.02, 0.02, 3); rng.uniform(-0.05, 0.05, 3); rng.uniform(-0.05, 0.05, 19); rng.uniform(-0.1, 0.1, 25)
-        uin.append(rng.uniform(-1.0, 1.0, (N, nu)))
     out["u_init"] = np.array(uin)
     out.update(N=N, h=h, gravity=grav, Q=Q, R=R, Qf=Qf, stance=stance, x_ref=x_ref, u_ref=u_ref, com_ref=com_ref, ee_ref=ee_ref,
                task_weights=np.array([w["com"], w["comvel"], w["eepos"], w["eevel"], w["upright"], w["balance"]]), w_joint=w["joint"], w_ctrl=w["ctrl"],
                max_iter=max_iter, tol=tol)
-    np.savez(os.path.join(HERE, "solve_golden.npz"), **out)
-    print("solve golden written")
+    if contact:
+        out.update(contact=contact, soft=1e-5)
+    np.savez(os.path.join(HERE, out_name), **out)
+    print("solve golden written:", out_name)
+
+
+def gen_solve_round3():
+    """Round 3: (i) the full N = 25 horizon with EXACT Jacobians of the Kane step (gains then pin far below the 1e-4 the
+    central differences of the 6-knot golden allowed); (ii) the contact row: gravity -9.81, unilateral stance constraints as a
+    NumPy KKT system, complex-step Jacobians of the constrained step, gravity-compensating initial controls."""
+    gen_solve(N=25, out_name="solve_golden_n25.npz", n_seeds=2, max_iter=4, jac="tangent", rng_seed=77, swing=(8, 14))
+    bodies, ctrl = load_mjcf()
+    xs = np.zeros(51); xs[2] = 1.0432; xs[3] = 1.0
+    g981 = np.array([0.0, 0.0, -9.81])
+    ug = kane_eval_c(bodies, xs[:26], xs[26:], np.zeros(25), g981, 0.1)[0][6:]          # qfrc_bias of the hinges at rest
+    gen_solve(N=6, out_name="solve_golden_contact.npz", n_seeds=1, max_iter=3, jac="complex", contact=2, grav=(0.0, 0.0, -9.81), rng_seed=99,
+              swing=None, u_scale=1.0, u_bias=ug)
 
 
 if __name__ == "__main__":
@@ -626,6 +833,9 @@ if __name__ == "__main__":
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "solve":
         gen_solve()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "solve3":
+        gen_solve_round3()
         sys.exit(0)
     gen_dynamics()
     gen_costs()
