@@ -75,6 +75,8 @@ def parse():
     ap.add_argument("--print-signature", action="store_true", help="print the run signature tools/pmc_summary.py --stamp expects, and exit")
     ap.add_argument("--rehearse-single-gpu", action="store_true",
                     help="rehearsal of the N > 1 path on a one-GPU box: every rank uses device 0, gloo instead of RCCL, payload staged through the host")
+    ap.add_argument("--try-rccl", action="store_true",
+                    help="with --rehearse-single-gpu: attempt the RCCL communicator anyway (two ranks on one device: RCCL refuses, which exercises the all-ranks fallback)")
     ap.add_argument("--gather-gains", action="store_true", help="include K0[19x51] in the per-step gather payload")
     ap.add_argument("--stage", choices=["full", "rollout_jacobians"], default="full",
                     help="full (headline) or BASELINE.json configs[1]: forward rollout + Jacobians only (use with --batch 1024)")
@@ -276,13 +278,28 @@ def main():
     # reduction).  One GPU: the same entry point degenerates to a device copy.  --rehearse-single-gpu (two ranks on ONE device,
     # which RCCL refuses): every rank runs the one-rank form and the rows are staged through the host over gloo.
     W = sh.payload_width(args.gather_gains)
-    rccl = world > 1 and not args.rehearse_single_gpu
+    rccl, rccl_error = False, None
+    if world > 1 and (not args.rehearse_single_gpu or args.try_rccl):
+        # Every rank reports whether its communicator came up; unless ALL did, every rank falls back together to the harness's
+        # own gather below (torch.distributed) -- the driver's scaling run must not die on a communicator problem, and the JSON
+        # says which collective carried the rows.
+        ok = 1
+        try:
+            idt = torch.zeros(128, dtype=torch.uint8, device=("cpu" if args.rehearse_single_gpu else dev))
+            if rank == 0:
+                idt.copy_(torch.frombuffer(bytearray(sv.BatchedILQR.comm_unique_id()), dtype=torch.uint8))
+            dist.broadcast(idt, src=0)
+            s.comm_init(world, rank, bytes(idt.cpu().numpy().tobytes()))
+        except Exception as e:  # noqa: BLE001 -- reported in the JSON line
+            ok, rccl_error = 0, repr(e)
+        flag = torch.tensor([ok], dtype=torch.int32, device=("cpu" if args.rehearse_single_gpu else dev))
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        rccl = int(flag.item()) == 1
+        if not rccl:
+            s.comm_destroy()
+            if rank == 0 and rccl_error is None:
+                rccl_error = "a peer rank failed to initialise its RCCL communicator"
     if rccl:
-        idt = torch.zeros(128, dtype=torch.uint8, device=dev)
-        if rank == 0:
-            idt.copy_(torch.frombuffer(bytearray(sv.BatchedILQR.comm_unique_id()), dtype=torch.uint8))
-        dist.broadcast(idt, src=0)
-        s.comm_init(world, rank, bytes(idt.cpu().numpy().tobytes()))
         recv = torch.zeros(world * B, W, dtype=torch.float64, device=dev) if rank == 0 else None
     else:
         s.comm_init(1, 0)
@@ -308,8 +325,8 @@ def main():
         s.gather_first_knot(None if recv is None else recv.data_ptr(), root=0, with_gains=args.gather_gains)
         s.synchronize()
         g = recv
-        if args.rehearse_single_gpu and world > 1:
-            g = sh.gather_first_knot(recv.cpu(), dst=0)
+        if world > 1 and not rccl:      # one-GPU rehearsal (host-staged over gloo), or the fallback when RCCL did not come up
+            g = sh.gather_first_knot(recv.cpu() if args.rehearse_single_gpu else recv, dst=0)
         if timed:
             record_stages(timed_ms, timed_n)
         return g
@@ -497,8 +514,10 @@ def main():
                        "batch_per_gpu": B, "global_batch": B * world, "horizon": N, "iterations_per_solve": iters,
                        "jacobians": "analytic (constrained step)" if args.contact else "analytic", "contact_mode": bool(args.contact), "batch_slices": n_slices, "gather": "u0+cost" + ("+K0" if args.gather_gains else ""), "gather_check": gather_check,
                        "collective": ("ilqr_hip_gather_first_knot, one rank: device copy (no RCCL)" if world == 1 else
+                                      "RCCL grouped send/recv behind the C ABI (ilqr_hip_gather_first_knot)" if rccl else
                                       "ilqr_hip_gather_first_knot per rank + gloo, host-staged (one-GPU rehearsal)" if args.rehearse_single_gpu else
-                                      "RCCL grouped send/recv behind the C ABI (ilqr_hip_gather_first_knot)")},
+                                      "FALLBACK: ilqr_hip_gather_first_knot per rank + torch.distributed.gather (RCCL communicator did not come up)"),
+                       "collective_error": rccl_error},
             "roofline": roof,
             "kernels": {n: {k: (round(v, 6) if isinstance(v, float) else v) for k, v in t.items() if k in
                             ("total_ms_per_step", "exclusive_ms_per_step", "avg_launch_ms", "frac_compute", "frac_hbm")} for n, t in table.items()},

@@ -533,19 +533,30 @@ def test_two_rank_shard_gather_equals_single_process_bitwise(tmp_path):
     s.close()
 
 
-def test_bench_two_ranks_rehearsed_on_one_gpu():
+@pytest.mark.parametrize("try_rccl", [False, True])
+def test_bench_two_ranks_rehearsed_on_one_gpu(try_rccl):
     """The world > 1 branch of bench.py (global batch sliced by shard_range, barrier, max-over-ranks timing, gather) executed
-    with two ranks on device 0 over gloo (--rehearse-single-gpu; on a multi-GPU node the same branch runs over RCCL)."""
+    with two ranks on device 0 over gloo (--rehearse-single-gpu; on a multi-GPU node the same branch gathers over RCCL through
+    the C ABI).  With --try-rccl the RCCL communicator of the C ABI is attempted for real: ilqr_hip_comm_get_unique_id, the
+    128-byte id over the process group, ilqr_hip_comm_init(world = 2) on both ranks -- on ONE device RCCL refuses the second
+    rank, every rank agrees on the fallback and the line says so (what would happen on a node whose RCCL does not come up)."""
     sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                         "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--batch", "64", "--steps", "1", "--warmup", "0",
-                        "--rehearse-single-gpu"], capture_output=True, text=True, timeout=900)
+                        "--rehearse-single-gpu"] + (["--try-rccl"] if try_rccl else []), capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 128 and d["value"] > 0 and "roofline" in d and "cpu_baseline" not in d
     assert d["config"]["gather_check"] == "rank 0 received 128 rows in global rollout order"
+    assert d["config"]["workload"].startswith("custom:")
+    if try_rccl:
+        # either RCCL accepted two ranks on one device (then its gather carried the rows) or both ranks fell back together
+        assert ("RCCL grouped send/recv" in d["config"]["collective"] and d["config"]["collective_error"] is None) or \
+               ("gloo" in d["config"]["collective"] and d["config"]["collective_error"])
+    else:
+        assert "gloo" in d["config"]["collective"] and d["config"]["collective_error"] is None
 
 
 # ---------------------------------------------------------------------------------------------------------------------
