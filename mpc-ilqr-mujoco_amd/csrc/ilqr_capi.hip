@@ -56,6 +56,12 @@ struct ilqr_hip_ctx {
   int* h_active = nullptr;
   std::vector<hipEvent_t> ev_active;
   int iterations_enqueued = 0;
+  // S.xbar is a rollout of (S.x0, S.ubar) by `rolled_variant` under `rolled_dyn` (the cold start): iteration 0 of the next solve
+  // may then re-roll it beside the linearisation like every later iteration (enqueue_solve); cleared by anything that changes
+  // the trajectory or x0 without a rollout
+  bool xbar_rolled = false, first_aside = false;
+  int rolled_variant = -1;
+  h1::DynParams rolled_dyn{};
   bool lxx_lower = false;    // S.lxx of the knots t < N holds the tiles I >= J only (last written inside a solve): getters mirror them
   double lin_fold_h = 0.0;   // step size h while S.A / S.Bm hold the analytic Jacobians (folded backward kernel), else 0
   std::string err;
@@ -220,6 +226,7 @@ int ilqr_hip_set_contact_schedule(ilqr_hip_ctx* c, const int* stance, int n_sets
   HIPCHK(c, hipMemcpyAsync(c->d_stance, stance, per * n_sets * sizeof(int), hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->P.stance_stride = n_sets == 1 ? 0 : (long)per;
+  c->xbar_rolled = false;      // (contact mode: the schedule is part of the dynamics)
   return ILQR_OK;
 }
 int ilqr_hip_set_ee_references(ilqr_hip_ctx* c, const double* ee_ref, const double* com_vel_ref, int n_sets) {
@@ -285,6 +292,8 @@ static int cold_start_device(ilqr_hip_ctx* c, const double* x0_dev, const double
   ilqr::launch_rollout(c->S, c->P, ilqr::MASK_ALL, 1, 0, c->S.Jbase, c->stream);  // N rollouts (ilqr.cpp:113-115)
   HIPCHK(c, hipGetLastError());
   c->initialized = true;
+  c->xbar_rolled = true;
+  c->rolled_variant = ilqr::variant_rollout_split(); c->rolled_dyn = c->P.dyn;
   return ILQR_OK;
 }
 int ilqr_hip_initialize_device(ilqr_hip_ctx* c, const double* x0_device, const double* u_init_device) {
@@ -305,6 +314,7 @@ int ilqr_hip_initialize(ilqr_hip_ctx* c, const double* x0, const double* u_init,
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->initialized = true;
+    c->xbar_rolled = false;
     return ILQR_OK;
   }
   std::vector<double> ug;
@@ -335,6 +345,7 @@ int ilqr_hip_initialize_warm_resident(ilqr_hip_ctx* c, const double* x0) {
   ilqr::launch_last_step(c->S, c->P, c->stream);
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->xbar_rolled = false;
   return ILQR_OK;
 }
 
@@ -419,6 +430,7 @@ static int enqueue_solve(ilqr_hip_ctx* c, const DevState& S, const h1::ProblemDe
   // without the convergence exit every rollout stays active: the per-knot kernels then skip the selection altogether
   const int sel_mode = c->early_exit ? ilqr::MASK_ACTIVE : ilqr::MASK_ALL;
   const bool gate = c->early_exit && S.order && early_exit_gate(c);
+  const bool xbar_rolled = c->first_aside;
   // the one-wave Riccati kernel reads only the tiles I >= J of lxx_t (t < N): the cost quadratics then leave the others unwritten
   const int lxx_lower = ilqr::variant_backward() == 2 ? 1 : 0;
   if (lxx_lower) c->lxx_lower = true;
@@ -439,7 +451,11 @@ static int enqueue_solve(ilqr_hip_ctx* c, const DevState& S, const h1::ProblemDe
     // before the backward pass.  ILQR_OVERLAP_ROLLOUT=0 restores the sequential order.
     // (only while the line search and the rollout run the same step implementation: otherwise the re-rollout would differ in
     // rounding from the trajectory the linearisation beside it sees)
-    const bool concurrent_roll = iter > 0 && !reuse_rollout() && overlap_rollout() && (P.dyn.contact || ilqr::variant_ls_split() == ilqr::variant_rollout_split());   // (contact mode: both on the two-lane kernels)
+    // (iteration 0 as well when the nominal trajectory is itself a rollout by this very kernel -- the cold start,
+    // initializeWithReference ilqr.cpp:113-115: the re-rollout of ilqr.cpp:563 then reproduces it bit for bit, same kernel, same
+    // inputs; a warm-shifted or caller-supplied trajectory is rolled out BEFORE the linearisation, as the reference does)
+    const bool first_aside = iter == 0 && xbar_rolled && !ilqr::variant_scalar_dyn();
+    const bool concurrent_roll = (iter > 0 || first_aside) && !reuse_rollout() && overlap_rollout() && (P.dyn.contact || ilqr::variant_ls_split() == ilqr::variant_rollout_split());   // (contact mode: both on the two-lane kernels)
     if ((iter == 0 || !reuse_rollout()) && !concurrent_roll) { StageTimer T(c, 0, st); ilqr::launch_rollout(S, P, ilqr::MASK_ACTIVE, 1, 0, S.Jbase, st); }
     if (iter == 0 && wait_lead) HIPCHK(c, hipStreamWaitEvent(st, wait_lead, 0));
     // linearisation (:576) and cost quadratics (:588) only depend on the rollout: run them concurrently
@@ -492,6 +508,8 @@ int ilqr_hip_solve_async(ilqr_hip_ctx* c) {
   const int k = slices_wanted(c->B);
   c->n_slices = k;
   c->lin_fold_h = ilqr::linearize_fold_h(P, c->jac_mode);   // what S.A / S.Bm hold after this solve
+  c->first_aside = c->xbar_rolled && c->rolled_variant == ilqr::variant_rollout_split() && std::memcmp(&c->rolled_dyn, &P.dyn, sizeof(P.dyn)) == 0;
+  c->xbar_rolled = false;                                   // after this solve xbar is an accepted line-search candidate
   if (k <= 1) {
     TRY(enqueue_solve(c, S, P, st, c->stream2, c->stream3, c->ev_fork, c->ev_join, c->ev_roll, c->d_shadowx, nullptr, nullptr, c->ev_lin, c->ev_adopt));
   } else {
@@ -524,7 +542,10 @@ int ilqr_hip_synchronize(ilqr_hip_ctx* c) {
 int ilqr_hip_solve(ilqr_hip_ctx* c, const double* x0, double* cost_out) {
   if (!c) return ILQR_ERR_ARG;
   enter(c);
-  if (x0) HIPCHK(c, hipMemcpyAsync(c->S.x0, x0, (size_t)c->B * ILQR_NX * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  if (x0) {      // (a new x0: the nominal trajectory is rolled out from it before the linearisation, as the reference does)
+    HIPCHK(c, hipMemcpyAsync(c->S.x0, x0, (size_t)c->B * ILQR_NX * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    c->xbar_rolled = false;
+  }
   TRY(ilqr_hip_solve_async(c));
   TRY(ilqr_hip_synchronize(c));
   if (cost_out) HIPCHK(c, hipMemcpy(cost_out, c->S.J, (size_t)c->B * sizeof(double), hipMemcpyDeviceToHost));
@@ -598,6 +619,7 @@ int ilqr_hip_set_trajectory(ilqr_hip_ctx* c, const double* xbar, const double* u
   HIPCHK(c, hipMemcpy2DAsync(c->S.x0, ILQR_NX * sizeof(double), c->S.xbar, (N + 1) * ILQR_NX * sizeof(double), ILQR_NX * sizeof(double), B, hipMemcpyDeviceToDevice, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->initialized = true;
+  c->xbar_rolled = false;
   return ILQR_OK;
 }
 #define STAGE_PRE if (!c) return ILQR_ERR_ARG; if (!c->initialized) return ILQR_ERR_STATE; enter(c)

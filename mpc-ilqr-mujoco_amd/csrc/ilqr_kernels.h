@@ -85,6 +85,7 @@ void refresh_variants();
 int variant_ls_split();
 int variant_rollout_split();
 int variant_backward();
+int variant_scalar_dyn();
 size_t backward_lds_bytes();
 size_t lin_dump_doubles();
 void launch_rollout_r(const DevState& S, const h1::ProblemDev& P, int mode, int do_roll, int count_iter, double* cost_out, hipStream_t st);

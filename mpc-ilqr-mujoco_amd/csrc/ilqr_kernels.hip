@@ -678,6 +678,7 @@ void refresh_variants() {
 int variant_ls_split() { return g_var.ls_split; }
 int variant_rollout_split() { return g_var.rollout_split; }
 int variant_backward() { return backward_kind(); }
+int variant_scalar_dyn() { return g_var.scalar_dyn; }
 void launch_rollout(const DevState& S, const ProblemDev& P, int mode, int do_roll, int count_iter, double* cost_out, hipStream_t st) {
   // contact mode (f4) runs on the two-lane kernels (the one-lane register kernels are constraint-free only)
   if (!use_scalar_dyn()) { if (g_var.rollout_split || P.dyn.contact) launch_rollout_s(S, P, mode, do_roll, count_iter, cost_out, st); else launch_rollout_r(S, P, mode, do_roll, count_iter, cost_out, st); return; }

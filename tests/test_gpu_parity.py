@@ -571,6 +571,21 @@ def test_launch_orchestration_variants_are_bitwise_equivalent():
         assert np.array_equal(a, b, equal_nan=True)
     assert np.array_equal(out["base"][3], out["seq"][3])
     assert np.allclose(out["base"][0], out["seq"][0], rtol=1e-9) and rel(out["base"][2], out["seq"][2]) < 1e-6
+    # Round 3: after a COLD start (the nominal trajectory is itself a rollout by the same kernel) iteration 0 re-rolls it beside the
+    # linearisation too.  solve(x0) hands over a new x0 and therefore rolls out first; solve() without one takes the concurrent
+    # path -- the re-rollout reproduces the cold start bit for bit, so nothing may change; a warm start always rolls out first.
+    s = _solver(B); s.set_problem(prob); s.set_max_iterations(4)
+    s.initialize(x0, ui); cost = s.solve()
+    got = (cost, s.trace()[0], s.gains_K(), s.iterations())
+    assert s.adopt_mismatches() == 0
+    for a, b in zip(out["base"], got):
+        assert np.array_equal(a, b, equal_nan=True)
+    s.set_regularization(1e-6); s.initialize_warm_resident(x0); c_async = s.solve()
+    K_async = s.gains_K()
+    s2 = _solver(B); s2.set_problem(prob); s2.set_max_iterations(4)
+    s2.initialize(x0, ui); s2.solve(x0); s2.set_regularization(1e-6); s2.initialize_warm_resident(x0); c_seq = s2.solve(x0)
+    assert np.array_equal(c_async, c_seq) and np.array_equal(K_async, s2.gains_K())
+    s.close(); s2.close()
 
 
 def test_per_rollout_reference_sets():
