@@ -65,15 +65,24 @@ __constant__ static const QRelTable QREL = make_rel_table();
 static_assert(make_rel_table().n == 158, "related joint pairs of the H1 tree");
 
 #define QMAXC 6   // at most: CoM pos, CoM vel, one functional per foot (swing: position / stance: velocity), 2 balance
+#define QMAXM 4   // after the merge of contexts on the same (point set, type): (CoM, pos), (CoM, vel), one per foot
 struct QuadCtx { int set, is_vel; double scale; double vec[3], til[3], Dv[4][3]; };
-// 20,2xx B of LDS: 8 waves per CU.  Phase-1/2 temporaries share storage with the per-joint vectors of phase 4.
+// 16,2xx B of LDS (round 3; 20,4xx before): ten two-wave workgroups per CU instead of eight -- the kernel is a chain of
+// dependent lane-parallel phases (62 % of its wave cycles parked on a wait), so what it gains is workgroups in flight.  Three
+// cuts: (i) a foot's point set carries ONE gradient-carrying functional per knot -- its position in swing, its velocity in
+// stance -- so the feet keep one Jacobian (Jf) instead of d c and d cdot both; (ii) at most four contexts survive the merge;
+// (iii) the second-order patch is packed (entry (a, b), a <= b: row a holds its columns a..50 only).
+// Phase-1/2 temporaries share storage with the per-joint vectors of phase 4.
 #define QS2_R0 3            // second-order patch: rows quat | theta (3..25), columns 3..50, entry (a, b) with a <= b
 #define QS2_NR 23
 #define QS2_NC 48
+#define QS2_SIZE (QS2_NR * QS2_NC - QS2_NR * (QS2_NR - 1) / 2)
+#define QS2_IDX(a, bb) (((a) - QS2_R0) * QS2_NC - ((a) - QS2_R0) * ((a) - QS2_R0 - 1) / 2 + ((bb) - (a)))
 struct QuadLds {
   union {
     struct {                               // phases 0..5 and the operand fetch of phase 6
-      double Jc[3][3][H1_NX], Jv[3][3][H1_NX];   // d c / d x_p, d cdot / d x_p per point set
+      double Jc[3][H1_NX], Jv[3][H1_NX];     // d c / d x_p, d cdot / d x_p of the whole-body CoM (point set 0)
+      double Jf[2][3][H1_NX];                // the feet (point sets 1, 2): d cdot / d x_p in stance, d c / d x_p in swing
       double jr[2][H1_NX];                   // balance rows jr0, jr1 (jz, Jv0, Jv1 are rows of Jc[0] / Jv[0])
       double xp[H1_NX];                      // Pinocchio-ordered state (derivatives.cpp:12-24)
       double R0[9], D[4][9];                 // base rotation (Eigen toRotationMatrix polynomial), dR/dquat_k
@@ -81,25 +90,25 @@ struct QuadLds {
       double us[H1_NU];
       double gsum[QMAXC][3];
     };
-    double S2[QS2_NR][QS2_NC];             // phase 6: second-order part of the entries that have one
+    double S2[QS2_SIZE];                   // phase 6: second-order part of the entries that have one (packed, QS2_IDX)
   };
   double beta[3][3], gamma[3][3], mfrac[3];
   double w[3][H1_NB][3], dgam[3][H1_NB][3];
   unsigned char on[3][H1_NB];
   QuadCtx ctx[QMAXC];
   double dg[H1_NX];                      // diagonal additions: Q (or Qf) + soft joint-limit penalty
-  double gscale[QMAXC];                  // scale of the gradient-carrying functionals (first-order product)
+  double gscale[QMAXM];                  // scale of the gradient-carrying functionals (first-order product): CoM position, CoM velocity, one per foot
   unsigned char gset[8], gvel[8]; int nctx, ng, has_bal; double bal[8];
   double uJ[3][4], ur[3];                // upright pieces
   unsigned anc[H1_NB];                   // bit j of anc[i]: body i is an ancestor of (or is) body j
   union {
     struct { double Rh[H1_NB][9], ph[H1_NB][3], mu[3][H1_NB], q[3][H1_NB][3]; } k;   // phases 1-2
-    struct { double tz[QMAXC][H1_NJ][3], Pp[QMAXC][H1_NJ][3]; } j;                    // phases 4-6: til_c x z_j, P'_j
+    struct { double tz[QMAXM][H1_NJ][3], Pp[QMAXM][H1_NJ][3]; } j;                    // phases 4-6: til_c x z_j, P'_j
   } u;
 };
-static_assert(sizeof(double) * QS2_NR * QS2_NC <= sizeof(double) * (2 * 9 * H1_NX + 2 * H1_NX + H1_NX + 9 + 36 + 6 * H1_NB + H1_NU + 3 * QMAXC), "the patch fits the storage it aliases");
+static_assert(sizeof(double) * QS2_SIZE <= sizeof(double) * (12 * H1_NX + 2 * H1_NX + H1_NX + 9 + 36 + 6 * H1_NB + H1_NU + 3 * QMAXC), "the patch fits the storage it aliases");
 static_assert(H1_NB * 3 >= H1_NX, "balance row m aliases Om");
-static_assert(sizeof(QuadLds) <= 20480, "QuadLds must fit 8 waves per CU");
+static_assert(sizeof(QuadLds) <= 16384, "QuadLds must fit ten two-wave workgroups per CU");
 
 __device__ __forceinline__ bool quad_selected(const DevState& S, int b, int mode) {
   if (mode == MASK_ALL) return true;
@@ -280,6 +289,8 @@ __global__ void __launch_bounds__(128, QUAD_WAVES) k_cost_quadratics(DevState S,
   QSTAMP(2)
 
   // ---- phase 3: Jacobian columns of c and cdot, lane = coordinate (h1_cost_dev.h knot_jac_column)
+  const int* stq = P.stance + b * P.stance_stride + 2 * t;      // (wave-uniform: scalar loads)
+  const int fvel[2] = {stq[0] == 1, stq[1] == 1};               // stance foot: the velocity functional; swing foot: the position one
   if (lane < H1_NX) {
     const int c = lane;
     for (int s = 0; s < 3; ++s) {
@@ -298,7 +309,10 @@ __global__ void __launch_bounds__(128, QUAD_WAVES) k_cost_quadratics(DevState S,
         mv3(L.R0, col, jv);
       }
 #pragma unroll
-      for (int r = 0; r < 3; ++r) { L.Jc[s][r][c] = jc[r]; L.Jv[s][r][c] = jv[r]; }
+      for (int r = 0; r < 3; ++r) {
+        if (s == 0) { L.Jc[r][c] = jc[r]; L.Jv[r][c] = jv[r]; }
+        else L.Jf[s - 1][r][c] = fvel[s - 1] ? jv[r] : jc[r];
+      }
     }
   }
   __syncthreads();
@@ -376,9 +390,9 @@ __global__ void __launch_bounds__(128, QUAD_WAVES) k_cost_quadratics(DevState S,
   if (has_bal && lane < H1_NX) {
     const int a = lane;
     const double om = L.bal[2], om1 = L.bal[3];
-    const double jz = L.Jc[0][2][a];
-    L.jr[0][a] = L.Jc[0][0][a] + om * L.Jv[0][0][a] + L.bal[5] * om1 * jz;
-    L.jr[1][a] = L.Jc[0][1][a] + om * L.Jv[0][1][a] + L.bal[6] * om1 * jz;
+    const double jz = L.Jc[2][a];
+    L.jr[0][a] = L.Jc[0][a] + om * L.Jv[0][a] + L.bal[5] * om1 * jz;
+    L.jr[1][a] = L.Jc[1][a] + om * L.Jv[1][a] + L.bal[6] * om1 * jz;
   }
   __syncthreads();   // (also: the phase-1/2 temporaries are dead, their storage becomes tz / Pp)
   for (int e = lane; e < nctx * H1_NJ; e += 128) {
@@ -395,7 +409,7 @@ __global__ void __launch_bounds__(128, QUAD_WAVES) k_cost_quadratics(DevState S,
   }
   __syncthreads();
   double* const balm = &L.Om[0][0];   // Om is dead from here on: its storage takes the balance row m = om1 (r0 Jv0 + r1 Jv1) + rv om2 jz / 2
-  if (has_bal && lane < H1_NX) balm[lane] = L.bal[3] * (L.bal[0] * L.Jv[0][0][lane] + L.bal[1] * L.Jv[0][1][lane]) + 0.5 * L.bal[7] * L.bal[4] * L.Jc[0][2][lane];
+  if (has_bal && lane < H1_NX) balm[lane] = L.bal[3] * (L.bal[0] * L.Jv[0][lane] + L.bal[1] * L.Jv[1][lane]) + 0.5 * L.bal[7] * L.bal[4] * L.Jc[2][lane];
   __syncthreads();
   QSTAMP(4)
 
@@ -407,7 +421,7 @@ __global__ void __launch_bounds__(128, QUAD_WAVES) k_cost_quadratics(DevState S,
     const int a = lane;
     double g = Qd[a] * (xg[a] - xr[a]);   // Q acts on the MuJoCo-ordered state
     for (int i = 0; i < ng; ++i) {
-      const double (*J)[H1_NX] = L.gvel[i] ? L.Jv[L.gset[i]] : L.Jc[L.gset[i]];
+      const double (*J)[H1_NX] = L.gset[i] == 0 ? (L.gvel[i] ? L.Jv : L.Jc) : L.Jf[L.gset[i] - 1];   // (a foot's Jf is of the type its functional has)
       g += J[0][a] * L.gsum[i][0] + J[1][a] * L.gsum[i][1] + J[2][a] * L.gsum[i][2];
     }
     if (P.w_upright > 0.0 && a >= 3 && a < 7) g += P.w_upright * (L.uJ[0][a - 3] * L.ur[0] + L.uJ[1][a - 3] * L.ur[1] + L.uJ[2][a - 3] * L.ur[2]);
@@ -455,9 +469,9 @@ __global__ void __launch_bounds__(128, QUAD_WAVES) k_cost_quadratics(DevState S,
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       const int ii = ks < ng ? ks : 0;
-      const double* rowJ = (L.gvel[ii] ? &L.Jv[L.gset[ii]][0][0] : &L.Jc[L.gset[ii]][0][0]) + (lk < 3 ? lk : 0) * H1_NX;
-      const double* rowA = lk < 3 ? rowJ : (ks == 0 ? L.jr[0] : (ks == 1 ? L.jr[1] : (ks == 2 ? L.Jc[0][2] : balm_)));
-      const double* rowB = lk < 3 ? rowJ : (ks == 0 ? L.jr[0] : (ks == 1 ? L.jr[1] : (ks == 2 ? balm_ : L.Jc[0][2])));
+      const double* rowJ = (L.gset[ii] == 0 ? (L.gvel[ii] ? &L.Jv[0][0] : &L.Jc[0][0]) : &L.Jf[L.gset[ii] - 1][0][0]) + (lk < 3 ? lk : 0) * H1_NX;
+      const double* rowA = lk < 3 ? rowJ : (ks == 0 ? L.jr[0] : (ks == 1 ? L.jr[1] : (ks == 2 ? L.Jc[2] : balm_)));
+      const double* rowB = lk < 3 ? rowJ : (ks == 0 ? L.jr[0] : (ks == 1 ? L.jr[1] : (ks == 2 ? balm_ : L.Jc[2])));
       const bool used = lk < 3 ? (ks < ng) : (has_bal != 0);
       const double sA = lk < 3 ? L.gscale[ii] : P.w_balance;
 #pragma unroll
@@ -473,11 +487,11 @@ __global__ void __launch_bounds__(128, QUAD_WAVES) k_cost_quadratics(DevState S,
   }
   QSTAMP(6)
   __syncthreads();   // the Jacobian rows are in registers: their storage becomes the second-order patch
-  for (int e = lane; e < QS2_NR * QS2_NC; e += 128) (&L.S2[0][0])[e] = 0.0;
+  for (int e = lane; e < QS2_SIZE; e += 128) L.S2[e] = 0.0;
   __syncthreads();
   // 6b: second-order part, block by block of the coordinate classes (a <= bb in every block).  The (merged) contexts'
   // set / type are wave-uniform: held in scalar registers, so the loops over them branch uniformly.
-  auto patch = [&](int a, int bb, double h) { L.S2[a - QS2_R0][bb - QS2_R0] = h; };
+  auto patch = [&](int a, int bb, double h) { L.S2[QS2_IDX(a, bb)] = h; };
   // triangular index -> (i, j), i <= j < n
   auto tri = [](int idx, int n, int& i, int& j) {
     int a = (int)((2 * n + 1 - sqrtf((float)((2 * n + 1) * (2 * n + 1) - 8 * idx))) * 0.5f);   // exact integers in fp32; corrected below
@@ -615,7 +629,7 @@ __global__ void __launch_bounds__(128, QUAD_WAVES) k_cost_quadratics(DevState S,
         double h = acc[J][r];
         if (a == bb) h += L.dg[a];
         const int lo2 = a < bb ? a : bb, hi2 = a < bb ? bb : a;
-        if (lo2 >= QS2_R0 && lo2 < QS2_R0 + QS2_NR && hi2 < H1_NX) h += L.S2[lo2 - QS2_R0][hi2 - QS2_R0];
+        if (lo2 >= QS2_R0 && lo2 < QS2_R0 + QS2_NR && hi2 < H1_NX) h += L.S2[QS2_IDX(lo2, hi2)];
         if (bb < H1_NX) Hg[a * H1_NX + bb] = h;
       }
     }
