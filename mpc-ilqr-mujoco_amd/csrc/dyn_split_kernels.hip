@@ -520,10 +520,15 @@ int dyn_split_kernels_set_attr() {
 #ifndef LS_RPW1_MAX_BATCH
 #define LS_RPW1_MAX_BATCH 1024      // one wave per SIMD on the 1024 SIMDs of an MI355X
 #endif
-void launch_line_search_s(const DevState& S, const ProblemDev& P, int mode, hipStream_t st, const int* list, const int* count) {
-  if (S.B <= LS_RPW1_MAX_BATCH) {        // a rollout per wave (see the kernel)
-    if (P.dyn.contact) hipLaunchKernelGGL((k_line_search_s<true, 1>), dim3(S.B), dim3(64), DYN_LDS_BYTES_S, st, S, P, mode, list, count);
-    else hipLaunchKernelGGL((k_line_search_s<false, 1>), dim3(S.B), dim3(64), DYN_LDS_BYTES_S, st, S, P, mode, list, count);
+void launch_line_search_s(const DevState& S, const ProblemDev& P, int mode, hipStream_t st, const int* list, const int* count, int max_rollouts) {
+  // a rollout per wave (see the kernel) for small batches -- and for the tail of an early-exit solve of a large one, where the
+  // host knows an upper bound of the compacted list's length (the selected rollouts are its first entries: blocks past the
+  // list's true count leave at once); the results do not depend on the choice
+  const int nsel = (list && max_rollouts >= 0 && max_rollouts < S.B) ? max_rollouts : S.B;
+  if (nsel <= LS_RPW1_MAX_BATCH) {
+    const int blocks = nsel > 0 ? nsel : 1;
+    if (P.dyn.contact) hipLaunchKernelGGL((k_line_search_s<true, 1>), dim3(blocks), dim3(64), DYN_LDS_BYTES_S, st, S, P, mode, list, count);
+    else hipLaunchKernelGGL((k_line_search_s<false, 1>), dim3(blocks), dim3(64), DYN_LDS_BYTES_S, st, S, P, mode, list, count);
     return;
   }
   if (P.dyn.contact) hipLaunchKernelGGL((k_line_search_s<true, 4>), dim3(cdiv_s((long)S.B * 16, 64)), dim3(64), DYN_LDS_BYTES_S, st, S, P, mode, list, count);

@@ -484,10 +484,13 @@ static int enqueue_solve(ilqr_hip_ctx* c, const DevState& S, const h1::ProblemDe
     { StageTimer T(c, 3, st); ilqr::launch_backward(S, ilqr::MASK_ACTIVE, st, fold_h, iter); }                                  // :601
     if (adopt_aside) HIPCHK(c, hipStreamWaitEvent(st, ev_adopt, 0));
     if (iter == 0 && lead) HIPCHK(c, hipEventRecord(lead, st));
-    { StageTimer T(c, 4, st); ilqr::launch_line_search(S, P, ilqr::MASK_ACTIVE, st, iter); }                            // :616
+    // (with the gate the host has seen how many rollouts were still active at the start of iteration iter - 1: an upper bound
+    // for this iteration's passes -- the active set only shrinks)
+    const int ls_bound = (gate && iter >= 2) ? c->h_active[iter - 1] : -1;
+    { StageTimer T(c, 4, st); ilqr::launch_line_search(S, P, ilqr::MASK_ACTIVE, st, iter, ls_bound); }                  // :616
     { StageTimer T(c, 5, st); ilqr::launch_control(S, 0, iter, c->tol, c->early_exit, st, ilqr::ls_costs_per_knot(P)); }                      // :619-620,645-655
     { StageTimer T(c, 6, st); ilqr::launch_backward(S, ilqr::MASK_RETRY, st, fold_h, iter); }                                  // :637
-    { StageTimer T(c, 7, st); ilqr::launch_line_search(S, P, ilqr::MASK_RETRY, st, iter); }                             // :638
+    { StageTimer T(c, 7, st); ilqr::launch_line_search(S, P, ilqr::MASK_RETRY, st, iter, ls_bound); }                   // :638
     { StageTimer T(c, 5, st); ilqr::launch_control(S, 1, iter, c->tol, c->early_exit, st, ilqr::ls_costs_per_knot(P)); }                      // :640-646
     if (gate) {
       HIPCHK(c, hipMemcpyAsync(&c->h_active[iter + 1], S.order_n + 2 * (iter + 1), sizeof(int), hipMemcpyDeviceToHost, st));

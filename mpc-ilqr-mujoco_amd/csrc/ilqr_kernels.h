@@ -69,7 +69,9 @@ inline WorkList work_list(const DevState& S, int mode, int iter) {
 }
 void launch_backward(const DevState& S, int mode, hipStream_t st, double fold_h = 0.0, int iter = -1);
 double linearize_fold_h(const h1::ProblemDev& P, int jac_mode);
-void launch_line_search(const DevState& S, const h1::ProblemDev& P, int mode, hipStream_t st, int iter = -1);
+// max_rollouts: upper bound of the rollouts this pass can select (the batch, or -- with the early-exit gate -- the count of
+// still-active rollouts the host saw two iterations ago): at most 1024 -> one rollout per wave in the two-lane line search
+void launch_line_search(const DevState& S, const h1::ProblemDev& P, int mode, hipStream_t st, int iter = -1, int max_rollouts = -1);
 void launch_control(const DevState& S, int phase, int iter, double tol, int early_exit, hipStream_t st, int sum_knots = 0);
 bool ls_costs_per_knot(const h1::ProblemDev& P);
 void launch_solve_begin(const DevState& S, hipStream_t st);
@@ -99,7 +101,7 @@ int dyn_kernels_set_attr();
 // dyn_split_kernels.hip: two lanes per rollout / candidate
 void launch_rollout_s(const DevState& S, const h1::ProblemDev& P, int mode, int do_roll, int count_iter, double* cost_out, hipStream_t st);
 void launch_lin_primal_s(const DevState& S, const h1::ProblemDev& P, int mode, hipStream_t st, const int* list = nullptr, const int* count = nullptr);
-void launch_line_search_s(const DevState& S, const h1::ProblemDev& P, int mode, hipStream_t st, const int* list = nullptr, const int* count = nullptr);
+void launch_line_search_s(const DevState& S, const h1::ProblemDev& P, int mode, hipStream_t st, const int* list = nullptr, const int* count = nullptr, int max_rollouts = -1);
 int dyn_split_kernels_set_attr();
 void launch_step_s(int count, const double* x, const double* u, const h1::DynParams& dyn, double* xn, hipStream_t st, int stance_l, int stance_r);
 void launch_last_step_s(const DevState& S, const h1::ProblemDev& P, hipStream_t st);

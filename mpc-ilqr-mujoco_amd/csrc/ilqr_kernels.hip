@@ -726,11 +726,11 @@ void launch_backward(const DevState& S, int mode, hipStream_t st, double fold_h,
   }
   else launch_backward_mfma(S, mode, st);
 }
-void launch_line_search(const DevState& S, const ProblemDev& P, int mode, hipStream_t st, int iter) {
+void launch_line_search(const DevState& S, const ProblemDev& P, int mode, hipStream_t st, int iter, int max_rollouts) {
   if (!use_scalar_dyn()) {
     if (g_var.ls_split || P.dyn.contact) {
       const int slot = (S.order && iter >= 0 && mode != MASK_ALL) ? 2 * iter + (mode == MASK_RETRY ? 1 : 0) : -1;      // as launch_backward
-      launch_line_search_s(S, P, mode, st, slot >= 0 ? S.order + (size_t)slot * S.B : nullptr, slot >= 0 ? S.order_n + slot : nullptr);
+      launch_line_search_s(S, P, mode, st, slot >= 0 ? S.order + (size_t)slot * S.B : nullptr, slot >= 0 ? S.order_n + slot : nullptr, slot >= 0 ? max_rollouts : -1);
       launch_cand_costs(S, P, mode, st, iter < 0);      // (inside a solve k_control adds the knot costs up)
     }   // candidates' costs: all knots in parallel
     else launch_line_search_r(S, P, mode, st);                                                  // (the one-lane kernel sums its own)
