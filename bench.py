@@ -283,16 +283,22 @@ def main():
         # Every rank reports whether its communicator came up; unless ALL did, every rank falls back together to the harness's
         # own gather below (torch.distributed) -- the driver's scaling run must not die on a communicator problem, and the JSON
         # says which collective carried the rows.
+        cdev = "cpu" if args.rehearse_single_gpu else dev
+        # (ncclCommInitRank is collective: first make sure EVERY rank can load librccl, or the others would wait in it for ever)
+        avail = torch.tensor([1 if sv.BatchedILQR.comm_available() else 0], dtype=torch.int32, device=cdev)
+        dist.all_reduce(avail, op=dist.ReduceOp.MIN)
         ok = 1
         try:
-            idt = torch.zeros(128, dtype=torch.uint8, device=("cpu" if args.rehearse_single_gpu else dev))
+            if int(avail.item()) != 1:
+                raise RuntimeError("librccl cannot be loaded on every rank")
+            idt = torch.zeros(128, dtype=torch.uint8, device=cdev)
             if rank == 0:
                 idt.copy_(torch.frombuffer(bytearray(sv.BatchedILQR.comm_unique_id()), dtype=torch.uint8))
             dist.broadcast(idt, src=0)
             s.comm_init(world, rank, bytes(idt.cpu().numpy().tobytes()))
         except Exception as e:  # noqa: BLE001 -- reported in the JSON line
             ok, rccl_error = 0, repr(e)
-        flag = torch.tensor([ok], dtype=torch.int32, device=("cpu" if args.rehearse_single_gpu else dev))
+        flag = torch.tensor([ok], dtype=torch.int32, device=cdev)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         rccl = int(flag.item()) == 1
         if not rccl:

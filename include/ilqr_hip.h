@@ -137,6 +137,10 @@ int ilqr_hip_pack_first_knot_device(ilqr_hip_ctx* ctx, double* u0_out_device, do
    recv_device (root only, else NULL): device buffer [world * B][ilqr_hip_payload_width(with_gains)]. */
 #define ILQR_COMM_ID_BYTES 128
 int ilqr_hip_payload_width(int with_gains);
+/* 1 if librccl can be opened and resolves every entry point the gather needs, else 0.  ncclCommInitRank is collective: a rank
+   that cannot load the library would leave its peers waiting inside ilqr_hip_comm_init, so a launcher lets every rank check
+   this (and agree on the outcome) BEFORE any rank calls ilqr_hip_comm_init with world > 1 (bench.py does). */
+int ilqr_hip_comm_available(void);
 int ilqr_hip_comm_get_unique_id(char* id /*[ILQR_COMM_ID_BYTES]*/);
 int ilqr_hip_comm_init(ilqr_hip_ctx* ctx, int world, int rank, const char* id /*[ILQR_COMM_ID_BYTES], may be NULL when world == 1*/);
 int ilqr_hip_comm_destroy(ilqr_hip_ctx* ctx);

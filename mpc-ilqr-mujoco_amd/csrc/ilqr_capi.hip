@@ -799,6 +799,7 @@ bool rccl_load() {
   } while (0)
 
 int ilqr_hip_payload_width(int with_gains) { return ILQR_NU + 1 + (with_gains ? ILQR_NU * ILQR_NX : 0); }
+int ilqr_hip_comm_available(void) { return rccl_load() ? 1 : 0; }
 int ilqr_hip_comm_get_unique_id(char* id) {
   if (!id) return ILQR_ERR_ARG;
   if (!rccl_load()) return ILQR_ERR_UNSUPPORTED;

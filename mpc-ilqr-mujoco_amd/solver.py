@@ -35,7 +35,7 @@ EXPORTS = [
     "ilqr_hip_stage_backward_pass", "ilqr_hip_stage_line_search", "ilqr_hip_stage_total_cost",
     "ilqr_hip_get_linearization", "ilqr_hip_set_linearization", "ilqr_hip_get_quadratics", "ilqr_hip_set_quadratics",
     "ilqr_hip_get_value_function", "ilqr_hip_step", "ilqr_hip_step_stance", "ilqr_hip_set_contact_mode", "ilqr_hip_enable_profiling", "ilqr_hip_get_stage_ms", "ilqr_hip_get_adopt_mismatches", "ilqr_hip_get_iterations_enqueued", "ilqr_hip_set_profiled_stages",
-    "ilqr_hip_payload_width", "ilqr_hip_comm_get_unique_id", "ilqr_hip_comm_init", "ilqr_hip_comm_destroy", "ilqr_hip_comm_world", "ilqr_hip_comm_rank",
+    "ilqr_hip_payload_width", "ilqr_hip_comm_available", "ilqr_hip_comm_get_unique_id", "ilqr_hip_comm_init", "ilqr_hip_comm_destroy", "ilqr_hip_comm_world", "ilqr_hip_comm_rank",
     "ilqr_hip_gather_first_knot",
     "ilqr_hip_reference_kinematics", "ilqr_hip_reference_com_velocity", "ilqr_hip_foot_clearance", "ilqr_hip_gravity_compensation", "ilqr_hip_stream",
 ]
@@ -250,6 +250,11 @@ class BatchedILQR:
         self._chk(self.L.ilqr_hip_pack_first_knot_device(self.h, C.c_void_p(u0_ptr), C.c_void_p(K0_ptr), C.c_void_p(cost_ptr)))
 
     # ---- multi-GPU: RCCL behind the C ABI (include/ilqr_hip.h "multi-GPU")
+    @staticmethod
+    def comm_available():
+        """True if librccl can be opened with every entry point the gather needs (check on EVERY rank before comm_init(world > 1))."""
+        return bool(load_library().ilqr_hip_comm_available())
+
     @staticmethod
     def comm_unique_id():
         """128-byte RCCL id (rank 0 creates it and hands it to every rank)."""
