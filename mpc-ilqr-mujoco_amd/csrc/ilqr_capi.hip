@@ -630,7 +630,13 @@ int ilqr_hip_set_trajectory(ilqr_hip_ctx* c, const double* xbar, const double* u
 int ilqr_hip_stage_rollout(ilqr_hip_ctx* c) { STAGE_PRE; ilqr::launch_rollout(c->S, c->P, ilqr::MASK_ALL, 1, 0, c->S.Jbase, c->stream); STAGE_POST; }
 int ilqr_hip_stage_linearize(ilqr_hip_ctx* c) { STAGE_PRE; ilqr::launch_linearize(c->S, c->P, ilqr::MASK_ALL, c->jac_mode, c->fd_eps, c->stream); c->lin_fold_h = ilqr::linearize_fold_h(c->P, c->jac_mode); STAGE_POST; }
 int ilqr_hip_stage_cost_quadratics(ilqr_hip_ctx* c) { STAGE_PRE; if (!c->refs_set) return ILQR_ERR_STATE; ilqr::launch_cost_quadratics(c->S, c->P, ilqr::MASK_ALL, c->stream); c->lxx_lower = false; STAGE_POST; }
-int ilqr_hip_stage_backward_pass(ilqr_hip_ctx* c) { STAGE_PRE; ilqr::launch_backward(c->S, ilqr::MASK_ALL, c->stream, c->lin_fold_h); STAGE_POST; }
+int ilqr_hip_stage_backward_pass(ilqr_hip_ctx* c) {
+  STAGE_PRE;
+  // the last solve left only the tiles I >= J of lxx_t behind and this call may run a kernel family that reads the whole matrix
+  if (c->lxx_lower && ilqr::variant_backward() != 2) { ilqr::launch_mirror_lxx(c->S, c->stream); c->lxx_lower = false; }
+  ilqr::launch_backward(c->S, ilqr::MASK_ALL, c->stream, c->lin_fold_h);
+  STAGE_POST;
+}
 int ilqr_hip_stage_total_cost(ilqr_hip_ctx* c, double* cost) {
   STAGE_PRE; if (!cost || !c->refs_set) return ILQR_ERR_ARG;
   ilqr::launch_rollout(c->S, c->P, ilqr::MASK_ALL, 0, 0, c->d_cost_tmp, c->stream);

@@ -81,6 +81,7 @@ void launch_last_step(const DevState& S, const h1::ProblemDev& P, hipStream_t st
 void launch_compute_control(const DevState& S, const double* x_meas, double* u_out, hipStream_t st);
 void launch_pack_first_knot(const DevState& S, double* u0, double* K0, hipStream_t st);
 void launch_pack_payload(const DevState& S, int with_gains, double* out, hipStream_t st);
+void launch_mirror_lxx(const DevState& S, hipStream_t st);   // fill the strictly upper tiles of lxx_t, t < N, from the lower ones
 int backward_needs_lds_attr();
 // kernel variants (ILQR_DYN / ILQR_ROLLOUT / ILQR_LS / ILQR_BACKWARD), re-read from the environment by refresh_variants()
 void refresh_variants();

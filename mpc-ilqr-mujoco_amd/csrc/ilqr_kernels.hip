@@ -636,6 +636,20 @@ __global__ void k_pack_payload(DevState S, int with_gains, double* out) {
   if (with_gains) for (int e = lane; e < m * n; e += blockDim.x) row[m + 1 + e] = S.K[(size_t)b * N * m * n + e];
 }
 
+// Inside a solve the cost quadratics leave the strictly upper 16 x 16 tiles of lxx_t (t < N) unwritten (quad_kernels.hip: the
+// one-wave Riccati kernel does not read them).  Before a consumer that reads the whole matrix from the device (the stage API's
+// backward pass on another kernel family) they are mirrored back: entry (i, j), tile(i) < tile(j), <- entry (j, i).
+__global__ void __launch_bounds__(256) k_mirror_lxx(DevState S) {
+  const size_t knot = blockIdx.x;                  // over B * (N + 1)
+  if ((int)(knot % (S.N + 1)) == S.N) return;      // the terminal knot is always written whole
+  double* H = S.lxx + knot * H1_NX * H1_NX;
+  for (int e = threadIdx.x; e < H1_NX * H1_NX; e += 256) {
+    const int i = e / H1_NX, j = e % H1_NX;
+    if ((i >> 4) < (j >> 4)) H[e] = H[j * H1_NX + i];
+  }
+}
+void launch_mirror_lxx(const DevState& S, hipStream_t st) { hipLaunchKernelGGL(k_mirror_lxx, dim3((unsigned)((size_t)S.B * (S.N + 1))), dim3(256), 0, st, S); }
+
 // ------------------------------------------------------------------ launchers
 // defaults measured on MI355X at B = 4096 (time per full launch): rollout one lane 1.18 ms, two lanes 0.78 ms (0.4 ms
 // without the in-kernel cost); line search one lane per candidate 2.35 ms, two lanes per candidate with side-owned

@@ -183,6 +183,35 @@ def test_folded_backward_pass_equals_generic_kernel_and_numpy(contact):
     s.close()
 
 
+def test_stage_backward_pass_on_another_kernel_family_after_a_solve_sees_the_whole_lxx():
+    """Inside a solve the cost quadratics store only the 16 x 16 tiles of lxx_t (t < N) on and below the diagonal (what the
+    one-wave Riccati kernel reads).  The stage API afterwards -- the getter, and the backward pass on a kernel family that reads the
+    full matrix -- must see the symmetric whole: tiles mirrored on the host (getter) / on the device (stage call)."""
+    B = 3
+    prob, x0, ui = standing(B, seed=29)
+    s = _solver(B); s.set_problem(prob); s.set_max_iterations(2); s.set_options(early_exit=False)
+    s.initialize(x0, ui); s.solve()
+    lx, lu, lxx, luu = s.quadratics()
+    # strictly upper tiles of the knots t < N = the mirrored lower ones (bit for bit), and not zero; inside a diagonal tile the two
+    # halves are computed independently (symmetric to rounding, as the full matrix of the terminal knot is)
+    for I in range(4):
+        for J in range(I + 1, 4):
+            up = lxx[:, :-1, 16 * I:16 * I + 16, 16 * J:16 * J + 16]; lo = lxx[:, :-1, 16 * J:16 * J + 16, 16 * I:16 * I + 16]
+            assert np.array_equal(up, np.swapaxes(lo, -1, -2))
+    assert np.abs(lxx[:, :-1, :16, 16:]).max() > 0 and np.abs(lxx - np.swapaxes(lxx, -1, -2)).max() < 1e-9 * np.abs(lxx).max()
+    s.set_regularization(1e-6)
+    with env(ILQR_BACKWARD="wave"):
+        s.stage_backward_pass(); Kw = s.gains_K()
+    with env(ILQR_BACKWARD="valu"):
+        s.stage_backward_pass(); Kv = s.gains_K()
+    assert rel(Kv, Kw) < 1e-9
+    A, Bm = s.linearization()
+    for b in range(B):
+        ref = _riccati_numpy(A[b], Bm[b], lx[b], lu[b], lxx[b], luu[b], 1e-6)
+        assert rel(Kv[b], ref[0]) < 1e-8
+    s.close()
+
+
 def test_early_exit_gate_stops_launching_and_changes_nothing():
     """With the convergence exit on, the host follows the device-side count of active rollouts and stops enqueuing iterations
     once the batch is done (ilqr_capi.hip enqueue_solve); the compacted work lists (DevState::order) feed the Riccati and
