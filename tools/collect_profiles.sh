@@ -4,7 +4,7 @@
 # 1. per-kernel time of the bench command; 2. HBM traffic (FETCH_SIZE / WRITE_SIZE, separate passes, as the microarch guide
 # prescribes) of the same command -> traffic JSON stamped with the run signature; 3. MFMA counters of the Riccati kernel.
 set -e
-tag=${1:-r02}
+tag=${1:-r03}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 out=gpurun_out/profiles_$tag
 rm -rf "$out"; mkdir -p "$out"
