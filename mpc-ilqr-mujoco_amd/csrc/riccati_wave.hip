@@ -106,6 +106,18 @@ __device__ __forceinline__ void fold_rows(const v4d& t0, const v4d& t1, v4d& t2,
   t2[3] = __builtin_fma(h, r11, t2[3]);
   t3[0] = (lk == 0) ? __builtin_fma(h, r12, t3[0]) : t3[0];     // row 48 only
 }
+// The same fold on the COLUMNS of one register row of M (four tiles c0..c3 of the same rows): columns 33..48 += h * columns 8..23.
+// Column 33 + m is (tile 2, lr = 1 + m) for m < 15 and (tile 3, lr = 0) for m = 15; its source column 8 + m is (tile 0, lr = 8 + m)
+// for m < 8 and (tile 1, lr = m - 8) beyond: in every case the lane seven to the right in the 16-lane row (mod 16), so the
+// sending lane picks the tile (lr >= 8: tile 0, else tile 1) and one rotation serves all sixteen columns.
+// Round 3: with M folded on BOTH sides (M~ = F M F^T) every product that has M on the left delivers its result with the rows
+// 33..48 already folded -- W = M~ A~, G0 = M~ B0 -- so the five per-product folds of G0 and W (accumulator tiles: a read and a
+// write of the AGPRs for every touched register) are replaced by nine register rows of M (the k-steps that are not skipped).
+__device__ __forceinline__ void fold_cols(const v4d& c0, const v4d& c1, v4d& c2, v4d& c3, int r, int lr, int caddr, double h) {
+  const double y = wrot16(lr >= 8 ? c0[r] : c1[r], caddr);
+  c2[r] = (lr >= 1) ? __builtin_fma(h, y, c2[r]) : c2[r];      // column 32 stays
+  c3[r] = (lr == 0) ? __builtin_fma(h, y, c3[r]) : c3[r];      // column 48 only
+}
 #define WFOLD_SKIP(s) (FOLD && (s) >= 2 && (s) <= 5)
 
 // Augmented cost Hessian of one knot in C layout: lxx inside, lx in row 51 and column 51, zeros beyond.  Every load is
@@ -381,17 +393,15 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
     // ---- folded: keep the identity part M[:, 8..23] of W for the rows about to change (row tiles 2, 3; rows 52.. of W are
     // never used), then rows 33..48 of M += h * rows 8..23 for every product that has M on the left (P2, P1)
     const int raddr = ((lane - 16) & 63) << 2;
-    double wid[2][5];
+    const int caddr = ((lane & 48) | ((lane + 7) & 15)) << 2;
     if (FOLD) {
-#pragma unroll
-      for (int J = 0; J < 2; ++J) {
-        const bool in = J == 0 ? lr >= 8 : lr < 8;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) wid[J][r] = in ? M[2][J][r] : 0.0;
-        wid[J][4] = in ? M[3][J][0] : 0.0;
-      }
+      // rows 33..48 of M += h * rows 8..23 (contraction over the rows of A~ / B_t), then the same on the columns of the register
+      // rows that serve as k-steps (results arrive with their rows 33..48 folded): M~ = F M F^T
 #pragma unroll
       for (int I = 0; I < 4; ++I) fold_rows(M[0][I], M[1][I], M[2][I], M[3][I], lk, raddr, fh);
+#pragma unroll
+      for (int s = 0; s < WKS; ++s)
+        if (!WFOLD_SKIP(s)) fold_cols(M[s >> 2][0], M[s >> 2][1], M[s >> 2][2], M[s >> 2][3], s & 3, lr, caddr, fh);
     }
     // ---- P2: G0 = M B0 (row 51: B0^T Vx)
     v4d g0[4];
@@ -407,8 +417,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
       for (int q = 0; q < 2; ++q)
 #pragma unroll
         for (int r = 0; r < 4; ++r) L.T[q][(4 * r + lk) * WLDT + lr] = g0[q][r];
-      // rows 33..48 of G0 += h * rows 8..23 for the products that contract over its rows (P4, P5)
-      fold_rows(g0[0], g0[1], g0[2], g0[3], lk, raddr, fh);
+      // (rows 33..48 of G0 arrive folded -- M~ on the left -- for the products that contract over its rows: P4, P5)
       __syncthreads();
     }
     WSTAMP(1)
@@ -444,13 +453,13 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
 #pragma unroll
       for (int J = 0; J < 4; ++J) W[I][J] = (v4d){0.0, 0.0, 0.0, 0.0};
     if (FOLD) {
-      // identity part of P1: W[:, 8..23] starts from M[:, 8..23] (row tiles 0, 1 of M are untouched by the fold)
+      // identity part of P1: W[:, 8..23] starts from the row-folded M[:, 8..23] (columns 8..23 are not touched by the column fold)
 #pragma unroll
       for (int J = 0; J < 2; ++J) {
         const bool in = J == 0 ? lr >= 8 : lr < 8;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { W[0][J][r] = in ? M[0][J][r] : 0.0; W[1][J][r] = in ? M[1][J][r] : 0.0; W[2][J][r] = wid[J][r]; }
-        W[3][J][0] = wid[J][4];
+        for (int r = 0; r < 4; ++r) { W[0][J][r] = in ? M[0][J][r] : 0.0; W[1][J][r] = in ? M[1][J][r] : 0.0; W[2][J][r] = in ? M[2][J][r] : 0.0; }
+        W[3][J][0] = in ? M[3][J][0] : 0.0;
       }
     }
 #pragma unroll
@@ -460,7 +469,6 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
 #pragma unroll
       for (int I = 0; I < 4; ++I) W[I][3] = wmfma(M[s >> 2][I][s & 3], a3, W[I][3]);
     }
-    if (FOLD) fold_rows(W[0][3], W[1][3], W[2][3], W[3][3], lk, raddr, fh);
     // ---- P3, tile (3, 3): rows / columns 52..54 = Quu[16..18, 16..18], column 51 = Qu[16..18] - lu (two accumulators)
     {
       v4d q1 = (v4d){0.0, 0.0, 0.0, 0.0};
@@ -507,11 +515,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
         for (int J = 0; J < 3; ++J) W[I][J] = wmfma(M[s >> 2][I][s & 3], aj[J], W[I][J]);
     }
     if (FOLD) {
-      // identity part of P3: rows 8..23 of Q += rows 8..23 of W (as computed), then rows 33..48 of W += h * rows 8..23
+      // identity part of P3: rows 8..23 of Q += rows 8..23 of W (rows 33..48 of W arrived folded)
 #pragma unroll
       for (int r = 0; r < 2; ++r) { Q[0][0][2 + r] += W[0][0][2 + r]; Q[1][0][r] += W[1][0][r]; Q[1][1][r] += W[1][1][r]; }
-#pragma unroll
-      for (int J = 0; J < 3; ++J) fold_rows(W[0][J], W[1][J], W[2][J], W[3][J], lk, raddr, fh);
     }
     // The factorisation of Quu (below) is a latency chain of 18 short steps on the same wave (pivot broadcast, rsqrt, scale,
     // column through LDS); Quu has been in LDS since before P1, so the sweep is woven into the MFMA of the rest of P3: the
