@@ -90,7 +90,8 @@ def cpu_baseline(pkg, prob, x0, ui, iters, budget_s, contact=False):
     """Oracle (CPU restatement, kind 'port') timed on the host cores on a bounded sample of the same batch."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as ol
-    o = ol.Oracle(prob["N"], prob["dt"])
+    _, flags = ol.lib_native()          # the timed copy: -O3 -march=native, built on this host (oracle/Makefile); the checker build stays portable
+    o = ol.Oracle(prob["N"], prob["dt"], native=True)
     o.set_problem(prob)
     if contact:      # same plant and the same kind of Jacobians as the GPU's contact mode: exact derivatives of the constrained step
         o.set_contact_mode(2)
@@ -108,7 +109,7 @@ def cpu_baseline(pkg, prob, x0, ui, iters, budget_s, contact=False):
     tot1, *_ = o.batch_solve(x0[:n1], ui[:n1], nthreads=cores)
     dt1 = time.perf_counter() - t0
     return dict(value=tot1 / dt1, unit="iLQR iterations/s", cores=int(cores), kind="port",
-                sample="oracle (CPU restatement, " + ("rigid-stance plant, exact (forward-mode AD) Jacobians of the constrained step as on the GPU" if contact else "forward-difference Jacobians as in the reference; its forward-mode-AD variant is ~2x slower") + ") on the first %d rollouts of the same batch, %d fixed iterations each, OpenMP over rollouts, %.1f s" % (n1, iters, dt1))
+                sample="oracle (CPU restatement, " + ("rigid-stance plant, exact (forward-mode AD) Jacobians of the constrained step as on the GPU" if contact else "forward-difference Jacobians as in the reference; its forward-mode-AD variant is ~2x slower") + ") on the first %d rollouts of the same batch, %d fixed iterations each, OpenMP over rollouts, %.1f s; compiler flags: %s" % (n1, iters, dt1, flags))
 
 
 def csrc_hash():
@@ -221,19 +222,56 @@ def stage_bench(args, s, sv, x0_d, ui_d, B, N, world, rank, dev, prob):
         dist.destroy_process_group()
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` (N > 1) started WITHOUT a launcher: this process never touches a GPU; it starts
+    `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a child, relays rank 0's JSON line and exits with the
+    child's code.  One rank per GPU needs N visible devices (unless --rehearse-single-gpu); if the ranks cannot be started the
+    exit code is non-zero -- a plain `--gpus 8` must never time ONE rank and print n_gpus: 1 (mpc.cpp:97-113 is the consumer
+    the per-step gather serves)."""
+    import socket
+    import subprocess
+    import torch                       # device_count() does not initialise the GPU on this image (task statement)
+    have = torch.cuda.device_count()
+    if not args.rehearse_single_gpu and have < args.gpus:
+        sys.stderr.write("bench.py: --gpus %d needs %d visible GPUs, this node shows %d; refusing to time fewer ranks than asked for "
+                         "(use --rehearse-single-gpu to rehearse the N > 1 path on one device)\n" % (args.gpus, args.gpus, have))
+        return 2
+    sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["ILQR_BENCH_SELF_LAUNCHED"] = "1"
+    sys.stderr.write("bench.py: --gpus %d without a launcher: starting %s\n" % (args.gpus, " ".join(cmd)))
+    child = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [l for l in child.stdout.splitlines() if l.startswith("{")]
+    for l in child.stdout.splitlines():
+        if not l.startswith("{"):
+            sys.stderr.write(l + "\n")
+    if child.returncode == 0 and len(lines) == 1 and json.loads(lines[0]).get("n_gpus") == args.gpus:
+        print(lines[0])
+        return 0
+    sys.stderr.write("bench.py: the %d-rank run did not produce its line (child exit code %d, %d JSON lines)\n" % (args.gpus, child.returncode, len(lines)))
+    return child.returncode if child.returncode != 0 else 3
+
+
 def main():
     args = parse()
     if args.print_signature:
         slices = max(1, int(os.environ.get("ILQR_SLICES", "1")))
         print(json.dumps(run_signature(args, slices), sort_keys=True))
         return
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
     import torch
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if args.gpus != world:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: refusing to time a different number of ranks than asked for" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback in the product path)")
     if args.rehearse_single_gpu:
@@ -295,7 +333,26 @@ def main():
             if rank == 0:
                 idt.copy_(torch.frombuffer(bytearray(sv.BatchedILQR.comm_unique_id()), dtype=torch.uint8))
             dist.broadcast(idt, src=0)
-            s.comm_init(world, rank, bytes(idt.cpu().numpy().tobytes()))
+            # ncclCommInitRank is collective: if it fails on ONE rank, its peers stay inside it.  It therefore runs on a helper
+            # thread with a deadline; a rank that is still inside after the deadline cannot join the all-ranks fallback safely
+            # (the handle is mid-call), so it ends the whole run loudly -- the launcher then takes the other ranks down.
+            import threading
+            box = {}
+
+            def _init():
+                try:
+                    s.comm_init(world, rank, bytes(idt.cpu().numpy().tobytes()))
+                except Exception as ee:  # noqa: BLE001
+                    box["err"] = ee
+            th = threading.Thread(target=_init, daemon=True)
+            th.start()
+            th.join(float(os.environ.get("ILQR_COMM_INIT_TIMEOUT_S", "180")))
+            if th.is_alive():
+                sys.stderr.write("bench.py rank %d: ilqr_hip_comm_init (ncclCommInitRank) did not return within its deadline; aborting the run\n" % rank)
+                sys.stderr.flush()
+                os._exit(4)
+            if "err" in box:
+                raise box["err"]
         except Exception as e:  # noqa: BLE001 -- reported in the JSON line
             ok, rccl_error = 0, repr(e)
         flag = torch.tensor([ok], dtype=torch.int32, device=cdev)
@@ -333,6 +390,9 @@ def main():
         g = recv
         if world > 1 and not rccl:      # one-GPU rehearsal (host-staged over gloo), or the fallback when RCCL did not come up
             g = sh.gather_first_knot(recv.cpu() if args.rehearse_single_gpu else recv, dst=0)
+            # the harness's gather reads `recv` on torch's stream; the next step's ilqr_hip_gather_first_knot rewrites it on the
+            # handle's stream -- order the two
+            torch.cuda.synchronize()
         if timed:
             record_stages(timed_ms, timed_n)
         return g
@@ -523,7 +583,13 @@ def main():
                                       "RCCL grouped send/recv behind the C ABI (ilqr_hip_gather_first_knot)" if rccl else
                                       "ilqr_hip_gather_first_knot per rank + gloo, host-staged (one-GPU rehearsal)" if args.rehearse_single_gpu else
                                       "FALLBACK: ilqr_hip_gather_first_knot per rank + torch.distributed.gather (RCCL communicator did not come up)"),
-                       "collective_error": rccl_error},
+                       "collective_error": rccl_error,
+                       "barrier": ("none (one rank)" if world == 1 else
+                                   "torch.distributed process group, backend %s%s: barrier before and after the timed region and the max-over-ranks all_reduce of the elapsed time; "
+                                   "the product's own RCCL communicator (ilqr_hip_comm_init) carries only the per-step gather" %
+                                   (dist.get_backend(), " (= RCCL on ROCm)" if dist.get_backend() == "nccl" else "")),
+                       "launcher": "self-launched by `python bench.py --gpus N` (child torch.distributed.run)" if os.environ.get("ILQR_BENCH_SELF_LAUNCHED") else
+                                   ("torch.distributed.run (WORLD_SIZE from the environment)" if "WORLD_SIZE" in os.environ else "single process")},
             "roofline": roof,
             "kernels": {n: {k: (round(v, 6) if isinstance(v, float) else v) for k, v in t.items() if k in
                             ("total_ms_per_step", "exclusive_ms_per_step", "avg_launch_ms", "frac_compute", "frac_hbm")} for n, t in table.items()},

@@ -24,18 +24,40 @@ def build_oracle():
 
 
 _lib = None
+_lib_native = None
+NATIVE_FLAGS = "-O3 -march=native"
+PORTABLE_FLAGS = "-O3"
+
+
+def _declare(L):
+    L.orc_create.restype = C.c_void_p
+    L.orc_create.argtypes = [C.c_int, C.c_double]
+    L.orc_total_cost.restype = C.c_double
+    L.orc_get_lambda.restype = C.c_double
+    L.orc_batch_solve.restype = C.c_long
+    return L
 
 
 def lib():
     global _lib
     if _lib is None:
-        _lib = C.CDLL(build_oracle())
-        _lib.orc_create.restype = C.c_void_p
-        _lib.orc_create.argtypes = [C.c_int, C.c_double]
-        _lib.orc_total_cost.restype = C.c_double
-        _lib.orc_get_lambda.restype = C.c_double
-        _lib.orc_batch_solve.restype = C.c_long
+        _lib = _declare(C.CDLL(build_oracle()))
     return _lib
+
+
+def lib_native():
+    """The TIMED copy of the restatement (bench.py's cpu_baseline leg): the same sources built `-O3 -march=native` ON THIS HOST
+    (oracle/Makefile target build/liboracle_native.so; never shipped between machines).  Returns (library, flags string); falls
+    back to the portable checker build -- and says so in the flags string -- when the host build is not possible."""
+    global _lib_native
+    if _lib_native is None:
+        so = os.path.join(ROOT, "oracle", "build", "liboracle_native.so")
+        try:
+            subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "build/liboracle_native.so"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            _lib_native = (_declare(C.CDLL(so)), "g++ " + NATIVE_FLAGS + " -fopenmp (built on this host)")
+        except Exception as e:  # noqa: BLE001
+            _lib_native = (lib(), "g++ " + PORTABLE_FLAGS + " -fopenmp (portable checker build; the -march=native build failed: %r)" % (e,))
+    return _lib_native
 
 
 def c64(a):
@@ -45,9 +67,9 @@ def c64(a):
 class Oracle:
     """One-rollout CPU restatement of iLQR (mirrors iLQR's API, ilqr.hpp:19-45)."""
 
-    def __init__(self, N=25, dt=0.02):
+    def __init__(self, N=25, dt=0.02, native=False):
         self.N = N
-        self.L = lib()
+        self.L = lib_native()[0] if native else lib()
         self.h = C.c_void_p(self.L.orc_create(N, C.c_double(dt)))
 
     def __del__(self):

@@ -125,3 +125,29 @@ def test_bench_names_a_baseline_config_only_when_it_runs_one_and_stamps_the_kern
     assert bench.workload_label(types.SimpleNamespace(contact=True), 4096, 25, 10, 1, (0, 0, -9.81)).startswith("custom (contact row f4")
     sig = bench.run_signature(a, 1)
     assert len(sig["csrc_sha"]) == 16 and sig["csrc_sha"] == bench.csrc_hash() and sig["batch"] == 4096
+
+
+def test_bench_gpus_n_without_a_launcher_never_times_one_rank_silently():
+    """`python bench.py --gpus 2` started plainly (the way the driver starts `--gpus 1`) must either run two ranks -- the parent
+    starts torch.distributed.run as a child and relays rank 0's line -- or exit non-zero; it must never print `n_gpus: 1` with
+    exit code 0 (a SCALE run that did not wrap the command would have measured one GPU).  Without a GPU both
+    forms fail loudly: too few devices for one rank per GPU, and -- with --rehearse-single-gpu, which does start the child
+    ranks -- the ranks themselves refuse to run without a device."""
+    import subprocess, sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    import torch
+    if torch.cuda.device_count() < 2:
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--batch", "8", "--steps", "1", "--warmup", "0"],
+                           capture_output=True, text=True, env=env, timeout=600)
+        assert r.returncode != 0 and "needs 2 visible GPUs" in r.stderr
+        assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+    if not torch.cuda.is_available():
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--batch", "8", "--steps", "1", "--warmup", "0", "--rehearse-single-gpu",
+                            "--no-cpu-baseline"], capture_output=True, text=True, env=env, timeout=600)
+        assert r.returncode != 0 and "starting" in r.stderr and "torch.distributed.run" in r.stderr
+        assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+    # a launcher environment that disagrees with --gpus is refused as well (WORLD_SIZE = 1 with --gpus 2)
+    env1 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--batch", "8", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, env=env1, timeout=600)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr and not [l for l in r.stdout.splitlines() if l.startswith("{")]
