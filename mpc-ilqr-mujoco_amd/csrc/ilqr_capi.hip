@@ -136,6 +136,7 @@ int ilqr_hip_create(ilqr_hip_ctx** out, int device, int batch, int horizon, doub
   A(dalloc(c, &S.A, B * N * n * n + 32)); A(dalloc(c, &S.Bm, B * N * n * m + 32));   // slack: riccati_wave.hip stages 16-byte pairs that may straddle the end of the last row
   A(dalloc(c, &S.lx, B * (N + 1) * n)); A(dalloc(c, &S.lu, B * N * m)); A(dalloc(c, &S.lxx, B * (N + 1) * n * n)); A(dalloc(c, &S.luu, B * N * m));
   A(dalloc(c, &S.lin_dump, B * N * ilqr::lin_dump_doubles()));
+  A(dalloc(c, &S.quad_rec, ilqr::quad_rec_doubles(B * (N + 1)))); S.quad_knot0 = 0;
   A(dalloc(c, &S.K, B * N * m * n + 32)); /* slack: the line search stages K_t in 16-byte pairs, the last one ends one double past the knot */ A(dalloc(c, &S.kff, B * N * m)); A(dalloc(c, &S.Vx, B * n)); A(dalloc(c, &S.Vxx, B * n * n));
   A(dalloc(c, &S.J, B)); A(dalloc(c, &S.Jbase, B)); A(dalloc(c, &S.ls_cost, B)); A(dalloc(c, &S.lambda, B));
   A(dalloc(c, &S.active, B)); A(dalloc(c, &S.need_retry, B)); A(dalloc(c, &S.iters, B)); A(dalloc(c, &S.improved, B)); A(dalloc(c, &S.alpha_idx, B));
@@ -178,7 +179,7 @@ int ilqr_hip_destroy(ilqr_hip_ctx* c) {
   if (!c) return ILQR_ERR_ARG;
   enter(c);
   DevState& S = c->S;
-  void* ptrs[] = {S.cand_knot, S.lin_dump, S.x0, S.xbar, S.ubar, S.xcand, S.ucand, S.cand_cost, S.A, S.Bm, S.lx, S.lu, S.lxx, S.luu, S.K, S.kff, S.Vx, S.Vxx, S.J, S.Jbase, S.ls_cost,
+  void* ptrs[] = {S.cand_knot, S.lin_dump, S.quad_rec, S.x0, S.xbar, S.ubar, S.xcand, S.ucand, S.cand_cost, S.A, S.Bm, S.lx, S.lu, S.lxx, S.luu, S.K, S.kff, S.Vx, S.Vxx, S.J, S.Jbase, S.ls_cost,
                   S.lambda, S.active, S.need_retry, S.iters, S.improved, S.alpha_idx, S.trace_cost, S.trace_alpha, S.trace_lambda, S.order, S.order_n, c->d_tmpx, c->d_tmpu,
                   c->d_prevx, c->d_prevu, c->d_shadowx, c->d_u0, c->d_K0, c->d_cost_tmp, c->d_stepx, c->d_stepu, c->d_stepn, c->d_mismatch, c->d_payload, c->d_xref, c->d_uref, c->d_comref, c->d_eeref, c->d_comvelref, c->d_stance};
   for (void* p : ptrs) if (p) hipFree(p);
@@ -379,6 +380,7 @@ static DevState slice_state(const DevState& S, size_t b0, int Bs) {
   T.A += b0 * N * n * n; T.Bm += b0 * N * n * m;
   T.lx += b0 * (N + 1) * n; T.lu += b0 * N * m; T.lxx += b0 * (N + 1) * n * n; T.luu += b0 * N * m;
   T.K += b0 * N * m * n; T.kff += b0 * N * m; T.lin_dump += b0 * N * ilqr::lin_dump_doubles();
+  T.quad_knot0 = S.quad_knot0 + (long)(b0 * (N + 1));      // (the record buffer is indexed by knot, 16 to a line: not a pointer offset)
   T.Vx += b0 * n; T.Vxx += b0 * n * n;
   T.J += b0; T.Jbase += b0; T.ls_cost += b0; T.lambda += b0;
   T.active += b0; T.need_retry += b0; T.iters += b0; T.improved += b0; T.alpha_idx += b0;

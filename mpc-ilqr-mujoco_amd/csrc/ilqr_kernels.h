@@ -32,6 +32,8 @@ struct DevState {
   double* K;           // [B][N][19][51]
   double* kff;         // [B][N][19]
   double* lin_dump;    // [B][N][sizeof(KnotDump)/8] primal per-body quantities of every knot
+  double* quad_rec;    // per-knot records of the cost quadratics (k_quad_kin -> k_cost_quadratics; quad_rec_doubles(B (N + 1)), 16 knots interleaved per line)
+  long quad_knot0;     // index of this view's first knot in quad_rec (batch slices share the handle's buffer)
   double* Vx;          // [B][51]           value gradient at knot 0
   double* Vxx;         // [B][51][51]
   double* J;           // [B] current cost
@@ -91,6 +93,7 @@ int variant_backward();
 int variant_scalar_dyn();
 size_t backward_lds_bytes();
 size_t lin_dump_doubles();
+size_t quad_rec_doubles(size_t knots);
 void launch_rollout_r(const DevState& S, const h1::ProblemDev& P, int mode, int do_roll, int count_iter, double* cost_out, hipStream_t st);
 void launch_step_r(int count, const double* x, const double* u, const h1::DynParams& dyn, double* xn, hipStream_t st);
 void launch_last_step_r(const DevState& S, const h1::ProblemDev& P, hipStream_t st);

@@ -1,19 +1,26 @@
 // K3: cost quadratics -- iLQR::computeCostQuadratics (reference src/ilqr/ilqr.cpp:133-244) with the exact task-term
 // Hessians of add{CoM,CoMVel,EEPos,EEVel,Upright,Balance}CostDerivatives (ilqr.cpp:662-800; closed forms of
-// derivatives.cpp:525-707, see h1_cost_dev.h).  One two-wave workgroup per (knot, rollout); every phase is lane-parallel:
-//   1  pelvis-frame kinematics of the URDF tree, lane = body, one barrier per tree level (5 levels)
-//   2  point sets (whole-body CoM, left / right ankle origin), lane = (set, body): subtree aggregates are direct
-//      sums over the ancestor bitmask instead of an inward sweep, so there is no sequential dependency
-//   3  Jacobian columns of c and cdot, lane = coordinate
-//   4  weighted functionals (one per active cost term) and their per-joint vectors til x z_j, P'_j, lane = (term, joint)
-//   5  gradient, lane = coordinate
-//   6  Hessian.  The first-order (Gauss-Newton) part -- sum_i scale_i J_i^T J_i over the <= 4 gradient-carrying functionals and
-//      the four dyads of the balance term -- is one 51 x 16 x 51 product on v_mfma_f64_16x16x4_f64 (4 k-steps x 16 tiles,
-//      operands straight from the Jacobian rows in LDS); the second-order part exists in 8 of the 21 pairs of coordinate
-//      classes p | quat | theta | v_b | omega_b | thetadot only: those entries are evaluated block by block (every lane of
-//      an iteration runs the same formula) into an LDS patch that the owner lanes of the accumulator tiles add before they
-//      store lxx row by row (128-byte runs; the version before this one evaluated 12 + 4 products per entry on the vector
-//      ALU behind 32 LDS reads and stored every entry twice at scattered addresses: 60 k of the kernel's 107 k cycles).
+// derivatives.cpp:525-707, see h1_cost_dev.h).  Two kernels since round 4:
+//
+//   k_quad_kin         ONE LANE PER KNOT.  Everything of a knot that is a chain of small dependent steps -- the pelvis-frame
+//                      kinematics of the URDF tree, the three point sets (whole-body CoM, left / right ankle origin) with their
+//                      subtree aggregates, the weighted functionals of the active cost terms -- runs serially in one lane with
+//                      the tree unrolled on compile-time body indices: ~50 wave instructions per knot instead of the ~2100 the
+//                      lane = body / lane = (set, body) / lane-0 phases of the one-kernel version issued (five tree levels with a
+//                      barrier each, 60 lanes looping over ancestor bitmasks, one lane pushing contexts while 127 wait: 37 k of
+//                      that kernel's 76 k cycles per knot).  It leaves a 468-double record per knot in HBM, 16 knots interleaved
+//                      per 128-byte line (field-major inside a group of 16 knots): every store instruction of a wave writes whole
+//                      lines.
+//   k_cost_quadratics  ONE TWO-WAVE WORKGROUP PER KNOT, the wide part: record -> LDS, then
+//                        1  wave 0, lane = coordinate: Jacobian columns of c and cdot of the three point sets, balance rows,
+//                           gradient lx (all per-column: no exchange);  wave 1, lane = (functional, joint): til x z_j, P'_j; lu, luu
+//                        2  Hessian.  The first-order (Gauss-Newton) part -- sum_i scale_i J_i^T J_i over the four gradient-carrying
+//                           functionals and the four dyads of the balance term -- is one 51 x 16 x 51 product on
+//                           v_mfma_f64_16x16x4_f64 (operands straight from the Jacobian rows in LDS); the second-order part exists
+//                           in 8 of the 21 pairs of coordinate classes p | quat | theta | v_b | omega_b | thetadot only: those
+//                           entries are evaluated block by block into an LDS patch that the owner lanes of the accumulator tiles
+//                           add before they store lxx row by row (128-byte runs).
+//                      Workgroups are numbered so that the 16 knots sharing the lines of a record group run on one XCD (one L2).
 #include <hip/hip_runtime.h>
 
 #include "h1_cost_dev.h"
@@ -26,9 +33,9 @@ using namespace h1;
 namespace ilqr {
 
 #ifndef QUAD_WAVES
-#define QUAD_WAVES 4   // waves per SIMD requested from the register allocator (8 two-wave workgroups per CU)
+#define QUAD_WAVES 5   // waves per SIMD requested from the register allocator (ten two-wave workgroups per CU)
 #endif
-// -DQUAD_STAMP: diagnostic build only -- per-phase cycle counts of workgroup (0, 0) land in S.J[0..7]
+// -DQUAD_STAMP: diagnostic build only -- per-phase cycle counts of the workgroup of knot (0, 0) land in S.J[0..7]
 #ifdef QUAD_STAMP
 #define QSTAMP(k) { const long long tn_ = clock64(); if (t == 0 && b == 0 && lane == 0) S.J[k] = (double)(tn_ - qlast); qlast = tn_; }
 #else
@@ -43,7 +50,6 @@ constexpr QAncTable make_anc_table() {
   for (int i = 1; i < H1_NB; ++i) { unsigned v = 0; for (int j = 1; j < H1_NB; ++j) v |= (h1c::C_ANC[i - 1][j - 1] ? 1u : 0u) << j; T.m[i] = v; }
   return T;
 }
-__constant__ static const QAncTable QANC = make_anc_table();
 
 // (theta, theta) upper-triangle and (theta, thetadot) full-block entries with a second-order part: the pairs of joints one of
 // which is an ancestor of (or is) the other -- 59 + 99 of the 190 + 361 entries.  Packed: ja | jb << 5 | isd << 10.
@@ -64,416 +70,513 @@ constexpr QRelTable make_rel_table() {
 __constant__ static const QRelTable QREL = make_rel_table();
 static_assert(make_rel_table().n == 158, "related joint pairs of the H1 tree");
 
-#define QMAXC 6   // at most: CoM pos, CoM vel, one functional per foot (swing: position / stance: velocity), 2 balance
-#define QMAXM 4   // after the merge of contexts on the same (point set, type): (CoM, pos), (CoM, vel), one per foot
-struct QuadCtx { int set, is_vel; double scale; double vec[3], til[3], Dv[4][3]; };
-// 16,2xx B of LDS (round 3; 20,4xx before): ten two-wave workgroups per CU instead of eight -- the kernel is a chain of
-// dependent lane-parallel phases (62 % of its wave cycles parked on a wait), so what it gains is workgroups in flight.  Three
-// cuts: (i) a foot's point set carries ONE gradient-carrying functional per knot -- its position in swing, its velocity in
-// stance -- so the feet keep one Jacobian (Jf) instead of d c and d cdot both; (ii) at most four contexts survive the merge;
-// (iii) the second-order patch is packed (entry (a, b), a <= b: row a holds its columns a..50 only).
-// Phase-1/2 temporaries share storage with the per-joint vectors of phase 4.
+// ---- the knot record (doubles; written by k_quad_kin, read by k_cost_quadratics) ---------------------------------------------
+// Four functionals in fixed slots: 0 = (CoM, position) [+ the position part of the balance term], 1 = (CoM, velocity) [+ its
+// velocity part], 2 / 3 = left / right foot (position in swing, velocity in stance).  A slot whose term is off has scale 0 and
+// vec = 0: every contribution is linear in them and vanishes (the one-kernel version kept a variable-length list and merged it).
+enum {
+  QR_R0 = 0,        // [9]  base rotation (Eigen toRotationMatrix polynomial on the raw coefficients)
+  QR_D = 9,         // [4][9] dR/dquat_k
+  QR_UR = 45,       // [3]  upright residual pieces
+  QR_UJ = 48,       // [3][4]
+  QR_MFRAC = 60,    // [3]
+  QR_HASBAL = 63,   // 1.0 when the balance term is active at this knot
+  QR_BETA = 64,     // [3][3]
+  QR_GAMMA = 73,    // [3][3]
+  QR_VEC = 82,      // [4][3] merged weighted directions (second-order part)
+  QR_TIL = 94,      // [4][3] R0^T vec
+  QR_DV = 106,      // [4][4][3] D_k^T vec
+  QR_GSUM = 154,    // [4][3] scale_i e_i (gradient)
+  QR_GSCALE = 166,  // [4]
+  QR_BAL = 170,     // [8]
+  QR_ZH = 180,      // [19][3] joint axes, pelvis frame (joint j = 1..19 at 3 (j - 1))
+  QR_OM = 237,      // [19][3] body angular velocities
+  QR_W0 = 294,      // [19][3] w_j of the CoM set
+  QR_DG0 = 351,     // [19][3] d gamma / d theta_j of the CoM set
+  QR_WF = 408,      // [2][5][3] w_j of the foot sets (their leg's five joints)
+  QR_DGF = 438,     // [2][5][3]
+  QREC_SIZE = 468,
+  QREC_GROUP = 16   // knots interleaved per group: field f of knot k at (k >> 4) * 468 * 16 + f * 16 + (k & 15)
+};
+size_t quad_rec_doubles(size_t knots) { return ((knots + QREC_GROUP - 1) / QREC_GROUP) * (size_t)QREC_GROUP * QREC_SIZE; }
+
+// ---- k_quad_kin: compile-time model tables ------------------------------------------------------------------------------------
+struct QMassTab { double mu[H1_NB], msub[H1_NB], mtot; };
+constexpr bool q_anc_or_self(int i, int j) { return i == 0 ? true : (j == 0 ? false : h1c::C_ANC[i - 1][j - 1] != 0); }
+constexpr QMassTab make_mass_tab() {
+  QMassTab T{};
+  double mtot = 0.0;
+  for (int k = 0; k < H1_NB; ++k) mtot += h1c::CU_MASS[k];
+  T.mtot = mtot;
+  for (int i = 0; i < H1_NB; ++i) T.mu[i] = h1c::CU_MASS[i] / mtot;
+  for (int i = 0; i < H1_NB; ++i) { double s = 0.0; for (int j = H1_NB - 1; j >= 0; --j) if (q_anc_or_self(i, j)) s += T.mu[j]; T.msub[i] = s; }
+  return T;
+}
+constexpr QMassTab QMASS = make_mass_tab();
+
+struct QB { double R[9], p[3], z[3], Om[3]; };   // body frame in the pelvis frame: rotation, origin, joint axis, angular velocity
+
+template <int I, int r> DEVFN void qk_rj_row(double cs, double sn, double* o) {   // row r of Rfix_I Rot(axis_I, theta)
+  constexpr double f0 = h1c::CU_RFIX[I][r][0], f1 = h1c::CU_RFIX[I][r][1], f2 = h1c::CU_RFIX[I][r][2];
+  constexpr int ax = h1c::C_AXIS[I];
+  if constexpr (ax == 0) { o[0] = f0; o[1] = f1 * cs + f2 * sn; o[2] = f2 * cs - f1 * sn; }
+  else if constexpr (ax == 1) { o[0] = f0 * cs - f2 * sn; o[1] = f1; o[2] = f2 * cs + f0 * sn; }
+  else { o[0] = f0 * cs + f1 * sn; o[1] = f1 * cs - f0 * sn; o[2] = f2; }
+}
+// body I from its parent P (h1_cost_dev.h knot_base_kin); q = mu_I (p_I + R_I com_I), its share of the whole-body CoM
+template <int I> DEVFN void qk_step(const QB& P, double th, double qd, QB& B, double* q) {
+  constexpr int ax = h1c::C_AXIS[I];
+  double sn, cs; h1f::sincos_fast(th, &sn, &cs);
+  double Rj[9];
+  qk_rj_row<I, 0>(cs, sn, Rj); qk_rj_row<I, 1>(cs, sn, Rj + 3); qk_rj_row<I, 2>(cs, sn, Rj + 6);
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) B.R[3 * r + c] = P.R[3 * r] * Rj[c] + P.R[3 * r + 1] * Rj[3 + c] + P.R[3 * r + 2] * Rj[6 + c];
+  constexpr double px = h1c::CU_POS[I][0], py = h1c::CU_POS[I][1], pz = h1c::CU_POS[I][2];
+  constexpr double c0 = h1c::CU_COM[I][0], c1 = h1c::CU_COM[I][1], c2 = h1c::CU_COM[I][2];
+  constexpr double mu = QMASS.mu[I];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    B.p[k] = P.p[k] + (P.R[3 * k] * px + P.R[3 * k + 1] * py + P.R[3 * k + 2] * pz);
+    B.z[k] = B.R[3 * k + ax];
+    B.Om[k] = P.Om[k] + B.z[k] * qd;
+    q[k] = mu * (B.p[k] + (B.R[3 * k] * c0 + B.R[3 * k + 1] * c1 + B.R[3 * k + 2] * c2));
+  }
+}
+// One chain of the tree (FIRST .. FIRST + LEN - 1, each body the parent of the next), processed outward then inward by one lane.
+//   FOOT = 0: CoM set only; 1 / 2: the chain is a leg and also carries the left / right ankle set (unit mass at the last body)
+// h   : in = sum of q over the subtrees hanging off the chain's LAST body (zero for a leaf), out = subtree sum of the chain's root
+// sv0 : in = sum of qd_j w_j over the strict descendants of the last body, out = the same over the root's subtree incl. the root
+template <int FIRST, int LEN, int FOOT, class Put> struct QChain {
+  QB B[LEN]; double q[LEN][3];
+  template <int K> DEVFN void out(const QB& par, const double* xg) {
+    constexpr int I = FIRST + K;
+    qk_step<I>(par, xg[7 + I - 1], xg[H1_NQ + 6 + I - 1], B[K], q[K]);
+    if constexpr (K + 1 < LEN) out<K + 1>(B[K], xg);
+  }
+  template <int K> DEVFN void in(const double* xg, double* h, double* sv0, const double* pee, double* svf, Put& put) {
+    constexpr int I = FIRST + K;
+    constexpr double msub = QMASS.msub[I];
+    const QB& b = B[K];
+    double r[3], w[3], a3[3], b3[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { h[k] = h[k] + q[K][k]; r[k] = h[k] - msub * b.p[k]; }
+    cross(b.z, r, w);
+    cross(b.Om, w, a3); cross(b.z, sv0, b3);
+    const double qd = xg[H1_NQ + 6 + I - 1];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      put(QR_ZH + 3 * (I - 1) + k, b.z[k]); put(QR_OM + 3 * (I - 1) + k, b.Om[k]);
+      put(QR_W0 + 3 * (I - 1) + k, w[k]); put(QR_DG0 + 3 * (I - 1) + k, a3[k] + b3[k]);
+      sv0[k] += qd * w[k];
+    }
+    if constexpr (FOOT != 0) {      // unit mass at the ankle: subtree sum = p_ee, subtree mass 1 along the leg
+      double rf[3], wf[3], af[3], bf[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) rf[k] = pee[k] - 1.0 * b.p[k];
+      cross(b.z, rf, wf);
+      cross(b.Om, wf, af); cross(b.z, svf, bf);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        put(QR_WF + 15 * (FOOT - 1) + 3 * K + k, wf[k]); put(QR_DGF + 15 * (FOOT - 1) + 3 * K + k, af[k] + bf[k]);
+        svf[k] += qd * wf[k];
+      }
+    }
+    if constexpr (K > 0) in<K - 1>(xg, h, sv0, pee, svf, put);
+  }
+};
+
+// One lane per knot.  `rec`: the record buffer (quad_rec_doubles); knot0: index of the view's first knot in it (batch slices).
+__global__ void __launch_bounds__(64) k_quad_kin(DevState S, ProblemDev P, const int* list, const int* count, double* rec, long knot0) {
+  const int N1 = S.N + 1;
+  const long g = (long)blockIdx.x * 64 + threadIdx.x;
+  const long total = (long)(list ? *count : S.B) * N1;
+  if (g >= total) return;
+  const int bs = (int)(g / N1), t = (int)(g - (long)bs * N1);
+  const int b = list ? list[bs] : bs;
+  const bool term = (t == S.N);
+  const double* xg = S.xbar + ((size_t)b * N1 + t) * H1_NX;
+  const long kn = knot0 + (long)b * N1 + t;
+  double* out = rec + (size_t)(kn >> 4) * ((size_t)QREC_SIZE * QREC_GROUP) + (kn & 15);
+  auto put = [&](int f, double v) { out[(size_t)f * QREC_GROUP] = v; };
+  typedef decltype(put) PutT;
+
+  // base: Pinocchio slot order of the quaternion (derivatives.cpp:12-24): xp[3..6] = (qx, qy, qz, qw)
+  const double qx = xg[4], qy = xg[5], qz = xg[6], qw = xg[3];
+  double R0[9], D[4][9];
+  {
+    const double tx = 2 * qx, ty = 2 * qy, tz = 2 * qz;
+    const double twx = tx * qw, twy = ty * qw, twz = tz * qw, txx = tx * qx, txy = ty * qx, txz = tz * qx, tyy = ty * qy, tyz = tz * qy, tzz = tz * qz;
+    R0[0] = 1 - (tyy + tzz); R0[1] = txy - twz; R0[2] = txz + twy;
+    R0[3] = txy + twz; R0[4] = 1 - (txx + tzz); R0[5] = tyz - twx;
+    R0[6] = txz - twy; R0[7] = tyz + twx; R0[8] = 1 - (txx + tyy);
+    const double qp[4] = {qx, qy, qz, qw};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) dR_dquat(k, qp, D[k]);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) put(QR_R0 + k, R0[k]);
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int e = 0; e < 9; ++e) put(QR_D + 9 * k + e, D[k][e]);
+    // upright pieces (4 quaternion slots, derivatives.cpp:646-666 labelling)
+    const double ua = qx, ub = qy, uc = qz, ud = qw;
+    put(QR_UR + 0, 2.0 * (ub * ud + ua * uc)); put(QR_UR + 1, 2.0 * (uc * ud - ua * ub)); put(QR_UR + 2, -2.0 * (ub * ub + uc * uc));
+    put(QR_UJ + 0, 2 * uc); put(QR_UJ + 1, 2 * ud); put(QR_UJ + 2, 2 * ua); put(QR_UJ + 3, 2 * ub);
+    put(QR_UJ + 4, -2 * ub); put(QR_UJ + 5, -2 * ua); put(QR_UJ + 6, 2 * ud); put(QR_UJ + 7, 2 * uc);
+    put(QR_UJ + 8, 0.0); put(QR_UJ + 9, -4 * ub); put(QR_UJ + 10, -4 * uc); put(QR_UJ + 11, 0.0);
+  }
+  const double vb[3] = {xg[H1_NQ], xg[H1_NQ + 1], xg[H1_NQ + 2]}, wb[3] = {xg[H1_NQ + 3], xg[H1_NQ + 4], xg[H1_NQ + 5]};
+  QB pel;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) pel.R[k] = (k % 4 == 0) ? 1.0 : 0.0;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { pel.p[k] = 0.0; pel.z[k] = 0.0; pel.Om[k] = wb[k]; }
+
+  double h0[3], sw0[3] = {0.0, 0.0, 0.0};          // whole-body: sum of q (-> beta_0), sum of qd_j w_j (-> gamma_0)
+  double betaf[2][3], swf[2][3];                 // feet
+  {  // pelvis' own share: q_0 = mu_0 (p_0 + R_0 com_0) with R_0 = 1, p_0 = 0
+    constexpr double mu = QMASS.mu[0];
+    h0[0] = mu * (0.0 + h1c::CU_COM[0][0]); h0[1] = mu * (0.0 + h1c::CU_COM[0][1]); h0[2] = mu * (0.0 + h1c::CU_COM[0][2]);
+  }
+  {  // torso and arms
+    QB tor; double qt[3];
+    qk_step<11>(pel, xg[7 + 10], xg[H1_NQ + 6 + 10], tor, qt);
+    double ht[3] = {0.0, 0.0, 0.0}, svt[3] = {0.0, 0.0, 0.0};
+    {
+      QChain<16, 4, 0, PutT> c; c.template out<0>(tor, xg);
+      double h[3] = {0.0, 0.0, 0.0}, sv[3] = {0.0, 0.0, 0.0};
+      c.template in<3>(xg, h, sv, nullptr, nullptr, put);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { ht[k] += h[k]; svt[k] += sv[k]; }
+    }
+    {
+      QChain<12, 4, 0, PutT> c; c.template out<0>(tor, xg);
+      double h[3] = {0.0, 0.0, 0.0}, sv[3] = {0.0, 0.0, 0.0};
+      c.template in<3>(xg, h, sv, nullptr, nullptr, put);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { ht[k] += h[k]; svt[k] += sv[k]; }
+    }
+    // the torso itself
+    constexpr double msub = QMASS.msub[11];
+    double r[3], w[3], a3[3], b3[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { ht[k] += qt[k]; r[k] = ht[k] - msub * tor.p[k]; }
+    cross(tor.z, r, w); cross(tor.Om, w, a3); cross(tor.z, svt, b3);
+    const double qd = xg[H1_NQ + 6 + 10];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      put(QR_ZH + 30 + k, tor.z[k]); put(QR_OM + 30 + k, tor.Om[k]); put(QR_W0 + 30 + k, w[k]); put(QR_DG0 + 30 + k, a3[k] + b3[k]);
+      svt[k] += qd * w[k];
+      h0[k] += ht[k]; sw0[k] += svt[k];
+    }
+  }
+  {  // right leg (ankle set 2), then left leg (ankle set 1)
+    QChain<6, 5, 2, PutT> c; c.template out<0>(pel, xg);
+    double h[3] = {0.0, 0.0, 0.0}, sv[3] = {0.0, 0.0, 0.0}, svf[3] = {0.0, 0.0, 0.0};
+    const double pee[3] = {c.B[4].p[0], c.B[4].p[1], c.B[4].p[2]};
+    c.template in<4>(xg, h, sv, pee, svf, put);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { h0[k] += h[k]; sw0[k] += sv[k]; betaf[1][k] = pee[k]; swf[1][k] = svf[k]; }
+  }
+  {
+    QChain<1, 5, 1, PutT> c; c.template out<0>(pel, xg);
+    double h[3] = {0.0, 0.0, 0.0}, sv[3] = {0.0, 0.0, 0.0}, svf[3] = {0.0, 0.0, 0.0};
+    const double pee[3] = {c.B[4].p[0], c.B[4].p[1], c.B[4].p[2]};
+    c.template in<4>(xg, h, sv, pee, svf, put);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { h0[k] += h[k]; sw0[k] += sv[k]; betaf[0][k] = pee[k]; swf[0][k] = svf[k]; }
+  }
+  // beta, gamma of the three sets (gamma = mfrac v_b + omega_b x beta + sum_j qd_j w_j)
+  constexpr double mfrac0 = QMASS.msub[0];
+  double beta[3][3], gamma[3][3];
+  const double mfr[3] = {mfrac0, 1.0, 1.0};
+#pragma unroll
+  for (int s = 0; s < 3; ++s) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) beta[s][k] = s == 0 ? h0[k] : betaf[s - 1][k];
+    double wxb[3]; cross(wb, beta[s], wxb);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      gamma[s][k] = (mfr[s] * vb[k] + wxb[k]) + (s == 0 ? sw0[k] : swf[s - 1][k]);
+      put(QR_BETA + 3 * s + k, beta[s][k]); put(QR_GAMMA + 3 * s + k, gamma[s][k]);
+    }
+    put(QR_MFRAC + s, mfr[s]);
+  }
+  // the weighted functionals of the active terms (order of ilqr.cpp:154-181), fixed slots
+  double vec[4][3], gsum[4][3], gscale[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) { gscale[c] = 0.0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { vec[c][k] = 0.0; gsum[c][k] = 0.0; } }
+  const int* st = P.stance + b * P.stance_stride + 2 * t;
+  const int st0 = st[0], st1 = st[1];
+  if (P.w_com > 0.0) {   // CoM position: w ||com - ref||^2
+    const double* ref = P.com_ref + b * P.com_ref_stride + t * 3;
+    double rb[3]; mv3(R0, beta[0], rb);
+    gscale[0] = 2.0 * P.w_com;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { const double e = mfr[0] * xg[k] + rb[k] - ref[k]; gsum[0][k] = gscale[0] * e; vec[0][k] = gscale[0] * e; }
+  }
+  if (!term && P.w_com_vel > 0.0) {
+    const double* ref = P.com_vel_ref + b * P.com_vel_ref_stride + t * 3;
+    double v[3]; mv3(R0, gamma[0], v);
+    gscale[1] = 2.0 * P.w_com_vel;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { const double e = v[k] - ref[k]; gsum[1][k] = gscale[1] * e; vec[1][k] = gscale[1] * e; }
+  }
+#pragma unroll
+  for (int ee = 0; ee < 2; ++ee) {
+    const int set = 1 + ee, ste = ee == 0 ? st0 : st1;
+    if (P.w_ee_pos > 0.0 && ste != 1) {
+      const double* ref = P.ee_ref + b * P.ee_ref_stride + (t * 2 + ee) * 3;
+      double rb[3]; mv3(R0, beta[set], rb);
+      gscale[2 + ee] = 2.0 * P.w_ee_pos;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { const double e = mfr[set] * xg[k] + rb[k] - ref[k]; gsum[2 + ee][k] = gscale[2 + ee] * e; vec[2 + ee][k] = gscale[2 + ee] * e; }
+    }
+    if (P.w_ee_vel > 0.0 && ste == 1) {
+      double e[3]; mv3(R0, gamma[set], e);   // zero target (ilqr.cpp:734)
+      gscale[2 + ee] = 2.0 * P.w_ee_vel;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { gsum[2 + ee][k] = gscale[2 + ee] * e[k]; vec[2 + ee][k] = gscale[2 + ee] * e[k]; }
+    }
+  }
+  double ps[2];
+  double hasbal = 0.0, bal[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (P.w_balance > 0.0 && support_point(P, b, t, ps)) {
+    double rb[3], vc[3]; mv3(R0, beta[0], rb); mv3(R0, gamma[0], vc);
+    double com[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) com[k] = mfr[0] * xg[k] + rb[k];
+    const double gg = 9.81;
+    const double om = sqrt(com[2] / gg), om1 = 1.0 / (2.0 * gg * om), om2 = -1.0 / (4.0 * gg * gg * om * om * om);
+    const double r0 = com[0] + vc[0] * om - ps[0], r1 = com[1] + vc[1] * om - ps[1];
+    const double rv = r0 * vc[0] + r1 * vc[1];
+    bal[0] = r0; bal[1] = r1; bal[2] = om; bal[3] = om1; bal[4] = om2; bal[5] = vc[0]; bal[6] = vc[1]; bal[7] = rv;
+    hasbal = 1.0;
+    const double mu[3] = {r0, r1, om1 * rv}, nu[3] = {om * r0, om * r1, 0.0};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { vec[0][k] += P.w_balance * mu[k]; vec[1][k] += P.w_balance * nu[k]; }
+  }
+  put(QR_HASBAL, hasbal);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) put(QR_BAL + k, bal[k]);
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    double til[3]; mtv3(R0, vec[c], til);
+    put(QR_GSCALE + c, gscale[c]);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { put(QR_VEC + 3 * c + k, vec[c][k]); put(QR_TIL + 3 * c + k, til[k]); put(QR_GSUM + 3 * c + k, gsum[c][k]); }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      double dv[3]; mtv3(D[q], vec[c], dv);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) put(QR_DV + 12 * c + 3 * q + k, dv[k]);
+    }
+  }
+}
+
+// ---- k_cost_quadratics ---------------------------------------------------------------------------------------------------------
 #define QS2_R0 3            // second-order patch: rows quat | theta (3..25), columns 3..50, entry (a, b) with a <= b
 #define QS2_NR 23
 #define QS2_NC 48
 #define QS2_SIZE (QS2_NR * QS2_NC - QS2_NR * (QS2_NR - 1) / 2)
 #define QS2_IDX(a, bb) (((a) - QS2_R0) * QS2_NC - ((a) - QS2_R0) * ((a) - QS2_R0 - 1) / 2 + ((bb) - (a)))
+enum { QJ_C = 0, QJ_V = 3, QJ_F0 = 6, QJ_F1 = 9, QJ_R0 = 12, QJ_R1 = 13, QJ_M = 14, QJ_ROWS = 15 };
 struct QuadLds {
+  double rec[QREC_SIZE];                     // the knot record
   union {
-    struct {                               // phases 0..5 and the operand fetch of phase 6
-      double Jc[3][H1_NX], Jv[3][H1_NX];     // d c / d x_p, d cdot / d x_p of the whole-body CoM (point set 0)
-      double Jf[2][3][H1_NX];                // the feet (point sets 1, 2): d cdot / d x_p in stance, d c / d x_p in swing
-      double jr[2][H1_NX];                   // balance rows jr0, jr1 (jz, Jv0, Jv1 are rows of Jc[0] / Jv[0])
-      double xp[H1_NX];                      // Pinocchio-ordered state (derivatives.cpp:12-24)
-      double R0[9], D[4][9];                 // base rotation (Eigen toRotationMatrix polynomial), dR/dquat_k
-      double zh[H1_NB][3], Om[H1_NB][3];     // joint axes and body angular velocities, pelvis frame
-      double us[H1_NU];
-      double gsum[QMAXC][3];
-    };
-    double S2[QS2_SIZE];                   // phase 6: second-order part of the entries that have one (packed, QS2_IDX)
+    struct { double J[QJ_ROWS][H1_NX]; };    // Jacobian rows: d c, d cdot of the CoM; the feet's; balance rows jr0, jr1, m
+    double S2[QS2_SIZE];                     // second-order part of the entries that have one (packed, QS2_IDX)
   };
-  double beta[3][3], gamma[3][3], mfrac[3];
-  double w[3][H1_NB][3], dgam[3][H1_NB][3];
-  unsigned char on[3][H1_NB];
-  QuadCtx ctx[QMAXC];
-  double dg[H1_NX];                      // diagonal additions: Q (or Qf) + soft joint-limit penalty
-  double gscale[QMAXM];                  // scale of the gradient-carrying functionals (first-order product): CoM position, CoM velocity, one per foot
-  unsigned char gset[8], gvel[8]; int nctx, ng, has_bal; double bal[8];
-  double uJ[3][4], ur[3];                // upright pieces
-  unsigned anc[H1_NB];                   // bit j of anc[i]: body i is an ancestor of (or is) body j
-  union {
-    struct { double Rh[H1_NB][9], ph[H1_NB][3], mu[3][H1_NB], q[3][H1_NB][3]; } k;   // phases 1-2
-    struct { double tz[QMAXM][H1_NJ][3], Pp[QMAXM][H1_NJ][3]; } j;                    // phases 4-6: til_c x z_j, P'_j
-  } u;
+  double tz[4][H1_NJ][3], Pp[3][H1_NJ][3];   // til_c x z_j (slots 0..3), P'_j (slots 1..3: slot 0 is never a velocity functional)
+  double dg[H1_NX];                          // diagonal additions: Q (or Qf) + soft joint-limit penalty
 };
-static_assert(sizeof(double) * QS2_SIZE <= sizeof(double) * (12 * H1_NX + 2 * H1_NX + H1_NX + 9 + 36 + 6 * H1_NB + H1_NU + 3 * QMAXC), "the patch fits the storage it aliases");
-static_assert(H1_NB * 3 >= H1_NX, "balance row m aliases Om");
 static_assert(sizeof(QuadLds) <= 16384, "QuadLds must fit ten two-wave workgroups per CU");
 
-__device__ __forceinline__ bool quad_selected(const DevState& S, int b, int mode) {
-  if (mode == MASK_ALL) return true;
-  if (mode == MASK_ACTIVE) return S.active[b] != 0;
-  return S.active[b] != 0 && S.need_retry[b] != 0;
-}
-DEVFN bool related_mask(const unsigned* anc, int ja, int jb, int& lo, int& hi) {
-  if ((anc[ja] >> jb) & 1u) { lo = ja; hi = jb; return true; }
-  if ((anc[jb] >> ja) & 1u) { lo = jb; hi = ja; return true; }
-  return false;
-}
 DEVFN double sel3(const double* v, int k) { return k == 0 ? v[0] : (k == 1 ? v[1] : v[2]); }   // no dynamic register index
 // d2R/dquat_k dquat_l: dR_dquat is linear in q, so this is dR_dquat(k, e_l)
 DEVFN void d2R_sel(int k, int l, double* D) {
   const double q[4] = {l == 0 ? 1.0 : 0.0, l == 1 ? 1.0 : 0.0, l == 2 ? 1.0 : 0.0, l == 3 ? 1.0 : 0.0};
   dR_dquat(k, q, D);
 }
+// joint j (1..19) of point set st carries it: the CoM set everywhere, a foot set along its own leg
+DEVFN bool q_on(int st, int j) { return st == 0 ? true : (st == 1 ? (j >= 1 && j <= 5) : (j >= 6 && j <= 10)); }
+// w_j / d gamma / d theta_j of point set st in the record (index clamped into the set's range: callers mask with q_on)
+DEVFN const double* q_w(const double* rec, int st, int j) {
+  if (st == 0) return rec + QR_W0 + 3 * (j - 1);
+  const int f = st == 1 ? 1 : 6; int k = j - f; k = k < 0 ? 0 : (k > 4 ? 4 : k);
+  return rec + QR_WF + 15 * (st - 1) + 3 * k;
+}
+DEVFN const double* q_dg(const double* rec, int st, int j) {
+  if (st == 0) return rec + QR_DG0 + 3 * (j - 1);
+  const int f = st == 1 ? 1 : 6; int k = j - f; k = k < 0 ? 0 : (k > 4 ? 4 : k);
+  return rec + QR_DGF + 15 * (st - 1) + 3 * k;
+}
 
-// Two waves per knot share the knot's LDS record (20.4 KB bound the occupancy at 8 one-wave workgroups per CU).  `lane` runs
-// over 0..127: the lane-parallel phases 1-5 have at most 64 work items and stay on wave 0 (wave 1 waits at the barriers),
-// the Hessian -- half of the kernel -- is split: patch entries over 128 lanes, two accumulator row tiles per wave.
+// Two waves per knot share the knot's LDS record.  `lane` runs over 0..127.
 // `lower` (inside a solve whose backward pass is the one-wave Riccati kernel): for the knots t < N only the tiles I >= J of lxx are
 // computed and stored -- exactly the ones k_backward_wave loads (load_aug<true>, riccati_wave.hip); lxx is symmetric, the six
 // strictly upper 16 x 16 tiles (35 % of its entries, 0.85 GB per launch at B = 4096) were written for nobody.  The terminal knot,
 // which that kernel loads whole, and every stage-API call keep the full matrix (ilqr_hip_get_quadratics mirrors the tiles back).
-__global__ void __launch_bounds__(128, QUAD_WAVES) k_cost_quadratics(DevState S, ProblemDev P, int mode, const int* list, const int* count, int lower) {
-  const int t = blockIdx.x, lane = threadIdx.x, wv = lane >> 6;
-  int b = blockIdx.y;
-  if (list) {                        // compacted selection (DevState::order): no per-rollout flags to fetch, unselected workgroups leave on one cached scalar
-    if (b >= *count) return;
-    b = list[b];
-    mode = MASK_ALL;
-  }
-  const int N = S.N;
+// Workgroup numbering: workgroups are dealt to the 8 XCDs round-robin by index, and 16 consecutive knots share the 128-byte
+// lines of a record group; workgroup L therefore takes knot item (L % 8) * ceil(total / 8) + L / 8 -- consecutive items on one XCD.
+__global__ void __launch_bounds__(128, QUAD_WAVES) k_cost_quadratics(DevState S, ProblemDev P, int mode, const int* list, const int* count, int lower,
+                                                                     const double* recg, long knot0) {
+  const int lane = threadIdx.x, wv = lane >> 6;
+  const int N = S.N, N1 = N + 1;
+  const long total = (long)(list ? *count : S.B) * N1;
+  const long per = (total + 7) >> 3;
+  const long item = (long)(blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  if ((long)(blockIdx.x >> 3) >= per || item >= total) return;
+  const int bs = (int)(item / N1), t = (int)(item - (long)bs * N1);
+  int b = bs;
+  if (list) { b = list[bs]; mode = MASK_ALL; }     // compacted selection (DevState::order): no per-rollout flags to fetch
   const bool term = (t == N);
   __shared__ QuadLds L;
 #ifdef QUAD_STAMP
   long long qlast = clock64();
 #endif
-  const double* xg = S.xbar + ((size_t)b * (N + 1) + t) * H1_NX;
+  const double* xg = S.xbar + ((size_t)b * N1 + t) * H1_NX;
+  const double* rec = L.rec;
 
-  // ---- phase 0: state (Pinocchio slot order of the quaternion), ancestor masks.  The rollout's selection flags are requested
-  // together with the knot's data (indices clamped instead of predicated) and tested before anything is written: flag, state,
-  // control and table one after the other were four serial HBM round trips at the top of every workgroup
+  // ---- phase 0: the knot's record -> LDS.  The rollout's selection flags are requested together with the knot's data (indices
+  // clamped instead of predicated) and tested before anything is written
+  double xv;
   {
     const int f1 = mode == MASK_ALL ? 1 : S.active[b], f2 = mode == MASK_RETRY ? S.need_retry[b] : 1;
-    const int lx = lane < H1_NX ? lane : 0;
-    const int src = (lx == 3) ? 4 : (lx == 4) ? 5 : (lx == 5) ? 6 : (lx == 6) ? 3 : lx;
-    const double xv = xg[src];
-    const int tu = term ? N - 1 : t;
-    const double uv = S.ubar[((size_t)b * N + tu) * H1_NU + (lane < H1_NU ? lane : 0)];
-    const unsigned an = QANC.m[lane < H1_NB ? lane : 0];
+    const long kn = knot0 + (long)b * N1 + t;
+    const double* rg = recg + (size_t)(kn >> 4) * ((size_t)QREC_SIZE * QREC_GROUP) + (kn & 15);
+    double rv[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { const int f = lane + 128 * k; rv[k] = rg[(size_t)(f < QREC_SIZE ? f : QREC_SIZE - 1) * QREC_GROUP]; }
+    xv = xg[lane < H1_NX ? lane : 0];
     if (!(f1 && f2)) return;
-    if (lane < H1_NX) L.xp[lane] = xv;
-    if (!term && lane < H1_NU) L.us[lane] = uv;
-    if (lane < H1_NB) L.anc[lane] = an;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { const int f = lane + 128 * k; if (f < QREC_SIZE) L.rec[f] = rv[k]; }
   }
   __syncthreads();
   QSTAMP(0)
 
-  // ---- phase 1: base kinematics, lane = body; Rj = Rfix * Rot(axis, theta) (child -> parent)
-  {
-    double Rj[9];
-    int par = 0, ax = 0, dep = -1;
-    if (lane >= 1 && lane < H1_NB) {
-      par = H1_PARENT[lane]; ax = H1_AXIS[lane]; dep = H1_DEPTH[lane];
-      double sn, cs; h1f::sincos_fast(L.xp[7 + lane - 1], &sn, &cs);
-#pragma unroll
-      for (int r = 0; r < 3; ++r) {
-        const double f0 = H1U_RFIX[lane][r][0], f1 = H1U_RFIX[lane][r][1], f2 = H1U_RFIX[lane][r][2];
-        Rj[3 * r + 0] = ax == 0 ? f0 : (ax == 1 ? f0 * cs - f2 * sn : f0 * cs + f1 * sn);
-        Rj[3 * r + 1] = ax == 0 ? f1 * cs + f2 * sn : (ax == 1 ? f1 : f1 * cs - f0 * sn);
-        Rj[3 * r + 2] = ax == 0 ? f2 * cs - f1 * sn : (ax == 1 ? f2 * cs + f0 * sn : f2);
-      }
-    } else if (lane == 0) {
-      const double qx = L.xp[3], qy = L.xp[4], qz = L.xp[5], qw = L.xp[6];
-      const double tx = 2 * qx, ty = 2 * qy, tz = 2 * qz;
-      const double twx = tx * qw, twy = ty * qw, twz = tz * qw, txx = tx * qx, txy = ty * qx, txz = tz * qx, tyy = ty * qy, tyz = tz * qy, tzz = tz * qz;
-      L.R0[0] = 1 - (tyy + tzz); L.R0[1] = txy - twz; L.R0[2] = txz + twy;
-      L.R0[3] = txy + twz; L.R0[4] = 1 - (txx + tzz); L.R0[5] = tyz - twx;
-      L.R0[6] = txz - twy; L.R0[7] = tyz + twx; L.R0[8] = 1 - (txx + tyy);
-#pragma unroll
-      for (int k = 0; k < 9; ++k) L.u.k.Rh[0][k] = (k % 4 == 0) ? 1.0 : 0.0;
-#pragma unroll
-      for (int k = 0; k < 3; ++k) { L.u.k.ph[0][k] = 0.0; L.zh[0][k] = 0.0; L.Om[0][k] = L.xp[H1_NQ + 3 + k]; }
-      // upright pieces (4 quaternion slots, derivatives.cpp:646-666 labelling)
-      const double ua = qx, ub = qy, uc = qz, ud = qw;
-      L.ur[0] = 2.0 * (ub * ud + ua * uc); L.ur[1] = 2.0 * (uc * ud - ua * ub); L.ur[2] = -2.0 * (ub * ub + uc * uc);
-      L.uJ[0][0] = 2 * uc; L.uJ[0][1] = 2 * ud; L.uJ[0][2] = 2 * ua; L.uJ[0][3] = 2 * ub;
-      L.uJ[1][0] = -2 * ub; L.uJ[1][1] = -2 * ua; L.uJ[1][2] = 2 * ud; L.uJ[1][3] = 2 * uc;
-      L.uJ[2][0] = 0.0; L.uJ[2][1] = -4 * ub; L.uJ[2][2] = -4 * uc; L.uJ[2][3] = 0.0;
-    } else if (lane >= 32 && lane < 36) {
-      dR_dquat(lane - 32, L.xp + 3, L.D[lane - 32]);
-    }
-    __syncthreads();
-    for (int d = 1; d <= 5; ++d) {
-      if (dep == d) {
-        const int i = lane, p = par;
-        double Rp[9], Ri[9];
-#pragma unroll
-        for (int k = 0; k < 9; ++k) Rp[k] = L.u.k.Rh[p][k];
-#pragma unroll
-        for (int r = 0; r < 3; ++r)
-#pragma unroll
-          for (int c = 0; c < 3; ++c) Ri[3 * r + c] = Rp[3 * r] * Rj[c] + Rp[3 * r + 1] * Rj[3 + c] + Rp[3 * r + 2] * Rj[6 + c];
-#pragma unroll
-        for (int k = 0; k < 9; ++k) L.u.k.Rh[i][k] = Ri[k];
-        const double px = H1U_POS[i][0], py = H1U_POS[i][1], pz = H1U_POS[i][2];
-        const double qd = L.xp[H1_NQ + 6 + i - 1];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-          const double z = sel3(Ri + 3 * k, ax);
-          L.u.k.ph[i][k] = L.u.k.ph[p][k] + (Rp[3 * k] * px + Rp[3 * k + 1] * py + Rp[3 * k + 2] * pz);
-          L.zh[i][k] = z;
-          L.Om[i][k] = L.Om[p][k] + z * qd;
-        }
-      }
-      __syncthreads();
-    }
-  }
-  QSTAMP(1)
-
-  // ---- phase 2: point sets, lane = (set, body)
-  {
-    const int s = lane / H1_NB, i = lane - s * H1_NB;
-    const bool act = lane < 3 * H1_NB;
-    if (act) {
-      double mu;
-      if (s == 0) { double mtot = 0.0; for (int k = 0; k < H1_NB; ++k) mtot += H1U_MASS[k]; mu = H1U_MASS[i] / mtot; }
-      else mu = (i == ((s == 1) ? H1_EE_LEFT : H1_EE_RIGHT)) ? 1.0 : 0.0;
-      double ch[3] = {0.0, 0.0, 0.0};
-      if (s == 0) mv3(L.u.k.Rh[i], H1U_COM[i], ch);
-      L.u.k.mu[s][i] = mu;
-#pragma unroll
-      for (int k = 0; k < 3; ++k) L.u.k.q[s][i][k] = mu * (L.u.k.ph[i][k] + ch[k]);
-    }
-    __syncthreads();
-    if (act) {
-      const unsigned m = L.anc[i];
-      double msub = 0.0, h[3] = {0.0, 0.0, 0.0};
-      for (int j = H1_NB - 1; j >= 0; --j)
-        if ((m >> j) & 1u) { msub += L.u.k.mu[s][j]; h[0] += L.u.k.q[s][j][0]; h[1] += L.u.k.q[s][j][1]; h[2] += L.u.k.q[s][j][2]; }
-      if (i == 0) {
-        L.mfrac[s] = msub; L.on[s][0] = 1;
-#pragma unroll
-        for (int k = 0; k < 3; ++k) { L.beta[s][k] = h[k]; L.w[s][0][k] = 0.0; L.dgam[s][0][k] = 0.0; }
-      } else {
-        L.on[s][i] = msub > 0.0 ? 1 : 0;
-        double r[3];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) r[k] = h[k] - msub * L.u.k.ph[i][k];
-        cross(L.zh[i], r, L.w[s][i]);
-      }
-    }
-    __syncthreads();
-    if (act) {
-      if (i == 0) {
-        const double* vb = L.xp + H1_NQ; const double* wb = L.xp + H1_NQ + 3;
-        double wxb[3]; cross(wb, L.beta[s], wxb);
-        double g[3];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) g[k] = L.mfrac[s] * vb[k] + wxb[k];
-        for (int j = 1; j < H1_NB; ++j) { const double qd = L.xp[H1_NQ + 6 + j - 1]; g[0] += qd * L.w[s][j][0]; g[1] += qd * L.w[s][j][1]; g[2] += qd * L.w[s][j][2]; }
-#pragma unroll
-        for (int k = 0; k < 3; ++k) L.gamma[s][k] = g[k];
-      } else {
-        const unsigned m = L.anc[i] & ~(1u << i);   // strict descendants
-        double sv[3] = {0.0, 0.0, 0.0};
-        for (int j = H1_NB - 1; j >= 1; --j)
-          if ((m >> j) & 1u) { const double qd = L.xp[H1_NQ + 6 + j - 1]; sv[0] += qd * L.w[s][j][0]; sv[1] += qd * L.w[s][j][1]; sv[2] += qd * L.w[s][j][2]; }
-        double a3[3], b3[3]; cross(L.Om[i], L.w[s][i], a3); cross(L.zh[i], sv, b3);
-#pragma unroll
-        for (int k = 0; k < 3; ++k) L.dgam[s][i][k] = a3[k] + b3[k];
-      }
-    }
-    __syncthreads();
-  }
-  QSTAMP(2)
-
-  // ---- phase 3: Jacobian columns of c and cdot, lane = coordinate (h1_cost_dev.h knot_jac_column)
   const int* stq = P.stance + b * P.stance_stride + 2 * t;      // (wave-uniform: scalar loads)
   const int fvel[2] = {stq[0] == 1, stq[1] == 1};               // stance foot: the velocity functional; swing foot: the position one
-  if (lane < H1_NX) {
-    const int c = lane;
-    for (int s = 0; s < 3; ++s) {
-      double jc[3] = {0, 0, 0}, jv[3] = {0, 0, 0};
-      if (c < 3) { jc[0] = c == 0 ? L.mfrac[s] : 0.0; jc[1] = c == 1 ? L.mfrac[s] : 0.0; jc[2] = c == 2 ? L.mfrac[s] : 0.0; }
-      else if (c < 7) { mv3(L.D[c - 3], L.beta[s], jc); mv3(L.D[c - 3], L.gamma[s], jv); }
-      else if (c < H1_NQ) { const int j = c - 7 + 1; if (L.on[s][j]) { mv3(L.R0, L.w[s][j], jc); mv3(L.R0, L.dgam[s][j], jv); } }
-      else {
-        const int cv = c - H1_NQ;
-        double col[3] = {0, 0, 0};
-        if (cv < 3) { col[0] = cv == 0 ? L.mfrac[s] : 0.0; col[1] = cv == 1 ? L.mfrac[s] : 0.0; col[2] = cv == 2 ? L.mfrac[s] : 0.0; }
-        else if (cv < 6) {  // -[beta]x column
-          const int k = cv - 3; const double* bt = L.beta[s];
-          if (k == 0) { col[1] = -bt[2]; col[2] = bt[1]; } else if (k == 1) { col[0] = bt[2]; col[2] = -bt[0]; } else { col[0] = -bt[1]; col[1] = bt[0]; }
-        } else { const int j = cv - 6 + 1; if (L.on[s][j]) { col[0] = L.w[s][j][0]; col[1] = L.w[s][j][1]; col[2] = L.w[s][j][2]; } }
-        mv3(L.R0, col, jv);
-      }
-#pragma unroll
-      for (int r = 0; r < 3; ++r) {
-        if (s == 0) { L.Jc[r][c] = jc[r]; L.Jv[r][c] = jv[r]; }
-        else L.Jf[s - 1][r][c] = fvel[s - 1] ? jv[r] : jc[r];
-      }
-    }
-  }
-  __syncthreads();
-  QSTAMP(3)
-
-  // ---- phase 4: the weighted functionals of the active terms (order = ilqr.cpp:154-181)
-  if (lane == 0) {
-    int n = 0, g = 0; L.has_bal = 0;
-    const int* st = P.stance + b * P.stance_stride + 2 * t;
-    auto push = [&](int set, int is_vel, double scale, const double* vec, bool grad) {
-      L.ctx[n].set = set; L.ctx[n].is_vel = is_vel; L.ctx[n].scale = scale;
-      for (int k = 0; k < 3; ++k) L.ctx[n].vec[k] = vec[k];
-      if (grad) { L.gset[g] = (unsigned char)set; L.gvel[g] = (unsigned char)is_vel; L.gscale[g] = scale; for (int k = 0; k < 3; ++k) L.gsum[g][k] = scale * vec[k]; ++g; }
-      ++n;
-    };
-    if (P.w_com > 0.0) {   // CoM position: w ||com - ref||^2
-      const double* ref = P.com_ref + b * P.com_ref_stride + t * 3;
-      double rb[3], e[3]; mv3(L.R0, L.beta[0], rb);
-      for (int k = 0; k < 3; ++k) e[k] = L.mfrac[0] * L.xp[k] + rb[k] - ref[k];
-      push(0, 0, 2.0 * P.w_com, e, true);
-    }
-    if (!term && P.w_com_vel > 0.0) {
-      const double* ref = P.com_vel_ref + b * P.com_vel_ref_stride + t * 3;
-      double v[3], e[3]; mv3(L.R0, L.gamma[0], v);
-      for (int k = 0; k < 3; ++k) e[k] = v[k] - ref[k];
-      push(0, 1, 2.0 * P.w_com_vel, e, true);
-    }
-    for (int ee = 0; ee < 2; ++ee) {
-      const int set = 1 + ee;
-      if (P.w_ee_pos > 0.0 && st[ee] != 1) {
-        const double* ref = P.ee_ref + b * P.ee_ref_stride + (t * 2 + ee) * 3;
-        double rb[3], e[3]; mv3(L.R0, L.beta[set], rb);
-        for (int k = 0; k < 3; ++k) e[k] = L.mfrac[set] * L.xp[k] + rb[k] - ref[k];
-        push(set, 0, 2.0 * P.w_ee_pos, e, true);
-      }
-      if (P.w_ee_vel > 0.0 && st[ee] == 1) {
-        double e[3]; mv3(L.R0, L.gamma[set], e);   // zero target (ilqr.cpp:734)
-        push(set, 1, 2.0 * P.w_ee_vel, e, true);
-      }
-    }
-    double ps[2];
-    if (P.w_balance > 0.0 && support_point(P, b, t, ps)) {
-      double rb[3], vc[3]; mv3(L.R0, L.beta[0], rb); mv3(L.R0, L.gamma[0], vc);
-      double com[3]; for (int k = 0; k < 3; ++k) com[k] = L.mfrac[0] * L.xp[k] + rb[k];
-      const double gg = 9.81;
-      const double om = sqrt(com[2] / gg), om1 = 1.0 / (2.0 * gg * om), om2 = -1.0 / (4.0 * gg * gg * om * om * om);
-      const double r0 = com[0] + vc[0] * om - ps[0], r1 = com[1] + vc[1] * om - ps[1];
-      const double rv = r0 * vc[0] + r1 * vc[1];
-      L.bal[0] = r0; L.bal[1] = r1; L.bal[2] = om; L.bal[3] = om1; L.bal[4] = om2; L.bal[5] = vc[0]; L.bal[6] = vc[1]; L.bal[7] = rv;
-      L.has_bal = 1;
-      const double mu[3] = {r0, r1, om1 * rv}, nu[3] = {om * r0, om * r1, 0.0};
-      push(0, 0, P.w_balance, mu, false);
-      push(0, 1, P.w_balance, nu, false);
-    }
-    // the second-order part is linear in scale_c vec_c: contexts acting on the same point set with the same type merge
-    // (typically 6 -> 4: CoM position + balance, balance velocity part, one per foot); their scale becomes 1
-    int nm = 0;
-    for (int c = 0; c < n; ++c) {
-      int at = -1;
-      for (int q = 0; q < nm; ++q) if (L.ctx[q].set == L.ctx[c].set && L.ctx[q].is_vel == L.ctx[c].is_vel) at = q;
-      const double sc = L.ctx[c].scale;
-      const double v0 = sc * L.ctx[c].vec[0], v1 = sc * L.ctx[c].vec[1], v2 = sc * L.ctx[c].vec[2];
-      if (at < 0) { const int st_ = L.ctx[c].set, iv = L.ctx[c].is_vel; at = nm++; L.ctx[at].set = st_; L.ctx[at].is_vel = iv; L.ctx[at].scale = 1.0; L.ctx[at].vec[0] = v0; L.ctx[at].vec[1] = v1; L.ctx[at].vec[2] = v2; }
-      else { L.ctx[at].vec[0] += v0; L.ctx[at].vec[1] += v1; L.ctx[at].vec[2] += v2; }
-    }
-    L.nctx = nm; L.ng = g;
-  }
-  __syncthreads();
-  const int nctx = L.nctx, ng = L.ng, has_bal = L.has_bal;
-  if (lane < nctx) {
-    QuadCtx& C = L.ctx[lane];
-    mtv3(L.R0, C.vec, C.til);
-    for (int k = 0; k < 4; ++k) mtv3(L.D[k], C.vec, C.Dv[k]);
-  }
-  if (has_bal && lane < H1_NX) {
-    const int a = lane;
-    const double om = L.bal[2], om1 = L.bal[3];
-    const double jz = L.Jc[2][a];
-    L.jr[0][a] = L.Jc[0][a] + om * L.Jv[0][a] + L.bal[5] * om1 * jz;
-    L.jr[1][a] = L.Jc[1][a] + om * L.Jv[1][a] + L.bal[6] * om1 * jz;
-  }
-  __syncthreads();   // (also: the phase-1/2 temporaries are dead, their storage becomes tz / Pp)
-  for (int e = lane; e < nctx * H1_NJ; e += 128) {
-    const int c = e / H1_NJ, j = 1 + e - c * H1_NJ;
-    const QuadCtx& C = L.ctx[c];
-    double tz[3]; cross(C.til, L.zh[j], tz);
-#pragma unroll
-    for (int k = 0; k < 3; ++k) L.u.j.tz[c][j - 1][k] = tz[k];
-    if (C.is_vel) {
-      double tO[3], p1[3], p2[3]; cross(C.til, L.Om[j], tO); cross(tO, L.zh[j], p1); cross(tz, L.Om[j], p2);
-#pragma unroll
-      for (int k = 0; k < 3; ++k) L.u.j.Pp[c][j - 1][k] = p1[k] - p2[k];
-    }
-  }
-  __syncthreads();
-  double* const balm = &L.Om[0][0];   // Om is dead from here on: its storage takes the balance row m = om1 (r0 Jv0 + r1 Jv1) + rv om2 jz / 2
-  if (has_bal && lane < H1_NX) balm[lane] = L.bal[3] * (L.bal[0] * L.Jv[0][lane] + L.bal[1] * L.Jv[1][lane]) + 0.5 * L.bal[7] * L.bal[4] * L.Jc[2][lane];
-  __syncthreads();
-  QSTAMP(4)
-
+  const int has_bal = __builtin_amdgcn_readfirstlane(rec[QR_HASBAL] != 0.0 ? 1 : 0);
   const double* Qd = term ? P.Qf : P.Q;
-  const double* xr = P.x_ref + b * P.x_ref_stride + t * H1_NX;
 
-  // ---- phase 5: gradient lx (lane = coordinate), lu / luu
-  if (lane < H1_NX) {
-    const int a = lane;
-    double g = Qd[a] * (xg[a] - xr[a]);   // Q acts on the MuJoCo-ordered state
-    for (int i = 0; i < ng; ++i) {
-      const double (*J)[H1_NX] = L.gset[i] == 0 ? (L.gvel[i] ? L.Jv : L.Jc) : L.Jf[L.gset[i] - 1];   // (a foot's Jf is of the type its functional has)
-      g += J[0][a] * L.gsum[i][0] + J[1][a] * L.gsum[i][1] + J[2][a] * L.gsum[i][2];
+  // ---- phase 1.  wave 0, lane = coordinate: Jacobian columns (h1_cost_dev.h knot_jac_column), balance rows, gradient lx, diagonal;
+  //                wave 1, lane = (functional, joint): til x z_j, P'_j; then lu / luu
+  if (wv == 0) {
+    if (lane < H1_NX) {
+      const int c = lane;
+      const double* R0 = rec + QR_R0;
+      double jj[4][3];                 // this column of the four gradient-carrying Jacobians (slots 0..3)
+      double jc0[3] = {0, 0, 0}, jv0[3] = {0, 0, 0};
+#pragma unroll
+      for (int s = 0; s < 3; ++s) {
+        const double mfrac = rec[QR_MFRAC + s];
+        const double* beta = rec + QR_BETA + 3 * s; const double* gamma = rec + QR_GAMMA + 3 * s;
+        double jc[3] = {0, 0, 0}, jv[3] = {0, 0, 0};
+        if (c < 3) { jc[0] = c == 0 ? mfrac : 0.0; jc[1] = c == 1 ? mfrac : 0.0; jc[2] = c == 2 ? mfrac : 0.0; }
+        else if (c < 7) { mv3(rec + QR_D + 9 * (c - 3), beta, jc); mv3(rec + QR_D + 9 * (c - 3), gamma, jv); }
+        else if (c < H1_NQ) { const int j = c - 7 + 1; if (q_on(s, j)) { mv3(R0, q_w(rec, s, j), jc); mv3(R0, q_dg(rec, s, j), jv); } }
+        else {
+          const int cv = c - H1_NQ;
+          double col[3] = {0, 0, 0};
+          if (cv < 3) { col[0] = cv == 0 ? mfrac : 0.0; col[1] = cv == 1 ? mfrac : 0.0; col[2] = cv == 2 ? mfrac : 0.0; }
+          else if (cv < 6) {  // -[beta]x column
+            const int k = cv - 3;
+            if (k == 0) { col[1] = -beta[2]; col[2] = beta[1]; } else if (k == 1) { col[0] = beta[2]; col[2] = -beta[0]; } else { col[0] = -beta[1]; col[1] = beta[0]; }
+          } else { const int j = cv - 6 + 1; if (q_on(s, j)) { const double* w = q_w(rec, s, j); col[0] = w[0]; col[1] = w[1]; col[2] = w[2]; } }
+          mv3(R0, col, jv);
+        }
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+          if (s == 0) { jc0[r] = jc[r]; jv0[r] = jv[r]; jj[0][r] = jc[r]; jj[1][r] = jv[r]; L.J[QJ_C + r][c] = jc[r]; L.J[QJ_V + r][c] = jv[r]; }
+          else { const double v = fvel[s - 1] ? jv[r] : jc[r]; jj[1 + s][r] = v; L.J[QJ_F0 + 3 * (s - 1) + r][c] = v; }
+        }
+      }
+      // balance rows jr0, jr1 and m = om1 (r0 Jv0 + r1 Jv1) + rv om2 jz / 2 (zero rows when the term is off)
+      const double* bal = rec + QR_BAL;
+      double jr0 = 0.0, jr1 = 0.0;
+      if (has_bal) {
+        const double om = bal[2], om1 = bal[3], jz = jc0[2];
+        jr0 = jc0[0] + om * jv0[0] + bal[5] * om1 * jz;
+        jr1 = jc0[1] + om * jv0[1] + bal[6] * om1 * jz;
+        L.J[QJ_M][c] = bal[3] * (bal[0] * jv0[0] + bal[1] * jv0[1]) + 0.5 * bal[7] * bal[4] * jz;
+      } else L.J[QJ_M][c] = 0.0;
+      L.J[QJ_R0][c] = jr0; L.J[QJ_R1][c] = jr1;
+      // gradient lx
+      const int a = c;
+      const double* xr = P.x_ref + b * P.x_ref_stride + t * H1_NX;
+      double g = Qd[a] * (xv - xr[a]);   // Q acts on the MuJoCo-ordered state
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { const double* gs = rec + QR_GSUM + 3 * i; g += jj[i][0] * gs[0] + jj[i][1] * gs[1] + jj[i][2] * gs[2]; }
+      if (P.w_upright > 0.0 && a >= 3 && a < 7) {
+        const double* uJ = rec + QR_UJ; const double* ur = rec + QR_UR;
+        g += P.w_upright * (uJ[a - 3] * ur[0] + uJ[4 + a - 3] * ur[1] + uJ[8 + a - 3] * ur[2]);
+      }
+      if (has_bal) g += P.w_balance * (jr0 * bal[0] + jr1 * bal[1]);
+      double dgl = Qd[a];
+      if (a >= 7 && a < H1_NQ) {
+        double lo, hi; limit_bounds(H1_JRANGE[a - 7], lo, hi);
+        const double q = xv;                           // (hinge slots are not permuted)
+        if (q > hi) g += 2.0 * P.w_joint * (q - hi);
+        if (q < lo) g += -2.0 * P.w_joint * (lo - q);
+        if (q > hi || q < lo) dgl += 2.0 * P.w_joint;
+      }
+      S.lx[((size_t)b * N1 + t) * H1_NX + a] = g;
+      L.dg[a] = dgl;
     }
-    if (P.w_upright > 0.0 && a >= 3 && a < 7) g += P.w_upright * (L.uJ[0][a - 3] * L.ur[0] + L.uJ[1][a - 3] * L.ur[1] + L.uJ[2][a - 3] * L.ur[2]);
-    if (has_bal) g += P.w_balance * (L.jr[0][a] * L.bal[0] + L.jr[1][a] * L.bal[1]);
-    if (a >= 7 && a < H1_NQ) {
-      double lo, hi; limit_bounds(H1_JRANGE[a - 7], lo, hi);
-      const double q = L.xp[a];
-      if (q > hi) g += 2.0 * P.w_joint * (q - hi);
-      if (q < lo) g += -2.0 * P.w_joint * (lo - q);
+  } else {
+    const int l1 = lane - 64;
+    for (int e = l1; e < 4 * H1_NJ; e += 64) {
+      const int c = e / H1_NJ, j = 1 + e - c * H1_NJ;
+      const double* til = rec + QR_TIL + 3 * c; const double* zj = rec + QR_ZH + 3 * (j - 1); const double* Oj = rec + QR_OM + 3 * (j - 1);
+      double tz[3]; cross(til, zj, tz);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) L.tz[c][j - 1][k] = tz[k];
+      const bool isv = c == 1 || (c >= 2 && fvel[c >= 2 ? c - 2 : 0]);
+      if (c >= 1 && isv) {
+        double tO[3], p1[3], p2[3]; cross(til, Oj, tO); cross(tO, zj, p1); cross(tz, Oj, p2);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) L.Pp[c - 1][j - 1][k] = p1[k] - p2[k];
+      }
     }
-    S.lx[((size_t)b * (N + 1) + t) * H1_NX + a] = g;
-    double dgl = Qd[a];
-    if (a >= 7 && a < H1_NQ) {
-      double lo, hi; limit_bounds(H1_JRANGE[a - 7], lo, hi);
-      const double q = L.xp[a];
-      if (q > hi || q < lo) dgl += 2.0 * P.w_joint;
+    if (!term && l1 < H1_NU) {
+      const double* ur_ = P.u_ref + b * P.u_ref_stride + t * H1_NU;
+      const double u = S.ubar[((size_t)b * N + t) * H1_NU + l1];
+      double g = P.R[l1] * (u - ur_[l1]), h = P.R[l1];
+      double lo, hi; limit_bounds(H1_CTRLRANGE[l1], lo, hi);
+      if (u > hi) g += 2.0 * P.w_ctrl * (u - hi);
+      if (u < lo) g += -2.0 * P.w_ctrl * (lo - u);
+      if (u > hi || u < lo) h += 2.0 * P.w_ctrl;
+      S.lu[((size_t)b * N + t) * H1_NU + l1] = g;
+      S.luu[((size_t)b * N + t) * H1_NU + l1] = h;
     }
-    L.dg[a] = dgl;
   }
-  if (!term && lane < H1_NU) {
-    const double* ur_ = P.u_ref + b * P.u_ref_stride + t * H1_NU;
-    const double u = L.us[lane];
-    double g = P.R[lane] * (u - ur_[lane]), h = P.R[lane];
-    double lo, hi; limit_bounds(H1_CTRLRANGE[lane], lo, hi);
-    if (u > hi) g += 2.0 * P.w_ctrl * (u - hi);
-    if (u < lo) g += -2.0 * P.w_ctrl * (lo - u);
-    if (u > hi || u < lo) h += 2.0 * P.w_ctrl;
-    S.lu[((size_t)b * N + t) * H1_NU + lane] = g;
-    S.luu[((size_t)b * N + t) * H1_NU + lane] = h;
-  }
-  QSTAMP(5)
+  __syncthreads();
+  QSTAMP(1)
 
-  // ---- phase 6: Hessian lxx
-  double* Hg = S.lxx + ((size_t)b * (N + 1) + t) * H1_NX * H1_NX;
+  // ---- phase 2: Hessian lxx
+  double* Hg = S.lxx + ((size_t)b * N1 + t) * H1_NX * H1_NX;
   typedef double v4d_q __attribute__((ext_vector_type(4)));
   const int lr = lane & 15, lk = (lane >> 4) & 3;
-  // 6a: operands of the first-order product H1[a][b] = sum_k sA_k RA_k[a] RB_k[b], k = 4 ks + lk:
-  //   lk < 3 : row lk of the Jacobian of gradient-carrying functional ks (RA = RB, sA = its scale)
+  // 2a: operands of the first-order product H1[a][b] = sum_k sA_k RA_k[a] RB_k[b], k = 4 ks + lk:
+  //   lk < 3 : row lk of the Jacobian of gradient-carrying functional ks (RA = RB, sA = its scale; 0 when its term is off)
   //   lk = 3 : the balance dyads w (jr0 jr0' + jr1 jr1' + jz m' + m jz'): ks = 0 jr0, 1 jr1, 2 (jz, m), 3 (m, jz)
   // operand of row tile I / column tile J = entry 16 I + lr of the row; everything beyond column 50 and every unused row is
   // a true zero (junk operands slow the fp64 MFMA down tenfold)
   double av[4][2], bv[4][4];            // this wave's two row tiles wv, wv + 2 (balanced when only the tiles I >= J are wanted); all four column tiles
   {
-    double* const balm_ = &L.Om[0][0];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      const int ii = ks < ng ? ks : 0;
-      const double* rowJ = (L.gset[ii] == 0 ? (L.gvel[ii] ? &L.Jv[0][0] : &L.Jc[0][0]) : &L.Jf[L.gset[ii] - 1][0][0]) + (lk < 3 ? lk : 0) * H1_NX;
-      const double* rowA = lk < 3 ? rowJ : (ks == 0 ? L.jr[0] : (ks == 1 ? L.jr[1] : (ks == 2 ? L.Jc[2] : balm_)));
-      const double* rowB = lk < 3 ? rowJ : (ks == 0 ? L.jr[0] : (ks == 1 ? L.jr[1] : (ks == 2 ? balm_ : L.Jc[2])));
-      const bool used = lk < 3 ? (ks < ng) : (has_bal != 0);
-      const double sA = lk < 3 ? L.gscale[ii] : P.w_balance;
+      const double* rowJ = L.J[3 * ks + (lk < 3 ? lk : 0)];
+      const double* rowA = lk < 3 ? rowJ : (ks == 0 ? L.J[QJ_R0] : (ks == 1 ? L.J[QJ_R1] : (ks == 2 ? L.J[QJ_C + 2] : L.J[QJ_M])));
+      const double* rowB = lk < 3 ? rowJ : (ks == 0 ? L.J[QJ_R0] : (ks == 1 ? L.J[QJ_R1] : (ks == 2 ? L.J[QJ_M] : L.J[QJ_C + 2])));
+      const double sA = lk < 3 ? rec[QR_GSCALE + ks] : P.w_balance;
+      const bool used = lk < 3 ? (sA != 0.0) : (has_bal != 0);
 #pragma unroll
       for (int T = 0; T < 4; ++T) {
         const int e = 16 * T + lr, ec = e < H1_NX ? e : H1_NX - 1;
@@ -485,28 +588,17 @@ __global__ void __launch_bounds__(128, QUAD_WAVES) k_cost_quadratics(DevState S,
       }
     }
   }
-  QSTAMP(6)
+  QSTAMP(2)
   __syncthreads();   // the Jacobian rows are in registers: their storage becomes the second-order patch
   for (int e = lane; e < QS2_SIZE; e += 128) L.S2[e] = 0.0;
   __syncthreads();
-  // 6b: second-order part, block by block of the coordinate classes (a <= bb in every block).  The (merged) contexts'
-  // set / type are wave-uniform: held in scalar registers, so the loops over them branch uniformly.
+  // 2b: second-order part, block by block of the coordinate classes (a <= bb in every block).  The four functionals' point set and
+  // type are compile-time (slots 0, 1) or wave-uniform (the feet): the loops over them branch uniformly.
   auto patch = [&](int a, int bb, double h) { L.S2[QS2_IDX(a, bb)] = h; };
-  // triangular index -> (i, j), i <= j < n
-  auto tri = [](int idx, int n, int& i, int& j) {
-    int a = (int)((2 * n + 1 - sqrtf((float)((2 * n + 1) * (2 * n + 1) - 8 * idx))) * 0.5f);   // exact integers in fp32; corrected below
-    while ((a + 1) * n - ((a + 1) * a) / 2 <= idx) ++a;
-    while (a * n - (a * (a - 1)) / 2 > idx) --a;
-    i = a; j = a + (idx - (a * n - (a * (a - 1)) / 2));
-  };
   const int Q0 = 3, T0 = 7, V0 = H1_NQ, W0 = H1_NQ + 3, D0 = H1_NQ + 6, NJ = H1_NJ;
-  int cset[QMAXC], cvel[QMAXC];
-#pragma unroll
-  for (int c = 0; c < QMAXC; ++c) {
-    const int cc = c < nctx ? c : 0;
-    cset[c] = __builtin_amdgcn_readfirstlane(L.ctx[cc].set); cvel[c] = __builtin_amdgcn_readfirstlane(L.ctx[cc].is_vel);
-  }
-  // (theta, theta) and (theta, thetadot), related joints only (compile-time list): three passes of 64 entries
+  const int cset[4] = {0, 0, 1, 2};
+  const int cvel[4] = {0, 1, fvel[0], fvel[1]};
+  // (theta, theta) and (theta, thetadot), related joints only (compile-time list): two passes of 128 entries
   for (int e = lane; e < 158; e += 128) {
     const unsigned pk = QREL.e[e];
     const int ja = pk & 31, jb = (pk >> 5) & 31;
@@ -514,17 +606,16 @@ __global__ void __launch_bounds__(128, QUAD_WAVES) k_cost_quadratics(DevState S,
     const int lo = ja < jb ? ja : jb, hi = ja < jb ? jb : ja;     // parents precede their children in the body numbering
     double h = 0.0;
 #pragma unroll
-    for (int c = 0; c < QMAXC; ++c) {
-      if (c >= nctx) break;
+    for (int c = 0; c < 4; ++c) {
       const int st_ = cset[c];
-      const double f = (L.on[st_][ja] & L.on[st_][jb]) ? 1.0 : 0.0;
-      const double* tz = L.u.j.tz[c][lo - 1];
-      const double* wh = L.w[st_][hi];
+      const bool on = q_on(st_, ja) && q_on(st_, jb);
+      const double* tz = L.tz[c][lo - 1];
+      const double* wh = q_w(rec, st_, hi);
       const double t1 = dot3(tz, wh);
       double v;
-      if (cvel[c]) { const double t2 = dot3(L.u.j.Pp[c][lo - 1], wh) + dot3(tz, L.dgam[st_][hi]); v = isd ? t1 : t2; }
+      if (cvel[c]) { const double t2 = dot3(L.Pp[c >= 1 ? c - 1 : 0][lo - 1], wh) + dot3(tz, q_dg(rec, st_, hi)); v = isd ? t1 : t2; }
       else v = isd ? 0.0 : t1;
-      h += f * v;                                  // (the merged contexts carry their weight in vec: scale = 1)
+      h += on ? v : 0.0;                           // (the functionals carry their weight in vec: scale = 1)
     }
     patch(T0 + ja - 1, (isd ? D0 : T0) + jb - 1, h);
   }
@@ -535,15 +626,13 @@ __global__ void __launch_bounds__(128, QUAD_WAVES) k_cost_quadratics(DevState S,
     const int k = e / NJ, j = 1 + e % NJ;
     double h = 0.0;
 #pragma unroll
-    for (int c = 0; c < QMAXC; ++c) {
-      if (c >= nctx) break;
+    for (int c = 0; c < 4; ++c) {
       const int st_ = cset[c];
-      const double f = L.on[st_][j] ? 1.0 : 0.0;
-      const double* Dv = L.ctx[c].Dv[k];
+      const double* Dv = rec + QR_DV + 12 * c + 3 * k;
       double v;
-      if (cvel[c]) v = dot3(Dv, isd ? L.w[st_][j] : L.dgam[st_][j]);
-      else v = isd ? 0.0 : dot3(Dv, L.w[st_][j]);
-      h += f * v;
+      if (cvel[c]) v = dot3(Dv, isd ? q_w(rec, st_, j) : q_dg(rec, st_, j));
+      else v = isd ? 0.0 : dot3(Dv, q_w(rec, st_, j));
+      h += q_on(st_, j) ? v : 0.0;
     }
     patch(Q0 + k, (isd ? D0 : T0) + j - 1, h);
   }
@@ -552,13 +641,11 @@ __global__ void __launch_bounds__(128, QUAD_WAVES) k_cost_quadratics(DevState S,
     const int ja = 1 + lane / 3, cc = lane % 3;
     double h = 0.0;
 #pragma unroll
-    for (int c = 0; c < QMAXC; ++c) {
-      if (c >= nctx) break;
+    for (int c = 1; c < 4; ++c) {
       if (!cvel[c]) continue;
       const int st_ = cset[c];
-      const double f = L.on[st_][ja] ? 1.0 : 0.0;
-      double tv[3]; cross(L.w[st_][ja], L.ctx[c].til, tv);
-      h += f * sel3(tv, cc);
+      double tv[3]; cross(q_w(rec, st_, ja), rec + QR_TIL + 3 * c, tv);
+      h += q_on(st_, ja) ? sel3(tv, cc) : 0.0;
     }
     patch(T0 + ja - 1, W0 + cc, h);
   }
@@ -568,42 +655,42 @@ __global__ void __launch_bounds__(128, QUAD_WAVES) k_cost_quadratics(DevState S,
     const int k = e / 3, cc = e % 3;
     double h = 0.0;
 #pragma unroll
-    for (int c = 0; c < QMAXC; ++c) {
-      if (c >= nctx) break;
+    for (int c = 1; c < 4; ++c) {
       if (!cvel[c]) continue;
-      const QuadCtx& C = L.ctx[c];
       const int st_ = cset[c];
-      if (!isw) h += C.Dv[k][cc] * L.mfrac[st_];
-      else { double tv[3]; cross(L.beta[st_], C.Dv[k], tv); h += sel3(tv, cc); }   // Dv . (-[beta]x e_c) = (beta x Dv)_c
+      const double* Dv = rec + QR_DV + 12 * c + 3 * k;
+      if (!isw) h += sel3(Dv, cc) * rec[QR_MFRAC + st_];
+      else { double tv[3]; cross(rec + QR_BETA + 3 * st_, Dv, tv); h += sel3(tv, cc); }   // Dv . (-[beta]x e_c) = (beta x Dv)_c
     }
     patch(Q0 + k, (isw ? W0 : V0) + cc, h);
   } else if (lane >= 96 && lane < 106) {
-    // (quat, quat): d2R/dq2 terms + upright
-    int ka, kb; tri(lane - 96, 4, ka, kb);
+    // (quat, quat): d2R/dq2 terms + upright; triangular index -> (ka, kb), ka <= kb < 4
+    const int idx = lane - 96;
+    const int ka = idx < 4 ? 0 : (idx < 7 ? 1 : (idx < 9 ? 2 : 3));
+    const int kb = idx < 4 ? idx : (idx < 7 ? idx - 3 : (idx < 9 ? idx - 5 : 3));
     double h = 0.0;
     double D2[9]; d2R_sel(ka, kb, D2);
 #pragma unroll
-    for (int c = 0; c < QMAXC; ++c) {
-      if (c >= nctx) break;
-      const QuadCtx& C = L.ctx[c];
+    for (int c = 0; c < 4; ++c) {
       const int st_ = cset[c];
-      double tv[3]; mv3(D2, cvel[c] ? L.gamma[st_] : L.beta[st_], tv);
-      h += dot3(C.vec, tv);
+      double tv[3]; mv3(D2, cvel[c] ? rec + QR_GAMMA + 3 * st_ : rec + QR_BETA + 3 * st_, tv);
+      h += dot3(rec + QR_VEC + 3 * c, tv);
     }
     if (P.w_upright > 0.0) {
       const int i = ka, j = kb;
-      double v = L.uJ[0][i] * L.uJ[0][j] + L.uJ[1][i] * L.uJ[1][j] + L.uJ[2][i] * L.uJ[2][j];
-      if ((i == 0 && j == 2) || (i == 1 && j == 3)) v += 2.0 * L.ur[0];
-      if (i == 2 && j == 3) v += 2.0 * L.ur[1];
-      if (i == 0 && j == 1) v += -2.0 * L.ur[1];
-      if ((i == 1 && j == 1) || (i == 2 && j == 2)) v += -4.0 * L.ur[2];
+      const double* uJ = rec + QR_UJ; const double* ur = rec + QR_UR;
+      double v = uJ[i] * uJ[j] + uJ[4 + i] * uJ[4 + j] + uJ[8 + i] * uJ[8 + j];
+      if ((i == 0 && j == 2) || (i == 1 && j == 3)) v += 2.0 * ur[0];
+      if (i == 2 && j == 3) v += 2.0 * ur[1];
+      if (i == 0 && j == 1) v += -2.0 * ur[1];
+      if ((i == 1 && j == 1) || (i == 2 && j == 2)) v += -4.0 * ur[2];
       h += P.w_upright * v;
     }
     patch(Q0 + ka, Q0 + kb, h);
   }
   __syncthreads();
-  QSTAMP(7)
-  // 6c: first-order product row tile by row tile; the owner lane of an accumulator element (row 16 I + 4 r + lk, column
+  QSTAMP(3)
+  // 2c: first-order product row tile by row tile; the owner lane of an accumulator element (row 16 I + 4 r + lk, column
   // 16 J + lr) adds the diagonal terms and the patch entry of its (unordered) index pair and stores it: for a fixed
   // register the wave writes four rows x 16 consecutive columns
   const bool low = lower && !term;
@@ -634,12 +721,17 @@ __global__ void __launch_bounds__(128, QUAD_WAVES) k_cost_quadratics(DevState S,
       }
     }
   }
-  QSTAMP(8)
+  QSTAMP(4)
 }
 
 void launch_cost_quadratics(const DevState& S, const ProblemDev& P, int mode, hipStream_t st, int iter, int lower) {
   const WorkList w = work_list(S, mode, iter);
-  hipLaunchKernelGGL(k_cost_quadratics, dim3(S.N + 1, S.B), dim3(128), 0, st, S, P, mode, w.list, w.count, lower);
+  const long knots = (long)S.B * (S.N + 1);
+  // the per-knot kinematics run for every rollout a masked (stage-API) launch might select; inside a solve for the compacted list
+  hipLaunchKernelGGL(k_quad_kin, dim3((unsigned)((knots + 63) / 64)), dim3(64), 0, st, S, P, w.list, w.count, S.quad_rec, S.quad_knot0);
+  // one workgroup per knot; the grid is padded to a multiple of 8 so that every XCD's share (L % 8) has ceil(total / 8) slots
+  const long per = (knots + 7) / 8;
+  hipLaunchKernelGGL(k_cost_quadratics, dim3((unsigned)(per * 8)), dim3(128), 0, st, S, P, mode, w.list, w.count, lower, (const double*)S.quad_rec, S.quad_knot0);
 }
 
 }  // namespace ilqr

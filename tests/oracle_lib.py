@@ -45,18 +45,44 @@ def lib():
     return _lib
 
 
+_SELFTEST = """
+import ctypes as C, sys
+import numpy as np
+L = C.CDLL(sys.argv[1])
+L.orc_create.restype = C.c_void_p; L.orc_create.argtypes = [C.c_int, C.c_double]; L.orc_batch_solve.restype = C.c_long
+h = C.c_void_p(L.orc_create(6, C.c_double(0.02)))
+dp = C.POINTER(C.c_double)
+x0 = np.zeros((2, 51)); x0[:, 2] = 1.0432; x0[:, 3] = 1.0; x0[1, 7:26] = 0.05
+cost = np.zeros(2); it = np.zeros(2, dtype=np.int32); u0 = np.zeros((2, 19))
+n = L.orc_batch_solve(h, 2, x0.ctypes.data_as(dp), None, cost.ctypes.data_as(dp), it.ctypes.data_as(C.POINTER(C.c_int)), u0.ctypes.data_as(dp), None, 2)
+assert n > 0 and np.all(np.isfinite(cost))
+print("ok")
+"""
+
+
 def lib_native():
-    """The TIMED copy of the restatement (bench.py's cpu_baseline leg): the same sources built `-O3 -march=native` ON THIS HOST
-    (oracle/Makefile target build/liboracle_native.so; never shipped between machines).  Returns (library, flags string); falls
-    back to the portable checker build -- and says so in the flags string -- when the host build is not possible."""
+    """The TIMED copy of the restatement (bench.py's cpu_baseline leg): the same sources built host-tuned ON THIS HOST
+    (oracle/Makefile; never shipped between machines).  Candidates in order: `-O3 -march=native`, `-O3 -march=x86-64-v3`; each
+    is run once in a CHILD process on a tiny problem before it is loaded here (a build that crashes on this CPU -- seen with
+    g++ 11.4 -march=native on an EPYC 9575F -- must not take the bench down).  Returns (library, flags string); falls back to
+    the portable checker build, and says so, when no host-tuned build works."""
     global _lib_native
     if _lib_native is None:
-        so = os.path.join(ROOT, "oracle", "build", "liboracle_native.so")
-        try:
-            subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "build/liboracle_native.so"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-            _lib_native = (_declare(C.CDLL(so)), "g++ " + NATIVE_FLAGS + " -fopenmp (built on this host)")
-        except Exception as e:  # noqa: BLE001
-            _lib_native = (lib(), "g++ " + PORTABLE_FLAGS + " -fopenmp (portable checker build; the -march=native build failed: %r)" % (e,))
+        import sys
+        notes = []
+        for tag, flags in (("native", "-O3 -march=native"), ("v3", "-O3 -march=x86-64-v3")):
+            so = os.path.join(ROOT, "oracle", "build", "liboracle_%s.so" % tag)
+            try:
+                subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "build/liboracle_%s.so" % tag], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+                r = subprocess.run([sys.executable, "-c", _SELFTEST, so], capture_output=True, text=True, timeout=300)
+                if r.returncode != 0 or "ok" not in r.stdout:
+                    raise RuntimeError("self-test of the build exited with code %d" % r.returncode)
+                _lib_native = (_declare(C.CDLL(so)), "g++ %s -fopenmp (built and self-tested on this host%s)" % (flags, "; " + "; ".join(notes) if notes else ""))
+                break
+            except Exception as e:  # noqa: BLE001
+                notes.append("%s: %s" % (flags, e))
+        if _lib_native is None:
+            _lib_native = (lib(), "g++ " + PORTABLE_FLAGS + " -fopenmp (portable checker build; " + "; ".join(notes) + ")")
     return _lib_native
 
 

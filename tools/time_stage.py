@@ -34,10 +34,10 @@ for _ in range(reps):
 dt = (time.perf_counter() - t0) / reps
 print("%s: %.3f ms per call (host-timed, includes sync)  K checksum %.9e" % (stage, dt * 1e3, float(np.abs(s.gains_K()[::97]).sum())))
 if os.environ.get("ILQR_QSTAMPS"):
-    names = ["load x,u", "base kinematics (lane = body, level-synchronous)", "point sets (lane = set x body)", "jac columns", "contexts (lane = term x joint)", "gradient", "hessian: operand fetch", "hessian: second-order patch", "hessian: MFMA + store"]
-    st = s.cost()[:9]
+    names = ["record -> LDS", "jac columns + gradient || til x z, P'", "hessian: operand fetch", "hessian: second-order patch", "hessian: MFMA + store"]
+    st = s.cost()[:5]
     for nme, v in zip(names, st):
-        print("  %-24s %10.0f cycles  %5.1f %%" % (nme, v, 100 * v / st.sum()))
+        print("  %-44s %10.0f cycles  %5.1f %%" % (nme, v, 100 * v / st.sum()))
     print("  total %.0f cycles" % st.sum())
 if os.environ.get("ILQR_SSTAMPS"):
     names = ["loads + dx exchange", "K dx + reduce", "cost (+CoM; one-lane kernel only)", "dynamics step", "store x"]
