@@ -33,7 +33,7 @@ using namespace h1;
 namespace ilqr {
 
 #ifndef QUAD_WAVES
-#define QUAD_WAVES 5   // waves per SIMD requested from the register allocator (ten two-wave workgroups per CU)
+#define QUAD_WAVES 4   // waves per SIMD requested from the register allocator: 128 registers, no spills (at 5 the operands of the product, live across the patch phase, spill: 1.44 vs 1.19 ms per launch)
 #endif
 // -DQUAD_STAMP: diagnostic build only -- per-phase cycle counts of the workgroup of knot (0, 0) land in S.J[0..7]
 #ifdef QUAD_STAMP
@@ -190,10 +190,10 @@ template <int FIRST, int LEN, int FOOT, class Put> struct QChain {
 // One lane per knot.  `rec`: the record buffer (quad_rec_doubles); knot0: index of the view's first knot in it (batch slices).
 __global__ void __launch_bounds__(64) k_quad_kin(DevState S, ProblemDev P, const int* list, const int* count, double* rec, long knot0) {
   const int N1 = S.N + 1;
-  const long g = (long)blockIdx.x * 64 + threadIdx.x;
-  const long total = (long)(list ? *count : S.B) * N1;
+  const unsigned g = blockIdx.x * 64u + threadIdx.x;                    // (32-bit on purpose: a 64-bit division is ~150 scalar instructions)
+  const unsigned total = (unsigned)(list ? *count : S.B) * (unsigned)N1;
   if (g >= total) return;
-  const int bs = (int)(g / N1), t = (int)(g - (long)bs * N1);
+  const int bs = (int)(g / (unsigned)N1), t = (int)(g - (unsigned)bs * (unsigned)N1);
   const int b = list ? list[bs] : bs;
   const bool term = (t == S.N);
   const double* xg = S.xbar + ((size_t)b * N1 + t) * H1_NX;
@@ -416,6 +416,69 @@ DEVFN const double* q_dg(const double* rec, int st, int j) {
   return rec + QR_DGF + 15 * (st - 1) + 3 * k;
 }
 
+// 2c of k_cost_quadratics: the first-order product of this wave's two row tiles (I = WV, WV + 2) and the write-out.  The owner
+// lane of an accumulator element (row a = 16 I + 4 r + lk, column bb = 16 J + lr) adds the diagonal term and the second-order
+// patch entry of its (unordered) index pair and stores it: for a fixed register the wave writes four rows x 16 consecutive columns.
+// Everything that depends on the tile only -- is it on the diagonal, can it hold a patched pair (the smaller index must be a row
+// 3..25 of the patch), do all its rows / columns exist -- is decided at compile time, the lane-dependent rest by selects: written
+// with an `if` per element the 32 elements of a wave compiled to ~100 exec-masked branches (1140 instructions, 21 k of the
+// kernel's 51 k cycles per knot).
+typedef double v4d_q __attribute__((ext_vector_type(4)));
+DEVFN int q_rowbase(int x) { const int d = x - QS2_R0; return d * QS2_NC - (d * (d - 1)) / 2; }
+template <int I, int J>
+DEVFN void quad_tile_out(const v4d_q& acc, const double* S2, const double* dg, double* Hg, int lr, int lk, int rbc0, int rbc1) {
+  const int bb = 16 * J + lr;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    if (16 * I + 4 * r >= H1_NX) continue;                     // (compile-time after unrolling: rows beyond 50 do not exist)
+    const int a = 16 * I + 4 * r + lk;
+    double h = acc[r];
+    if (I == J) { const double d = dg[a < H1_NX ? a : 0]; h += (a == bb) ? d : 0.0; }
+    if (I < 2 || J < 2) {                                      // the pair's smaller index can be a patched row
+      bool cond; int idx;
+      if (I > J) { cond = J == 0 ? (lr >= QS2_R0) : (lr < QS2_R0 + QS2_NR - 16); idx = (J == 0 ? rbc0 : rbc1) + (a - bb); }
+      else if (I < J) { cond = (I == 0 ? (a >= QS2_R0) : (a < QS2_R0 + QS2_NR)) && bb < H1_NX; idx = q_rowbase(a) + (bb - a); }
+      else {
+        const bool a_lo = a < bb; const int lo = a_lo ? a : bb, df = a_lo ? bb - a : a - bb;
+        cond = I == 0 ? (lo >= QS2_R0) : (lo < QS2_R0 + QS2_NR);
+        idx = (a_lo ? q_rowbase(a) : (J == 0 ? rbc0 : rbc1)) + df;
+      }
+      const double pv = S2[cond ? idx : 0];
+      h += cond ? pv : 0.0;
+    }
+    const bool rows_ok = 16 * I + 4 * r + 3 < H1_NX, cols_ok = 16 * J + 15 < H1_NX;      // (compile-time)
+    if (rows_ok && cols_ok) Hg[a * H1_NX + bb] = h;
+    else if ((rows_ok || a < H1_NX) && (cols_ok || bb < H1_NX)) Hg[a * H1_NX + bb] = h;
+  }
+}
+template <int WV>
+DEVFN void quad_hessian_tiles(const double (&av)[4][2], const double (&bv)[4][4], const double* S2, const double* dg, double* Hg, bool low, int lr, int lk) {
+  // row base of this lane's column as the smaller index of a patched pair (clamped into the patch: masked where it is not one)
+  const int rbc0 = q_rowbase(lr < QS2_R0 ? QS2_R0 : lr), rbc1 = q_rowbase(16 + (lr < QS2_R0 + QS2_NR - 16 ? lr : QS2_R0 + QS2_NR - 17));
+#pragma unroll
+  for (int Ii = 0; Ii < 2; ++Ii) {
+    constexpr int I0 = WV;                                       // row tiles WV and WV + 2
+    v4d_q acc[4];
+#pragma unroll
+    for (int J = 0; J < 4; ++J) acc[J] = (v4d_q){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int J = 0; J < 4; ++J)
+        if (!(low && J > I0 + 2 * Ii)) acc[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ks][Ii], bv[ks][J], acc[J], 0, 0, 0);      // (wave-uniform)
+    if (Ii == 0) {
+      quad_tile_out<I0, 0>(acc[0], S2, dg, Hg, lr, lk, rbc0, rbc1);
+      if (!(low && 1 > I0)) quad_tile_out<I0, 1>(acc[1], S2, dg, Hg, lr, lk, rbc0, rbc1);
+      if (!low) { quad_tile_out<I0, 2>(acc[2], S2, dg, Hg, lr, lk, rbc0, rbc1); quad_tile_out<I0, 3>(acc[3], S2, dg, Hg, lr, lk, rbc0, rbc1); }
+    } else {
+      quad_tile_out<I0 + 2, 0>(acc[0], S2, dg, Hg, lr, lk, rbc0, rbc1);
+      quad_tile_out<I0 + 2, 1>(acc[1], S2, dg, Hg, lr, lk, rbc0, rbc1);
+      quad_tile_out<I0 + 2, 2>(acc[2], S2, dg, Hg, lr, lk, rbc0, rbc1);
+      if (!(low && 3 > I0 + 2)) quad_tile_out<I0 + 2, 3>(acc[3], S2, dg, Hg, lr, lk, rbc0, rbc1);
+    }
+  }
+}
+
 // Two waves per knot share the knot's LDS record.  `lane` runs over 0..127.
 // `lower` (inside a solve whose backward pass is the one-wave Riccati kernel): for the knots t < N only the tiles I >= J of lxx are
 // computed and stored -- exactly the ones k_backward_wave loads (load_aug<true>, riccati_wave.hip); lxx is symmetric, the six
@@ -427,11 +490,11 @@ __global__ void __launch_bounds__(128, QUAD_WAVES) k_cost_quadratics(DevState S,
                                                                      const double* recg, long knot0) {
   const int lane = threadIdx.x, wv = lane >> 6;
   const int N = S.N, N1 = N + 1;
-  const long total = (long)(list ? *count : S.B) * N1;
-  const long per = (total + 7) >> 3;
-  const long item = (long)(blockIdx.x & 7) * per + (blockIdx.x >> 3);
-  if ((long)(blockIdx.x >> 3) >= per || item >= total) return;
-  const int bs = (int)(item / N1), t = (int)(item - (long)bs * N1);
+  const unsigned total = (unsigned)(list ? *count : S.B) * (unsigned)N1;   // (32-bit on purpose: a 64-bit division is ~150 scalar instructions)
+  const unsigned per = (total + 7u) >> 3;
+  const unsigned item = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
+  if ((blockIdx.x >> 3) >= per || item >= total) return;
+  const int bs = (int)(item / (unsigned)N1), t = (int)(item - (unsigned)bs * (unsigned)N1);
   int b = bs;
   if (list) { b = list[bs]; mode = MASK_ALL; }     // compacted selection (DevState::order): no per-rollout flags to fetch
   const bool term = (t == N);
@@ -443,8 +506,9 @@ __global__ void __launch_bounds__(128, QUAD_WAVES) k_cost_quadratics(DevState S,
   const double* rec = L.rec;
 
   // ---- phase 0: the knot's record -> LDS.  The rollout's selection flags are requested together with the knot's data (indices
-  // clamped instead of predicated) and tested before anything is written
-  double xv;
+  // clamped instead of predicated) and tested before anything is written; so is everything phase 1 wants from HBM
+  const double* Qd = term ? P.Qf : P.Q;
+  double xv, xrv, qdv, uv = 0.0, urv = 0.0;
   {
     const int f1 = mode == MASK_ALL ? 1 : S.active[b], f2 = mode == MASK_RETRY ? S.need_retry[b] : 1;
     const long kn = knot0 + (long)b * N1 + t;
@@ -452,7 +516,10 @@ __global__ void __launch_bounds__(128, QUAD_WAVES) k_cost_quadratics(DevState S,
     double rv[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) { const int f = lane + 128 * k; rv[k] = rg[(size_t)(f < QREC_SIZE ? f : QREC_SIZE - 1) * QREC_GROUP]; }
-    xv = xg[lane < H1_NX ? lane : 0];
+    const int a = lane < H1_NX ? lane : 0;
+    xv = xg[a]; xrv = (P.x_ref + b * P.x_ref_stride + t * H1_NX)[a]; qdv = Qd[a];
+    const int l1 = lane - 64, iu = (l1 >= 0 && l1 < H1_NU) ? l1 : 0, tu = term ? N - 1 : t;
+    if (wv == 1) { uv = S.ubar[((size_t)b * N + tu) * H1_NU + iu]; urv = (P.u_ref + b * P.u_ref_stride + tu * H1_NU)[iu]; }
     if (!(f1 && f2)) return;
 #pragma unroll
     for (int k = 0; k < 4; ++k) { const int f = lane + 128 * k; if (f < QREC_SIZE) L.rec[f] = rv[k]; }
@@ -463,54 +530,67 @@ __global__ void __launch_bounds__(128, QUAD_WAVES) k_cost_quadratics(DevState S,
   const int* stq = P.stance + b * P.stance_stride + 2 * t;      // (wave-uniform: scalar loads)
   const int fvel[2] = {stq[0] == 1, stq[1] == 1};               // stance foot: the velocity functional; swing foot: the position one
   const int has_bal = __builtin_amdgcn_readfirstlane(rec[QR_HASBAL] != 0.0 ? 1 : 0);
-  const double* Qd = term ? P.Qf : P.Q;
 
-  // ---- phase 1.  wave 0, lane = coordinate: Jacobian columns (h1_cost_dev.h knot_jac_column), balance rows, gradient lx, diagonal;
-  //                wave 1, lane = (functional, joint): til x z_j, P'_j; then lu / luu
-  if (wv == 0) {
-    if (lane < H1_NX) {
-      const int c = lane;
-      const double* R0 = rec + QR_R0;
-      double jj[4][3];                 // this column of the four gradient-carrying Jacobians (slots 0..3)
-      double jc0[3] = {0, 0, 0}, jv0[3] = {0, 0, 0};
+  // ---- phase 1a: the Jacobian rows of the four functionals (h1_cost_dev.h knot_jac_column), lane = coordinate, one functional per
+  // wave and pass: wave 0 the CoM's d c then the left foot's, wave 1 the CoM's d cdot then the right foot's (a foot's rows are
+  // d cdot in stance, d c in swing).  One 3-vector per lane and pass; the functional's type is wave-uniform.
 #pragma unroll
-      for (int s = 0; s < 3; ++s) {
-        const double mfrac = rec[QR_MFRAC + s];
-        const double* beta = rec + QR_BETA + 3 * s; const double* gamma = rec + QR_GAMMA + 3 * s;
-        double jc[3] = {0, 0, 0}, jv[3] = {0, 0, 0};
-        if (c < 3) { jc[0] = c == 0 ? mfrac : 0.0; jc[1] = c == 1 ? mfrac : 0.0; jc[2] = c == 2 ? mfrac : 0.0; }
-        else if (c < 7) { mv3(rec + QR_D + 9 * (c - 3), beta, jc); mv3(rec + QR_D + 9 * (c - 3), gamma, jv); }
-        else if (c < H1_NQ) { const int j = c - 7 + 1; if (q_on(s, j)) { mv3(R0, q_w(rec, s, j), jc); mv3(R0, q_dg(rec, s, j), jv); } }
-        else {
+  for (int p = 0; p < 2; ++p) {
+    const int f = 2 * p + wv;                       // (wave-uniform)
+    const int s = f < 2 ? 0 : f - 1;
+    const bool isv = f == 1 || (f >= 2 && fvel[f >= 2 ? f - 2 : 0]);
+    const int c = lane & 63;
+    if (c < H1_NX) {
+      const double* R0 = rec + QR_R0;
+      const double mfrac = rec[QR_MFRAC + s];
+      double v3[3] = {0.0, 0.0, 0.0};
+      if (!isv) {
+        if (c < 3) { v3[0] = c == 0 ? mfrac : 0.0; v3[1] = c == 1 ? mfrac : 0.0; v3[2] = c == 2 ? mfrac : 0.0; }
+        else if (c < 7) mv3(rec + QR_D + 9 * (c - 3), rec + QR_BETA + 3 * s, v3);
+        else if (c < H1_NQ) { const int j = c - 7 + 1; if (q_on(s, j)) mv3(R0, q_w(rec, s, j), v3); }
+      } else {
+        if (c >= 3 && c < 7) mv3(rec + QR_D + 9 * (c - 3), rec + QR_GAMMA + 3 * s, v3);
+        else if (c >= 7 && c < H1_NQ) { const int j = c - 7 + 1; if (q_on(s, j)) mv3(R0, q_dg(rec, s, j), v3); }
+        else if (c >= H1_NQ) {
           const int cv = c - H1_NQ;
+          const double* beta = rec + QR_BETA + 3 * s;
           double col[3] = {0, 0, 0};
           if (cv < 3) { col[0] = cv == 0 ? mfrac : 0.0; col[1] = cv == 1 ? mfrac : 0.0; col[2] = cv == 2 ? mfrac : 0.0; }
           else if (cv < 6) {  // -[beta]x column
             const int k = cv - 3;
             if (k == 0) { col[1] = -beta[2]; col[2] = beta[1]; } else if (k == 1) { col[0] = beta[2]; col[2] = -beta[0]; } else { col[0] = -beta[1]; col[1] = beta[0]; }
           } else { const int j = cv - 6 + 1; if (q_on(s, j)) { const double* w = q_w(rec, s, j); col[0] = w[0]; col[1] = w[1]; col[2] = w[2]; } }
-          mv3(R0, col, jv);
-        }
-#pragma unroll
-        for (int r = 0; r < 3; ++r) {
-          if (s == 0) { jc0[r] = jc[r]; jv0[r] = jv[r]; jj[0][r] = jc[r]; jj[1][r] = jv[r]; L.J[QJ_C + r][c] = jc[r]; L.J[QJ_V + r][c] = jv[r]; }
-          else { const double v = fvel[s - 1] ? jv[r] : jc[r]; jj[1 + s][r] = v; L.J[QJ_F0 + 3 * (s - 1) + r][c] = v; }
+          mv3(R0, col, v3);
         }
       }
+#pragma unroll
+      for (int r = 0; r < 3; ++r) L.J[3 * f + r][c] = v3[r];
+    }
+  }
+  __syncthreads();
+  QSTAMP(1)
+  // ---- phase 1b.  wave 0, lane = coordinate: balance rows, gradient lx, diagonal;  wave 1, lane = (functional, joint): til x z_j,
+  //                 P'_j; then lu / luu
+  if (wv == 0) {
+    if (lane < H1_NX) {
+      const int c = lane, a = lane;
+      double jj[4][3];                 // this column of the four gradient-carrying Jacobians (slots 0..3)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 3; ++r) jj[i][r] = L.J[3 * i + r][c];
       // balance rows jr0, jr1 and m = om1 (r0 Jv0 + r1 Jv1) + rv om2 jz / 2 (zero rows when the term is off)
       const double* bal = rec + QR_BAL;
-      double jr0 = 0.0, jr1 = 0.0;
+      double jr0 = 0.0, jr1 = 0.0, jm = 0.0;
       if (has_bal) {
-        const double om = bal[2], om1 = bal[3], jz = jc0[2];
-        jr0 = jc0[0] + om * jv0[0] + bal[5] * om1 * jz;
-        jr1 = jc0[1] + om * jv0[1] + bal[6] * om1 * jz;
-        L.J[QJ_M][c] = bal[3] * (bal[0] * jv0[0] + bal[1] * jv0[1]) + 0.5 * bal[7] * bal[4] * jz;
-      } else L.J[QJ_M][c] = 0.0;
-      L.J[QJ_R0][c] = jr0; L.J[QJ_R1][c] = jr1;
+        const double om = bal[2], om1 = bal[3], jz = jj[0][2];
+        jr0 = jj[0][0] + om * jj[1][0] + bal[5] * om1 * jz;
+        jr1 = jj[0][1] + om * jj[1][1] + bal[6] * om1 * jz;
+        jm = bal[3] * (bal[0] * jj[1][0] + bal[1] * jj[1][1]) + 0.5 * bal[7] * bal[4] * jz;
+      }
+      L.J[QJ_R0][c] = jr0; L.J[QJ_R1][c] = jr1; L.J[QJ_M][c] = jm;
       // gradient lx
-      const int a = c;
-      const double* xr = P.x_ref + b * P.x_ref_stride + t * H1_NX;
-      double g = Qd[a] * (xv - xr[a]);   // Q acts on the MuJoCo-ordered state
+      double g = qdv * (xv - xrv);   // Q acts on the MuJoCo-ordered state
 #pragma unroll
       for (int i = 0; i < 4; ++i) { const double* gs = rec + QR_GSUM + 3 * i; g += jj[i][0] * gs[0] + jj[i][1] * gs[1] + jj[i][2] * gs[2]; }
       if (P.w_upright > 0.0 && a >= 3 && a < 7) {
@@ -518,7 +598,7 @@ __global__ void __launch_bounds__(128, QUAD_WAVES) k_cost_quadratics(DevState S,
         g += P.w_upright * (uJ[a - 3] * ur[0] + uJ[4 + a - 3] * ur[1] + uJ[8 + a - 3] * ur[2]);
       }
       if (has_bal) g += P.w_balance * (jr0 * bal[0] + jr1 * bal[1]);
-      double dgl = Qd[a];
+      double dgl = qdv;
       if (a >= 7 && a < H1_NQ) {
         double lo, hi; limit_bounds(H1_JRANGE[a - 7], lo, hi);
         const double q = xv;                           // (hinge slots are not permuted)
@@ -545,9 +625,8 @@ __global__ void __launch_bounds__(128, QUAD_WAVES) k_cost_quadratics(DevState S,
       }
     }
     if (!term && l1 < H1_NU) {
-      const double* ur_ = P.u_ref + b * P.u_ref_stride + t * H1_NU;
-      const double u = S.ubar[((size_t)b * N + t) * H1_NU + l1];
-      double g = P.R[l1] * (u - ur_[l1]), h = P.R[l1];
+      const double u = uv;
+      double g = P.R[l1] * (u - urv), h = P.R[l1];
       double lo, hi; limit_bounds(H1_CTRLRANGE[l1], lo, hi);
       if (u > hi) g += 2.0 * P.w_ctrl * (u - hi);
       if (u < lo) g += -2.0 * P.w_ctrl * (lo - u);
@@ -557,11 +636,10 @@ __global__ void __launch_bounds__(128, QUAD_WAVES) k_cost_quadratics(DevState S,
     }
   }
   __syncthreads();
-  QSTAMP(1)
+  QSTAMP(2)
 
   // ---- phase 2: Hessian lxx
   double* Hg = S.lxx + ((size_t)b * N1 + t) * H1_NX * H1_NX;
-  typedef double v4d_q __attribute__((ext_vector_type(4)));
   const int lr = lane & 15, lk = (lane >> 4) & 3;
   // 2a: operands of the first-order product H1[a][b] = sum_k sA_k RA_k[a] RB_k[b], k = 4 ks + lk:
   //   lk < 3 : row lk of the Jacobian of gradient-carrying functional ks (RA = RB, sA = its scale; 0 when its term is off)
@@ -588,7 +666,7 @@ __global__ void __launch_bounds__(128, QUAD_WAVES) k_cost_quadratics(DevState S,
       }
     }
   }
-  QSTAMP(2)
+  QSTAMP(3)
   __syncthreads();   // the Jacobian rows are in registers: their storage becomes the second-order patch
   for (int e = lane; e < QS2_SIZE; e += 128) L.S2[e] = 0.0;
   __syncthreads();
@@ -689,39 +767,14 @@ __global__ void __launch_bounds__(128, QUAD_WAVES) k_cost_quadratics(DevState S,
     patch(Q0 + ka, Q0 + kb, h);
   }
   __syncthreads();
-  QSTAMP(3)
+  QSTAMP(4)
   // 2c: first-order product row tile by row tile; the owner lane of an accumulator element (row 16 I + 4 r + lk, column
   // 16 J + lr) adds the diagonal terms and the patch entry of its (unordered) index pair and stores it: for a fixed
   // register the wave writes four rows x 16 consecutive columns
   const bool low = lower && !term;
-#pragma unroll
-  for (int Ii = 0; Ii < 2; ++Ii) {
-    const int I = wv + 2 * Ii;
-    v4d_q acc[4];
-#pragma unroll
-    for (int J = 0; J < 4; ++J) acc[J] = (v4d_q){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-      for (int J = 0; J < 4; ++J)
-        if (!(low && J > I)) acc[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ks][Ii], bv[ks][J], acc[J], 0, 0, 0);      // (wave-uniform)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int a = 16 * I + 4 * r + lk;
-      if (a >= H1_NX) continue;                        // rows beyond 50 do not exist (last row tile)
-#pragma unroll
-      for (int J = 0; J < 4; ++J) {
-        if (low && J > I) continue;
-        const int bb = 16 * J + lr;
-        double h = acc[J][r];
-        if (a == bb) h += L.dg[a];
-        const int lo2 = a < bb ? a : bb, hi2 = a < bb ? bb : a;
-        if (lo2 >= QS2_R0 && lo2 < QS2_R0 + QS2_NR && hi2 < H1_NX) h += L.S2[QS2_IDX(lo2, hi2)];
-        if (bb < H1_NX) Hg[a * H1_NX + bb] = h;
-      }
-    }
-  }
-  QSTAMP(4)
+  if (wv == 0) quad_hessian_tiles<0>(av, bv, L.S2, L.dg, Hg, low, lr, lk);
+  else quad_hessian_tiles<1>(av, bv, L.S2, L.dg, Hg, low, lr, lk);
+  QSTAMP(5)
 }
 
 void launch_cost_quadratics(const DevState& S, const ProblemDev& P, int mode, hipStream_t st, int iter, int lower) {

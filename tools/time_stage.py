@@ -34,8 +34,8 @@ for _ in range(reps):
 dt = (time.perf_counter() - t0) / reps
 print("%s: %.3f ms per call (host-timed, includes sync)  K checksum %.9e" % (stage, dt * 1e3, float(np.abs(s.gains_K()[::97]).sum())))
 if os.environ.get("ILQR_QSTAMPS"):
-    names = ["record -> LDS", "jac columns + gradient || til x z, P'", "hessian: operand fetch", "hessian: second-order patch", "hessian: MFMA + store"]
-    st = s.cost()[:5]
+    names = ["record -> LDS", "jacobian rows (both waves)", "gradient, balance rows || til x z, P'", "hessian: operand fetch", "hessian: second-order patch", "hessian: MFMA + store"]
+    st = s.cost()[:6]
     for nme, v in zip(names, st):
         print("  %-44s %10.0f cycles  %5.1f %%" % (nme, v, 100 * v / st.sum()))
     print("  total %.0f cycles" % st.sum())
