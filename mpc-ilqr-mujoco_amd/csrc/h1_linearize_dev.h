@@ -37,9 +37,9 @@ struct LinDump {
 };
 struct LinShared {
   LinDump D;
-  union {                        // 25 KB in all: six waves per CU
-    struct { double U[H1_NB][6], Dinv[H1_NB], IA0inv[36]; } m;      // Minv sweeps only: articulated-body U_i, 1 / D_i, pelvis inverse
-    struct { double part[4][6][19], part11[2][19]; } t;             // tangent sweeps only: pelvis / torso-hinge shares of the four
+  struct {                       // (a union until round 4: k_lin_tangent2 runs the outward Minv sweeps BESIDE the tangent sweeps)
+    struct { double U[H1_NB][6], Dinv[H1_NB], IA0inv[36]; } m;      // Minv sweeps: articulated-body U_i, 1 / D_i, pelvis inverse
+    struct { double part[4][6][19], part11[2][19]; } t;             // tangent sweeps: pelvis / torso-hinge shares of the four
   } u;                                                              // chain groups (LL, RL, torso+LA, torso+RA) per group slot
   double Minv[H1_NV * (H1_NV + 1) / 2];   // d qacc / d tau in MuJoCo coordinates: symmetric, lower triangle packed (MINV)
   double dT[H1_NV][LIN_LD];      // tangent generalized forces, then d qacc / d direction
@@ -677,6 +677,192 @@ DEVFN void lin_apply_minv_2(LinShared& L, int tid) {
       for (int J = 0; J < 3; ++J) L.dT[row][16 * J + lr] = acc[J][r];
     }
   }
+}
+
+// ---- two knots per four-wave workgroup (k_lin_tangent2, round 4) ---------------------------------------------------------------
+// The constraint-free step does not depend on the base's linear velocity (Galilean invariance: a uniform world-frame translation
+// velocity moves no force; d f / d v_lin = [h I; 0; I; 0] to 7e-17 on the oracle's forward-mode AD): the three v_lin directions
+// are not swept, their columns of dT stay zero and lin_column writes the constant columns.  A chain group then has 16 direction
+// slots instead of 19 -- 6 base directions (phi, omega) + its own hinges' angles and rates --, so 2 sides x 16 slots x TWO KNOTS
+// fill a wave exactly: wave 0 sweeps the legs of both knots, wave 1 torso + arms of both, with the instruction count one knot
+// needed before (38 of 64 lanes active).  The same packing for the Minv columns (2 x 25 lanes), the force accumulation
+// (2 x 20), the integrator prologue (2 x 1).  (The stance-constrained step DOES depend on v_lin through the foot's velocity
+// constraint: k_lin_tangent_c keeps the 19-slot groups.)
+DEVFN void slot_direction2(bool arms, bool side, int q, int& kind, int& idx) {
+  if (q < 3) { kind = DIR_PHI; idx = q; }
+  else if (q < 6) { kind = DIR_OMEGA; idx = q - 3; }
+  else if (!arms) { const int first = side ? 6 : 1; if (q < 11) { kind = DIR_THETA; idx = first + q - 6; } else { kind = DIR_THETADOT; idx = first + q - 11; } }
+  else {
+    const int first = side ? 16 : 12;
+    if (q == 6) { kind = DIR_THETA; idx = 11; } else if (q == 7) { kind = DIR_THETADOT; idx = 11; }
+    else if (q < 12) { kind = DIR_THETA; idx = first + q - 8; } else { kind = DIR_THETADOT; idx = first + q - 12; }
+  }
+}
+DEVFN int slot_in_group2(int c, int kind, int idx) {
+  if (kind == DIR_PHI) return idx;
+  if (kind == DIR_OMEGA) return 3 + idx;
+  const int off = kind == DIR_THETA ? 0 : 1;
+  if (c < 2) { const int first = c ? 6 : 1; return (idx >= first && idx < first + 5) ? 6 + 5 * off + (idx - first) : -1; }
+  if (idx == 11) return 6 + off;
+  const int first = c == 2 ? 12 : 16;
+  return (idx >= first && idx < first + 4) ? 8 + 4 * off + (idx - first) : -1;
+}
+// lane = (knot slot, side, direction slot): all 64 lanes sweep
+DEVFN void lin2_tangent_legs(LinShared* L2, int lane) {
+  LinShared& L = L2[lane >> 5];
+  const int grp = (lane >> 4) & 1, q = lane & 15;
+  const bool side = grp == 1;
+  int kind, idx; slot_direction2(false, side, q, kind, idx);
+  const int col = dir_lane(kind, idx);
+  double dv0[6], da0[6]; tan_base(L, kind, idx, dv0, da0);
+  double dFj[6] = {0, 0, 0, 0, 0, 0};
+  TanChain2<1, 6, 5>::run(L, side, kind, idx, dv0, da0, dFj, col);
+#pragma unroll
+  for (int k = 0; k < 6; ++k) L.u.t.part[grp][k][q] = dFj[k];
+}
+DEVFN void lin2_tangent_arms(LinShared* L2, int lane) {
+  LinShared& L = L2[lane >> 5];
+  const int grp = (lane >> 4) & 1, q = lane & 15;
+  const bool side = grp == 1;
+  int kind, idx; slot_direction2(true, side, q, kind, idx);
+  const int col = dir_lane(kind, idx);
+  double dv0[6], da0[6]; tan_base(L, kind, idx, dv0, da0);
+  double tv[6], ta[6], dF11[6];
+  tan_body_fwd<11>(L, kind, idx, dv0, da0, tv, ta, dF11);     // the torso's own force tangent: counted by the left group only
+  if (side) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) dF11[k] = 0.0;
+  }
+  TanChain2<12, 16, 4>::run(L, side, kind, idx, tv, ta, dF11, col);
+  double dFj[6] = {0, 0, 0, 0, 0, 0};
+  L.u.t.part11[grp][q] = tan_body_bwd<11>(L, side ? DIR_NONE : kind, idx, dF11, dFj);
+#pragma unroll
+  for (int k = 0; k < 6; ++k) L.u.t.part[2 + grp][k][q] = dFj[k];
+}
+// pelvis: own force tangent + the four chain shares, lane = direction (lane_direction numbering; the v_lin lanes 22..24 sit out)
+DEVFN void lin2_tangent_pelvis(LinShared& L, int lane) {
+  const LinDump& D = L.D;
+  int kind, idx; lane_direction(lane, kind, idx);
+  if (kind != DIR_NONE && kind != DIR_VLIN) {
+    double dv0[6], da0[6]; tan_base(L, kind, idx, dv0, da0);
+    double dF0[6];
+    {
+      double Ida[6], Idv[6], h[6], t1[6], t2[6];
+      h1r::inertia_mul<0>(da0, Ida); h1r::inertia_mul<0>(dv0, Idv);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) h[k] = L.Iv[0][k];
+      h1r::crf(dv0, h, t1); h1r::crf(D.v[0], Idv, t2);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) dF0[k] = Ida[k] + t1[k] + t2[k];
+    }
+    int qs[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) qs[c] = slot_in_group2(c, kind, idx);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      const double p2 = qs[2] >= 0 ? L.u.t.part[2][k][qs[2] < 0 ? 0 : qs[2]] : 0.0, p3 = qs[3] >= 0 ? L.u.t.part[3][k][qs[3] < 0 ? 0 : qs[3]] : 0.0;
+      const double p0 = qs[0] >= 0 ? L.u.t.part[0][k][qs[0] < 0 ? 0 : qs[0]] : 0.0, p1 = qs[1] >= 0 ? L.u.t.part[1][k][qs[1] < 0 ? 0 : qs[1]] : 0.0;
+      dF0[k] += ((p2 + p3) + p0) + p1;
+    }
+    L.dT[5 + 11][lane] = (qs[2] >= 0 ? L.u.t.part11[0][qs[2] < 0 ? 0 : qs[2]] : 0.0) + (qs[3] >= 0 ? L.u.t.part11[1][qs[3] < 0 ? 0 : qs[3]] : 0.0);
+    double fl[3] = {dF0[3], dF0[4], dF0[5]};
+    if (kind == DIR_PHI) {  // d(R0 f) = R0 (dphi x f + df)
+      double t[3]; cross_axis(D.F[0] + 3, idx, t);   // F x e_k = -(e_k x F)
+      fl[0] -= t[0]; fl[1] -= t[1]; fl[2] -= t[2];
+    }
+    double fw[3]; mv3(D.R0, fl, fw);
+    L.dT[0][lane] = fw[0]; L.dT[1][lane] = fw[1]; L.dT[2][lane] = fw[2];
+    L.dT[3][lane] = dF0[0]; L.dT[4][lane] = dF0[1]; L.dT[5][lane] = dF0[2];
+    if (kind == DIR_THETADOT) L.dT[5 + idx][lane] += H1_DAMPING;
+  }
+}
+// lin_accumulate_forces_w for two knots on one wave: lane = (knot slot, body)
+DEVFN void lin2_accumulate_forces_w(LinShared* L2, int lane) {
+  LinShared& L = L2[lane >> 5];
+  const int i = lane & 31;
+  int dep = -1, c0 = 0, c1 = 0, c2 = 0;
+  if (i < H1_NB) {
+    dep = H1_DEPTH[i];
+    if (i == 0) { c0 = 1; c1 = 6; c2 = 11; }
+    else if (i == 11) { c0 = 12; c1 = 16; }
+    else if (i != 5 && i != 10 && i != 15 && i != 19) c0 = i + 1;
+  }
+  for (int d = 4; d >= 0; --d) {
+    if (dep == d && c0) {
+      double acc[6];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) acc[k] = L.D.F[i][k];
+      xf_force_acc(L.D.Rj[c0], H1_POS[c0], L.D.F[c0], acc);
+      if (c1) xf_force_acc(L.D.Rj[c1], H1_POS[c1], L.D.F[c1], acc);
+      if (c2) xf_force_acc(L.D.Rj[c2], H1_POS[c2], L.D.F[c2], acc);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) L.D.F[i][k] = acc[k];
+    }
+    wave_sync();
+  }
+}
+// lin_minv_lane in two halves (lane = (knot slot, column)): the inward sweep and the pelvis solve, then -- behind the workgroup
+// barrier that releases the tangent sweeps of the other waves, so beside them -- the outward sweeps
+struct MinvCarry { MinvPath P; double a0[6]; };
+DEVFN void lin2_minv_in(LinShared& L, int c, MinvCarry& C) {
+  double p0[6] = {0, 0, 0, 0, 0, 0};
+  MinvPath& P = C.P;
+#pragma unroll
+  for (int d = 0; d < 6; ++d) { P.body[d] = -1; P.du[d] = 0.0; }
+  {
+    int i = (c >= 6) ? c - 5 : 0;        // current body on the path (0: done)
+    double acc[6] = {0, 0, 0, 0, 0, 0};
+    bool first = true;
+#pragma unroll
+    for (int d = 5; d >= 1; --d) {
+      if (i > 0 && H1_DEPTH[i] == d) {
+        const int ax = H1_AXIS[i];
+        const double du = (first ? 1.0 : 0.0) - (ax == 0 ? acc[0] : (ax == 1 ? acc[1] : acc[2]));
+        first = false;
+        P.body[d] = i; P.du[d] = du;
+        const double s = du * L.u.m.Dinv[i];
+        double pa[6];
+#pragma unroll
+        for (int r = 0; r < 6; ++r) { pa[r] = acc[r] + L.u.m.U[i][r] * s; acc[r] = 0.0; }
+        xf_force_acc(L.D.Rj[i], H1_POS[i], pa, acc);
+        i = H1_PARENT[i];
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 6; ++r) p0[r] = acc[r];
+  }
+  double rhs[6] = {-p0[0], -p0[1], -p0[2], -p0[3], -p0[4], -p0[5]};
+  if (c < 3) { rhs[3] += L.D.R0[3 * c]; rhs[4] += L.D.R0[3 * c + 1]; rhs[5] += L.D.R0[3 * c + 2]; }
+  else if (c < 6) rhs[c - 3] += 1.0;
+#pragma unroll
+  for (int r = 0; r < 6; ++r) { double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) s += L.u.m.IA0inv[6 * r + k] * rhs[k];
+    C.a0[r] = s; }
+  double lw[3]; mv3(L.D.R0, C.a0 + 3, lw);
+#pragma unroll
+  for (int r = 0; r < 3; ++r) if (r >= c) L.Minv[MINV_IDX(r, c)] = lw[r];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) if (3 + r >= c) L.Minv[MINV_IDX(3 + r, c)] = C.a0[r];
+}
+DEVFN void lin2_minv_out(LinShared& L, int c, const MinvCarry& C) {
+  const MinvPath& P = C.P;
+  double a11[6];
+  {  // torso outward
+    constexpr int I = 11, ax = h1c::C_AXIS[11];
+    const double r[3] = {h1c::C_POS[I][0], h1c::C_POS[I][1], h1c::C_POS[I][2]};
+    xf_motion(L.D.Rj[I], r, C.a0, a11);
+    double s = (P.body[1] == I) ? P.du[1] : 0.0;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) s -= L.u.m.U[I][q] * a11[q];
+    const double qdd = s * L.u.m.Dinv[I];
+    a11[ax] += qdd;
+    if (5 + I >= c) L.Minv[MINV_IDX(5 + I, c)] = qdd;
+  }
+  MinvChainOut<12, 4>::step<0>(L, P, a11, c);
+  MinvChainOut<16, 4>::step<0>(L, P, a11, c);
+  MinvChainOut<1, 5>::step<0>(L, P, C.a0, c);
+  MinvChainOut<6, 5>::step<0>(L, P, C.a0, c);
 }
 
 // uniform integrator quantities (one lane)

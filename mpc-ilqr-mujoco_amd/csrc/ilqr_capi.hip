@@ -63,6 +63,7 @@ struct ilqr_hip_ctx {
   int rolled_variant = -1;
   h1::DynParams rolled_dyn{};
   bool lxx_lower = false;    // S.lxx of the knots t < N holds the tiles I >= J only (last written inside a solve): getters mirror them
+  double ab_unfold_h = 0.0;  // != 0: rows 8..23 of S.A / S.Bm are unwritten (last solve: folded Riccati kernel); = e_r + h row (r + 25), rebuilt on demand
   double lin_fold_h = 0.0;   // step size h while S.A / S.Bm hold the analytic Jacobians (folded backward kernel), else 0
   std::string err;
   // profiling
@@ -436,6 +437,9 @@ static int enqueue_solve(ilqr_hip_ctx* c, const DevState& S, const h1::ProblemDe
   // the one-wave Riccati kernel reads only the tiles I >= J of lxx_t (t < N): the cost quadratics then leave the others unwritten
   const int lxx_lower = ilqr::variant_backward() == 2 ? 1 : 0;
   if (lxx_lower) c->lxx_lower = true;
+  // ... and, folded, never the rows 8..23 of A_t / B_t: the two-knot tangent kernel then leaves them unwritten
+  const int skip_fold_rows = (fold_h != 0.0 && ilqr::linearize_skips_fold_rows(P, c->jac_mode)) ? 1 : 0;
+  c->ab_unfold_h = skip_fold_rows ? fold_h : 0.0;
   if (gate) TRY(ensure_gate(c));
   c->iterations_enqueued = c->max_iter;
   for (int iter = 0; iter < c->max_iter; ++iter) {
@@ -471,7 +475,7 @@ static int enqueue_solve(ilqr_hip_ctx* c, const DevState& S, const h1::ProblemDe
     }
     { StageTimer T(c, 2, st2); ilqr::launch_cost_quadratics(S, P, sel_mode, st2, iter, lxx_lower); }
     HIPCHK(c, hipEventRecord(ev_join, st2));
-    { StageTimer T(c, 1, st); ilqr::launch_linearize(S, P, sel_mode, c->jac_mode, c->fd_eps, st, 3, iter); }
+    { StageTimer T(c, 1, st); ilqr::launch_linearize(S, P, sel_mode, c->jac_mode, c->fd_eps, st, 3, iter, skip_fold_rows); }
     // The re-rolled trajectory replaces xbar once the linearisation and the cost quadratics have read the old one.  The backward
     // pass reads neither: with the extra events the adoption runs on the rollout's stream beside it and only the line search waits.
     const bool adopt_aside = concurrent_roll && ev_lin && ev_adopt;
@@ -630,12 +634,14 @@ int ilqr_hip_set_trajectory(ilqr_hip_ctx* c, const double* xbar, const double* u
 #define STAGE_PRE if (!c) return ILQR_ERR_ARG; if (!c->initialized) return ILQR_ERR_STATE; enter(c)
 #define STAGE_POST HIPCHK(c, hipGetLastError()); HIPCHK(c, hipStreamSynchronize(c->stream)); return ILQR_OK
 int ilqr_hip_stage_rollout(ilqr_hip_ctx* c) { STAGE_PRE; ilqr::launch_rollout(c->S, c->P, ilqr::MASK_ALL, 1, 0, c->S.Jbase, c->stream); STAGE_POST; }
-int ilqr_hip_stage_linearize(ilqr_hip_ctx* c) { STAGE_PRE; ilqr::launch_linearize(c->S, c->P, ilqr::MASK_ALL, c->jac_mode, c->fd_eps, c->stream); c->lin_fold_h = ilqr::linearize_fold_h(c->P, c->jac_mode); STAGE_POST; }
+int ilqr_hip_stage_linearize(ilqr_hip_ctx* c) { STAGE_PRE; ilqr::launch_linearize(c->S, c->P, ilqr::MASK_ALL, c->jac_mode, c->fd_eps, c->stream); c->lin_fold_h = ilqr::linearize_fold_h(c->P, c->jac_mode); c->ab_unfold_h = 0.0; STAGE_POST; }
 int ilqr_hip_stage_cost_quadratics(ilqr_hip_ctx* c) { STAGE_PRE; if (!c->refs_set) return ILQR_ERR_STATE; ilqr::launch_cost_quadratics(c->S, c->P, ilqr::MASK_ALL, c->stream); c->lxx_lower = false; STAGE_POST; }
 int ilqr_hip_stage_backward_pass(ilqr_hip_ctx* c) {
   STAGE_PRE;
   // the last solve left only the tiles I >= J of lxx_t behind and this call may run a kernel family that reads the whole matrix
   if (c->lxx_lower && ilqr::variant_backward() != 2) { ilqr::launch_mirror_lxx(c->S, c->stream); c->lxx_lower = false; }
+  // ... and no rows 8..23 of A_t / B_t: every kernel but the folded one reads them
+  if (c->ab_unfold_h != 0.0) { ilqr::launch_unfold_rows(c->S, c->ab_unfold_h, c->stream); c->ab_unfold_h = 0.0; }
   ilqr::launch_backward(c->S, ilqr::MASK_ALL, c->stream, c->lin_fold_h);
   STAGE_POST;
 }
@@ -665,6 +671,7 @@ int ilqr_hip_stage_line_search(ilqr_hip_ctx* c, int* improved, double* new_cost,
 int ilqr_hip_get_linearization(ilqr_hip_ctx* c, double* A, double* Bm) {
   if (!c) return ILQR_ERR_ARG; enter(c);
   const size_t B = c->B, N = c->N;
+  if (c->ab_unfold_h != 0.0) { ilqr::launch_unfold_rows(c->S, c->ab_unfold_h, c->stream); c->ab_unfold_h = 0.0; HIPCHK(c, hipGetLastError()); }   // rows the last solve did not write
   HIPCHK(c, hipStreamSynchronize(c->stream));
   if (A) HIPCHK(c, hipMemcpy(A, c->S.A, B * N * ILQR_NX * ILQR_NX * sizeof(double), hipMemcpyDeviceToHost));
   if (Bm) HIPCHK(c, hipMemcpy(Bm, c->S.Bm, B * N * ILQR_NX * ILQR_NU * sizeof(double), hipMemcpyDeviceToHost));
@@ -677,6 +684,7 @@ int ilqr_hip_set_linearization(ilqr_hip_ctx* c, const double* A, const double* B
   HIPCHK(c, hipMemcpy(c->S.Bm, Bm, B * N * ILQR_NX * ILQR_NU * sizeof(double), hipMemcpyHostToDevice));
   c->initialized = true;
   c->lin_fold_h = 0.0;      // Jacobians of unknown origin: generic backward kernel
+  c->ab_unfold_h = 0.0;
   return ILQR_OK;
 }
 int ilqr_hip_get_quadratics(ilqr_hip_ctx* c, double* lx, double* lu, double* lxx, double* luu) {

@@ -59,7 +59,10 @@ struct DevState {
 
 void launch_rollout(const DevState& S, const h1::ProblemDev& P, int mode, int do_roll, int count_iter, double* cost_out, hipStream_t st);
 void launch_step(int count, const double* x, const double* u, const h1::DynParams& dyn, double* xn, hipStream_t st, int stance_l = 1, int stance_r = 1);
-void launch_linearize(const DevState& S, const h1::ProblemDev& P, int mode, int jac_mode, double eps, hipStream_t st, int phases = 3, int iter = -1);
+// skip_fold_rows != 0 (a solve whose backward pass is the folded one-wave Riccati kernel): rows 8..23 of A_t, B_t may stay unwritten
+void launch_linearize(const DevState& S, const h1::ProblemDev& P, int mode, int jac_mode, double eps, hipStream_t st, int phases = 3, int iter = -1, int skip_fold_rows = 0);
+int linearize_skips_fold_rows(const h1::ProblemDev& P, int jac_mode);
+void launch_unfold_rows(const DevState& S, double h, hipStream_t st);
 // lower != 0: knots t < N get only the tiles I >= J of lxx (what k_backward_wave loads); the stage API always asks for the full matrix
 void launch_cost_quadratics(const DevState& S, const h1::ProblemDev& P, int mode, hipStream_t st, int iter = -1, int lower = 0);
 // compacted list of the rollouts of a pass inside a solve (DevState::order), or nulls: MASK_ACTIVE at iteration iter -> list (iter, 0), MASK_RETRY -> (iter, 1)

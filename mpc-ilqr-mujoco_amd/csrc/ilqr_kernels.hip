@@ -137,6 +137,92 @@ __global__ void __launch_bounds__(128, 3) k_lin_tangent(DevState S, ProblemDev P
   LSTAMP(6)
 }
 
+// Round 4: TWO knots per four-wave workgroup (h1_linearize_dev.h "two knots per four-wave workgroup").  The one-knot kernel
+// above issued ~6600 vector instructions per knot with 47 / 38 / 25 of 64 lanes active and sat at 70 % VALU busy: it was bound by
+// its instruction count.  Without the three base-linear-velocity directions a chain group has 16 slots, so the lane-parallel
+// phases of two knots pack into one wave each:
+//   wave 0  force accumulation of both knots (2 x 20 lanes) | BAR | tangent sweeps of the legs of both knots (64 lanes)
+//   wave 1                                                  | BAR | tangent sweeps of torso + arms of both knots (64 lanes)
+//   wave 2  Minv columns of both knots, inward + pelvis     | BAR | ... outward sweeps (2 x 25 lanes), beside the tangent sweeps
+//   wave 3  integrator prologue of both knots (2 lanes)     | BAR |
+// then pelvis rows (wave = knot), the Minv product on the MFMA (wave = knot x row tile), the columns: A of knot 0 on wave 0,
+// A of knot 1 on wave 1, B of both knots on wave 2.  Work items are (selected rollout, knot) pairs in rollout-major order.
+// SKIP: inside a solve whose backward pass is the folded one-wave Riccati kernel the rows 8..23 of A_t and B_t -- hinge-position rows,
+// copies of their velocity rows through the integrator: row r = e_r + h row (r + 25) -- are read by nobody (riccati_wave.hip stage_A /
+// load_b0 with FOLD): they are not written (16 of 51 store instructions per column, 0.9 GB per launch at B = 4096); k_unfold_rows
+// rebuilds them for the getters and the other kernel families.
+template <bool SKIP>
+__global__ void __launch_bounds__(256, 3) k_lin_tangent2(DevState S, ProblemDev P, int mode, const int* list, const int* count) {
+  const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+  const int ks = tid >> 7, tid7 = tid & 127;                   // knot slot of this thread in the 128-thread phases
+  const unsigned N = (unsigned)S.N;
+  const unsigned total = (unsigned)(list ? *count : S.B) * N;
+  const unsigned it0 = 2u * blockIdx.x;
+  if (it0 >= total) return;
+  __shared__ LinShared L2[2];
+#ifdef LIN_STAMP
+  long long qlast = clock64();
+  const int t = (int)(it0 % N), b = (int)(it0 / N);
+#endif
+  // both slots always compute (an odd item count: slot 1 repeats slot 0's knot); `valid` gates the stores only
+  size_t knot[2]; bool valid[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const unsigned it = it0 + k < total ? it0 + k : it0;
+    const unsigned bs = it / N, tt = it - bs * N;
+    const int bb = list ? list[bs] : (int)bs;
+    knot[k] = (size_t)bb * N + tt;
+    bool ok = (it0 + k < total);
+    if (!list && mode != MASK_ALL) ok = ok && S.active[bb] != 0 && (mode != MASK_RETRY || S.need_retry[bb] != 0);
+    valid[k] = ok;
+  }
+  if (!valid[0] && !valid[1]) return;
+  {
+    const size_t kn = knot[ks];
+    const size_t bb = kn / N, tt = kn - bb * N;
+    lin_load_dump2(L2[ks], S.lin_dump + kn * LinDumpG_SIZE, tid7, S.xbar + (bb * (N + 1) + tt) * H1_NX, S.ubar + kn * H1_NU);
+    if (tid7 == 127) L2[ks].h = P.dyn.h;
+    for (int e = tid7; e < H1_NV * LIN_LD; e += 128) (&L2[ks].dT[0][0])[e] = 0.0;     // all rows: the v_lin columns are written by nobody
+  }
+  __syncthreads();
+  LSTAMP(0)
+  if (wv == 0) {
+    lin2_accumulate_forces_w(L2, lane);
+    LSTAMP(1)
+    __syncthreads();
+    lin2_tangent_legs(L2, lane);
+  } else if (wv == 1) {
+    __syncthreads();
+    lin2_tangent_arms(L2, lane);
+  } else if (wv == 2) {
+    MinvCarry C;
+    const int c = lane & 31;
+    LinShared& L = L2[lane >> 5];
+    if (c < H1_NV) lin2_minv_in(L, c, C);
+    __syncthreads();
+    if (c < H1_NV) lin2_minv_out(L, c, C);
+  } else {
+    if ((lane & 31) == 0) lin_prologue(L2[lane >> 5]);
+    __syncthreads();
+  }
+  __syncthreads();
+  LSTAMP(2)
+  if (wv < 2) lin2_tangent_pelvis(L2[wv], lane);
+  __syncthreads();
+  LSTAMP(3)
+  lin_apply_minv_2(L2[ks], tid7);
+  __syncthreads();
+  LSTAMP(4)
+  // each lane streams one column; for a fixed row the lanes write consecutive addresses
+  if (wv < 2) {
+    if (lane < H1_NX && valid[wv]) { double* Ag = S.A + knot[wv] * H1_NX * H1_NX; lin_column(L2[wv], 0, lane, [&](int r, double v) { if (!(SKIP && r >= 8 && r < 24)) Ag[r * H1_NX + lane] = v; }); }
+  } else if (wv == 2) {
+    const int k = lane >> 5, c = lane & 31;
+    if (c < H1_NU && valid[k]) { double* Bg = S.Bm + knot[k] * H1_NX * H1_NU; lin_column(L2[k], 1, c, [&](int r, double v) { if (!(SKIP && r >= 8 && r < 24)) Bg[r * H1_NU + c] = v; }); }
+  }
+  LSTAMP(5)
+}
+
 // Contact row f4: analytic Jacobians of the stance-constrained step (h1_linearize_contact_dev.h).  Same two-wave layout; the
 // primal dump is the free solve, the multipliers and the constrained accelerations are rebuilt here (twelve unit-wrench
 // lanes beside the 25 Minv lanes), the tangent sweeps carry the contact wrench as an external force and collect the
@@ -672,8 +758,8 @@ static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 // One copy per host thread: every C-ABI call refreshes the calling thread's copy on entry (ilqr_capi.hip enter()) and the
 // launchers it then calls read that same copy, so handles driven from different host threads (one thread and one handle per
 // GPU, tests/cpp/cpp_multi_gpu_demo.cpp) never write to shared state.
-struct Variants { int scalar_dyn, rollout_split, ls_split, backward, fold; };
-static thread_local Variants g_var = {0, ROLLOUT_SPLIT_DEFAULT, LS_SPLIT_DEFAULT, -1, 1};
+struct Variants { int scalar_dyn, rollout_split, ls_split, backward, fold, lin_one_knot; };
+static thread_local Variants g_var = {0, ROLLOUT_SPLIT_DEFAULT, LS_SPLIT_DEFAULT, -1, 1, 0};
 static int env_split(const char* var, int dflt) { const char* e = getenv(var); return !e ? dflt : (e[0] == 's' ? 1 : 0); }
 #ifndef BACKWARD_DEFAULT
 #define BACKWARD_DEFAULT 2
@@ -688,6 +774,8 @@ void refresh_variants() {
   e = getenv("ILQR_BACKWARD");
   g_var.backward = !e ? BACKWARD_DEFAULT : (e[0] == 'v') ? 1 : (e[0] == 'w' && e[1] == 'a') ? 2 : 0;
   g_var.fold = !(e && strstr(e, "generic"));
+  e = getenv("ILQR_LINT");                                // 1: the one-knot two-wave tangent kernel (cross-check of k_lin_tangent2)
+  g_var.lin_one_knot = (e && e[0] == '1') ? 1 : 0;
 }
 int variant_ls_split() { return g_var.ls_split; }
 int variant_rollout_split() { return g_var.rollout_split; }
@@ -703,16 +791,34 @@ void launch_step(int count, const double* x, const double* u, const DynParams& d
   hipLaunchKernelGGL(k_step, dim3(cdiv(count, 64)), dim3(64), 0, st, count, x, u, dyn, xn, stance_l, stance_r);
 }
 // phases: 1 = primal dump only, 2 = tangent sweeps / FD only, 3 = both
-void launch_linearize(const DevState& S, const ProblemDev& P, int mode, int jac_mode, double eps, hipStream_t st, int phases, int iter) {
+// constraint-free tangent kernel: two knots per four-wave workgroup (default) or, ILQR_LINT=1, the one-knot two-wave kernel
+static void launch_lin_tangent_free(const DevState& S, const ProblemDev& P, int mode, hipStream_t st, const WorkList& w, int skip_fold_rows) {
+  if (g_var.lin_one_knot) { hipLaunchKernelGGL(k_lin_tangent, dim3(S.N, S.B), dim3(128), 0, st, S, P, mode, w.list, w.count); return; }
+  const long items = (long)S.B * S.N;
+  if (skip_fold_rows) hipLaunchKernelGGL(k_lin_tangent2<true>, dim3((unsigned)((items + 1) / 2)), dim3(256), 0, st, S, P, mode, w.list, w.count);
+  else hipLaunchKernelGGL(k_lin_tangent2<false>, dim3((unsigned)((items + 1) / 2)), dim3(256), 0, st, S, P, mode, w.list, w.count);
+}
+// rows 8..23 of A_t and B_t from their velocity rows (k_lin_tangent2<true> left them unwritten): the same expression lin_column evaluates
+__global__ void __launch_bounds__(256) k_unfold_rows(DevState S, double h) {
+  const size_t knot = blockIdx.x;
+  double* Ag = S.A + knot * H1_NX * H1_NX;
+  double* Bg = S.Bm + knot * H1_NX * H1_NU;
+  for (int e = threadIdx.x; e < 16 * H1_NX; e += 256) { const int r = 8 + e / H1_NX, k = e % H1_NX; Ag[r * H1_NX + k] = ((k == r) ? 1.0 : 0.0) + h * Ag[(r + 25) * H1_NX + k]; }
+  for (int e = threadIdx.x; e < 16 * H1_NU; e += 256) { const int r = 8 + e / H1_NU, k = e % H1_NU; Bg[r * H1_NU + k] = 0.0 + h * Bg[(r + 25) * H1_NU + k]; }
+}
+void launch_unfold_rows(const DevState& S, double h, hipStream_t st) { hipLaunchKernelGGL(k_unfold_rows, dim3((unsigned)((size_t)S.B * S.N)), dim3(256), 0, st, S, h); }
+// does launch_linearize(..., skip_fold_rows = 1) leave rows 8..23 unwritten?  (only the two-knot constraint-free tangent kernel does)
+int linearize_skips_fold_rows(const ProblemDev& P, int jac_mode) { return (jac_mode == 0 && !P.dyn.contact && !g_var.lin_one_knot) ? 1 : 0; }
+void launch_linearize(const DevState& S, const ProblemDev& P, int mode, int jac_mode, double eps, hipStream_t st, int phases, int iter, int skip_fold_rows) {
   const WorkList w = work_list(S, mode, iter);
   if (jac_mode == 0 && !use_scalar_dyn()) {
     // primal dump: on two lanes per knot beside the two-lane rollout kernels, one lane per knot with ILQR_ROLLOUT=r
     if (phases & 1) { if (g_var.rollout_split || P.dyn.contact) launch_lin_primal_s(S, P, mode, st, w.list, w.count); else launch_lin_primal_r(S, P, mode, st); }   // (contact mode: the dump is the free solve, see k_lin_tangent_c)
     if ((phases & 2) && P.dyn.contact) hipLaunchKernelGGL(k_lin_tangent_c, dim3(S.N, S.B), dim3(128), 0, st, S, P, mode, w.list, w.count);
-    else if (phases & 2) hipLaunchKernelGGL(k_lin_tangent, dim3(S.N, S.B), dim3(128), 0, st, S, P, mode, w.list, w.count);
+    else if (phases & 2) launch_lin_tangent_free(S, P, mode, st, w, skip_fold_rows);
   } else if (jac_mode == 0 && !P.dyn.contact) {               // ILQR_DYN=s: the analytic kernels are constraint-free only
     if (phases & 1) launch_lin_primal_r(S, P, mode, st);
-    if (phases & 2) hipLaunchKernelGGL(k_lin_tangent, dim3(S.N, S.B), dim3(128), 0, st, S, P, mode, w.list, w.count);
+    if (phases & 2) launch_lin_tangent_free(S, P, mode, st, w, skip_fold_rows);
   } else if ((phases & 2) && !use_scalar_dyn()) {
     launch_linearize_fd_s(S, P, mode, eps, st);       // forward differences on the two-lane step (any contact mode)
   } else if (phases & 2) {

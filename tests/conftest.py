@@ -4,6 +4,14 @@ import sys
 
 import pytest
 
+# Some tests hand torch device buffers to the C ABI (the gather payload).  torch's wheel bundles its own HIP runtime: it has to be
+# the first one loaded in the process -- the product library then binds to it -- or a later torch.cuda initialisation finds "no HIP
+# GPUs" beside the runtime the product library already brought up (seen when a test selection starts with a torch-free test).
+try:
+    import torch  # noqa: F401
+except Exception:  # noqa: BLE001 -- the CPU-only suite does not need it
+    torch = None
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

@@ -212,6 +212,37 @@ def test_stage_backward_pass_on_another_kernel_family_after_a_solve_sees_the_who
     s.close()
 
 
+def test_rows_of_the_jacobians_the_folded_riccati_kernel_never_reads_are_rebuilt_on_demand():
+    """Inside a solve whose backward pass is the folded one-wave Riccati kernel the two-knot tangent kernel does not write the rows
+    8..23 of A_t / B_t (hinge-position rows = e_r + h x velocity row r + 25; riccati_wave.hip never fetches them).  The getter
+    rebuilds them: the result equals, to the last bits, what the one-knot kernel (ILQR_LINT=1, which writes every row and also
+    sweeps the three base-linear-velocity directions the two-knot kernel drops as analytically zero) leaves behind in the same
+    solve, and the structure holds exactly."""
+    B = 5
+    prob, x0, ui = standing(B, seed=37)
+    out = {}
+    for lint in ("0", "1"):
+        with env(ILQR_LINT=lint):
+            s = _solver(B); s.set_problem(prob); s.set_max_iterations(3); s.set_options(early_exit=False)
+            s.initialize(x0, ui); s.solve()
+            out[lint] = s.linearization() + (s.gains_K(), s.cost())
+            s.close()
+    A2, B2, K2, c2 = out["0"]; A1, B1, K1, c1 = out["1"]
+    h = prob["dt"]
+    assert np.all(np.isfinite(A2)) and np.all(np.isfinite(B2))
+    # the solves agree (the rows in question are read by nobody; the dropped directions are zero to 1e-16)
+    assert rel(K2, K1) < 1e-9 and rel(c2, c1) < 1e-12
+    assert np.abs(A2 - A1).max() < 1e-12 and np.abs(B2 - B1).max() < 1e-12
+    # structure of the rebuilt rows
+    r = np.arange(8, 24)
+    E = np.zeros((16, 51)); E[np.arange(16), r] = 1.0
+    assert np.abs(A2[:, :, 8:24, :] - (E + h * A2[:, :, 33:49, :])).max() < 1e-15
+    assert np.abs(B2[:, :, 8:24, :] - h * B2[:, :, 33:49, :]).max() < 1e-15
+    # base linear velocity columns: d f / d v_lin = [h I; 0; I; 0] exactly in the two-knot kernel
+    C = np.zeros((51, 3)); C[0:3] = h * np.eye(3); C[26:29] = np.eye(3)
+    assert np.array_equal(A2[:, :, :, 26:29], np.broadcast_to(C, A2[:, :, :, 26:29].shape))
+
+
 def test_early_exit_gate_stops_launching_and_changes_nothing():
     """With the convergence exit on, the host follows the device-side count of active rollouts and stops enqueuing iterations
     once the batch is done (ilqr_capi.hip enqueue_solve); the compacted work lists (DevState::order) feed the Riccati and

@@ -52,6 +52,12 @@ if os.environ.get("ILQR_LSTAMPS") and CONTACT:
     for nme, v in zip(names, st):
         print("  %-44s %10.0f cycles  %5.1f %%" % (nme, v, 100 * v / st.sum()))
     print("  total %.0f cycles" % st.sum())
+elif os.environ.get("ILQR_LSTAMPS") and os.environ.get("ILQR_LINT") != "1":
+    names = ["load dump (two knots)", "accumulate forces (wave 0, 2 x 20 lanes)", "tangent sweeps (64 lanes) || Minv outward", "pelvis rows", "apply Minv (MFMA)", "columns + store"]
+    st = s.cost()[:6]
+    for nme, v in zip(names, st):
+        print("  %-44s %10.0f cycles  %5.1f %%" % (nme, v, 100 * v / st.sum()))
+    print("  total %.0f cycles per PAIR of knots" % st.sum())
 elif os.environ.get("ILQR_LSTAMPS"):
     names = ["load dump", "accumulate forces (level-synchronous)", "prologue (one lane)", "Minv sweeps (25 lanes)", "tangent RNEA (47 lanes)", "apply Minv (MFMA)", "columns + store"]
     st = s.cost()[:7]
