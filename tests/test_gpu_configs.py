@@ -494,6 +494,12 @@ def test_config3_global_batch_of_32768_on_one_device():
     xb = s2.xbar(); K = s2.gains_K(); tc2 = s2.trace()[0]; it2 = s2.iterations()
     assert np.abs(np.linalg.norm(xb[:, :, 3:7], axis=2) - 1).max() < 1e-12
     s2.close()
+    # 32 rollouts spread over the global batch on the oracle's OpenMP batch: final cost, iteration count, first control, first gain
+    spot = [int(i) for i in np.linspace(0, B - 1, 32)]
+    ob = ol.Oracle(N, prob["dt"]); ob.set_problem(prob); ob.set_options(max_iter=iters)
+    _, oc32, oit32, ou0, oK0 = ob.batch_solve(x0[spot], ui[spot], nthreads=0, want_gains=True)
+    assert np.array_equal(oit32, it[spot]) and np.allclose(oc32, cost[spot], rtol=1e-5, atol=0)
+    assert rel(rows[spot, :19], ou0) < 1e-5 and rel(rows[spot, 20:].reshape(32, 19, 51), oK0) < 1e-5
     for j, b in enumerate(pick[:2]):
         o = ol.Oracle(N, prob["dt"]); o.set_problem(prob); o.set_options(max_iter=iters)
         o.initialize(x0[b], ui[b]); ok, c = o.solve(x0[b])

@@ -228,6 +228,75 @@ def test_full_solve_parity_trace_and_gains(walking, gravity, seed):
     s.close()
 
 
+def _bench_batch(seed=0, gravity=None, B=4096, N=25):
+    """The batch bench.py times (scenario.synthetic_batch of the WHOLE batch: a rollout's inputs depend on its index in it)."""
+    from mpc_ilqr_mujoco_amd import solver as sv
+    prob = sc.make_problem(sv.reference_kinematics, N=N, gravity=gravity)
+    ug = sv.gravity_compensation(sc.standing_state(), prob["gravity"])
+    x0, ui = sc.synthetic_batch(B, N, seed, ug)
+    return prob, x0, ui
+
+
+def test_the_mode_the_bench_times_fixed_ten_iterations_analytic_vs_oracle():
+    """The headline configuration exactly as bench.py runs it -- analytic Jacobians, early_exit = 0, max_iter = 10, rollouts of the
+    seed-0 bench batch -- against the oracle: the FULL cost trace, every accepted step size, the lambda schedule and the final
+    gains.  Iterations 4..9 of these rollouts are the fail -> lambda x 10 -> retry -> fail -> `continue` chain of ilqr.cpp:619-644
+    with lambda saturating at 1e-3: a quarter of the timed work."""
+    prob, x0g, uig = _bench_batch()
+    pick = list(range(12)) + [777, 2048, 3333, 4095]
+    x0, ui = x0g[pick], uig[pick]
+    B = len(pick)
+    from mpc_ilqr_mujoco_amd import solver as sv
+    s = _solver(B); s.set_problem(prob); s.set_max_iterations(10)
+    s.set_options(jacobian_mode=sv.JAC_ANALYTIC, early_exit=False)
+    s.initialize(x0, ui)
+    cost = s.solve(x0)
+    tc, ta, tl = s.trace()
+    K, kff, xb, ub, it, lam = s.gains_K(), s.gains_kff(), s.xbar(), s.ubar(), s.iterations(), s.lambdas()
+    assert np.all(it == 10) and s.adopt_mismatches() == 0
+    saw_saturation = saw_retry_chain = False
+    for b in range(B):
+        o = oracle_for(prob, jac_mode=0, early_exit=0, max_iter=10)
+        o.initialize(x0[b], ui[b]); ok, c = o.solve(x0[b])
+        n, oc, oa, olam = o.trace()
+        assert n == 10
+        assert np.allclose(tc[b], oc, rtol=1e-5, atol=0), (b, tc[b], oc)
+        assert np.array_equal(ta[b], oa), (b, ta[b], oa)                       # accepted step sizes (0 = both searches failed)
+        assert np.allclose(tl[b], olam, rtol=1e-12, atol=0), (b, tl[b], olam)
+        assert abs(cost[b] - c) <= 1e-5 * abs(c) and abs(lam[b] - o.get_lambda()) < 1e-18
+        assert rel(K[b], o.get("K")) < 1e-5 and rel(kff[b], o.get("kff")) < 1e-5
+        assert rel(xb[b], o.get("xbar")) < 1e-5 and rel(ub[b], o.get("ubar")) < 1e-5
+        saw_saturation |= bool(np.any(olam >= 1e-3 * (1 - 1e-12)) or o.get_lambda() >= 1e-3 * (1 - 1e-12))
+        saw_retry_chain |= bool(np.sum(oa[4:] == 0.0) >= 3)
+    assert saw_saturation and saw_retry_chain      # the chain the docstring names is really exercised by these rollouts
+    s.close()
+
+
+def test_the_contact_leg_of_the_bench_fixed_ten_iterations_vs_oracle():
+    """bench.py's `contact` object: gravity -9.81, both feet scheduled in stance, contact mode 2 (unilateral), analytic Jacobians of
+    the constrained step, 10 fixed iterations -- the same rollouts on the oracle (its forward-mode AD through the constrained step)."""
+    prob, x0g, uig = _bench_batch(gravity=(0.0, 0.0, -9.81))
+    pick = [0, 1, 777, 4095]
+    x0, ui = x0g[pick], uig[pick]
+    B = len(pick)
+    from mpc_ilqr_mujoco_amd import solver as sv
+    s = _solver(B); s.set_problem(prob); s.set_contact_mode(2); s.set_max_iterations(10)
+    s.set_options(jacobian_mode=sv.JAC_ANALYTIC, early_exit=False)
+    s.initialize(x0, ui)
+    cost = s.solve(x0)
+    tc, ta, tl = s.trace()
+    K, it = s.gains_K(), s.iterations()
+    assert np.all(it == 10) and s.adopt_mismatches() == 0
+    for b in range(B):
+        o = oracle_for(prob, jac_mode=0, early_exit=0, max_iter=10); o.set_contact_mode(2)
+        o.initialize(x0[b], ui[b]); ok, c = o.solve(x0[b])
+        n, oc, oa, olam = o.trace()
+        assert n == 10 and np.allclose(tc[b], oc, rtol=1e-5, atol=0), (b, tc[b], oc)
+        assert np.array_equal(ta[b], oa) and np.allclose(tl[b], olam, rtol=1e-12, atol=0)
+        assert abs(cost[b] - c) <= 1e-5 * abs(c) and rel(K[b], o.get("K")) < 1e-5
+    s.close()
+
+
 def test_fixed_iteration_mode_and_fd_mode_parity():
     B = 3
     prob, x0, ui = make(B, seed=6)
@@ -626,16 +695,21 @@ def test_bench_size_properties():
     assert np.array_equal(xb[:, 0], x0)
     # batch invariance: any rollout solved alone gives bit-identical results (no cross-rollout coupling)
     pick = [0, 1, 777, 2048, 4095]
-    K_all = s.gains_K()[pick]
+    Kfull = s.gains_K()
+    K_all = Kfull[pick]; K0_all = Kfull[:, 0].copy(); ub_all = s.ubar()
+    del Kfull
     s.close()
     s2 = _solver(len(pick)); s2.set_problem(prob)
     s2.initialize(x0[pick], ui[pick]); c2 = s2.solve(x0[pick])
     assert np.array_equal(c2, cost[pick]) and np.array_equal(s2.gains_K(), K_all)
-    # spot-check against the oracle
-    o = oracle_for(prob)
-    o.initialize(x0[777], ui[777]); ok, c = o.solve(x0[777])
-    assert abs(c - cost[777]) <= 1e-5 * abs(c)
     s2.close()
+    # spot-check against the oracle: 32 rollouts spread over the batch through its OpenMP batch (final cost, iteration count,
+    # first control, first-knot gain)
+    spot = [int(i) for i in np.linspace(0, B - 1, 32)]
+    o = oracle_for(prob)
+    _, oc, oit, ou0, oK0 = o.batch_solve(x0[spot], ui[spot], nthreads=0, want_gains=True)
+    assert np.array_equal(oit, it[spot]) and np.allclose(oc, cost[spot], rtol=1e-5, atol=0)
+    assert rel(ub_all[spot, 0], ou0) < 1e-5 and rel(K0_all[spot], oK0) < 1e-5
 
 
 def test_bench_contract_json_line():
