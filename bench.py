@@ -50,6 +50,12 @@ def workload_label(args, B, N, iters, world, gravity):
     """Names a BASELINE.json config only when (batch, horizon, stage, contact, iterations) IS that config; else 'custom: ...'."""
     body = ("batch=%d/GPU full iLQR (rollout+Jacobians+cost quadratics+Riccati+8-alpha line search), H1 standing balance, N=%d, dt=0.02, "
             "%d fixed iterations per rollout, shipped config.yaml weights, gravity %s" % (B, N, iters, list(gravity)))
+    if getattr(args, "workload", "default") == "config3" and world == 1:
+        return "global batch of BASELINE.json configs[3] (32768 rollouts) on ONE GPU: " + body
+    if getattr(args, "workload", "default") == "config4" and world == 1:
+        return ("global batch of BASELINE.json configs[4] on ONE GPU: batch=%d windows of the H1 walking reference (data/h1_walking_pin.csv rows), N=%d, dt=0.02, per-rollout references and "
+                "contact schedule (contact-scheduled costs), unilateral rigid stance constraints on the scheduled feet (contact mode 2), analytic Jacobians of the constrained step, "
+                "%d fixed iterations per rollout, shipped config.yaml weights, gravity %s" % (B, N, iters, list(gravity)))
     if args.contact:
         return "custom (contact row f4: unilateral rigid stance on the scheduled feet): " + body
     if B == 4096 and N == 25 and iters == 10:
@@ -83,6 +89,10 @@ def parse():
     ap.add_argument("--contact", action="store_true",
                     help="not the headline: contact row f4 (unilateral rigid stance on the scheduled feet, physical gravity -9.81, two-lane kernels, analytic Jacobians of the constrained step)")
     ap.add_argument("--no-contact-line", action="store_true", help="skip the short contact-mode measurement added to the default line")
+    ap.add_argument("--workload", choices=["default", "config3", "config4"], default="default",
+                    help="default: --batch / --horizon as given (BASELINE configs[2] by default).  config3 / config4: the GLOBAL batch of BASELINE.json "
+                         "configs[3] (32768 standing rollouts, N = 25) / configs[4] (8192 windows of the H1 walking reference, N = 50, contact-scheduled "
+                         "costs, unilateral stance constraints) on ONE GPU -- the N = 1 anchors of the 8-GPU scaling series")
     return ap.parse_args()
 
 
@@ -263,6 +273,13 @@ def main():
         return
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
+    if args.workload != "default":
+        if args.gpus != 1:
+            raise SystemExit("--workload config3 / config4 are the one-GPU anchors (the whole global batch on one device); the 8-GPU points are --gpus 8 with the default workload")
+        args.batch, args.horizon = (32768, 25) if args.workload == "config3" else (8192, 50)
+        args.no_contact_line = True
+        if args.workload == "config4":
+            args.contact = True          # (contact mode 2 with the walking problem's own gravity, see below)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args))
     import torch
@@ -291,14 +308,21 @@ def main():
     sc = pkg.scenario
     B, N, iters = args.batch, args.horizon, args.iters
 
-    prob = sc.make_problem(sv.reference_kinematics, N=N, gravity=(0.0, 0.0, -9.81)) if args.contact else sc.make_problem(sv.reference_kinematics, N=N)
-    ug = sv.gravity_compensation(sc.standing_state(), prob["gravity"])
-    # ONE seeded global batch of world x B rollouts; rank r owns the contiguous range shard_range gives it,
-    # so a rollout's inputs -- and therefore its results -- do not depend on the number of GPUs
-    x0g, uig = sc.synthetic_batch(B * world, N, args.seed, ug)
-    lo, hi = sh.shard_range(B * world, rank, world)
-    x0, ui = np.ascontiguousarray(x0g[lo:hi]), np.ascontiguousarray(uig[lo:hi])
-    del x0g, uig
+    if args.workload == "config4":
+        # the same builder the -m gpu test of configs[4] uses (tests/test_gpu_configs.py walking_problem): 8192 windows, per-rollout sets
+        from mpc_ilqr_mujoco_amd import references as rf
+        prob, x0, ui, _t0 = sc.walking_batch(B, N, args.seed, os.path.join(ROOT, "tests", "golden", "refdata_golden.npz"), sv, rf)
+        x0, ui = np.ascontiguousarray(x0), np.ascontiguousarray(ui)
+        lo, hi = 0, B
+    else:
+        prob = sc.make_problem(sv.reference_kinematics, N=N, gravity=(0.0, 0.0, -9.81)) if args.contact else sc.make_problem(sv.reference_kinematics, N=N)
+        ug = sv.gravity_compensation(sc.standing_state(), prob["gravity"])
+        # ONE seeded global batch of world x B rollouts; rank r owns the contiguous range shard_range gives it,
+        # so a rollout's inputs -- and therefore its results -- do not depend on the number of GPUs
+        x0g, uig = sc.synthetic_batch(B * world, N, args.seed, ug)
+        lo, hi = sh.shard_range(B * world, rank, world)
+        x0, ui = np.ascontiguousarray(x0g[lo:hi]), np.ascontiguousarray(uig[lo:hi])
+        del x0g, uig
     s = sv.BatchedILQR(B, N=N, dt=prob["dt"], device=local_rank)
     s.set_problem(prob)
     s.set_max_iterations(iters)
@@ -602,7 +626,9 @@ def main():
         }
         if contact_line is not None:
             out["contact"] = contact_line
-        if not args.no_cpu_baseline and world == 1:   # the CPU baseline is timed on rank 0 of the one-GPU run only
+        if args.workload == "config4":
+            out["cpu_baseline"] = None     # (the oracle's OpenMP batch shares ONE reference set; per-rollout windows are checked rollout by rollout in the -m gpu tests)
+        elif not args.no_cpu_baseline and world == 1:   # the CPU baseline is timed on rank 0 of the one-GPU run only
             try:
                 out["cpu_baseline"] = cpu_baseline(pkg, prob, x0, ui, iters, args.cpu_seconds, contact=args.contact)
             except Exception as e:  # the oracle is optional test infrastructure

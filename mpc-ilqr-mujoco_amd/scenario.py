@@ -94,3 +94,37 @@ def synthetic_batch(B, N, seed, u_gravcomp):
     u = np.asarray(u_gravcomp, dtype=np.float64)[None, None, :] + rng.uniform(-1.0, 1.0, size=(B, N, NU))
     u = np.clip(u, -0.8 * CTRLRANGE, 0.8 * CTRLRANGE)
     return x0, u
+
+
+def walking_batch(B, N, seed, refdata_npz, sv, rf):
+    """BASELINE.json configs[4]: B receding-horizon windows of the H1 walking reference (data/h1_walking_pin.csv rows, shipped as
+    the fixture tests/golden/refdata_golden.npz), each with its own references and contact schedule: offline preparation as
+    references.prepare_reference does it (Pinocchio -> MuJoCo quaternion order, velocities, stance flags from the foot hull),
+    window start t0 drawn per rollout, initial state = the reference row perturbed, gravity-compensation controls + noise.
+    `sv` = the solver module (host kinematics), `rf` = the references module.  Returns (problem with per-rollout sets, x0, u_init, t0)."""
+    r = np.load(refdata_npz)
+    q_mj = rf.pinocchio_to_mujoco(r["walking_pin_rows"])
+    v = rf.differentiate_positions(q_mj, float(r["dt"]))
+    flags = rf.contact_schedule(q_mj, sv.foot_clearance)
+    rd = rf.ReferenceData(sv.reference_kinematics, sv.reference_com_velocity)
+    rd.set_states(np.concatenate([q_mj, v], axis=1)); rd.contact = flags
+    T = q_mj.shape[0]
+    base = make_problem(sv.reference_kinematics, N=N, gravity=(0.0, 0.0, -1.0))
+    rng = np.random.default_rng(seed)
+    t0 = rng.integers(0, T - N - 1, size=B)
+    probs = {}
+    keys = ("x_ref", "u_ref", "com_ref", "stance", "ee_ref", "com_vel_ref")
+    stacks = {k: [] for k in keys}
+    for b in range(B):
+        if int(t0[b]) not in probs:
+            probs[int(t0[b])] = rd.problem_at(int(t0[b]), N, base, follow_schedule=True)
+        for k in keys:
+            stacks[k].append(probs[int(t0[b])][k][0])
+    prob = dict(base); prob["N"] = N
+    for k in keys:
+        prob[k] = np.stack(stacks[k])
+    x0 = rd.x_ref[t0].copy()
+    x0[:, 7:26] += rng.uniform(-0.02, 0.02, (B, 19)); x0[:, 0:3] += rng.uniform(-0.01, 0.01, (B, 3)); x0[:, 26:] *= 0.5
+    ug = sv.gravity_compensation(standing_state(), prob["gravity"])
+    ui = np.tile(ug, (B, N, 1)) + rng.uniform(-0.5, 0.5, (B, N, 19))
+    return prob, x0, ui, t0

@@ -386,38 +386,14 @@ def test_config1_rollout_and_jacobians_at_1024():
 # BASELINE.json configs[4] at its per-GPU shape: B = 1024, N = 50, walking windows cut from the reference's walking file with
 # per-rollout start rows t0, contact-scheduled cost terms
 def walking_problem(B, N, seed):
+    """scenario.walking_batch (shared with bench.py --workload config4) + the check that the contact-schedule tool reproduces the
+    clearance signs stored with the fixture."""
     from mpc_ilqr_mujoco_amd import references as rf
     from mpc_ilqr_mujoco_amd import solver as sv
     r = np.load(os.path.join(G, "refdata_golden.npz"))
-    # rows of data/h1_walking_pin.csv (Pinocchio quaternion order) -> MuJoCo order, velocities, stance flags: the offline
-    # preparation of references.prepare_reference, row for row
-    q_pin = r["walking_pin_rows"]
-    q_mj = rf.pinocchio_to_mujoco(q_pin)
-    v = rf.differentiate_positions(q_mj, float(r["dt"]))
-    flags = rf.contact_schedule(q_mj, sv.foot_clearance)
+    flags = rf.contact_schedule(rf.pinocchio_to_mujoco(r["walking_pin_rows"]), sv.foot_clearance)
     assert np.array_equal(flags, (r["walking_pin_clearance"] < 0).astype(np.int32))
-    rd = rf.ReferenceData(sv.reference_kinematics, sv.reference_com_velocity)
-    rd.set_states(np.concatenate([q_mj, v], axis=1)); rd.contact = flags
-    T = q_mj.shape[0]
-    base = sc.make_problem(sv.reference_kinematics, N=N, gravity=(0.0, 0.0, -1.0))
-    rng = np.random.default_rng(seed)
-    t0 = rng.integers(0, T - N - 1, size=B)
-    probs = {}
-    keys = ("x_ref", "u_ref", "com_ref", "stance", "ee_ref", "com_vel_ref")
-    stacks = {k: [] for k in keys}
-    for b in range(B):
-        if int(t0[b]) not in probs:
-            probs[int(t0[b])] = rd.problem_at(int(t0[b]), N, base, follow_schedule=True)
-        for k in keys:
-            stacks[k].append(probs[int(t0[b])][k][0])
-    prob = dict(base); prob["N"] = N
-    for k in keys:
-        prob[k] = np.stack(stacks[k])
-    x0 = rd.x_ref[t0].copy()
-    x0[:, 7:26] += rng.uniform(-0.02, 0.02, (B, 19)); x0[:, 0:3] += rng.uniform(-0.01, 0.01, (B, 3)); x0[:, 26:] *= 0.5
-    ug = sv.gravity_compensation(sc.standing_state(), prob["gravity"])
-    ui = np.tile(ug, (B, N, 1)) + rng.uniform(-0.5, 0.5, (B, N, 19))
-    return prob, x0, ui, t0
+    return sc.walking_batch(B, N, seed, os.path.join(G, "refdata_golden.npz"), sv, rf)
 
 
 def test_config4_walking_windows_at_per_gpu_shape():
