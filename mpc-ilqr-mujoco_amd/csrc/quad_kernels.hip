@@ -51,25 +51,6 @@ constexpr QAncTable make_anc_table() {
   return T;
 }
 
-// (theta, theta) upper-triangle and (theta, thetadot) full-block entries with a second-order part: the pairs of joints one of
-// which is an ancestor of (or is) the other -- 59 + 99 of the 190 + 361 entries.  Packed: ja | jb << 5 | isd << 10.
-struct QRelTable { unsigned short e[192]; int n; };
-constexpr QRelTable make_rel_table() {
-  QRelTable T{};
-  int n = 0;
-  const QAncTable A = make_anc_table();
-  for (int ja = 1; ja < H1_NB; ++ja)
-    for (int jb = ja; jb < H1_NB; ++jb)
-      if ((A.m[ja] >> jb) & 1u) T.e[n++] = (unsigned short)(ja | (jb << 5));
-  for (int ja = 1; ja < H1_NB; ++ja)
-    for (int jb = 1; jb < H1_NB; ++jb)
-      if (((A.m[ja] >> jb) & 1u) || ((A.m[jb] >> ja) & 1u)) T.e[n++] = (unsigned short)(ja | (jb << 5) | (1 << 10));
-  T.n = n;
-  return T;
-}
-__constant__ static const QRelTable QREL = make_rel_table();
-static_assert(make_rel_table().n == 158, "related joint pairs of the H1 tree");
-
 // ---- the knot record (doubles; written by k_quad_kin, read by k_cost_quadratics) ---------------------------------------------
 // Four functionals in fixed slots: 0 = (CoM, position) [+ the position part of the balance term], 1 = (CoM, velocity) [+ its
 // velocity part], 2 / 3 = left / right foot (position in swing, velocity in stance).  A slot whose term is off has scale 0 and
@@ -385,16 +366,93 @@ __global__ void __launch_bounds__(64) k_quad_kin(DevState S, ProblemDev P, const
 #define QS2_SIZE (QS2_NR * QS2_NC - QS2_NR * (QS2_NR - 1) / 2)
 #define QS2_IDX(a, bb) (((a) - QS2_R0) * QS2_NC - ((a) - QS2_R0) * ((a) - QS2_R0 - 1) / 2 + ((bb) - (a)))
 enum { QJ_C = 0, QJ_V = 3, QJ_F0 = 6, QJ_F1 = 9, QJ_R0 = 12, QJ_R1 = 13, QJ_M = 14, QJ_ROWS = 15 };
+enum { QA_I9 = 0, QA_ZERO = 9, QA_UE = 12, QA_NBX = 39, QAUX_SIZE = 66 };   // LDS-only constants of phase 1a, right behind the record
 struct QuadLds {
   double rec[QREC_SIZE];                     // the knot record
+  double aux[QAUX_SIZE];                     // identity, zero vector, mfrac_s e_k, e_k x beta_s: operands of the uniform column formula
   union {
     struct { double J[QJ_ROWS][H1_NX]; };    // Jacobian rows: d c, d cdot of the CoM; the feet's; balance rows jr0, jr1, m
     double S2[QS2_SIZE];                     // second-order part of the entries that have one (packed, QS2_IDX)
   };
-  double tz[4][H1_NJ][3], Pp[3][H1_NJ][3];   // til_c x z_j (slots 0..3), P'_j (slots 1..3: slot 0 is never a velocity functional)
+  double tz[4][H1_NJ][3];                    // [0]: til_0 x z_j + P'_1,j (the CoM's two functionals merged); [1..3]: til_c x z_j
+  double Pp[2][H1_NJ][3];                    // P'_j of the feet's functionals (slots 2, 3)
   double dg[H1_NX];                          // diagonal additions: Q (or Qf) + soft joint-limit penalty
 };
 static_assert(sizeof(QuadLds) <= 16384, "QuadLds must fit ten two-wave workgroups per CU");
+static_assert(offsetof(QuadLds, aux) == sizeof(double) * QREC_SIZE, "aux directly behind rec: one base pointer for the column table");
+
+// Phase 1a as ONE formula: column c of the Jacobian rows of functional (type, point set) = M(c) u(c), M a 3 x 3 block and u a
+// 3-vector of the record (or of the LDS constants behind it): offsets from the record base, built at compile time.
+//   position type: p -> I . mfrac e_c | quat -> D_k beta | theta_j (on the set) -> R0 w_j | velocity columns -> 0
+//   velocity type: p -> 0 | quat -> D_k gamma | theta_j -> R0 dgamma_j | v_b -> R0 . mfrac e_k | omega_b -> R0 (e_k x beta) | thetadot_j -> R0 w_j
+// (the divergent four-way class switch this replaces was ~350 instructions per pass, half of them scalar branch bookkeeping)
+struct QColTable { unsigned e[2 * 3 * H1_NX]; };
+constexpr bool qc_on(int s, int j) { return s == 0 ? true : (s == 1 ? (j >= 1 && j <= 5) : (j >= 6 && j <= 10)); }
+constexpr int qc_w(int s, int j) { return s == 0 ? QR_W0 + 3 * (j - 1) : QR_WF + 15 * (s - 1) + 3 * (j - (s == 1 ? 1 : 6)); }
+constexpr int qc_dg(int s, int j) { return s == 0 ? QR_DG0 + 3 * (j - 1) : QR_DGF + 15 * (s - 1) + 3 * (j - (s == 1 ? 1 : 6)); }
+constexpr QColTable make_col_table() {
+  QColTable T{};
+  const int I9 = QREC_SIZE + QA_I9, Z = QREC_SIZE + QA_ZERO;
+  for (int v = 0; v < 2; ++v)
+    for (int s = 0; s < 3; ++s)
+      for (int c = 0; c < H1_NX; ++c) {
+        int m = I9, u = Z;
+        if (c < 3) { if (!v) { m = I9; u = QREC_SIZE + QA_UE + 9 * s + 3 * c; } }
+        else if (c < 7) { m = QR_D + 9 * (c - 3); u = (v ? QR_GAMMA : QR_BETA) + 3 * s; }
+        else if (c < H1_NQ) { const int j = c - 7 + 1; if (qc_on(s, j)) { m = QR_R0; u = v ? qc_dg(s, j) : qc_w(s, j); } }
+        else if (v) {
+          const int cv = c - H1_NQ;
+          if (cv < 3) { m = QR_R0; u = QREC_SIZE + QA_UE + 9 * s + 3 * cv; }
+          else if (cv < 6) { m = QR_R0; u = QREC_SIZE + QA_NBX + 9 * s + 3 * (cv - 3); }
+          else { const int j = cv - 6 + 1; if (qc_on(s, j)) { m = QR_R0; u = qc_w(s, j); } }
+        }
+        T.e[(v * 3 + s) * H1_NX + c] = (unsigned)m | ((unsigned)u << 16);
+      }
+  return T;
+}
+__constant__ static const QColTable QCOL = make_col_table();
+
+// Second-order patch, entry lists (compile time).  A: the related joint pairs of (theta, theta) / (theta, thetadot); B: (quat_k, theta_j) /
+// (quat_k, thetadot_j).  Each word: everything the lane needs -- joint indices, block, which foot's set also carries the entry, the
+// entry's position in the packed patch.  Entries a foot set contributes to come first (A: 80 of 158, B: 80 of 152), so the passes
+// past them skip the feet's code altogether.
+//   A word: (lo - 1) | (hi - 1) << 5 | isd << 10 | foot << 11 | patch index << 16      (foot: 0 none, 1 left leg, 2 right leg)
+//   B word: k | (j - 1) << 5 | isd << 10 | foot << 11 | patch index << 16
+struct QPatchTable { unsigned a[160], b[160]; int na, nb, nfa, nfb; };
+constexpr QPatchTable make_patch_table() {
+  QPatchTable T{};
+  const QAncTable A = make_anc_table();
+  const int T0 = 7, D0 = H1_NQ + 6, Q0 = 3;
+  int n = 0;
+  for (int pass = 0; pass < 3; ++pass)            // foot = 1, 2, then 0
+    for (int isd = 0; isd < 2; ++isd)
+      for (int ja = 1; ja < H1_NB; ++ja)
+        for (int jb = (isd ? 1 : ja); jb < H1_NB; ++jb) {
+          const bool relat = ((A.m[ja] >> jb) & 1u) || ((A.m[jb] >> ja) & 1u);
+          if (!relat) continue;
+          const int foot = (ja <= 5 && jb <= 5) ? 1 : ((ja >= 6 && ja <= 10 && jb >= 6 && jb <= 10) ? 2 : 0);
+          if (foot != (pass == 0 ? 1 : (pass == 1 ? 2 : 0))) continue;
+          const int lo = ja < jb ? ja : jb, hi = ja < jb ? jb : ja;
+          const int a = T0 + ja - 1, bb = (isd ? D0 : T0) + jb - 1;
+          T.a[n++] = (unsigned)(lo - 1) | ((unsigned)(hi - 1) << 5) | ((unsigned)isd << 10) | ((unsigned)foot << 11) | ((unsigned)QS2_IDX(a, bb) << 16);
+        }
+  T.na = n; T.nfa = 0;
+  for (int i = 0; i < n; ++i) if ((T.a[i] >> 11) & 3u) T.nfa = i + 1;
+  n = 0;
+  for (int pass = 0; pass < 3; ++pass)
+    for (int isd = 0; isd < 2; ++isd)
+      for (int k = 0; k < 4; ++k)
+        for (int j = 1; j < H1_NB; ++j) {
+          const int foot = j <= 5 ? 1 : (j <= 10 ? 2 : 0);
+          if (foot != (pass == 0 ? 1 : (pass == 1 ? 2 : 0))) continue;
+          T.b[n++] = (unsigned)k | ((unsigned)(j - 1) << 5) | ((unsigned)isd << 10) | ((unsigned)foot << 11) | ((unsigned)QS2_IDX(Q0 + k, (isd ? D0 : T0) + j - 1) << 16);
+        }
+  T.nb = n; T.nfb = 0;
+  for (int i = 0; i < n; ++i) if ((T.b[i] >> 11) & 3u) T.nfb = i + 1;
+  return T;
+}
+__constant__ static const QPatchTable QPATCH = make_patch_table();
+static_assert(make_patch_table().na == 158 && make_patch_table().nb == 152 && make_patch_table().nfa == 80 && make_patch_table().nfb == 80, "patch entry lists");
 
 DEVFN double sel3(const double* v, int k) { return k == 0 ? v[0] : (k == 1 ? v[1] : v[2]); }   // no dynamic register index
 // d2R/dquat_k dquat_l: dR_dquat is linear in q, so this is dR_dquat(k, e_l)
@@ -508,7 +566,10 @@ __global__ void __launch_bounds__(128, QUAD_WAVES) k_cost_quadratics(DevState S,
   // ---- phase 0: the knot's record -> LDS.  The rollout's selection flags are requested together with the knot's data (indices
   // clamped instead of predicated) and tested before anything is written; so is everything phase 1 wants from HBM
   const double* Qd = term ? P.Qf : P.Q;
+  const int* stq = P.stance + b * P.stance_stride + 2 * t;      // (wave-uniform: scalar loads)
+  const int fvel[2] = {stq[0] == 1, stq[1] == 1};               // stance foot: the velocity functional; swing foot: the position one
   double xv, xrv, qdv, uv = 0.0, urv = 0.0;
+  unsigned colw[2], patw[3];
   {
     const int f1 = mode == MASK_ALL ? 1 : S.active[b], f2 = mode == MASK_RETRY ? S.need_retry[b] : 1;
     const long kn = knot0 + (long)b * N1 + t;
@@ -520,49 +581,55 @@ __global__ void __launch_bounds__(128, QUAD_WAVES) k_cost_quadratics(DevState S,
     xv = xg[a]; xrv = (P.x_ref + b * P.x_ref_stride + t * H1_NX)[a]; qdv = Qd[a];
     const int l1 = lane - 64, iu = (l1 >= 0 && l1 < H1_NU) ? l1 : 0, tu = term ? N - 1 : t;
     if (wv == 1) { uv = S.ubar[((size_t)b * N + tu) * H1_NU + iu]; urv = (P.u_ref + b * P.u_ref_stride + tu * H1_NU)[iu]; }
+    // the table words of phases 1a and 2b travel with the knot's data as well (each was a dependent round trip to the constant
+    // segment in the middle of its phase: 8 k cycles for a phase of ~40 instructions)
+    {
+      const int c = (lane & 63) < H1_NX ? (lane & 63) : 0;
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        const int f = 2 * p + wv, s_ = f < 2 ? 0 : f - 1;
+        const int isv = (f == 1 || (f >= 2 && fvel[f >= 2 ? f - 2 : 0])) ? 1 : 0;
+        colw[p] = QCOL.e[(isv * 3 + s_) * H1_NX + c];
+      }
+#pragma unroll
+      for (int pass = 0; pass < 3; ++pass) {
+        const int e = 64 * pass + (lane & 63);
+        patw[pass] = wv == 0 ? QPATCH.a[e < 158 ? e : 0] : QPATCH.b[e < 152 ? e : 0];
+      }
+    }
     if (!(f1 && f2)) return;
 #pragma unroll
     for (int k = 0; k < 4; ++k) { const int f = lane + 128 * k; if (f < QREC_SIZE) L.rec[f] = rv[k]; }
+    // constants of the uniform column formula (QColTable): identity and zero vector; mfrac_s e_k and e_k x beta_s from the lanes that
+    // hold mfrac_s (field 60 + s: lane 60 + s, k = 0) and beta_s[j] (field 64 + 3 s + j: lane 64 + 3 s + j, k = 0)
+    if (lane < QAUX_SIZE) L.aux[lane] = (lane < 9 && lane % 4 == 0) ? 1.0 : 0.0;     // (everything else starts as zero; the writes below land behind the wave barrier)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    if (lane >= QR_MFRAC && lane < QR_MFRAC + 3) { const int s_ = lane - QR_MFRAC; L.aux[QA_UE + 9 * s_] = rv[0]; L.aux[QA_UE + 9 * s_ + 4] = rv[0]; L.aux[QA_UE + 9 * s_ + 8] = rv[0]; }
+    if (lane >= QR_BETA && lane < QR_BETA + 9) {
+      const int s_ = (lane - QR_BETA) / 3, j = (lane - QR_BETA) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+      // (e_k x beta)_i = eps_ikj beta_j: (i, k) = (j + 1, j + 2) -> +beta_j, (j + 2, j + 1) -> -beta_j
+      L.aux[QA_NBX + 9 * s_ + 3 * j2 + j1] = rv[0];
+      L.aux[QA_NBX + 9 * s_ + 3 * j1 + j2] = -rv[0];
+    }
   }
   __syncthreads();
   QSTAMP(0)
 
-  const int* stq = P.stance + b * P.stance_stride + 2 * t;      // (wave-uniform: scalar loads)
-  const int fvel[2] = {stq[0] == 1, stq[1] == 1};               // stance foot: the velocity functional; swing foot: the position one
   const int has_bal = __builtin_amdgcn_readfirstlane(rec[QR_HASBAL] != 0.0 ? 1 : 0);
 
   // ---- phase 1a: the Jacobian rows of the four functionals (h1_cost_dev.h knot_jac_column), lane = coordinate, one functional per
   // wave and pass: wave 0 the CoM's d c then the left foot's, wave 1 the CoM's d cdot then the right foot's (a foot's rows are
-  // d cdot in stance, d c in swing).  One 3-vector per lane and pass; the functional's type is wave-uniform.
+  // d cdot in stance, d c in swing).  One 3 x 3 block times one 3-vector per lane and pass, both picked by QColTable.
 #pragma unroll
   for (int p = 0; p < 2; ++p) {
     const int f = 2 * p + wv;                       // (wave-uniform)
     const int s = f < 2 ? 0 : f - 1;
-    const bool isv = f == 1 || (f >= 2 && fvel[f >= 2 ? f - 2 : 0]);
     const int c = lane & 63;
     if (c < H1_NX) {
-      const double* R0 = rec + QR_R0;
-      const double mfrac = rec[QR_MFRAC + s];
-      double v3[3] = {0.0, 0.0, 0.0};
-      if (!isv) {
-        if (c < 3) { v3[0] = c == 0 ? mfrac : 0.0; v3[1] = c == 1 ? mfrac : 0.0; v3[2] = c == 2 ? mfrac : 0.0; }
-        else if (c < 7) mv3(rec + QR_D + 9 * (c - 3), rec + QR_BETA + 3 * s, v3);
-        else if (c < H1_NQ) { const int j = c - 7 + 1; if (q_on(s, j)) mv3(R0, q_w(rec, s, j), v3); }
-      } else {
-        if (c >= 3 && c < 7) mv3(rec + QR_D + 9 * (c - 3), rec + QR_GAMMA + 3 * s, v3);
-        else if (c >= 7 && c < H1_NQ) { const int j = c - 7 + 1; if (q_on(s, j)) mv3(R0, q_dg(rec, s, j), v3); }
-        else if (c >= H1_NQ) {
-          const int cv = c - H1_NQ;
-          const double* beta = rec + QR_BETA + 3 * s;
-          double col[3] = {0, 0, 0};
-          if (cv < 3) { col[0] = cv == 0 ? mfrac : 0.0; col[1] = cv == 1 ? mfrac : 0.0; col[2] = cv == 2 ? mfrac : 0.0; }
-          else if (cv < 6) {  // -[beta]x column
-            const int k = cv - 3;
-            if (k == 0) { col[1] = -beta[2]; col[2] = beta[1]; } else if (k == 1) { col[0] = beta[2]; col[2] = -beta[0]; } else { col[0] = -beta[1]; col[1] = beta[0]; }
-          } else { const int j = cv - 6 + 1; if (q_on(s, j)) { const double* w = q_w(rec, s, j); col[0] = w[0]; col[1] = w[1]; col[2] = w[2]; } }
-          mv3(R0, col, v3);
-        }
-      }
+      const unsigned e = colw[p];
+      const double* M = rec + (e & 0xffffu);
+      const double* u = rec + (e >> 16);
+      double v3[3]; mv3(M, u, v3);
 #pragma unroll
       for (int r = 0; r < 3; ++r) L.J[3 * f + r][c] = v3[r];
     }
@@ -611,17 +678,32 @@ __global__ void __launch_bounds__(128, QUAD_WAVES) k_cost_quadratics(DevState S,
     }
   } else {
     const int l1 = lane - 64;
-    for (int e = l1; e < 4 * H1_NJ; e += 64) {
-      const int c = e / H1_NJ, j = 1 + e - c * H1_NJ;
-      const double* til = rec + QR_TIL + 3 * c; const double* zj = rec + QR_ZH + 3 * (j - 1); const double* Oj = rec + QR_OM + 3 * (j - 1);
-      double tz[3]; cross(til, zj, tz);
+    {
+      // lanes 0..18: the CoM's two functionals of joint j (tz[0] = til_0 x z_j + P'_1,j: what the (theta, theta) entries contract with
+      // w_hi; tz[1] = til_1 x z_j); lanes 32..50: the feet's (tz[2], tz[3], and P' where the foot's functional is a velocity)
+      const int half = l1 >> 5, j = 1 + (l1 & 31);
+      if (j <= H1_NJ) {
+        const double* zj = rec + QR_ZH + 3 * (j - 1); const double* Oj = rec + QR_OM + 3 * (j - 1);
 #pragma unroll
-      for (int k = 0; k < 3; ++k) L.tz[c][j - 1][k] = tz[k];
-      const bool isv = c == 1 || (c >= 2 && fvel[c >= 2 ? c - 2 : 0]);
-      if (c >= 1 && isv) {
-        double tO[3], p1[3], p2[3]; cross(til, Oj, tO); cross(tO, zj, p1); cross(tz, Oj, p2);
+        for (int q = 0; q < 2; ++q) {
+          const int c = 2 * half + q;
+          const double* til = rec + QR_TIL + 3 * c;
+          double tz[3]; cross(til, zj, tz);
+          const bool isv = half == 0 ? (q == 1) : (fvel[q] != 0);
+          double pp[3] = {0.0, 0.0, 0.0};
+          if (isv) { double tO[3], p1[3], p2[3]; cross(til, Oj, tO); cross(tO, zj, p1); cross(tz, Oj, p2); pp[0] = p1[0] - p2[0]; pp[1] = p1[1] - p2[1]; pp[2] = p1[2] - p2[2]; }
+          if (half == 0 && q == 0) {
+            // slot 0 is a position functional: its tz is only ever added to slot 1's P' -> store the sum once both are known
 #pragma unroll
-        for (int k = 0; k < 3; ++k) L.Pp[c - 1][j - 1][k] = p1[k] - p2[k];
+            for (int k = 0; k < 3; ++k) L.tz[0][j - 1][k] = tz[k];
+          } else if (half == 0) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { L.tz[1][j - 1][k] = tz[k]; L.tz[0][j - 1][k] += pp[k]; }      // (same lane wrote tz[0] just above)
+          } else {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { L.tz[c][j - 1][k] = tz[k]; L.Pp[q][j - 1][k] = pp[k]; }
+          }
+        }
       }
     }
     if (!term && l1 < H1_NU) {
@@ -670,101 +752,120 @@ __global__ void __launch_bounds__(128, QUAD_WAVES) k_cost_quadratics(DevState S,
   __syncthreads();   // the Jacobian rows are in registers: their storage becomes the second-order patch
   for (int e = lane; e < QS2_SIZE; e += 128) L.S2[e] = 0.0;
   __syncthreads();
-  // 2b: second-order part, block by block of the coordinate classes (a <= bb in every block).  The four functionals' point set and
-  // type are compile-time (slots 0, 1) or wave-uniform (the feet): the loops over them branch uniformly.
+  // 2b: second-order part.  Wave 0: the related joint pairs of (theta, theta) / (theta, thetadot) (QPatchTable A, three passes of 64);
+  // wave 1: (quat, theta) / (quat, thetadot) (table B, three passes) and the small blocks.  The CoM's two functionals (slot 0 position,
+  // slot 1 velocity) are merged in closed form; the feet's (slots 2, 3; type by the stance flag) only touch their own leg's entries,
+  // which the tables list first.
   auto patch = [&](int a, int bb, double h) { L.S2[QS2_IDX(a, bb)] = h; };
-  const int Q0 = 3, T0 = 7, V0 = H1_NQ, W0 = H1_NQ + 3, D0 = H1_NQ + 6, NJ = H1_NJ;
+  const int Q0 = 3, T0 = 7, V0 = H1_NQ, W0 = H1_NQ + 3, NJ = H1_NJ;
   const int cset[4] = {0, 0, 1, 2};
   const int cvel[4] = {0, 1, fvel[0], fvel[1]};
-  // (theta, theta) and (theta, thetadot), related joints only (compile-time list): two passes of 128 entries
-  for (int e = lane; e < 158; e += 128) {
-    const unsigned pk = QREL.e[e];
-    const int ja = pk & 31, jb = (pk >> 5) & 31;
-    const bool isd = (pk >> 10) != 0;
-    const int lo = ja < jb ? ja : jb, hi = ja < jb ? jb : ja;     // parents precede their children in the body numbering
-    double h = 0.0;
+  if (wv == 0) {
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const int st_ = cset[c];
-      const bool on = q_on(st_, ja) && q_on(st_, jb);
-      const double* tz = L.tz[c][lo - 1];
-      const double* wh = q_w(rec, st_, hi);
-      const double t1 = dot3(tz, wh);
-      double v;
-      if (cvel[c]) { const double t2 = dot3(L.Pp[c >= 1 ? c - 1 : 0][lo - 1], wh) + dot3(tz, q_dg(rec, st_, hi)); v = isd ? t1 : t2; }
-      else v = isd ? 0.0 : t1;
-      h += on ? v : 0.0;                           // (the functionals carry their weight in vec: scale = 1)
+    for (int pass = 0; pass < 3; ++pass) {
+      const int e = 64 * pass + lane;
+      if (e < 158) {
+        const unsigned pk = patw[pass];
+        const int lo = pk & 31, hi = (pk >> 5) & 31;                  // (joint index - 1)
+        const bool isd = (pk >> 10) & 1u;
+        const double* t0 = L.tz[0][lo]; const double* t1 = L.tz[1][lo];
+        const double* w = rec + QR_W0 + 3 * hi; const double* dg = rec + QR_DG0 + 3 * hi;
+        // CoM: (theta, theta): (til_0 x z_lo + P'_1,lo) . w_hi + (til_1 x z_lo) . dgamma_hi;  (theta, thetadot): (til_1 x z_lo) . w_hi
+        double h = isd ? dot3(t1, w) : dot3(t0, w) + dot3(t1, dg);
+        if (64 * pass < 80) {                                          // (compile-time: the entries a foot set carries are the first 80)
+          const int foot = (pk >> 11) & 3;
+          const int fi = foot == 2 ? 1 : 0, first = fi ? 5 : 0;
+          int hk = hi - first; hk = hk < 0 ? 0 : (hk > 4 ? 4 : hk);
+          const double* tf = L.tz[2 + fi][lo]; const double* pf = L.Pp[fi][lo];
+          const double* wf = rec + QR_WF + 15 * fi + 3 * hk; const double* dgf = rec + QR_DGF + 15 * fi + 3 * hk;
+          const bool fv = fi ? (fvel[1] != 0) : (fvel[0] != 0);
+          const double d1 = dot3(tf, wf), d2 = dot3(pf, wf) + dot3(tf, dgf);
+          const double v = fv ? (isd ? d1 : d2) : (isd ? 0.0 : d1);
+          h += foot ? v : 0.0;
+        }
+        L.S2[pk >> 16] = h;
+      }
     }
-    patch(T0 + ja - 1, (isd ? D0 : T0) + jb - 1, h);
-  }
-  // (quat, theta) and (quat, thetadot): Dv . w / Dv . dgam
-  for (int idx = lane; idx < 2 * 4 * NJ; idx += 128) {
-    const bool isd = idx >= 4 * NJ;
-    const int e = isd ? idx - 4 * NJ : idx;
-    const int k = e / NJ, j = 1 + e % NJ;
-    double h = 0.0;
+  } else {
+    const int l1 = lane - 64;
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const int st_ = cset[c];
-      const double* Dv = rec + QR_DV + 12 * c + 3 * k;
-      double v;
-      if (cvel[c]) v = dot3(Dv, isd ? q_w(rec, st_, j) : q_dg(rec, st_, j));
-      else v = isd ? 0.0 : dot3(Dv, q_w(rec, st_, j));
-      h += q_on(st_, j) ? v : 0.0;
+    for (int pass = 0; pass < 3; ++pass) {
+      const int e = 64 * pass + l1;
+      if (e < 152) {
+        const unsigned pk = patw[pass];
+        const int k = pk & 3, j = (pk >> 5) & 31;                     // (joint index - 1)
+        const bool isd = (pk >> 10) & 1u;
+        const double* w = rec + QR_W0 + 3 * j; const double* dg = rec + QR_DG0 + 3 * j;
+        const double* D0v = rec + QR_DV + 3 * k; const double* D1v = rec + QR_DV + 12 + 3 * k;
+        // CoM: (quat, theta): Dv_0 . w_j + Dv_1 . dgamma_j;  (quat, thetadot): Dv_1 . w_j
+        double h = isd ? dot3(D1v, w) : dot3(D0v, w) + dot3(D1v, dg);
+        if (64 * pass < 80) {
+          const int foot = (pk >> 11) & 3;
+          const int fi = foot == 2 ? 1 : 0, first = fi ? 5 : 0;
+          int jk = j - first; jk = jk < 0 ? 0 : (jk > 4 ? 4 : jk);
+          const double* Dfv = rec + QR_DV + 12 * (2 + fi) + 3 * k;
+          const double* wf = rec + QR_WF + 15 * fi + 3 * jk; const double* dgf = rec + QR_DGF + 15 * fi + 3 * jk;
+          const bool fv = fi ? (fvel[1] != 0) : (fvel[0] != 0);
+          const double d1 = dot3(Dfv, wf), d2 = dot3(Dfv, dgf);
+          const double v = fv ? (isd ? d1 : d2) : (isd ? 0.0 : d1);
+          h += foot ? v : 0.0;
+        }
+        L.S2[pk >> 16] = h;
+      }
     }
-    patch(Q0 + k, (isd ? D0 : T0) + j - 1, h);
-  }
-  // (theta, omega_b): (w_j x til)_c on wave 0; (quat, v_b), (quat, omega_b) and (quat, quat) on wave 1
-  if (lane < 3 * NJ) {
-    const int ja = 1 + lane / 3, cc = lane % 3;
-    double h = 0.0;
+    // (theta, omega_b): (w_j x til)_c, velocity functionals only
+    if (l1 < 3 * NJ) {
+      const int ja = 1 + l1 / 3, cc = l1 % 3;
+      double h = 0.0;
 #pragma unroll
-    for (int c = 1; c < 4; ++c) {
-      if (!cvel[c]) continue;
-      const int st_ = cset[c];
-      double tv[3]; cross(q_w(rec, st_, ja), rec + QR_TIL + 3 * c, tv);
-      h += q_on(st_, ja) ? sel3(tv, cc) : 0.0;
+      for (int c = 1; c < 4; ++c) {
+        if (!cvel[c]) continue;
+        const int st_ = cset[c];
+        double tv[3]; cross(q_w(rec, st_, ja), rec + QR_TIL + 3 * c, tv);
+        h += q_on(st_, ja) ? sel3(tv, cc) : 0.0;
+      }
+      patch(T0 + ja - 1, W0 + cc, h);
     }
-    patch(T0 + ja - 1, W0 + cc, h);
-  }
-  if (lane >= 64 && lane < 64 + 24) {
-    const bool isw = lane >= 64 + 12;
-    const int e = isw ? lane - 64 - 12 : lane - 64;
-    const int k = e / 3, cc = e % 3;
-    double h = 0.0;
+    // (quat, v_b), (quat, omega_b) on lanes 0..23, (quat, quat) on lanes 32..41
+    if (l1 < 24) {
+      const bool isw = l1 >= 12;
+      const int e = isw ? l1 - 12 : l1;
+      const int k = e / 3, cc = e % 3;
+      double h = 0.0;
 #pragma unroll
-    for (int c = 1; c < 4; ++c) {
-      if (!cvel[c]) continue;
-      const int st_ = cset[c];
-      const double* Dv = rec + QR_DV + 12 * c + 3 * k;
-      if (!isw) h += sel3(Dv, cc) * rec[QR_MFRAC + st_];
-      else { double tv[3]; cross(rec + QR_BETA + 3 * st_, Dv, tv); h += sel3(tv, cc); }   // Dv . (-[beta]x e_c) = (beta x Dv)_c
-    }
-    patch(Q0 + k, (isw ? W0 : V0) + cc, h);
-  } else if (lane >= 96 && lane < 106) {
-    // (quat, quat): d2R/dq2 terms + upright; triangular index -> (ka, kb), ka <= kb < 4
-    const int idx = lane - 96;
-    const int ka = idx < 4 ? 0 : (idx < 7 ? 1 : (idx < 9 ? 2 : 3));
-    const int kb = idx < 4 ? idx : (idx < 7 ? idx - 3 : (idx < 9 ? idx - 5 : 3));
-    double h = 0.0;
-    double D2[9]; d2R_sel(ka, kb, D2);
+      for (int c = 1; c < 4; ++c) {
+        if (!cvel[c]) continue;
+        const int st_ = cset[c];
+        const double* Dv = rec + QR_DV + 12 * c + 3 * k;
+        if (!isw) h += Dv[cc] * rec[QR_MFRAC + st_];
+        else { double tv[3]; cross(rec + QR_BETA + 3 * st_, Dv, tv); h += sel3(tv, cc); }   // Dv . (-[beta]x e_c) = (beta x Dv)_c
+      }
+      patch(Q0 + k, (isw ? W0 : V0) + cc, h);
+    } else if (l1 >= 32 && l1 < 42) {
+      // (quat, quat): d2R/dq2 terms + upright; triangular index -> (ka, kb), ka <= kb < 4
+      const int idx = l1 - 32;
+      const int ka = idx < 4 ? 0 : (idx < 7 ? 1 : (idx < 9 ? 2 : 3));
+      const int kb = idx < 4 ? idx : (idx < 7 ? idx - 3 : (idx < 9 ? idx - 5 : 3));
+      double h = 0.0;
+      double D2[9]; d2R_sel(ka, kb, D2);
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const int st_ = cset[c];
-      double tv[3]; mv3(D2, cvel[c] ? rec + QR_GAMMA + 3 * st_ : rec + QR_BETA + 3 * st_, tv);
-      h += dot3(rec + QR_VEC + 3 * c, tv);
+      for (int c = 0; c < 4; ++c) {
+        const int st_ = cset[c];
+        double tv[3]; mv3(D2, cvel[c] ? rec + QR_GAMMA + 3 * st_ : rec + QR_BETA + 3 * st_, tv);
+        h += dot3(rec + QR_VEC + 3 * c, tv);
+      }
+      if (P.w_upright > 0.0) {
+        const int i = ka, j = kb;
+        const double* uJ = rec + QR_UJ; const double* ur = rec + QR_UR;
+        double v = uJ[i] * uJ[j] + uJ[4 + i] * uJ[4 + j] + uJ[8 + i] * uJ[8 + j];
+        if ((i == 0 && j == 2) || (i == 1 && j == 3)) v += 2.0 * ur[0];
+        if (i == 2 && j == 3) v += 2.0 * ur[1];
+        if (i == 0 && j == 1) v += -2.0 * ur[1];
+        if ((i == 1 && j == 1) || (i == 2 && j == 2)) v += -4.0 * ur[2];
+        h += P.w_upright * v;
+      }
+      patch(Q0 + ka, Q0 + kb, h);
     }
-    if (P.w_upright > 0.0) {
-      const int i = ka, j = kb;
-      const double* uJ = rec + QR_UJ; const double* ur = rec + QR_UR;
-      double v = uJ[i] * uJ[j] + uJ[4 + i] * uJ[4 + j] + uJ[8 + i] * uJ[8 + j];
-      if ((i == 0 && j == 2) || (i == 1 && j == 3)) v += 2.0 * ur[0];
-      if (i == 2 && j == 3) v += 2.0 * ur[1];
-      if (i == 0 && j == 1) v += -2.0 * ur[1];
-      if ((i == 1 && j == 1) || (i == 2 && j == 2)) v += -4.0 * ur[2];
-      h += P.w_upright * v;
-    }
-    patch(Q0 + ka, Q0 + kb, h);
   }
   __syncthreads();
   QSTAMP(4)
