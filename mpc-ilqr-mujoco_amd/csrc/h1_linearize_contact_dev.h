@@ -378,6 +378,9 @@ DEVFN void lin_tangent_legs_c(LinShared& L, LinContact& Cc, int lane) {
 // multiplier tangents.  wave 0: W = G^T dT (12 x 25 times 25 x 47) on the MFMA -- 7 k-steps x 3 column tiles, A operand lane
 // (lr = j, lk) = G[4 s + lk][j], B operand = dT[4 s + lk][16 J + lr] -- written to Cc.W, then lane = direction subtracts the
 // constraint-row tangents and back-substitutes; wave 1: lane = control column (19)
+// (TWO: the 16-slot chain groups of the two-knot kernel, base-linear-velocity directions in the extra slots 16..18)
+DEVFN int slot_in_group2c(int c, int kind, int idx) { return kind == DIR_VLIN ? 16 + idx : slot_in_group2(c, kind, idx); }
+template <bool TWO = false>
 DEVFN void lin_contact_multipliers(const LinShared& L, LinContact& Cc, int wv, int lane) {
   typedef double v4d_c __attribute__((ext_vector_type(4)));
   if (wv == 0) {
@@ -407,7 +410,7 @@ DEVFN void lin_contact_multipliers(const LinShared& L, LinContact& Cc, int wv, i
       double w[12];
 #pragma unroll
       for (int g = 0; g < 2; ++g) {
-        const int sl = slot_in_group(g, kind, idx);
+        const int sl = TWO ? slot_in_group2c(g, kind, idx) : slot_in_group(g, kind, idx);
 #pragma unroll
         for (int k = 0; k < 6; ++k) {
           const double dr = sl >= 0 ? Cc.dR[g][k][sl < 0 ? 0 : sl] : 0.0;
@@ -431,6 +434,70 @@ DEVFN void lin_contact_multipliers(const LinShared& L, LinContact& Cc, int wv, i
     for (int j = 0; j < 12; ++j) Cc.WU[j][lane] = w[j];
   }
 }
+// ---- two knots per four-wave workgroup (k_lin_tangent2c, round 4) -------------------------------------------------------------
+// As k_lin_tangent2: 16-slot chain groups, so the leg sweeps of two knots fill one wave.  The inverse-dynamics tangent does not
+// depend on the base's linear velocity here either (the contact wrench is an external force fixed in link coordinates), but the
+// constraint row does -- through the foot's velocity v_f / h and the velocity-product part of its acceleration: pure kinematics.
+// The three v_lin directions therefore run a kinematics-only forward chain (lin2_leg_vlin_dR: dv, da down the leg, no inertia,
+// no forces, no backward pass) on 2 knots x 2 feet x 3 = 12 lanes of an otherwise idle wave, into the slots 16..18 of dR.
+DEVFN void lin2_tangent_legs_c(LinShared* L2, LinContact* C2, int lane) {
+  LinShared& L = L2[lane >> 5]; LinContact& Cc = C2[lane >> 5];
+  const int grp = (lane >> 4) & 1, q = lane & 15;
+  const bool side = grp == 1;
+  int kind, idx; slot_direction2(false, side, q, kind, idx);
+  const int col = dir_lane(kind, idx);
+  double dv0[6], da0[6]; tan_base(L, kind, idx, dv0, da0);
+  {
+    double dg0[3] = {0.0, 0.0, 0.0}, dgf[3];
+    if (kind == DIR_PHI) cross_axis(Cc.offb[0], idx, dg0);        // d(R0^T u) = (R0^T u) x dphi
+    tan_leg_gravity<0>(L, Cc, side, kind, idx, dg0, dgf);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) Cc.dR[grp][3 + k][q] = -dgf[k];
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  double df[5][6], dvf[6], daf[6];
+  TanChain2<1, 6, 5>::fwd<0>(L, side, kind, idx, dv0, da0, df, dvf, daf);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    Cc.dR[grp][k][q] = daf[k] + dvf[k] / L.h;
+    Cc.dR[grp][3 + k][q] += daf[3 + k] + dvf[3 + k] / L.h;
+  }
+  double dFj[6] = {0, 0, 0, 0, 0, 0};
+  double acc[6] = {0, 0, 0, 0, 0, 0};
+  TanChain2<1, 6, 5>::bwd<4>(L, side, kind, idx, df, acc, dFj, col);
+#pragma unroll
+  for (int k = 0; k < 6; ++k) L.u.t.part[grp][k][q] = dFj[k];
+}
+// kinematics-only tangent of (v_i, a_i) down a leg for a direction that moves no hinge (tan_body_fwd2 without its own-hinge terms)
+template <int K> DEVFN void tan_leg_kin(const LinShared& L, bool side, const double* pv, const double* pa, double* dvf, double* daf) {
+  constexpr int IL = 1 + K, IR = 6 + K, ax = h1c::C_AXIS[IL];
+  const int i = side ? IR : IL;
+  const double qd = L.x[H1_NQ + 6 + i - 1];
+  const double r[3] = {side ? h1c::C_POS[IR][0] : h1c::C_POS[IL][0], side ? h1c::C_POS[IR][1] : h1c::C_POS[IL][1], side ? h1c::C_POS[IR][2] : h1c::C_POS[IL][2]};
+  double dv[6], da[6];
+  xf_motion(L.D.Rj[i], r, pv, dv);
+  xf_motion(L.D.Rj[i], r, pa, da);
+  double t[3];
+  h1r::cross_axis<ax>(dv, t);     da[0] += qd * t[0]; da[1] += qd * t[1]; da[2] += qd * t[2];
+  h1r::cross_axis<ax>(dv + 3, t); da[3] += qd * t[0]; da[4] += qd * t[1]; da[5] += qd * t[2];
+  if constexpr (K + 1 < 5) tan_leg_kin<K + 1>(L, side, dv, da, dvf, daf);
+  else {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) { dvf[k] = dv[k]; daf[k] = da[k]; }
+  }
+}
+// lanes 0..11: (knot slot, foot, base-linear-velocity direction) -> dR slots 16..18 (no gravity-offset part: v_lin turns nothing)
+DEVFN void lin2_leg_vlin_dR(LinShared* L2, LinContact* C2, int lane) {
+  if (lane >= 12) return;
+  const int ks = lane / 6, g = (lane / 3) & 1, k3 = lane % 3;
+  LinShared& L = L2[ks]; LinContact& Cc = C2[ks];
+  double dv0[6], da0[6]; tan_base(L, DIR_VLIN, k3, dv0, da0);
+  double dvf[6], daf[6];
+  tan_leg_kin<0>(L, g == 1, dv0, da0, dvf, daf);
+#pragma unroll
+  for (int k = 0; k < 6; ++k) Cc.dR[g][k][16 + k3] = daf[k] + dvf[k] / L.h;
+}
+
 // dT <- -Minv dT + G W on the MFMA (row tile I = wave index): the 7 k-steps of the Minv product + 3 of the G product
 DEVFN void lin_apply_minv_2c(LinShared& L, const LinContact& Cc, int tid) {
   typedef double v4d_l __attribute__((ext_vector_type(4)));

@@ -281,6 +281,82 @@ __global__ void __launch_bounds__(128, 2) k_lin_tangent_c(DevState S, ProblemDev
   LSTAMP(7)
 }
 
+// Round 4: the stance-constrained tangent kernel with two knots per four-wave workgroup (h1_linearize_contact_dev.h "two knots per
+// four-wave workgroup"): the leg and arm sweeps of both knots on one wave each (64 lanes), the Minv columns of both knots on wave
+// 2 and the twelve unit-wrench columns of both on wave 3, one constraint solve per wave, the three base-linear-velocity
+// directions as kinematics-only lanes.
+__global__ void __launch_bounds__(256, 2) k_lin_tangent2c(DevState S, ProblemDev P, int mode, const int* list, const int* count) {
+  const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+  const int ks = tid >> 7, tid7 = tid & 127;
+  const unsigned N = (unsigned)S.N;
+  const unsigned total = (unsigned)(list ? *count : S.B) * N;
+  const unsigned it0 = 2u * blockIdx.x;
+  if (it0 >= total) return;
+  __shared__ LinShared L2[2];
+  __shared__ LinContact C2[2];
+#ifdef LIN_STAMP
+  long long qlast = clock64();
+  const int t = (int)(it0 % N), b = (int)(it0 / N);
+#endif
+  size_t knot[2]; bool valid[2]; const int* stance[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const unsigned it = it0 + k < total ? it0 + k : it0;
+    const unsigned bs = it / N, tt = it - bs * N;
+    const int bb = list ? list[bs] : (int)bs;
+    knot[k] = (size_t)bb * N + tt;
+    stance[k] = P.stance + bb * P.stance_stride + 2 * tt;
+    bool ok = (it0 + k < total);
+    if (!list && mode != MASK_ALL) ok = ok && S.active[bb] != 0 && (mode != MASK_RETRY || S.need_retry[bb] != 0);
+    valid[k] = ok;
+  }
+  if (!valid[0] && !valid[1]) return;
+  {
+    const size_t kn = knot[ks];
+    const size_t bb = kn / N, tt = kn - bb * N;
+    lin_load_dump2c(L2[ks], C2[ks], S.lin_dump + kn * LinDumpG_SIZE, tid7, S.xbar + (bb * (N + 1) + tt) * H1_NX, S.ubar + kn * H1_NU, nullptr, nullptr);
+    if (tid7 == 127) L2[ks].h = P.dyn.h;
+    for (int e = tid7; e < H1_NV * LIN_LD; e += 128) (&L2[ks].dT[0][0])[e] = 0.0;
+  }
+  __syncthreads();
+  LSTAMP(0)
+  if (wv == 2) { const int c = lane & 31; if (c < H1_NV) lin_minv_lane_c(L2[lane >> 5], C2[lane >> 5], c); }          // Minv columns of both knots
+  else if (wv == 3) { const int c = lane & 31; if (c < 12) lin_minv_lane_c(L2[lane >> 5], C2[lane >> 5], H1_NV + c); }   // unit-wrench columns (G, C) of both
+  else if (wv == 0 && (lane & 31) < 2) lin_contact_rhs(L2[lane >> 5], C2[lane >> 5], P.dyn.g, lane & 31);
+  __syncthreads();
+  LSTAMP(1)
+  if (wv < 2) lin_contact_solve_w(C2[wv], stance[wv], P.dyn.soft, P.dyn.contact, lane);      // one constraint solve per wave
+  __syncthreads();
+  LSTAMP(2)
+  if (wv < 2) lin_contact_correct(L2[wv], C2[wv], lane);
+  __syncthreads();
+  if (wv == 0) lin2_accumulate_forces_w(L2, lane);
+  else if (wv == 3 && (lane & 31) == 0) lin_prologue(L2[lane >> 5]);
+  __syncthreads();
+  LSTAMP(3)
+  if (wv == 0) lin2_tangent_legs_c(L2, C2, lane);
+  else if (wv == 1) lin2_tangent_arms(L2, lane);
+  else if (wv == 2) lin2_leg_vlin_dR(L2, C2, lane);
+  __syncthreads();
+  if (wv < 2) lin2_tangent_pelvis(L2[wv], lane);
+  __syncthreads();
+  LSTAMP(4)
+  if (wv < 2) lin_contact_multipliers<true>(L2[wv], C2[wv], 0, lane);                          // W = G^T dT, then dlambda per direction
+  else if (wv == 2) { const int c = lane & 31; lin_contact_multipliers<true>(L2[lane >> 5], C2[lane >> 5], 1, c < H1_NU ? c : 63); }   // dlambda per control column
+  __syncthreads();
+  LSTAMP(5)
+  lin_apply_minv_2c(L2[ks], C2[ks], tid7);
+  __syncthreads();
+  LSTAMP(6)
+  if (wv < 2) {
+    if (lane < H1_NX && valid[wv]) { double* Ag = S.A + knot[wv] * H1_NX * H1_NX; lin_column(L2[wv], 0, lane, [&](int r, double v) { Ag[r * H1_NX + lane] = v; }); }
+  } else if (wv == 2) {
+    const int k = lane >> 5, c = lane & 31;
+    if (c < H1_NU && valid[k]) { double* Bg = S.Bm + knot[k] * H1_NX * H1_NU; lin_column(L2[k], 1, c, [&](int r, double v) { Bg[r * H1_NU + c] = v; }, C2[k].G, C2[k].WU); }
+  }
+  LSTAMP(7)
+}
+
 // Reference-style forward differences (RobotUtils::linearizeDynamicsFD, robot_utils.cpp:120-160):
 // thread per (rollout, knot, column); columns 0..50 = d/dx, 51..69 = d/du.
 // The unperturbed step f(x_t, u_t) is evaluated once per knot (k_fd_base, thread per knot, into the first 51 slots of the
@@ -814,7 +890,10 @@ void launch_linearize(const DevState& S, const ProblemDev& P, int mode, int jac_
   if (jac_mode == 0 && !use_scalar_dyn()) {
     // primal dump: on two lanes per knot beside the two-lane rollout kernels, one lane per knot with ILQR_ROLLOUT=r
     if (phases & 1) { if (g_var.rollout_split || P.dyn.contact) launch_lin_primal_s(S, P, mode, st, w.list, w.count); else launch_lin_primal_r(S, P, mode, st); }   // (contact mode: the dump is the free solve, see k_lin_tangent_c)
-    if ((phases & 2) && P.dyn.contact) hipLaunchKernelGGL(k_lin_tangent_c, dim3(S.N, S.B), dim3(128), 0, st, S, P, mode, w.list, w.count);
+    if ((phases & 2) && P.dyn.contact) {
+      if (g_var.lin_one_knot) hipLaunchKernelGGL(k_lin_tangent_c, dim3(S.N, S.B), dim3(128), 0, st, S, P, mode, w.list, w.count);
+      else hipLaunchKernelGGL(k_lin_tangent2c, dim3((unsigned)(((long)S.B * S.N + 1) / 2)), dim3(256), 0, st, S, P, mode, w.list, w.count);
+    }
     else if (phases & 2) launch_lin_tangent_free(S, P, mode, st, w, skip_fold_rows);
   } else if (jac_mode == 0 && !P.dyn.contact) {               // ILQR_DYN=s: the analytic kernels are constraint-free only
     if (phases & 1) launch_lin_primal_r(S, P, mode, st);

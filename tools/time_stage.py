@@ -46,7 +46,7 @@ if os.environ.get("ILQR_SSTAMPS"):
         print("  %-28s %10.0f cycles/step  %5.1f %%" % (nme, v / 25, 100 * v / st.sum()))
     print("  total %.0f cycles per step" % (st.sum() / 25))
 if os.environ.get("ILQR_LSTAMPS") and CONTACT:
-    names = ["load dump", "Minv + wrench sweeps || constraint rhs", "constraint solve (wave 0)", "correction, forces, prologue (wave 0)", "tangent sweeps + pelvis",
+    names = ["load dump", "Minv + wrench sweeps || constraint rhs", "constraint solve", "correction, forces, prologue", "tangent sweeps + pelvis",
              "multiplier tangents", "apply Minv + G (MFMA)", "columns + store"]
     st = s.cost()[:8]
     for nme, v in zip(names, st):
