@@ -138,7 +138,7 @@ def run_signature(args, n_slices):
     configuration AND the kernel sources (a kernel change without a re-collection must not inherit the old traffic figure)."""
     return {"csrc_sha": csrc_hash(), "batch": args.batch, "horizon": args.horizon, "iters": args.iters, "contact": bool(args.contact), "slices": int(n_slices),
             "backward": os.environ.get("ILQR_BACKWARD", "wave"), "ls": os.environ.get("ILQR_LS", "s"), "rollout": os.environ.get("ILQR_ROLLOUT", "s"),
-            "dyn": os.environ.get("ILQR_DYN", "")}
+            "dyn": os.environ.get("ILQR_DYN", ""), "lint": os.environ.get("ILQR_LINT", "0")}
 
 
 def kernel_groups(args, B, N, n_slices):
@@ -148,6 +148,8 @@ def kernel_groups(args, B, N, n_slices):
     bk_env = os.environ.get("ILQR_BACKWARD", "wave")
     bk_name = {"wg": "k_backward_mfma", "va": "k_backward"}.get(bk_env[:2], "k_backward_wave")
     primal = "k_lin_primal_r" if os.environ.get("ILQR_ROLLOUT", "s")[:1] == "r" and not args.contact else "k_lin_primal_s"
+    one_knot = os.environ.get("ILQR_LINT", "0") == "1"
+    tangent = ("k_lin_tangent_c" if one_knot else "k_lin_tangent2c") if args.contact else ("k_lin_tangent" if one_knot else "k_lin_tangent2")
     return {
         bk_name: dict(stages=["iLQR_backwardPass", "iLQR_backwardPass_retry"], unit="fp64 MFMA",
                       flops=RICCATI_FLOPS_PER_KNOT * N * Bl,
@@ -156,12 +158,13 @@ def kernel_groups(args, B, N, n_slices):
                       dict(stages=["iLQR_lineSearch", "iLQR_lineSearch_retry"], unit="fp64 VALU",
                       flops=ALPHA_TRIAL_FLOPS_PER_KNOT * N * Bl,      # the accepted alpha's trial is the algorithmic work
                       bytes=D * Bl * N * ((969 + 19 + 51 + 19) + 8 * (51 + 19))),
-        primal + "+k_lin_tangent": dict(stages=["iLQR_linearization"], unit="fp64 VALU",
-                                        flops=JACOBIAN_FLOPS_PER_KNOT * N * Bl,
-                                        bytes=D * Bl * N * (70 + 493 + 493 + 70 + 2601 + 969)),
-        "k_cost_quadratics": dict(stages=["iLQR_costQuadratics"], unit="fp64 VALU",
+        # (group names = the kernels' names as rocprofv3 / profiles/traffic_latest.json list them, template arguments stripped)
+        primal + "+" + tangent: dict(stages=["iLQR_linearization"], unit="fp64 VALU",
+                                     flops=JACOBIAN_FLOPS_PER_KNOT * N * Bl,
+                                     bytes=D * Bl * N * (70 + 493 + 493 + 70 + 2601 + 969)),      # x, u, dump written + read, A_t, B_t
+        "k_quad_kin+k_cost_quadratics": dict(stages=["iLQR_costQuadratics"], unit="fp64 VALU",
                                   flops=QUAD_FLOPS_PER_KNOT * (N + 1) * Bl,
-                                  bytes=D * Bl * (N + 1) * (70 + 2601 + 51 + 19 + 19)),
+                                  bytes=D * Bl * (N + 1) * (70 + 2601 + 51 + 19 + 19)),           # x, u, lxx, lx, lu, luu (the per-knot record between the two kernels is not algorithmic)
         "k_rollout_s": dict(stages=["iLQR_computeCost+forwardRollout"], unit="fp64 VALU",
                             flops=STEP_FLOPS * N * Bl, bytes=D * Bl * N * (51 + 19 + 51)),
     }
@@ -172,7 +175,7 @@ def dominant_group(kernels, stage_ms):
     quadratics and the nominal re-rollout run on three streams at the same time, so their spans are scaled by (longest span /
     sum of spans), i.e. the region is counted once and split in proportion."""
     total = {n: sum(stage_ms.get(x, 0.0) for x in k["stages"]) for n, k in kernels.items()}
-    conc = [n for n in total if n.startswith("k_lin_") or n.startswith("k_cost_quadratics") or n.startswith("k_rollout")]
+    conc = [n for n in total if n.startswith("k_lin_") or n.startswith("k_quad_kin") or n.startswith("k_rollout")]
     tot = sum(total[n] for n in conc)
     scale = (max(total[n] for n in conc) / tot) if tot > 0 else 1.0
     excl = {n: total[n] * (scale if n in conc else 1.0) for n in total}
@@ -548,7 +551,7 @@ def main():
         # on exclusive-equivalent time: the spans of the concurrent groups are scaled by (longest span / sum of spans), i.e.
         # the region is counted once and split in proportion (rocprofv3's per-kernel totals, profiles/, rank the same way
         # once the contention-inflated durations of these kernels are set against their stand-alone times).
-        conc = [n for n in table if n.startswith("k_lin_") or n.startswith("k_cost_quadratics") or n.startswith("k_rollout")]
+        conc = [n for n in table if n.startswith("k_lin_") or n.startswith("k_quad_kin") or n.startswith("k_rollout")]
         tot = sum(table[n]["total_ms_per_step"] for n in conc)
         scale = (max(table[n]["total_ms_per_step"] for n in conc) / tot) if tot > 0 else 1.0
         for n in table:

@@ -105,7 +105,7 @@ def test_bench_picks_the_dominant_kernel_group_on_exclusive_equivalent_time():
     assert name == "k_backward_wave" and keys == ["iLQR_backwardPass", "iLQR_backwardPass_retry"]      # 35 ms against 37 * 37 / 65 = 21 ms
     stage["iLQR_backwardPass"] = 2.0; stage["iLQR_backwardPass_retry"] = 1.0
     name, keys = bench.dominant_group(groups, stage)
-    assert name == "k_lin_primal_s+k_lin_tangent" and keys == ["iLQR_linearization"]
+    assert name == "k_lin_primal_s+k_lin_tangent2" and keys == ["iLQR_linearization"]
 
 
 def test_bench_names_a_baseline_config_only_when_it_runs_one_and_stamps_the_kernel_sources():

@@ -1,0 +1,71 @@
+#!/bin/bash
+# Everything profiles/ keeps for a round, in one go on the GPU box (about ten minutes):  tools/collect_round.sh r04
+#   -> gpurun_out/profiles_<tag>/ : <tag>_kernel_stats.csv, traffic_latest.json, <tag>_pmc/*, <tag>_sq_issue_wait_summary.txt,
+#      <tag>_fp64_instruction_mix.txt, <tag>_iteration_timeline.txt, <tag>_iteration_spans_fixed_and_early_exit.txt, <tag>_bench_lines/*.json
+set -e
+tag=${1:-r04}
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+out=gpurun_out/profiles_$tag
+bash tools/collect_profiles.sh "$tag" > /dev/null 2>&1 || true
+echo "[collect] kernel stats, traffic, mfma done"
+bash tools/sq_profile.sh "$tag" > /dev/null 2>&1 || true
+cp gpurun_out/sq_$tag/sq_summary.txt "$out/${tag}_sq_issue_wait_summary.txt"
+cp gpurun_out/sq_$tag/sq_counter_collection.csv "$out/${tag}_pmc/sq_counter_collection.csv"
+echo "[collect] sq done"
+BENCH1="python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-contact-line"
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU SQ_INSTS_VALU_MFMA_MOPS_F64 \
+  --output-format csv -d "$out/mix" -o x -- $BENCH1 > "$out/bench_mix.log" 2>&1
+cp "$(find "$out/mix" -name '*counter_collection.csv' | head -1)" "$out/${tag}_pmc/fp64_mix_counter_collection.csv"; rm -rf "$out/mix"
+python3 - "$out/${tag}_pmc/fp64_mix_counter_collection.csv" > "$out/${tag}_fp64_instruction_mix.txt" <<'PY'
+import collections, csv, sys
+rows = collections.defaultdict(dict)
+for r in csv.DictReader(open(sys.argv[1])):
+    name = r["Kernel_Name"].split("(")[0].replace("ilqr::", "").replace("void ", "")
+    rows[(name, r["Dispatch_Id"])][r["Counter_Name"]] = float(r["Counter_Value"])
+best = {}
+for (name, d), c in rows.items():
+    if name not in best or c.get("SQ_INSTS_VALU", 0) > best[name].get("SQ_INSTS_VALU", 0):
+        best[name] = c
+print("# fp64 instruction mix of the largest (full-batch) launch of every kernel, one rocprofv3 pass (wave-level instruction counts;")
+print("# exec_gflop = (ADD + MUL + 2 FMA) x 64 lanes + MOPS x 512: what the hardware issued if every lane were active)")
+print("%-30s %11s %11s %11s %11s %11s %11s %6s %10s" % ("kernel", "valu", "add_f64", "mul_f64", "fma_f64", "trans_f64", "mfma_mops", "f64%", "exec_gflop"))
+for name, c in sorted(best.items(), key=lambda kv: -kv[1].get("SQ_INSTS_VALU", 0)):
+    if not name.startswith("k_"):
+        continue
+    g = lambda k: c.get(k, 0.0)
+    a, m, f, t, v, mo = g("SQ_INSTS_VALU_ADD_F64"), g("SQ_INSTS_VALU_MUL_F64"), g("SQ_INSTS_VALU_FMA_F64"), g("SQ_INSTS_VALU_TRANS_F64"), g("SQ_INSTS_VALU"), g("SQ_INSTS_VALU_MFMA_MOPS_F64")
+    print("%-30s %11.4g %11.4g %11.4g %11.4g %11.4g %11.4g %6.1f %10.1f" % (name[:30], v, a, m, f, t, mo, 100 * (a + m + f + t) / max(v, 1), ((a + m + 2 * f) * 64 + mo * 512) / 1e9))
+PY
+echo "[collect] fp64 mix done"
+rocprofv3 --kernel-trace --output-format csv -d "$out/tr" -o t -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-contact-line > "$out/bench_trace.log" 2>&1
+f=$(find "$out/tr" -name "*kernel_trace.csv" | head -1)
+python3 tools/timeline.py "$f" 16 > "$out/${tag}_iteration_timeline.txt"
+python3 tools/timeline.py "$f" 5 all | sed -n '/^iter/,$p' > "$out/${tag}_iteration_spans_fixed_and_early_exit.txt"
+rm -rf "$out/tr"
+echo "[collect] timelines done"
+# the contact workload's own passes: per-kernel time and HBM traffic of `bench.py --contact`
+CB="python3 bench.py --contact --steps 1 --warmup 0 --no-cpu-baseline"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$out/cst" -o k -- python3 bench.py --contact --steps 2 --warmup 1 --no-cpu-baseline > "$out/bench_contact_stats.log" 2>&1
+cp "$(find "$out/cst" -name '*kernel_stats.csv' | head -1)" "$out/${tag}_contact_kernel_stats.csv"; rm -rf "$out/cst"
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$out/cf" -o f -- $CB > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$out/cw" -o w -- $CB > /dev/null 2>&1
+cp "$(find "$out/cf" -name '*counter_collection.csv' | head -1)" "$out/${tag}_pmc/contact_fetch_size_counter_collection.csv"
+cp "$(find "$out/cw" -name '*counter_collection.csv' | head -1)" "$out/${tag}_pmc/contact_write_size_counter_collection.csv"
+rm -rf "$out/cf" "$out/cw"
+python3 tools/pmc_summary.py --traffic-json "$out/${tag}_contact_traffic.json" --stamp "$(python3 bench.py --contact --print-signature)" \
+  "$out/${tag}_pmc/contact_fetch_size_counter_collection.csv" "$out/${tag}_pmc/contact_write_size_counter_collection.csv" > /dev/null
+echo "[collect] contact passes done"
+mkdir -p "$out/${tag}_bench_lines"
+L="$out/${tag}_bench_lines"
+python3 bench.py 2>/dev/null | grep '^{' > "$L/bench_default.json"; echo "[collect] default line done"
+python3 bench.py --contact --no-cpu-baseline 2>/dev/null | grep '^{' > "$L/bench_contact.json"
+python3 bench.py --batch 1 --no-cpu-baseline --no-contact-line --steps 20 --warmup 3 2>/dev/null | grep '^{' > "$L/bench_b1.json"
+python3 bench.py --stage rollout_jacobians --batch 1024 --no-cpu-baseline --steps 20 --warmup 3 2>/dev/null | grep '^{' > "$L/bench_cfg1.json"
+python3 bench.py --batch 1024 --no-cpu-baseline --no-contact-line 2>/dev/null | grep '^{' > "$L/bench_b1024.json"
+python3 bench.py --batch 1024 --horizon 50 --no-cpu-baseline --no-contact-line 2>/dev/null | grep '^{' > "$L/bench_b1024_n50.json"
+python3 bench.py --batch 8192 --no-cpu-baseline --no-contact-line 2>/dev/null | grep '^{' > "$L/bench_b8192.json"
+echo "[collect] small lines done"
+python3 bench.py --workload config3 --steps 3 --no-cpu-baseline 2>/dev/null | grep '^{' > "$L/bench_config3_global_batch_one_gpu.json"
+python3 bench.py --workload config4 --steps 3 2>/dev/null | grep '^{' > "$L/bench_config4_global_batch_one_gpu.json"
+echo "[collect] all done"
+ls "$out" "$L"

@@ -10,7 +10,7 @@ it = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 rows = [r for r in csv.DictReader(open(path))]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 # an iteration starts at each k_cost_quadratics launch that follows a k_control
-marks = [i for i, r in enumerate(rows) if "k_cost_quadratics" in r["Kernel_Name"]]
+marks = [i for i, r in enumerate(rows) if "k_quad_kin" in r["Kernel_Name"]]
 lo = marks[it]
 # include the kernels that started a little before (lin primal / rollout of the same fork)
 while lo > 0 and "k_control" not in rows[lo - 1]["Kernel_Name"] and "k_solve_begin" not in rows[lo - 1]["Kernel_Name"]:
@@ -49,6 +49,6 @@ if len(sys.argv) > 3 and sys.argv[3] == "all":
         parts = []
         for r in seg:
             nm = r["Kernel_Name"].replace("void ", "").replace("ilqr::", "").split("(")[0].split("<")[0]
-            if nm in ("k_lin_primal_r", "k_lin_primal_s", "k_lin_tangent", "k_cost_quadratics", "k_backward_wave", "k_line_search_s", "k_rollout_s"):
-                parts.append("%s %.0f" % (nm[2:9], (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3))
+            if nm in ("k_lin_primal_r", "k_lin_primal_s", "k_lin_tangent", "k_lin_tangent2", "k_lin_tangent2c", "k_quad_kin", "k_cost_quadratics", "k_backward_wave", "k_line_search_s", "k_rollout_s"):
+                parts.append("%s %.0f" % (nm[2:14], (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3))
         print("%4d %9.1f  %s" % (k, (b - a) / 1e3, "  ".join(parts)))
