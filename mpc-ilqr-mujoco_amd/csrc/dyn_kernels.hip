@@ -297,7 +297,7 @@ __global__ void __launch_bounds__(64) k_lin_primal_r(DevState S, ProblemDev P, i
     if (ui > h1c::C_CTRLRANGE[i][1]) ui = h1c::C_CTRLRANGE[i][1];
     tau[i] = ui - H1_DAMPING * x[H1_NQ + 6 + i];
   }
-  double* g = S.lin_dump + (size_t)knot * LinDumpG_SIZE;
+  double* g = (double*)__builtin_assume_aligned(S.lin_dump + (size_t)knot * LinDumpG_SIZE, 16);
   DumpSink sink{g};
   double inv36[36], aL[3];
   h1r::forward_dynamics(R0, x + 7, x + H1_NQ, tau, H1_ARMATURE + h * H1_DAMPING, P.dyn.g, L, qacc, sink, inv36, aL);

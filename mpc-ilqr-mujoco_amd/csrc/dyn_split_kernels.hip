@@ -164,13 +164,13 @@ __global__ void __launch_bounds__(64) k_line_search_s(DevState S, ProblemDev P, 
     // exchange and its barrier -- a second exposed HBM round trip per step), then this lane's half of the nominal state (for
     // x - xbar), nominal control and feedforward.  The scheduling fence keeps the order of issue.
     typedef double v4d_s __attribute__((ext_vector_type(4)));
-    typedef double v2d_s __attribute__((ext_vector_type(2)));
+    typedef double v2d_s __attribute__((ext_vector_type(2), aligned(8)));      // rows of K_t have an odd pitch (51 doubles): the pairs are 8-byte aligned only
     const int lk = lane >> 4, lr = lane & 15;
     const int rowA1 = (16 + lr) < m ? (16 + lr) : (m - 1);
     // K_t operands of the MFMA feedback, fetched sector by sector.  The 51 contraction indices can be dealt to the (k-step,
     // lk) slots in any order as long as both operands agree: instruction j = 0..5 takes 16 bytes per lane at
     // K_t[row][8 j + 2 lk], i.e. indices 8 j + 2 lk + h (h = 0, 1) for the k-steps 2 j + h, so the four lk lanes of a row
-    // fetch ONE contiguous 64-byte sector and every sector of K_t is requested exactly once (with the plain mapping 4 sk + lk
+    // fetch ONE contiguous 64-byte run (one or two sectors, the rows not being sector-aligned) and every byte of K_t is requested exactly once (with the plain mapping 4 sk + lk
     // a lane fetched 8 bytes and every sector was requested by two to four instructions, out of an L1 the four waves of a
     // CU thrash: the line search waited on its own re-fetches); k-step 12 takes the last three columns 48 + lk as before.
     const unsigned offA0 = (unsigned)(lr * n + 2 * lk), offA1 = (unsigned)(rowA1 * n + 2 * lk);
@@ -359,7 +359,7 @@ __global__ void __launch_bounds__(64) k_lin_primal_s(DevState S, ProblemDev P, i
   for (int k = 0; k < 5; ++k) tau.tL[k] = h1s::clampu(u.uL[k], h1s::C_CTRLRANGE[h1s::jleg(side, k)]) - h1s::DAMPING * h.q.qdL[k];
 #pragma unroll
   for (int k = 0; k < 4; ++k) tau.tA[k] = h1s::clampu(u.uA[k], h1s::C_CTRLRANGE[h1s::jarm(side, k)]) - h1s::DAMPING * h.q.qdA[k];
-  double* g = S.lin_dump + ((size_t)b * S.N + t) * LinDumpG_SIZE;
+  double* g = (double*)__builtin_assume_aligned(S.lin_dump + ((size_t)b * S.N + t) * LinDumpG_SIZE, 16);     // (even record size, hipMalloc'ed base)
   DumpSinkS all{g};
   // pelvis and torso are computed on both lanes: only the left one stores them
   auto sink = [&](int i, const double* v, const double* a, double s, double c) { if (!side || (i != 0 && i != 11)) all(i, v, a, s, c); };

@@ -20,8 +20,13 @@
 namespace h1 {
 
 // global (HBM) layout of the primal dump of one knot, written by k_lin_primal_r (doubles)
-enum { LinDumpG_R0 = 0, LinDumpG_aL = 9, LinDumpG_qacc = 12, LinDumpG_sc = 37, LinDumpG_v = 77, LinDumpG_a = 197,
-       LinDumpG_U = 317, LinDumpG_Dinv = 437, LinDumpG_IA0inv = 457, LinDumpG_SIZE = 493 };
+// Every block starts at an even offset and the record has an even size: the primal kernels' pieces (pairs of sin / cos, the
+// 6-vectors of a body, the rows of the pelvis inverse) are then 16-byte aligned and leave as dwordx4 stores -- half the store
+// instructions of a kernel that spends 78 % of its cycles stalled on store issue (round 4; the record was 493 doubles with odd offsets).
+// (Measured and not kept: 16 knots interleaved per line as for the cost quadratics' record -- the primal kernel halves, 304 -> 143 us,
+// but the tangent kernels' load turns into a 493-line gather per knot: 1.53 -> 1.82 ms.)
+enum { LinDumpG_R0 = 0, LinDumpG_aL = 10, LinDumpG_qacc = 14, LinDumpG_sc = 40, LinDumpG_v = 80, LinDumpG_a = 200,
+       LinDumpG_U = 320, LinDumpG_Dinv = 440, LinDumpG_IA0inv = 460, LinDumpG_SIZE = 496 };
 
 #define LIN_NDIR 47   // tangent directions: phi(3) theta(19) v_lin(3) omega(3) thetadot(19)
 #define LIN_LD 48     // padded lane stride of the direction arrays

@@ -287,6 +287,16 @@ int ilqr_hip_set_options(ilqr_hip_ctx* c, int jacobian_mode, double fd_eps, int 
 int ilqr_hip_set_early_exit_gate(ilqr_hip_ctx* c, int on) { if (!c) return ILQR_ERR_ARG; c->ee_gate = on ? 1 : 0; return ILQR_OK; }
 
 // ---------------------------------------------------------------- initializeWithReference
+// Which kernel rolls a trajectory out under these switches: the scalar kernels (ILQR_DYN=s), the two-lane kernels (ILQR_ROLLOUT=s,
+// and always in contact mode) or the one-lane ones.  Iteration 0 of a solve may re-roll a cold start BESIDE the linearisation only
+// if it is this very kernel under these very dynamics parameters (bit-identical result); compared field by field, not by memcmp
+// (padding bytes).
+static int rollout_kernel_identity(const h1::ProblemDev& P) {
+  return ilqr::variant_scalar_dyn() ? 2 : ((ilqr::variant_rollout_split() || P.dyn.contact) ? 1 : 0);
+}
+static bool same_dyn(const h1::DynParams& a, const h1::DynParams& b) {
+  return a.h == b.h && a.g[0] == b.g[0] && a.g[1] == b.g[1] && a.g[2] == b.g[2] && a.contact == b.contact && a.soft == b.soft;
+}
 static int cold_start_device(ilqr_hip_ctx* c, const double* x0_dev, const double* uinit_dev) {
   const size_t B = c->B, N = c->N;
   HIPCHK(c, hipMemcpyAsync(c->S.x0, x0_dev, B * ILQR_NX * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
@@ -295,7 +305,7 @@ static int cold_start_device(ilqr_hip_ctx* c, const double* x0_dev, const double
   HIPCHK(c, hipGetLastError());
   c->initialized = true;
   c->xbar_rolled = true;
-  c->rolled_variant = ilqr::variant_rollout_split(); c->rolled_dyn = c->P.dyn;
+  c->rolled_variant = rollout_kernel_identity(c->P); c->rolled_dyn = c->P.dyn;
   return ILQR_OK;
 }
 int ilqr_hip_initialize_device(ilqr_hip_ctx* c, const double* x0_device, const double* u_init_device) {
@@ -436,7 +446,7 @@ static int enqueue_solve(ilqr_hip_ctx* c, const DevState& S, const h1::ProblemDe
   const bool xbar_rolled = c->first_aside;
   // the one-wave Riccati kernel reads only the tiles I >= J of lxx_t (t < N): the cost quadratics then leave the others unwritten
   const int lxx_lower = ilqr::variant_backward() == 2 ? 1 : 0;
-  if (lxx_lower) c->lxx_lower = true;
+  c->lxx_lower = lxx_lower != 0;      // (iteration 0 rewrites lxx of every rollout: a solve on a full-matrix family leaves the whole matrix behind)
   // ... and, folded, never the rows 8..23 of A_t / B_t: the two-knot tangent kernel then leaves them unwritten
   const int skip_fold_rows = (fold_h != 0.0 && ilqr::linearize_skips_fold_rows(P, c->jac_mode)) ? 1 : 0;
   c->ab_unfold_h = skip_fold_rows ? fold_h : 0.0;
@@ -517,7 +527,7 @@ int ilqr_hip_solve_async(ilqr_hip_ctx* c) {
   const int k = slices_wanted(c->B);
   c->n_slices = k;
   c->lin_fold_h = ilqr::linearize_fold_h(P, c->jac_mode);   // what S.A / S.Bm hold after this solve
-  c->first_aside = c->xbar_rolled && c->rolled_variant == ilqr::variant_rollout_split() && std::memcmp(&c->rolled_dyn, &P.dyn, sizeof(P.dyn)) == 0;
+  c->first_aside = c->xbar_rolled && c->rolled_variant == rollout_kernel_identity(P) && same_dyn(c->rolled_dyn, P.dyn);
   c->xbar_rolled = false;                                   // after this solve xbar is an accepted line-search candidate
   if (k <= 1) {
     TRY(enqueue_solve(c, S, P, st, c->stream2, c->stream3, c->ev_fork, c->ev_join, c->ev_roll, c->d_shadowx, nullptr, nullptr, c->ev_lin, c->ev_adopt));

@@ -27,7 +27,7 @@ struct DevState {
   double* Bm;          // [B][N][51][19]
   double* lx;          // [B][N+1][51]
   double* lu;          // [B][N][19]
-  double* lxx;         // [B][N+1][51][51]
+  double* lxx;         // [B][N+1][51][51]  (inside a solve with the one-wave Riccati kernel: knots t < N hold the 16 x 16 tiles I >= J only)
   double* luu;         // [B][N][19]        diagonal
   double* K;           // [B][N][19][51]
   double* kff;         // [B][N][19]
