@@ -601,6 +601,22 @@ def test_bench_two_ranks_rehearsed_on_one_gpu(try_rccl):
         assert "gloo" in d["config"]["collective"] and d["config"]["collective_error"] is None
 
 
+def test_bench_gpus_2_without_a_launcher_starts_its_own_ranks():
+    """`python bench.py --gpus 2 --rehearse-single-gpu` started PLAINLY (no torch.distributed.run around it, the way the driver
+    starts `--gpus 1`): the parent never touches the GPU, starts the two ranks as a child process and relays rank 0's line --
+    `n_gpus: 2`, the global batch of both ranks gathered, the launcher named in the line (it used to time one rank)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--batch", "64", "--steps", "1", "--warmup", "0", "--rehearse-single-gpu"],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 128 and d["value"] > 0
+    assert d["config"]["gather_check"] == "rank 0 received 128 rows in global rollout order"
+    assert d["config"]["launcher"].startswith("self-launched") and "gloo" in d["config"]["barrier"]
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # C++ drop-in sharding without Python: the demo's one-rank form against the Python wrapper on the same rollouts
 def _demo_rollout(g, N):
