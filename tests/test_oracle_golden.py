@@ -226,6 +226,38 @@ def test_analytic_jacobians_vs_finite_differences():
     assert np.abs(o.get("A")[0] - A0).max() < 5e-5 and np.abs(o.get("B")[0] - B0).max() < 1e-7
 
 
+def test_structure_of_the_step_jacobians_the_tangent_and_riccati_kernels_rely_on():
+    """Two structural facts the round-4 tangent kernel (k_lin_tangent2) and the folded Riccati kernel build on, checked on the oracle's
+    forward-mode AD Jacobians of the constraint-free step and on a complex-step-free, plain central difference of the step itself:
+    (i) Galilean invariance -- the step does not depend on the base's linear velocity beyond the integrator: d f / d v_lin =
+    [h I; 0; I; 0] (so the kernel does not sweep those three directions); (ii) the semi-implicit Euler integrator makes every
+    hinge-position row a copy of its velocity row: A[7 + j] = e_(7+j) + h A[32 + j], B[7 + j] = h B[32 + j] (rows 8..23 are the ones the
+    folded kernel never reads and k_lin_tangent2<true> does not write)."""
+    h = 0.02
+    o = ol.Oracle(2, h)
+    rng = np.random.default_rng(11)
+    for gravity in ((0.0, 0.0, -1.0), (0.0, 0.0, -9.81)):
+        prob = sc.make_problem(ol.reference_kinematics, N=2, gravity=gravity)
+        o.set_problem(prob)
+        x = sc.standing_state()
+        x[7:26] = rng.uniform(-0.4, 0.4, 19); x[3:7] = sc._axis_angle_quat(rng.uniform(-0.8, 0.8, 3)); x[26:] = rng.uniform(-1.5, 1.5, 25)
+        u = rng.uniform(-20, 20, 19)
+        o.set_trajectory(np.tile(x, (3, 1)), np.tile(u, (2, 1)))
+        o.set_options(jac_mode=0)
+        o.linearize()
+        A, B = o.get("A")[0], o.get("B")[0]
+        C = np.zeros((51, 3)); C[0:3] = h * np.eye(3); C[26:29] = np.eye(3)
+        assert np.abs(A[:, 26:29] - C).max() < 1e-15
+        # the same from the step itself (no derivative code involved): shifting v_lin shifts p' by h dv and v_lin' by dv, nothing else
+        dv = np.array([0.3, -0.2, 0.5])
+        x2 = x.copy(); x2[26:29] += dv
+        d = o.step(x2, u) - o.step(x, u)
+        want = np.zeros(51); want[0:3] = h * dv; want[26:29] = dv
+        assert np.abs(d - want).max() < 1e-13
+        E = np.zeros((19, 51)); E[np.arange(19), 7 + np.arange(19)] = 1.0
+        assert np.abs(A[7:26] - (E + h * A[32:51])).max() < 1e-15 and np.abs(B[7:26] - h * B[32:51]).max() < 1e-15
+
+
 def test_solve_control_flow_and_trace():
     o = ol.Oracle(25, 0.02)
     prob = sc.make_problem(ol.reference_kinematics)

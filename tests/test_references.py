@@ -175,3 +175,21 @@ def test_prepare_reference_on_walking_pin_rows_beyond_the_shipped_schedule(tmp_p
     with pytest.raises(ValueError):
         (tmp_path / "empty.csv").write_text("1,2,3\n")
         rf.prepare_reference(str(tmp_path / "empty.csv"), 0.02, sv.foot_clearance)
+
+
+def test_walking_batch_of_configs4_is_built_from_the_reference_rows_and_their_contact_schedule():
+    """scenario.walking_batch (bench.py --workload config4 and the -m gpu tests of BASELINE configs[4]): per-rollout windows of the
+    walking reference with their own contact schedule, initial states on the (perturbed) reference, host-side only."""
+    B, N = 16, 50
+    prob, x0, ui, t0 = sc.walking_batch(B, N, 3, os.path.join(G, "refdata_golden.npz"), sv, rf)
+    assert prob["N"] == N and prob["x_ref"].shape == (B, N + 1, 51) and prob["stance"].shape == (B, N + 1, 2) and prob["ee_ref"].shape[:2] == (B, N + 1)
+    assert x0.shape == (B, 51) and ui.shape == (B, N, 19) and len(set(t0.tolist())) > 4
+    assert set(np.unique(prob["stance"]).tolist()) <= {0, 1} and prob["stance"].min() == 0      # swing phases are in the windows
+    # a window's first reference row is the row the rollout starts from, up to the perturbation of the initial state
+    assert np.abs(x0[:, 7:26] - prob["x_ref"][:, 0, 7:26]).max() <= 0.02 + 1e-12 and np.abs(x0[:, 0:3] - prob["x_ref"][:, 0, 0:3]).max() <= 0.01 + 1e-12
+    assert np.abs(np.linalg.norm(x0[:, 3:7], axis=1) - 1).max() < 1e-5        # (the CSV rows carry six digits; the step normalises)
+    # horizon-local contact index (SURVEY Appendix D #3): the window's schedule rows are the reference's rows t0 .. t0 + N
+    r = np.load(os.path.join(G, "refdata_golden.npz"))
+    flags = (r["walking_pin_clearance"] < 0).astype(np.int32)
+    for b in range(B):
+        assert np.array_equal(prob["stance"][b], flags[t0[b]:t0[b] + N + 1])
