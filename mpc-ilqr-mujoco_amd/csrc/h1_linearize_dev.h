@@ -781,6 +781,62 @@ DEVFN void lin2_tangent_pelvis(LinShared& L, int lane) {
     if (kind == DIR_THETADOT) L.dT[5 + idx][lane] += H1_DAMPING;
   }
 }
+// lin_load_dump2 for both knots of a four-wave workgroup (tid 0..255): the plain copies by knot slot tid >> 7 as before; the two
+// rebuild roles -- joint rotations + parent accelerations, body forces + momenta: lane = body, 19 / 20 lanes -- packed for both knots
+// on waves 0 and 1 (lane = (knot slot, body)) instead of running on all four waves with a third of their lanes.
+DEVFN void lin2_load_dump(LinShared* L2, const double* g0, const double* g1, int tid, const double* xg0, const double* ug0, const double* xg1, const double* ug1) {
+  const int ks = tid >> 7, t7 = tid & 127, wv = tid >> 6, lane = tid & 63;
+  LinShared& L = L2[ks];
+  LinDump& D = L.D;
+  const double* g = ks ? g1 : g0;
+  const double r0 = g[LinDumpG_R0 + (t7 < 9 ? t7 : 0)];
+  const double al = g[LinDumpG_aL + (t7 < 3 ? t7 : 0)];
+  const double qa = g[LinDumpG_qacc + (t7 < H1_NV ? t7 : 0)];
+  const int ev = t7 < H1_NB * 6 ? t7 : 0;
+  const double vv = g[LinDumpG_v + ev], uu = g[LinDumpG_U + ev];
+  const double di = g[LinDumpG_Dinv + (t7 < H1_NB ? t7 : 0)];
+  const double ia = g[LinDumpG_IA0inv + (t7 < 36 ? t7 : 0)];
+  const double* xg = ks ? xg1 : xg0; const double* ug = ks ? ug1 : ug0;
+  const double xu = (t7 < 64) ? xg[t7 < H1_NX ? t7 : 0] : ug[(t7 - 64) < H1_NU ? t7 - 64 : 0];
+  // rebuild roles on waves 0 / 1: knot slot lane >> 5, body lane & 31
+  const int kr = lane >> 5, bi = lane & 31;
+  const double* gr = kr ? g1 : g0;
+  const int i0 = (bi >= 1 && bi < H1_NB) ? bi : 1, i1 = bi < H1_NB ? bi : 0;
+  const int ib = wv == 0 ? i0 : i1;
+  const int par0 = (i0 == 1 || i0 == 6 || i0 == 11) ? 0 : ((i0 == 12 || i0 == 16) ? 11 : i0 - 1);
+  double w6[6], a6[6], s = 0.0, c = 0.0;
+  if (wv < 2) {
+    const double* p6 = gr + (wv == 0 ? LinDumpG_a + 6 * par0 : LinDumpG_v + 6 * i1);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) { w6[k] = p6[k]; a6[k] = gr[LinDumpG_a + 6 * ib + k]; }
+    s = gr[LinDumpG_sc + 2 * i0]; c = gr[LinDumpG_sc + 2 * i0 + 1];
+  }
+  if (t7 < H1_NX) L.x[t7] = xu;
+  if (t7 >= 64 && t7 < 64 + H1_NU) L.u_[t7 - 64] = xu;
+  if (t7 < 9) D.R0[t7] = r0;
+  if (t7 < 3) D.aL[t7] = al;
+  if (t7 < H1_NV) D.qacc[t7] = qa;
+  if (t7 < H1_NB * 6) { (&D.v[0][0])[t7] = vv; (&L.u.m.U[0][0])[t7] = uu; }
+  if (t7 < H1_NB) L.u.m.Dinv[t7] = di;
+  if (t7 < 36) L.u.m.IA0inv[t7] = ia;
+  LinShared& Lr = L2[kr];
+  if (wv == 0 && bi >= 1 && bi < H1_NB) {
+    const int i = bi, a = H1_AXIS[i], b = (a + 1) % 3, d = (a + 2) % 3;
+    for (int r = 0; r < 3; ++r) {
+      const double fa = H1_RFIX[i][r][a], fb = H1_RFIX[i][r][b], fd = H1_RFIX[i][r][d];
+      Lr.D.Rj[i][3 * r + a] = fa; Lr.D.Rj[i][3 * r + b] = fb * c + fd * s; Lr.D.Rj[i][3 * r + d] = fd * c - fb * s;
+    }
+    double xa[6];
+    xf_motion(Lr.D.Rj[i], H1_POS[i], w6, xa);
+    for (int k = 0; k < 6; ++k) Lr.xa[i][k] = xa[k];
+  }
+  if (wv == 1 && bi < H1_NB) {
+    const int i = bi;
+    double Iv[6], Ia[6], vIv[6];
+    inertia_mul(i, w6, Iv); inertia_mul(i, a6, Ia); crf(w6, Iv, vIv);
+    for (int k = 0; k < 6; ++k) { Lr.D.F[i][k] = Ia[k] + vIv[k]; Lr.Iv[i][k] = Iv[k]; }
+  }
+}
 // lin_accumulate_forces_w for two knots on one wave: lane = (knot slot, body)
 DEVFN void lin2_accumulate_forces_w(LinShared* L2, int lane) {
   LinShared& L = L2[lane >> 5];

@@ -178,9 +178,9 @@ __global__ void __launch_bounds__(256, 3) k_lin_tangent2(DevState S, ProblemDev 
   }
   if (!valid[0] && !valid[1]) return;
   {
-    const size_t kn = knot[ks];
-    const size_t bb = kn / N, tt = kn - bb * N;
-    lin_load_dump2(L2[ks], S.lin_dump + kn * LinDumpG_SIZE, tid7, S.xbar + (bb * (N + 1) + tt) * H1_NX, S.ubar + kn * H1_NU);
+    const size_t b0 = knot[0] / N, t0 = knot[0] - b0 * N, b1 = knot[1] / N, t1 = knot[1] - b1 * N;
+    lin2_load_dump(L2, S.lin_dump + knot[0] * LinDumpG_SIZE, S.lin_dump + knot[1] * LinDumpG_SIZE, tid, S.xbar + (b0 * (N + 1) + t0) * H1_NX, S.ubar + knot[0] * H1_NU,
+                   S.xbar + (b1 * (N + 1) + t1) * H1_NX, S.ubar + knot[1] * H1_NU);
     if (tid7 == 127) L2[ks].h = P.dyn.h;
     for (int e = tid7; e < H1_NV * LIN_LD; e += 128) (&L2[ks].dT[0][0])[e] = 0.0;     // all rows: the v_lin columns are written by nobody
   }

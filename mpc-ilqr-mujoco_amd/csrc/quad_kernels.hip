@@ -173,11 +173,31 @@ __global__ void __launch_bounds__(64) k_quad_kin(DevState S, ProblemDev P, const
   const int N1 = S.N + 1;
   const unsigned g = blockIdx.x * 64u + threadIdx.x;                    // (32-bit on purpose: a 64-bit division is ~150 scalar instructions)
   const unsigned total = (unsigned)(list ? *count : S.B) * (unsigned)N1;
-  if (g >= total) return;
-  const int bs = (int)(g / (unsigned)N1), t = (int)(g - (unsigned)bs * (unsigned)N1);
+  if (blockIdx.x * 64u >= total) return;                               // (whole wave past the end)
+  // a lane past the end repeats the last knot (same values to the same record: harmless) so that the wave loads cooperatively
+  const unsigned gc = g < total ? g : total - 1u;
+  const int bs = (int)(gc / (unsigned)N1), t = (int)(gc - (unsigned)bs * (unsigned)N1);
   const int b = list ? list[bs] : bs;
   const bool term = (t == S.N);
-  const double* xg = S.xbar + ((size_t)b * N1 + t) * H1_NX;
+  // The wave's 64 states through LDS: read knot-major by one lane each they were 51 loads x 64 different lines; the flattened
+  // [64][51] block is fetched 64 consecutive doubles per instruction (consecutive knots are contiguous in xbar) and each lane then
+  // reads its own row (odd pitch: no bank conflicts).
+  __shared__ double xs[64 * H1_NX];
+  __shared__ const double* xrow[64];
+  xrow[threadIdx.x] = S.xbar + ((size_t)b * N1 + t) * H1_NX;
+  __syncthreads();
+  {
+    double tmp[H1_NX];
+#pragma unroll
+    for (int it = 0; it < H1_NX; ++it) {
+      const unsigned e = 64u * it + threadIdx.x, r = (e * 5141u) >> 18, c = e - r * (unsigned)H1_NX;       // r = e / 51 for e < 3264
+      tmp[it] = xrow[r][c];
+    }
+#pragma unroll
+    for (int it = 0; it < H1_NX; ++it) xs[64 * it + threadIdx.x] = tmp[it];
+  }
+  __syncthreads();
+  const double* xg = xs + threadIdx.x * H1_NX;
   const long kn = knot0 + (long)b * N1 + t;
   double* out = rec + (size_t)(kn >> 4) * ((size_t)QREC_SIZE * QREC_GROUP) + (kn & 15);
   auto put = [&](int f, double v) { out[(size_t)f * QREC_GROUP] = v; };
