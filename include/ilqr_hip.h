@@ -177,9 +177,16 @@ int ilqr_hip_step(ilqr_hip_ctx* ctx, int count, const double* x /*[count][51]*/,
    reference's forward differences (ILQR_JAC_FD_FORWARD, robot_utils.cpp:120-160), as ilqr_hip_set_options selects.
    ilqr_hip_step_stance: one step with explicit stance flags (the flags only matter in contact mode).
    ILQR_CONTACT_UNILATERAL_STANCE: the same constraint, but the floor only pushes: a scheduled stance foot whose constraint
-   force has a negative component along the world up axis is released for that step and the remaining set solved again. */
-enum ilqr_contact_mode { ILQR_CONTACT_NONE = 0, ILQR_CONTACT_RIGID_STANCE = 1, ILQR_CONTACT_UNILATERAL_STANCE = 2 };
+   force has a negative component along the world up axis is released for that step and the remaining set solved again.
+   ILQR_CONTACT_FRICTION_STANCE: unilateral, and sticking is limited by Coulomb friction, the other half of what MuJoCo's floor
+   contacts do inside mj_step: a foot whose constraint force leaves the cone |f_t| <= mu f_n (f_n along the world up axis) slides --
+   its two tangential translation rows are dropped (rotation and normal rows stay, no tangential force on a sliding foot) and
+   the set is solved again, once.  mu: ilqr_hip_set_friction (default 1, MuJoCo's default sliding friction; the reference's
+   robots/h1_description/mjcf model sets none).  Jacobians in this mode: ILQR_JAC_FD_FORWARD only (the reference's own scheme);
+   a solve / stage_linearize with ILQR_JAC_ANALYTIC returns ILQR_ERR_UNSUPPORTED. */
+enum ilqr_contact_mode { ILQR_CONTACT_NONE = 0, ILQR_CONTACT_RIGID_STANCE = 1, ILQR_CONTACT_UNILATERAL_STANCE = 2, ILQR_CONTACT_FRICTION_STANCE = 3 };
 int ilqr_hip_set_contact_mode(ilqr_hip_ctx* ctx, int mode, double softness);
+int ilqr_hip_set_friction(ilqr_hip_ctx* ctx, double mu);
 int ilqr_hip_step_stance(ilqr_hip_ctx* ctx, int count, const double* x, const double* u, int stance_left, int stance_right, double* x_next);
 
 /* per-stage device time of the last solve in milliseconds, keyed like the reference's profiler

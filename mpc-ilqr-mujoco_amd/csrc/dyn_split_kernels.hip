@@ -43,14 +43,14 @@ __device__ __forceinline__ double shfl_xor_f64(double v, int mask) {
 // The constraint-free path (contact mode 0, the headline) keeps its inlined step and is not touched by this.
 extern __shared__ double dyn_lds_c[];
 __device__ __attribute__((noinline)) void step_stance_shared(h1s::HalfX* hp, const h1s::HalfU* up, double dt, double gx, double gy, double gz,
-                                                             double soft, int mode, int st_left, int st_right) {
+                                                             double soft, int mode, int st_left, int st_right, double mu) {
   const int lane = threadIdx.x;
   const bool side = (lane & 1) != 0;
   const h1s::LaneLds L{dyn_lds_c, 64, lane};
   const double grav[3] = {gx, gy, gz};
   h1s::HalfX h = *hp;
   const h1s::HalfU u = *up;
-  h1s::step_stance(side, h, u, dt, grav, L, soft, mode, (side ? st_right : st_left) == 1, (side ? st_left : st_right) == 1);
+  h1s::step_stance(side, h, u, dt, grav, L, soft, mode, (side ? st_right : st_left) == 1, (side ? st_left : st_right) == 1, mu);
   *hp = h;
 }
 // one step of either kind; `st` = stance flags (left, right) of the knot being stepped
@@ -79,7 +79,7 @@ DEVFN void pin_half_u(h1s::HalfU& u) {
 }
 template <bool CONTACT>
 DEVFN void step_any(bool side, h1s::HalfX& h, const h1s::HalfU& u, const DynParams& dyn, const int* st, const h1s::LaneLds& L) {
-  if constexpr (CONTACT) step_stance_shared(&h, &u, dyn.h, dyn.g[0], dyn.g[1], dyn.g[2], dyn.soft, dyn.contact, st[0], st[1]);
+  if constexpr (CONTACT) step_stance_shared(&h, &u, dyn.h, dyn.g[0], dyn.g[1], dyn.g[2], dyn.soft, dyn.contact, st[0], st[1], dyn.mu);
   else {
     // (the step size behind an opaque barrier as well: with h a loop invariant the articulated quantities of the chains' leaf
     // bodies -- constants plus the armature term h * damping -- are hoisted out of the knot loop, spilled and reloaded per step)

@@ -37,6 +37,7 @@ DEVFN double xch(double v) {
   const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0xB1, 0xF, 0xF, true);
   return __hiloint2double(hi, lo);
 }
+DEVFN bool xch_flag(bool f) { return __builtin_amdgcn_update_dpp(0, f ? 1 : 0, 0xB1, 0xF, 0xF, true) != 0; }
 DEVFN double pair_sum(double v) { return v + xch(v); }   // a + b == b + a: identical on both lanes
 
 #define SD(IL, IR, expr_l, expr_r) ((IL) == (IR) ? (expr_l) : (side ? (expr_r) : (expr_l)))
@@ -716,11 +717,34 @@ DEVFN void chol12_solve(double* C, double* b) {
     b[i] = t * C[pidx(i, i)]; }
 }
 
+// Coulomb limit (contact mode 3): a sliding foot keeps the rotation rows and the normal translation row of its constraint.  With
+// Pi = blockdiag(I3, u u^T) (u: world up axis in link coordinates) the reduced system S (C + soft I) S^T lambda_s = S b, S = [I3 0; 0 u^T],
+// is the range-of-Pi part of  (Pi (C + soft I) Pi + (I - Pi)) lambda = Pi b  -- same 12 x 12 shape as the rigid system, so the
+// masked solve below serves it: this routine applies Pi from both sides to the packed matrix in place (translation block at
+// rows / columns o..o+2) and puts the identity on the removed directions.
+DEVFN void project_sliding_foot(double* Cw, int o, const double* u) {
+#pragma unroll
+  for (int j = 0; j < 12; ++j) if (j < o || j > o + 2) {
+    const double w = u[0] * Cw[pidx(o, j)] + u[1] * Cw[pidx(o + 1, j)] + u[2] * Cw[pidx(o + 2, j)];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) Cw[pidx(o + a, j)] = u[a] * w;
+  }
+  double s = 0.0;
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) s += u[a] * u[c] * Cw[pidx(o + a, o + c)];
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int c = 0; c <= a; ++c) Cw[pidx(o + a, o + c)] = u[a] * u[c] * (s - 1.0) + (a == c ? 1.0 : 0.0);
+}
+
 // Corrects the accelerations of the free solve (qbase, qacc; U_i, 1/D_i of it still in LDS) for the stance constraints.
-// st_own / st_par: stance flags of this lane's / the partner's foot; mode 2 = unilateral.  Y0, a0: pelvis articulated inertia
-// and raw (gravity-offset, body-frame) pelvis acceleration of the free solve.
+// st_own / st_par: stance flags of this lane's / the partner's foot; mode 2 = unilateral, 3 = unilateral + Coulomb limit mu.
+// Y0, a0: pelvis articulated inertia and raw (gravity-offset, body-frame) pelvis acceleration of the free solve.
 DEVFN void stance_correct(bool side, const double* R0, const double* vb, const HalfState& q, double h, double soft, int mode, bool st_own, bool st_par,
-                          const double* grav, const LaneLds& L, const Art& Y0, const double* a0, double* qbase, HalfAcc& qacc) {
+                          const double* grav, const LaneLds& L, const Art& Y0, const double* a0, double* qbase, HalfAcc& qacc, double mu = 1.0) {
   LegTrig T;
 #pragma unroll
   for (int k = 0; k < 5; ++k) h1f::sincos_fast(q.thL[k], &T.sn[k], &T.cs[k]);
@@ -794,13 +818,44 @@ DEVFN void stance_correct(bool side, const double* R0, const double* vb, const H
     chol12_solve(Cw, lam);
   };
   solve_masked();
-  if (mode == 2) {
+  if (mode >= 2) {
     // unilateral: normal force on a foot = (world up axis in link coordinates) . (force part of its multiplier)
     const double* lo = lam + (side ? 6 : 0);
     const double fz_own = zl[0] * lo[3] + zl[1] * lo[4] + zl[2] * lo[5], fz_par = xch(fz_own);
     const double fzL = side ? fz_par : fz_own, fzR = side ? fz_own : fz_par;
     const bool relL = actL && fzL < 0.0, relR = actR && fzR < 0.0;
     if (relL || relR) { actL = actL && !relL; actR = actR && !relR; solve_masked(); }
+  }
+  if (mode == 3) {
+    // Coulomb limit on the feet that still push: |f_t|^2 = |f|^2 - f_n^2 > mu^2 f_n^2 -> the foot slides (oracle
+    // forward_dynamics_mj_stance, mode 3): project its translation block on the up axis and solve once more
+    const double* lo = lam + (side ? 6 : 0);
+    const double fn = zl[0] * lo[3] + zl[1] * lo[4] + zl[2] * lo[5];
+    const double ft2 = lo[3] * lo[3] + lo[4] * lo[4] + lo[5] * lo[5] - fn * fn;
+    const bool act_own = side ? actR : actL;
+    const bool sl_own = act_own && ft2 > mu * mu * fn * fn, sl_par = xch_flag(sl_own);
+    const bool slL = side ? sl_par : sl_own, slR = side ? sl_own : sl_par;
+    if (slL || slR) {
+      double uL[3], uR[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { const double mine = zl[k], theirs = xch(mine); uL[k] = side ? theirs : mine; uR[k] = side ? mine : theirs; }
+#pragma unroll
+      for (int i = 0; i < 12; ++i) {
+        const bool ai = i < 6 ? actL : actR;
+        lam[i] = ai ? b[i] : 0.0;
+#pragma unroll
+        for (int j = 0; j < 12; ++j) if (j <= i) {
+          const bool aj = j < 6 ? actL : actR;
+          Cw[pidx(i, j)] = (ai && aj) ? C[pidx(i, j)] + (i == j ? soft : 0.0) : (i == j ? 1.0 : 0.0);
+        }
+      }
+      if (slL) { project_sliding_foot(Cw, 3, uL); const double w = uL[0] * lam[3] + uL[1] * lam[4] + uL[2] * lam[5]; lam[3] = uL[0] * w; lam[4] = uL[1] * w; lam[5] = uL[2] * w; }
+      if (slR) { project_sliding_foot(Cw, 9, uR); const double w = uR[0] * lam[9] + uR[1] * lam[10] + uR[2] * lam[11]; lam[9] = uR[0] * w; lam[10] = uR[1] * w; lam[11] = uR[2] * w; }
+      chol12_solve(Cw, lam);
+      // (the removed directions carry zero up to rounding: make it exact, both lanes alike)
+      if (slL) { const double w = uL[0] * lam[3] + uL[1] * lam[4] + uL[2] * lam[5]; lam[3] = uL[0] * w; lam[4] = uL[1] * w; lam[5] = uL[2] * w; }
+      if (slR) { const double w = uR[0] * lam[9] + uR[1] * lam[10] + uR[2] * lam[11]; lam[9] = uR[0] * w; lam[10] = uR[1] * w; lam[11] = uR[2] * w; }
+    }
   }
   // propagate the multipliers: own wrench inward, pelvis, outward along every chain of this lane
   {
@@ -921,8 +976,8 @@ DEVFN void step(bool side, HalfX& h, const HalfU& u, double dt, const double* gr
   h.quat[0] = rw / rn; h.quat[1] = rx / rn; h.quat[2] = ry / rn; h.quat[3] = rz / rn;
 }
 
-// x <- f(x, u) with the stance constraints of the scheduled feet (contact mode 1 / 2)
-DEVFN void step_stance(bool side, HalfX& h, const HalfU& u, double dt, const double* grav, const LaneLds& L, double soft, int mode, bool st_own, bool st_par) {
+// x <- f(x, u) with the stance constraints of the scheduled feet (contact mode 1 / 2 / 3)
+DEVFN void step_stance(bool side, HalfX& h, const HalfU& u, double dt, const double* grav, const LaneLds& L, double soft, int mode, bool st_own, bool st_par, double mu = 1.0) {
   const double qn = sqrt(h.quat[0] * h.quat[0] + h.quat[1] * h.quat[1] + h.quat[2] * h.quat[2] + h.quat[3] * h.quat[3]);
   const double qh[4] = {h.quat[0] / qn, h.quat[1] / qn, h.quat[2] / qn, h.quat[3] / qn};
   double R0[9]; quat_R(qh[0], qh[1], qh[2], qh[3], R0);
@@ -942,7 +997,7 @@ DEVFN void step_stance(bool side, HalfX& h, const HalfU& u, double dt, const dou
   }
   double qb[6]; HalfAcc qa; Art Y0; double a0[6];
   forward_dynamics(side, R0, h.vb, h.q, tau, ARMATURE + dt * DAMPING, grav, L, qb, qa, &Y0, a0);
-  if (st_own || st_par) stance_correct(side, R0, h.vb, h.q, dt, soft, mode, st_own, st_par, grav, L, Y0, a0, qb, qa);
+  if (st_own || st_par) stance_correct(side, R0, h.vb, h.q, dt, soft, mode, st_own, st_par, grav, L, Y0, a0, qb, qa, mu);
 #pragma unroll
   for (int k = 0; k < 6; ++k) h.vb[k] += dt * qb[k];
 #pragma unroll

@@ -56,7 +56,9 @@ struct DynParams {
   double g[3];
   int contact;      // 0: constraint-free step; 1: rigid stance constraints on the scheduled feet;
                     // 2: the same, unilateral (a stance foot the floor would have to pull on is released)
+                    // 3: unilateral + Coulomb limit (a foot outside the cone |f_t| <= mu f_n slides: tangential rows dropped)
   double soft;      // diagonal softness of the stance constraint (1 / kg)
+  double mu;        // sliding friction coefficient of mode 3
 };
 
 // ---------- 3-vectors / 3x3 (row-major) ----------

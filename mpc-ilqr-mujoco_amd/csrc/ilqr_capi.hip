@@ -152,7 +152,7 @@ int ilqr_hip_create(ilqr_hip_ctx** out, int device, int batch, int horizon, doub
   if (rc != ILQR_OK) { *out = c; return rc; }
   if (ilqr::backward_needs_lds_attr() != 0) { c->err = "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed"; *out = c; return ILQR_ERR_HIP; }
   h1::ProblemDev& P = c->P;
-  P.N = horizon; P.dyn.h = dt; P.dyn.g[0] = 0; P.dyn.g[1] = 0; P.dyn.g[2] = -9.81; P.dyn.contact = 0; P.dyn.soft = 1e-5;
+  P.N = horizon; P.dyn.h = dt; P.dyn.g[0] = 0; P.dyn.g[1] = 0; P.dyn.g[2] = -9.81; P.dyn.contact = 0; P.dyn.soft = 1e-5; P.dyn.mu = 1.0;
   for (int i = 0; i < ILQR_NX; ++i) { P.Q[i] = 1.0; P.Qf[i] = 1.0; }
   for (int i = 0; i < ILQR_NU; ++i) P.R[i] = 1.0;
   P.w_com = P.w_com_vel = P.w_ee_pos = P.w_ee_vel = P.w_upright = P.w_balance = 0.0;
@@ -295,7 +295,7 @@ static int rollout_kernel_identity(const h1::ProblemDev& P) {
   return ilqr::variant_scalar_dyn() ? 2 : ((ilqr::variant_rollout_split() || P.dyn.contact) ? 1 : 0);
 }
 static bool same_dyn(const h1::DynParams& a, const h1::DynParams& b) {
-  return a.h == b.h && a.g[0] == b.g[0] && a.g[1] == b.g[1] && a.g[2] == b.g[2] && a.contact == b.contact && a.soft == b.soft;
+  return a.h == b.h && a.g[0] == b.g[0] && a.g[1] == b.g[1] && a.g[2] == b.g[2] && a.contact == b.contact && a.soft == b.soft && a.mu == b.mu;
 }
 static int cold_start_device(ilqr_hip_ctx* c, const double* x0_dev, const double* uinit_dev) {
   const size_t B = c->B, N = c->N;
@@ -516,9 +516,19 @@ static int enqueue_solve(ilqr_hip_ctx* c, const DevState& S, const h1::ProblemDe
   return ILQR_OK;
 }
 int ilqr_hip_num_slices(const ilqr_hip_ctx* c) { return c ? slices_wanted(c->B) : -1; }
+// The analytic Jacobians differentiate the constrained step with the active set held fixed (modes 1, 2); a sliding foot's
+// constraint rows turn with the foot, which they do not carry: mode 3 linearises by the reference's forward differences.
+static int jacobians_available(ilqr_hip_ctx* c) {
+  if (c->P.dyn.contact == ILQR_CONTACT_FRICTION_STANCE && c->jac_mode == ILQR_JAC_ANALYTIC) {
+    c->err = "contact mode 3 (Coulomb limit): analytic Jacobians are not available, select ILQR_JAC_FD_FORWARD with ilqr_hip_set_options";
+    return ILQR_ERR_UNSUPPORTED;
+  }
+  return ILQR_OK;
+}
 int ilqr_hip_solve_async(ilqr_hip_ctx* c) {
   if (!c) return ILQR_ERR_ARG;
   if (!c->initialized || !c->refs_set) { c->err = "solve before initialize/set_references"; return ILQR_ERR_STATE; }
+  if (int rc = jacobians_available(c)) return rc;
   enter(c);
   hipStream_t st = c->stream;
   const DevState& S = c->S; const h1::ProblemDev& P = c->P;
@@ -644,7 +654,7 @@ int ilqr_hip_set_trajectory(ilqr_hip_ctx* c, const double* xbar, const double* u
 #define STAGE_PRE if (!c) return ILQR_ERR_ARG; if (!c->initialized) return ILQR_ERR_STATE; enter(c)
 #define STAGE_POST HIPCHK(c, hipGetLastError()); HIPCHK(c, hipStreamSynchronize(c->stream)); return ILQR_OK
 int ilqr_hip_stage_rollout(ilqr_hip_ctx* c) { STAGE_PRE; ilqr::launch_rollout(c->S, c->P, ilqr::MASK_ALL, 1, 0, c->S.Jbase, c->stream); STAGE_POST; }
-int ilqr_hip_stage_linearize(ilqr_hip_ctx* c) { STAGE_PRE; ilqr::launch_linearize(c->S, c->P, ilqr::MASK_ALL, c->jac_mode, c->fd_eps, c->stream); c->lin_fold_h = ilqr::linearize_fold_h(c->P, c->jac_mode); c->ab_unfold_h = 0.0; STAGE_POST; }
+int ilqr_hip_stage_linearize(ilqr_hip_ctx* c) { STAGE_PRE; if (int rc = jacobians_available(c)) return rc; ilqr::launch_linearize(c->S, c->P, ilqr::MASK_ALL, c->jac_mode, c->fd_eps, c->stream); c->lin_fold_h = ilqr::linearize_fold_h(c->P, c->jac_mode); c->ab_unfold_h = 0.0; STAGE_POST; }
 int ilqr_hip_stage_cost_quadratics(ilqr_hip_ctx* c) { STAGE_PRE; if (!c->refs_set) return ILQR_ERR_STATE; ilqr::launch_cost_quadratics(c->S, c->P, ilqr::MASK_ALL, c->stream); c->lxx_lower = false; STAGE_POST; }
 int ilqr_hip_stage_backward_pass(ilqr_hip_ctx* c) {
   STAGE_PRE;
@@ -738,9 +748,15 @@ int ilqr_hip_step(ilqr_hip_ctx* c, int count, const double* x, const double* u, 
   return ilqr_hip_step_stance(c, count, x, u, 1, 1, x_next);
 }
 int ilqr_hip_set_contact_mode(ilqr_hip_ctx* c, int mode, double softness) {
-  if (!c || (mode != ILQR_CONTACT_NONE && mode != ILQR_CONTACT_RIGID_STANCE && mode != ILQR_CONTACT_UNILATERAL_STANCE)) return ILQR_ERR_ARG;
+  if (!c || (mode != ILQR_CONTACT_NONE && mode != ILQR_CONTACT_RIGID_STANCE && mode != ILQR_CONTACT_UNILATERAL_STANCE && mode != ILQR_CONTACT_FRICTION_STANCE)) return ILQR_ERR_ARG;
+  if (mode == ILQR_CONTACT_FRICTION_STANCE && ilqr::variant_scalar_dyn()) { c->err = "contact mode 3 (Coulomb limit) exists on the two-lane kernels only; unset ILQR_DYN=s"; return ILQR_ERR_UNSUPPORTED; }
   c->P.dyn.contact = mode;
   if (softness > 0.0) c->P.dyn.soft = softness;
+  return ILQR_OK;
+}
+int ilqr_hip_set_friction(ilqr_hip_ctx* c, double mu) {
+  if (!c || !(mu >= 0.0)) return ILQR_ERR_ARG;
+  c->P.dyn.mu = mu;            // (a nominal rolled under another mu is recognised by same_dyn)
   return ILQR_OK;
 }
 int ilqr_hip_step_stance(ilqr_hip_ctx* c, int count, const double* x, const double* u, int stance_left, int stance_right, double* x_next) {

@@ -29,6 +29,9 @@ struct DynParams {
   double g[3];  // world gravity vector
   int contact = 0;       // 0: constraint-free step; 1: rigid stance constraints on the scheduled feet;
                          // 2: the same, unilateral: a stance foot the floor would have to pull on is released
+                         // 3: unilateral + Coulomb limit: a foot whose force leaves the cone |f_t| <= mu f_n slides (its two
+                         //    tangential translation rows are dropped, rotation + normal rows stay; solved again, once)
+  double mu = 1.0;       // sliding friction coefficient of mode 3 (MuJoCo's default geom friction; the H1 model file sets none)
   double soft = 1e-5;    // diagonal softness of the stance constraint (1 / kg), keeps J Minv J^T invertible with straight knees
 };
 
@@ -268,7 +271,8 @@ constexpr int H1_FOOT_BODY[2] = {5, 10};   // left / right ankle link (leaf of e
 
 template <class T>
 inline void forward_dynamics_mj_stance(const T* quat_hat, const T* theta, const T* v, const T* tau, double arm_eff,
-                                       const double* grav, double h, double soft, const int* stance, T* qacc, int contact_mode = 1) {
+                                       const double* grav, double h, double soft, const int* stance, T* qacc, int contact_mode = 1,
+                                       double mu = 1.0) {
   double Isp[H1_NB][36];
   for (int i = 0; i < H1_NB; ++i) spatial_inertia(H1_MASS[i], H1_COM[i], H1_INERTIA[i], Isp[i]);
   T R0[9]; quat_wxyz_to_R(quat_hat[0], quat_hat[1], quat_hat[2], quat_hat[3], R0);
@@ -378,7 +382,7 @@ inline void forward_dynamics_mj_stance(const T* quat_hat, const T* theta, const 
       chol_solve_inplace(C, lam, nc);
     };
     solve_set();
-    if (contact_mode == 2) {
+    if (contact_mode >= 2) {
       // unilateral: the floor pushes, it does not pull.  Normal force on foot g = (world up axis in link coordinates) . (force part
       // of lambda_g); feet with a negative one are released and the remaining set is solved again (once).
       int keep[2], nk = 0;
@@ -389,6 +393,58 @@ inline void forward_dynamics_mj_stance(const T* quat_hat, const T* theta, const 
         if (!(val(fz) < 0.0)) keep[nk++] = fb[g];
       }
       if (nk < nf) { nf = nk; for (int g = 0; g < nk; ++g) fb[g] = keep[g]; if (nf > 0) solve_set(); }
+    }
+    if (contact_mode == 3 && nf > 0) {
+      // Coulomb limit on the feet that are left: f_n = up . f, |f_t|^2 = |f|^2 - f_n^2 (f: force part of lambda_g, link coordinates).
+      // A foot outside the cone slides: its constraint keeps the three rotation rows and the normal translation row,
+      //     S_g = [I3 0; 0 up^T]  (4 x 6),   (S C S^T + soft I) lambda_s = S b,   lambda = S^T lambda_s
+      // with C, b the rigid system of the current set (built again: solve_set factorises in place).
+      T up[2][3]; bool slide[2] = {false, false}; bool any = false;
+      for (int g = 0; g < nf; ++g) {
+        T zl[6] = {T(0.0), T(0.0), T(0.0), R0[6], R0[7], R0[8]};
+        for (int i = fb[g] - 4; i <= fb[g]; ++i) { T o2[6]; xf_motion(Rj[i], H1_POS[i], zl, o2); for (int k = 0; k < 6; ++k) zl[k] = o2[k]; }
+        for (int k = 0; k < 3; ++k) up[g][k] = zl[3 + k];
+        const T* f = lam + 6 * g + 3;
+        const T fn = up[g][0] * f[0] + up[g][1] * f[1] + up[g][2] * f[2];
+        const T ft2 = f[0] * f[0] + f[1] * f[1] + f[2] * f[2] - fn * fn;
+        if (val(ft2) > mu * mu * val(fn) * val(fn)) { slide[g] = true; any = true; }
+      }
+      if (any) {
+        const int nc = 6 * nf;
+        T C[144], b[12];
+        for (int g = 0; g < nf; ++g)
+          for (int c = 0; c < 6; ++c) {
+            T fext[2][6], daf[2][6];
+            for (int g2 = 0; g2 < 2; ++g2) for (int k = 0; k < 6; ++k) fext[g2][k] = T(0.0);
+            fext[g][c] = T(1.0);
+            respond(fext, daf, false, nullptr, nullptr);
+            for (int g2 = 0; g2 < nf; ++g2) for (int k = 0; k < 6; ++k) C[(6 * g2 + k) * nc + 6 * g + c] = daf[g2][k];
+          }
+        for (int g = 0; g < nf; ++g) {
+          T off[6]; for (int k = 0; k < 6; ++k) off[k] = a0p[k];
+          for (int i = fb[g] - 4; i <= fb[g]; ++i) { T o2[6]; xf_motion(Rj[i], H1_POS[i], off, o2); for (int k = 0; k < 6; ++k) off[k] = o2[k]; }
+          for (int k = 0; k < 6; ++k) b[6 * g + k] = -vel[fb[g]][k] / h - (acc[fb[g]][k] - off[k]);
+        }
+        T S[12][12]; int ns = 0;
+        for (int g = 0; g < nf; ++g) {
+          const int rows = slide[g] ? 4 : 6;
+          for (int r = 0; r < rows; ++r, ++ns) {
+            for (int c = 0; c < nc; ++c) S[ns][c] = T(0.0);
+            if (slide[g] && r == 3) for (int k = 0; k < 3; ++k) S[ns][6 * g + 3 + k] = up[g][k];
+            else S[ns][6 * g + r] = T(1.0);
+          }
+        }
+        T CS[144], Cs[144], bs[12];
+        for (int i = 0; i < nc; ++i) for (int j = 0; j < ns; ++j) { T a = T(0.0); for (int k = 0; k < nc; ++k) a += C[i * nc + k] * S[j][k]; CS[i * ns + j] = a; }
+        for (int i = 0; i < ns; ++i) {
+          for (int j = 0; j < ns; ++j) { T a = T(0.0); for (int k = 0; k < nc; ++k) a += S[i][k] * CS[k * ns + j]; Cs[i * ns + j] = a; }
+          Cs[i * ns + i] += soft;
+          T a = T(0.0); for (int k = 0; k < nc; ++k) a += S[i][k] * b[k];
+          bs[i] = a;
+        }
+        chol_solve_inplace(Cs, bs, ns);
+        for (int c = 0; c < nc; ++c) { T a = T(0.0); for (int i = 0; i < ns; ++i) a += S[i][c] * bs[i]; lam[c] = a; }
+      }
     }
     if (nf > 0) {
       T fext[2][6], daf[2][6], dq[H1_NB];
@@ -430,7 +486,7 @@ inline void h1_step(const T* x, const T* u, const DynParams& P, T* xn, const int
     tau[i] = ui - H1_DAMPING * x[H1_NQ + 6 + i];
   }
   T qacc[H1_NV];
-  if (P.contact && stance) forward_dynamics_mj_stance(qh, x + 7, x + H1_NQ, tau, H1_ARMATURE + h * H1_DAMPING, P.g, h, P.soft, stance, qacc, P.contact);
+  if (P.contact && stance) forward_dynamics_mj_stance(qh, x + 7, x + H1_NQ, tau, H1_ARMATURE + h * H1_DAMPING, P.g, h, P.soft, stance, qacc, P.contact, P.mu);
   else forward_dynamics_mj(qh, x + 7, x + H1_NQ, tau, H1_ARMATURE + h * H1_DAMPING, P.g, qacc);
   T vn[H1_NV];
   for (int i = 0; i < H1_NV; ++i) { vn[i] = x[H1_NQ + i] + h * qacc[i]; xn[H1_NQ + i] = vn[i]; }

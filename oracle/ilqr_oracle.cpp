@@ -306,6 +306,7 @@ void orc_step(void* s, const double* x, const double* u, double* xn) { Solver* S
 // one step with explicit stance flags (left, right) -- contact mode only uses them when set_contact_mode(1)
 void orc_step_stance(void* s, const double* x, const double* u, const int* stance, double* xn) { Solver* S = (Solver*)s; orc::h1_step<double>(x, u, S->P.dyn, xn, stance); }
 void orc_set_contact_mode(void* s, int mode, double soft) { Solver* S = (Solver*)s; S->P.dyn.contact = mode; if (soft > 0.0) S->P.dyn.soft = soft; }
+void orc_set_friction(void* s, double mu) { ((Solver*)s)->P.dyn.mu = mu; }   // sliding friction coefficient of contact mode 3
 void orc_rollout(void* s) { ((Solver*)s)->rollout_nominal(); }
 void orc_linearize(void* s) { ((Solver*)s)->linearize(); }
 void orc_cost_quadratics(void* s) { ((Solver*)s)->cost_quadratics(); }

@@ -235,12 +235,16 @@ def integrate_c(q, v, qacc, h):
     return np.concatenate([qn, vn])
 
 
-def kane_step_c(bodies, ctrlrange, x, u, h, grav, stance=(1, 1), contact=0, soft=1e-5, damping=1.0, armature=0.1, want=False):
+def kane_step_c(bodies, ctrlrange, x, u, h, grav, stance=(1, 1), contact=0, soft=1e-5, damping=1.0, armature=0.1, want=False, mu=1.0):
     """One MuJoCo-semantics step of the constraint-free plant (contact = 0) or with the feet the schedule
     marks as stance held by velocity-level rigid constraints over the step (contact = 1 bilateral, 2 unilateral: a foot whose
     normal force would pull is released and the rest solved again, once):
         Mhat qacc - J^T lambda = tau - D v - bias ,   J qacc + gamma + v_f / h + soft lambda = 0 ,   Mhat = M + armature + h D
-    with J, gamma from a_f(qacc) = gamma + J qacc (spatial acceleration of the ankle link in link coordinates)."""
+    with J, gamma from a_f(qacc) = gamma + J qacc (spatial acceleration of the ankle link in link coordinates).
+    contact = 3 (round 4): unilateral + Coulomb limit.  A foot whose constraint force leaves the friction cone, |f_t| > mu f_n
+    (f_n = force along the world up axis, f_t the rest of the force; MuJoCo's default sliding friction is mu = 1), cannot stick:
+    its two tangential translation rows are dropped -- the rotation rows and the normal row stay -- and the set is solved again, once
+    (`release` variant: a slipping foot receives no tangential force)."""
     q, v = x[:26], x[26:]
     z25 = np.zeros(25)
     bias, feet0 = kane_eval_c(bodies, q, v, z25, grav, armature)
@@ -253,32 +257,58 @@ def kane_step_c(bodies, ctrlrange, x, u, h, grav, stance=(1, 1), contact=0, soft
     Mh = M + h * np.diag(D)
     rhs = tau - D * v - bias
     act = [bool(contact) and stance[0] == 1, bool(contact) and stance[1] == 1]
+    slide = [False, False]
     lam = np.zeros(12, dtype=rhs.dtype)
-    for _pass in range(2):
+    re_ = (lambda a: a.real) if np.iscomplexobj(rhs) else (lambda a: a)
+    stage = 0                      # 0: rigid set; 1: after the unilateral check; 2: after the Coulomb check
+    while True:
         rows = [f for f in range(2) if act[f]]
         if not rows:
             qacc = np.linalg.solve(Mh, rhs); lam[:] = 0
             break
-        J = np.concatenate([np.stack([cols[k][1][f]["acc"] - feet0[f]["acc"] for k in range(25)], axis=1) for f in rows], axis=0)
-        b = np.concatenate([-feet0[f]["vel"] / h - feet0[f]["acc"] for f in rows])
+        # row selection per foot: all six components of the link's spatial velocity, or -- sliding -- rotation + normal translation
+        Ssel = []
+        for f in rows:
+            if slide[f]:
+                Sf = np.zeros((4, 6), dtype=feet0[f]["up"].dtype); Sf[0:3, 0:3] = np.eye(3); Sf[3, 3:6] = feet0[f]["up"]
+            else:
+                Sf = np.eye(6)
+            Ssel.append(Sf)
+        J = np.concatenate([Sf @ np.stack([cols[k][1][f]["acc"] - feet0[f]["acc"] for k in range(25)], axis=1) for Sf, f in zip(Ssel, rows)], axis=0)
+        b = np.concatenate([Sf @ (-feet0[f]["vel"] / h - feet0[f]["acc"]) for Sf, f in zip(Ssel, rows)])
         nc = J.shape[0]
         KKT = np.block([[Mh, -J.T], [J, soft * np.eye(nc)]])
         sol = np.linalg.solve(KKT, np.concatenate([rhs, b]))
         qacc = sol[:25]
         lam[:] = 0
-        for j, f in enumerate(rows):
-            lam[6 * f:6 * f + 6] = sol[25 + 6 * j:25 + 6 * j + 6]
+        o = 25
+        for Sf, f in zip(Ssel, rows):
+            lam[6 * f:6 * f + 6] = Sf.T @ sol[o:o + Sf.shape[0]]; o += Sf.shape[0]
         again = False
-        if contact == 2 and _pass == 0:
+        if contact >= 2 and stage == 0:
+            stage = 1
             for f in rows:
                 fz = feet0[f]["up"] @ lam[6 * f + 3:6 * f + 6]
-                if (fz.real if np.iscomplexobj(fz) else fz) < 0.0:
+                if re_(fz) < 0.0:
                     act[f] = False; again = True
-        if not again:
-            break
+            if again:
+                continue
+        if contact == 3 and stage == 1:
+            stage = 2
+            for f in rows:
+                if not act[f]:
+                    continue
+                fo = lam[6 * f + 3:6 * f + 6]
+                fn = feet0[f]["up"] @ fo
+                ft2 = fo @ fo - fn * fn
+                if re_(ft2) > mu * mu * re_(fn) * re_(fn):
+                    slide[f] = True; again = True
+            if again:
+                continue
+        break
     xn = integrate_c(q, v, qacc, h)
     if want:
-        return xn, qacc, Mh, lam, act
+        return xn, qacc, Mh, lam, act, slide
     return xn
 
 
@@ -300,7 +330,7 @@ def jacobians_tangent_free(bodies, ctrlrange, x, u, h, grav, damping=1.0, armatu
     r = F(q, v, qacc) + D v - tau differentiated at fixed qacc (ONE complex residual evaluation per state coordinate instead of
     a whole step with its 26), then the integrator by complex step."""
     q, v = x[:26], x[26:]
-    xn, qacc, Mh, _, _ = kane_step_c(bodies, ctrlrange, x, u, h, grav, want=True)
+    xn, qacc, Mh, _, _, _ = kane_step_c(bodies, ctrlrange, x, u, h, grav, want=True)
     D = np.concatenate([np.zeros(6), damping * np.ones(19)])
     free_u = ((u >= ctrlrange[:, 0]) & (u <= ctrlrange[:, 1])).astype(float)
     Mi = np.linalg.inv(Mh)
@@ -826,8 +856,56 @@ def gen_solve_round3():
               swing=None, u_scale=1.0, u_bias=ug)
 
 
+def gen_friction():
+    """friction_golden.npz: single steps of the stance row in contact mode 3 (unilateral + Coulomb release) -- states where the cone
+    is inactive (the step equals mode 2), where one foot slips and where both do, with the margin by which each decision is taken
+    (the oracle / the kernels must take the same branch: cases within 5 % of the cone's surface are rejected here)."""
+    bodies, ctrl = load_mjcf()
+    rng = np.random.default_rng(2026)
+    h, grav = 0.02, np.array([0.0, 0.0, -9.81])
+    out = dict(x=[], u=[], stance=[], mu=[], x_next=[], x_next_mode2=[], slide=[], act=[], lam=[])
+    tries = 0
+    want = {(0, 0): 3, (1, 0): 2, (0, 1): 2, (1, 1): 3}
+    while any(v > 0 for v in want.values()) and tries < 2000:
+        tries += 1
+        x = np.zeros(51); x[2] = 1.0432; x[3] = 1.0
+        x[0:3] += rng.uniform(-0.02, 0.02, 3)
+        aa = rng.uniform(-0.05, 0.05, 3); ang = np.linalg.norm(aa); x[3] = np.cos(ang / 2); x[4:7] = np.sin(ang / 2) / ang * aa
+        x[7:26] = rng.uniform(-0.15, 0.15, 19)
+        x[26:] = rng.uniform(-0.4, 0.4, 25)
+        x[26:29] += rng.uniform(-0.6, 0.6, 3) * (tries % 2)            # a lateral push on every second draw
+        u = rng.uniform(-20, 20, 19)
+        mu = [1.0, 0.6, 0.3, 0.1][tries % 4]
+        stance = (1, 1)
+        xn, qacc, Mh, lam, act, slide = kane_step_c(bodies, ctrl, x, u, h, grav, stance=stance, contact=3, mu=mu, want=True)
+        xn2, _, _, lam2, act2, _ = kane_step_c(bodies, ctrl, x, u, h, grav, stance=stance, contact=2, want=True)
+        # margins of the decisions on the mode-2 solution (what the Coulomb check looks at)
+        _, feet0 = kane_eval_c(bodies, x[:26], x[26:], np.zeros(25), grav, 0.1)
+        ok = True
+        for f in range(2):
+            if not act2[f]:
+                ok = False          # keep to states where both feet push (the unilateral branch has its own goldens)
+                continue
+            fo = lam2[6 * f + 3:6 * f + 6]; fn = feet0[f]["up"] @ fo; ft = np.sqrt(max(fo @ fo - fn * fn, 0.0))
+            if abs(ft / (mu * fn) - 1.0) < 0.05 or fn < 1.0:
+                ok = False
+        key = (int(slide[0]), int(slide[1]))
+        if not ok or want.get(key, 0) <= 0:
+            continue
+        want[key] -= 1
+        for k, val_ in (("x", x), ("u", u), ("stance", np.array(stance)), ("mu", mu), ("x_next", xn), ("x_next_mode2", xn2), ("slide", np.array(key)), ("act", np.array(act, dtype=int)), ("lam", lam)):
+            out[k].append(val_)
+    assert all(v == 0 for v in want.values()), want
+    np.savez(os.path.join(HERE, "friction_golden.npz"), h=h, gravity=grav, soft=1e-5, **{k: np.array(v) for k, v in out.items()})
+    sl = np.array(out["slide"])
+    print("friction golden:", len(out["x"]), "cases; sliding patterns", sl.tolist(), "max |x_next - x_next_mode2|", [float(np.abs(a - b).max()) for a, b in zip(out["x_next"], out["x_next_mode2"])])
+
+
 if __name__ == "__main__":
     import sys
+    if len(sys.argv) > 1 and sys.argv[1] == "friction":
+        gen_friction()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "refdata":
         gen_refdata()
         sys.exit(0)

@@ -130,8 +130,13 @@ class Oracle:
         self.max_iter = max_iter
 
     def set_contact_mode(self, mode, soft=0.0):
-        """0: constraint-free step; 1: rigid stance constraints on the feet the contact schedule marks."""
+        """0: constraint-free step; 1: rigid stance constraints on the feet the contact schedule marks (SURVEY 8(f) f4);
+        2: unilateral; 3: unilateral + Coulomb limit (set_friction)."""
         self.L.orc_set_contact_mode(self.h, int(mode), C.c_double(soft))
+
+    def set_friction(self, mu):
+        """Sliding friction coefficient of contact mode 3 (unilateral + Coulomb release)."""
+        self.L.orc_set_friction(self.h, C.c_double(mu))
 
     def step_stance(self, x, u, stance):
         x, u = c64(x), c64(u)

@@ -390,6 +390,69 @@ def test_unilateral_contact_mode_releases_pulled_feet_and_matches_oracle():
     s.close()
 
 
+def test_friction_limited_contact_mode_slides_feet_outside_the_cone_and_matches_oracle_and_golden():
+    """Contact mode 3 (ILQR_CONTACT_FRICTION_STANCE): unilateral stance + Coulomb limit.  (i) the step on the two-lane kernels
+    against the committed vectors of the independent NumPy KKT formulation (tests/golden/friction_golden.npz: no foot, one foot,
+    both feet sliding) and against the oracle, 1e-9; (ii) with the cone inactive the step IS mode 2, bit for bit; (iii) analytic
+    Jacobians are refused loudly in this mode; (iv) a full solve with the reference's forward-difference Jacobians on a walking
+    schedule (mu = 0.7) reproduces the oracle's trace, and the nominal re-rollout reproduces the accepted
+    candidates bit for bit."""
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "friction_golden.npz"))
+    n = len(g["x"])
+    B = n
+    prob, x0, ui = make(B, seed=28, gravity=list(g["gravity"]), walking=True)
+    s = _solver(B); s.set_problem(prob)
+    o = oracle_for(prob)
+    slid = 0
+    for i in range(n):
+        mu = float(g["mu"][i])
+        xs = np.tile(g["x"][i], (B, 1)); us = np.tile(g["u"][i], (B, 1))
+        s.set_contact_mode(3, float(g["soft"])); s.set_friction(mu)
+        got3 = s.step_stance(xs, us, int(g["stance"][i][0]), int(g["stance"][i][1]))
+        s.set_contact_mode(2, float(g["soft"]))
+        got2 = s.step_stance(xs, us, int(g["stance"][i][0]), int(g["stance"][i][1]))
+        o.set_contact_mode(3, float(g["soft"])); o.set_friction(mu)
+        want = o.step_stance(g["x"][i], g["u"][i], g["stance"][i])
+        assert np.abs(got3 - got3[0]).max() == 0.0                                    # every lane pair alike
+        assert np.abs(got3[0] - g["x_next"][i]).max() < 1e-9 * max(1.0, np.abs(g["x_next"][i]).max()), (i, np.abs(got3[0] - g["x_next"][i]).max())
+        assert np.abs(got3[0] - want).max() < 1e-9 * max(1.0, np.abs(want).max())
+        assert np.abs(got2[0] - g["x_next_mode2"][i]).max() < 1e-9 * max(1.0, np.abs(g["x_next_mode2"][i]).max())
+        if g["slide"][i].any():
+            slid += 1
+            assert np.abs(got3[0] - got2[0]).max() > 1e-3
+        else:
+            assert np.array_equal(got3[0], got2[0])
+    assert slid >= 5
+    # (iii) loud refusal of the analytic Jacobians
+    s.set_contact_mode(3); s.set_friction(0.3)
+    s.set_options(jacobian_mode=0, early_exit=False); s.set_max_iterations(3)
+    s.initialize(x0, ui)
+    with pytest.raises(RuntimeError, match="analytic Jacobians are not available"):
+        s.solve(x0)
+    # (iv) the solve, forward differences on both sides
+    Bs = 4
+    s.close()
+    prob, x0, ui = make(Bs, seed=28, gravity=list(g["gravity"]), walking=True)
+    s = _solver(Bs); s.set_problem(prob); s.set_contact_mode(3); s.set_friction(0.7)   # (the cold-started gait loads its feet sideways)
+    s.set_options(jacobian_mode=1, fd_eps=1e-5, early_exit=False); s.set_max_iterations(3)
+    s.initialize(x0, ui)
+    cost = s.solve(x0)
+    tc, ta, tl = s.trace()
+    assert s.adopt_mismatches() == 0
+    differs = 0
+    for b in range(Bs):
+        ob = oracle_for(prob, jac_mode=1, fd_eps=1e-5, early_exit=0, max_iter=3); ob.set_contact_mode(3); ob.set_friction(0.7)
+        ob.initialize(x0[b], ui[b]); ok, c = ob.solve(x0[b])
+        nn, oc, oa, ol_ = ob.trace()
+        assert nn == 3 and np.allclose(tc[b], oc, rtol=1e-5) and np.array_equal(ta[b], oa), (tc[b], oc, ta[b], oa)
+        assert abs(cost[b] - c) <= 1e-5 * abs(c) and rel(s.gains_K()[b], ob.get("K")) < 1e-4 and rel(s.xbar()[b], ob.get("xbar")) < 1e-5
+        o2 = oracle_for(prob, jac_mode=1, fd_eps=1e-5, early_exit=0, max_iter=3); o2.set_contact_mode(2)
+        o2.initialize(x0[b], ui[b]); _, c2 = o2.solve(x0[b])
+        differs += int(abs(c2 - c) > 1e-6 * abs(c))
+    assert differs >= 1                              # the cone was active somewhere along these solves
+    s.close()
+
+
 @pytest.mark.parametrize("mode", [1, 2])
 def test_contact_analytic_jacobians_match_oracle_ad(mode):
     """Contact row f4: analytic Jacobians of the stance-constrained step (k_lin_tangent_c: KKT differentiation with the contact

@@ -347,6 +347,43 @@ def test_stance_constrained_step_identities():
         assert np.abs(A[:, j] - col).max() < 1e-5 * max(1.0, np.abs(col).max()), (j, np.abs(A[:, j] - col).max())
 
 
+def test_friction_limited_stance_step_against_the_independent_kkt_formulation():
+    """Contact mode 3 (unilateral + Coulomb limit, round 4).  The oracle works through articulated-body unit-wrench responses and a
+    projected constraint-space system; tests/golden/friction_golden.npz was produced by the dense NumPy KKT formulation of
+    gen_golden.py (mass matrix by inverse dynamics, explicit constraint Jacobian, rows selected by S = [I3 0; 0 up^T] on a sliding
+    foot) -- two derivations of the same rule.  Covers: cone inactive (== mode 2), one foot sliding (left / right), both sliding;
+    and the rule's defining properties on the oracle alone: a sliding foot receives no tangential force (its horizontal
+    acceleration equals that of the foot with the tangential rows absent) while its normal velocity is still held."""
+    g = np.load(os.path.join(G, "friction_golden.npz"))
+    prob = sc.make_problem(ol.reference_kinematics, N=5, gravity=list(g["gravity"]))
+    o = ol.Oracle(5, float(g["h"])); o.set_problem(prob)
+    pat = set()
+    for i in range(len(g["x"])):
+        o.set_contact_mode(3, float(g["soft"])); o.set_friction(float(g["mu"][i]))
+        xn = o.step_stance(g["x"][i], g["u"][i], g["stance"][i])
+        o.set_contact_mode(2, float(g["soft"]))
+        x2 = o.step_stance(g["x"][i], g["u"][i], g["stance"][i])
+        assert np.abs(xn - g["x_next"][i]).max() < 1e-9 * max(1.0, np.abs(g["x_next"][i]).max()), (i, np.abs(xn - g["x_next"][i]).max())
+        assert np.abs(x2 - g["x_next_mode2"][i]).max() < 1e-9 * max(1.0, np.abs(g["x_next_mode2"][i]).max())
+        if g["slide"][i].any():
+            assert np.abs(xn - x2).max() > 1e-3
+        else:
+            assert np.array_equal(xn, x2)
+        pat.add(tuple(int(v) for v in g["slide"][i]))
+        # normal velocity of every foot that carries load is held either way: the foot's height moves O(h^2)
+        ee0 = ol.reference_kinematics(g["x"][i])[1]; ee1 = ol.reference_kinematics(xn)[1]
+        for f in range(2):
+            if g["act"][i][f]:
+                assert abs(ee1[f][2] - ee0[f][2]) < 2e-3, (i, f, ee1[f][2] - ee0[f][2])
+    assert pat == {(0, 0), (1, 0), (0, 1), (1, 1)}
+    # mu = 0: every loaded foot slides; a huge mu: none does (== mode 2)
+    i = 0
+    o.set_contact_mode(3, float(g["soft"])); o.set_friction(1e9)
+    o.set_contact_mode(3, float(g["soft"])); a = o.step_stance(g["x"][i], g["u"][i], g["stance"][i])
+    o.set_contact_mode(2, float(g["soft"])); b2 = o.step_stance(g["x"][i], g["u"][i], g["stance"][i])
+    assert np.array_equal(a, b2)
+
+
 def test_op_counter_pins_the_algorithmic_flop_figures_of_the_bench():
     """'flops of dynamics + analytic Jacobians + cost quadratics + one line-search alpha: to be taken from the CPU
     restatement's op counter'.  The counter (oracle/opcount.cpp) runs the oracle's own code on a counting scalar; bench.py's
