@@ -476,6 +476,7 @@ def main():
     for _ in range(max(1, args.steps // 2)):
         one_step(False)
         ee_iters += float(s.iterations().sum())
+    ee_spec = s.speculative_iterations()     # of the last step: iterations whose lambda retry ran beside the first pass (passes of <= 512 rollouts)
     torch.cuda.synchronize()
     ee_elapsed = time.perf_counter() - t1
     if world > 1:
@@ -624,8 +625,10 @@ def main():
             "stage_ms_source": "one untimed step after the timed region with event pairs around every stage (inside the timed region only the roofline kernel is timed: "
                                "the event records of all eight stages cost about 1.3 ms per step)",
             "early_exit": {"value": ee_iters / ee_elapsed, "unit": "iterations/s", "mean_iterations_per_solve": ee_iters / (world * B * ee_steps),
-                           "ms_per_step": 1e3 * ee_elapsed / ee_steps,
-                           "note": "same step with the reference's convergence exit (|dJ| < 1e-4) enabled: executed iterations per second; not the headline"},
+                           "ms_per_step": 1e3 * ee_elapsed / ee_steps, "speculative_retry_iterations_last_step": ee_spec,
+                           "note": "same step with the reference's convergence exit (|dJ| < 1e-4) enabled: executed iterations per second; not the headline; "
+                                   "once at most 512 rollouts are still active the lambda retry of ilqr.cpp:619-644 runs beside the first pass "
+                                   "(same results, ilqr_hip_get_speculative_iterations; ILQR_SPEC=0 for the sequential order)"},
         }
         if contact_line is not None:
             out["contact"] = contact_line

@@ -207,6 +207,12 @@ int ilqr_hip_get_stage_ms(ilqr_hip_ctx* ctx, double* ms /*[8]*/, double* launche
    count of active rollouts one iteration behind and stops launching (ilqr_hip_set_early_exit_gate(ctx, 0) turns that off).
    Returns the count, or -1 for a null handle. */
 int ilqr_hip_get_iterations_enqueued(const ilqr_hip_ctx* ctx);
+/* Iterations of the last solve that ran the lambda retry of ilqr.cpp:619-644 speculatively: while a pass holds at most 512
+   rollouts (the whole batch, or -- convergence exit -- the count of rollouts still active the host has seen), the Riccati pass and
+   the line search for lambda and for min(10 lambda, 1e-3) run side by side on two streams and the bookkeeping of :619-655 is
+   played once with both outcomes known; results (gains, value function, trajectory, lambda, trace) are those of the sequential
+   order, one pass of latency sooner.  Environment ILQR_SPEC=0 keeps the sequential order.  Returns the count, -1 for a null handle. */
+int ilqr_hip_get_speculative_iterations(const ilqr_hip_ctx* ctx);
 
 /* ---- host-side model helpers (no GPU needed) ---- */
 /* reference construction as RobotUtils::loadReferences does it (src/common/robot_utils.cpp:369-403):

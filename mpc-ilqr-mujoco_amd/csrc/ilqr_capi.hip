@@ -81,6 +81,11 @@ struct ilqr_hip_ctx {
   std::vector<Slice> slices;
   hipEvent_t ev_begin = nullptr;
   int n_slices = 1;
+  // speculative lambda retry (ilqr_kernels.hip k_control_spec): the twin view's own buffers, allocated by the first solve that can use them
+  DevState T{};
+  bool twin = false;
+  hipEvent_t ev_spec_fork = nullptr, ev_spec_join = nullptr;
+  int spec_iterations = 0;    // iterations of the last solve that ran both passes side by side
 };
 
 #define HIPCHK(ctx, call)                                                                   \
@@ -184,6 +189,9 @@ int ilqr_hip_destroy(ilqr_hip_ctx* c) {
                   S.lambda, S.active, S.need_retry, S.iters, S.improved, S.alpha_idx, S.trace_cost, S.trace_alpha, S.trace_lambda, S.order, S.order_n, c->d_tmpx, c->d_tmpu,
                   c->d_prevx, c->d_prevu, c->d_shadowx, c->d_u0, c->d_K0, c->d_cost_tmp, c->d_stepx, c->d_stepu, c->d_stepn, c->d_mismatch, c->d_payload, c->d_xref, c->d_uref, c->d_comref, c->d_eeref, c->d_comvelref, c->d_stance};
   for (void* p : ptrs) if (p) hipFree(p);
+  if (c->twin) { void* tw[] = {c->T.K, c->T.kff, c->T.Vx, c->T.Vxx, c->T.xcand, c->T.ucand, c->T.cand_cost, c->T.cand_knot, c->T.lambda}; for (void* p : tw) if (p) hipFree(p); }
+  if (c->ev_spec_fork) hipEventDestroy(c->ev_spec_fork);
+  if (c->ev_spec_join) hipEventDestroy(c->ev_spec_join);
   if (c->comm) ilqr_hip_comm_destroy(c);
   for (hipEvent_t e : c->pool) hipEventDestroy(e);
   for (hipEvent_t e : c->ev_active) hipEventDestroy(e);
@@ -429,6 +437,34 @@ static int ensure_gate(ilqr_hip_ctx* c) {
   while ((int)c->ev_active.size() < c->max_iter + 2) { hipEvent_t e; HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming)); c->ev_active.push_back(e); }
   return ILQR_OK;
 }
+// Speculative lambda retry: while at most SPEC_MAX rollouts are in a pass (the whole batch, or -- convergence exit with the gate --
+// the count the host has seen), two Riccati passes / line searches of that many one-wave rollouts fit on the chip's 1024 SIMDs side by
+// side.  ILQR_SPEC=0 switches it off (sequential retry as for large passes), ILQR_SPEC_MAX moves the threshold (diagnostics, tests).
+static int spec_enabled() { const char* e = getenv("ILQR_SPEC"); return e ? atoi(e) : 1; }
+static int spec_max() { const char* e = getenv("ILQR_SPEC_MAX"); return e ? atoi(e) : 512; }
+static int ensure_twin(ilqr_hip_ctx* c) {
+  if (c->twin) return ILQR_OK;
+  const size_t B = c->B, N = c->N, n = ILQR_NX, m = ILQR_NU;
+  DevState& T = c->T;
+  T = c->S;
+  T.K = T.kff = T.Vx = T.Vxx = T.xcand = T.ucand = T.cand_cost = T.cand_knot = T.lambda = nullptr;
+  c->twin = true;       // (from here on destroy frees whatever was allocated)
+  TRY(dalloc(c, &T.K, B * N * m * n + 32)); TRY(dalloc(c, &T.kff, B * N * m)); TRY(dalloc(c, &T.Vx, B * n)); TRY(dalloc(c, &T.Vxx, B * n * n));
+  TRY(dalloc(c, &T.xcand, B * 8 * (N + 1) * n)); TRY(dalloc(c, &T.ucand, B * 8 * N * m)); TRY(dalloc(c, &T.cand_cost, B * 8)); TRY(dalloc(c, &T.cand_knot, B * 8 * (N + 1)));
+  TRY(dalloc(c, &T.lambda, B));
+  if (!c->ev_spec_fork) HIPCHK(c, hipEventCreateWithFlags(&c->ev_spec_fork, hipEventDisableTiming));
+  if (!c->ev_spec_join) HIPCHK(c, hipEventCreateWithFlags(&c->ev_spec_join, hipEventDisableTiming));
+  return ILQR_OK;
+}
+// the twin view of (a slice of) the batch: everything of S, with the twin's own gains, value function, candidates and lambda
+static DevState twin_view(const ilqr_hip_ctx* c, const DevState& S) {
+  DevState T = S;
+  const DevState& W = c->T; const DevState& F = c->S;
+  T.K = W.K + (S.K - F.K); T.kff = W.kff + (S.kff - F.kff); T.Vx = W.Vx + (S.Vx - F.Vx); T.Vxx = W.Vxx + (S.Vxx - F.Vxx);
+  T.xcand = W.xcand + (S.xcand - F.xcand); T.ucand = W.ucand + (S.ucand - F.ucand); T.cand_cost = W.cand_cost + (S.cand_cost - F.cand_cost);
+  T.cand_knot = W.cand_knot + (S.cand_knot - F.cand_knot); T.lambda = W.lambda + (S.lambda - F.lambda);
+  return T;
+}
 static int enqueue_solve(ilqr_hip_ctx* c, const DevState& S, const h1::ProblemDev& P, hipStream_t st, hipStream_t st2, hipStream_t st3,
                          hipEvent_t ev_fork, hipEvent_t ev_join, hipEvent_t ev_roll, const double* shadow_base, hipEvent_t wait_lead, hipEvent_t lead,
                          hipEvent_t ev_lin = nullptr, hipEvent_t ev_adopt = nullptr) {
@@ -497,12 +533,35 @@ static int enqueue_solve(ilqr_hip_ctx* c, const DevState& S, const h1::ProblemDe
     }
     HIPCHK(c, hipStreamWaitEvent(st, ev_join, 0));
     if (concurrent_roll && !adopt_aside) { HIPCHK(c, hipStreamWaitEvent(st, ev_roll, 0)); ilqr::launch_adopt_rollout(S, shadow, ilqr::MASK_ACTIVE, c->d_mismatch, st); }
-    { StageTimer T(c, 3, st); ilqr::launch_backward(S, ilqr::MASK_ACTIVE, st, fold_h, iter); }                                  // :601
-    if (adopt_aside) HIPCHK(c, hipStreamWaitEvent(st, ev_adopt, 0));
-    if (iter == 0 && lead) HIPCHK(c, hipEventRecord(lead, st));
     // (with the gate the host has seen how many rollouts were still active at the start of iteration iter - 1: an upper bound
     // for this iteration's passes -- the active set only shrinks)
     const int ls_bound = (gate && iter >= 2) ? c->h_active[iter - 1] : -1;
+    const int pass_bound = ls_bound >= 0 ? ls_bound : S.B;
+    if (c->twin && spec_enabled() && S.order && pass_bound <= spec_max()) {
+      // both passes of ilqr.cpp:601-646 side by side (k_control_spec): the twin on the second stream
+      const DevState Tw = twin_view(c, S);
+      ++c->spec_iterations;
+      HIPCHK(c, hipEventRecord(c->ev_spec_fork, st));
+      HIPCHK(c, hipStreamWaitEvent(st2, c->ev_spec_fork, 0));
+      ilqr::launch_spec_lambda(S, Tw.lambda, st2);
+      { StageTimer T(c, 3, st); ilqr::launch_backward(S, ilqr::MASK_ACTIVE, st, fold_h, iter); }
+      { StageTimer T(c, 6, st2); ilqr::launch_backward(Tw, ilqr::MASK_ACTIVE, st2, fold_h, iter); }
+      if (adopt_aside) { HIPCHK(c, hipStreamWaitEvent(st, ev_adopt, 0)); HIPCHK(c, hipStreamWaitEvent(st2, ev_adopt, 0)); }
+      if (iter == 0 && lead) HIPCHK(c, hipEventRecord(lead, st));
+      { StageTimer T(c, 4, st); ilqr::launch_line_search(S, P, ilqr::MASK_ACTIVE, st, iter, ls_bound); }
+      { StageTimer T(c, 7, st2); ilqr::launch_line_search(Tw, P, ilqr::MASK_ACTIVE, st2, iter, ls_bound); }
+      HIPCHK(c, hipEventRecord(c->ev_spec_join, st2));
+      HIPCHK(c, hipStreamWaitEvent(st, c->ev_spec_join, 0));
+      { StageTimer T(c, 5, st); ilqr::launch_control_spec(S, Tw, iter, c->tol, c->early_exit, st, ilqr::ls_costs_per_knot(P)); }
+      if (gate) {
+        HIPCHK(c, hipMemcpyAsync(&c->h_active[iter + 1], S.order_n + 2 * (iter + 1), sizeof(int), hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipEventRecord(c->ev_active[iter], st));
+      }
+      continue;
+    }
+    { StageTimer T(c, 3, st); ilqr::launch_backward(S, ilqr::MASK_ACTIVE, st, fold_h, iter); }                                  // :601
+    if (adopt_aside) HIPCHK(c, hipStreamWaitEvent(st, ev_adopt, 0));
+    if (iter == 0 && lead) HIPCHK(c, hipEventRecord(lead, st));
     { StageTimer T(c, 4, st); ilqr::launch_line_search(S, P, ilqr::MASK_ACTIVE, st, iter, ls_bound); }                  // :616
     { StageTimer T(c, 5, st); ilqr::launch_control(S, 0, iter, c->tol, c->early_exit, st, ilqr::ls_costs_per_knot(P)); }                      // :619-620,645-655
     { StageTimer T(c, 6, st); ilqr::launch_backward(S, ilqr::MASK_RETRY, st, fold_h, iter); }                                  // :637
@@ -515,6 +574,7 @@ static int enqueue_solve(ilqr_hip_ctx* c, const DevState& S, const h1::ProblemDe
   }
   return ILQR_OK;
 }
+int ilqr_hip_get_speculative_iterations(const ilqr_hip_ctx* c) { return c ? c->spec_iterations : -1; }
 int ilqr_hip_num_slices(const ilqr_hip_ctx* c) { return c ? slices_wanted(c->B) : -1; }
 // The analytic Jacobians differentiate the constrained step with the active set held fixed (modes 1, 2); a sliding foot's
 // constraint rows turn with the foot, which they do not carry: mode 3 linearises by the reference's forward differences.
@@ -536,6 +596,8 @@ int ilqr_hip_solve_async(ilqr_hip_ctx* c) {
   HIPCHK(c, hipMemsetAsync(c->d_mismatch, 0, sizeof(unsigned long long), st));
   const int k = slices_wanted(c->B);
   c->n_slices = k;
+  c->spec_iterations = 0;
+  if (spec_enabled() && k <= 1 && !c->twin && (c->B <= spec_max() || (c->early_exit && early_exit_gate(c)))) TRY(ensure_twin(c));
   c->lin_fold_h = ilqr::linearize_fold_h(P, c->jac_mode);   // what S.A / S.Bm hold after this solve
   c->first_aside = c->xbar_rolled && c->rolled_variant == rollout_kernel_identity(P) && same_dyn(c->rolled_dyn, P.dyn);
   c->xbar_rolled = false;                                   // after this solve xbar is an accepted line-search candidate

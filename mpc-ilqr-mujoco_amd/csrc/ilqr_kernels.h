@@ -73,6 +73,9 @@ inline WorkList work_list(const DevState& S, int mode, int iter) {
   return WorkList{S.order + (size_t)slot * S.B, S.order_n + slot};
 }
 void launch_backward(const DevState& S, int mode, hipStream_t st, double fold_h = 0.0, int iter = -1);
+// speculative lambda retry (ilqr_kernels.hip k_control_spec): T = the twin view whose K, kff, Vx, Vxx, candidates and lambda are its own
+void launch_spec_lambda(const DevState& S, double* lambda2, hipStream_t st);
+void launch_control_spec(const DevState& S, const DevState& T, int iter, double tol, int early_exit, hipStream_t st, int sum_knots);
 double linearize_fold_h(const h1::ProblemDev& P, int jac_mode);
 // max_rollouts: upper bound of the rollouts this pass can select (the batch, or -- with the early-exit gate -- the count of
 // still-active rollouts the host saw two iterations ago): at most 1024 -> one rollout per wave in the two-lane line search

@@ -706,6 +706,105 @@ __global__ void __launch_bounds__(64 * CTRL_WAVES) k_control(DevState S, int pha
   wave_copy(ub, uc, N * H1_NU, lane);
 }
 
+// ---- speculative lambda retry (small active sets) ---------------------------------------------------------------------------
+// The retry of ilqr.cpp:619-644 -- lambda <- min(10 lambda, 1e-3), backward pass, line search -- only depends on data that exist
+// before the FIRST line search of the iteration has decided anything.  While the rollouts of a pass fill at most half of the chip's
+// SIMDs, both Riccati passes (lambda and 10 lambda) and both line searches run side by side on two streams, each into its own
+// buffers (T = the twin view: K, kff, Vx, Vxx, candidates, lambda), and this kernel then plays ilqr.cpp:619-655 once with both
+// outcomes on the table: first search accepted -> the twin is dropped; else the twin IS the retry the reference would have run
+// (its gains, value function, candidates and costs replace the first pass's, accepted or not).  Same results, one pass of latency.
+__global__ void k_spec_lambda(DevState S, double* lambda2) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < S.B) lambda2[b] = fmin(S.lambda[b] * 10.0, 1e-3);
+}
+__global__ void __launch_bounds__(64 * CTRL_WAVES) k_control_spec(DevState S, DevState T, int iter, double tol, int early_exit, int sum_knots) {
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int b = blockIdx.x * CTRL_WAVES + wv;
+  __shared__ int s_accept[CTRL_WAVES], s_retry[CTRL_WAVES], s_slot[CTRL_WAVES], s_base[1];
+  const int N = S.N;
+  const bool run = b < S.B && S.active[b];
+  if (lane == 0) { s_accept[wv] = -1; s_retry[wv] = 0; s_slot[wv] = -1; }
+  // lanes 0..7: candidates of the first search, lanes 8..15: of the twin
+  double csum = 0.0;
+  if (run && lane < 16) {
+    const DevState& D = lane < 8 ? S : T;
+    const int a = lane & 7;
+    if (sum_knots) {
+      const double* ck = D.cand_knot + ((size_t)b * 8 + a) * (N + 1);
+      for (int t = 0; t <= N; ++t) csum += ck[t];
+    } else csum = D.cand_cost[(size_t)b * 8 + a];
+  }
+  double cc[16];
+#pragma unroll
+  for (int a = 0; a < 16; ++a) {
+    const int lo = __shfl(__double2loint(csum), a), hi = __shfl(__double2hiint(csum), a);
+    cc[a] = __hiloint2double(hi, lo);
+  }
+  if (run && lane == 0) {
+    S.iters[b] += 1;
+    const double base = S.Jbase[b];
+    int acc1 = -1, acc2 = -1;
+#pragma unroll
+    for (int a = 7; a >= 0; --a) { if (cc[a] < base - 1e-6) acc1 = a; if (cc[8 + a] < base - 1e-6) acc2 = a; }
+    const double lam0 = S.lambda[b];
+    const bool retry = acc1 < 0;
+    const double lam_used = retry ? fmin(lam0 * 10.0, 1e-3) : lam0;      // (ilqr.cpp:634)
+    const int acc = retry ? acc2 : acc1;
+    s_accept[wv] = acc; s_retry[wv] = retry ? 1 : 0;
+    S.improved[b] = acc >= 0;
+    S.alpha_idx[b] = acc;
+    S.need_retry[b] = 0;
+#pragma unroll
+    for (int a = 0; a < 8; ++a) S.cand_cost[(size_t)b * 8 + a] = retry ? cc[8 + a] : cc[a];
+    const int tr = iter;
+    if (acc >= 0) {
+      const double Jprev = S.J[b];
+      const double Jn = retry ? cc[8 + acc] : cc[acc];
+      S.J[b] = Jn;
+      S.Jbase[b] = Jn;
+      S.lambda[b] = fmax(lam_used / 2.0, 1e-6);
+      S.trace_cost[(size_t)b * (S.max_iter + 1) + tr + 1] = Jn;
+      S.trace_alpha[(size_t)b * S.max_iter + tr] = ALPHAS[acc];
+      S.trace_lambda[(size_t)b * S.max_iter + tr] = lam_used;
+      if (early_exit && (fabs(Jn - Jprev) < tol || Jn > 1e6)) S.active[b] = 0;
+    } else {
+      S.lambda[b] = lam_used;
+      S.trace_cost[(size_t)b * (S.max_iter + 1) + tr + 1] = S.J[b];
+      S.trace_alpha[(size_t)b * S.max_iter + tr] = 0.0;
+      S.trace_lambda[(size_t)b * S.max_iter + tr] = lam_used;
+      if (early_exit && iter > 1) S.active[b] = 0;
+    }
+    if (S.order && S.active[b]) s_slot[wv] = 0;
+  }
+  __syncthreads();
+  if (S.order) {
+    if (threadIdx.x == 0) {
+      int cnt = 0;
+      for (int w = 0; w < CTRL_WAVES; ++w) cnt += s_slot[w] == 0;
+      s_base[0] = cnt ? atomicAdd(&S.order_n[2 * (iter + 1)], cnt) : 0;
+    }
+    __syncthreads();
+    if (lane == 0 && s_slot[wv] == 0) {
+      int pos = s_base[0];
+      for (int w = 0; w < wv; ++w) pos += s_slot[w] == 0;
+      S.order[(size_t)(2 * (iter + 1)) * S.B + pos] = b;
+    }
+  }
+  if (!run) return;
+  const int acc = s_accept[wv];
+  const bool retry = s_retry[wv] != 0;
+  if (retry) {      // the last backward pass the reference would have executed is the twin's: its gains and value function stay
+    wave_copy(S.K + (size_t)b * N * H1_NU * H1_NX, T.K + (size_t)b * N * H1_NU * H1_NX, N * H1_NU * H1_NX, lane);
+    wave_copy(S.kff + (size_t)b * N * H1_NU, T.kff + (size_t)b * N * H1_NU, N * H1_NU, lane);
+    wave_copy(S.Vx + (size_t)b * H1_NX, T.Vx + (size_t)b * H1_NX, H1_NX, lane);
+    wave_copy(S.Vxx + (size_t)b * H1_NX * H1_NX, T.Vxx + (size_t)b * H1_NX * H1_NX, H1_NX * H1_NX, lane);
+  }
+  if (acc < 0) return;
+  const DevState& D = retry ? T : S;
+  wave_copy(S.xbar + (size_t)b * (N + 1) * H1_NX, D.xcand + ((size_t)b * 8 + acc) * (N + 1) * H1_NX, (N + 1) * H1_NX, lane);
+  wave_copy(S.ubar + (size_t)b * N * H1_NU, D.ucand + ((size_t)b * 8 + acc) * N * H1_NU, N * H1_NU, lane);
+}
+
 // solve prologue: J = initial cost, trace[0], counters
 __global__ void k_solve_begin(DevState S) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -941,6 +1040,10 @@ void launch_line_search(const DevState& S, const ProblemDev& P, int mode, hipStr
 bool ls_costs_per_knot(const ProblemDev& P) { return !use_scalar_dyn() && (g_var.ls_split || P.dyn.contact); }
 void launch_control(const DevState& S, int phase, int iter, double tol, int early_exit, hipStream_t st, int sum_knots) {
   hipLaunchKernelGGL(k_control, dim3(cdiv(S.B, CTRL_WAVES)), dim3(64 * CTRL_WAVES), 0, st, S, phase, iter, tol, early_exit, sum_knots);
+}
+void launch_spec_lambda(const DevState& S, double* lambda2, hipStream_t st) { hipLaunchKernelGGL(k_spec_lambda, dim3(cdiv(S.B, 256)), dim3(256), 0, st, S, lambda2); }
+void launch_control_spec(const DevState& S, const DevState& T, int iter, double tol, int early_exit, hipStream_t st, int sum_knots) {
+  hipLaunchKernelGGL(k_control_spec, dim3(cdiv(S.B, CTRL_WAVES)), dim3(64 * CTRL_WAVES), 0, st, S, T, iter, tol, early_exit, sum_knots);
 }
 void launch_solve_begin(const DevState& S, hipStream_t st) { hipLaunchKernelGGL(k_solve_begin, dim3(cdiv(S.B, 64)), dim3(64), 0, st, S); }
 void launch_adopt_rollout(const DevState& S, const double* shadow, int mode, unsigned long long* mismatches, hipStream_t st) { hipLaunchKernelGGL(k_adopt_rollout, dim3(S.B), dim3(64), 0, st, S, shadow, mode, mismatches); }

@@ -277,6 +277,57 @@ def test_early_exit_gate_stops_launching_and_changes_nothing():
         assert abs(out["1"][0][b] - c) <= 1e-5 * abs(c)
 
 
+@pytest.mark.parametrize("mode", ["fixed", "early_exit", "contact", "wg-r"])
+def test_speculative_lambda_retry_is_the_sequential_retry_bit_for_bit(mode):
+    """Small passes run the lambda retry of ilqr.cpp:619-644 beside the first pass (k_control_spec): Riccati and line search for
+    lambda and for min(10 lambda, 1e-3) on two streams, the bookkeeping played once with both outcomes.  Every observable of the
+    solve -- cost trace, accepted step sizes, lambda schedule, iteration counts, gains, feed-forward, value function, trajectory,
+    final lambda -- equals the sequential order's (ILQR_SPEC=0) bit for bit, on cold starts that walk through accept, fail -> retry
+    -> accept and fail -> retry -> fail (-> continue / break), with and without the convergence exit, in contact mode and on the
+    other kernel families; a pass above the threshold (ILQR_SPEC_MAX) stays sequential."""
+    B = 12
+    gravity = [0.0, 0.0, -9.81] if mode == "contact" else None
+    prob, x0, ui = standing(B, seed=53, gravity=gravity)
+    var = dict(ILQR_BACKWARD="wg", ILQR_LS="r", ILQR_ROLLOUT="r") if mode == "wg-r" else {}
+    out = {}
+    for spec in ("1", "0", "max"):
+        kv = dict(var); kv.update(ILQR_SPEC="1" if spec == "max" else spec)
+        if spec == "max":
+            kv["ILQR_SPEC_MAX"] = str(B - 1)
+        with env(**kv):
+            s = _solver(B); s.set_problem(prob); s.set_options(early_exit=(mode == "early_exit")); s.set_max_iterations(10)
+            if mode == "contact":
+                s.set_contact_mode(2)
+            s.initialize(x0, ui); cost = s.solve(x0)
+            tc, ta, tl = s.trace()
+            Vx, Vxx = s.value_function()
+            out[spec] = (cost, tc, ta, tl, s.iterations(), s.gains_K(), s.gains_kff(), Vx, Vxx, s.xbar(), s.ubar(), s.lambdas(), s.speculative_iterations(), s.adopt_mismatches())
+            s.close()
+    assert out["1"][12] >= 3 and out["0"][12] == 0 and out["1"][13] == 0
+    if mode != "early_exit":
+        assert out["1"][12] == 10 and out["max"][12] == 0         # (early exit: the pass shrinks below the threshold on its way)
+    else:
+        assert 0 < out["max"][12] < out["1"][12]
+    for k in range(12):
+        assert np.array_equal(out["1"][k], out["0"][k], equal_nan=True), k
+        assert np.array_equal(out["max"][k], out["0"][k], equal_nan=True), k
+    ta = out["1"][2]
+    it = out["1"][4]
+    fails = sum(int((ta[b, : it[b]] == 0.0).sum()) for b in range(B))
+    accepts = sum(int((ta[b, : it[b]] > 0.0).sum()) for b in range(B))
+    assert fails >= 3 and accepts >= 2 * B                            # both outcomes of the retry occur
+    tl = out["1"][3]
+    assert np.nanmax(tl) > 1e-6                                        # ... and accepted steps that needed the bumped lambda
+    for b in (0, B - 1):
+        o = ol.Oracle(prob["N"], prob["dt"]); o.set_problem(prob); o.set_options(max_iter=10, early_exit=int(mode == "early_exit"))   # (lambda lives in the solver object)
+        if mode == "contact":
+            o.set_contact_mode(2)
+        o.initialize(x0[b], ui[b]); ok, c = o.solve(x0[b])
+        n, oc, oa, olam = o.trace()
+        assert n == it[b] and np.allclose(out["1"][1][b, : n + 1], oc[: n + 1], rtol=1e-5) and np.array_equal(ta[b, :n], oa[:n])
+        assert np.allclose(tl[b, :n], olam[:n], rtol=1e-12) and rel(out["1"][5][b], o.get("K")) < 1e-5
+
+
 def test_profiled_stage_mask_times_only_the_chosen_stages():
     """bench.py keeps event pairs only around the roofline kernel group inside its timed region (ilqr_hip_set_profiled_stages)."""
     B = 4
