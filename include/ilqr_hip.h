@@ -213,6 +213,12 @@ int ilqr_hip_get_iterations_enqueued(const ilqr_hip_ctx* ctx);
    played once with both outcomes known; results (gains, value function, trajectory, lambda, trace) are those of the sequential
    order, one pass of latency sooner.  Environment ILQR_SPEC=0 keeps the sequential order.  Returns the count, -1 for a null handle. */
 int ilqr_hip_get_speculative_iterations(const ilqr_hip_ctx* ctx);
+/* Iterations of the last solve whose concurrent region (linearisation, cost quadratics, nominal re-rollout: ilqr.cpp:551-588) ran in
+   two groups: the rollouts whose first line search of the previous iteration accepted a step start right behind that iteration's first
+   bookkeeping pass, beside the lambda retry (:619-644) of the others, which follow behind the second; both meet at the backward pass.
+   Bit-identical results.  On by default when the convergence exit is enabled (where it pays; with a fixed iteration count nearly every
+   rollout retries and the early group is small); environment ILQR_SPLIT=0 / 1 forces it off / on.  Returns the count, -1 for a null handle. */
+int ilqr_hip_get_split_iterations(const ilqr_hip_ctx* ctx);
 
 /* ---- host-side model helpers (no GPU needed) ---- */
 /* reference construction as RobotUtils::loadReferences does it (src/common/robot_utils.cpp:369-403):

@@ -86,6 +86,10 @@ struct ilqr_hip_ctx {
   bool twin = false;
   hipEvent_t ev_spec_fork = nullptr, ev_spec_join = nullptr;
   int spec_iterations = 0;    // iterations of the last solve that ran both passes side by side
+  // early continuation (enqueue_solve): streams / events of the group that starts the next iteration behind the first control pass
+  hipStream_t a1 = nullptr, a2 = nullptr, a3 = nullptr;
+  hipEvent_t evA_fork = nullptr, evA_join = nullptr, evA_roll = nullptr, evA_lin = nullptr, evA_adopt = nullptr;
+  int split_iterations = 0;   // iterations of the last solve whose concurrent region ran in two groups
 };
 
 #define HIPCHK(ctx, call)                                                                   \
@@ -148,6 +152,11 @@ int ilqr_hip_create(ilqr_hip_ctx** out, int device, int batch, int horizon, doub
   A(dalloc(c, &S.active, B)); A(dalloc(c, &S.need_retry, B)); A(dalloc(c, &S.iters, B)); A(dalloc(c, &S.improved, B)); A(dalloc(c, &S.alpha_idx, B));
   A(dalloc(c, &S.trace_cost, B * (c->max_iter + 1))); A(dalloc(c, &S.trace_alpha, B * c->max_iter)); A(dalloc(c, &S.trace_lambda, B * c->max_iter));
   A(dalloc(c, &S.order, B * 2 * (c->max_iter + 1))); A(dalloc(c, &S.order_n, 2 * (size_t)(c->max_iter + 1)));
+  A(dalloc(c, &S.grp_a, B)); A(dalloc(c, &S.grp_r, B)); A(dalloc(c, &S.order_r, B)); A(dalloc(c, &S.order_rn, (size_t)c->max_iter + 2)); A(dalloc(c, &S.order_an, (size_t)c->max_iter + 2));
+  if (rc == ILQR_OK && (hipStreamCreate(&c->a1) != hipSuccess || hipStreamCreate(&c->a2) != hipSuccess || hipStreamCreate(&c->a3) != hipSuccess ||
+      hipEventCreateWithFlags(&c->evA_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->evA_join, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&c->evA_roll, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->evA_lin, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&c->evA_adopt, hipEventDisableTiming) != hipSuccess)) { c->err = "stream / event creation failed (early continuation)"; rc = ILQR_ERR_HIP; }
   A(dalloc(c, &c->d_tmpx, B * (N + 1) * n)); A(dalloc(c, &c->d_tmpu, B * N * m));
   A(dalloc(c, &c->d_prevx, B * (N + 1) * n)); A(dalloc(c, &c->d_prevu, B * N * m)); A(dalloc(c, &c->d_shadowx, B * (N + 1) * n));
   A(dalloc(c, &c->d_u0, B * m)); A(dalloc(c, &c->d_K0, B * m * n)); A(dalloc(c, &c->d_cost_tmp, B)); A(dalloc(c, &c->d_mismatch, 1));
@@ -190,6 +199,9 @@ int ilqr_hip_destroy(ilqr_hip_ctx* c) {
                   c->d_prevx, c->d_prevu, c->d_shadowx, c->d_u0, c->d_K0, c->d_cost_tmp, c->d_stepx, c->d_stepu, c->d_stepn, c->d_mismatch, c->d_payload, c->d_xref, c->d_uref, c->d_comref, c->d_eeref, c->d_comvelref, c->d_stance};
   for (void* p : ptrs) if (p) hipFree(p);
   if (c->twin) { void* tw[] = {c->T.K, c->T.kff, c->T.Vx, c->T.Vxx, c->T.xcand, c->T.ucand, c->T.cand_cost, c->T.cand_knot, c->T.lambda}; for (void* p : tw) if (p) hipFree(p); }
+  { void* gp[] = {S.grp_a, S.grp_r, S.order_r, S.order_rn, S.order_an}; for (void* p : gp) if (p) hipFree(p); }
+  for (hipEvent_t e : {c->evA_fork, c->evA_join, c->evA_roll, c->evA_lin, c->evA_adopt}) if (e) hipEventDestroy(e);
+  for (hipStream_t t : {c->a1, c->a2, c->a3}) if (t) hipStreamDestroy(t);
   if (c->ev_spec_fork) hipEventDestroy(c->ev_spec_fork);
   if (c->ev_spec_join) hipEventDestroy(c->ev_spec_join);
   if (c->comm) ilqr_hip_comm_destroy(c);
@@ -283,6 +295,10 @@ int ilqr_hip_set_max_iterations(ilqr_hip_ctx* c, int max_iter) {
     c->max_iter = max_iter; c->S.max_iter = max_iter;
     TRY(dalloc(c, &c->S.trace_cost, (size_t)c->B * (max_iter + 1))); TRY(dalloc(c, &c->S.trace_alpha, (size_t)c->B * max_iter)); TRY(dalloc(c, &c->S.trace_lambda, (size_t)c->B * max_iter));
     TRY(dalloc(c, &c->S.order, (size_t)c->B * 2 * (max_iter + 1))); TRY(dalloc(c, &c->S.order_n, 2 * (size_t)(max_iter + 1)));
+    if (c->S.order_rn) hipFree(c->S.order_rn);
+    if (c->S.order_an) hipFree(c->S.order_an);
+    c->S.order_rn = c->S.order_an = nullptr;
+    TRY(dalloc(c, &c->S.order_rn, (size_t)max_iter + 2)); TRY(dalloc(c, &c->S.order_an, (size_t)max_iter + 2));
   }
   return ILQR_OK;
 }
@@ -405,6 +421,7 @@ static DevState slice_state(const DevState& S, size_t b0, int Bs) {
   T.active += b0; T.need_retry += b0; T.iters += b0; T.improved += b0; T.alpha_idx += b0;
   T.trace_cost += b0 * (mi + 1); T.trace_alpha += b0 * mi; T.trace_lambda += b0 * mi;
   T.order = nullptr; T.order_n = nullptr;      // the compacted lists index the whole batch: not used by slices
+  T.grp_a = T.grp_r = T.order_r = T.order_rn = T.order_an = nullptr;
   return T;
 }
 static h1::ProblemDev slice_problem(const h1::ProblemDev& P, long b0) {
@@ -440,6 +457,11 @@ static int ensure_gate(ilqr_hip_ctx* c) {
 // Speculative lambda retry: while at most SPEC_MAX rollouts are in a pass (the whole batch, or -- convergence exit with the gate --
 // the count the host has seen), two Riccati passes / line searches of that many one-wave rollouts fit on the chip's 1024 SIMDs side by
 // side.  ILQR_SPEC=0 switches it off (sequential retry as for large passes), ILQR_SPEC_MAX moves the threshold (diagnostics, tests).
+// early continuation (enqueue_solve): by default with the convergence exit only -- measured on one MI355X, executed iterations/s with / without:
+// constraint-free B = 4096 +1.5 %, contact B = 4096 +9 %, contact B = 1024 +5 %, configs[4] +4 %; with a fixed iteration count most rollouts
+// retry in most iterations, the early group is small, and its kernels only take SIMDs from the one-wave-per-SIMD kernels of the retry
+// (headline -3 %, contact +3 % / -3.5 % at B = 4096 / 1024).  ILQR_SPLIT=0 / 1 forces it off / on.
+static int split_enabled(const ilqr_hip_ctx* c) { const char* e = getenv("ILQR_SPLIT"); return e ? atoi(e) : c->early_exit; }
 static int spec_enabled() { const char* e = getenv("ILQR_SPEC"); return e ? atoi(e) : 1; }
 static int spec_max() { const char* e = getenv("ILQR_SPEC_MAX"); return e ? atoi(e) : 512; }
 static int ensure_twin(ilqr_hip_ctx* c) {
@@ -488,51 +510,82 @@ static int enqueue_solve(ilqr_hip_ctx* c, const DevState& S, const h1::ProblemDe
   c->ab_unfold_h = skip_fold_rows ? fold_h : 0.0;
   if (gate) TRY(ensure_gate(c));
   c->iterations_enqueued = c->max_iter;
+  // One group's share of the concurrent region of an iteration -- linearisation (:576) on G.m, cost quadratics (:588) on G.q, the
+  // nominal re-rollout (:551,563) into the shadow buffer and its adoption on G.r -- behind an event recorded on fork_src.
+  //   From the second iteration on the nominal trajectory already is a rollout from x0 (the accepted line-search candidate, or the
+  //   unchanged previous nominal), so the re-rollout reproduces it bit for bit (ilqr_hip_get_adopt_mismatches): it runs beside the
+  //   linearisation and is adopted (with its cost, the line-search baseline) once the linearisation and the cost quadratics have
+  //   read the old copy; the backward pass reads neither, only the line search waits for the adoption.  ILQR_OVERLAP_ROLLOUT=0
+  //   restores the sequential order; ILQR_REUSE_ROLLOUT=1 skips the re-rollout (not the default: SURVEY 8(d) counts it).
+  //   (only while the line search and the rollout run the same step implementation; iteration 0 as well when the nominal trajectory
+  //   is itself a rollout by this very kernel -- the cold start, initializeWithReference ilqr.cpp:113-115; a warm-shifted or
+  //   caller-supplied trajectory is rolled out BEFORE the linearisation, as the reference does)
+  // Sm: the view the mask-selected kernels (rollout, trajectory cost, adoption) get -- S, or S with a group's flags as `active`;
+  // wl: the group's compacted list for the per-knot kernels (null: the iteration's own list / mask, as knot_mode and iter_l say).
+  struct Rg { hipStream_t m, q, r; hipEvent_t fork, join, roll, lin, adopt; };
+  const Rg G0{st, st2, st3, ev_fork, ev_join, ev_roll, ev_lin, ev_adopt};
+  // (group A's cost quadratics and re-rollout share the second and third stream with group R -- idle while the retry runs, and R's
+  // work comes behind A's anyway --, only its linearisation has a stream of its own: the runtime maps streams onto four hardware
+  // queues by default, and streams that share a queue serialise)
+  const Rg GA{c->a1, st2, st3, c->evA_fork, c->evA_join, c->evA_roll, c->evA_lin, c->evA_adopt};
+  auto region = [&](const Rg& G, hipStream_t fork_src, const DevState& Sm, int knot_mode, int iter_l, const ilqr::WorkList* wl, bool concurrent_roll) -> int {
+    HIPCHK(c, hipEventRecord(G.fork, fork_src));
+    if (G.m != fork_src) HIPCHK(c, hipStreamWaitEvent(G.m, G.fork, 0));
+    HIPCHK(c, hipStreamWaitEvent(G.q, G.fork, 0));
+    if (concurrent_roll) {
+      HIPCHK(c, hipStreamWaitEvent(G.r, G.fork, 0));
+      DevState Sr = Sm; Sr.xbar = shadow;
+      { StageTimer T(c, 0, G.r); ilqr::launch_rollout(Sr, P, ilqr::MASK_ACTIVE, 1, 0, S.Jbase, G.r); }
+      HIPCHK(c, hipEventRecord(G.roll, G.r));
+    }
+    { StageTimer T(c, 2, G.q); ilqr::launch_cost_quadratics(S, P, knot_mode, G.q, iter_l, lxx_lower, wl); }
+    HIPCHK(c, hipEventRecord(G.join, G.q));
+    { StageTimer T(c, 1, G.m); ilqr::launch_linearize(S, P, knot_mode, c->jac_mode, c->fd_eps, G.m, 3, iter_l, skip_fold_rows, wl); }
+    if (concurrent_roll && G.lin && G.adopt) {
+      HIPCHK(c, hipEventRecord(G.lin, G.m));
+      HIPCHK(c, hipStreamWaitEvent(G.r, G.lin, 0)); HIPCHK(c, hipStreamWaitEvent(G.r, G.join, 0));
+      ilqr::launch_adopt_rollout(Sm, shadow, ilqr::MASK_ACTIVE, c->d_mismatch, G.r);
+      HIPCHK(c, hipEventRecord(G.adopt, G.r));
+    }
+    return ILQR_OK;
+  };
+  auto rolls_aside = [&](int iter) {
+    const bool first_aside = iter == 0 && xbar_rolled && !ilqr::variant_scalar_dyn();
+    return (iter > 0 || first_aside) && !reuse_rollout() && overlap_rollout() && (P.dyn.contact || ilqr::variant_ls_split() == ilqr::variant_rollout_split());   // (contact mode: both on the two-lane kernels)
+  };
+  // Early continuation: the rollouts whose first line search of iteration i accepted a step are done with iteration i; their share of
+  // iteration i + 1's concurrent region (group A) starts right behind the first control pass, on streams of its own, while the
+  // others take their lambda retry (:619-644); those follow as group R behind the second control pass, and both groups meet again at
+  // the backward pass.  The retry of an early iteration keeps a fraction of the chip busy for two latency-bound passes: the time it
+  // left idle is what this recovers.  Same kernels on the same data in the same per-rollout order: results are bit-identical
+  // (GPU test).  On by default with the convergence exit (split_enabled above); ILQR_SPLIT=0 / 1 forces one / two groups.
+  const bool can_split = split_enabled(c) && S.order && S.grp_a && ev_lin && ev_adopt && c->a1 != nullptr;
+  bool prev_split = false;      // group A of the iteration at hand is already enqueued
   for (int iter = 0; iter < c->max_iter; ++iter) {
     if (gate && iter >= 2) {
       HIPCHK(c, hipEventSynchronize(c->ev_active[iter - 2]));
       if (c->h_active[iter - 1] == 0) { c->iterations_enqueued = iter; break; }     // nobody was active in iteration iter - 1
     }
-    // :551,563 nominal rollout at the top of every iteration, as the reference does.  From the second iteration on the
-    // nominal trajectory is the candidate the line search accepted (or the unchanged previous one), so the re-rollout
-    // only reproduces it; ILQR_REUSE_ROLLOUT=1 skips it (not the default: the headline metric counts the rollout
-    // as part of an iteration)
-    // From the second iteration on the nominal trajectory already is a rollout from x0 (the accepted line-search
-    // candidate, or the unchanged previous nominal), so the re-rollout reproduces it to rounding: it runs on a third
-    // stream into a shadow buffer beside the linearisation and is adopted (with its cost, the line-search baseline)
-    // before the backward pass.  ILQR_OVERLAP_ROLLOUT=0 restores the sequential order.
-    // (only while the line search and the rollout run the same step implementation: otherwise the re-rollout would differ in
-    // rounding from the trajectory the linearisation beside it sees)
-    // (iteration 0 as well when the nominal trajectory is itself a rollout by this very kernel -- the cold start,
-    // initializeWithReference ilqr.cpp:113-115: the re-rollout of ilqr.cpp:563 then reproduces it bit for bit, same kernel, same
-    // inputs; a warm-shifted or caller-supplied trajectory is rolled out BEFORE the linearisation, as the reference does)
-    const bool first_aside = iter == 0 && xbar_rolled && !ilqr::variant_scalar_dyn();
-    const bool concurrent_roll = (iter > 0 || first_aside) && !reuse_rollout() && overlap_rollout() && (P.dyn.contact || ilqr::variant_ls_split() == ilqr::variant_rollout_split());   // (contact mode: both on the two-lane kernels)
-    if ((iter == 0 || !reuse_rollout()) && !concurrent_roll) { StageTimer T(c, 0, st); ilqr::launch_rollout(S, P, ilqr::MASK_ACTIVE, 1, 0, S.Jbase, st); }
-    if (iter == 0 && wait_lead) HIPCHK(c, hipStreamWaitEvent(st, wait_lead, 0));
-    // linearisation (:576) and cost quadratics (:588) only depend on the rollout: run them concurrently
-    HIPCHK(c, hipEventRecord(ev_fork, st));
-    HIPCHK(c, hipStreamWaitEvent(st2, ev_fork, 0));
-    if (concurrent_roll) {
-      HIPCHK(c, hipStreamWaitEvent(st3, ev_fork, 0));
-      DevState Sr = S; Sr.xbar = shadow;
-      { StageTimer T(c, 0, st3); ilqr::launch_rollout(Sr, P, ilqr::MASK_ACTIVE, 1, 0, S.Jbase, st3); }
-      HIPCHK(c, hipEventRecord(ev_roll, st3));
+    const bool concurrent_roll = rolls_aside(iter);
+    if (!prev_split) {
+      if ((iter == 0 || !reuse_rollout()) && !concurrent_roll) { StageTimer T(c, 0, st); ilqr::launch_rollout(S, P, ilqr::MASK_ACTIVE, 1, 0, S.Jbase, st); }
+      if (iter == 0 && wait_lead) HIPCHK(c, hipStreamWaitEvent(st, wait_lead, 0));
+      TRY(region(G0, st, S, sel_mode, iter, nullptr, concurrent_roll));
+    } else {
+      DevState Sg = S; Sg.active = S.grp_r;
+      const ilqr::WorkList wr{S.order_r, S.order_rn + iter};
+      TRY(region(G0, st, Sg, ilqr::MASK_ACTIVE, -1, &wr, true));
+      ++c->split_iterations;
     }
-    { StageTimer T(c, 2, st2); ilqr::launch_cost_quadratics(S, P, sel_mode, st2, iter, lxx_lower); }
-    HIPCHK(c, hipEventRecord(ev_join, st2));
-    { StageTimer T(c, 1, st); ilqr::launch_linearize(S, P, sel_mode, c->jac_mode, c->fd_eps, st, 3, iter, skip_fold_rows); }
-    // The re-rolled trajectory replaces xbar once the linearisation and the cost quadratics have read the old one.  The backward
-    // pass reads neither: with the extra events the adoption runs on the rollout's stream beside it and only the line search waits.
     const bool adopt_aside = concurrent_roll && ev_lin && ev_adopt;
-    if (adopt_aside) {
-      HIPCHK(c, hipEventRecord(ev_lin, st));
-      HIPCHK(c, hipStreamWaitEvent(st3, ev_lin, 0)); HIPCHK(c, hipStreamWaitEvent(st3, ev_join, 0));
-      ilqr::launch_adopt_rollout(S, shadow, ilqr::MASK_ACTIVE, c->d_mismatch, st3);
-      HIPCHK(c, hipEventRecord(ev_adopt, st3));
-    }
     HIPCHK(c, hipStreamWaitEvent(st, ev_join, 0));
+    if (prev_split) { HIPCHK(c, hipStreamWaitEvent(st, GA.join, 0)); HIPCHK(c, hipStreamWaitEvent(st, GA.lin, 0)); }
     if (concurrent_roll && !adopt_aside) { HIPCHK(c, hipStreamWaitEvent(st, ev_roll, 0)); ilqr::launch_adopt_rollout(S, shadow, ilqr::MASK_ACTIVE, c->d_mismatch, st); }
+    auto wait_adoption = [&](hipStream_t t) -> int {
+      if (adopt_aside) HIPCHK(c, hipStreamWaitEvent(t, ev_adopt, 0));
+      if (prev_split) HIPCHK(c, hipStreamWaitEvent(t, GA.adopt, 0));
+      return ILQR_OK;
+    };
     // (with the gate the host has seen how many rollouts were still active at the start of iteration iter - 1: an upper bound
     // for this iteration's passes -- the active set only shrinks)
     const int ls_bound = (gate && iter >= 2) ? c->h_active[iter - 1] : -1;
@@ -546,7 +599,7 @@ static int enqueue_solve(ilqr_hip_ctx* c, const DevState& S, const h1::ProblemDe
       ilqr::launch_spec_lambda(S, Tw.lambda, st2);
       { StageTimer T(c, 3, st); ilqr::launch_backward(S, ilqr::MASK_ACTIVE, st, fold_h, iter); }
       { StageTimer T(c, 6, st2); ilqr::launch_backward(Tw, ilqr::MASK_ACTIVE, st2, fold_h, iter); }
-      if (adopt_aside) { HIPCHK(c, hipStreamWaitEvent(st, ev_adopt, 0)); HIPCHK(c, hipStreamWaitEvent(st2, ev_adopt, 0)); }
+      TRY(wait_adoption(st)); TRY(wait_adoption(st2));
       if (iter == 0 && lead) HIPCHK(c, hipEventRecord(lead, st));
       { StageTimer T(c, 4, st); ilqr::launch_line_search(S, P, ilqr::MASK_ACTIVE, st, iter, ls_bound); }
       { StageTimer T(c, 7, st2); ilqr::launch_line_search(Tw, P, ilqr::MASK_ACTIVE, st2, iter, ls_bound); }
@@ -557,13 +610,22 @@ static int enqueue_solve(ilqr_hip_ctx* c, const DevState& S, const h1::ProblemDe
         HIPCHK(c, hipMemcpyAsync(&c->h_active[iter + 1], S.order_n + 2 * (iter + 1), sizeof(int), hipMemcpyDeviceToHost, st));
         HIPCHK(c, hipEventRecord(c->ev_active[iter], st));
       }
+      prev_split = false;
       continue;
     }
     { StageTimer T(c, 3, st); ilqr::launch_backward(S, ilqr::MASK_ACTIVE, st, fold_h, iter); }                                  // :601
-    if (adopt_aside) HIPCHK(c, hipStreamWaitEvent(st, ev_adopt, 0));
+    TRY(wait_adoption(st));
     if (iter == 0 && lead) HIPCHK(c, hipEventRecord(lead, st));
     { StageTimer T(c, 4, st); ilqr::launch_line_search(S, P, ilqr::MASK_ACTIVE, st, iter, ls_bound); }                  // :616
     { StageTimer T(c, 5, st); ilqr::launch_control(S, 0, iter, c->tol, c->early_exit, st, ilqr::ls_costs_per_knot(P)); }                      // :619-620,645-655
+    const bool split_next = can_split && iter + 1 < c->max_iter && rolls_aside(iter + 1);
+    if (split_next) {
+      // group A of iteration iter + 1: the first entries of its list, as many as the first control pass has just put there
+      HIPCHK(c, hipMemcpyAsync(S.order_an + iter + 1, S.order_n + 2 * (iter + 1), sizeof(int), hipMemcpyDeviceToDevice, st));
+      DevState Sg = S; Sg.active = S.grp_a;
+      const ilqr::WorkList wa{S.order + (size_t)(2 * (iter + 1)) * S.B, S.order_an + iter + 1};
+      TRY(region(GA, st, Sg, ilqr::MASK_ACTIVE, -1, &wa, true));
+    }
     { StageTimer T(c, 6, st); ilqr::launch_backward(S, ilqr::MASK_RETRY, st, fold_h, iter); }                                  // :637
     { StageTimer T(c, 7, st); ilqr::launch_line_search(S, P, ilqr::MASK_RETRY, st, iter, ls_bound); }                   // :638
     { StageTimer T(c, 5, st); ilqr::launch_control(S, 1, iter, c->tol, c->early_exit, st, ilqr::ls_costs_per_knot(P)); }                      // :640-646
@@ -571,9 +633,14 @@ static int enqueue_solve(ilqr_hip_ctx* c, const DevState& S, const h1::ProblemDe
       HIPCHK(c, hipMemcpyAsync(&c->h_active[iter + 1], S.order_n + 2 * (iter + 1), sizeof(int), hipMemcpyDeviceToHost, st));
       HIPCHK(c, hipEventRecord(c->ev_active[iter], st));
     }
+    prev_split = split_next;
+  }
+  if (prev_split) {      // (the convergence exit ended the loop behind a group A that found nothing to do: its streams rejoin)
+    HIPCHK(c, hipStreamWaitEvent(st, GA.join, 0)); HIPCHK(c, hipStreamWaitEvent(st, GA.lin, 0)); HIPCHK(c, hipStreamWaitEvent(st, GA.adopt, 0));
   }
   return ILQR_OK;
 }
+int ilqr_hip_get_split_iterations(const ilqr_hip_ctx* c) { return c ? c->split_iterations : -1; }
 int ilqr_hip_get_speculative_iterations(const ilqr_hip_ctx* c) { return c ? c->spec_iterations : -1; }
 int ilqr_hip_num_slices(const ilqr_hip_ctx* c) { return c ? slices_wanted(c->B) : -1; }
 // The analytic Jacobians differentiate the constrained step with the active set held fixed (modes 1, 2); a sliding foot's
@@ -596,7 +663,7 @@ int ilqr_hip_solve_async(ilqr_hip_ctx* c) {
   HIPCHK(c, hipMemsetAsync(c->d_mismatch, 0, sizeof(unsigned long long), st));
   const int k = slices_wanted(c->B);
   c->n_slices = k;
-  c->spec_iterations = 0;
+  c->spec_iterations = 0; c->split_iterations = 0;
   if (spec_enabled() && k <= 1 && !c->twin && (c->B <= spec_max() || (c->early_exit && early_exit_gate(c)))) TRY(ensure_twin(c));
   c->lin_fold_h = ilqr::linearize_fold_h(P, c->jac_mode);   // what S.A / S.Bm hold after this solve
   c->first_aside = c->xbar_rolled && c->rolled_variant == rollout_kernel_identity(P) && same_dyn(c->rolled_dyn, P.dyn);

@@ -55,16 +55,27 @@ struct DevState {
   // round-robin by index: with a scattered selection one engine needs an extra 0.5 ms round of the one-wave-per-SIMD kernel).
   int* order;          // [2 (max_iter + 1)][B]
   int* order_n;        // [2 (max_iter + 1)]
+  // Early continuation (ilqr_capi.hip enqueue_solve): the rollouts whose FIRST line search of iteration it - 1 accepted a step start
+  // the linearisation / cost quadratics / re-rollout of iteration it while the others still take their lambda retry.  Group A =
+  // the first order_an[it] entries of list (it, 0) (k_control phase 0 fills that list first; the count is snapshot after it), group R =
+  // order_r[0 .. order_rn[it]) (filled by phase 1); grp_a / grp_r: the same two sets as per-rollout flags for the kernels that select
+  // by mask (rollout, trajectory cost, adoption).  Null: not in use.
+  int* grp_a;          // [B]
+  int* grp_r;          // [B]
+  int* order_r;        // [B]
+  int* order_rn;       // [max_iter + 2]
+  int* order_an;       // [max_iter + 2]
 };
 
 void launch_rollout(const DevState& S, const h1::ProblemDev& P, int mode, int do_roll, int count_iter, double* cost_out, hipStream_t st);
 void launch_step(int count, const double* x, const double* u, const h1::DynParams& dyn, double* xn, hipStream_t st, int stance_l = 1, int stance_r = 1);
 // skip_fold_rows != 0 (a solve whose backward pass is the folded one-wave Riccati kernel): rows 8..23 of A_t, B_t may stay unwritten
-void launch_linearize(const DevState& S, const h1::ProblemDev& P, int mode, int jac_mode, double eps, hipStream_t st, int phases = 3, int iter = -1, int skip_fold_rows = 0);
+struct WorkList;
+void launch_linearize(const DevState& S, const h1::ProblemDev& P, int mode, int jac_mode, double eps, hipStream_t st, int phases = 3, int iter = -1, int skip_fold_rows = 0, const WorkList* wl = nullptr);
 int linearize_skips_fold_rows(const h1::ProblemDev& P, int jac_mode);
 void launch_unfold_rows(const DevState& S, double h, hipStream_t st);
 // lower != 0: knots t < N get only the tiles I >= J of lxx (what k_backward_wave loads); the stage API always asks for the full matrix
-void launch_cost_quadratics(const DevState& S, const h1::ProblemDev& P, int mode, hipStream_t st, int iter = -1, int lower = 0);
+void launch_cost_quadratics(const DevState& S, const h1::ProblemDev& P, int mode, hipStream_t st, int iter = -1, int lower = 0, const WorkList* wl = nullptr);
 // compacted list of the rollouts of a pass inside a solve (DevState::order), or nulls: MASK_ACTIVE at iteration iter -> list (iter, 0), MASK_RETRY -> (iter, 1)
 struct WorkList { const int* list; const int* count; };
 inline WorkList work_list(const DevState& S, int mode, int iter) {

@@ -611,7 +611,7 @@ __device__ __forceinline__ void wave_copy(double* dst, const double* src, int le
 __global__ void __launch_bounds__(64 * CTRL_WAVES) k_control(DevState S, int phase, int iter, double tol, int early_exit, int sum_knots) {
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int b = blockIdx.x * CTRL_WAVES + wv;
-  __shared__ int s_accept[CTRL_WAVES], s_slot[CTRL_WAVES], s_base[2];
+  __shared__ int s_accept[CTRL_WAVES], s_slot[CTRL_WAVES], s_base[3];
   const int N = S.N;
   bool run = b < S.B;
   if (run && phase == 0 && !S.active[b]) run = false;
@@ -676,6 +676,11 @@ __global__ void __launch_bounds__(64 * CTRL_WAVES) k_control(DevState S, int pha
         const int retry = phase == 0 && S.need_retry[b];
         if (retry || S.active[b]) s_slot[wv] = retry ? 1 : 0;
       }
+      // early continuation: who starts iteration iter + 1 now (group A, decided by the first search) and who after the retry (R)
+      if (S.grp_a) {
+        if (phase == 0) { S.grp_a[b] = (!S.need_retry[b] && S.active[b]) ? 1 : 0; S.grp_r[b] = 0; }
+        else S.grp_r[b] = S.active[b] ? 1 : 0;
+      }
     }
   }
   __syncthreads();
@@ -686,14 +691,16 @@ __global__ void __launch_bounds__(64 * CTRL_WAVES) k_control(DevState S, int pha
       for (int w = 0; w < CTRL_WAVES; ++w) cnt += s_slot[w] == (int)threadIdx.x;
       const int slot = threadIdx.x ? 2 * iter + 1 : 2 * (iter + 1);
       s_base[threadIdx.x] = cnt ? atomicAdd(&S.order_n[slot], cnt) : 0;
+      if (threadIdx.x == 0 && phase == 1 && S.order_r) s_base[2] = cnt ? atomicAdd(&S.order_rn[iter + 1], cnt) : 0;
     }
     __syncthreads();
     if (lane == 0 && s_slot[wv] >= 0) {
       const int kind = s_slot[wv];
-      int pos = s_base[kind];
-      for (int w = 0; w < wv; ++w) pos += s_slot[w] == kind;
+      int pos = s_base[kind], posr = s_base[2];
+      for (int w = 0; w < wv; ++w) { pos += s_slot[w] == kind; posr += s_slot[w] == kind; }
       const int slot = kind ? 2 * iter + 1 : 2 * (iter + 1);
       S.order[(size_t)slot * S.B + pos] = b;
+      if (kind == 0 && phase == 1 && S.order_r) S.order_r[posr] = b;
     }
   }
   const int acc = s_accept[wv];
@@ -813,6 +820,10 @@ __global__ void k_solve_begin(DevState S) {
   if (S.order) {       // iteration 0: every rollout, in order; the other lists are filled by k_control
     S.order[b] = b;
     if (b == 0) { S.order_n[0] = S.B; for (int i = 1; i < 2 * (S.max_iter + 1); ++i) S.order_n[i] = 0; }
+  }
+  if (S.grp_a) {
+    S.grp_a[b] = 0; S.grp_r[b] = 0;
+    if (b == 0) for (int i = 0; i < S.max_iter + 2; ++i) { S.order_rn[i] = 0; S.order_an[i] = 0; }
   }
   const double J0 = S.Jbase[b];
   S.J[b] = J0;
@@ -984,8 +995,8 @@ __global__ void __launch_bounds__(256) k_unfold_rows(DevState S, double h) {
 void launch_unfold_rows(const DevState& S, double h, hipStream_t st) { hipLaunchKernelGGL(k_unfold_rows, dim3((unsigned)((size_t)S.B * S.N)), dim3(256), 0, st, S, h); }
 // does launch_linearize(..., skip_fold_rows = 1) leave rows 8..23 unwritten?  (only the two-knot constraint-free tangent kernel does)
 int linearize_skips_fold_rows(const ProblemDev& P, int jac_mode) { return (jac_mode == 0 && !P.dyn.contact && !g_var.lin_one_knot) ? 1 : 0; }
-void launch_linearize(const DevState& S, const ProblemDev& P, int mode, int jac_mode, double eps, hipStream_t st, int phases, int iter, int skip_fold_rows) {
-  const WorkList w = work_list(S, mode, iter);
+void launch_linearize(const DevState& S, const ProblemDev& P, int mode, int jac_mode, double eps, hipStream_t st, int phases, int iter, int skip_fold_rows, const WorkList* wl) {
+  const WorkList w = wl ? *wl : work_list(S, mode, iter);
   if (jac_mode == 0 && !use_scalar_dyn()) {
     // primal dump: on two lanes per knot beside the two-lane rollout kernels, one lane per knot with ILQR_ROLLOUT=r
     if (phases & 1) { if (g_var.rollout_split || P.dyn.contact) launch_lin_primal_s(S, P, mode, st, w.list, w.count); else launch_lin_primal_r(S, P, mode, st); }   // (contact mode: the dump is the free solve, see k_lin_tangent_c)

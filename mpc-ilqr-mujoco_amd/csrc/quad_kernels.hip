@@ -898,8 +898,8 @@ __global__ void __launch_bounds__(128, QUAD_WAVES) k_cost_quadratics(DevState S,
   QSTAMP(5)
 }
 
-void launch_cost_quadratics(const DevState& S, const ProblemDev& P, int mode, hipStream_t st, int iter, int lower) {
-  const WorkList w = work_list(S, mode, iter);
+void launch_cost_quadratics(const DevState& S, const ProblemDev& P, int mode, hipStream_t st, int iter, int lower, const WorkList* wl) {
+  const WorkList w = wl ? *wl : work_list(S, mode, iter);
   const long knots = (long)S.B * (S.N + 1);
   // the per-knot kinematics run for every rollout a masked (stage-API) launch might select; inside a solve for the compacted list
   hipLaunchKernelGGL(k_quad_kin, dim3((unsigned)((knots + 63) / 64)), dim3(64), 0, st, S, P, w.list, w.count, S.quad_rec, S.quad_knot0);

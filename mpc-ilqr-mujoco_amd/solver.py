@@ -34,7 +34,7 @@ EXPORTS = [
     "ilqr_hip_set_trajectory", "ilqr_hip_stage_rollout", "ilqr_hip_stage_linearize", "ilqr_hip_stage_cost_quadratics",
     "ilqr_hip_stage_backward_pass", "ilqr_hip_stage_line_search", "ilqr_hip_stage_total_cost",
     "ilqr_hip_get_linearization", "ilqr_hip_set_linearization", "ilqr_hip_get_quadratics", "ilqr_hip_set_quadratics",
-    "ilqr_hip_get_value_function", "ilqr_hip_step", "ilqr_hip_step_stance", "ilqr_hip_set_contact_mode", "ilqr_hip_set_friction", "ilqr_hip_enable_profiling", "ilqr_hip_get_stage_ms", "ilqr_hip_get_adopt_mismatches", "ilqr_hip_get_iterations_enqueued", "ilqr_hip_get_speculative_iterations", "ilqr_hip_set_profiled_stages",
+    "ilqr_hip_get_value_function", "ilqr_hip_step", "ilqr_hip_step_stance", "ilqr_hip_set_contact_mode", "ilqr_hip_set_friction", "ilqr_hip_enable_profiling", "ilqr_hip_get_stage_ms", "ilqr_hip_get_adopt_mismatches", "ilqr_hip_get_iterations_enqueued", "ilqr_hip_get_speculative_iterations", "ilqr_hip_get_split_iterations", "ilqr_hip_set_profiled_stages",
     "ilqr_hip_payload_width", "ilqr_hip_comm_available", "ilqr_hip_comm_get_unique_id", "ilqr_hip_comm_init", "ilqr_hip_comm_destroy", "ilqr_hip_comm_world", "ilqr_hip_comm_rank",
     "ilqr_hip_gather_first_knot",
     "ilqr_hip_reference_kinematics", "ilqr_hip_reference_com_velocity", "ilqr_hip_foot_clearance", "ilqr_hip_gravity_compensation", "ilqr_hip_stream",
@@ -377,6 +377,10 @@ class BatchedILQR:
     def speculative_iterations(self):
         """Iterations of the last solve whose lambda retry ran beside the first pass (small passes; ILQR_SPEC=0 disables)."""
         return int(self.L.ilqr_hip_get_speculative_iterations(self.h))
+
+    def split_iterations(self):
+        """Iterations of the last solve whose concurrent region ran in two groups (early continuation; ILQR_SPLIT=0 disables)."""
+        return int(self.L.ilqr_hip_get_split_iterations(self.h))
 
     def num_slices(self):
         """Batch slices a solve is enqueued as (ILQR_SLICES)."""

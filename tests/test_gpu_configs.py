@@ -279,21 +279,24 @@ def test_early_exit_gate_stops_launching_and_changes_nothing():
 
 @pytest.mark.parametrize("mode", ["fixed", "early_exit", "contact", "wg-r"])
 def test_speculative_lambda_retry_is_the_sequential_retry_bit_for_bit(mode):
-    """Small passes run the lambda retry of ilqr.cpp:619-644 beside the first pass (k_control_spec): Riccati and line search for
+    """(i) Small passes run the lambda retry of ilqr.cpp:619-644 beside the first pass (k_control_spec): Riccati and line search for
     lambda and for min(10 lambda, 1e-3) on two streams, the bookkeeping played once with both outcomes.  Every observable of the
     solve -- cost trace, accepted step sizes, lambda schedule, iteration counts, gains, feed-forward, value function, trajectory,
     final lambda -- equals the sequential order's (ILQR_SPEC=0) bit for bit, on cold starts that walk through accept, fail -> retry
     -> accept and fail -> retry -> fail (-> continue / break), with and without the convergence exit, in contact mode and on the
-    other kernel families; a pass above the threshold (ILQR_SPEC_MAX) stays sequential."""
+    other kernel families; a pass above the threshold (ILQR_SPEC_MAX) stays sequential.  (ii) Where the retry stays sequential, the
+    rollouts whose first line search accepted start the next iteration's linearisation / cost quadratics / re-rollout beside the
+    retry of the others (early continuation, two groups per concurrent region): bit for bit the one-group order (ILQR_SPLIT=0)."""
     B = 12
     gravity = [0.0, 0.0, -9.81] if mode == "contact" else None
     prob, x0, ui = standing(B, seed=53, gravity=gravity)
     var = dict(ILQR_BACKWARD="wg", ILQR_LS="r", ILQR_ROLLOUT="r") if mode == "wg-r" else {}
     out = {}
-    for spec in ("1", "0", "max"):
-        kv = dict(var); kv.update(ILQR_SPEC="1" if spec == "max" else spec)
+    for spec in ("1", "0", "max", "0-nosplit"):
+        kv = dict(var); kv.update(ILQR_SPEC="1" if spec == "max" else spec[0])
         if spec == "max":
             kv["ILQR_SPEC_MAX"] = str(B - 1)
+        kv["ILQR_SPLIT"] = "0" if spec == "0-nosplit" else "1"       # (the default: on with the convergence exit only)
         with env(**kv):
             s = _solver(B); s.set_problem(prob); s.set_options(early_exit=(mode == "early_exit")); s.set_max_iterations(10)
             if mode == "contact":
@@ -301,9 +304,15 @@ def test_speculative_lambda_retry_is_the_sequential_retry_bit_for_bit(mode):
             s.initialize(x0, ui); cost = s.solve(x0)
             tc, ta, tl = s.trace()
             Vx, Vxx = s.value_function()
-            out[spec] = (cost, tc, ta, tl, s.iterations(), s.gains_K(), s.gains_kff(), Vx, Vxx, s.xbar(), s.ubar(), s.lambdas(), s.speculative_iterations(), s.adopt_mismatches())
+            out[spec] = (cost, tc, ta, tl, s.iterations(), s.gains_K(), s.gains_kff(), Vx, Vxx, s.xbar(), s.ubar(), s.lambdas(), s.speculative_iterations(), s.adopt_mismatches(), s.split_iterations())
             s.close()
     assert out["1"][12] >= 3 and out["0"][12] == 0 and out["1"][13] == 0
+    # early continuation (two groups per concurrent region): on wherever the sequential retry runs beside a concurrent re-rollout
+    assert out["0-nosplit"][14] == 0 and out["0-nosplit"][12] == 0 and out["0"][13] == 0 and out["max"][13] == 0
+    if mode != "wg-r":
+        assert out["0"][14] >= 3 and out["1"][14] == (0 if mode != "early_exit" else out["1"][14])
+    for k in range(12):
+        assert np.array_equal(out["0"][k], out["0-nosplit"][k], equal_nan=True), k
     if mode != "early_exit":
         assert out["1"][12] == 10 and out["max"][12] == 0         # (early exit: the pass shrinks below the threshold on its way)
     else:
