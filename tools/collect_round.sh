@@ -37,10 +37,14 @@ for name, c in sorted(best.items(), key=lambda kv: -kv[1].get("SQ_INSTS_VALU", 0
     print("%-30s %11.4g %11.4g %11.4g %11.4g %11.4g %11.4g %6.1f %10.1f" % (name[:30], v, a, m, f, t, mo, 100 * (a + m + f + t) / max(v, 1), ((a + m + 2 * f) * 64 + mo * 512) / 1e9))
 PY
 echo "[collect] fp64 mix done"
+# (one group per concurrent region for this trace: with the early continuation of the convergence-exit leg the regions of consecutive
+# iterations overlap and tools/timeline.py, which cuts at k_quad_kin, cannot attribute kernels to iterations)
+export ILQR_SPLIT=0
 rocprofv3 --kernel-trace --output-format csv -d "$out/tr" -o t -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-contact-line > "$out/bench_trace.log" 2>&1
+unset ILQR_SPLIT
 f=$(find "$out/tr" -name "*kernel_trace.csv" | head -1)
 python3 tools/timeline.py "$f" 16 > "$out/${tag}_iteration_timeline.txt"
-python3 tools/timeline.py "$f" 5 all | sed -n '/^iter/,$p' > "$out/${tag}_iteration_spans_fixed_and_early_exit.txt"
+{ echo "# ILQR_SPLIT=0 (one group per concurrent region, see tools/collect_round.sh); iterations 30.. are the convergence-exit leg:"; echo "# from the iteration whose pass holds <= 512 rollouts on, both lambda passes run side by side (two backward_wav / line_search_ entries, overlapping)"; python3 tools/timeline.py "$f" 5 all | sed -n '/^iter/,$p'; } > "$out/${tag}_iteration_spans_fixed_and_early_exit.txt"
 rm -rf "$out/tr"
 echo "[collect] timelines done"
 # the contact workload's own passes: per-kernel time and HBM traffic of `bench.py --contact`
@@ -60,6 +64,10 @@ L="$out/${tag}_bench_lines"
 python3 bench.py 2>/dev/null | grep '^{' > "$L/bench_default.json"; echo "[collect] default line done"
 python3 bench.py --contact --no-cpu-baseline 2>/dev/null | grep '^{' > "$L/bench_contact.json"
 python3 bench.py --batch 1 --no-cpu-baseline --no-contact-line --steps 20 --warmup 3 2>/dev/null | grep '^{' > "$L/bench_b1.json"
+ILQR_SPEC=0 python3 bench.py --batch 1 --no-cpu-baseline --no-contact-line --steps 20 --warmup 3 2>/dev/null | grep '^{' > "$L/bench_b1_sequential_retry.json"
+python3 bench.py --batch 256 --no-cpu-baseline --no-contact-line 2>/dev/null | grep '^{' > "$L/bench_b256.json"
+ILQR_SPEC=0 python3 bench.py --batch 256 --no-cpu-baseline --no-contact-line 2>/dev/null | grep '^{' > "$L/bench_b256_sequential_retry.json"
+ILQR_SPEC=0 ILQR_SPLIT=0 python3 bench.py --no-cpu-baseline --no-contact-line 2>/dev/null | grep '^{' > "$L/bench_default_sequential_retry_one_group.json"
 python3 bench.py --stage rollout_jacobians --batch 1024 --no-cpu-baseline --steps 20 --warmup 3 2>/dev/null | grep '^{' > "$L/bench_cfg1.json"
 python3 bench.py --batch 1024 --no-cpu-baseline --no-contact-line 2>/dev/null | grep '^{' > "$L/bench_b1024.json"
 python3 bench.py --batch 1024 --horizon 50 --no-cpu-baseline --no-contact-line 2>/dev/null | grep '^{' > "$L/bench_b1024_n50.json"
