@@ -211,7 +211,9 @@ int ilqr_hip_get_iterations_enqueued(const ilqr_hip_ctx* ctx);
    rollouts (the whole batch, or -- convergence exit -- the count of rollouts still active the host has seen), the Riccati pass and
    the line search for lambda and for min(10 lambda, 1e-3) run side by side on two streams and the bookkeeping of :619-655 is
    played once with both outcomes known; results (gains, value function, trajectory, lambda, trace) are those of the sequential
-   order, one pass of latency sooner.  Environment ILQR_SPEC=0 keeps the sequential order.  Returns the count, -1 for a null handle. */
+   order, one pass of latency sooner.  Counted: the iterations that ENQUEUED the side-by-side passes -- while the host's count (one iteration
+   old) is between 512 and 2048 both orders are enqueued and the device takes one by the length of the work list (ILQR_SPEC_DUAL=0: host
+   count alone).  Environment ILQR_SPEC=0 keeps the sequential order.  Returns the count, -1 for a null handle. */
 int ilqr_hip_get_speculative_iterations(const ilqr_hip_ctx* ctx);
 /* Iterations of the last solve whose concurrent region (linearisation, cost quadratics, nominal re-rollout: ilqr.cpp:551-588) ran in
    two groups: the rollouts whose first line search of the previous iteration accepted a step start right behind that iteration's first

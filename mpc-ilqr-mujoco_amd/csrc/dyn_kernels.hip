@@ -200,7 +200,9 @@ __global__ void __launch_bounds__(64) k_line_search_r(DevState S, ProblemDev P, 
 #define CK_LD 51
 // rows = consecutive [N+1][51] trajectories in xsrc ([B][8] candidates: cshift = 3, oshift = 0; [B] nominal
 // trajectories: cshift = 0, oshift = 3 -- they use the slots of candidate 0 of their rollout in the knot buffer)
-__global__ void __launch_bounds__(64) k_traj_knot_cost(DevState S, ProblemDev P, int mode, const double* xsrc, const double* usrc, int cshift, int oshift) {
+// gate (optional): the launch does nothing when *gate == 0 (device-side choice between two enqueued launch orders, ilqr_capi.hip)
+__global__ void __launch_bounds__(64) k_traj_knot_cost(DevState S, ProblemDev P, int mode, const double* xsrc, const double* usrc, int cshift, int oshift, const int* gate) {
+  if (gate && *gate == 0) return;
   __shared__ double xs[32 * CK_LD];     // half a wave's rows at a time: 13 KB, so that the registers (two waves per SIMD), not the LDS, set the occupancy
   const int N = S.N, lane = threadIdx.x;
   const long total = ((long)S.B << cshift) * (N + 1);
@@ -253,15 +255,15 @@ __global__ void __launch_bounds__(64) k_traj_cost_sum(DevState S, int mode, int 
   for (int t = 0; t <= S.N; ++t) c += ck[t];
   cost_out[cand] = c;
 }
-void launch_cand_costs(const DevState& S, const ProblemDev& P, int mode, hipStream_t st, bool with_sum) {
+void launch_cand_costs(const DevState& S, const ProblemDev& P, int mode, hipStream_t st, bool with_sum, const int* gate) {
   const long total = (long)S.B * 8 * (S.N + 1);
-  hipLaunchKernelGGL(k_traj_knot_cost, dim3((unsigned)((total + 63) / 64)), dim3(64), 0, st, S, P, mode, S.xcand, S.ucand, 3, 0);
+  hipLaunchKernelGGL(k_traj_knot_cost, dim3((unsigned)((total + 63) / 64)), dim3(64), 0, st, S, P, mode, S.xcand, S.ucand, 3, 0, gate);
   if (with_sum) hipLaunchKernelGGL(k_traj_cost_sum, dim3((unsigned)(((long)S.B * 8 + 63) / 64)), dim3(64), 0, st, S, mode, 3, 0, S.cand_cost);
 }
 // computeTotalCost of the nominal trajectories (S.xbar, S.ubar) into cost_out[B], same kernels, same summation order
 void launch_nominal_costs(const DevState& S, const ProblemDev& P, int mode, double* cost_out, hipStream_t st) {
   const long total = (long)S.B * (S.N + 1);
-  hipLaunchKernelGGL(k_traj_knot_cost, dim3((unsigned)((total + 63) / 64)), dim3(64), 0, st, S, P, mode, S.xbar, S.ubar, 0, 3);
+  hipLaunchKernelGGL(k_traj_knot_cost, dim3((unsigned)((total + 63) / 64)), dim3(64), 0, st, S, P, mode, S.xbar, S.ubar, 0, 3, (const int*)nullptr);
   hipLaunchKernelGGL(k_traj_cost_sum, dim3((unsigned)((S.B + 63) / 64)), dim3(64), 0, st, S, mode, 0, 3, cost_out);
 }
 

@@ -85,7 +85,8 @@ struct ilqr_hip_ctx {
   DevState T{};
   bool twin = false;
   hipEvent_t ev_spec_fork = nullptr, ev_spec_join = nullptr;
-  int spec_iterations = 0;    // iterations of the last solve that ran both passes side by side
+  int spec_iterations = 0;    // iterations of the last solve that enqueued both passes side by side
+  int* d_spec_gate = nullptr; // [4] device-side choice of the order (launch_spec_gate)
   // early continuation (enqueue_solve): streams / events of the group that starts the next iteration behind the first control pass
   hipStream_t a1 = nullptr, a2 = nullptr, a3 = nullptr;
   hipEvent_t evA_fork = nullptr, evA_join = nullptr, evA_roll = nullptr, evA_lin = nullptr, evA_adopt = nullptr;
@@ -198,7 +199,7 @@ int ilqr_hip_destroy(ilqr_hip_ctx* c) {
                   S.lambda, S.active, S.need_retry, S.iters, S.improved, S.alpha_idx, S.trace_cost, S.trace_alpha, S.trace_lambda, S.order, S.order_n, c->d_tmpx, c->d_tmpu,
                   c->d_prevx, c->d_prevu, c->d_shadowx, c->d_u0, c->d_K0, c->d_cost_tmp, c->d_stepx, c->d_stepu, c->d_stepn, c->d_mismatch, c->d_payload, c->d_xref, c->d_uref, c->d_comref, c->d_eeref, c->d_comvelref, c->d_stance};
   for (void* p : ptrs) if (p) hipFree(p);
-  if (c->twin) { void* tw[] = {c->T.K, c->T.kff, c->T.Vx, c->T.Vxx, c->T.xcand, c->T.ucand, c->T.cand_cost, c->T.cand_knot, c->T.lambda}; for (void* p : tw) if (p) hipFree(p); }
+  if (c->twin) { void* tw[] = {c->T.K, c->T.kff, c->T.Vx, c->T.Vxx, c->T.xcand, c->T.ucand, c->T.cand_cost, c->T.cand_knot, c->T.lambda, c->d_spec_gate}; for (void* p : tw) if (p) hipFree(p); }
   { void* gp[] = {S.grp_a, S.grp_r, S.order_r, S.order_rn, S.order_an}; for (void* p : gp) if (p) hipFree(p); }
   for (hipEvent_t e : {c->evA_fork, c->evA_join, c->evA_roll, c->evA_lin, c->evA_adopt}) if (e) hipEventDestroy(e);
   for (hipStream_t t : {c->a1, c->a2, c->a3}) if (t) hipStreamDestroy(t);
@@ -463,6 +464,7 @@ static int ensure_gate(ilqr_hip_ctx* c) {
 // (headline -3 %, contact +3 % / -3.5 % at B = 4096 / 1024).  ILQR_SPLIT=0 / 1 forces it off / on.
 static int split_enabled(const ilqr_hip_ctx* c) { const char* e = getenv("ILQR_SPLIT"); return e ? atoi(e) : c->early_exit; }
 static int spec_enabled() { const char* e = getenv("ILQR_SPEC"); return e ? atoi(e) : 1; }
+static int spec_dual() { const char* e = getenv("ILQR_SPEC_DUAL"); return e ? atoi(e) : 1; }
 static int spec_max() { const char* e = getenv("ILQR_SPEC_MAX"); return e ? atoi(e) : 512; }
 static int ensure_twin(ilqr_hip_ctx* c) {
   if (c->twin) return ILQR_OK;
@@ -474,6 +476,7 @@ static int ensure_twin(ilqr_hip_ctx* c) {
   TRY(dalloc(c, &T.K, B * N * m * n + 32)); TRY(dalloc(c, &T.kff, B * N * m)); TRY(dalloc(c, &T.Vx, B * n)); TRY(dalloc(c, &T.Vxx, B * n * n));
   TRY(dalloc(c, &T.xcand, B * 8 * (N + 1) * n)); TRY(dalloc(c, &T.ucand, B * 8 * N * m)); TRY(dalloc(c, &T.cand_cost, B * 8)); TRY(dalloc(c, &T.cand_knot, B * 8 * (N + 1)));
   TRY(dalloc(c, &T.lambda, B));
+  TRY(dalloc(c, &c->d_spec_gate, 4));
   if (!c->ev_spec_fork) HIPCHK(c, hipEventCreateWithFlags(&c->ev_spec_fork, hipEventDisableTiming));
   if (!c->ev_spec_join) HIPCHK(c, hipEventCreateWithFlags(&c->ev_spec_join, hipEventDisableTiming));
   return ILQR_OK;
@@ -610,6 +613,40 @@ static int enqueue_solve(ilqr_hip_ctx* c, const DevState& S, const h1::ProblemDe
         HIPCHK(c, hipMemcpyAsync(&c->h_active[iter + 1], S.order_n + 2 * (iter + 1), sizeof(int), hipMemcpyDeviceToHost, st));
         HIPCHK(c, hipEventRecord(c->ev_active[iter], st));
       }
+      prev_split = false;
+      continue;
+    }
+    if (c->twin && spec_enabled() && spec_dual() && S.order && gate && pass_bound <= 4 * spec_max() && ilqr::spec_dual_available(P)) {
+      // The host's count is one iteration old: between spec_max and 4 spec_max the pass may or may not have shrunk below the
+      // threshold by now.  Both orders are enqueued and the device takes one (launch_spec_gate): the twin's launches and the
+      // one-rollout-per-wave line search see a count of zero unless the list holds <= spec_max rollouts, the sequential first line
+      // search and bookkeeping see zero if it does; the lambda-retry launches find an empty retry list behind k_control_spec.
+      const DevState Tw = twin_view(c, S);
+      const int* list = S.order + (size_t)(2 * iter) * S.B;
+      int* g = c->d_spec_gate;
+      ++c->spec_iterations;
+      ilqr::launch_spec_gate(S, iter, spec_max(), g, st);
+      HIPCHK(c, hipEventRecord(c->ev_spec_fork, st));
+      HIPCHK(c, hipStreamWaitEvent(st2, c->ev_spec_fork, 0));
+      ilqr::launch_spec_lambda(S, Tw.lambda, st2);
+      { StageTimer T(c, 3, st); ilqr::launch_backward(S, ilqr::MASK_ACTIVE, st, fold_h, iter); }
+      { StageTimer T(c, 6, st2); ilqr::launch_backward_list(Tw, st2, fold_h, list, g); }
+      TRY(wait_adoption(st)); TRY(wait_adoption(st2));
+      { StageTimer T(c, 4, st);
+        ilqr::launch_line_search_list(S, P, st, list, g, spec_max());
+        ilqr::launch_line_search_list(S, P, st, list, g + 2, ls_bound);
+        ilqr::launch_cand_costs(S, P, ilqr::MASK_ACTIVE, st, false); }
+      { StageTimer T(c, 7, st2); ilqr::launch_line_search_list(Tw, P, st2, list, g, spec_max()); ilqr::launch_cand_costs(Tw, P, ilqr::MASK_ACTIVE, st2, false, g); }
+      HIPCHK(c, hipEventRecord(c->ev_spec_join, st2));
+      HIPCHK(c, hipStreamWaitEvent(st, c->ev_spec_join, 0));
+      { StageTimer T(c, 5, st);
+        ilqr::launch_control_spec(S, Tw, iter, c->tol, c->early_exit, st, ilqr::ls_costs_per_knot(P), g);
+        ilqr::launch_control(S, 0, iter, c->tol, c->early_exit, st, ilqr::ls_costs_per_knot(P), g + 1); }
+      { StageTimer T(c, 6, st); ilqr::launch_backward(S, ilqr::MASK_RETRY, st, fold_h, iter); }
+      { StageTimer T(c, 7, st); ilqr::launch_line_search(S, P, ilqr::MASK_RETRY, st, iter, ls_bound); }
+      { StageTimer T(c, 5, st); ilqr::launch_control(S, 1, iter, c->tol, c->early_exit, st, ilqr::ls_costs_per_knot(P)); }
+      HIPCHK(c, hipMemcpyAsync(&c->h_active[iter + 1], S.order_n + 2 * (iter + 1), sizeof(int), hipMemcpyDeviceToHost, st));
+      HIPCHK(c, hipEventRecord(c->ev_active[iter], st));
       prev_split = false;
       continue;
     }

@@ -86,12 +86,19 @@ inline WorkList work_list(const DevState& S, int mode, int iter) {
 void launch_backward(const DevState& S, int mode, hipStream_t st, double fold_h = 0.0, int iter = -1);
 // speculative lambda retry (ilqr_kernels.hip k_control_spec): T = the twin view whose K, kff, Vx, Vxx, candidates and lambda are its own
 void launch_spec_lambda(const DevState& S, double* lambda2, hipStream_t st);
-void launch_control_spec(const DevState& S, const DevState& T, int iter, double tol, int early_exit, hipStream_t st, int sum_knots);
+void launch_control_spec(const DevState& S, const DevState& T, int iter, double tol, int early_exit, hipStream_t st, int sum_knots, const int* gate = nullptr);
+// Device-side choice between the two orders (the host's count of active rollouts is one iteration old): g[0] = n if n <= max else 0 (count of
+// the speculative launches), g[1] = 0 / 1 (gate of the sequential bookkeeping), g[2] = 0 / n (count of the sequential first line search), with
+// n = the length of list (iter, 0).  The launchers below take an explicit list / count (default kernel families only: spec_dual_available).
+void launch_spec_gate(const DevState& S, int iter, int max, int* g, hipStream_t st);
+bool spec_dual_available(const h1::ProblemDev& P);
+void launch_backward_list(const DevState& S, hipStream_t st, double fold_h, const int* list, const int* count);
+void launch_line_search_list(const DevState& S, const h1::ProblemDev& P, hipStream_t st, const int* list, const int* count, int max_rollouts);
 double linearize_fold_h(const h1::ProblemDev& P, int jac_mode);
 // max_rollouts: upper bound of the rollouts this pass can select (the batch, or -- with the early-exit gate -- the count of
 // still-active rollouts the host saw two iterations ago): at most 1024 -> one rollout per wave in the two-lane line search
 void launch_line_search(const DevState& S, const h1::ProblemDev& P, int mode, hipStream_t st, int iter = -1, int max_rollouts = -1);
-void launch_control(const DevState& S, int phase, int iter, double tol, int early_exit, hipStream_t st, int sum_knots = 0);
+void launch_control(const DevState& S, int phase, int iter, double tol, int early_exit, hipStream_t st, int sum_knots = 0, const int* gate = nullptr);
 bool ls_costs_per_knot(const h1::ProblemDev& P);
 void launch_solve_begin(const DevState& S, hipStream_t st);
 void launch_adopt_rollout(const DevState& S, const double* shadow, int mode, unsigned long long* mismatches, hipStream_t st);
@@ -114,7 +121,7 @@ size_t quad_rec_doubles(size_t knots);
 void launch_rollout_r(const DevState& S, const h1::ProblemDev& P, int mode, int do_roll, int count_iter, double* cost_out, hipStream_t st);
 void launch_step_r(int count, const double* x, const double* u, const h1::DynParams& dyn, double* xn, hipStream_t st);
 void launch_last_step_r(const DevState& S, const h1::ProblemDev& P, hipStream_t st);
-void launch_cand_costs(const DevState& S, const h1::ProblemDev& P, int mode, hipStream_t st, bool with_sum = true);
+void launch_cand_costs(const DevState& S, const h1::ProblemDev& P, int mode, hipStream_t st, bool with_sum = true, const int* gate = nullptr);
 void launch_nominal_costs(const DevState& S, const h1::ProblemDev& P, int mode, double* cost_out, hipStream_t st);
 void launch_line_search_r(const DevState& S, const h1::ProblemDev& P, int mode, hipStream_t st);
 void launch_lin_primal_r(const DevState& S, const h1::ProblemDev& P, int mode, hipStream_t st);

@@ -608,7 +608,8 @@ __device__ __forceinline__ void wave_copy(double* dst, const double* src, int le
   }
 }
 #define CTRL_WAVES 16
-__global__ void __launch_bounds__(64 * CTRL_WAVES) k_control(DevState S, int phase, int iter, double tol, int early_exit, int sum_knots) {
+__global__ void __launch_bounds__(64 * CTRL_WAVES) k_control(DevState S, int phase, int iter, double tol, int early_exit, int sum_knots, const int* gate) {
+  if (gate && *gate == 0) return;      // (device-side choice between two enqueued launch orders: launch_spec_gate)
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int b = blockIdx.x * CTRL_WAVES + wv;
   __shared__ int s_accept[CTRL_WAVES], s_slot[CTRL_WAVES], s_base[3];
@@ -720,11 +721,13 @@ __global__ void __launch_bounds__(64 * CTRL_WAVES) k_control(DevState S, int pha
 // buffers (T = the twin view: K, kff, Vx, Vxx, candidates, lambda), and this kernel then plays ilqr.cpp:619-655 once with both
 // outcomes on the table: first search accepted -> the twin is dropped; else the twin IS the retry the reference would have run
 // (its gains, value function, candidates and costs replace the first pass's, accepted or not).  Same results, one pass of latency.
+__global__ void k_spec_gate(const int* n_ptr, int max, int* g) { const int n = *n_ptr; g[0] = n <= max ? n : 0; g[1] = n <= max ? 0 : 1; g[2] = n <= max ? 0 : n; }
 __global__ void k_spec_lambda(DevState S, double* lambda2) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b < S.B) lambda2[b] = fmin(S.lambda[b] * 10.0, 1e-3);
 }
-__global__ void __launch_bounds__(64 * CTRL_WAVES) k_control_spec(DevState S, DevState T, int iter, double tol, int early_exit, int sum_knots) {
+__global__ void __launch_bounds__(64 * CTRL_WAVES) k_control_spec(DevState S, DevState T, int iter, double tol, int early_exit, int sum_knots, const int* gate) {
+  if (gate && *gate == 0) return;
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int b = blockIdx.x * CTRL_WAVES + wv;
   __shared__ int s_accept[CTRL_WAVES], s_retry[CTRL_WAVES], s_slot[CTRL_WAVES], s_base[1];
@@ -1049,13 +1052,17 @@ void launch_line_search(const DevState& S, const ProblemDev& P, int mode, hipStr
 }
 // inside a solve the two-lane line search leaves per-knot costs behind and k_control sums them itself (ls_costs_per_knot)
 bool ls_costs_per_knot(const ProblemDev& P) { return !use_scalar_dyn() && (g_var.ls_split || P.dyn.contact); }
-void launch_control(const DevState& S, int phase, int iter, double tol, int early_exit, hipStream_t st, int sum_knots) {
-  hipLaunchKernelGGL(k_control, dim3(cdiv(S.B, CTRL_WAVES)), dim3(64 * CTRL_WAVES), 0, st, S, phase, iter, tol, early_exit, sum_knots);
+void launch_control(const DevState& S, int phase, int iter, double tol, int early_exit, hipStream_t st, int sum_knots, const int* gate) {
+  hipLaunchKernelGGL(k_control, dim3(cdiv(S.B, CTRL_WAVES)), dim3(64 * CTRL_WAVES), 0, st, S, phase, iter, tol, early_exit, sum_knots, gate);
 }
 void launch_spec_lambda(const DevState& S, double* lambda2, hipStream_t st) { hipLaunchKernelGGL(k_spec_lambda, dim3(cdiv(S.B, 256)), dim3(256), 0, st, S, lambda2); }
-void launch_control_spec(const DevState& S, const DevState& T, int iter, double tol, int early_exit, hipStream_t st, int sum_knots) {
-  hipLaunchKernelGGL(k_control_spec, dim3(cdiv(S.B, CTRL_WAVES)), dim3(64 * CTRL_WAVES), 0, st, S, T, iter, tol, early_exit, sum_knots);
+void launch_control_spec(const DevState& S, const DevState& T, int iter, double tol, int early_exit, hipStream_t st, int sum_knots, const int* gate) {
+  hipLaunchKernelGGL(k_control_spec, dim3(cdiv(S.B, CTRL_WAVES)), dim3(64 * CTRL_WAVES), 0, st, S, T, iter, tol, early_exit, sum_knots, gate);
 }
+void launch_spec_gate(const DevState& S, int iter, int max, int* g, hipStream_t st) { hipLaunchKernelGGL(k_spec_gate, dim3(1), dim3(1), 0, st, (const int*)(S.order_n + 2 * iter), max, g); }
+bool spec_dual_available(const ProblemDev& P) { return !use_scalar_dyn() && backward_kind() == 2 && (g_var.ls_split || P.dyn.contact); }
+void launch_backward_list(const DevState& S, hipStream_t st, double fold_h, const int* list, const int* count) { launch_backward_wave(S, MASK_ACTIVE, st, g_var.fold ? fold_h : 0.0, list, count); }
+void launch_line_search_list(const DevState& S, const ProblemDev& P, hipStream_t st, const int* list, const int* count, int max_rollouts) { launch_line_search_s(S, P, MASK_ACTIVE, st, list, count, max_rollouts); }
 void launch_solve_begin(const DevState& S, hipStream_t st) { hipLaunchKernelGGL(k_solve_begin, dim3(cdiv(S.B, 64)), dim3(64), 0, st, S); }
 void launch_adopt_rollout(const DevState& S, const double* shadow, int mode, unsigned long long* mismatches, hipStream_t st) { hipLaunchKernelGGL(k_adopt_rollout, dim3(S.B), dim3(64), 0, st, S, shadow, mode, mismatches); }
 void launch_warm_shift(const DevState& S, const double* px, const double* pu, hipStream_t st) { hipLaunchKernelGGL(k_warm_shift, dim3(S.B), dim3(64), 0, st, S, px, pu); }
