@@ -270,11 +270,15 @@ void launch_nominal_costs(const DevState& S, const ProblemDev& P, int mode, doub
 // primal dump of one knot per lane: see LinDumpG in h1_linearize_dev.h
 struct DumpSink {
   double* g;   // this knot's LinDumpG as doubles
+  const h1r::LaneLds* L;      // U_i, 1 / D_i of hinge i - 1 at slots 8 (i - 1) .. + 6, left there by the inward sweep
   DEVFN void operator()(int i, const double* v, const double* a, double s, double c) const {
-    double* sc = g + LinDumpG_sc + 2 * i; sc[0] = s; sc[1] = c;
-    double* vv = g + LinDumpG_v + 6 * i; double* aa = g + LinDumpG_a + 6 * i;
+    double* blk = (double*)__builtin_assume_aligned(g + ldg_v(i), 16);
+    double U[7];
 #pragma unroll
-    for (int k = 0; k < 6; ++k) { vv[k] = v[k]; aa[k] = a[k]; }
+    for (int k = 0; k < 7; ++k) U[k] = i == 0 ? 0.0 : (*L)[8 * (i == 0 ? 0 : i - 1) + k];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) { blk[k] = v[k]; blk[6 + k] = a[k]; blk[12 + k] = U[k]; }
+    blk[18] = U[6]; blk[19] = s; blk[20] = c; blk[21] = 0.0;
   }
 };
 __global__ void __launch_bounds__(64) k_lin_primal_r(DevState S, ProblemDev P, int mode) {
@@ -300,7 +304,7 @@ __global__ void __launch_bounds__(64) k_lin_primal_r(DevState S, ProblemDev P, i
     tau[i] = ui - H1_DAMPING * x[H1_NQ + 6 + i];
   }
   double* g = (double*)__builtin_assume_aligned(S.lin_dump + (size_t)knot * LinDumpG_SIZE, 16);
-  DumpSink sink{g};
+  DumpSink sink{g, &L};
   double inv36[36], aL[3];
   h1r::forward_dynamics(R0, x + 7, x + H1_NQ, tau, H1_ARMATURE + h * H1_DAMPING, P.dyn.g, L, qacc, sink, inv36, aL);
 #pragma unroll
@@ -311,10 +315,6 @@ __global__ void __launch_bounds__(64) k_lin_primal_r(DevState S, ProblemDev P, i
   for (int k = 0; k < H1_NV; ++k) g[LinDumpG_qacc + k] = qacc[k];
 #pragma unroll
   for (int k = 0; k < 36; ++k) g[LinDumpG_IA0inv + k] = inv36[k];
-  for (int i = 1; i < H1_NB; ++i) {
-    for (int k = 0; k < 6; ++k) g[LinDumpG_U + 6 * i + k] = L[8 * (i - 1) + k];
-    g[LinDumpG_Dinv + i] = L[8 * (i - 1) + 6];
-  }
 }
 
 static inline int cdiv2(long a, long b) { return (int)((a + b - 1) / b); }

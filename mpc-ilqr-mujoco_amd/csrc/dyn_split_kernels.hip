@@ -323,13 +323,19 @@ __global__ void __launch_bounds__(64) k_rollout_s(DevState S, ProblemDev P, int 
 // ---- primal dump of the analytic linearisation on two lanes per knot (replaces k_lin_primal_r, dyn_kernels.hip, wherever the
 // two-lane kernels run): forward dynamics of the nominal knot, every body's velocity / acceleration / sin, cos / U / 1/D, the base
 // rotation, the joint accelerations and the inverse of the pelvis' articulated inertia -> LinDumpG (h1_linearize_dev.h)
+// One body's whole block in one burst (see LinDumpG): U_i, 1 / D_i come from this lane's LDS slots, where the inward sweeps left them
+// before the outward sweep calls the sink (torso: slot block 0, leg hinge K: 8 + 8 K, arm hinge K: 48 + 8 K; the pelvis has none).
 struct DumpSinkS {
-  double* g;
+  double* g; const h1s::LaneLds* L; bool side;
   DEVFN void operator()(int i, const double* v, const double* a, double s, double c) const {
-    double* sc = g + LinDumpG_sc + 2 * i; sc[0] = s; sc[1] = c;
-    double* vv = g + LinDumpG_v + 6 * i; double* aa = g + LinDumpG_a + 6 * i;
+    double* blk = (double*)__builtin_assume_aligned(g + ldg_v(i), 16);
+    const int slot = i == 11 ? 0 : (i >= 12 ? 48 + 8 * (i - (side ? 16 : 12)) : 8 + 8 * (i - (side ? 6 : 1)));
+    double U[7];
 #pragma unroll
-    for (int k = 0; k < 6; ++k) { vv[k] = v[k]; aa[k] = a[k]; }
+    for (int k = 0; k < 7; ++k) U[k] = i == 0 ? 0.0 : (*L)[(i == 0 ? 0 : slot) + k];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) { blk[k] = v[k]; blk[6 + k] = a[k]; blk[12 + k] = U[k]; }
+    blk[18] = U[6]; blk[19] = s; blk[20] = c; blk[21] = 0.0;
   }
 };
 __global__ void __launch_bounds__(64) k_lin_primal_s(DevState S, ProblemDev P, int mode, const int* list, const int* count) {
@@ -360,7 +366,7 @@ __global__ void __launch_bounds__(64) k_lin_primal_s(DevState S, ProblemDev P, i
 #pragma unroll
   for (int k = 0; k < 4; ++k) tau.tA[k] = h1s::clampu(u.uA[k], h1s::C_CTRLRANGE[h1s::jarm(side, k)]) - h1s::DAMPING * h.q.qdA[k];
   double* g = (double*)__builtin_assume_aligned(S.lin_dump + ((size_t)b * S.N + t) * LinDumpG_SIZE, 16);     // (even record size, hipMalloc'ed base)
-  DumpSinkS all{g};
+  DumpSinkS all{g, &L, side};
   // pelvis and torso are computed on both lanes: only the left one stores them
   auto sink = [&](int i, const double* v, const double* a, double s, double c) { if (!side || (i != 0 && i != 11)) all(i, v, a, s, c); };
   double qb[6], inv36[36], aL[3]; h1s::HalfAcc qa;
@@ -371,31 +377,15 @@ __global__ void __launch_bounds__(64) k_lin_primal_s(DevState S, ProblemDev P, i
 #pragma unroll
     for (int k = 0; k < 3; ++k) g[LinDumpG_aL + k] = aL[k];
 #pragma unroll
-    for (int k = 0; k < 6; ++k) { g[LinDumpG_qacc + k] = qb[k]; g[LinDumpG_U + k] = 0.0; }
-    g[LinDumpG_Dinv] = 0.0;
+    for (int k = 0; k < 6; ++k) g[LinDumpG_qacc + k] = qb[k];
     g[LinDumpG_qacc + 6 + 10] = qa.q11;
 #pragma unroll
     for (int k = 0; k < 36; ++k) g[LinDumpG_IA0inv + k] = inv36[k];
-#pragma unroll
-    for (int k = 0; k < 6; ++k) g[LinDumpG_U + 6 * 11 + k] = L[k];
-    g[LinDumpG_Dinv + 11] = L[6];
   }
 #pragma unroll
-  for (int K = 0; K < 5; ++K) {
-    const int i = (side ? 6 : 1) + K;             // body of leg hinge K on this side
-    g[LinDumpG_qacc + 6 + i - 1] = qa.qL[K];
+  for (int K = 0; K < 5; ++K) g[LinDumpG_qacc + 6 + (side ? 6 : 1) + K - 1] = qa.qL[K];      // body of leg hinge K on this side: (side ? 6 : 1) + K
 #pragma unroll
-    for (int k = 0; k < 6; ++k) g[LinDumpG_U + 6 * i + k] = L[8 + 8 * K + k];
-    g[LinDumpG_Dinv + i] = L[8 + 8 * K + 6];
-  }
-#pragma unroll
-  for (int K = 0; K < 4; ++K) {
-    const int i = (side ? 16 : 12) + K;
-    g[LinDumpG_qacc + 6 + i - 1] = qa.qA[K];
-#pragma unroll
-    for (int k = 0; k < 6; ++k) g[LinDumpG_U + 6 * i + k] = L[48 + 8 * K + k];
-    g[LinDumpG_Dinv + i] = L[48 + 8 * K + 6];
-  }
+  for (int K = 0; K < 4; ++K) g[LinDumpG_qacc + 6 + (side ? 16 : 12) + K - 1] = qa.qA[K];
 }
 __global__ void __launch_bounds__(64) k_count_iter(DevState S, int mode) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;

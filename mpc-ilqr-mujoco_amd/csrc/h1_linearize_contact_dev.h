@@ -144,14 +144,14 @@ DEVFN bool lin_load_dump2c(LinShared& L, LinContact& Cc, const double* g, int ti
   const double al = g[LinDumpG_aL + (tid < 3 ? tid : 0)];
   const double qa = g[LinDumpG_qacc + (tid < H1_NV ? tid : 0)];
   const int ev = tid < H1_NB * 6 ? tid : 0;
-  const double vv = g[LinDumpG_v + ev], uu = g[LinDumpG_U + ev], aa = g[LinDumpG_a + ev];
-  const double di = g[LinDumpG_Dinv + (tid < H1_NB ? tid : 0)];
+  const double vv = g[ldg_v_lin(ev)], uu = g[ldg_U_lin(ev)], aa = g[ldg_a_lin(ev)];
+  const double di = g[ldg_Dinv(tid < H1_NB ? tid : 0)];
   const double ia = g[LinDumpG_IA0inv + (tid < 36 ? tid : 0)];
   const int i0 = (lane >= 1 && lane < H1_NB) ? lane : 1, i1 = lane < H1_NB ? lane : 0;
-  const double s = g[LinDumpG_sc + 2 * i0], c = g[LinDumpG_sc + 2 * i0 + 1];
+  const double s = g[ldg_s(i0)], c = g[ldg_c(i0)];
   double v6[6];
 #pragma unroll
-  for (int k = 0; k < 6; ++k) v6[k] = g[LinDumpG_v + 6 * i1 + k];
+  for (int k = 0; k < 6; ++k) v6[k] = g[ldg_v(i1, k)];
   const double xu = (tid < 64) ? xg[tid < H1_NX ? tid : 0] : ug[(tid - 64) < H1_NU ? tid - 64 : 0];
   if (!(f1 && f2)) return false;
   if (tid < H1_NX) L.x[tid] = xu;

@@ -25,8 +25,21 @@ namespace h1 {
 // instructions of a kernel that spends 78 % of its cycles stalled on store issue (round 4; the record was 493 doubles with odd offsets).
 // (Measured and not kept: 16 knots interleaved per line as for the cost quadratics' record -- the primal kernel halves, 304 -> 143 us,
 // but the tangent kernels' load turns into a 493-line gather per knot: 1.53 -> 1.82 ms.)
-enum { LinDumpG_R0 = 0, LinDumpG_aL = 10, LinDumpG_qacc = 14, LinDumpG_sc = 40, LinDumpG_v = 80, LinDumpG_a = 200,
-       LinDumpG_U = 320, LinDumpG_Dinv = 440, LinDumpG_IA0inv = 460, LinDumpG_SIZE = 496 };
+// (round 4, second layout) everything of one body in one 176-byte block -- velocity, acceleration, U_i, 1 / D_i, sin, cos -- written by
+// its lane in ONE burst of 16-byte stores when the outward sweep reaches the body: the block's lines complete while they are still in L2
+// and leave as full lines (with the fields in arrays of their own every line was touched by up to 20 stores spread over the whole kernel,
+// and left L2 partially written: 2.2 x write amplification).  Readers go through the accessors below.
+enum { LinDumpG_R0 = 0, LinDumpG_aL = 10, LinDumpG_qacc = 14, LinDumpG_IA0inv = 40, LinDumpG_BODY = 76, LinDumpG_STRIDE = 22, LinDumpG_SIZE = 516 };
+DEVFN constexpr int ldg_v(int i, int k = 0) { return LinDumpG_BODY + LinDumpG_STRIDE * i + k; }
+DEVFN constexpr int ldg_a(int i, int k = 0) { return LinDumpG_BODY + LinDumpG_STRIDE * i + 6 + k; }
+DEVFN constexpr int ldg_U(int i, int k = 0) { return LinDumpG_BODY + LinDumpG_STRIDE * i + 12 + k; }
+DEVFN constexpr int ldg_Dinv(int i) { return LinDumpG_BODY + LinDumpG_STRIDE * i + 18; }
+DEVFN constexpr int ldg_s(int i) { return LinDumpG_BODY + LinDumpG_STRIDE * i + 19; }
+DEVFN constexpr int ldg_c(int i) { return LinDumpG_BODY + LinDumpG_STRIDE * i + 20; }
+// e = 6 i + k
+DEVFN int ldg_v_lin(int e) { return ldg_v(e / 6, e % 6); }
+DEVFN int ldg_a_lin(int e) { return ldg_a(e / 6, e % 6); }
+DEVFN int ldg_U_lin(int e) { return ldg_U(e / 6, e % 6); }
 
 #define LIN_NDIR 47   // tangent directions: phi(3) theta(19) v_lin(3) omega(3) thetadot(19)
 #define LIN_LD 48     // padded lane stride of the direction arrays
@@ -516,25 +529,25 @@ DEVFN void lin_load_dump(LinShared& L, const double* g, int lane) {
   for (int e = lane; e < 9; e += 64) D.R0[e] = g[LinDumpG_R0 + e];
   for (int e = lane; e < 3; e += 64) D.aL[e] = g[LinDumpG_aL + e];
   for (int e = lane; e < H1_NV; e += 64) D.qacc[e] = g[LinDumpG_qacc + e];
-  for (int e = lane; e < H1_NB * 6; e += 64) { (&D.v[0][0])[e] = g[LinDumpG_v + e]; (&L.u.m.U[0][0])[e] = g[LinDumpG_U + e]; }
-  for (int e = lane; e < H1_NB; e += 64) L.u.m.Dinv[e] = g[LinDumpG_Dinv + e];
+  for (int e = lane; e < H1_NB * 6; e += 64) { (&D.v[0][0])[e] = g[ldg_v_lin(e)]; (&L.u.m.U[0][0])[e] = g[ldg_U_lin(e)]; }
+  for (int e = lane; e < H1_NB; e += 64) L.u.m.Dinv[e] = g[ldg_Dinv(e)];
   for (int e = lane; e < 36; e += 64) L.u.m.IA0inv[e] = g[LinDumpG_IA0inv + e];
   if (lane >= 1 && lane < H1_NB) {
     const int i = lane, a = H1_AXIS[i], b = (a + 1) % 3, d = (a + 2) % 3;
-    const double s = g[LinDumpG_sc + 2 * i], c = g[LinDumpG_sc + 2 * i + 1];
+    const double s = g[ldg_s(i)], c = g[ldg_c(i)];
     for (int r = 0; r < 3; ++r) {
       const double fa = H1_RFIX[i][r][a], fb = H1_RFIX[i][r][b], fd = H1_RFIX[i][r][d];
       D.Rj[i][3 * r + a] = fa; D.Rj[i][3 * r + b] = fb * c + fd * s; D.Rj[i][3 * r + d] = fd * c - fb * s;
     }
     double ap[6], xa[6];
-    for (int k = 0; k < 6; ++k) ap[k] = g[LinDumpG_a + 6 * H1_PARENT[i] + k];
+    for (int k = 0; k < 6; ++k) ap[k] = g[ldg_a(H1_PARENT[i], k)];
     xf_motion(D.Rj[i], H1_POS[i], ap, xa);
     for (int k = 0; k < 6; ++k) L.xa[i][k] = xa[k];
   }
   if (lane < H1_NB) {
     const int i = lane;
     double v[6], a[6], Iv[6], Ia[6], vIv[6];
-    for (int k = 0; k < 6; ++k) { v[k] = g[LinDumpG_v + 6 * i + k]; a[k] = g[LinDumpG_a + 6 * i + k]; }
+    for (int k = 0; k < 6; ++k) { v[k] = g[ldg_v(i, k)]; a[k] = g[ldg_a(i, k)]; }
     inertia_mul(i, v, Iv); inertia_mul(i, a, Ia); crf(v, Iv, vIv);
     for (int k = 0; k < 6; ++k) { D.F[i][k] = Ia[k] + vIv[k]; L.Iv[i][k] = Iv[k]; }
   }
@@ -583,18 +596,18 @@ DEVFN bool lin_load_dump2(LinShared& L, const double* g, int tid, const double* 
   const double al = g[LinDumpG_aL + (tid < 3 ? tid : 0)];
   const double qa = g[LinDumpG_qacc + (tid < H1_NV ? tid : 0)];
   const int ev = tid < H1_NB * 6 ? tid : 0;
-  const double vv = g[LinDumpG_v + ev], uu = g[LinDumpG_U + ev];
-  const double di = g[LinDumpG_Dinv + (tid < H1_NB ? tid : 0)];
+  const double vv = g[ldg_v_lin(ev)], uu = g[ldg_U_lin(ev)];
+  const double di = g[ldg_Dinv(tid < H1_NB ? tid : 0)];
   const double ia = g[LinDumpG_IA0inv + (tid < 36 ? tid : 0)];
   // wave 0, lanes 1..19: sin / cos of the body's joint and the parent's acceleration; wave 1, lanes 0..19: the body's v and a
   const int i0 = (lane >= 1 && lane < H1_NB) ? lane : 1, i1 = lane < H1_NB ? lane : 0;
   const int ib = wv == 0 ? i0 : i1;
   const int par0 = (i0 == 1 || i0 == 6 || i0 == 11) ? 0 : ((i0 == 12 || i0 == 16) ? 11 : i0 - 1);     // H1_PARENT without the table's round trip
-  const double* p6 = g + (wv == 0 ? LinDumpG_a + 6 * par0 : LinDumpG_v + 6 * i1);
+  const double* p6 = g + (wv == 0 ? ldg_a(par0) : ldg_v(i1));
   double w6[6], a6[6];
 #pragma unroll
-  for (int k = 0; k < 6; ++k) { w6[k] = p6[k]; a6[k] = g[LinDumpG_a + 6 * ib + k]; }
-  const double s = g[LinDumpG_sc + 2 * i0], c = g[LinDumpG_sc + 2 * i0 + 1];
+  for (int k = 0; k < 6; ++k) { w6[k] = p6[k]; a6[k] = g[ldg_a(ib, k)]; }
+  const double s = g[ldg_s(i0)], c = g[ldg_c(i0)];
   double xu = 0.0;
   if (xg) xu = (tid < 64) ? xg[tid < H1_NX ? tid : 0] : ug[(tid - 64) < H1_NU ? tid - 64 : 0];
   if (!(f1 && f2)) return false;
@@ -793,8 +806,8 @@ DEVFN void lin2_load_dump(LinShared* L2, const double* g0, const double* g1, int
   const double al = g[LinDumpG_aL + (t7 < 3 ? t7 : 0)];
   const double qa = g[LinDumpG_qacc + (t7 < H1_NV ? t7 : 0)];
   const int ev = t7 < H1_NB * 6 ? t7 : 0;
-  const double vv = g[LinDumpG_v + ev], uu = g[LinDumpG_U + ev];
-  const double di = g[LinDumpG_Dinv + (t7 < H1_NB ? t7 : 0)];
+  const double vv = g[ldg_v_lin(ev)], uu = g[ldg_U_lin(ev)];
+  const double di = g[ldg_Dinv(t7 < H1_NB ? t7 : 0)];
   const double ia = g[LinDumpG_IA0inv + (t7 < 36 ? t7 : 0)];
   const double* xg = ks ? xg1 : xg0; const double* ug = ks ? ug1 : ug0;
   const double xu = (t7 < 64) ? xg[t7 < H1_NX ? t7 : 0] : ug[(t7 - 64) < H1_NU ? t7 - 64 : 0];
@@ -806,10 +819,10 @@ DEVFN void lin2_load_dump(LinShared* L2, const double* g0, const double* g1, int
   const int par0 = (i0 == 1 || i0 == 6 || i0 == 11) ? 0 : ((i0 == 12 || i0 == 16) ? 11 : i0 - 1);
   double w6[6], a6[6], s = 0.0, c = 0.0;
   if (wv < 2) {
-    const double* p6 = gr + (wv == 0 ? LinDumpG_a + 6 * par0 : LinDumpG_v + 6 * i1);
+    const double* p6 = gr + (wv == 0 ? ldg_a(par0) : ldg_v(i1));
 #pragma unroll
-    for (int k = 0; k < 6; ++k) { w6[k] = p6[k]; a6[k] = gr[LinDumpG_a + 6 * ib + k]; }
-    s = gr[LinDumpG_sc + 2 * i0]; c = gr[LinDumpG_sc + 2 * i0 + 1];
+    for (int k = 0; k < 6; ++k) { w6[k] = p6[k]; a6[k] = gr[ldg_a(ib, k)]; }
+    s = gr[ldg_s(i0)]; c = gr[ldg_c(i0)];
   }
   if (t7 < H1_NX) L.x[t7] = xu;
   if (t7 >= 64 && t7 < 64 + H1_NU) L.u_[t7 - 64] = xu;
