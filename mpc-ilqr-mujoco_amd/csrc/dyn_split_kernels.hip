@@ -323,39 +323,75 @@ __global__ void __launch_bounds__(64) k_rollout_s(DevState S, ProblemDev P, int 
 // ---- primal dump of the analytic linearisation on two lanes per knot (replaces k_lin_primal_r, dyn_kernels.hip, wherever the
 // two-lane kernels run): forward dynamics of the nominal knot, every body's velocity / acceleration / sin, cos / U / 1/D, the base
 // rotation, the joint accelerations and the inverse of the pelvis' articulated inertia -> LinDumpG (h1_linearize_dev.h)
-// One body's whole block in one burst (see LinDumpG): U_i, 1 / D_i come from this lane's LDS slots, where the inward sweeps left them
-// before the outward sweep calls the sink (torso: slot block 0, leg hinge K: 8 + 8 K, arm hinge K: 48 + 8 K; the pelvis has none).
+// Transposing store of the primal dump.  A lane owns a knot's side, so a plain store instruction puts 64 pieces of 64 different records
+// on the CU's store path (3200 lone waves: 0.28 ms, bound by exactly that).  Every lane parks 22 doubles and the offset of their home
+// in the dump in its row of a staging area in LDS; the wave then writes the 64 rows out with consecutive lanes on consecutive doubles of
+// ONE row: eleven coalesced 16-byte store instructions instead of eleven scattered ones.  The staging area (13 KB per wave) brings the kernel from four
+// to three waves per CU -- each of them several times shorter.  Every lane of the wave must call flush() at the same program point.
+#define DUMP_STG_LD 26      // row pitch in doubles: 11 chunks of 16 bytes + the offset word; 52 dwords -> 16-byte accesses of 16 lanes hit 64 distinct banks
+#define DUMP_STG_BYTES (64 * DUMP_STG_LD * sizeof(double))
+struct DumpStage {
+  double* stg; double* dump; int lane;
+  DEVFN void flush(const double* vals, long off) const {      // off < 0: nothing of this lane's is written
+    typedef double v2d_t __attribute__((ext_vector_type(2)));
+    v2d_t* my = reinterpret_cast<v2d_t*>(stg + lane * DUMP_STG_LD);
+#pragma unroll
+    for (int c = 0; c < 11; ++c) { v2d_t w; w.x = vals[2 * c]; w.y = vals[2 * c + 1]; my[c] = w; }
+    stg[lane * DUMP_STG_LD + 22] = __longlong_as_double(off);
+    // (one wave per workgroup, LDS operations of a wave execute in order: the reads below see the rows, the next flush's writes come
+    // after these reads -- only the compiler has to be kept from moving them across)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    // chunk e = 64 r + lane of the 64 x 11 chunks: row e / 11, chunk e % 11 (advanced by 64 = 5 x 11 + 9 per instruction)
+    int src = lane / 11, c = lane - 11 * (lane / 11);
+#pragma unroll
+    for (int r = 0; r < 11; ++r) {
+      const double* row = stg + src * DUMP_STG_LD;
+      const v2d_t x = reinterpret_cast<const v2d_t*>(row)[c];
+      const long o = __double_as_longlong(row[22]);
+      if (o >= 0) *reinterpret_cast<v2d_t*>(dump + o + 2 * c) = x;
+      c += 9; src += 5;
+      if (c >= 11) { c -= 11; src += 1; }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+  }
+};
+// One body's block (see LinDumpG): U_i, 1 / D_i come from this lane's LDS slots, where the inward sweeps left them before the outward
+// sweep calls the sink (torso: slot block 0, leg hinge K: 8 + 8 K, arm hinge K: 48 + 8 K; the pelvis has none).
 struct DumpSinkS {
-  double* g; const h1s::LaneLds* L; bool side;
+  const DumpStage* st; long rec; const h1s::LaneLds* L; bool side, live;
   DEVFN void operator()(int i, const double* v, const double* a, double s, double c) const {
-    double* blk = (double*)__builtin_assume_aligned(g + ldg_v(i), 16);
     const int slot = i == 11 ? 0 : (i >= 12 ? 48 + 8 * (i - (side ? 16 : 12)) : 8 + 8 * (i - (side ? 6 : 1)));
-    double U[7];
+    double blk[22];
 #pragma unroll
-    for (int k = 0; k < 7; ++k) U[k] = i == 0 ? 0.0 : (*L)[(i == 0 ? 0 : slot) + k];
-#pragma unroll
-    for (int k = 0; k < 6; ++k) { blk[k] = v[k]; blk[6 + k] = a[k]; blk[12 + k] = U[k]; }
-    blk[18] = U[6]; blk[19] = s; blk[20] = c; blk[21] = 0.0;
+    for (int k = 0; k < 6; ++k) { blk[k] = v[k]; blk[6 + k] = a[k]; blk[12 + k] = i == 0 ? 0.0 : (*L)[(i == 0 ? 0 : slot) + k]; }
+    blk[18] = i == 0 ? 0.0 : (*L)[(i == 0 ? 0 : slot) + 6]; blk[19] = s; blk[20] = c; blk[21] = 0.0;
+    // pelvis and torso are computed on both lanes: only the left one stores them
+    const bool write = live && (!side || (i != 0 && i != 11));
+    st->flush(blk, write ? rec + ldg_v(i) : -1L);
   }
 };
 __global__ void __launch_bounds__(64) k_lin_primal_s(DevState S, ProblemDev P, int mode, const int* list, const int* count) {
   extern __shared__ double lds[];
   const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  const long knot = gid >> 1;
+  long knot = gid >> 1;
   const bool side = (gid & 1) != 0;
-  if (knot >= (long)S.B * S.N) return;
+  // (no lane leaves alone: the dump is written cooperatively; lanes without a knot run along on the last one and store nothing)
+  const long total = (long)(list ? *count : S.B) * S.N;
+  bool live = knot < total;
+  if (!__any(live)) return;
+  knot = live ? knot : total - 1;
   const int t = (int)(knot % S.N);
   int b = (int)(knot / S.N);
-  if (list) {                        // compacted selection (DevState::order): position -> rollout
-    if (b >= *count) return;
-    b = list[b];
-    mode = MASK_ALL;
-  }
+  if (list) { b = list[b]; mode = MASK_ALL; }      // compacted selection (DevState::order): position -> rollout
   const int f1 = mode == MASK_ALL ? 1 : S.active[b], f2 = mode == MASK_RETRY ? S.need_retry[b] : 1;   // requested with the knot's data, tested after
   const h1s::LaneLds L{lds, 64, (int)threadIdx.x};
   h1s::HalfX h; h1s::load_half(side, S.xbar + ((size_t)b * (S.N + 1) + t) * H1_NX, h);
   h1s::HalfU u; load_half_u(side, S.ubar + ((size_t)b * S.N + t) * H1_NU, u);
-  if (!(f1 && f2)) return;
+  live = live && f1 && f2;
+  if (!__any(live)) return;
   const double dt = P.dyn.h;
   const double qn = sqrt(h.quat[0] * h.quat[0] + h.quat[1] * h.quat[1] + h.quat[2] * h.quat[2] + h.quat[3] * h.quat[3]);
   double R0[9]; h1s::quat_R(h.quat[0] / qn, h.quat[1] / qn, h.quat[2] / qn, h.quat[3] / qn, R0);
@@ -365,27 +401,28 @@ __global__ void __launch_bounds__(64) k_lin_primal_s(DevState S, ProblemDev P, i
   for (int k = 0; k < 5; ++k) tau.tL[k] = h1s::clampu(u.uL[k], h1s::C_CTRLRANGE[h1s::jleg(side, k)]) - h1s::DAMPING * h.q.qdL[k];
 #pragma unroll
   for (int k = 0; k < 4; ++k) tau.tA[k] = h1s::clampu(u.uA[k], h1s::C_CTRLRANGE[h1s::jarm(side, k)]) - h1s::DAMPING * h.q.qdA[k];
-  double* g = (double*)__builtin_assume_aligned(S.lin_dump + ((size_t)b * S.N + t) * LinDumpG_SIZE, 16);     // (even record size, hipMalloc'ed base)
-  DumpSinkS all{g, &L, side};
-  // pelvis and torso are computed on both lanes: only the left one stores them
-  auto sink = [&](int i, const double* v, const double* a, double s, double c) { if (!side || (i != 0 && i != 11)) all(i, v, a, s, c); };
+  const long rec = (long)(((size_t)b * S.N + t) * LinDumpG_SIZE);
+  const DumpStage stage{lds + h1s::LDS_SLOTS * 64, S.lin_dump, (int)threadIdx.x};
+  const DumpSinkS sink{&stage, rec, &L, side, live};
   double qb[6], inv36[36], aL[3]; h1s::HalfAcc qa;
   h1s::forward_dynamics_dump(side, R0, h.vb, h.q, tau, h1s::ARMATURE + dt * h1s::DAMPING, P.dyn.g, L, qb, qa, sink, inv36, aL);
-  if (!side) {
+  // the record's header, all of it from the left lane (the right lane's hinge accelerations cross over): four chunks of 22, the last
+  // two overlapping (same values) so that nothing beyond the 76 doubles is touched
+  double qLr[5], qAr[4];
 #pragma unroll
-    for (int k = 0; k < 9; ++k) g[LinDumpG_R0 + k] = R0[k];
+  for (int k = 0; k < 5; ++k) qLr[k] = h1s::xch(qa.qL[k]);
 #pragma unroll
-    for (int k = 0; k < 3; ++k) g[LinDumpG_aL + k] = aL[k];
-#pragma unroll
-    for (int k = 0; k < 6; ++k) g[LinDumpG_qacc + k] = qb[k];
-    g[LinDumpG_qacc + 6 + 10] = qa.q11;
-#pragma unroll
-    for (int k = 0; k < 36; ++k) g[LinDumpG_IA0inv + k] = inv36[k];
+  for (int k = 0; k < 4; ++k) qAr[k] = h1s::xch(qa.qA[k]);
+  const bool wh = live && !side;
+  {
+    const double c0[22] = {R0[0], R0[1], R0[2], R0[3], R0[4], R0[5], R0[6], R0[7], R0[8], 0.0, aL[0], aL[1], aL[2], 0.0, qb[0], qb[1], qb[2], qb[3], qb[4], qb[5], qa.qL[0], qa.qL[1]};
+    stage.flush(c0, wh ? rec + 0 : -1L);
+    const double c1[22] = {qa.qL[2], qa.qL[3], qa.qL[4], qLr[0], qLr[1], qLr[2], qLr[3], qLr[4], qa.q11, qa.qA[0], qa.qA[1], qa.qA[2], qa.qA[3], qAr[0], qAr[1], qAr[2], qAr[3], 0.0,
+                           inv36[0], inv36[1], inv36[2], inv36[3]};
+    stage.flush(c1, wh ? rec + 22 : -1L);
+    stage.flush(inv36 + 4, wh ? rec + 44 : -1L);
+    stage.flush(inv36 + 14, wh ? rec + 54 : -1L);
   }
-#pragma unroll
-  for (int K = 0; K < 5; ++K) g[LinDumpG_qacc + 6 + (side ? 6 : 1) + K - 1] = qa.qL[K];      // body of leg hinge K on this side: (side ? 6 : 1) + K
-#pragma unroll
-  for (int K = 0; K < 4; ++K) g[LinDumpG_qacc + 6 + (side ? 16 : 12) + K - 1] = qa.qA[K];
 }
 __global__ void __launch_bounds__(64) k_count_iter(DevState S, int mode) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -502,7 +539,7 @@ int dyn_split_kernels_set_attr() {
   rc |= hipFuncSetAttribute((const void*)k_rollout_s<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DYN_LDS_BYTES_S) != hipSuccess;
   rc |= hipFuncSetAttribute((const void*)k_rollout_s<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DYN_LDS_BYTES_S) != hipSuccess;
   rc |= hipFuncSetAttribute((const void*)k_step_s, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DYN_LDS_BYTES_S) != hipSuccess;
-  rc |= hipFuncSetAttribute((const void*)k_lin_primal_s, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DYN_LDS_BYTES_S) != hipSuccess;
+  rc |= hipFuncSetAttribute((const void*)k_lin_primal_s, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(DYN_LDS_BYTES_S + DUMP_STG_BYTES)) != hipSuccess;
   rc |= hipFuncSetAttribute((const void*)k_last_step_s, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DYN_LDS_BYTES_S) != hipSuccess;
   rc |= hipFuncSetAttribute((const void*)k_fd_steps_s, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DYN_LDS_BYTES_S) != hipSuccess;
   return rc;
@@ -525,7 +562,7 @@ void launch_line_search_s(const DevState& S, const ProblemDev& P, int mode, hipS
   else hipLaunchKernelGGL((k_line_search_s<false, 4>), dim3(cdiv_s((long)S.B * 16, 64)), dim3(64), DYN_LDS_BYTES_S, st, S, P, mode, list, count);
 }
 void launch_lin_primal_s(const DevState& S, const ProblemDev& P, int mode, hipStream_t st, const int* list, const int* count) {
-  hipLaunchKernelGGL(k_lin_primal_s, dim3(cdiv_s((long)S.B * S.N * 2, 64)), dim3(64), DYN_LDS_BYTES_S, st, S, P, mode, list, count);
+  hipLaunchKernelGGL(k_lin_primal_s, dim3(cdiv_s((long)S.B * S.N * 2, 64)), dim3(64), DYN_LDS_BYTES_S + DUMP_STG_BYTES, st, S, P, mode, list, count);
 }
 void launch_step_s(int count, const double* x, const double* u, const DynParams& dyn, double* xn, hipStream_t st, int stance_l, int stance_r) {
   hipLaunchKernelGGL(k_step_s, dim3(cdiv_s((long)count * 2, 64)), dim3(64), DYN_LDS_BYTES_S, st, count, x, u, dyn, xn, stance_l, stance_r);
