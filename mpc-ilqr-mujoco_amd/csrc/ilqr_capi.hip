@@ -83,7 +83,7 @@ struct ilqr_hip_ctx {
   int n_slices = 1;
   // speculative lambda retry (ilqr_kernels.hip k_control_spec): the twin view's own buffers, allocated by the first solve that can use them
   DevState T{};
-  bool twin = false;
+  bool twin = false, twin_failed = false;
   hipEvent_t ev_spec_fork = nullptr, ev_spec_join = nullptr;
   int spec_iterations = 0;    // iterations of the last solve that enqueued both passes side by side
   int* d_spec_gate = nullptr; // [4] device-side choice of the order (launch_spec_gate)
@@ -466,8 +466,19 @@ static int split_enabled(const ilqr_hip_ctx* c) { const char* e = getenv("ILQR_S
 static int spec_enabled() { const char* e = getenv("ILQR_SPEC"); return e ? atoi(e) : 1; }
 static int spec_dual() { const char* e = getenv("ILQR_SPEC_DUAL"); return e ? atoi(e) : 1; }
 static int spec_max() { const char* e = getenv("ILQR_SPEC_MAX"); return e ? atoi(e) : 512; }
+static int alloc_twin(ilqr_hip_ctx* c);
+// (the side-by-side order is an optimisation: a handle that cannot get the memory keeps the sequential order instead of failing the solve)
 static int ensure_twin(ilqr_hip_ctx* c) {
-  if (c->twin) return ILQR_OK;
+  if (c->twin || c->twin_failed) return ILQR_OK;
+  if (alloc_twin(c) != ILQR_OK) {
+    void* tw[] = {c->T.K, c->T.kff, c->T.Vx, c->T.Vxx, c->T.xcand, c->T.ucand, c->T.cand_cost, c->T.cand_knot, c->T.lambda, c->d_spec_gate};
+    for (void* p : tw) if (p) (void)hipFree(p);
+    c->T = DevState{}; c->d_spec_gate = nullptr; c->twin = false; c->twin_failed = true;
+    (void)hipGetLastError();
+  }
+  return ILQR_OK;
+}
+static int alloc_twin(ilqr_hip_ctx* c) {
   const size_t B = c->B, N = c->N, n = ILQR_NX, m = ILQR_NU;
   DevState& T = c->T;
   T = c->S;
