@@ -1,3 +1,4 @@
+"""One line per bench JSON: python tools/bench_line.py <file with the JSON line> -- value, ms per step, the early-exit and contact objects."""
 import json, sys
 d = json.loads([l for l in open(sys.argv[1]) if l.startswith("{")][-1])
 ee = d.get("early_exit") or {}

@@ -1,3 +1,4 @@
+"""Per-kernel table of a rocprofv3 --kernel-trace --stats CSV: python tools/kernel_stats_table.py <..._kernel_stats.csv>"""
 import csv, sys
 for r in csv.DictReader(open(sys.argv[1])):
     n = r["Name"].split("(")[0].replace("ilqr::", "").replace("void ", "")

@@ -1,3 +1,4 @@
+"""Largest per-launch value of every counter of a rocprofv3 --pmc CSV, per kernel: python tools/pmc_counter_table.py <..._counter_collection.csv>"""
 import csv, sys, collections
 acc = collections.defaultdict(list)
 for r in csv.DictReader(open(sys.argv[1])):
