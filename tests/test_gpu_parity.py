@@ -678,6 +678,38 @@ def test_closed_loop_standing_under_physical_gravity_needs_the_contact_row(tmp_p
     s.close()
 
 
+def test_closed_loop_with_the_coulomb_limit_stands_on_grip_and_slides_on_ice(tmp_path):
+    """Contact mode 3 in the closed loop (plant and solver on the friction-limited stance row, the reference's forward-difference
+    Jacobians).  A robot standing still under physical gravity loads its feet almost along the normal: with MuJoCo's default friction
+    the plant's feet stay where they are, as in the unilateral mode.  Pushed sideways at 0.6 m/s, the rigid rows of mode 2 hold the
+    feet whatever it takes (infinite friction); on mu = 0.02 the same push makes them slide -- along the floor: the normal row still
+    holds them down.  (tools/probes/friction_loop_probe.py prints the figures.)"""
+    from mpc_ilqr_mujoco_amd import mpc_loop as ml
+    from mpc_ilqr_mujoco_amd import references as rf
+    from mpc_ilqr_mujoco_amd import solver as sv
+    B, N = 2, 25
+    base = sc.make_problem(sv.reference_kinematics, N=N, gravity=(0.0, 0.0, -9.81))
+    rd = rf.ReferenceData(sv.reference_kinematics, sv.reference_com_velocity)
+    rd.set_states(np.tile(sc.standing_state(), (60, 1))); rd.contact = np.ones((60, 2), dtype=np.int32)
+    ug = sv.gravity_compensation(sc.standing_state(), base["gravity"])
+    x_still = np.tile(sc.standing_state(), (B, 1)); u_still = np.tile(ug, (B, N, 1))
+    out = {}
+    for mode, mu, push in ((2, 1.0, 0.0), (3, 1.0, 0.0), (2, 1.0, 0.6), (3, 0.02, 0.6)):
+        s = _solver(B); s.set_max_iterations(3); s.set_contact_mode(mode); s.set_friction(mu); s.set_options(jacobian_mode=1, fd_eps=1e-5)
+        xp = x_still.copy(); xp[:, 27] += push                                  # a sideways velocity of the pelvis
+        xs, us = ml.MPCRunner(s, rd, base).run(xp, 6, u_init=u_still)
+        assert np.all(np.isfinite(xs)) and np.all(np.isfinite(us))
+        ee0 = sv.reference_kinematics(xs[0, 0])[1]; ee1 = sv.reference_kinematics(xs[-1, 0])[1]
+        out[(mode, push)] = (xs, np.abs(ee1[:, :2] - ee0[:, :2]).max(), np.abs(ee1[:, 2] - ee0[:, 2]).max())
+        s.close()
+    # standing still the plant's feet carry f_t / f_n = 0.06: no foot slides, in either mode (the solver's line-search candidates do
+    # leave the cone, so the two closed loops are not the same trajectory)
+    for m in (2, 3):
+        assert out[(m, 0.0)][0][:, :, 2].min() > 0.97 and out[(m, 0.0)][1] < 5e-3 and out[(m, 0.0)][2] < 5e-3, (m, out[(m, 0.0)][1:])
+    assert out[(2, 0.6)][1] < 5e-3                                                               # rigid rows: the push does not move the feet
+    assert out[(3, 0.6)][1] > 2e-2 and out[(3, 0.6)][2] < 3e-2, out[(3, 0.6)][1:]                # ice: they slide, along the floor
+
+
 def test_launch_orchestration_variants_are_bitwise_equivalent():
     """The solve may be enqueued as contiguous batch slices on separate streams (ILQR_SLICES) and the nominal re-rollout
     of iterations >= 1 may run beside the linearisation into a shadow buffer (ILQR_OVERLAP_ROLLOUT): the kernels and the
