@@ -183,8 +183,13 @@ int ilqr_hip_step(ilqr_hip_ctx* ctx, int count, const double* x /*[count][51]*/,
    its two tangential translation rows are dropped (rotation and normal rows stay, no tangential force on a sliding foot) and
    the set is solved again, once.  mu: ilqr_hip_set_friction (default 1, MuJoCo's default sliding friction; the reference's
    robots/h1_description/mjcf model sets none).  Jacobians in this mode: ILQR_JAC_FD_FORWARD only (the reference's own scheme);
-   a solve / stage_linearize with ILQR_JAC_ANALYTIC returns ILQR_ERR_UNSUPPORTED. */
-enum ilqr_contact_mode { ILQR_CONTACT_NONE = 0, ILQR_CONTACT_RIGID_STANCE = 1, ILQR_CONTACT_UNILATERAL_STANCE = 2, ILQR_CONTACT_FRICTION_STANCE = 3 };
+   a solve / stage_linearize with ILQR_JAC_ANALYTIC returns ILQR_ERR_UNSUPPORTED.
+   ILQR_CONTACT_KINETIC_FRICTION_STANCE: the same decision, but the sliding foot keeps kinetic friction: a tangential force mu f_n along
+   the direction in which the sticking solution pulled (the one that opposes the slip); its normal multiplier then acts along
+   up + mu t while the constraint row stays the normal one -- an unsymmetric 12 x 12 system, Gaussian elimination with partial
+   pivoting for the knots where a foot slides.  Forward-difference Jacobians only, as mode 3. */
+enum ilqr_contact_mode { ILQR_CONTACT_NONE = 0, ILQR_CONTACT_RIGID_STANCE = 1, ILQR_CONTACT_UNILATERAL_STANCE = 2, ILQR_CONTACT_FRICTION_STANCE = 3,
+                         ILQR_CONTACT_KINETIC_FRICTION_STANCE = 4 };
 int ilqr_hip_set_contact_mode(ilqr_hip_ctx* ctx, int mode, double softness);
 int ilqr_hip_set_friction(ilqr_hip_ctx* ctx, double mu);
 int ilqr_hip_step_stance(ilqr_hip_ctx* ctx, int count, const double* x, const double* u, int stance_left, int stance_right, double* x_next);

@@ -50,7 +50,19 @@ __device__ __attribute__((noinline)) void step_stance_shared(h1s::HalfX* hp, con
   const double grav[3] = {gx, gy, gz};
   h1s::HalfX h = *hp;
   const h1s::HalfU u = *up;
-  h1s::step_stance(side, h, u, dt, grav, L, soft, mode, (side ? st_right : st_left) == 1, (side ? st_left : st_right) == 1, mu);
+  h1s::step_stance<false>(side, h, u, dt, grav, L, soft, mode, (side ? st_right : st_left) == 1, (side ? st_left : st_right) == 1, mu);
+  *hp = h;
+}
+// the copy with kinetic friction on sliding feet (contact mode 4), see h1s::stance_correct<KIN>
+__device__ __attribute__((noinline)) void step_stance_shared_kin(h1s::HalfX* hp, const h1s::HalfU* up, double dt, double gx, double gy, double gz,
+                                                                 double soft, int st_left, int st_right, double mu) {
+  const int lane = threadIdx.x;
+  const bool side = (lane & 1) != 0;
+  const h1s::LaneLds L{dyn_lds_c, 64, lane};
+  const double grav[3] = {gx, gy, gz};
+  h1s::HalfX h = *hp;
+  const h1s::HalfU u = *up;
+  h1s::step_stance<true>(side, h, u, dt, grav, L, soft, 4, (side ? st_right : st_left) == 1, (side ? st_left : st_right) == 1, mu);
   *hp = h;
 }
 // one step of either kind; `st` = stance flags (left, right) of the knot being stepped
@@ -77,9 +89,13 @@ DEVFN void pin_half_u(h1s::HalfU& u) {
 #pragma unroll
   for (int k = 0; k < 4; ++k) pin(u.uA[k]);
 }
-template <bool CONTACT>
+// CONTACT: 0 constraint-free, 1 stance constraints (contact modes 1-3), 2 stance constraints with kinetic friction on sliding feet (mode 4).
+// Mode 4 has kernels of its own: the private segment of a kernel is the largest frame it can reach, and the constrained kernels lose with
+// every kilobyte of it (1.4 -> 1.8 KB per lane: -0.7 % on the contact bench, -> 4 KB: -4 %, same machine code otherwise).
+template <int CONTACT>
 DEVFN void step_any(bool side, h1s::HalfX& h, const h1s::HalfU& u, const DynParams& dyn, const int* st, const h1s::LaneLds& L) {
-  if constexpr (CONTACT) step_stance_shared(&h, &u, dyn.h, dyn.g[0], dyn.g[1], dyn.g[2], dyn.soft, dyn.contact, st[0], st[1], dyn.mu);
+  if constexpr (CONTACT == 2) step_stance_shared_kin(&h, &u, dyn.h, dyn.g[0], dyn.g[1], dyn.g[2], dyn.soft, st[0], st[1], dyn.mu);
+  else if constexpr (CONTACT == 1) step_stance_shared(&h, &u, dyn.h, dyn.g[0], dyn.g[1], dyn.g[2], dyn.soft, dyn.contact, st[0], st[1], dyn.mu);
   else {
     // (the step size behind an opaque barrier as well: with h a loop invariant the articulated quantities of the chains' leaf
     // bodies -- constants plus the armature term h * damping -- are hoisted out of the knot loop, spilled and reloaded per step)
@@ -110,7 +126,7 @@ DEVFN void load_half_u(bool side, const double* u, h1s::HalfU& o) {
 // would leave SIMDs empty: the wave's lanes 16..63 then mirror lanes 0..15 (same rollout, same candidates, no stores), a step
 // fetches one rollout's K_t and runs one feedback product instead of four, and every rollout has a SIMD to itself.  The per-rollout
 // arithmetic is the same instruction sequence in both: results are bit-identical (batch invariance, GPU tests).
-template <bool CONTACT, int RPW>
+template <int CONTACT, int RPW>
 __global__ void __launch_bounds__(64) k_line_search_s(DevState S, ProblemDev P, int mode, const int* list, const int* count) {
   extern __shared__ double lds[];
   const int gid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -291,7 +307,7 @@ __global__ void __launch_bounds__(64) k_line_search_s(DevState S, ProblemDev P, 
 
 // thread per (rollout, side): nominal rollout
 // (the cost of the trajectory is evaluated afterwards, all knots in parallel: launch_nominal_costs, dyn_kernels.hip)
-template <bool CONTACT>
+template <int CONTACT>
 __global__ void __launch_bounds__(64) k_rollout_s(DevState S, ProblemDev P, int mode, int count_iter) {
   extern __shared__ double lds[];
   const int gid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -439,6 +455,7 @@ __global__ void __launch_bounds__(64) k_count_iter(DevState S, int mode) {
 }
 
 // two lanes per item: plain batched step with explicit stance flags (stage API / plant of the closed loop)
+template <bool KIN>
 __global__ void __launch_bounds__(64) k_step_s(int count, const double* x, const double* u, DynParams dyn, double* xn, int st_l, int st_r) {
   extern __shared__ double lds[];
   const int gid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -449,10 +466,11 @@ __global__ void __launch_bounds__(64) k_step_s(int count, const double* x, const
   h1s::HalfX h; h1s::load_half(side, x + (size_t)i * H1_NX, h);
   h1s::HalfU uu; load_half_u(side, u + (size_t)i * H1_NU, uu);
   const int st[2] = {st_l, st_r};
-  if (dyn.contact) step_any<true>(side, h, uu, dyn, st, L); else step_any<false>(side, h, uu, dyn, st, L);
+  if (dyn.contact) step_any<KIN ? 2 : 1>(side, h, uu, dyn, st, L); else step_any<0>(side, h, uu, dyn, st, L);
   h1s::store_half(side, h, xn + (size_t)i * H1_NX);
 }
 // last knot of the warm start: xbar[N] = f(xbar[N-1], ubar[N-1])  (ilqr.cpp:72-80)
+template <bool KIN>
 __global__ void __launch_bounds__(64) k_last_step_s(DevState S, ProblemDev P) {
   extern __shared__ double lds[];
   const int gid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -463,7 +481,7 @@ __global__ void __launch_bounds__(64) k_last_step_s(DevState S, ProblemDev P) {
   const int N = S.N;
   h1s::HalfX h; h1s::load_half(side, S.xbar + ((size_t)b * (N + 1) + N - 1) * H1_NX, h);
   h1s::HalfU uu; load_half_u(side, S.ubar + ((size_t)b * N + N - 1) * H1_NU, uu);
-  if (P.dyn.contact) step_any<true>(side, h, uu, P.dyn, P.stance + b * P.stance_stride + 2 * (N - 1), L); else step_any<false>(side, h, uu, P.dyn, P.stance + b * P.stance_stride + 2 * (N - 1), L);
+  if (P.dyn.contact) step_any<KIN ? 2 : 1>(side, h, uu, P.dyn, P.stance + b * P.stance_stride + 2 * (N - 1), L); else step_any<0>(side, h, uu, P.dyn, P.stance + b * P.stance_stride + 2 * (N - 1), L);
   h1s::store_half(side, h, S.xbar + ((size_t)b * (N + 1) + N) * H1_NX);
 }
 // Reference-style forward differences (RobotUtils::linearizeDynamicsFD, robot_utils.cpp:120-160) on the two-lane step:
@@ -501,6 +519,7 @@ DEVFN void store_half_col(bool side, const h1s::HalfX& h, double* M, int ld, int
   for (int k = 0; k < 4; ++k) { M[(7 + h1s::jarm(side, k)) * ld + col] = h.q.thA[k]; M[(H1_NQ + 6 + h1s::jarm(side, k)) * ld + col] = h.q.qdA[k]; }
 }
 #define FD_NCOL (H1_NX + H1_NU + 1)
+template <bool KIN>
 __global__ void __launch_bounds__(64) k_fd_steps_s(DevState S, ProblemDev P, int mode, double eps, int dump_doubles) {
   extern __shared__ double lds[];
   const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -517,7 +536,7 @@ __global__ void __launch_bounds__(64) k_fd_steps_s(DevState S, ProblemDev P, int
   h1s::HalfX h; h1s::load_half(side, S.xbar + ((size_t)b * (S.N + 1) + t) * H1_NX, h);
   h1s::HalfU uu; load_half_u(side, S.ubar + ((size_t)b * S.N + t) * H1_NU, uu);
   perturb_half(side, h, uu, col, eps);
-  if (P.dyn.contact) step_any<true>(side, h, uu, P.dyn, P.stance + b * P.stance_stride + 2 * t, L); else step_any<false>(side, h, uu, P.dyn, P.stance + b * P.stance_stride + 2 * t, L);
+  if (P.dyn.contact) step_any<KIN ? 2 : 1>(side, h, uu, P.dyn, P.stance + b * P.stance_stride + 2 * t, L); else step_any<0>(side, h, uu, P.dyn, P.stance + b * P.stance_stride + 2 * t, L);
   if (!act) return;
   if (col < H1_NX) store_half_col(side, h, S.A + (size_t)item * H1_NX * H1_NX, H1_NX, col);
   else if (col < H1_NX + H1_NU) store_half_col(side, h, S.Bm + (size_t)item * H1_NX * H1_NU, H1_NU, col - H1_NX);
@@ -541,16 +560,23 @@ __global__ void __launch_bounds__(256) k_fd_finish(DevState S, int mode, double 
 static inline int cdiv_s(long a, long b) { return (int)((a + b - 1) / b); }
 int dyn_split_kernels_set_attr() {
   int rc = 0;
-  rc |= hipFuncSetAttribute((const void*)k_line_search_s<false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DYN_LDS_BYTES_S) != hipSuccess;
-  rc |= hipFuncSetAttribute((const void*)k_line_search_s<true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DYN_LDS_BYTES_S) != hipSuccess;
-  rc |= hipFuncSetAttribute((const void*)k_line_search_s<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DYN_LDS_BYTES_S) != hipSuccess;
-  rc |= hipFuncSetAttribute((const void*)k_line_search_s<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DYN_LDS_BYTES_S) != hipSuccess;
-  rc |= hipFuncSetAttribute((const void*)k_rollout_s<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DYN_LDS_BYTES_S) != hipSuccess;
-  rc |= hipFuncSetAttribute((const void*)k_rollout_s<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DYN_LDS_BYTES_S) != hipSuccess;
-  rc |= hipFuncSetAttribute((const void*)k_step_s, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DYN_LDS_BYTES_S) != hipSuccess;
+  const int lds = (int)DYN_LDS_BYTES_S;
+  rc |= hipFuncSetAttribute((const void*)k_line_search_s<0, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess;
+  rc |= hipFuncSetAttribute((const void*)k_line_search_s<1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess;
+  rc |= hipFuncSetAttribute((const void*)k_line_search_s<2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess;
+  rc |= hipFuncSetAttribute((const void*)k_line_search_s<0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess;
+  rc |= hipFuncSetAttribute((const void*)k_line_search_s<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess;
+  rc |= hipFuncSetAttribute((const void*)k_line_search_s<2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess;
+  rc |= hipFuncSetAttribute((const void*)k_rollout_s<0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess;
+  rc |= hipFuncSetAttribute((const void*)k_rollout_s<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess;
+  rc |= hipFuncSetAttribute((const void*)k_rollout_s<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess;
+  rc |= hipFuncSetAttribute((const void*)k_step_s<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess;
+  rc |= hipFuncSetAttribute((const void*)k_step_s<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess;
   rc |= hipFuncSetAttribute((const void*)k_lin_primal_s, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(DYN_LDS_BYTES_S + DUMP_STG_BYTES)) != hipSuccess;
-  rc |= hipFuncSetAttribute((const void*)k_last_step_s, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DYN_LDS_BYTES_S) != hipSuccess;
-  rc |= hipFuncSetAttribute((const void*)k_fd_steps_s, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DYN_LDS_BYTES_S) != hipSuccess;
+  rc |= hipFuncSetAttribute((const void*)k_last_step_s<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess;
+  rc |= hipFuncSetAttribute((const void*)k_last_step_s<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess;
+  rc |= hipFuncSetAttribute((const void*)k_fd_steps_s<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess;
+  rc |= hipFuncSetAttribute((const void*)k_fd_steps_s<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess;
   return rc;
 }
 #ifndef LS_RPW1_MAX_BATCH
@@ -563,12 +589,14 @@ void launch_line_search_s(const DevState& S, const ProblemDev& P, int mode, hipS
   const int nsel = (list && max_rollouts >= 0 && max_rollouts < S.B) ? max_rollouts : S.B;
   if (nsel <= LS_RPW1_MAX_BATCH) {
     const int blocks = nsel > 0 ? nsel : 1;
-    if (P.dyn.contact) hipLaunchKernelGGL((k_line_search_s<true, 1>), dim3(blocks), dim3(64), DYN_LDS_BYTES_S, st, S, P, mode, list, count);
-    else hipLaunchKernelGGL((k_line_search_s<false, 1>), dim3(blocks), dim3(64), DYN_LDS_BYTES_S, st, S, P, mode, list, count);
+    if (P.dyn.contact == 4) hipLaunchKernelGGL((k_line_search_s<2, 1>), dim3(blocks), dim3(64), DYN_LDS_BYTES_S, st, S, P, mode, list, count);
+    else if (P.dyn.contact) hipLaunchKernelGGL((k_line_search_s<1, 1>), dim3(blocks), dim3(64), DYN_LDS_BYTES_S, st, S, P, mode, list, count);
+    else hipLaunchKernelGGL((k_line_search_s<0, 1>), dim3(blocks), dim3(64), DYN_LDS_BYTES_S, st, S, P, mode, list, count);
     return;
   }
-  if (P.dyn.contact) hipLaunchKernelGGL((k_line_search_s<true, 4>), dim3(cdiv_s((long)S.B * 16, 64)), dim3(64), DYN_LDS_BYTES_S, st, S, P, mode, list, count);
-  else hipLaunchKernelGGL((k_line_search_s<false, 4>), dim3(cdiv_s((long)S.B * 16, 64)), dim3(64), DYN_LDS_BYTES_S, st, S, P, mode, list, count);
+  if (P.dyn.contact == 4) hipLaunchKernelGGL((k_line_search_s<2, 4>), dim3(cdiv_s((long)S.B * 16, 64)), dim3(64), DYN_LDS_BYTES_S, st, S, P, mode, list, count);
+  else if (P.dyn.contact) hipLaunchKernelGGL((k_line_search_s<1, 4>), dim3(cdiv_s((long)S.B * 16, 64)), dim3(64), DYN_LDS_BYTES_S, st, S, P, mode, list, count);
+  else hipLaunchKernelGGL((k_line_search_s<0, 4>), dim3(cdiv_s((long)S.B * 16, 64)), dim3(64), DYN_LDS_BYTES_S, st, S, P, mode, list, count);
 }
 void launch_lin_primal_s(const DevState& S, const ProblemDev& P, int mode, hipStream_t st, const int* list, const int* count) {
   // up to one wave per SIMD (32 knots per wave): the lanes store their blocks themselves, without the staging area (and its LDS: four waves per CU)
@@ -577,19 +605,23 @@ void launch_lin_primal_s(const DevState& S, const ProblemDev& P, int mode, hipSt
   hipLaunchKernelGGL(k_lin_primal_s, dim3(waves), dim3(64), DYN_LDS_BYTES_S + (direct ? 0 : DUMP_STG_BYTES), st, S, P, mode, list, count, direct);
 }
 void launch_step_s(int count, const double* x, const double* u, const DynParams& dyn, double* xn, hipStream_t st, int stance_l, int stance_r) {
-  hipLaunchKernelGGL(k_step_s, dim3(cdiv_s((long)count * 2, 64)), dim3(64), DYN_LDS_BYTES_S, st, count, x, u, dyn, xn, stance_l, stance_r);
+  if (dyn.contact == 4) hipLaunchKernelGGL(k_step_s<true>, dim3(cdiv_s((long)count * 2, 64)), dim3(64), DYN_LDS_BYTES_S, st, count, x, u, dyn, xn, stance_l, stance_r);
+  else hipLaunchKernelGGL(k_step_s<false>, dim3(cdiv_s((long)count * 2, 64)), dim3(64), DYN_LDS_BYTES_S, st, count, x, u, dyn, xn, stance_l, stance_r);
 }
 void launch_last_step_s(const DevState& S, const ProblemDev& P, hipStream_t st) {
-  hipLaunchKernelGGL(k_last_step_s, dim3(cdiv_s((long)S.B * 2, 64)), dim3(64), DYN_LDS_BYTES_S, st, S, P);
+  if (P.dyn.contact == 4) hipLaunchKernelGGL(k_last_step_s<true>, dim3(cdiv_s((long)S.B * 2, 64)), dim3(64), DYN_LDS_BYTES_S, st, S, P);
+  else hipLaunchKernelGGL(k_last_step_s<false>, dim3(cdiv_s((long)S.B * 2, 64)), dim3(64), DYN_LDS_BYTES_S, st, S, P);
 }
 void launch_linearize_fd_s(const DevState& S, const ProblemDev& P, int mode, double eps, hipStream_t st) {
   const int dd = (int)lin_dump_doubles();
-  hipLaunchKernelGGL(k_fd_steps_s, dim3(cdiv_s((long)S.B * S.N * FD_NCOL * 2, 64)), dim3(64), DYN_LDS_BYTES_S, st, S, P, mode, eps, dd);
+  if (P.dyn.contact == 4) hipLaunchKernelGGL(k_fd_steps_s<true>, dim3(cdiv_s((long)S.B * S.N * FD_NCOL * 2, 64)), dim3(64), DYN_LDS_BYTES_S, st, S, P, mode, eps, dd);
+  else hipLaunchKernelGGL(k_fd_steps_s<false>, dim3(cdiv_s((long)S.B * S.N * FD_NCOL * 2, 64)), dim3(64), DYN_LDS_BYTES_S, st, S, P, mode, eps, dd);
   hipLaunchKernelGGL(k_fd_finish, dim3(cdiv_s((long)S.B * S.N * H1_NX * (H1_NX + H1_NU), 256)), dim3(256), 0, st, S, mode, eps, dd);
 }
 void launch_rollout_s(const DevState& S, const ProblemDev& P, int mode, int do_roll, int count_iter, double* cost_out, hipStream_t st) {
-  if (do_roll && P.dyn.contact) hipLaunchKernelGGL(k_rollout_s<true>, dim3(cdiv_s((long)S.B * 2, 64)), dim3(64), DYN_LDS_BYTES_S, st, S, P, mode, count_iter);
-  else if (do_roll) hipLaunchKernelGGL(k_rollout_s<false>, dim3(cdiv_s((long)S.B * 2, 64)), dim3(64), DYN_LDS_BYTES_S, st, S, P, mode, count_iter);
+  if (do_roll && P.dyn.contact == 4) hipLaunchKernelGGL(k_rollout_s<2>, dim3(cdiv_s((long)S.B * 2, 64)), dim3(64), DYN_LDS_BYTES_S, st, S, P, mode, count_iter);
+  else if (do_roll && P.dyn.contact) hipLaunchKernelGGL(k_rollout_s<1>, dim3(cdiv_s((long)S.B * 2, 64)), dim3(64), DYN_LDS_BYTES_S, st, S, P, mode, count_iter);
+  else if (do_roll) hipLaunchKernelGGL(k_rollout_s<0>, dim3(cdiv_s((long)S.B * 2, 64)), dim3(64), DYN_LDS_BYTES_S, st, S, P, mode, count_iter);
   else if (count_iter) hipLaunchKernelGGL(k_count_iter, dim3(cdiv_s(S.B, 64)), dim3(64), 0, st, S, mode);
   launch_nominal_costs(S, P, mode, cost_out, st);
 }

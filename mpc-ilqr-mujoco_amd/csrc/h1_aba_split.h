@@ -688,7 +688,37 @@ typedef ChainResp<12, 16, 4, 48> ArmResp;
 
 // symmetric n x n in packed lower storage (row i: i (i + 1) / 2 + j, j <= i)
 DEVFN constexpr int pidx(int i, int j) { return i >= j ? i * (i + 1) / 2 + j : j * (j + 1) / 2 + i; }
-// in-place Cholesky of the packed SPD 12 x 12 and solution of C x = b (b overwritten)
+// in-place Cholesky of the packed SPD 12 x 12 (chol12_factor; the reciprocals of the pivots on the diagonal) and solution of C x = b with
+// the factor (chol12_apply, b overwritten); chol12_solve = both
+DEVFN void chol12_apply(const double* C, double* b) {
+#pragma unroll
+  for (int i = 0; i < 12; ++i) { double t = b[i];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) if (k < i) t -= C[pidx(i, k)] * b[k];
+    b[i] = t * C[pidx(i, i)]; }
+#pragma unroll
+  for (int i = 11; i >= 0; --i) { double t = b[i];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) if (k > i) t -= C[pidx(k, i)] * b[k];
+    b[i] = t * C[pidx(i, i)]; }
+}
+DEVFN void chol12_factor(double* C) {
+#pragma unroll
+  for (int j = 0; j < 12; ++j) {
+    double d = C[pidx(j, j)];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) if (k < j) d -= C[pidx(j, k)] * C[pidx(j, k)];
+    const double r = sqrt(d), ri = 1.0 / r;
+    C[pidx(j, j)] = ri;                       // the reciprocal of the pivot is kept
+#pragma unroll
+    for (int i = 0; i < 12; ++i) if (i > j) {
+      double t = C[pidx(i, j)];
+#pragma unroll
+      for (int k = 0; k < 12; ++k) if (k < j) t -= C[pidx(i, k)] * C[pidx(j, k)];
+      C[pidx(i, j)] = t * ri;
+    }
+  }
+}
 DEVFN void chol12_solve(double* C, double* b) {
 #pragma unroll
   for (int j = 0; j < 12; ++j) {
@@ -741,8 +771,11 @@ DEVFN void project_sliding_foot(double* Cw, int o, const double* u) {
 }
 
 // Corrects the accelerations of the free solve (qbase, qacc; U_i, 1/D_i of it still in LDS) for the stance constraints.
-// st_own / st_par: stance flags of this lane's / the partner's foot; mode 2 = unilateral, 3 = unilateral + Coulomb limit mu.
+// st_own / st_par: stance flags of this lane's / the partner's foot; mode 2 = unilateral, 3 = unilateral + Coulomb limit mu, 4 = 3 with kinetic friction on the sliding feet.
 // Y0, a0: pelvis articulated inertia and raw (gravity-offset, body-frame) pelvis acceleration of the free solve.
+// KIN: the copy that knows kinetic friction (mode 4); the other one is compiled without that branch (the constrained step is register- and
+// scratch-critical: the mere presence of the branch costs the common modes 2.5 %, measured on the contact bench)
+template <bool KIN>
 DEVFN void stance_correct(bool side, const double* R0, const double* vb, const HalfState& q, double h, double soft, int mode, bool st_own, bool st_par,
                           const double* grav, const LaneLds& L, const Art& Y0, const double* a0, double* qbase, HalfAcc& qacc, double mu = 1.0) {
   LegTrig T;
@@ -826,7 +859,7 @@ DEVFN void stance_correct(bool side, const double* R0, const double* vb, const H
     const bool relL = actL && fzL < 0.0, relR = actR && fzR < 0.0;
     if (relL || relR) { actL = actL && !relL; actR = actR && !relR; solve_masked(); }
   }
-  if (mode == 3) {
+  if (mode >= 3) {
     // Coulomb limit on the feet that still push: |f_t|^2 = |f|^2 - f_n^2 > mu^2 f_n^2 -> the foot slides (oracle
     // forward_dynamics_mj_stance, mode 3): project its translation block on the up axis and solve once more
     const double* lo = lam + (side ? 6 : 0);
@@ -839,6 +872,50 @@ DEVFN void stance_correct(bool side, const double* R0, const double* vb, const H
       double uL[3], uR[3];
 #pragma unroll
       for (int k = 0; k < 3; ++k) { const double mine = zl[k], theirs = xch(mine); uL[k] = side ? theirs : mine; uR[k] = side ? mine : theirs; }
+      if (KIN && mode == 4) {
+        // Kinetic friction: the sliding foot's normal multiplier pushes along up + mu t (t: the unit direction in which the sticking solution
+        // pulled), its constraint row stays up^T.  With G = blockdiag(I3, I3 + mu t up^T) the system (oracle, mode 4: S C F^T + soft I) is
+        //     (K + sum_f c_f u_f^T) y = Pi b ,   K = Pi (C + soft I) Pi + (I - Pi)  (the matrix of mode 3, SPD),   c_f = mu Pi C t_f ,   lambda = G y
+        // -- a rank-one update of K per sliding foot: one Cholesky factorisation, three substitutions and a 2 x 2 system (Woodbury),
+        // all on the packed matrix in registers, same bits on both lanes.
+        const double nt = sqrt(ft2 > 0.0 ? ft2 : 1.0);
+        double tL[3], tR[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { const double mine = sl_own ? (lo[3 + k] - fn * zl[k]) / nt : 0.0, theirs = xch(mine); tL[k] = side ? theirs : mine; tR[k] = side ? mine : theirs; }
+        double z0[12], zL[12], zR[12];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {
+          const bool ai = i < 6 ? actL : actR;
+          z0[i] = ai ? b[i] : 0.0;
+          // c_f = mu C t_f on the active rows (t_f lives in the translation block of foot f; zero unless that foot slides)
+          double cl = 0.0, cr = 0.0;
+#pragma unroll
+          for (int k = 0; k < 3; ++k) { cl += C[pidx(i, 3 + k)] * tL[k]; cr += C[pidx(i, 9 + k)] * tR[k]; }
+          zL[i] = (ai && slL) ? mu * cl : 0.0; zR[i] = (ai && slR) ? mu * cr : 0.0;
+#pragma unroll
+          for (int j = 0; j < 12; ++j) if (j <= i) {
+            const bool aj = j < 6 ? actL : actR;
+            Cw[pidx(i, j)] = (ai && aj) ? C[pidx(i, j)] + (i == j ? soft : 0.0) : (i == j ? 1.0 : 0.0);
+          }
+        }
+        // Pi on the right-hand sides and on the matrix
+        auto proj3 = [](double* v, const double* u) { const double w = u[0] * v[0] + u[1] * v[1] + u[2] * v[2]; v[0] = u[0] * w; v[1] = u[1] * w; v[2] = u[2] * w; };
+        if (slL) { project_sliding_foot(Cw, 3, uL); proj3(z0 + 3, uL); proj3(zL + 3, uL); proj3(zR + 3, uL); }
+        if (slR) { project_sliding_foot(Cw, 9, uR); proj3(z0 + 9, uR); proj3(zL + 9, uR); proj3(zR + 9, uR); }
+        chol12_factor(Cw);
+        chol12_apply(Cw, z0); chol12_apply(Cw, zL); chol12_apply(Cw, zR);
+        // (I + U^T Z) alpha = U^T z0 with U = [u_L, u_R] embedded: 2 x 2 (a foot that does not slide has c = 0: its alpha is u^T z0, unused)
+        const double aLL = 1.0 + uL[0] * zL[3] + uL[1] * zL[4] + uL[2] * zL[5], aLR = uL[0] * zR[3] + uL[1] * zR[4] + uL[2] * zR[5];
+        const double aRL = uR[0] * zL[9] + uR[1] * zL[10] + uR[2] * zL[11], aRR = 1.0 + uR[0] * zR[9] + uR[1] * zR[10] + uR[2] * zR[11];
+        const double rL = uL[0] * z0[3] + uL[1] * z0[4] + uL[2] * z0[5], rR = uR[0] * z0[9] + uR[1] * z0[10] + uR[2] * z0[11];
+        const double det = aLL * aRR - aLR * aRL;
+        const double alL = (rL * aRR - aLR * rR) / det, alR = (aLL * rR - aRL * rL) / det;
+#pragma unroll
+        for (int i = 0; i < 12; ++i) lam[i] = z0[i] - zL[i] * alL - zR[i] * alR;
+        // lambda = G y (y made exactly a multiple of up on the sliding feet first)
+        if (slL) { const double w = uL[0] * lam[3] + uL[1] * lam[4] + uL[2] * lam[5]; lam[3] = (uL[0] + mu * tL[0]) * w; lam[4] = (uL[1] + mu * tL[1]) * w; lam[5] = (uL[2] + mu * tL[2]) * w; }
+        if (slR) { const double w = uR[0] * lam[9] + uR[1] * lam[10] + uR[2] * lam[11]; lam[9] = (uR[0] + mu * tR[0]) * w; lam[10] = (uR[1] + mu * tR[1]) * w; lam[11] = (uR[2] + mu * tR[2]) * w; }
+      } else {
 #pragma unroll
       for (int i = 0; i < 12; ++i) {
         const bool ai = i < 6 ? actL : actR;
@@ -855,6 +932,7 @@ DEVFN void stance_correct(bool side, const double* R0, const double* vb, const H
       // (the removed directions carry zero up to rounding: make it exact, both lanes alike)
       if (slL) { const double w = uL[0] * lam[3] + uL[1] * lam[4] + uL[2] * lam[5]; lam[3] = uL[0] * w; lam[4] = uL[1] * w; lam[5] = uL[2] * w; }
       if (slR) { const double w = uR[0] * lam[9] + uR[1] * lam[10] + uR[2] * lam[11]; lam[9] = uR[0] * w; lam[10] = uR[1] * w; lam[11] = uR[2] * w; }
+      }
     }
   }
   // propagate the multipliers: own wrench inward, pelvis, outward along every chain of this lane
@@ -977,6 +1055,7 @@ DEVFN void step(bool side, HalfX& h, const HalfU& u, double dt, const double* gr
 }
 
 // x <- f(x, u) with the stance constraints of the scheduled feet (contact mode 1 / 2 / 3)
+template <bool KIN = false>
 DEVFN void step_stance(bool side, HalfX& h, const HalfU& u, double dt, const double* grav, const LaneLds& L, double soft, int mode, bool st_own, bool st_par, double mu = 1.0) {
   const double qn = sqrt(h.quat[0] * h.quat[0] + h.quat[1] * h.quat[1] + h.quat[2] * h.quat[2] + h.quat[3] * h.quat[3]);
   const double qh[4] = {h.quat[0] / qn, h.quat[1] / qn, h.quat[2] / qn, h.quat[3] / qn};
@@ -997,7 +1076,7 @@ DEVFN void step_stance(bool side, HalfX& h, const HalfU& u, double dt, const dou
   }
   double qb[6]; HalfAcc qa; Art Y0; double a0[6];
   forward_dynamics(side, R0, h.vb, h.q, tau, ARMATURE + dt * DAMPING, grav, L, qb, qa, &Y0, a0);
-  if (st_own || st_par) stance_correct(side, R0, h.vb, h.q, dt, soft, mode, st_own, st_par, grav, L, Y0, a0, qb, qa, mu);
+  if (st_own || st_par) stance_correct<KIN>(side, R0, h.vb, h.q, dt, soft, mode, st_own, st_par, grav, L, Y0, a0, qb, qa, mu);
 #pragma unroll
   for (int k = 0; k < 6; ++k) h.vb[k] += dt * qb[k];
 #pragma unroll

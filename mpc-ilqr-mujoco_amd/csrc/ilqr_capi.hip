@@ -694,8 +694,8 @@ int ilqr_hip_num_slices(const ilqr_hip_ctx* c) { return c ? slices_wanted(c->B) 
 // The analytic Jacobians differentiate the constrained step with the active set held fixed (modes 1, 2); a sliding foot's
 // constraint rows turn with the foot, which they do not carry: mode 3 linearises by the reference's forward differences.
 static int jacobians_available(ilqr_hip_ctx* c) {
-  if (c->P.dyn.contact == ILQR_CONTACT_FRICTION_STANCE && c->jac_mode == ILQR_JAC_ANALYTIC) {
-    c->err = "contact mode 3 (Coulomb limit): analytic Jacobians are not available, select ILQR_JAC_FD_FORWARD with ilqr_hip_set_options";
+  if (c->P.dyn.contact >= ILQR_CONTACT_FRICTION_STANCE && c->jac_mode == ILQR_JAC_ANALYTIC) {
+    c->err = "contact modes 3 / 4 (Coulomb limit): analytic Jacobians are not available, select ILQR_JAC_FD_FORWARD with ilqr_hip_set_options";
     return ILQR_ERR_UNSUPPORTED;
   }
   return ILQR_OK;
@@ -925,8 +925,8 @@ int ilqr_hip_step(ilqr_hip_ctx* c, int count, const double* x, const double* u, 
   return ilqr_hip_step_stance(c, count, x, u, 1, 1, x_next);
 }
 int ilqr_hip_set_contact_mode(ilqr_hip_ctx* c, int mode, double softness) {
-  if (!c || (mode != ILQR_CONTACT_NONE && mode != ILQR_CONTACT_RIGID_STANCE && mode != ILQR_CONTACT_UNILATERAL_STANCE && mode != ILQR_CONTACT_FRICTION_STANCE)) return ILQR_ERR_ARG;
-  if (mode == ILQR_CONTACT_FRICTION_STANCE && ilqr::variant_scalar_dyn()) { c->err = "contact mode 3 (Coulomb limit) exists on the two-lane kernels only; unset ILQR_DYN=s"; return ILQR_ERR_UNSUPPORTED; }
+  if (!c || (mode != ILQR_CONTACT_NONE && mode != ILQR_CONTACT_RIGID_STANCE && mode != ILQR_CONTACT_UNILATERAL_STANCE && mode != ILQR_CONTACT_FRICTION_STANCE && mode != ILQR_CONTACT_KINETIC_FRICTION_STANCE)) return ILQR_ERR_ARG;
+  if (mode >= ILQR_CONTACT_FRICTION_STANCE && ilqr::variant_scalar_dyn()) { c->err = "contact modes 3 / 4 (Coulomb limit) exist on the two-lane kernels only; unset ILQR_DYN=s"; return ILQR_ERR_UNSUPPORTED; }
   c->P.dyn.contact = mode;
   if (softness > 0.0) c->P.dyn.soft = softness;
   return ILQR_OK;

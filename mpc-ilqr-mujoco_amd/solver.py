@@ -345,7 +345,7 @@ class BatchedILQR:
 
     def set_contact_mode(self, mode, softness=0.0):
         """0: constraint-free step; 1: rigid stance constraints on the feet the contact schedule marks (SURVEY 8(f) f4);
-        2: unilateral; 3: unilateral + Coulomb limit (set_friction)."""
+        2: unilateral; 3: unilateral + Coulomb limit (set_friction), sliding feet without tangential force; 4: with kinetic friction."""
         self._chk(self.L.ilqr_hip_set_contact_mode(self.h, int(mode), C.c_double(softness)))
         self.contact_mode = int(mode)
 

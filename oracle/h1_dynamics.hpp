@@ -31,6 +31,7 @@ struct DynParams {
                          // 2: the same, unilateral: a stance foot the floor would have to pull on is released
                          // 3: unilateral + Coulomb limit: a foot whose force leaves the cone |f_t| <= mu f_n slides (its two
                          //    tangential translation rows are dropped, rotation + normal rows stay; solved again, once)
+                         // 4: as 3, and the sliding foot keeps kinetic friction mu lambda_n along the direction the sticking force had
   double mu = 1.0;       // sliding friction coefficient of mode 3 (MuJoCo's default geom friction; the H1 model file sets none)
   double soft = 1e-5;    // diagonal softness of the stance constraint (1 / kg), keeps J Minv J^T invertible with straight knees
 };
@@ -394,12 +395,15 @@ inline void forward_dynamics_mj_stance(const T* quat_hat, const T* theta, const 
       }
       if (nk < nf) { nf = nk; for (int g = 0; g < nk; ++g) fb[g] = keep[g]; if (nf > 0) solve_set(); }
     }
-    if (contact_mode == 3 && nf > 0) {
+    if (contact_mode >= 3 && nf > 0) {
       // Coulomb limit on the feet that are left: f_n = up . f, |f_t|^2 = |f|^2 - f_n^2 (f: force part of lambda_g, link coordinates).
       // A foot outside the cone slides: its constraint keeps the three rotation rows and the normal translation row,
       //     S_g = [I3 0; 0 up^T]  (4 x 6),   (S C S^T + soft I) lambda_s = S b,   lambda = S^T lambda_s
       // with C, b the rigid system of the current set (built again: solve_set factorises in place).
-      T up[2][3]; bool slide[2] = {false, false}; bool any = false;
+      // contact_mode 4: the sliding foot keeps kinetic friction, mu lambda_n along the unit direction t in which the sticking solution
+      // pulled: the normal multiplier's force acts along up + mu t while its constraint row stays up^T -- F = [I3 0; 0 (up + mu t)^T],
+      //     (S C F^T + soft I) lambda_s = S b,   lambda = F^T lambda_s     (unsymmetric: Gaussian elimination with partial pivoting)
+      T up[2][3], tdir[2][3]; bool slide[2] = {false, false}; bool any = false;
       for (int g = 0; g < nf; ++g) {
         T zl[6] = {T(0.0), T(0.0), T(0.0), R0[6], R0[7], R0[8]};
         for (int i = fb[g] - 4; i <= fb[g]; ++i) { T o2[6]; xf_motion(Rj[i], H1_POS[i], zl, o2); for (int k = 0; k < 6; ++k) zl[k] = o2[k]; }
@@ -407,7 +411,11 @@ inline void forward_dynamics_mj_stance(const T* quat_hat, const T* theta, const 
         const T* f = lam + 6 * g + 3;
         const T fn = up[g][0] * f[0] + up[g][1] * f[1] + up[g][2] * f[2];
         const T ft2 = f[0] * f[0] + f[1] * f[1] + f[2] * f[2] - fn * fn;
-        if (val(ft2) > mu * mu * val(fn) * val(fn)) { slide[g] = true; any = true; }
+        if (val(ft2) > mu * mu * val(fn) * val(fn)) {
+          slide[g] = true; any = true;
+          const T nt = sqrt(ft2);
+          for (int k = 0; k < 3; ++k) tdir[g][k] = (f[k] - fn * up[g][k]) / nt;
+        }
       }
       if (any) {
         const int nc = 6 * nf;
@@ -434,16 +442,38 @@ inline void forward_dynamics_mj_stance(const T* quat_hat, const T* theta, const 
             else S[ns][6 * g + r] = T(1.0);
           }
         }
+        // F: the force map of the multipliers (= S, except the normal row of a sliding foot in mode 4)
+        T F[12][12];
+        for (int i = 0; i < ns; ++i) for (int c = 0; c < nc; ++c) F[i][c] = S[i][c];
+        if (contact_mode == 4) {
+          int r = 0;
+          for (int g = 0; g < nf; ++g) {
+            if (slide[g]) for (int k = 0; k < 3; ++k) F[r + 3][6 * g + 3 + k] = up[g][k] + mu * tdir[g][k];
+            r += slide[g] ? 4 : 6;
+          }
+        }
         T CS[144], Cs[144], bs[12];
-        for (int i = 0; i < nc; ++i) for (int j = 0; j < ns; ++j) { T a = T(0.0); for (int k = 0; k < nc; ++k) a += C[i * nc + k] * S[j][k]; CS[i * ns + j] = a; }
+        for (int i = 0; i < nc; ++i) for (int j = 0; j < ns; ++j) { T a = T(0.0); for (int k = 0; k < nc; ++k) a += C[i * nc + k] * F[j][k]; CS[i * ns + j] = a; }
         for (int i = 0; i < ns; ++i) {
           for (int j = 0; j < ns; ++j) { T a = T(0.0); for (int k = 0; k < nc; ++k) a += S[i][k] * CS[k * ns + j]; Cs[i * ns + j] = a; }
           Cs[i * ns + i] += soft;
           T a = T(0.0); for (int k = 0; k < nc; ++k) a += S[i][k] * b[k];
           bs[i] = a;
         }
-        chol_solve_inplace(Cs, bs, ns);
-        for (int c = 0; c < nc; ++c) { T a = T(0.0); for (int i = 0; i < ns; ++i) a += S[i][c] * bs[i]; lam[c] = a; }
+        if (contact_mode == 4) {
+          for (int j = 0; j < ns; ++j) {                      // Gaussian elimination, partial pivoting
+            int piv = j; double best = std::fabs(val(Cs[j * ns + j]));
+            for (int i = j + 1; i < ns; ++i) if (std::fabs(val(Cs[i * ns + j])) > best) { best = std::fabs(val(Cs[i * ns + j])); piv = i; }
+            if (piv != j) { for (int k = 0; k < ns; ++k) { T t_ = Cs[j * ns + k]; Cs[j * ns + k] = Cs[piv * ns + k]; Cs[piv * ns + k] = t_; } T t_ = bs[j]; bs[j] = bs[piv]; bs[piv] = t_; }
+            for (int i = j + 1; i < ns; ++i) {
+              const T m_ = Cs[i * ns + j] / Cs[j * ns + j];
+              for (int k = j; k < ns; ++k) Cs[i * ns + k] -= m_ * Cs[j * ns + k];
+              bs[i] -= m_ * bs[j];
+            }
+          }
+          for (int i = ns - 1; i >= 0; --i) { T a = bs[i]; for (int k = i + 1; k < ns; ++k) a -= Cs[i * ns + k] * bs[k]; bs[i] = a / Cs[i * ns + i]; }
+        } else chol_solve_inplace(Cs, bs, ns);
+        for (int c = 0; c < nc; ++c) { T a = T(0.0); for (int i = 0; i < ns; ++i) a += F[i][c] * bs[i]; lam[c] = a; }
       }
     }
     if (nf > 0) {

@@ -244,7 +244,10 @@ def kane_step_c(bodies, ctrlrange, x, u, h, grav, stance=(1, 1), contact=0, soft
     contact = 3 (round 4): unilateral + Coulomb limit.  A foot whose constraint force leaves the friction cone, |f_t| > mu f_n
     (f_n = force along the world up axis, f_t the rest of the force; MuJoCo's default sliding friction is mu = 1), cannot stick:
     its two tangential translation rows are dropped -- the rotation rows and the normal row stay -- and the set is solved again, once
-    (`release` variant: a slipping foot receives no tangential force)."""
+    (`release` variant: a slipping foot receives no tangential force).
+    contact = 4: the same decision, but the sliding foot keeps kinetic friction: a tangential force mu lambda_n along the unit direction in
+    which the sticking solution pulled (the direction that opposes the slip), i.e. its normal multiplier acts along up + mu t while the
+    constraint row stays the normal one -- an unsymmetric system, solved once."""
     q, v = x[:26], x[26:]
     z25 = np.zeros(25)
     bias, feet0 = kane_eval_c(bodies, q, v, z25, grav, armature)
@@ -258,6 +261,7 @@ def kane_step_c(bodies, ctrlrange, x, u, h, grav, stance=(1, 1), contact=0, soft
     rhs = tau - D * v - bias
     act = [bool(contact) and stance[0] == 1, bool(contact) and stance[1] == 1]
     slide = [False, False]
+    tdir = [None, None]
     lam = np.zeros(12, dtype=rhs.dtype)
     re_ = (lambda a: a.real) if np.iscomplexobj(rhs) else (lambda a: a)
     stage = 0                      # 0: rigid set; 1: after the unilateral check; 2: after the Coulomb check
@@ -274,16 +278,26 @@ def kane_step_c(bodies, ctrlrange, x, u, h, grav, stance=(1, 1), contact=0, soft
             else:
                 Sf = np.eye(6)
             Ssel.append(Sf)
-        J = np.concatenate([Sf @ np.stack([cols[k][1][f]["acc"] - feet0[f]["acc"] for k in range(25)], axis=1) for Sf, f in zip(Ssel, rows)], axis=0)
+        # force map of the multipliers: the constraint rows themselves, except (contact = 4) the normal multiplier of a sliding foot, which
+        # also carries the kinetic friction mu lambda_n along tdir (the direction in which the sticking solution pulled)
+        Fsel = []
+        for Sf, f in zip(Ssel, rows):
+            Ff = Sf.copy()
+            if slide[f] and contact == 4:
+                Ff[3, 3:6] = feet0[f]["up"] + mu * tdir[f]
+            Fsel.append(Ff)
+        Jfull = {f: np.stack([cols[k][1][f]["acc"] - feet0[f]["acc"] for k in range(25)], axis=1) for f in rows}
+        J = np.concatenate([Sf @ Jfull[f] for Sf, f in zip(Ssel, rows)], axis=0)
+        JF = np.concatenate([Ff @ Jfull[f] for Ff, f in zip(Fsel, rows)], axis=0)
         b = np.concatenate([Sf @ (-feet0[f]["vel"] / h - feet0[f]["acc"]) for Sf, f in zip(Ssel, rows)])
         nc = J.shape[0]
-        KKT = np.block([[Mh, -J.T], [J, soft * np.eye(nc)]])
+        KKT = np.block([[Mh, -JF.T], [J, soft * np.eye(nc)]])
         sol = np.linalg.solve(KKT, np.concatenate([rhs, b]))
         qacc = sol[:25]
         lam[:] = 0
         o = 25
-        for Sf, f in zip(Ssel, rows):
-            lam[6 * f:6 * f + 6] = Sf.T @ sol[o:o + Sf.shape[0]]; o += Sf.shape[0]
+        for Ff, f in zip(Fsel, rows):
+            lam[6 * f:6 * f + 6] = Ff.T @ sol[o:o + Ff.shape[0]]; o += Ff.shape[0]
         again = False
         if contact >= 2 and stage == 0:
             stage = 1
@@ -293,7 +307,7 @@ def kane_step_c(bodies, ctrlrange, x, u, h, grav, stance=(1, 1), contact=0, soft
                     act[f] = False; again = True
             if again:
                 continue
-        if contact == 3 and stage == 1:
+        if contact >= 3 and stage == 1:
             stage = 2
             for f in rows:
                 if not act[f]:
@@ -303,6 +317,7 @@ def kane_step_c(bodies, ctrlrange, x, u, h, grav, stance=(1, 1), contact=0, soft
                 ft2 = fo @ fo - fn * fn
                 if re_(ft2) > mu * mu * re_(fn) * re_(fn):
                     slide[f] = True; again = True
+                    tdir[f] = (fo - fn * feet0[f]["up"]) / np.sqrt(ft2)
             if again:
                 continue
         break
@@ -863,7 +878,7 @@ def gen_friction():
     bodies, ctrl = load_mjcf()
     rng = np.random.default_rng(2026)
     h, grav = 0.02, np.array([0.0, 0.0, -9.81])
-    out = dict(x=[], u=[], stance=[], mu=[], x_next=[], x_next_mode2=[], slide=[], act=[], lam=[])
+    out = dict(x=[], u=[], stance=[], mu=[], x_next=[], x_next_mode2=[], x_next_mode4=[], slide=[], act=[], lam=[], lam_mode4=[])
     tries = 0
     want = {(0, 0): 3, (1, 0): 2, (0, 1): 2, (1, 1): 3}
     while any(v > 0 for v in want.values()) and tries < 2000:
@@ -879,6 +894,8 @@ def gen_friction():
         stance = (1, 1)
         xn, qacc, Mh, lam, act, slide = kane_step_c(bodies, ctrl, x, u, h, grav, stance=stance, contact=3, mu=mu, want=True)
         xn2, _, _, lam2, act2, _ = kane_step_c(bodies, ctrl, x, u, h, grav, stance=stance, contact=2, want=True)
+        xn4, _, _, lam4, _, slide4 = kane_step_c(bodies, ctrl, x, u, h, grav, stance=stance, contact=4, mu=mu, want=True)
+        assert list(slide4) == list(slide)
         # margins of the decisions on the mode-2 solution (what the Coulomb check looks at)
         _, feet0 = kane_eval_c(bodies, x[:26], x[26:], np.zeros(25), grav, 0.1)
         ok = True
@@ -893,7 +910,7 @@ def gen_friction():
         if not ok or want.get(key, 0) <= 0:
             continue
         want[key] -= 1
-        for k, val_ in (("x", x), ("u", u), ("stance", np.array(stance)), ("mu", mu), ("x_next", xn), ("x_next_mode2", xn2), ("slide", np.array(key)), ("act", np.array(act, dtype=int)), ("lam", lam)):
+        for k, val_ in (("x", x), ("u", u), ("stance", np.array(stance)), ("mu", mu), ("x_next", xn), ("x_next_mode2", xn2), ("x_next_mode4", xn4), ("lam_mode4", lam4), ("slide", np.array(key)), ("act", np.array(act, dtype=int)), ("lam", lam)):
             out[k].append(val_)
     assert all(v == 0 for v in want.values()), want
     np.savez(os.path.join(HERE, "friction_golden.npz"), h=h, gravity=grav, soft=1e-5, **{k: np.array(v) for k, v in out.items()})

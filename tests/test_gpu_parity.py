@@ -417,11 +417,19 @@ def test_friction_limited_contact_mode_slides_feet_outside_the_cone_and_matches_
         assert np.abs(got3[0] - g["x_next"][i]).max() < 1e-9 * max(1.0, np.abs(g["x_next"][i]).max()), (i, np.abs(got3[0] - g["x_next"][i]).max())
         assert np.abs(got3[0] - want).max() < 1e-9 * max(1.0, np.abs(want).max())
         assert np.abs(got2[0] - g["x_next_mode2"][i]).max() < 1e-9 * max(1.0, np.abs(g["x_next_mode2"][i]).max())
+        # mode 4 (kinetic friction on the sliding feet): golden of the unsymmetric KKT formulation, oracle
+        s.set_contact_mode(4, float(g["soft"]))
+        got4 = s.step_stance(xs, us, int(g["stance"][i][0]), int(g["stance"][i][1]))
+        o.set_contact_mode(4, float(g["soft"]))
+        want4 = o.step_stance(g["x"][i], g["u"][i], g["stance"][i])
+        assert np.abs(got4 - got4[0]).max() == 0.0
+        assert np.abs(got4[0] - g["x_next_mode4"][i]).max() < 1e-9 * max(1.0, np.abs(g["x_next_mode4"][i]).max()), (i, np.abs(got4[0] - g["x_next_mode4"][i]).max())
+        assert np.abs(got4[0] - want4).max() < 1e-9 * max(1.0, np.abs(want4).max())
         if g["slide"][i].any():
             slid += 1
-            assert np.abs(got3[0] - got2[0]).max() > 1e-3
+            assert np.abs(got3[0] - got2[0]).max() > 1e-3 and np.abs(got4[0] - got3[0]).max() > 1e-3
         else:
-            assert np.array_equal(got3[0], got2[0])
+            assert np.array_equal(got3[0], got2[0]) and np.array_equal(got4[0], got2[0])
     assert slid >= 5
     # (iii) loud refusal of the analytic Jacobians
     s.set_contact_mode(3); s.set_friction(0.3)
@@ -433,24 +441,25 @@ def test_friction_limited_contact_mode_slides_feet_outside_the_cone_and_matches_
     Bs = 4
     s.close()
     prob, x0, ui = make(Bs, seed=28, gravity=list(g["gravity"]), walking=True)
-    s = _solver(Bs); s.set_problem(prob); s.set_contact_mode(3); s.set_friction(0.7)   # (the cold-started gait loads its feet sideways)
-    s.set_options(jacobian_mode=1, fd_eps=1e-5, early_exit=False); s.set_max_iterations(3)
-    s.initialize(x0, ui)
-    cost = s.solve(x0)
-    tc, ta, tl = s.trace()
-    assert s.adopt_mismatches() == 0
-    differs = 0
-    for b in range(Bs):
-        ob = oracle_for(prob, jac_mode=1, fd_eps=1e-5, early_exit=0, max_iter=3); ob.set_contact_mode(3); ob.set_friction(0.7)
-        ob.initialize(x0[b], ui[b]); ok, c = ob.solve(x0[b])
-        nn, oc, oa, ol_ = ob.trace()
-        assert nn == 3 and np.allclose(tc[b], oc, rtol=1e-5) and np.array_equal(ta[b], oa), (tc[b], oc, ta[b], oa)
-        assert abs(cost[b] - c) <= 1e-5 * abs(c) and rel(s.gains_K()[b], ob.get("K")) < 1e-4 and rel(s.xbar()[b], ob.get("xbar")) < 1e-5
-        o2 = oracle_for(prob, jac_mode=1, fd_eps=1e-5, early_exit=0, max_iter=3); o2.set_contact_mode(2)
-        o2.initialize(x0[b], ui[b]); _, c2 = o2.solve(x0[b])
-        differs += int(abs(c2 - c) > 1e-6 * abs(c))
-    assert differs >= 1                              # the cone was active somewhere along these solves
-    s.close()
+    for cmode in (3, 4):
+        s = _solver(Bs); s.set_problem(prob); s.set_contact_mode(cmode); s.set_friction(0.7)   # (the cold-started gait loads its feet sideways)
+        s.set_options(jacobian_mode=1, fd_eps=1e-5, early_exit=False); s.set_max_iterations(3)
+        s.initialize(x0, ui)
+        cost = s.solve(x0)
+        tc, ta, tl = s.trace()
+        assert s.adopt_mismatches() == 0
+        differs = 0
+        for b in range(Bs):
+            ob = oracle_for(prob, jac_mode=1, fd_eps=1e-5, early_exit=0, max_iter=3); ob.set_contact_mode(cmode); ob.set_friction(0.7)
+            ob.initialize(x0[b], ui[b]); ok, c = ob.solve(x0[b])
+            nn, oc, oa, ol_ = ob.trace()
+            assert nn == 3 and np.allclose(tc[b], oc, rtol=1e-5) and np.array_equal(ta[b], oa), (cmode, tc[b], oc, ta[b], oa)
+            assert abs(cost[b] - c) <= 1e-5 * abs(c) and rel(s.gains_K()[b], ob.get("K")) < 1e-4 and rel(s.xbar()[b], ob.get("xbar")) < 1e-5
+            o2 = oracle_for(prob, jac_mode=1, fd_eps=1e-5, early_exit=0, max_iter=3); o2.set_contact_mode(2)
+            o2.initialize(x0[b], ui[b]); _, c2 = o2.solve(x0[b])
+            differs += int(abs(c2 - c) > 1e-6 * abs(c))
+        assert differs >= 1                              # the cone was active somewhere along these solves
+        s.close()
 
 
 @pytest.mark.parametrize("mode", [1, 2])
@@ -694,13 +703,13 @@ def test_closed_loop_with_the_coulomb_limit_stands_on_grip_and_slides_on_ice(tmp
     ug = sv.gravity_compensation(sc.standing_state(), base["gravity"])
     x_still = np.tile(sc.standing_state(), (B, 1)); u_still = np.tile(ug, (B, N, 1))
     out = {}
-    for mode, mu, push in ((2, 1.0, 0.0), (3, 1.0, 0.0), (2, 1.0, 0.6), (3, 0.02, 0.6)):
+    for mode, mu, push in ((2, 1.0, 0.0), (3, 1.0, 0.0), (2, 1.0, 0.6), (3, 0.02, 0.6), (4, 1.0, 0.6), (4, 0.02, 0.6)):
         s = _solver(B); s.set_max_iterations(3); s.set_contact_mode(mode); s.set_friction(mu); s.set_options(jacobian_mode=1, fd_eps=1e-5)
         xp = x_still.copy(); xp[:, 27] += push                                  # a sideways velocity of the pelvis
         xs, us = ml.MPCRunner(s, rd, base).run(xp, 6, u_init=u_still)
         assert np.all(np.isfinite(xs)) and np.all(np.isfinite(us))
         ee0 = sv.reference_kinematics(xs[0, 0])[1]; ee1 = sv.reference_kinematics(xs[-1, 0])[1]
-        out[(mode, push)] = (xs, np.abs(ee1[:, :2] - ee0[:, :2]).max(), np.abs(ee1[:, 2] - ee0[:, 2]).max())
+        out[(mode, push) if mode != 4 else (mode, mu)] = (xs, np.abs(ee1[:, :2] - ee0[:, :2]).max(), np.abs(ee1[:, 2] - ee0[:, 2]).max())
         s.close()
     # standing still the plant's feet carry f_t / f_n = 0.06: no foot slides, in either mode (the solver's line-search candidates do
     # leave the cone, so the two closed loops are not the same trajectory)
@@ -708,6 +717,8 @@ def test_closed_loop_with_the_coulomb_limit_stands_on_grip_and_slides_on_ice(tmp
         assert out[(m, 0.0)][0][:, :, 2].min() > 0.97 and out[(m, 0.0)][1] < 5e-3 and out[(m, 0.0)][2] < 5e-3, (m, out[(m, 0.0)][1:])
     assert out[(2, 0.6)][1] < 5e-3                                                               # rigid rows: the push does not move the feet
     assert out[(3, 0.6)][1] > 2e-2 and out[(3, 0.6)][2] < 3e-2, out[(3, 0.6)][1:]                # ice: they slide, along the floor
+    # mode 4 keeps kinetic friction on a sliding foot: the friction coefficient now matters -- less slip on grip than on ice
+    assert np.all(np.isfinite(out[(4, 1.0)][0])) and out[(4, 1.0)][1] < 0.7 * out[(4, 0.02)][1], (out[(4, 1.0)][1:], out[(4, 0.02)][1:])
 
 
 def test_launch_orchestration_variants_are_bitwise_equivalent():

@@ -369,6 +369,15 @@ def test_friction_limited_stance_step_against_the_independent_kkt_formulation():
             assert np.abs(xn - x2).max() > 1e-3
         else:
             assert np.array_equal(xn, x2)
+        # mode 4: the same decision, kinetic friction mu f_n on the sliding feet (unsymmetric KKT in the generator, unit-wrench responses +
+        # Gaussian elimination in the oracle)
+        o.set_contact_mode(4, float(g["soft"]))
+        x4 = o.step_stance(g["x"][i], g["u"][i], g["stance"][i])
+        assert np.abs(x4 - g["x_next_mode4"][i]).max() < 1e-9 * max(1.0, np.abs(g["x_next_mode4"][i]).max()), (i, np.abs(x4 - g["x_next_mode4"][i]).max())
+        if g["slide"][i].any():
+            assert np.abs(x4 - xn).max() > 1e-3 and np.abs(x4 - x2).max() > 1e-3            # neither frictionless sliding nor sticking
+        else:
+            assert np.array_equal(x4, x2)
         pat.add(tuple(int(v) for v in g["slide"][i]))
         # normal velocity of every foot that carries load is held either way: the foot's height moves O(h^2)
         ee0 = ol.reference_kinematics(g["x"][i])[1]; ee1 = ol.reference_kinematics(xn)[1]

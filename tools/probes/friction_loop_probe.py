@@ -14,7 +14,7 @@ rd = rf.ReferenceData(sv.reference_kinematics, sv.reference_com_velocity)
 rd.set_states(np.tile(sc.standing_state(), (60, 1))); rd.contact = np.ones((60, 2), dtype=np.int32)
 ug = sv.gravity_compensation(sc.standing_state(), base["gravity"])
 x_still = np.tile(sc.standing_state(), (B, 1)); u_still = np.tile(ug, (B, N, 1))
-for mode, mu, push in ((2, 1.0, 0.0), (3, 1.0, 0.0), (3, 0.3, 0.0), (2, 1.0, 0.6), (3, 1.0, 0.6), (3, 0.3, 0.6), (3, 0.02, 0.6), (3, 0.02, 0.0)):
+for mode, mu, push in ((2, 1.0, 0.0), (3, 1.0, 0.0), (3, 0.3, 0.0), (2, 1.0, 0.6), (3, 1.0, 0.6), (3, 0.3, 0.6), (3, 0.02, 0.6), (3, 0.02, 0.0), (4, 1.0, 0.0), (4, 1.0, 0.6), (4, 0.3, 0.6), (4, 0.02, 0.6)):
     s = sv.BatchedILQR(B, N=N); s.set_max_iterations(3); s.set_contact_mode(mode); s.set_friction(mu); s.set_options(jacobian_mode=1, fd_eps=1e-5)
     xp = x_still.copy(); xp[:, 27] += push
     xs, us = ml.MPCRunner(s, rd, base).run(xp, 6, u_init=u_still)
