@@ -88,7 +88,7 @@ struct ilqr_hip_ctx {
   int spec_iterations = 0;    // iterations of the last solve that enqueued both passes side by side
   int* d_spec_gate = nullptr; // [4] device-side choice of the order (launch_spec_gate)
   // early continuation (enqueue_solve): streams / events of the group that starts the next iteration behind the first control pass
-  hipStream_t a1 = nullptr, a2 = nullptr, a3 = nullptr;
+  hipStream_t a1 = nullptr;     // (its cost quadratics and re-rollout share streams 2 and 3 with the other group, see enqueue_solve)
   hipEvent_t evA_fork = nullptr, evA_join = nullptr, evA_roll = nullptr, evA_lin = nullptr, evA_adopt = nullptr;
   int split_iterations = 0;   // iterations of the last solve whose concurrent region ran in two groups
 };
@@ -154,7 +154,7 @@ int ilqr_hip_create(ilqr_hip_ctx** out, int device, int batch, int horizon, doub
   A(dalloc(c, &S.trace_cost, B * (c->max_iter + 1))); A(dalloc(c, &S.trace_alpha, B * c->max_iter)); A(dalloc(c, &S.trace_lambda, B * c->max_iter));
   A(dalloc(c, &S.order, B * 2 * (c->max_iter + 1))); A(dalloc(c, &S.order_n, 2 * (size_t)(c->max_iter + 1)));
   A(dalloc(c, &S.grp_a, B)); A(dalloc(c, &S.grp_r, B)); A(dalloc(c, &S.order_r, B)); A(dalloc(c, &S.order_rn, (size_t)c->max_iter + 2)); A(dalloc(c, &S.order_an, (size_t)c->max_iter + 2));
-  if (rc == ILQR_OK && (hipStreamCreate(&c->a1) != hipSuccess || hipStreamCreate(&c->a2) != hipSuccess || hipStreamCreate(&c->a3) != hipSuccess ||
+  if (rc == ILQR_OK && (hipStreamCreate(&c->a1) != hipSuccess ||
       hipEventCreateWithFlags(&c->evA_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->evA_join, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&c->evA_roll, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->evA_lin, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&c->evA_adopt, hipEventDisableTiming) != hipSuccess)) { c->err = "stream / event creation failed (early continuation)"; rc = ILQR_ERR_HIP; }
@@ -202,7 +202,7 @@ int ilqr_hip_destroy(ilqr_hip_ctx* c) {
   if (c->twin) { void* tw[] = {c->T.K, c->T.kff, c->T.Vx, c->T.Vxx, c->T.xcand, c->T.ucand, c->T.cand_cost, c->T.cand_knot, c->T.lambda, c->d_spec_gate}; for (void* p : tw) if (p) hipFree(p); }
   { void* gp[] = {S.grp_a, S.grp_r, S.order_r, S.order_rn, S.order_an}; for (void* p : gp) if (p) hipFree(p); }
   for (hipEvent_t e : {c->evA_fork, c->evA_join, c->evA_roll, c->evA_lin, c->evA_adopt}) if (e) hipEventDestroy(e);
-  for (hipStream_t t : {c->a1, c->a2, c->a3}) if (t) hipStreamDestroy(t);
+  if (c->a1) hipStreamDestroy(c->a1);
   if (c->ev_spec_fork) hipEventDestroy(c->ev_spec_fork);
   if (c->ev_spec_join) hipEventDestroy(c->ev_spec_join);
   if (c->comm) ilqr_hip_comm_destroy(c);
