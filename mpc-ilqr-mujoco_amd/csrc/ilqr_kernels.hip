@@ -800,19 +800,34 @@ __global__ void __launch_bounds__(64 * CTRL_WAVES) k_control_spec(DevState S, De
       S.order[(size_t)(2 * (iter + 1)) * S.B + pos] = b;
     }
   }
-  if (!run) return;
-  const int acc = s_accept[wv];
-  const bool retry = s_retry[wv] != 0;
-  if (retry) {      // the last backward pass the reference would have executed is the twin's: its gains and value function stay
-    wave_copy(S.K + (size_t)b * N * H1_NU * H1_NX, T.K + (size_t)b * N * H1_NU * H1_NX, N * H1_NU * H1_NX, lane);
-    wave_copy(S.kff + (size_t)b * N * H1_NU, T.kff + (size_t)b * N * H1_NU, N * H1_NU, lane);
-    wave_copy(S.Vx + (size_t)b * H1_NX, T.Vx + (size_t)b * H1_NX, H1_NX, lane);
-    wave_copy(S.Vxx + (size_t)b * H1_NX * H1_NX, T.Vxx + (size_t)b * H1_NX * H1_NX, H1_NX * H1_NX, lane);
+  // The copies: the whole workgroup serves its sixteen rollouts one after the other (a rollout's retry moves 200 KB of gains: by its own
+  // wave alone 46 us -- 4 % of an iteration of a single-rollout solve; sixteen waves take 5).
+  __syncthreads();
+  for (int w = 0; w < CTRL_WAVES; ++w) {
+    const int acc = s_accept[w];
+    const bool retry = s_retry[w] != 0;
+    if (acc < 0 && !retry) continue;            // (rollouts that did not run have neither)
+    const size_t bb = (size_t)blockIdx.x * CTRL_WAVES + w;
+    auto block_copy = [&](double* dst, const double* src, int len) {
+      for (int base = 0; base < len; base += 64 * CTRL_WAVES * 4) {
+        double v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const int e = base + 64 * CTRL_WAVES * j + (int)threadIdx.x; v[j] = src[e < len ? e : 0]; }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const int e = base + 64 * CTRL_WAVES * j + (int)threadIdx.x; if (e < len) dst[e] = v[j]; }
+      }
+    };
+    if (retry) {      // the last backward pass the reference would have executed is the twin's: its gains and value function stay
+      block_copy(S.K + bb * N * H1_NU * H1_NX, T.K + bb * N * H1_NU * H1_NX, N * H1_NU * H1_NX);
+      block_copy(S.kff + bb * N * H1_NU, T.kff + bb * N * H1_NU, N * H1_NU);
+      block_copy(S.Vx + bb * H1_NX, T.Vx + bb * H1_NX, H1_NX);
+      block_copy(S.Vxx + bb * H1_NX * H1_NX, T.Vxx + bb * H1_NX * H1_NX, H1_NX * H1_NX);
+    }
+    if (acc < 0) continue;
+    const DevState& D = retry ? T : S;
+    block_copy(S.xbar + bb * (N + 1) * H1_NX, D.xcand + (bb * 8 + acc) * (N + 1) * H1_NX, (N + 1) * H1_NX);
+    block_copy(S.ubar + bb * N * H1_NU, D.ucand + (bb * 8 + acc) * N * H1_NU, N * H1_NU);
   }
-  if (acc < 0) return;
-  const DevState& D = retry ? T : S;
-  wave_copy(S.xbar + (size_t)b * (N + 1) * H1_NX, D.xcand + ((size_t)b * 8 + acc) * (N + 1) * H1_NX, (N + 1) * H1_NX, lane);
-  wave_copy(S.ubar + (size_t)b * N * H1_NU, D.ucand + ((size_t)b * 8 + acc) * N * H1_NU, N * H1_NU, lane);
 }
 
 // solve prologue: J = initial cost, trace[0], counters
