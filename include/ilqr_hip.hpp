@@ -94,6 +94,8 @@ class iLQR {
   void setContactSchedule(const std::vector<int>& stance /*[N+1][2]*/) { chk(ilqr_hip_set_contact_schedule(ctx_, stance.data(), 1)); }
   // contact row: ILQR_CONTACT_NONE (default) or ILQR_CONTACT_RIGID_STANCE on the scheduled feet
   void setContactMode(int mode, double softness = 0.0) { chk(ilqr_hip_set_contact_mode(ctx_, mode, softness)); }
+  // sliding friction coefficient of contact modes 3 / 4 (ilqr_hip.h: Coulomb limit on the stance feet; forward-difference Jacobians only)
+  void setFriction(double mu) { chk(ilqr_hip_set_friction(ctx_, mu)); }
   void setEEReferences(const Vec& ee_ref /*[N+1][2][3]*/, const Vec* com_vel_ref = nullptr) { chk(ilqr_hip_set_ee_references(ctx_, ee_ref.data(), com_vel_ref ? com_vel_ref->data() : nullptr, 1)); }
 
   // include/ilqr/ilqr.hpp:22-24
