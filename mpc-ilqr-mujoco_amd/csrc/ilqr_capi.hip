@@ -573,7 +573,9 @@ static int enqueue_solve(ilqr_hip_ctx* c, const DevState& S, const h1::ProblemDe
   // the backward pass.  The retry of an early iteration keeps a fraction of the chip busy for two latency-bound passes: the time it
   // left idle is what this recovers.  Same kernels on the same data in the same per-rollout order: results are bit-identical
   // (GPU test).  On by default with the convergence exit (split_enabled above); ILQR_SPLIT=0 / 1 forces one / two groups.
-  const bool can_split = split_enabled(c) && S.order && S.grp_a && ev_lin && ev_adopt && c->a1 != nullptr;
+  // (analytic Jacobians only: the forward-difference launchers select by S.active, not by the group's list, and use S.A / S.Bm as
+  // scratch that k_fd_finish rewrites in place -- group A's pass would rewrite the Jacobians the retry's backward pass is reading)
+  const bool can_split = split_enabled(c) && S.order && S.grp_a && ev_lin && ev_adopt && c->a1 != nullptr && c->jac_mode == ILQR_JAC_ANALYTIC;
   bool prev_split = false;      // group A of the iteration at hand is already enqueued
   for (int iter = 0; iter < c->max_iter; ++iter) {
     if (gate && iter >= 2) {
@@ -839,7 +841,16 @@ int ilqr_hip_stage_backward_pass(ilqr_hip_ctx* c) {
   if (c->lxx_lower && ilqr::variant_backward() != 2) { ilqr::launch_mirror_lxx(c->S, c->stream); c->lxx_lower = false; }
   // ... and no rows 8..23 of A_t / B_t: every kernel but the folded one reads them
   if (c->ab_unfold_h != 0.0) { ilqr::launch_unfold_rows(c->S, c->ab_unfold_h, c->stream); c->ab_unfold_h = 0.0; }
-  ilqr::launch_backward(c->S, ilqr::MASK_ALL, c->stream, c->lin_fold_h);
+  if (c->lin_fold_h != 0.0 && ilqr::variant_pack()) {
+    // analytic Jacobians and the operand-layout kernel (riccati_pack.hip): convert in place, run, convert back -- the stage API keeps
+    // the standard layout between calls (inside a solve the producers write the operand layout themselves)
+    if (c->lxx_lower) { ilqr::launch_mirror_lxx(c->S, c->stream); c->lxx_lower = false; }
+    ilqr::launch_pack_ab(c->S, c->stream); ilqr::launch_pack_lxx(c->S, c->stream);
+    ilqr::launch_backward_pack(c->S, ilqr::MASK_ALL, c->stream, c->lin_fold_h, nullptr, nullptr);
+    ilqr::launch_unpack_ab(c->S, c->lin_fold_h, c->stream); ilqr::launch_unpack_lxx(c->S, c->stream);
+  } else {
+    ilqr::launch_backward(c->S, ilqr::MASK_ALL, c->stream, c->lin_fold_h);
+  }
   STAGE_POST;
 }
 int ilqr_hip_stage_total_cost(ilqr_hip_ctx* c, double* cost) {

@@ -138,5 +138,13 @@ void launch_backward_mfma(const DevState& S, int mode, hipStream_t st);
 int backward_mfma_set_attr();
 void launch_backward_wave(const DevState& S, int mode, hipStream_t st, double fold_h, const int* list, const int* count);
 size_t backward_mfma_lds_bytes();
+// riccati_pack.hip: the one-wave kernel on the operand layout of riccati_pack.h and the conversions between that layout and the
+// standard one (in place, per knot region)
+int variant_pack();
+void launch_backward_pack(const DevState& S, int mode, hipStream_t st, double fold_h, const int* list, const int* count);
+void launch_pack_ab(const DevState& S, hipStream_t st);
+void launch_unpack_ab(const DevState& S, double h, hipStream_t st);
+void launch_pack_lxx(const DevState& S, hipStream_t st);
+void launch_unpack_lxx(const DevState& S, hipStream_t st);
 
 }  // namespace ilqr

@@ -977,7 +977,9 @@ void refresh_variants() {
   g_var.ls_split = env_split("ILQR_LS", LS_SPLIT_DEFAULT);
   e = getenv("ILQR_BACKWARD");
   g_var.backward = !e ? BACKWARD_DEFAULT : (e[0] == 'v') ? 1 : (e[0] == 'w' && e[1] == 'a') ? 2 : 0;
-  g_var.fold = !(e && strstr(e, "generic"));
+  // fold: 0 never ("wave-generic"), 1 the folded kernel on the standard layout ("wave-fold": cross-check), 2 the operand-layout kernel
+  // riccati_pack.hip (default)
+  g_var.fold = (e && strstr(e, "generic")) ? 0 : (e && strstr(e, "fold")) ? 1 : 2;
   e = getenv("ILQR_LINT");                                // 1: the one-knot two-wave tangent kernel (cross-check of k_lin_tangent2)
   g_var.lin_one_knot = (e && e[0] == '1') ? 1 : 0;
 }
@@ -985,6 +987,7 @@ int variant_ls_split() { return g_var.ls_split; }
 int variant_rollout_split() { return g_var.rollout_split; }
 int variant_backward() { return backward_kind(); }
 int variant_scalar_dyn() { return g_var.scalar_dyn; }
+int variant_pack() { return (backward_kind() == 2 && g_var.fold == 2) ? 1 : 0; }
 void launch_rollout(const DevState& S, const ProblemDev& P, int mode, int do_roll, int count_iter, double* cost_out, hipStream_t st) {
   // contact mode (f4) runs on the two-lane kernels (the one-lane register kernels are constraint-free only)
   if (!use_scalar_dyn()) { if (g_var.rollout_split || P.dyn.contact) launch_rollout_s(S, P, mode, do_roll, count_iter, cost_out, st); else launch_rollout_r(S, P, mode, do_roll, count_iter, cost_out, st); return; }
