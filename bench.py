@@ -42,8 +42,14 @@ FLOP_SOURCE = ("Riccati: exact count of the minimal-reuse formulation (SURVEY.md
 ITER_FLOPS_N25, ITER_BYTES_N25 = 27.8e6, 2.43e6
 # the same total from the counted figures: Riccati + N x (nominal step + Jacobians + line-search trial) + (N + 1) x quadratics
 ITER_FLOPS_COUNTED_N25 = 25 * (RICCATI_FLOPS_PER_KNOT + STEP_FLOPS + JACOBIAN_FLOPS_PER_KNOT + ALPHA_TRIAL_FLOPS_PER_KNOT) + 26 * QUAD_FLOPS_PER_KNOT
-# v_mfma_f64_16x16x4_f64 per knot issued by the one-wave Riccati kernel (riccati_wave.hip): folded / generic variant, 2048 flops each
-MFMA_PER_KNOT = {"folded": 429, "generic": 569}
+# v_mfma_f64_16x16x4_f64 per knot issued by the one-wave Riccati kernels, 2048 flops each: operand layout (riccati_pack.hip, the default
+# with analytic Jacobians), folded / generic on the standard layout (riccati_wave.hip)
+MFMA_PER_KNOT = {"packed": 354, "folded": 429, "generic": 569}
+
+
+def riccati_variant():
+    bk = os.environ.get("ILQR_BACKWARD", "wave")
+    return "generic" if "generic" in bk else ("folded" if "fold" in bk else "packed")
 
 
 def workload_label(args, B, N, iters, world, gravity):
@@ -146,7 +152,7 @@ def kernel_groups(args, B, N, n_slices):
     D = 8.0
     Bl = B / n_slices      # rollouts per kernel launch (a solve is enqueued slice by slice, include/ilqr_hip.h)
     bk_env = os.environ.get("ILQR_BACKWARD", "wave")
-    bk_name = {"wg": "k_backward_mfma", "va": "k_backward"}.get(bk_env[:2], "k_backward_wave")
+    bk_name = {"wg": "k_backward_mfma", "va": "k_backward"}.get(bk_env[:2], "k_backward_pack" if riccati_variant() == "packed" else "k_backward_wave")
     primal = "k_lin_primal_r" if os.environ.get("ILQR_ROLLOUT", "s")[:1] == "r" and not args.contact else "k_lin_primal_s"
     one_knot = os.environ.get("ILQR_LINT", "0") == "1"
     tangent = ("k_lin_tangent_c" if one_knot else "k_lin_tangent2c") if args.contact else ("k_lin_tangent" if one_knot else "k_lin_tangent2")
@@ -576,10 +582,10 @@ def main():
         roof["whole_iteration_frac"] = value * ITER_FLOPS_N25 * it_scale / (FP64_PEAK_TFLOPS * 1e12 * world)
         roof["whole_iteration_frac_hbm"] = value * ITER_BYTES_N25 * it_scale / (HBM_PEAK_GBS * 1e9 * world)
         roof["whole_iteration_frac_counted_flops"] = value * ITER_FLOPS_COUNTED_N25 * it_scale / (FP64_PEAK_TFLOPS * 1e12 * world)
-        if dom_kernel == "k_backward_wave" and d["avg_launch_ms"] > 0:
+        if dom_kernel in ("k_backward_wave", "k_backward_pack") and d["avg_launch_ms"] > 0:
             # `achieved` / `frac` are ALGORITHMIC-equivalent rates (914 786 flop per knot, the dense minimal-reuse count); the kernel
             # issues fewer, padded products: MFMA count x 2048 flops is what the hardware executes
-            variant = "folded" if (os.environ.get("ILQR_BACKWARD", "wave") == "wave") else "generic"
+            variant = riccati_variant()
             ex = MFMA_PER_KNOT[variant] * 2048.0 * N * (B / n_slices)
             roof["executed_mfma_flops_per_launch"] = ex
             roof["frac_executed_mfma"] = ex / (d["avg_launch_ms"] * 1e-3) / 1e12 / FP64_PEAK_TFLOPS

@@ -62,8 +62,12 @@ struct ilqr_hip_ctx {
   bool xbar_rolled = false, first_aside = false;
   int rolled_variant = -1;
   h1::DynParams rolled_dyn{};
-  bool lxx_lower = false;    // S.lxx of the knots t < N holds the tiles I >= J only (last written inside a solve): getters mirror them
-  double ab_unfold_h = 0.0;  // != 0: rows 8..23 of S.A / S.Bm are unwritten (last solve: folded Riccati kernel); = e_r + h row (r + 25), rebuilt on demand
+  // Layouts the last writer left behind (riccati_pack.h).  lxx: 0 whole matrices, 1 the tiles I >= J of the knots t < N only (getters
+  // mirror them), 2 operand layout; ab_packed: S.A / S.Bm in the operand layout; ab_pads_clean: the slots of those images that the
+  // tangent kernels never write are zeros (true after k_pack_zero_pads or a whole-batch k_pack_ab, false once anything wrote the
+  // standard layout over them).  The stage API and the getters convert on demand (in place, per knot region).
+  int lxx_layout = 0;
+  bool ab_packed = false, ab_pads_clean = false;
   double lin_fold_h = 0.0;   // step size h while S.A / S.Bm hold the analytic Jacobians (folded backward kernel), else 0
   std::string err;
   // profiling
@@ -516,12 +520,14 @@ static int enqueue_solve(ilqr_hip_ctx* c, const DevState& S, const h1::ProblemDe
   const int sel_mode = c->early_exit ? ilqr::MASK_ACTIVE : ilqr::MASK_ALL;
   const bool gate = c->early_exit && S.order && early_exit_gate(c);
   const bool xbar_rolled = c->first_aside;
-  // the one-wave Riccati kernel reads only the tiles I >= J of lxx_t (t < N): the cost quadratics then leave the others unwritten
-  const int lxx_lower = ilqr::variant_backward() == 2 ? 1 : 0;
-  c->lxx_lower = lxx_lower != 0;      // (iteration 0 rewrites lxx of every rollout: a solve on a full-matrix family leaves the whole matrix behind)
-  // ... and, folded, never the rows 8..23 of A_t / B_t: the two-knot tangent kernel then leaves them unwritten
-  const int skip_fold_rows = (fold_h != 0.0 && ilqr::linearize_skips_fold_rows(P, c->jac_mode)) ? 1 : 0;
-  c->ab_unfold_h = skip_fold_rows ? fold_h : 0.0;
+  // the operand-layout Riccati kernel (analytic Jacobians, riccati_pack.hip) has its producers write A_t, B_t and lxx~_t in its own
+  // layout; the generic one-wave kernel reads only the tiles I >= J of lxx_t (t < N): the cost quadratics then leave the others unwritten
+  const int pack = (fold_h != 0.0 && ilqr::variant_pack()) ? 1 : 0;
+  const int lxx_lower = pack ? 2 : (ilqr::variant_backward() == 2 ? 1 : 0);
+  // (iteration 0 rewrites A_t, B_t, lxx_t of every rollout: a solve leaves one layout behind; ilqr_hip_solve_async has prepared the padding)
+  c->lxx_layout = lxx_lower;
+  c->ab_packed = pack != 0;
+  if (!pack) c->ab_pads_clean = false;
   if (gate) TRY(ensure_gate(c));
   c->iterations_enqueued = c->max_iter;
   // One group's share of the concurrent region of an iteration -- linearisation (:576) on G.m, cost quadratics (:588) on G.q, the
@@ -554,7 +560,7 @@ static int enqueue_solve(ilqr_hip_ctx* c, const DevState& S, const h1::ProblemDe
     }
     { StageTimer T(c, 2, G.q); ilqr::launch_cost_quadratics(S, P, knot_mode, G.q, iter_l, lxx_lower, wl); }
     HIPCHK(c, hipEventRecord(G.join, G.q));
-    { StageTimer T(c, 1, G.m); ilqr::launch_linearize(S, P, knot_mode, c->jac_mode, c->fd_eps, G.m, 3, iter_l, skip_fold_rows, wl); }
+    { StageTimer T(c, 1, G.m); ilqr::launch_linearize(S, P, knot_mode, c->jac_mode, c->fd_eps, G.m, 3, iter_l, pack, wl); }
     if (concurrent_roll && G.lin && G.adopt) {
       HIPCHK(c, hipEventRecord(G.lin, G.m));
       HIPCHK(c, hipStreamWaitEvent(G.r, G.lin, 0)); HIPCHK(c, hipStreamWaitEvent(G.r, G.join, 0));
@@ -716,6 +722,7 @@ int ilqr_hip_solve_async(ilqr_hip_ctx* c) {
   c->spec_iterations = 0; c->split_iterations = 0;
   if (spec_enabled() && k <= 1 && !c->twin && (c->B <= spec_max() || (c->early_exit && early_exit_gate(c)))) TRY(ensure_twin(c));
   c->lin_fold_h = ilqr::linearize_fold_h(P, c->jac_mode);   // what S.A / S.Bm hold after this solve
+  if (c->lin_fold_h != 0.0 && ilqr::variant_pack() && !c->ab_pads_clean) { ilqr::launch_pack_zero_pads(S, st); c->ab_pads_clean = true; }
   c->first_aside = c->xbar_rolled && c->rolled_variant == rollout_kernel_identity(P) && same_dyn(c->rolled_dyn, P.dyn);
   c->xbar_rolled = false;                                   // after this solve xbar is an accepted line-search candidate
   if (k <= 1) {
@@ -833,24 +840,27 @@ int ilqr_hip_set_trajectory(ilqr_hip_ctx* c, const double* xbar, const double* u
 #define STAGE_PRE if (!c) return ILQR_ERR_ARG; if (!c->initialized) return ILQR_ERR_STATE; enter(c)
 #define STAGE_POST HIPCHK(c, hipGetLastError()); HIPCHK(c, hipStreamSynchronize(c->stream)); return ILQR_OK
 int ilqr_hip_stage_rollout(ilqr_hip_ctx* c) { STAGE_PRE; ilqr::launch_rollout(c->S, c->P, ilqr::MASK_ALL, 1, 0, c->S.Jbase, c->stream); STAGE_POST; }
-int ilqr_hip_stage_linearize(ilqr_hip_ctx* c) { STAGE_PRE; if (int rc = jacobians_available(c)) return rc; ilqr::launch_linearize(c->S, c->P, ilqr::MASK_ALL, c->jac_mode, c->fd_eps, c->stream); c->lin_fold_h = ilqr::linearize_fold_h(c->P, c->jac_mode); c->ab_unfold_h = 0.0; STAGE_POST; }
-int ilqr_hip_stage_cost_quadratics(ilqr_hip_ctx* c) { STAGE_PRE; if (!c->refs_set) return ILQR_ERR_STATE; ilqr::launch_cost_quadratics(c->S, c->P, ilqr::MASK_ALL, c->stream); c->lxx_lower = false; STAGE_POST; }
+int ilqr_hip_stage_linearize(ilqr_hip_ctx* c) { STAGE_PRE; if (int rc = jacobians_available(c)) return rc; ilqr::launch_linearize(c->S, c->P, ilqr::MASK_ALL, c->jac_mode, c->fd_eps, c->stream); c->lin_fold_h = ilqr::linearize_fold_h(c->P, c->jac_mode); c->ab_packed = false; c->ab_pads_clean = false; STAGE_POST; }
+int ilqr_hip_stage_cost_quadratics(ilqr_hip_ctx* c) { STAGE_PRE; if (!c->refs_set) return ILQR_ERR_STATE; ilqr::launch_cost_quadratics(c->S, c->P, ilqr::MASK_ALL, c->stream); c->lxx_layout = 0; STAGE_POST; }
+// layout conversions on demand (in place): what a consumer of the standard layout (getters, any kernel family but the operand-layout
+// one) or of the operand layout (stage API on riccati_pack.hip) calls first
+static void want_standard_ab(ilqr_hip_ctx* c) { if (c->ab_packed) { ilqr::launch_unpack_ab(c->S, c->lin_fold_h, c->stream); c->ab_packed = false; c->ab_pads_clean = false; } }
+static void want_standard_lxx(ilqr_hip_ctx* c, bool whole) {
+  if (c->lxx_layout == 2) { ilqr::launch_unpack_lxx(c->S, c->stream); c->lxx_layout = 0; }
+  if (c->lxx_layout == 1 && whole) { ilqr::launch_mirror_lxx(c->S, c->stream); c->lxx_layout = 0; }
+}
 int ilqr_hip_stage_backward_pass(ilqr_hip_ctx* c) {
   STAGE_PRE;
-  // the last solve left only the tiles I >= J of lxx_t behind and this call may run a kernel family that reads the whole matrix
-  if (c->lxx_lower && ilqr::variant_backward() != 2) { ilqr::launch_mirror_lxx(c->S, c->stream); c->lxx_lower = false; }
-  // ... and no rows 8..23 of A_t / B_t: every kernel but the folded one reads them
-  if (c->ab_unfold_h != 0.0) { ilqr::launch_unfold_rows(c->S, c->ab_unfold_h, c->stream); c->ab_unfold_h = 0.0; }
   if (c->lin_fold_h != 0.0 && ilqr::variant_pack()) {
-    // analytic Jacobians and the operand-layout kernel (riccati_pack.hip): convert in place, run, convert back -- the stage API keeps
-    // the standard layout between calls (inside a solve the producers write the operand layout themselves)
-    if (c->lxx_lower) { ilqr::launch_mirror_lxx(c->S, c->stream); c->lxx_lower = false; }
-    ilqr::launch_pack_ab(c->S, c->stream); ilqr::launch_pack_lxx(c->S, c->stream);
-    ilqr::launch_backward_pack(c->S, ilqr::MASK_ALL, c->stream, c->lin_fold_h, nullptr, nullptr);
-    ilqr::launch_unpack_ab(c->S, c->lin_fold_h, c->stream); ilqr::launch_unpack_lxx(c->S, c->stream);
+    // analytic Jacobians and the operand-layout kernel (riccati_pack.hip): convert in place what is not yet in its layout
+    if (!c->ab_packed) { ilqr::launch_pack_ab(c->S, c->stream); c->ab_packed = true; c->ab_pads_clean = true; }
+    if (c->lxx_layout != 2) { want_standard_lxx(c, true); ilqr::launch_pack_lxx(c->S, c->stream); c->lxx_layout = 2; }
   } else {
-    ilqr::launch_backward(c->S, ilqr::MASK_ALL, c->stream, c->lin_fold_h);
+    // any other family reads the standard layout (the one-wave kernel: the tiles I >= J of lxx_t, t < N, suffice)
+    want_standard_ab(c);
+    want_standard_lxx(c, ilqr::variant_backward() != 2);
   }
+  ilqr::launch_backward(c->S, ilqr::MASK_ALL, c->stream, c->lin_fold_h);
   STAGE_POST;
 }
 int ilqr_hip_stage_total_cost(ilqr_hip_ctx* c, double* cost) {
@@ -879,7 +889,7 @@ int ilqr_hip_stage_line_search(ilqr_hip_ctx* c, int* improved, double* new_cost,
 int ilqr_hip_get_linearization(ilqr_hip_ctx* c, double* A, double* Bm) {
   if (!c) return ILQR_ERR_ARG; enter(c);
   const size_t B = c->B, N = c->N;
-  if (c->ab_unfold_h != 0.0) { ilqr::launch_unfold_rows(c->S, c->ab_unfold_h, c->stream); c->ab_unfold_h = 0.0; HIPCHK(c, hipGetLastError()); }   // rows the last solve did not write
+  want_standard_ab(c); HIPCHK(c, hipGetLastError());      // (the last solve may have left the operand layout behind)
   HIPCHK(c, hipStreamSynchronize(c->stream));
   if (A) HIPCHK(c, hipMemcpy(A, c->S.A, B * N * ILQR_NX * ILQR_NX * sizeof(double), hipMemcpyDeviceToHost));
   if (Bm) HIPCHK(c, hipMemcpy(Bm, c->S.Bm, B * N * ILQR_NX * ILQR_NU * sizeof(double), hipMemcpyDeviceToHost));
@@ -892,18 +902,19 @@ int ilqr_hip_set_linearization(ilqr_hip_ctx* c, const double* A, const double* B
   HIPCHK(c, hipMemcpy(c->S.Bm, Bm, B * N * ILQR_NX * ILQR_NU * sizeof(double), hipMemcpyHostToDevice));
   c->initialized = true;
   c->lin_fold_h = 0.0;      // Jacobians of unknown origin: generic backward kernel
-  c->ab_unfold_h = 0.0;
+  c->ab_packed = false; c->ab_pads_clean = false;
   return ILQR_OK;
 }
 int ilqr_hip_get_quadratics(ilqr_hip_ctx* c, double* lx, double* lu, double* lxx, double* luu) {
   if (!c) return ILQR_ERR_ARG; enter(c);
   const size_t B = c->B, N = c->N;
+  if (lxx) { want_standard_lxx(c, false); HIPCHK(c, hipGetLastError()); }
   HIPCHK(c, hipStreamSynchronize(c->stream));
   if (lx) HIPCHK(c, hipMemcpy(lx, c->S.lx, B * (N + 1) * ILQR_NX * sizeof(double), hipMemcpyDeviceToHost));
   if (lu) HIPCHK(c, hipMemcpy(lu, c->S.lu, B * N * ILQR_NU * sizeof(double), hipMemcpyDeviceToHost));
   if (lxx) {
     HIPCHK(c, hipMemcpy(lxx, c->S.lxx, B * (N + 1) * ILQR_NX * ILQR_NX * sizeof(double), hipMemcpyDeviceToHost));
-    if (c->lxx_lower) {   // the last solve stored the tiles I >= J of the knots t < N only (quad_kernels.hip): lxx is symmetric
+    if (c->lxx_layout == 1) {   // the last solve stored the tiles I >= J of the knots t < N only (quad_kernels.hip): lxx is symmetric
       for (size_t k = 0; k < B * (N + 1); ++k) {
         if (k % (N + 1) == N) continue;
         double* H = lxx + k * ILQR_NX * ILQR_NX;
@@ -920,7 +931,7 @@ int ilqr_hip_set_quadratics(ilqr_hip_ctx* c, const double* lx, const double* lu,
   HIPCHK(c, hipMemcpy(c->S.lx, lx, B * (N + 1) * ILQR_NX * sizeof(double), hipMemcpyHostToDevice));
   HIPCHK(c, hipMemcpy(c->S.lu, lu, B * N * ILQR_NU * sizeof(double), hipMemcpyHostToDevice));
   HIPCHK(c, hipMemcpy(c->S.lxx, lxx, B * (N + 1) * ILQR_NX * ILQR_NX * sizeof(double), hipMemcpyHostToDevice));
-  c->lxx_lower = false;
+  c->lxx_layout = 0;
   HIPCHK(c, hipMemcpy(c->S.luu, luu, B * N * ILQR_NU * sizeof(double), hipMemcpyHostToDevice));
   return ILQR_OK;
 }

@@ -69,12 +69,12 @@ struct DevState {
 
 void launch_rollout(const DevState& S, const h1::ProblemDev& P, int mode, int do_roll, int count_iter, double* cost_out, hipStream_t st);
 void launch_step(int count, const double* x, const double* u, const h1::DynParams& dyn, double* xn, hipStream_t st, int stance_l = 1, int stance_r = 1);
-// skip_fold_rows != 0 (a solve whose backward pass is the folded one-wave Riccati kernel): rows 8..23 of A_t, B_t may stay unwritten
+// pack != 0 (a solve whose backward pass is the operand-layout Riccati kernel): A_t, B_t in the layout of riccati_pack.h (the two-knot
+// analytic kernels write it themselves, any other producer is followed by the conversion kernel)
 struct WorkList;
-void launch_linearize(const DevState& S, const h1::ProblemDev& P, int mode, int jac_mode, double eps, hipStream_t st, int phases = 3, int iter = -1, int skip_fold_rows = 0, const WorkList* wl = nullptr);
-int linearize_skips_fold_rows(const h1::ProblemDev& P, int jac_mode);
-void launch_unfold_rows(const DevState& S, double h, hipStream_t st);
-// lower != 0: knots t < N get only the tiles I >= J of lxx (what k_backward_wave loads); the stage API always asks for the full matrix
+void launch_linearize(const DevState& S, const h1::ProblemDev& P, int mode, int jac_mode, double eps, hipStream_t st, int phases = 3, int iter = -1, int pack = 0, const WorkList* wl = nullptr);
+// lower = 1: knots t < N get only the tiles I >= J of lxx (what k_backward_wave loads); 2: every knot in the operand layout of
+// riccati_pack.h (lx in row / column "aug"); the stage API always asks for the full matrix (0)
 void launch_cost_quadratics(const DevState& S, const h1::ProblemDev& P, int mode, hipStream_t st, int iter = -1, int lower = 0, const WorkList* wl = nullptr);
 // compacted list of the rollouts of a pass inside a solve (DevState::order), or nulls: MASK_ACTIVE at iteration iter -> list (iter, 0), MASK_RETRY -> (iter, 1)
 struct WorkList { const int* list; const int* count; };
@@ -142,7 +142,8 @@ size_t backward_mfma_lds_bytes();
 // standard one (in place, per knot region)
 int variant_pack();
 void launch_backward_pack(const DevState& S, int mode, hipStream_t st, double fold_h, const int* list, const int* count);
-void launch_pack_ab(const DevState& S, hipStream_t st);
+void launch_pack_ab(const DevState& S, hipStream_t st, int mode = MASK_ALL, const int* list = nullptr, const int* count = nullptr);
+void launch_pack_zero_pads(const DevState& S, hipStream_t st);
 void launch_unpack_ab(const DevState& S, double h, hipStream_t st);
 void launch_pack_lxx(const DevState& S, hipStream_t st);
 void launch_unpack_lxx(const DevState& S, hipStream_t st);

@@ -21,6 +21,7 @@
 #include "h1_linearize_contact_dev.h"
 #include <type_traits>
 #include "ilqr_kernels.h"
+#include "riccati_pack.h"
 
 using namespace h1;
 
@@ -137,6 +138,32 @@ __global__ void __launch_bounds__(128, 3) k_lin_tangent(DevState S, ProblemDev P
   LSTAMP(6)
 }
 
+// Column stores of the two-knot tangent kernels.  PACK (inside a solve whose backward pass is the operand-layout Riccati kernel,
+// riccati_pack.hip): column c of A_t goes to column slot pk_state_slot(c) of the packed image A~, row r to row slot pk_state_slot(r)
+// -- the 22 position rows (copies of their velocity rows through the integrator, lin_column) have no slot and are not written;
+// columns 0..15 of B_t go to the packed B0, columns 16..18 to column slots 60..62 of A~.  For a fixed row the lanes of a column tile
+// write consecutive addresses, as in the standard layout.  (Padding slots are zeroed once by k_pack_zero_pads when a handle's
+// buffers change over to this layout: nothing ever writes them afterwards.)
+template <bool PACK, class Cfn>
+DEVFN void lin2_store_A(const LinShared& L, int c, double* Ag, Cfn&& call) {
+  if (PACK) {
+    const int C = pk_state_slot(c);
+    double* col = pk_align(Ag) + (C >> 4) * 512 + (C & 15);
+    call([&](int r, double v) { const int R = pk_state_slot(r); if (R >= 32) col[(R - 32) * 16] = v; });
+  } else {
+    call([&](int r, double v) { Ag[r * H1_NX + c] = v; });
+  }
+}
+template <bool PACK, class Cfn>
+DEVFN void lin2_store_B(const LinShared& L, int c, double* Ag, double* Bg, Cfn&& call) {
+  if (PACK) {
+    double* col = c < 16 ? pk_align(Bg) + c : pk_align(Ag) + 3 * 512 + 12 + (c - 16);
+    call([&](int r, double v) { const int R = pk_state_slot(r); if (R >= 32) col[(R - 32) * 16] = v; });
+  } else {
+    call([&](int r, double v) { Bg[r * H1_NU + c] = v; });
+  }
+}
+
 // Round 4: TWO knots per four-wave workgroup (h1_linearize_dev.h "two knots per four-wave workgroup").  The one-knot kernel
 // above issued ~6600 vector instructions per knot with 47 / 38 / 25 of 64 lanes active and sat at 70 % VALU busy: it was bound by
 // its instruction count.  Without the three base-linear-velocity directions a chain group has 16 slots, so the lane-parallel
@@ -147,11 +174,9 @@ __global__ void __launch_bounds__(128, 3) k_lin_tangent(DevState S, ProblemDev P
 //   wave 3  integrator prologue of both knots (2 lanes)     | BAR |
 // then pelvis rows (wave = knot), the Minv product on the MFMA (wave = knot x row tile), the columns: A of knot 0 on wave 0,
 // A of knot 1 on wave 1, B of both knots on wave 2.  Work items are (selected rollout, knot) pairs in rollout-major order.
-// SKIP: inside a solve whose backward pass is the folded one-wave Riccati kernel the rows 8..23 of A_t and B_t -- hinge-position rows,
-// copies of their velocity rows through the integrator: row r = e_r + h row (r + 25) -- are read by nobody (riccati_wave.hip stage_A /
-// load_b0 with FOLD): they are not written (16 of 51 store instructions per column, 0.9 GB per launch at B = 4096); k_unfold_rows
-// rebuilds them for the getters and the other kernel families.
-template <bool SKIP>
+// PACK: operand layout of riccati_pack.h (lin2_store_A / lin2_store_B above); getters and the other kernel families get the standard
+// layout back from k_unpack_ab.
+template <bool PACK>
 __global__ void __launch_bounds__(256, 3) k_lin_tangent2(DevState S, ProblemDev P, int mode, const int* list, const int* count) {
   const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
   const int ks = tid >> 7, tid7 = tid & 127;                   // knot slot of this thread in the 128-thread phases
@@ -215,10 +240,10 @@ __global__ void __launch_bounds__(256, 3) k_lin_tangent2(DevState S, ProblemDev 
   LSTAMP(4)
   // each lane streams one column; for a fixed row the lanes write consecutive addresses
   if (wv < 2) {
-    if (lane < H1_NX && valid[wv]) { double* Ag = S.A + knot[wv] * H1_NX * H1_NX; lin_column(L2[wv], 0, lane, [&](int r, double v) { if (!(SKIP && r >= 8 && r < 24)) Ag[r * H1_NX + lane] = v; }); }
+    if (lane < H1_NX && valid[wv]) lin2_store_A<PACK>(L2[wv], lane, S.A + knot[wv] * H1_NX * H1_NX, [&](auto&& out) { lin_column(L2[wv], 0, lane, out); });
   } else if (wv == 2) {
     const int k = lane >> 5, c = lane & 31;
-    if (c < H1_NU && valid[k]) { double* Bg = S.Bm + knot[k] * H1_NX * H1_NU; lin_column(L2[k], 1, c, [&](int r, double v) { if (!(SKIP && r >= 8 && r < 24)) Bg[r * H1_NU + c] = v; }); }
+    if (c < H1_NU && valid[k]) lin2_store_B<PACK>(L2[k], c, S.A + knot[k] * H1_NX * H1_NX, S.Bm + knot[k] * H1_NX * H1_NU, [&](auto&& out) { lin_column(L2[k], 1, c, out); });
   }
   LSTAMP(5)
 }
@@ -285,6 +310,7 @@ __global__ void __launch_bounds__(128, 2) k_lin_tangent_c(DevState S, ProblemDev
 // four-wave workgroup"): the leg and arm sweeps of both knots on one wave each (64 lanes), the Minv columns of both knots on wave
 // 2 and the twelve unit-wrench columns of both on wave 3, one constraint solve per wave, the three base-linear-velocity
 // directions as kinematics-only lanes.
+template <bool PACK>
 __global__ void __launch_bounds__(256, 2) k_lin_tangent2c(DevState S, ProblemDev P, int mode, const int* list, const int* count) {
   const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
   const int ks = tid >> 7, tid7 = tid & 127;
@@ -349,10 +375,10 @@ __global__ void __launch_bounds__(256, 2) k_lin_tangent2c(DevState S, ProblemDev
   __syncthreads();
   LSTAMP(6)
   if (wv < 2) {
-    if (lane < H1_NX && valid[wv]) { double* Ag = S.A + knot[wv] * H1_NX * H1_NX; lin_column(L2[wv], 0, lane, [&](int r, double v) { Ag[r * H1_NX + lane] = v; }); }
+    if (lane < H1_NX && valid[wv]) lin2_store_A<PACK>(L2[wv], lane, S.A + knot[wv] * H1_NX * H1_NX, [&](auto&& out) { lin_column(L2[wv], 0, lane, out); });
   } else if (wv == 2) {
     const int k = lane >> 5, c = lane & 31;
-    if (c < H1_NU && valid[k]) { double* Bg = S.Bm + knot[k] * H1_NX * H1_NU; lin_column(L2[k], 1, c, [&](int r, double v) { Bg[r * H1_NU + c] = v; }, C2[k].G, C2[k].WU); }
+    if (c < H1_NU && valid[k]) lin2_store_B<PACK>(L2[k], c, S.A + knot[k] * H1_NX * H1_NX, S.Bm + knot[k] * H1_NX * H1_NU, [&](auto&& out) { lin_column(L2[k], 1, c, out, C2[k].G, C2[k].WU); });
   }
   LSTAMP(7)
 }
@@ -999,36 +1025,27 @@ void launch_step(int count, const double* x, const double* u, const DynParams& d
 }
 // phases: 1 = primal dump only, 2 = tangent sweeps / FD only, 3 = both
 // constraint-free tangent kernel: two knots per four-wave workgroup (default) or, ILQR_LINT=1, the one-knot two-wave kernel
-static void launch_lin_tangent_free(const DevState& S, const ProblemDev& P, int mode, hipStream_t st, const WorkList& w, int skip_fold_rows) {
-  if (g_var.lin_one_knot) { hipLaunchKernelGGL(k_lin_tangent, dim3(S.N, S.B), dim3(128), 0, st, S, P, mode, w.list, w.count); return; }
+static void launch_lin_tangent_free(const DevState& S, const ProblemDev& P, int mode, hipStream_t st, const WorkList& w, int pack) {
+  if (g_var.lin_one_knot) { hipLaunchKernelGGL(k_lin_tangent, dim3(S.N, S.B), dim3(128), 0, st, S, P, mode, w.list, w.count); if (pack) launch_pack_ab(S, st, mode, w.list, w.count); return; }
   const long items = (long)S.B * S.N;
-  if (skip_fold_rows) hipLaunchKernelGGL(k_lin_tangent2<true>, dim3((unsigned)((items + 1) / 2)), dim3(256), 0, st, S, P, mode, w.list, w.count);
+  if (pack) hipLaunchKernelGGL(k_lin_tangent2<true>, dim3((unsigned)((items + 1) / 2)), dim3(256), 0, st, S, P, mode, w.list, w.count);
   else hipLaunchKernelGGL(k_lin_tangent2<false>, dim3((unsigned)((items + 1) / 2)), dim3(256), 0, st, S, P, mode, w.list, w.count);
 }
-// rows 8..23 of A_t and B_t from their velocity rows (k_lin_tangent2<true> left them unwritten): the same expression lin_column evaluates
-__global__ void __launch_bounds__(256) k_unfold_rows(DevState S, double h) {
-  const size_t knot = blockIdx.x;
-  double* Ag = S.A + knot * H1_NX * H1_NX;
-  double* Bg = S.Bm + knot * H1_NX * H1_NU;
-  for (int e = threadIdx.x; e < 16 * H1_NX; e += 256) { const int r = 8 + e / H1_NX, k = e % H1_NX; Ag[r * H1_NX + k] = ((k == r) ? 1.0 : 0.0) + h * Ag[(r + 25) * H1_NX + k]; }
-  for (int e = threadIdx.x; e < 16 * H1_NU; e += 256) { const int r = 8 + e / H1_NU, k = e % H1_NU; Bg[r * H1_NU + k] = 0.0 + h * Bg[(r + 25) * H1_NU + k]; }
-}
-void launch_unfold_rows(const DevState& S, double h, hipStream_t st) { hipLaunchKernelGGL(k_unfold_rows, dim3((unsigned)((size_t)S.B * S.N)), dim3(256), 0, st, S, h); }
-// does launch_linearize(..., skip_fold_rows = 1) leave rows 8..23 unwritten?  (only the two-knot constraint-free tangent kernel does)
-int linearize_skips_fold_rows(const ProblemDev& P, int jac_mode) { return (jac_mode == 0 && !P.dyn.contact && !g_var.lin_one_knot) ? 1 : 0; }
-void launch_linearize(const DevState& S, const ProblemDev& P, int mode, int jac_mode, double eps, hipStream_t st, int phases, int iter, int skip_fold_rows, const WorkList* wl) {
+void launch_linearize(const DevState& S, const ProblemDev& P, int mode, int jac_mode, double eps, hipStream_t st, int phases, int iter, int pack, const WorkList* wl) {
   const WorkList w = wl ? *wl : work_list(S, mode, iter);
   if (jac_mode == 0 && !use_scalar_dyn()) {
     // primal dump: on two lanes per knot beside the two-lane rollout kernels, one lane per knot with ILQR_ROLLOUT=r
     if (phases & 1) { if (g_var.rollout_split || P.dyn.contact) launch_lin_primal_s(S, P, mode, st, w.list, w.count); else launch_lin_primal_r(S, P, mode, st); }   // (contact mode: the dump is the free solve, see k_lin_tangent_c)
     if ((phases & 2) && P.dyn.contact) {
-      if (g_var.lin_one_knot) hipLaunchKernelGGL(k_lin_tangent_c, dim3(S.N, S.B), dim3(128), 0, st, S, P, mode, w.list, w.count);
-      else hipLaunchKernelGGL(k_lin_tangent2c, dim3((unsigned)(((long)S.B * S.N + 1) / 2)), dim3(256), 0, st, S, P, mode, w.list, w.count);
+      const dim3 grid2((unsigned)(((long)S.B * S.N + 1) / 2));
+      if (g_var.lin_one_knot) { hipLaunchKernelGGL(k_lin_tangent_c, dim3(S.N, S.B), dim3(128), 0, st, S, P, mode, w.list, w.count); if (pack) launch_pack_ab(S, st, mode, w.list, w.count); }
+      else if (pack) hipLaunchKernelGGL(k_lin_tangent2c<true>, grid2, dim3(256), 0, st, S, P, mode, w.list, w.count);
+      else hipLaunchKernelGGL(k_lin_tangent2c<false>, grid2, dim3(256), 0, st, S, P, mode, w.list, w.count);
     }
-    else if (phases & 2) launch_lin_tangent_free(S, P, mode, st, w, skip_fold_rows);
+    else if (phases & 2) launch_lin_tangent_free(S, P, mode, st, w, pack);
   } else if (jac_mode == 0 && !P.dyn.contact) {               // ILQR_DYN=s: the analytic kernels are constraint-free only
     if (phases & 1) launch_lin_primal_r(S, P, mode, st);
-    if (phases & 2) launch_lin_tangent_free(S, P, mode, st, w, skip_fold_rows);
+    if (phases & 2) launch_lin_tangent_free(S, P, mode, st, w, pack);
   } else if ((phases & 2) && !use_scalar_dyn()) {
     launch_linearize_fd_s(S, P, mode, eps, st);       // forward differences on the two-lane step (any contact mode)
   } else if (phases & 2) {
@@ -1052,7 +1069,9 @@ void launch_backward(const DevState& S, int mode, hipStream_t st, double fold_h,
   else if (kind == 2) {
     // inside a solve (iter >= 0) the selected rollouts come from the compacted list of this pass
     const int slot = (S.order && iter >= 0 && mode != MASK_ALL) ? 2 * iter + (mode == MASK_RETRY ? 1 : 0) : -1;
-    launch_backward_wave(S, mode, st, g_var.fold ? fold_h : 0.0, slot >= 0 ? S.order + (size_t)slot * S.B : nullptr, slot >= 0 ? S.order_n + slot : nullptr);
+    const int* list = slot >= 0 ? S.order + (size_t)slot * S.B : nullptr; const int* count = slot >= 0 ? S.order_n + slot : nullptr;
+    if (g_var.fold == 2 && fold_h != 0.0) launch_backward_pack(S, mode, st, fold_h, list, count);      // (S.A, S.Bm, S.lxx in the operand layout: the caller's business)
+    else launch_backward_wave(S, mode, st, g_var.fold == 1 ? fold_h : 0.0, list, count);
   }
   else launch_backward_mfma(S, mode, st);
 }
@@ -1079,7 +1098,10 @@ void launch_control_spec(const DevState& S, const DevState& T, int iter, double 
 }
 void launch_spec_gate(const DevState& S, int iter, int max, int* g, hipStream_t st) { hipLaunchKernelGGL(k_spec_gate, dim3(1), dim3(1), 0, st, (const int*)(S.order_n + 2 * iter), max, g); }
 bool spec_dual_available(const ProblemDev& P) { return !use_scalar_dyn() && backward_kind() == 2 && (g_var.ls_split || P.dyn.contact); }
-void launch_backward_list(const DevState& S, hipStream_t st, double fold_h, const int* list, const int* count) { launch_backward_wave(S, MASK_ACTIVE, st, g_var.fold ? fold_h : 0.0, list, count); }
+void launch_backward_list(const DevState& S, hipStream_t st, double fold_h, const int* list, const int* count) {
+  if (g_var.fold == 2 && fold_h != 0.0) launch_backward_pack(S, MASK_ACTIVE, st, fold_h, list, count);
+  else launch_backward_wave(S, MASK_ACTIVE, st, g_var.fold == 1 ? fold_h : 0.0, list, count);
+}
 void launch_line_search_list(const DevState& S, const ProblemDev& P, hipStream_t st, const int* list, const int* count, int max_rollouts) { launch_line_search_s(S, P, MASK_ACTIVE, st, list, count, max_rollouts); }
 void launch_solve_begin(const DevState& S, hipStream_t st) { hipLaunchKernelGGL(k_solve_begin, dim3(cdiv(S.B, 64)), dim3(64), 0, st, S); }
 void launch_adopt_rollout(const DevState& S, const double* shadow, int mode, unsigned long long* mismatches, hipStream_t st) { hipLaunchKernelGGL(k_adopt_rollout, dim3(S.B), dim3(64), 0, st, S, shadow, mode, mismatches); }

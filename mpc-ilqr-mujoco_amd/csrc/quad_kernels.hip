@@ -27,6 +27,7 @@
 #include "h1_fast_math.h"
 #include "h1_model_constexpr.h"
 #include "ilqr_kernels.h"
+#include "riccati_pack.h"
 
 using namespace h1;
 
@@ -397,6 +398,8 @@ struct QuadLds {
   double tz[4][H1_NJ][3];                    // [0]: til_0 x z_j + P'_1,j (the CoM's two functionals merged); [1..3]: til_c x z_j
   double Pp[2][H1_NJ][3];                    // P'_j of the feet's functionals (slots 2, 3)
   double dg[H1_NX];                          // diagonal additions: Q (or Qf) + soft joint-limit penalty
+  double lxs[H1_NX];                         // operand layout (riccati_pack.h): the gradient lx, which rides in row / column "aug" of lxx~
+  unsigned pk[64];                           // ... and the slot table: state of slot s | row base of that state in the patch << 8
 };
 static_assert(sizeof(QuadLds) <= 16384, "QuadLds must fit ten two-wave workgroups per CU");
 static_assert(offsetof(QuadLds, aux) == sizeof(double) * QREC_SIZE, "aux directly behind rec: one base pointer for the column table");
@@ -529,10 +532,63 @@ DEVFN void quad_tile_out(const v4d_q& acc, const double* S2, const double* dg, d
     else if ((rows_ok || a < H1_NX) && (cols_ok || bb < H1_NX)) Hg[a * H1_NX + bb] = h;
   }
 }
+// Operand layout (riccati_pack.h; inside a solve with analytic Jacobians): the first-order product runs in SLOT order (the operands
+// are picked through the slot table), and tile (I, J), I >= J, is stored as the Riccati kernel's accumulator image: lane-major, the
+// lane's four registers contiguous (two 16-byte stores per lane, 2 KB per tile and wave).  The owner lane looks up the states (a, bb)
+// of its element; second-order entries exist where the smaller state is a quat | theta coordinate, i.e. anywhere but in tile (2, 2);
+// row and column "aug" carry the gradient; padding slots and the control-column slots are written as true zeros.
+struct QPkTable { unsigned w[64]; };
+constexpr QPkTable make_pk_table() {
+  QPkTable T{};
+  for (int s_ = 0; s_ < 64; ++s_) {
+    const int st = pk_slot_state(s_);
+    const int d = st - QS2_R0;
+    const int rb = (st >= QS2_R0 && st < QS2_R0 + QS2_NR) ? d * QS2_NC - (d * (d - 1)) / 2 : 0;
+    T.w[s_] = (unsigned)st | ((unsigned)rb << 8);
+  }
+  return T;
+}
+__constant__ static const QPkTable QPK = make_pk_table();
+template <int I, int J>
+DEVFN void quad_tile_out_pk(const v4d_q& acc, const double* S2, const double* dg, const double* lxs, const unsigned* pkt, double* Hp, int lane64, int lr, int lk) {
+  const unsigned wc = pkt[16 * J + lr];
+  const int bb = (int)(wc & 63u), rbc = (int)(wc >> 8);
+  v4d_q out;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    if (I == 1 && r >= 2) { out[r] = 0.0; continue; }         // slots 24..31: padding
+    const unsigned wr = pkt[16 * I + 4 * r + lk];
+    const int a = (int)(wr & 63u), rbr = (int)(wr >> 8);
+    double h = acc[r];
+    if (I == J) { const double d = dg[a < H1_NX ? a : 0]; h += (a == bb) ? d : 0.0; }
+    if (!(I == 2 && J == 2)) {
+      const bool a_lo = a < bb; const int lo = a_lo ? a : bb, hi = a_lo ? bb : a;
+      const bool cond = lo >= QS2_R0 && lo < QS2_R0 + QS2_NR && hi < H1_NX;
+      const double pv = S2[cond ? (a_lo ? rbr : rbc) + (hi - lo) : 0];
+      h += cond ? pv : 0.0;
+    }
+    constexpr bool mixed_rows = (I == 1) || (I == 3), mixed_cols = (J == 1) || (J == 3);
+    if (mixed_rows || mixed_cols) {
+      const bool real = a < H1_NX && bb < H1_NX;
+      double alt = 0.0;
+      if ((I == 1 && r == 1) || J == 1) {                        // row or column "aug"
+        const bool ra = a == PK_AUG && bb < H1_NX, ca = bb == PK_AUG && a < H1_NX;
+        const double lv = lxs[ra ? bb : (ca ? a : 0)];
+        alt = (ra || ca) ? lv : 0.0;
+      }
+      h = real ? h : alt;
+    }
+    out[r] = h;
+  }
+  *reinterpret_cast<v4d_q*>(Hp + pk_l_tile(I, J) * 256 + lane64 * 4) = out;
+}
+// low: 0 whole matrix, 1 the tiles I >= J in the standard layout, 2 the tiles I >= J in the operand layout
 template <int WV>
-DEVFN void quad_hessian_tiles(const double (&av)[4][2], const double (&bv)[4][4], const double* S2, const double* dg, double* Hg, bool low, int lr, int lk) {
+DEVFN void quad_hessian_tiles(const double (&av)[4][2], const double (&bv)[4][4], const double* S2, const double* dg, double* Hg, int low, int lr, int lk,
+                              const double* lxs, const unsigned* pkt, int lane64) {
   // row base of this lane's column as the smaller index of a patched pair (clamped into the patch: masked where it is not one)
   const int rbc0 = q_rowbase(lr < QS2_R0 ? QS2_R0 : lr), rbc1 = q_rowbase(16 + (lr < QS2_R0 + QS2_NR - 16 ? lr : QS2_R0 + QS2_NR - 17));
+  double* Hp = pk_align(Hg);
 #pragma unroll
   for (int Ii = 0; Ii < 2; ++Ii) {
     constexpr int I0 = WV;                                       // row tiles WV and WV + 2
@@ -544,6 +600,18 @@ DEVFN void quad_hessian_tiles(const double (&av)[4][2], const double (&bv)[4][4]
 #pragma unroll
       for (int J = 0; J < 4; ++J)
         if (!(low && J > I0 + 2 * Ii)) acc[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ks][Ii], bv[ks][J], acc[J], 0, 0, 0);      // (wave-uniform)
+    if (low == 2) {
+      if (Ii == 0) {
+        quad_tile_out_pk<I0, 0>(acc[0], S2, dg, lxs, pkt, Hp, lane64, lr, lk);
+        if (1 <= I0) quad_tile_out_pk<I0, I0 >= 1 ? 1 : 0>(acc[1], S2, dg, lxs, pkt, Hp, lane64, lr, lk);
+      } else {
+        quad_tile_out_pk<I0 + 2, 0>(acc[0], S2, dg, lxs, pkt, Hp, lane64, lr, lk);
+        quad_tile_out_pk<I0 + 2, 1>(acc[1], S2, dg, lxs, pkt, Hp, lane64, lr, lk);
+        quad_tile_out_pk<I0 + 2, 2>(acc[2], S2, dg, lxs, pkt, Hp, lane64, lr, lk);
+        if (3 <= I0 + 2) quad_tile_out_pk<I0 + 2, I0 + 2 >= 3 ? 3 : 0>(acc[3], S2, dg, lxs, pkt, Hp, lane64, lr, lk);
+      }
+      continue;
+    }
     if (Ii == 0) {
       quad_tile_out<I0, 0>(acc[0], S2, dg, Hg, lr, lk, rbc0, rbc1);
       if (!(low && 1 > I0)) quad_tile_out<I0, 1>(acc[1], S2, dg, Hg, lr, lk, rbc0, rbc1);
@@ -576,6 +644,7 @@ __global__ void __launch_bounds__(128, QUAD_WAVES) k_cost_quadratics(DevState S,
   int b = bs;
   if (list) { b = list[bs]; mode = MASK_ALL; }     // compacted selection (DevState::order): no per-rollout flags to fetch
   const bool term = (t == N);
+  const bool pk = lower == 2;            // operand layout (every knot, the terminal one included)
   __shared__ QuadLds L;
 #ifdef QUAD_STAMP
   long long qlast = clock64();
@@ -617,9 +686,11 @@ __global__ void __launch_bounds__(128, QUAD_WAVES) k_cost_quadratics(DevState S,
         patw[pass] = wv == 0 ? QPATCH.a[e < 158 ? e : 0] : QPATCH.b[e < 152 ? e : 0];
       }
     }
+    const unsigned pkw = QPK.w[lane & 63];
     if (!(f1 && f2)) return;
 #pragma unroll
     for (int k = 0; k < 4; ++k) { const int f = lane + 128 * k; if (f < QREC_SIZE) L.rec[f] = rv[k]; }
+    if (lane < 64) L.pk[lane] = pkw;
     // constants of the uniform column formula (QColTable): identity and zero vector; mfrac_s e_k and e_k x beta_s from the lanes that
     // hold mfrac_s (field 60 + s: lane 60 + s, k = 0) and beta_s[j] (field 64 + 3 s + j: lane 64 + 3 s + j, k = 0)
     if (lane < QAUX_SIZE) L.aux[lane] = (lane < 9 && lane % 4 == 0) ? 1.0 : 0.0;     // (everything else starts as zero; the writes below land behind the wave barrier)
@@ -695,6 +766,7 @@ __global__ void __launch_bounds__(128, QUAD_WAVES) k_cost_quadratics(DevState S,
       }
       S.lx[((size_t)b * N1 + t) * H1_NX + a] = g;
       L.dg[a] = dgl;
+      L.lxs[a] = g;
     }
   } else {
     const int l1 = lane - 64;
@@ -759,7 +831,7 @@ __global__ void __launch_bounds__(128, QUAD_WAVES) k_cost_quadratics(DevState S,
       const bool used = lk < 3 ? (sA != 0.0) : (has_bal != 0);
 #pragma unroll
       for (int T = 0; T < 4; ++T) {
-        const int e = 16 * T + lr, ec = e < H1_NX ? e : H1_NX - 1;
+        const int e = pk ? (int)(L.pk[16 * T + lr] & 63u) : 16 * T + lr, ec = e < H1_NX ? e : H1_NX - 1;      // operand layout: the state of slot 16 T + lr
         const double ra = rowA[ec], rb = rowB[ec];
         const bool ok = used && e < H1_NX;
         bv[ks][T] = ok ? rb : 0.0;
@@ -892,9 +964,9 @@ __global__ void __launch_bounds__(128, QUAD_WAVES) k_cost_quadratics(DevState S,
   // 2c: first-order product row tile by row tile; the owner lane of an accumulator element (row 16 I + 4 r + lk, column
   // 16 J + lr) adds the diagonal terms and the patch entry of its (unordered) index pair and stores it: for a fixed
   // register the wave writes four rows x 16 consecutive columns
-  const bool low = lower && !term;
-  if (wv == 0) quad_hessian_tiles<0>(av, bv, L.S2, L.dg, Hg, low, lr, lk);
-  else quad_hessian_tiles<1>(av, bv, L.S2, L.dg, Hg, low, lr, lk);
+  const int low = pk ? 2 : ((lower && !term) ? 1 : 0);
+  if (wv == 0) quad_hessian_tiles<0>(av, bv, L.S2, L.dg, Hg, low, lr, lk, L.lxs, L.pk, lane & 63);
+  else quad_hessian_tiles<1>(av, bv, L.S2, L.dg, Hg, low, lr, lk, L.lxs, L.pk, lane & 63);
   QSTAMP(5)
 }
 

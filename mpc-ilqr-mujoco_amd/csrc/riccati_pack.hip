@@ -517,10 +517,14 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
 // ------------------------------------------------------------------ layout conversions (stage API, getters; one workgroup per knot)
 // standard -> packed (in place: the knot's region is read whole into LDS first).  The 22 position rows are dropped: the caller
 // guarantees they are e_p + h * velocity row (analytic Jacobians).
-__global__ void __launch_bounds__(256) k_pack_ab(DevState S) {
+__global__ void __launch_bounds__(256) k_pack_ab(DevState S, int mode, const int* list, const int* count) {
   __shared__ double sa[PN * PN];
   __shared__ double sb[PN * PM];
-  const size_t knot = blockIdx.x;
+  const int bs = (int)(blockIdx.x / (unsigned)S.N), t = (int)(blockIdx.x % (unsigned)S.N);
+  int b = bs;
+  if (list) { if (bs >= *count) return; b = list[bs]; }
+  else if ((mode == MASK_ACTIVE && !S.active[b]) || (mode == MASK_RETRY && !(S.active[b] && S.need_retry[b]))) return;
+  const size_t knot = (size_t)b * S.N + t;
   double* Ag = S.A + knot * PN * PN;
   double* Bg = S.Bm + knot * PN * PM;
   for (int e = threadIdx.x; e < PN * PN; e += 256) sa[e] = Ag[e];
@@ -538,6 +542,16 @@ __global__ void __launch_bounds__(256) k_pack_ab(DevState S) {
     const int sr = pk_slot_state(R);
     pk_align(Bg)[e] = sr < PN ? sb[sr * PM + u] : 0.0;
   }
+}
+// the entries of the packed A~ / B0 images the tangent kernels never write: column slots 22..31 (vector slot, padding), row slots 60..62
+// (the control-column slots have no row)
+__global__ void __launch_bounds__(256) k_pack_zero_pads(DevState S) {
+  const size_t knot = blockIdx.x;
+  double* Ap = pk_align(S.A + knot * PN * PN);
+  double* Bp = pk_align(S.Bm + knot * PN * PM);
+  for (int e = threadIdx.x; e < 32 * 10; e += 256) { const int R = 32 + e / 10, C = 22 + e % 10; Ap[pk_a_index(R, C)] = 0.0; }
+  for (int e = threadIdx.x; e < 3 * 64; e += 256) { const int R = 60 + e / 64, C = e % 64; Ap[pk_a_index(R, C)] = 0.0; }
+  for (int e = threadIdx.x; e < 3 * 16; e += 256) { const int R = 60 + e / 16, u = e % 16; Bp[pk_b_index(R, u)] = 0.0; }
 }
 // packed -> standard; position rows rebuilt as lin_column writes them: e_p + h * velocity row (B: h * velocity row)
 __global__ void __launch_bounds__(256) k_unpack_ab(DevState S, double h) {
@@ -600,7 +614,8 @@ __global__ void __launch_bounds__(256) k_unpack_lxx(DevState S) {
 void launch_backward_pack(const DevState& S, int mode, hipStream_t st, double fold_h, const int* list, const int* count) {
   hipLaunchKernelGGL(k_backward_pack, dim3(S.B), dim3(64), 0, st, S, mode, fold_h, list, count);
 }
-void launch_pack_ab(const DevState& S, hipStream_t st) { hipLaunchKernelGGL(k_pack_ab, dim3((unsigned)((size_t)S.B * S.N)), dim3(256), 0, st, S); }
+void launch_pack_ab(const DevState& S, hipStream_t st, int mode, const int* list, const int* count) { hipLaunchKernelGGL(k_pack_ab, dim3((unsigned)((size_t)S.B * S.N)), dim3(256), 0, st, S, mode, list, count); }
+void launch_pack_zero_pads(const DevState& S, hipStream_t st) { hipLaunchKernelGGL(k_pack_zero_pads, dim3((unsigned)((size_t)S.B * S.N)), dim3(256), 0, st, S); }
 void launch_unpack_ab(const DevState& S, double h, hipStream_t st) { hipLaunchKernelGGL(k_unpack_ab, dim3((unsigned)((size_t)S.B * S.N)), dim3(256), 0, st, S, h); }
 void launch_pack_lxx(const DevState& S, hipStream_t st) { hipLaunchKernelGGL(k_pack_lxx, dim3((unsigned)((size_t)S.B * (S.N + 1))), dim3(256), 0, st, S); }
 void launch_unpack_lxx(const DevState& S, hipStream_t st) { hipLaunchKernelGGL(k_unpack_lxx, dim3((unsigned)((size_t)S.B * (S.N + 1))), dim3(256), 0, st, S); }

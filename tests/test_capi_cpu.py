@@ -102,7 +102,7 @@ def test_bench_picks_the_dominant_kernel_group_on_exclusive_equivalent_time():
     stage = {"iLQR_backwardPass": 20.0, "iLQR_backwardPass_retry": 15.0, "iLQR_lineSearch": 9.0, "iLQR_lineSearch_retry": 7.0,
              "iLQR_linearization": 37.0, "iLQR_costQuadratics": 19.0, "iLQR_computeCost+forwardRollout": 9.0}
     name, keys = bench.dominant_group(groups, stage)
-    assert name == "k_backward_wave" and keys == ["iLQR_backwardPass", "iLQR_backwardPass_retry"]      # 35 ms against 37 * 37 / 65 = 21 ms
+    assert name == "k_backward_pack" and keys == ["iLQR_backwardPass", "iLQR_backwardPass_retry"]      # 35 ms against 37 * 37 / 65 = 21 ms
     stage["iLQR_backwardPass"] = 2.0; stage["iLQR_backwardPass_retry"] = 1.0
     name, keys = bench.dominant_group(groups, stage)
     assert name == "k_lin_primal_s+k_lin_tangent2" and keys == ["iLQR_linearization"]

@@ -61,6 +61,7 @@ VARIANTS = [
     dict(ILQR_BACKWARD="wg", ILQR_LS="r", ILQR_ROLLOUT="r"),       # four-wave MFMA Riccati, one lane per trajectory
     dict(ILQR_BACKWARD="valu", ILQR_LS="s", ILQR_ROLLOUT="r"),     # VALU Riccati; mixed line search / rollout -> sequential re-rollout
     dict(ILQR_BACKWARD="wave", ILQR_DYN="s"),                      # scratch-resident scalar dynamics everywhere
+    dict(ILQR_BACKWARD="wave-fold", ILQR_LS="s", ILQR_ROLLOUT="s"),  # the folded one-wave Riccati kernel on the standard layout
 ]
 
 
@@ -147,10 +148,11 @@ def _riccati_numpy(A, Bm, lx, lu, lxx, luu, lam):
 
 @pytest.mark.parametrize("contact", [0, 2])
 def test_folded_backward_pass_equals_generic_kernel_and_numpy(contact):
-    """The one-wave Riccati kernel drops the k-steps of the hinge-position rows when the Jacobians come from the analytic
-    linearisation (riccati_wave.hip fold_rows: A[7+j] = e + h A[32+j], B[7+j] = h B[32+j]).  Same Jacobians and quadratics
-    through the folded kernel, the generic kernel (ILQR_BACKWARD=wave-generic) and NumPy; then with an indefinite Quu, where
-    the folded products feed the Gauss-Jordan fallback."""
+    """The one-wave Riccati kernels drop the k-steps of the position rows when the Jacobians come from the analytic linearisation
+    (A[p] = e_p + h A[v(p)], B[p] = h B[v(p)] for the nineteen hinge angles and the three base positions): riccati_pack.hip
+    (ILQR_BACKWARD=wave, the default: operand layout, all 22 rows) and riccati_wave.hip fold_rows (ILQR_BACKWARD=wave-fold: standard
+    layout, the sixteen rows that fill whole k-steps).  Same Jacobians and quadratics through both, the generic kernel
+    (ILQR_BACKWARD=wave-generic) and NumPy; then with an indefinite Quu, where the folded products feed the Gauss-Jordan fallback."""
     B = 3
     prob, x0, ui = standing(B, seed=17, gravity=[0.0, 0.0, -9.81] if contact else None)
     s = _solver(B); s.set_problem(prob); s.set_contact_mode(contact); s.set_options(jacobian_mode=0); s.set_regularization(1e-6)
@@ -159,48 +161,67 @@ def test_folded_backward_pass_equals_generic_kernel_and_numpy(contact):
     A, Bm = s.linearization()
     # the structure the fold relies on: exact off the diagonal, one rounding of 1 + h a on it (the kernel may fuse it)
     h = prob["dt"]
-    for j in range(19):
-        e = np.zeros(51); e[7 + j] = 1.0
-        assert np.abs(A[:, :, 7 + j, :] - (e + h * A[:, :, 32 + j, :])).max() <= 2.3e-16 and np.array_equal(Bm[:, :, 7 + j, :], h * Bm[:, :, 32 + j, :])
+    for p_, v_ in [(7 + j, 32 + j) for j in range(19)] + [(i, 26 + i) for i in range(3)]:
+        e = np.zeros(51); e[p_] = 1.0
+        assert np.abs(A[:, :, p_, :] - (e + h * A[:, :, v_, :])).max() <= 2.3e-16 and np.array_equal(Bm[:, :, p_, :], h * Bm[:, :, v_, :])
     lx, lu, lxx, luu = s.quadratics()
     for indefinite in (False, True):
         if indefinite:
             luu = luu.copy(); luu[:, 7, 3] = -4e4; luu[:, 20, 11] = -2.5e4
             s.set_quadratics(lx, lu, lxx, luu)
         out = {}
-        for kind in ("wave", "wave-generic"):
+        for kind in ("wave", "wave-fold", "wave-generic"):
             with env(ILQR_BACKWARD=kind):
                 s.stage_backward_pass()
                 out[kind] = (s.gains_K(), s.gains_kff()) + tuple(s.value_function())
         tol = 1e-6 if indefinite else 1e-9
-        for got, want in zip(out["wave"], out["wave-generic"]):
-            assert rel(got, want) < tol, (contact, indefinite, rel(got, want))
-        assert any(not np.array_equal(g, w) for g, w in zip(out["wave"], out["wave-generic"]))     # two different kernels did run
+        for kind in ("wave", "wave-fold"):
+            for got, want in zip(out[kind], out["wave-generic"]):
+                assert rel(got, want) < tol, (kind, contact, indefinite, rel(got, want))
+            assert any(not np.array_equal(g, w) for g, w in zip(out[kind], out["wave-generic"]))     # different kernels did run
+        assert any(not np.array_equal(g, w) for g, w in zip(out["wave"], out["wave-fold"]))
+        # the conversions to the operand layout and back leave the standard layout as it was (lxx: symmetrised from its stored half)
+        A_, B_ = s.linearization(); q_ = s.quadratics()
+        assert np.array_equal(A_, A) and np.array_equal(B_, Bm) and np.array_equal(q_[0], lx) and rel(q_[2], lxx) < 1e-12
         for b in range(B):
             ref = _riccati_numpy(A[b], Bm[b], lx[b], lu[b], lxx[b], luu[b], 1e-6)
-            for got, want in zip(out["wave"], ref):
-                assert rel(got[b], want) < 10 * tol, (contact, indefinite, b, rel(got[b], want))
+            for kind in ("wave", "wave-fold"):
+                for got, want in zip(out[kind], ref):
+                    assert rel(got[b], want) < 10 * tol, (kind, contact, indefinite, b, rel(got[b], want))
     s.close()
 
 
-def test_stage_backward_pass_on_another_kernel_family_after_a_solve_sees_the_whole_lxx():
-    """Inside a solve the cost quadratics store only the 16 x 16 tiles of lxx_t (t < N) on and below the diagonal (what the
-    one-wave Riccati kernel reads).  The stage API afterwards -- the getter, and the backward pass on a kernel family that reads the
-    full matrix -- must see the symmetric whole: tiles mirrored on the host (getter) / on the device (stage call)."""
+def _slot_tile():
+    """slot tile (0..3) of every state in the operand layout (csrc/riccati_pack.h pk_state_slot)"""
+    def slot(st):
+        return 19 + st if st < 3 else 51 + st if st < 7 else st - 7 if st < 26 else st + 25 if st < 29 else st + 29 if st < 31 else 63 if st == 31 else st
+    return np.array([slot(st) >> 4 for st in range(51)])
+
+
+@pytest.mark.parametrize("kind", ["wave", "wave-generic"])
+def test_stage_backward_pass_on_another_kernel_family_after_a_solve_sees_the_whole_lxx(kind):
+    """Inside a solve the cost quadratics store only half of the symmetric lxx_t: the tiles on and below the diagonal of the operand
+    layout (default kernel, riccati_pack.h: every knot, in slot order, with lx in the vector slot) or of the state order (generic
+    one-wave kernel: the knots t < N).  The stage API afterwards -- the getter, and the backward pass on a kernel family that reads
+    the full matrix in the standard layout -- must see the symmetric whole: mirrored by the conversion kernel / on the host (getter)
+    or on the device (stage call)."""
     B = 3
     prob, x0, ui = standing(B, seed=29)
-    s = _solver(B); s.set_problem(prob); s.set_max_iterations(2); s.set_options(early_exit=False)
-    s.initialize(x0, ui); s.solve()
-    lx, lu, lxx, luu = s.quadratics()
-    # strictly upper tiles of the knots t < N = the mirrored lower ones (bit for bit), and not zero; inside a diagonal tile the two
-    # halves are computed independently (symmetric to rounding, as the full matrix of the terminal knot is)
-    for I in range(4):
-        for J in range(I + 1, 4):
-            up = lxx[:, :-1, 16 * I:16 * I + 16, 16 * J:16 * J + 16]; lo = lxx[:, :-1, 16 * J:16 * J + 16, 16 * I:16 * I + 16]
-            assert np.array_equal(up, np.swapaxes(lo, -1, -2))
-    assert np.abs(lxx[:, :-1, :16, 16:]).max() > 0 and np.abs(lxx - np.swapaxes(lxx, -1, -2)).max() < 1e-9 * np.abs(lxx).max()
+    with env(ILQR_BACKWARD=kind):
+        s = _solver(B); s.set_problem(prob); s.set_max_iterations(2); s.set_options(early_exit=False)
+        s.initialize(x0, ui); s.solve()
+        Ksolve = s.gains_K()
+        lx, lu, lxx, luu = s.quadratics()
+    # entries whose two indices lie in different tiles exist once and are mirrored bit for bit; inside a diagonal tile the two halves
+    # are computed independently (symmetric to rounding)
+    tile = _slot_tile() if kind == "wave" else np.arange(51) >> 4
+    knots = slice(None) if kind == "wave" else slice(None, -1)
+    off = tile[:, None] != tile[None, :]
+    H = lxx[:, knots]
+    assert np.array_equal(H[..., off], np.swapaxes(H, -1, -2)[..., off])
+    assert np.abs(H[..., off]).max() > 0 and np.abs(lxx - np.swapaxes(lxx, -1, -2)).max() < 1e-9 * np.abs(lxx).max()
     s.set_regularization(1e-6)
-    with env(ILQR_BACKWARD="wave"):
+    with env(ILQR_BACKWARD=kind):
         s.stage_backward_pass(); Kw = s.gains_K()
     with env(ILQR_BACKWARD="valu"):
         s.stage_backward_pass(); Kv = s.gains_K()
@@ -212,32 +233,39 @@ def test_stage_backward_pass_on_another_kernel_family_after_a_solve_sees_the_who
     s.close()
 
 
-def test_rows_of_the_jacobians_the_folded_riccati_kernel_never_reads_are_rebuilt_on_demand():
-    """Inside a solve whose backward pass is the folded one-wave Riccati kernel the two-knot tangent kernel does not write the rows
-    8..23 of A_t / B_t (hinge-position rows = e_r + h x velocity row r + 25; riccati_wave.hip never fetches them).  The getter
-    rebuilds them: the result equals, to the last bits, what the one-knot kernel (ILQR_LINT=1, which writes every row and also
-    sweeps the three base-linear-velocity directions the two-knot kernel drops as analytically zero) leaves behind in the same
-    solve, and the structure holds exactly."""
+def test_position_rows_of_the_jacobians_have_no_slot_in_the_operand_layout_and_are_rebuilt_on_demand():
+    """Inside a solve whose backward pass is the operand-layout Riccati kernel the two-knot tangent kernel writes A_t / B_t straight into
+    that layout (riccati_pack.h), which has no slot for the 22 position rows (= e_p + h x their velocity row).  The getter converts
+    back and rebuilds them: the result equals, to the last bits, what the one-knot kernel (ILQR_LINT=1: standard layout, converted by
+    k_pack_ab inside the solve; it also sweeps the three base-linear-velocity directions the two-knot kernel drops as analytically
+    zero) and the standard-layout solve (ILQR_BACKWARD=wave-fold) leave behind, and the structure holds exactly."""
     B = 5
     prob, x0, ui = standing(B, seed=37)
     out = {}
-    for lint in ("0", "1"):
-        with env(ILQR_LINT=lint):
+    for name, var in (("pack", {}), ("lint", dict(ILQR_LINT="1")), ("fold", dict(ILQR_BACKWARD="wave-fold"))):
+        with env(**var):
             s = _solver(B); s.set_problem(prob); s.set_max_iterations(3); s.set_options(early_exit=False)
             s.initialize(x0, ui); s.solve()
-            out[lint] = s.linearization() + (s.gains_K(), s.cost())
+            out[name] = s.linearization() + (s.gains_K(), s.cost())
+            out[name + "2"] = s.linearization()          # (a second call finds the standard layout)
             s.close()
-    A2, B2, K2, c2 = out["0"]; A1, B1, K1, c1 = out["1"]
+    A2, B2, K2, c2 = out["pack"]
     h = prob["dt"]
     assert np.all(np.isfinite(A2)) and np.all(np.isfinite(B2))
-    # the solves agree (the rows in question are read by nobody; the dropped directions are zero to 1e-16)
-    assert rel(K2, K1) < 1e-9 and rel(c2, c1) < 1e-12
-    assert np.abs(A2 - A1).max() < 1e-12 and np.abs(B2 - B1).max() < 1e-12
+    assert np.array_equal(out["pack2"][0], A2) and np.array_equal(out["pack2"][1], B2)
+    for other in ("lint", "fold"):
+        A1, B1, K1, c1 = out[other]
+        assert rel(K2, K1) < 1e-9 and rel(c2, c1) < 1e-12, other
+        assert np.abs(A2 - A1).max() < 1e-12 and np.abs(B2 - B1).max() < 1e-12, other
+    # the two-knot kernel's entries are the same numbers in either layout (the rebuilt rows: to the rounding of 1 + h a)
+    pos = np.r_[0:3, 7:26]; vel = np.r_[26:29, 32:51]
+    kept = np.setdiff1d(np.arange(51), pos)
+    assert np.array_equal(A2[:, :, kept], out["fold"][0][:, :, kept]) and np.array_equal(B2[:, :, kept], out["fold"][1][:, :, kept])
+    assert np.abs(A2 - out["fold"][0]).max() <= 2.3e-16 and np.abs(B2 - out["fold"][1]).max() <= 2.3e-16
     # structure of the rebuilt rows
-    r = np.arange(8, 24)
-    E = np.zeros((16, 51)); E[np.arange(16), r] = 1.0
-    assert np.abs(A2[:, :, 8:24, :] - (E + h * A2[:, :, 33:49, :])).max() < 1e-15
-    assert np.abs(B2[:, :, 8:24, :] - h * B2[:, :, 33:49, :]).max() < 1e-15
+    E = np.zeros((22, 51)); E[np.arange(22), pos] = 1.0
+    assert np.abs(A2[:, :, pos, :] - (E + h * A2[:, :, vel, :])).max() < 1e-15
+    assert np.abs(B2[:, :, pos, :] - h * B2[:, :, vel, :]).max() < 1e-15
     # base linear velocity columns: d f / d v_lin = [h I; 0; I; 0] exactly in the two-knot kernel
     C = np.zeros((51, 3)); C[0:3] = h * np.eye(3); C[26:29] = np.eye(3)
     assert np.array_equal(A2[:, :, :, 26:29], np.broadcast_to(C, A2[:, :, :, 26:29].shape))

@@ -22,7 +22,7 @@ python3 tools/pmc_summary.py --traffic-json "$out/traffic_latest.json" --stamp "
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_WAVE_CYCLES --output-format csv \
   -d "$out/mfma" -o m -- python3 tools/time_stage.py backward 3 > "$out/mfma.log" 2>&1
 cp "$(find "$out/mfma" -name '*counter_collection.csv' | head -1)" "$out/${tag}_pmc/mfma_backward_wave_counter_collection.csv"
-python3 tools/pmc_summary.py "$out/${tag}_pmc/mfma_backward_wave_counter_collection.csv" | grep k_backward_wave > "$out/mfma_summary.txt" || true
+python3 tools/pmc_summary.py "$out/${tag}_pmc/mfma_backward_wave_counter_collection.csv" | grep "k_backward_\(wave\|pack\)" > "$out/mfma_summary.txt" || true
 rm -rf "$out/stats" "$out/fetch" "$out/write" "$out/mfma"
 tail -1 "$out/bench_stats.log" | cut -c1-200
 head -8 "$out/${tag}_kernel_stats.csv" | cut -c1-160

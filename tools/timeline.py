@@ -49,6 +49,6 @@ if len(sys.argv) > 3 and sys.argv[3] == "all":
         parts = []
         for r in seg:
             nm = r["Kernel_Name"].replace("void ", "").replace("ilqr::", "").split("(")[0].split("<")[0]
-            if nm in ("k_lin_primal_r", "k_lin_primal_s", "k_lin_tangent", "k_lin_tangent2", "k_lin_tangent2c", "k_quad_kin", "k_cost_quadratics", "k_backward_wave", "k_line_search_s", "k_rollout_s"):
+            if nm in ("k_lin_primal_r", "k_lin_primal_s", "k_lin_tangent", "k_lin_tangent2", "k_lin_tangent2c", "k_quad_kin", "k_cost_quadratics", "k_backward_wave", "k_backward_pack", "k_line_search_s", "k_rollout_s"):
                 parts.append("%s %.0f" % (nm[2:14], (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3))
         print("%4d %9.1f  %s" % (k, (b - a) / 1e3, "  ".join(parts)))
