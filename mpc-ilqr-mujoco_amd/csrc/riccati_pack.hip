@@ -225,6 +225,22 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
     const double h1r = (lk == 2) ? 0.0 : fh;       // register 1 of row tile 1: slots 20, 21 fold with h, the vector slot 22 does not (23: padding)
     const double hc1 = (lr == 6) ? 0.0 : fh;       // the same for column slots 16..31 -> 48..63
 #define AOP(J, s) L.Aop[((J) * 8 + (s)) * 64 + lane]
+    // A~ was staged into LDS during the previous knot (behind P6 / P7), B0 arrived in registers: nothing of this knot is in flight yet
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    wave_sync();
+    // ---- lxx~_t straight from HBM into the accumulators of P3 (issued now, needed after P1); lu_t, luu_t for the lanes that need them
+    v4d Qn[10];
+#ifdef PK_EXP_NOLXX
+#pragma unroll
+    for (int q = 0; q < 10; ++q) Qn[q] = (v4d){1.0, 0.0, 0.0, 1.0};
+#else
+    pload_q(Qn, pk_align(lpk + (size_t)t * n * n), lane);
+#endif
+    const double lu_c = lug[lr], lu_16 = lug[16 + (lk < 3 ? lk : 2)];
+    double luu4[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) luu4[r] = luug[4 * r + lk];
+    const double luu16 = luug[16 + (lk < 3 ? lk : 2)];
     // ---- M = sym(Q), M~ = F M F^T: the two bottom tile rows
     put_tile(L.T[0], Q[QI(1, 0)], lk, lr); put_tile(L.T[1], Q[QI(2, 0)], lk, lr); put_tile(L.T[2], Q[QI(2, 1)], lk, lr); put_tile(L.T[3], Q[QI(3, 1)], lk, lr);
     wave_sync();
@@ -250,17 +266,6 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
     }
     // the unfolded block M[0..1][0..1] (identity part of P1): the accumulators of W start from it
     const v4d M00 = Q[QI(0, 0)], M10 = Q[QI(1, 0)], M11 = Q[QI(1, 1)];
-    // ---- lxx~_t straight from HBM into the accumulators of P3 (issued now, needed after P1); lu_t, luu_t for the lanes that need them
-    v4d Qn[10];
-    pload_q(Qn, pk_align(lpk + (size_t)t * n * n), lane);
-    const double lu_c = lug[lr], lu_16 = lug[16 + (lk < 3 ? lk : 2)];
-    double luu4[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) luu4[r] = luug[4 * r + lk];
-    const double luu16 = luug[16 + (lk < 3 ? lk : 2)];
-    // A~ was staged into LDS during the previous knot, B0 arrived in registers
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    wave_sync();
     PSTAMP(0)
     // ---- P2: G0 = M~ B0
     v4d g0[4];
@@ -318,12 +323,12 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
     {
       const v4d quu = quu0 + quu1;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int ar = 4 * r + lk;
-        L.QL[ar * PLDQ + lr] = quu[r] + ((ar == lr) ? (luu4[r] + lam) : 0.0);
-        if (lr >= 12 && lr < 15) { const double v = qux0[3][r]; L.QL[ar * PLDQ + 4 + lr] = v; L.QL[(4 + lr) * PLDQ + ar] = v; }
+      for (int r = 0; r < 4; ++r) L.QL[(4 * r + lk) * PLDQ + lr] = quu[r] + ((4 * r + lk == lr) ? (luu4[r] + lam) : 0.0);
+      if (lr >= 12 && lr < 15) {      // columns 60..62 of Qux~[0..15, :] and of rows 60..62 of Q: Quu[:, 16..18]
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const double v = qux0[3][r]; L.QL[(4 * r + lk) * PLDQ + 4 + lr] = v; L.QL[(4 + lr) * PLDQ + 4 * r + lk] = v; }
+        if (lk < 3) L.QL[(16 + lk) * PLDQ + 4 + lr] = Qn[QI(3, 3)][3] + ((lk == lr - 12) ? (luu16 + lam) : 0.0);
       }
-      if (lk < 3 && lr >= 12 && lr < 15) L.QL[(16 + lk) * PLDQ + 4 + lr] = Qn[QI(3, 3)][3] + ((lk == lr - 12) ? (luu16 + lam) : 0.0);
     }
     wave_sync();
     PSTAMP(4)
@@ -351,7 +356,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
       }
     }
     PSTAMP(5)
-    // ---- the rest of P3 (tiles I >= J other than (3, 3)); rows 0..31 get their identity part W[0..31, :]
+    // ---- the rest of P3 (tiles I >= J other than (3, 3)); rows 0..31 get their identity part W[0..31, :] first (an add behind the
+    // last product would wait for the MFMA pipeline to drain)
+    Qn[QI(0, 0)] += W00; Qn[QI(1, 0)] += W10; Qn[QI(1, 1)] += W11;
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
       double ai[4];
@@ -362,7 +369,6 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
 #pragma unroll
         for (int J = 0; J <= I && J < 3; ++J) Qn[QI(I, J)] = pmfma(ai[I], Wb[s >> 2][J][s & 3], Qn[QI(I, J)]);
     }
-    Qn[QI(0, 0)] += W00; Qn[QI(1, 0)] += W10; Qn[QI(1, 1)] += W11;
     // Qu[16..18] = lu[16..18] + B[:, 16..18]^T Vx: rows 60..62 of column aug
     Qn[QI(3, 1)][3] += (lr == 6 && lk < 3) ? lu_16 : 0.0;
     PSTAMP(6)
@@ -373,7 +379,11 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
     {
 #pragma unroll
       for (int c = 0; c < PM; ++c) v[c] = L.QL[lane * PLDQ + c];
+#ifdef PK_EXP_NOCHOL
+      fail = 0;
+#else
       fail = pchol_linv(v, L.col, lane);
+#endif
       if (fail) {
         // ilqr.cpp:278-281: one retry with Quu + 1e-4 I
         if (lane < m) L.QL[lane * PLDQ + lane] += 1e-4;
@@ -402,7 +412,12 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
       pgauss_jordan_inverse(L, lane);
     }
     // ---- every operand of this knot has left the A~ buffer: stage the next knot behind P6 / P7
-    if (t > 0) {
+#ifndef PK_EXP_NOSTAGE
+    if (t > 0)
+#else
+    if (t > 100)
+#endif
+    {
       asm volatile("" ::: "memory");
       pstage_A(L, pk_align(S.A + ((size_t)b * N + (t - 1)) * n * n), lane);
       pload_b0(b0, pk_align(S.Bm + ((size_t)b * N + (t - 1)) * n * m), lane);
@@ -449,6 +464,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
       }
       // K[u][state of the column slot]: tiles 0 and 2 are whole runs of states (7 + lr, 32 + lr), tiles 1 and 3 mix; the vector slot
       // (tile 1, lr = 6) is k
+#ifdef PK_EXP_NOKSTORE
+      if (kk[0][0][0] == 123.456)
+#endif
       {
         double* K0 = Kg + lk * n + 7 + lr;
         double* K2 = Kg + lk * n + 32 + lr;

@@ -257,12 +257,8 @@ def test_position_rows_of_the_jacobians_have_no_slot_in_the_operand_layout_and_a
         A1, B1, K1, c1 = out[other]
         assert rel(K2, K1) < 1e-9 and rel(c2, c1) < 1e-12, other
         assert np.abs(A2 - A1).max() < 1e-12 and np.abs(B2 - B1).max() < 1e-12, other
-    # the two-knot kernel's entries are the same numbers in either layout (the rebuilt rows: to the rounding of 1 + h a)
-    pos = np.r_[0:3, 7:26]; vel = np.r_[26:29, 32:51]
-    kept = np.setdiff1d(np.arange(51), pos)
-    assert np.array_equal(A2[:, :, kept], out["fold"][0][:, :, kept]) and np.array_equal(B2[:, :, kept], out["fold"][1][:, :, kept])
-    assert np.abs(A2 - out["fold"][0]).max() <= 2.3e-16 and np.abs(B2 - out["fold"][1]).max() <= 2.3e-16
     # structure of the rebuilt rows
+    pos = np.r_[0:3, 7:26]; vel = np.r_[26:29, 32:51]
     E = np.zeros((22, 51)); E[np.arange(22), pos] = 1.0
     assert np.abs(A2[:, :, pos, :] - (E + h * A2[:, :, vel, :])).max() < 1e-15
     assert np.abs(B2[:, :, pos, :] - h * B2[:, :, vel, :]).max() < 1e-15

@@ -64,7 +64,15 @@ elif os.environ.get("ILQR_LSTAMPS"):
     for nme, v in zip(names, st):
         print("  %-28s %10.0f cycles  %5.1f %%" % (nme, v, 100 * v / st.sum()))
     print("  total %.0f cycles" % st.sum())
-if os.environ.get("ILQR_WSTAMPS"):
+if os.environ.get("ILQR_WSTAMPS") and "fold" not in os.environ.get("ILQR_BACKWARD", "wave") and "generic" not in os.environ.get("ILQR_BACKWARD", "wave"):
+    names = ["sym + fold (5 transposes), lxx loads, wait staging", "P2 + G0 transposes", "P4 + P5", "P1 tile 3, P3 (3,3)", "Quu -> LDS", "rest of P1", "rest of P3", "chol + Linv",
+             "stage next + P6a", "P6b + K store", "P7"]
+    st = s.cost()[:11]
+    tot = st.sum()
+    for nme, v in zip(names, st):
+        print("  %-50s %10.0f cycles  %5.1f %%" % (nme, v / N, 100 * v / tot))
+    print("  per knot total %.0f cycles (clock64 ticks)" % (tot / N))
+elif os.environ.get("ILQR_WSTAMPS"):
     names = ["wait staging, fix, lxx loads", "P2", "P4+P5", "P1 tile 3, P3 (3,3)", "Qu, Quu -> LDS", "rest of P1, P3", "chol + Linv", "stage next + P6a", "P6b + K store", "P7", "transposes"]
     st = s.cost()[:11]
     tot = st.sum()
