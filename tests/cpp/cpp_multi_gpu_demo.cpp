@@ -2,9 +2,10 @@
 // into contiguous shards, ONE RCCL gather of the first-knot payload [u0 | cost | K0] to rank 0 per MPC step
 // (ilqr_hip_comm_* / ilqr_hip_gather_first_knot in include/ilqr_hip.h).  The consumer of the gathered rows in the reference
 // is MPC::stepOnce (src/ilqr/mpc.cpp:97-113).  Test harness, not product code.
-//   usage: cpp_multi_gpu_demo <world> <batch_per_gpu> <with_gains 0|1> <out.bin> [device_of_every_rank]
-//   Every rank draws its shard from one global, deterministic batch; rank 0 writes the gathered [world * B][width] rows.
-//   With the optional last argument all ranks share that device (world must then be 1: RCCL refuses duplicate GPUs).
+//   usage: cpp_multi_gpu_demo <world> <batch_per_gpu> <with_gains 0|1> <out.bin> [device_of_every_rank [root]]
+//   Every rank draws its shard from one global, deterministic batch; the root (default 0) writes the gathered [world * B][width] rows.
+//   With the optional fifth argument all ranks share that device: world must then be 1 (RCCL refuses duplicate GPUs) unless the
+//   stand-in library tests/cpp/fake_rccl.cpp is selected with ILQR_RCCL_LIB (the -m gpu test of the world > 1 gather branch).
 #include <atomic>
 #include <cmath>
 #include <cstdio>
@@ -39,6 +40,8 @@ int main(int argc, char** argv) {
   if (argc < 5) { std::fprintf(stderr, "usage: %s world batch_per_gpu with_gains out.bin [device]\n", argv[0]); return 2; }
   const int world = std::atoi(argv[1]), B = std::atoi(argv[2]), with_gains = std::atoi(argv[3]);
   const int forced_dev = argc > 5 ? std::atoi(argv[5]) : -1;
+  const int root = argc > 6 ? std::atoi(argv[6]) : 0;
+  if (root < 0 || root >= world) { std::fprintf(stderr, "root out of range\n"); return 2; }
   const int N = 25; const double dt = 0.02;
   const int W = ilqr_hip_payload_width(with_gains);
   char id[ILQR_COMM_ID_BYTES] = {0};
@@ -69,10 +72,10 @@ int main(int argc, char** argv) {
       if (ilqr_hip_initialize(c, x0.data(), ui.data(), nullptr, nullptr) != ILQR_OK || ilqr_hip_solve(c, x0.data(), nullptr) != ILQR_OK)
         throw std::runtime_error(std::string("solve: ") + ilqr_hip_last_error(c));
       double* recv = nullptr;
-      if (rank == 0 && hipMalloc((void**)&recv, gathered.size() * sizeof(double)) != hipSuccess) throw std::runtime_error("hipMalloc");
-      if (ilqr_hip_gather_first_knot(c, 0, with_gains, recv) != ILQR_OK || ilqr_hip_synchronize(c) != ILQR_OK)
+      if (rank == root && hipMalloc((void**)&recv, gathered.size() * sizeof(double)) != hipSuccess) throw std::runtime_error("hipMalloc");
+      if (ilqr_hip_gather_first_knot(c, root, with_gains, recv) != ILQR_OK || ilqr_hip_synchronize(c) != ILQR_OK)
         throw std::runtime_error(std::string("gather: ") + ilqr_hip_last_error(c));
-      if (rank == 0) {
+      if (rank == root) {
         if (hipMemcpy(gathered.data(), recv, gathered.size() * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) throw std::runtime_error("hipMemcpy");
         (void)hipFree(recv);
       }

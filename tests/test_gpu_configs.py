@@ -747,3 +747,46 @@ def test_cpp_multi_gpu_demo_one_rank(tmp_path):
     s.initialize(x0, ui); c = s.solve(x0)
     assert rel(rows[:, 19], c) < 1e-9 and rel(rows[:, :19], s.ubar()[:, 0]) < 1e-8 and rel(rows[:, 20:].reshape(B, 19, 51), s.gains_K()[:, 0]) < 1e-7
     s.close()
+
+
+def _demo_and_fake_rccl():
+    exe = os.path.join(ROOT, "tests", "cpp", "build", "cpp_multi_gpu_demo")
+    fake = os.path.join(ROOT, "tests", "cpp", "build", "libfake_rccl.so")
+    assert os.path.exists(exe) and os.path.exists(fake), "built by __graft_entry__.build()"
+    return exe, fake
+
+
+@pytest.mark.parametrize("root", [0, 1])
+def test_world_2_gather_branch_of_the_c_abi_runs_on_one_device_through_a_stand_in_rccl(tmp_path, root):
+    """ilqr_hip_gather_first_knot with world > 1 (ilqr_capi.hip: ncclGroupStart, the root's ncclRecv loop with receive offsets r * cnt,
+    the peers' ncclSend, ncclGroupEnd) cannot run under real RCCL on a one-GPU box (it refuses a second rank on the same device).  A
+    test-only stand-in library (tests/cpp/fake_rccl.cpp: the eight symbols the loader resolves, send / recv between two
+    communicators of one process as stream-ordered device copies), selected with ILQR_RCCL_LIB, lets tests/cpp/cpp_multi_gpu_demo
+    run it with two host threads and two handles on device 0: the root's [2 B][989] rows equal the single-handle solve of the whole
+    batch bit for bit, for either root.  The consumer of these rows in the reference: MPC::stepOnce (src/ilqr/mpc.cpp:97-113)."""
+    exe, fake = _demo_and_fake_rccl()
+    B, W = 5, 20 + 19 * 51
+    two, one = str(tmp_path / "two.bin"), str(tmp_path / "one.bin")
+    r = subprocess.run([exe, "2", str(B), "1", two, "0", str(root)], capture_output=True, text=True, timeout=600, env=dict(os.environ, ILQR_RCCL_LIB=fake))
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([exe, "1", str(2 * B), "1", one, "0"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    rows2, rows1 = np.fromfile(two).reshape(2 * B, W), np.fromfile(one).reshape(2 * B, W)
+    assert np.all(np.isfinite(rows1)) and np.abs(rows1[:, 20:]).max() > 0
+    assert np.array_equal(rows2, rows1)
+    # (without gains: the 160-byte payload rows)
+    r = subprocess.run([exe, "2", str(B), "0", two, "0", str(root)], capture_output=True, text=True, timeout=600, env=dict(os.environ, ILQR_RCCL_LIB=fake))
+    assert r.returncode == 0, r.stderr
+    assert np.array_equal(np.fromfile(two).reshape(2 * B, 20), rows1[:, :20])
+
+
+def test_an_rccl_error_inside_the_gather_group_closes_the_group_and_surfaces_through_last_error(tmp_path):
+    """An ncclRecv that fails inside the group (injected by the stand-in library) still has the group closed (ncclGroupEnd is called,
+    the peer's ncclGroupEnd returns instead of waiting forever) and comes back as ILQR_ERR_HIP with the RCCL error text in
+    ilqr_hip_last_error; the demo prints it and exits non-zero."""
+    exe, fake = _demo_and_fake_rccl()
+    out = str(tmp_path / "never.bin")
+    r = subprocess.run([exe, "2", "3", "0", out, "0"], capture_output=True, text=True, timeout=600, env=dict(os.environ, ILQR_RCCL_LIB=fake, FAKE_RCCL_FAIL_RECV="1"))
+    assert r.returncode == 1 and not os.path.exists(out)
+    assert "RCCL gather (grouped send/recv)" in r.stderr and "injected" in r.stderr, r.stderr
+    assert "rank 0: gather" in r.stderr and "rank 1: gather" in r.stderr, r.stderr      # the peer's group end reported the remote failure
