@@ -47,9 +47,15 @@ ITER_FLOPS_COUNTED_N25 = 25 * (RICCATI_FLOPS_PER_KNOT + STEP_FLOPS + JACOBIAN_FL
 MFMA_PER_KNOT = {"packed": 354, "folded": 429, "generic": 569}
 
 
+JAC_FD = False      # set from --jacobians: forward-difference Jacobians carry no structure, the generic Riccati kernel runs
+
+
 def riccati_variant():
     bk = os.environ.get("ILQR_BACKWARD", "wave")
-    return "generic" if "generic" in bk else ("folded" if "fold" in bk else "packed")
+    return "generic" if ("generic" in bk or JAC_FD) else ("folded" if "fold" in bk else "packed")
+
+
+FD_STEPS_PER_KNOT = 71.0             # base step + 51 state columns + 19 control columns (robot_utils.cpp:126-160)
 
 
 def workload_label(args, B, N, iters, world, gravity):
@@ -95,6 +101,10 @@ def parse():
     ap.add_argument("--contact", action="store_true",
                     help="not the headline: contact row f4 (unilateral rigid stance on the scheduled feet, physical gravity -9.81, two-lane kernels, analytic Jacobians of the constrained step)")
     ap.add_argument("--no-contact-line", action="store_true", help="skip the short contact-mode measurement added to the default line")
+    ap.add_argument("--jacobians", choices=["analytic", "fd"], default="analytic",
+                    help="fd: the reference's own scheme, forward differences with eps 1e-5 (robot_utils.cpp:120-160: 71 steps per knot) -- the like-for-like line "
+                         "against cpu_baseline, which times the oracle with the same scheme; the default line carries a short measurement of it as its `fd` object")
+    ap.add_argument("--no-fd-line", action="store_true", help="skip the short forward-difference measurement added to the default line")
     ap.add_argument("--workload", choices=["default", "config3", "config4"], default="default",
                     help="default: --batch / --horizon as given (BASELINE configs[2] by default).  config3 / config4: the GLOBAL batch of BASELINE.json "
                          "configs[3] (32768 standing rollouts, N = 25) / configs[4] (8192 windows of the H1 walking reference, N = 50, contact-scheduled "
@@ -165,9 +175,9 @@ def kernel_groups(args, B, N, n_slices):
                       flops=ALPHA_TRIAL_FLOPS_PER_KNOT * N * Bl,      # the accepted alpha's trial is the algorithmic work
                       bytes=D * Bl * N * ((969 + 19 + 51 + 19) + 8 * (51 + 19))),
         # (group names = the kernels' names as rocprofv3 / profiles/traffic_latest.json list them, template arguments stripped)
-        primal + "+" + tangent: dict(stages=["iLQR_linearization"], unit="fp64 VALU",
-                                     flops=JACOBIAN_FLOPS_PER_KNOT * N * Bl,
-                                     bytes=D * Bl * N * (70 + 493 + 493 + 70 + 2601 + 969)),      # x, u, dump written + read, A_t, B_t
+        ("k_fd_steps_s+k_fd_finish" if JAC_FD else primal + "+" + tangent): dict(stages=["iLQR_linearization"], unit="fp64 VALU",
+                                     flops=(FD_STEPS_PER_KNOT * STEP_FLOPS if JAC_FD else JACOBIAN_FLOPS_PER_KNOT) * N * Bl,
+                                     bytes=D * Bl * N * ((70 + 2601 + 969) if JAC_FD else (70 + 493 + 493 + 70 + 2601 + 969))),      # x, u, (dump written + read,) A_t, B_t
         "k_quad_kin+k_cost_quadratics": dict(stages=["iLQR_costQuadratics"], unit="fp64 VALU",
                                   flops=QUAD_FLOPS_PER_KNOT * (N + 1) * Bl,
                                   bytes=D * Bl * (N + 1) * (70 + 2601 + 51 + 19 + 19)),           # x, u, lxx, lx, lu, luu (the per-knot record between the two kernels is not algorithmic)
@@ -282,6 +292,10 @@ def main():
         return
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
+    global JAC_FD
+    JAC_FD = args.jacobians == "fd"
+    if JAC_FD:
+        args.no_fd_line = True
     if args.workload != "default":
         if args.gpus != 1:
             raise SystemExit("--workload config3 / config4 are the one-GPU anchors (the whole global batch on one device); the 8-GPU points are --gpus 8 with the default workload")
@@ -337,7 +351,8 @@ def main():
     s.set_max_iterations(iters)
     if args.contact:
         s.set_contact_mode(2)
-    s.set_options(jacobian_mode=sv.JAC_ANALYTIC, early_exit=False)
+    jac_mode = sv.JAC_FD_FORWARD if JAC_FD else sv.JAC_ANALYTIC
+    s.set_options(jacobian_mode=jac_mode, fd_eps=1e-5, early_exit=False)
     s.enable_profiling(True)
 
     dev = torch.device("cuda", local_rank)
@@ -473,7 +488,7 @@ def main():
 
     # second number: the same MPC step with the reference's convergence exit enabled -- iterations
     # actually executed per second; not the headline value
-    s.set_options(jacobian_mode=sv.JAC_ANALYTIC, early_exit=True)
+    s.set_options(jacobian_mode=jac_mode, fd_eps=1e-5, early_exit=True)
     s.enable_profiling(False)
     one_step(False)
     torch.cuda.synchronize()
@@ -517,6 +532,38 @@ def main():
                         "workload": "same batch, gravity [0, 0, -9.81], both feet scheduled in stance: unilateral rigid stance constraints in rollout / line search, "
                                     "analytic Jacobians of the constrained step, %d fixed iterations" % iters}
         s.set_contact_mode(0)
+
+    # fourth number (not the headline): the same batch with the REFERENCE'S OWN Jacobian scheme, forward differences
+    # with eps 1e-5 (RobotUtils::linearizeDynamicsFD, robot_utils.cpp:120-160: one base step + 70 perturbed steps per knot), fixed
+    # iterations -- the like-for-like line against cpu_baseline (the oracle is timed with the same scheme).  Its own roofline: the FD
+    # kernel pair's span (HIP events on its launch stream) against 71 dynamics steps per knot.
+    fd_line = None
+    if not args.contact and not args.no_fd_line and not JAC_FD and world == 1 and args.workload == "default":
+        s.set_problem(prob); s.set_contact_mode(0); s.set_options(jacobian_mode=sv.JAC_FD_FORWARD, fd_eps=1e-5, early_exit=False)
+
+        def fstep():
+            s.initialize_device(x0_d.data_ptr(), ui_d.data_ptr()); s.solve_async(); s.synchronize()
+        fstep()
+        s.enable_profiling(True); s.set_profiled_stages(["iLQR_linearization"])      # event pairs around the linearisation's launches only
+        torch.cuda.synchronize(); tf0 = time.perf_counter()
+        fsteps = 2
+        for _ in range(fsteps):
+            fstep()
+        torch.cuda.synchronize(); tf = time.perf_counter() - tf0
+        assert np.all(s.iterations() == iters) and np.all(np.isfinite(s.cost()))
+        fms, fn = s.stage_ms()      # (of the last solve: one span per iteration)
+        lin_ms = float(fms["iLQR_linearization"]) / max(1.0, float(fn["iLQR_linearization"]))
+        fd_flops = FD_STEPS_PER_KNOT * STEP_FLOPS * N * B
+        fd_bytes = 8.0 * B * N * (70 + 2601 + 969)
+        fd_line = {"value": B * iters * fsteps / tf, "unit": "iterations/s", "ms_per_step": 1e3 * tf / fsteps,
+                   "jacobians": "forward differences, eps 1e-5, 71 steps per knot (robot_utils.cpp:120-160); the generic one-wave Riccati kernel (no row structure to fold)",
+                   "roofline": {"kernel": "k_fd_steps_s+k_fd_finish", "bound": "fp64 VALU (latency: one wave per SIMD)", "avg_launch_ms": lin_ms,
+                                "algorithmic_flops_per_launch": fd_flops, "algorithmic_bytes_per_launch": fd_bytes,
+                                "frac_compute": fd_flops / (lin_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS if lin_ms > 0 else None,
+                                "frac_hbm": fd_bytes / (lin_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if lin_ms > 0 else None,
+                                "note": "span of the pair's launches inside the solve (beside the cost quadratics and the re-rollout on their own streams)"}}
+        s.enable_profiling(False); s.set_profiled_stages(None)
+        s.set_options(jacobian_mode=sv.JAC_ANALYTIC, early_exit=False)
 
     if rank == 0:
         total_iters = float(world) * B * iters * args.steps
@@ -638,6 +685,8 @@ def main():
         }
         if contact_line is not None:
             out["contact"] = contact_line
+        if fd_line is not None:
+            out["fd"] = fd_line
         if args.workload == "config4":
             out["cpu_baseline"] = None     # (the oracle's OpenMP batch shares ONE reference set; per-rollout windows are checked rollout by rollout in the -m gpu tests)
         elif not args.no_cpu_baseline and world == 1:   # the CPU baseline is timed on rank 0 of the one-GPU run only
