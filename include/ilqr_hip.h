@@ -47,6 +47,11 @@ typedef struct ilqr_hip_ctx ilqr_hip_ctx;
    The H1 model constants (h1.xml / h1.urdf) are compiled in.  device = HIP device ordinal. */
 int ilqr_hip_create(ilqr_hip_ctx** out, int device, int batch, int horizon, double dt);
 int ilqr_hip_destroy(ilqr_hip_ctx* ctx);
+/* The diagnostic environment switches (kernel families ILQR_BACKWARD / ILQR_LS / ILQR_ROLLOUT / ILQR_DYN / ILQR_LINT, launch orders
+   ILQR_SLICES / ILQR_STAGGER / ILQR_OVERLAP_ROLLOUT / ILQR_REUSE_ROLLOUT / ILQR_EE_GATE / ILQR_SPLIT / ILQR_SPEC*) are read ONCE, by
+   ilqr_hip_create, and kept in the handle: no getenv on the call path.  This call re-reads them for one handle (tests, profiling
+   tools); ILQR_ENV_PER_CALL=1 at creation makes every call of the handle do so.  No reference counterpart. */
+int ilqr_hip_reload_environment(ilqr_hip_ctx* ctx);
 const char* ilqr_hip_last_error(const ilqr_hip_ctx* ctx);
 int ilqr_hip_batch(const ilqr_hip_ctx* ctx);
 int ilqr_hip_horizon(const ilqr_hip_ctx* ctx);

@@ -20,6 +20,34 @@
 
 using ilqr::DevState;
 
+// Environment switches (diagnostics, tests): ONE pass over the environment when a handle is created, kept in the handle; no getenv on
+// the call path.  ILQR_ENV_PER_CALL=1 (itself read at creation) restores the re-read at the top of every C-ABI call -- the test
+// suite and the tools that switch kernel families within one process set it (tests/conftest.py); ilqr_hip_reload_environment
+// re-reads on demand.
+struct Knobs {
+  ilqr::Variants var;
+  int slices, stagger, overlap_rollout, reuse_rollout, ee_gate /* -1: the handle's own setting */, split /* -1: on with the convergence exit */, spec, spec_dual, spec_max;
+  bool per_call;
+};
+static Knobs read_knobs() {
+  Knobs k;
+  auto geti = [](const char* n, int d) { const char* e = getenv(n); return e ? atoi(e) : d; };
+  k.var = ilqr::read_variants();
+#ifndef SLICES_DEFAULT
+#define SLICES_DEFAULT 1
+#endif
+  k.slices = geti("ILQR_SLICES", SLICES_DEFAULT);
+  k.stagger = geti("ILQR_STAGGER", 1);
+  k.overlap_rollout = geti("ILQR_OVERLAP_ROLLOUT", 1);
+  { const char* e = getenv("ILQR_REUSE_ROLLOUT"); k.reuse_rollout = (e && e[0] == '1') ? 1 : 0; }
+  k.ee_gate = geti("ILQR_EE_GATE", -1);
+  k.split = geti("ILQR_SPLIT", -1);
+  k.spec = geti("ILQR_SPEC", 1);
+  k.spec_dual = geti("ILQR_SPEC_DUAL", 1);
+  k.spec_max = geti("ILQR_SPEC_MAX", 512);
+  k.per_call = geti("ILQR_ENV_PER_CALL", 0) != 0;
+  return k;
+}
 struct ilqr_hip_ctx {
   int device = 0, B = 0, N = 0;
   hipStream_t stream = nullptr;
@@ -68,6 +96,7 @@ struct ilqr_hip_ctx {
   // standard layout over them).  The stage API and the getters convert on demand (in place, per knot region).
   int lxx_layout = 0;
   bool ab_packed = false, ab_pads_clean = false;
+  Knobs knobs = read_knobs();   // (constructed in ilqr_hip_create)
   double lin_fold_h = 0.0;   // step size h while S.A / S.Bm hold the analytic Jacobians (folded backward kernel), else 0
   std::string err;
   // profiling
@@ -127,7 +156,11 @@ struct StageTimer {
   ~StageTimer() { if (a && b) { hipEventRecord(b, st); c->spans.push_back({stage, a, b}); } }
 };
 
-static inline void enter(const ilqr_hip_ctx* c) { hipSetDevice(c->device); ilqr::refresh_variants(); }
+static inline void enter(ilqr_hip_ctx* c) {
+  hipSetDevice(c->device);
+  if (c->knobs.per_call) c->knobs = read_knobs();
+  ilqr::set_variants(c->knobs.var);
+}
 
 extern "C" {
 
@@ -397,19 +430,13 @@ static void collect_profile(ilqr_hip_ctx* c) {
   c->spans.clear(); c->pool_next = 0;
 }
 
-static int reuse_rollout() { const char* e = getenv("ILQR_REUSE_ROLLOUT"); return (e && e[0] == '1') ? 1 : 0; }   // read at every solve, like every other switch
-#ifndef SLICES_DEFAULT
-#define SLICES_DEFAULT 1
-#endif
-static int slices_wanted(int B) {      // read at every solve: tests switch it within one process
-  const char* e = getenv("ILQR_SLICES");
-  int k = e ? atoi(e) : SLICES_DEFAULT;
+static int slices_wanted(const ilqr_hip_ctx* c, int B) {
+  int k = c->knobs.slices;
   if (k < 1) k = 1;
   if (k > 32) k = 32;
   while (k > 1 && B / k < 64) --k;   // a slice is at least one wave of the widest kernels
   return k;
 }
-static int stagger_wanted() { const char* e = getenv("ILQR_STAGGER"); return e ? atoi(e) : 1; }
 // view of rollouts [b0, b0 + Bs) of the batch (every array is rollout-major)
 static DevState slice_state(const DevState& S, size_t b0, int Bs) {
   DevState T = S;
@@ -449,9 +476,8 @@ static int ensure_slices(ilqr_hip_ctx* c, int k) {
 }
 // the launch sequence of iLQR::solve (ilqr.cpp:521-660) for one slice on its streams; `wait_lead` (optional) delays the
 // first throughput-bound stage until the previous slice has finished its first backward pass, `lead` is recorded there
-static int overlap_rollout() { const char* e = getenv("ILQR_OVERLAP_ROLLOUT"); return e ? atoi(e) : 1; }
 // the handle's own setting (ilqr_hip_set_early_exit_gate); the environment, when set, overrides it (diagnostics, tests)
-static int early_exit_gate(const ilqr_hip_ctx* c) { const char* e = getenv("ILQR_EE_GATE"); return e ? atoi(e) : c->ee_gate; }
+static int early_exit_gate(const ilqr_hip_ctx* c) { return c->knobs.ee_gate >= 0 ? c->knobs.ee_gate : c->ee_gate; }
 static int ensure_gate(ilqr_hip_ctx* c) {
   if ((int)c->ev_active.size() >= c->max_iter + 2 && c->h_active) return ILQR_OK;
   if (c->h_active) { (void)hipHostFree(c->h_active); c->h_active = nullptr; }
@@ -466,10 +492,7 @@ static int ensure_gate(ilqr_hip_ctx* c) {
 // constraint-free B = 4096 +1.5 %, contact B = 4096 +9 %, contact B = 1024 +5 %, configs[4] +4 %; with a fixed iteration count most rollouts
 // retry in most iterations, the early group is small, and its kernels only take SIMDs from the one-wave-per-SIMD kernels of the retry
 // (headline -3 %, contact +3 % / -3.5 % at B = 4096 / 1024).  ILQR_SPLIT=0 / 1 forces it off / on.
-static int split_enabled(const ilqr_hip_ctx* c) { const char* e = getenv("ILQR_SPLIT"); return e ? atoi(e) : c->early_exit; }
-static int spec_enabled() { const char* e = getenv("ILQR_SPEC"); return e ? atoi(e) : 1; }
-static int spec_dual() { const char* e = getenv("ILQR_SPEC_DUAL"); return e ? atoi(e) : 1; }
-static int spec_max() { const char* e = getenv("ILQR_SPEC_MAX"); return e ? atoi(e) : 512; }
+static int split_enabled(const ilqr_hip_ctx* c) { return c->knobs.split >= 0 ? c->knobs.split : c->early_exit; }
 static int alloc_twin(ilqr_hip_ctx* c);
 // (the side-by-side order is an optimisation: a handle that cannot get the memory keeps the sequential order instead of failing the solve)
 static int ensure_twin(ilqr_hip_ctx* c) {
@@ -571,7 +594,7 @@ static int enqueue_solve(ilqr_hip_ctx* c, const DevState& S, const h1::ProblemDe
   };
   auto rolls_aside = [&](int iter) {
     const bool first_aside = iter == 0 && xbar_rolled && !ilqr::variant_scalar_dyn();
-    return (iter > 0 || first_aside) && !reuse_rollout() && overlap_rollout() && (P.dyn.contact || ilqr::variant_ls_split() == ilqr::variant_rollout_split());   // (contact mode: both on the two-lane kernels)
+    return (iter > 0 || first_aside) && !c->knobs.reuse_rollout && c->knobs.overlap_rollout && (P.dyn.contact || ilqr::variant_ls_split() == ilqr::variant_rollout_split());   // (contact mode: both on the two-lane kernels)
   };
   // Early continuation: the rollouts whose first line search of iteration i accepted a step are done with iteration i; their share of
   // iteration i + 1's concurrent region (group A) starts right behind the first control pass, on streams of its own, while the
@@ -590,7 +613,7 @@ static int enqueue_solve(ilqr_hip_ctx* c, const DevState& S, const h1::ProblemDe
     }
     const bool concurrent_roll = rolls_aside(iter);
     if (!prev_split) {
-      if ((iter == 0 || !reuse_rollout()) && !concurrent_roll) { StageTimer T(c, 0, st); ilqr::launch_rollout(S, P, ilqr::MASK_ACTIVE, 1, 0, S.Jbase, st); }
+      if ((iter == 0 || !c->knobs.reuse_rollout) && !concurrent_roll) { StageTimer T(c, 0, st); ilqr::launch_rollout(S, P, ilqr::MASK_ACTIVE, 1, 0, S.Jbase, st); }
       if (iter == 0 && wait_lead) HIPCHK(c, hipStreamWaitEvent(st, wait_lead, 0));
       TRY(region(G0, st, S, sel_mode, iter, nullptr, concurrent_roll));
     } else {
@@ -612,7 +635,7 @@ static int enqueue_solve(ilqr_hip_ctx* c, const DevState& S, const h1::ProblemDe
     // for this iteration's passes -- the active set only shrinks)
     const int ls_bound = (gate && iter >= 2) ? c->h_active[iter - 1] : -1;
     const int pass_bound = ls_bound >= 0 ? ls_bound : S.B;
-    if (c->twin && spec_enabled() && S.order && pass_bound <= spec_max()) {
+    if (c->twin && c->knobs.spec && S.order && pass_bound <= c->knobs.spec_max) {
       // both passes of ilqr.cpp:601-646 side by side (k_control_spec): the twin on the second stream
       const DevState Tw = twin_view(c, S);
       ++c->spec_iterations;
@@ -635,7 +658,7 @@ static int enqueue_solve(ilqr_hip_ctx* c, const DevState& S, const h1::ProblemDe
       prev_split = false;
       continue;
     }
-    if (c->twin && spec_enabled() && spec_dual() && S.order && gate && pass_bound <= 4 * spec_max() && ilqr::spec_dual_available(P)) {
+    if (c->twin && c->knobs.spec && c->knobs.spec_dual && S.order && gate && pass_bound <= 4 * c->knobs.spec_max && ilqr::spec_dual_available(P)) {
       // The host's count is one iteration old: between spec_max and 4 spec_max the pass may or may not have shrunk below the
       // threshold by now.  Both orders are enqueued and the device takes one (launch_spec_gate): the twin's launches and the
       // one-rollout-per-wave line search see a count of zero unless the list holds <= spec_max rollouts, the sequential first line
@@ -644,7 +667,7 @@ static int enqueue_solve(ilqr_hip_ctx* c, const DevState& S, const h1::ProblemDe
       const int* list = S.order + (size_t)(2 * iter) * S.B;
       int* g = c->d_spec_gate;
       ++c->spec_iterations;
-      ilqr::launch_spec_gate(S, iter, spec_max(), g, st);
+      ilqr::launch_spec_gate(S, iter, c->knobs.spec_max, g, st);
       HIPCHK(c, hipEventRecord(c->ev_spec_fork, st));
       HIPCHK(c, hipStreamWaitEvent(st2, c->ev_spec_fork, 0));
       ilqr::launch_spec_lambda(S, Tw.lambda, st2);
@@ -652,10 +675,10 @@ static int enqueue_solve(ilqr_hip_ctx* c, const DevState& S, const h1::ProblemDe
       { StageTimer T(c, 6, st2); ilqr::launch_backward_list(Tw, st2, fold_h, list, g); }
       TRY(wait_adoption(st)); TRY(wait_adoption(st2));
       { StageTimer T(c, 4, st);
-        ilqr::launch_line_search_list(S, P, st, list, g, spec_max());
+        ilqr::launch_line_search_list(S, P, st, list, g, c->knobs.spec_max);
         ilqr::launch_line_search_list(S, P, st, list, g + 2, ls_bound);
         ilqr::launch_cand_costs(S, P, ilqr::MASK_ACTIVE, st, false); }
-      { StageTimer T(c, 7, st2); ilqr::launch_line_search_list(Tw, P, st2, list, g, spec_max()); ilqr::launch_cand_costs(Tw, P, ilqr::MASK_ACTIVE, st2, false, g); }
+      { StageTimer T(c, 7, st2); ilqr::launch_line_search_list(Tw, P, st2, list, g, c->knobs.spec_max); ilqr::launch_cand_costs(Tw, P, ilqr::MASK_ACTIVE, st2, false, g); }
       HIPCHK(c, hipEventRecord(c->ev_spec_join, st2));
       HIPCHK(c, hipStreamWaitEvent(st, c->ev_spec_join, 0));
       { StageTimer T(c, 5, st);
@@ -698,7 +721,8 @@ static int enqueue_solve(ilqr_hip_ctx* c, const DevState& S, const h1::ProblemDe
 }
 int ilqr_hip_get_split_iterations(const ilqr_hip_ctx* c) { return c ? c->split_iterations : -1; }
 int ilqr_hip_get_speculative_iterations(const ilqr_hip_ctx* c) { return c ? c->spec_iterations : -1; }
-int ilqr_hip_num_slices(const ilqr_hip_ctx* c) { return c ? slices_wanted(c->B) : -1; }
+int ilqr_hip_reload_environment(ilqr_hip_ctx* c) { if (!c) return ILQR_ERR_ARG; const bool pc = c->knobs.per_call; c->knobs = read_knobs(); c->knobs.per_call = c->knobs.per_call || pc; return ILQR_OK; }
+int ilqr_hip_num_slices(const ilqr_hip_ctx* c) { return c ? slices_wanted(c, c->B) : -1; }
 // The analytic Jacobians differentiate the constrained step with the active set held fixed (modes 1, 2); a sliding foot's
 // constraint rows turn with the foot, which they do not carry: mode 3 linearises by the reference's forward differences.
 static int jacobians_available(ilqr_hip_ctx* c) {
@@ -717,10 +741,10 @@ int ilqr_hip_solve_async(ilqr_hip_ctx* c) {
   const DevState& S = c->S; const h1::ProblemDev& P = c->P;
   c->spans.clear(); c->pool_next = 0;
   HIPCHK(c, hipMemsetAsync(c->d_mismatch, 0, sizeof(unsigned long long), st));
-  const int k = slices_wanted(c->B);
+  const int k = slices_wanted(c, c->B);
   c->n_slices = k;
   c->spec_iterations = 0; c->split_iterations = 0;
-  if (spec_enabled() && k <= 1 && !c->twin && (c->B <= spec_max() || (c->early_exit && early_exit_gate(c)))) TRY(ensure_twin(c));
+  if (c->knobs.spec && k <= 1 && !c->twin && (c->B <= c->knobs.spec_max || (c->early_exit && early_exit_gate(c)))) TRY(ensure_twin(c));
   c->lin_fold_h = ilqr::linearize_fold_h(P, c->jac_mode);   // what S.A / S.Bm hold after this solve
   if (c->lin_fold_h != 0.0 && ilqr::variant_pack() && !c->ab_pads_clean) { ilqr::launch_pack_zero_pads(S, st); c->ab_pads_clean = true; }
   c->first_aside = c->xbar_rolled && c->rolled_variant == rollout_kernel_identity(P) && same_dyn(c->rolled_dyn, P.dyn);
@@ -731,7 +755,7 @@ int ilqr_hip_solve_async(ilqr_hip_ctx* c) {
     TRY(ensure_slices(c, k));
     HIPCHK(c, hipEventRecord(c->ev_begin, st));
     const int per = (c->B + k - 1) / k;
-    const bool stagger = stagger_wanted() != 0;
+    const bool stagger = c->knobs.stagger != 0;
     for (int i = 0; i < k; ++i) {
       const int b0 = i * per, Bs = (b0 + per <= c->B) ? per : (c->B - b0);
       if (Bs <= 0) continue;

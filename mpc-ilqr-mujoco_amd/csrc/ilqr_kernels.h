@@ -109,8 +109,11 @@ void launch_pack_first_knot(const DevState& S, double* u0, double* K0, hipStream
 void launch_pack_payload(const DevState& S, int with_gains, double* out, hipStream_t st);
 void launch_mirror_lxx(const DevState& S, hipStream_t st);   // fill the strictly upper tiles of lxx_t, t < N, from the lower ones
 int backward_needs_lds_attr();
-// kernel variants (ILQR_DYN / ILQR_ROLLOUT / ILQR_LS / ILQR_BACKWARD), re-read from the environment by refresh_variants()
-void refresh_variants();
+// kernel variants (ILQR_DYN / ILQR_ROLLOUT / ILQR_LS / ILQR_BACKWARD / ILQR_LINT): read from the environment ONCE per handle
+// (ilqr_hip_create; read_variants) and installed for the calling host thread at the top of every C-ABI call (set_variants)
+struct Variants { int scalar_dyn, rollout_split, ls_split, backward, fold, lin_one_knot; };
+Variants read_variants();
+void set_variants(const Variants& v);
 int variant_ls_split();
 int variant_rollout_split();
 int variant_backward();

@@ -978,37 +978,40 @@ void launch_mirror_lxx(const DevState& S, hipStream_t st) { hipLaunchKernelGGL(k
 #endif
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
-// Kernel variants, selectable at run time (environment) and re-read at the start of every solve / stage call
-// (refresh_variants), so that a test can switch them within one process:
+// Kernel variants, selectable through the environment.  The switches are read ONCE when a handle is created (read_variants, called
+// from ilqr_hip_create) and kept in the handle; every C-ABI call installs its handle's copy for the calling host thread (set_variants)
+// and the launchers it then calls read that thread-local copy -- no getenv on the call path, and handles driven from different host
+// threads (one thread and one handle per GPU, tests/cpp/cpp_multi_gpu_demo.cpp) never write to shared state.
 //   ILQR_DYN=s        scratch-resident scalar ABA kernels for every dynamics stage (on-device cross-check; always in contact mode)
 //   ILQR_ROLLOUT=s|r  nominal rollout on two lanes (dyn_split_kernels.hip) or one lane per rollout
 //   ILQR_LS=s|r       line search on two lanes or one lane per candidate
-//   ILQR_BACKWARD=wave|wave-generic|wg|valu  one-wave MFMA (riccati_wave.hip; "wave-generic" = never the folded variant) /
-//                     four-wave MFMA (riccati_mfma.hip) / LDS + VALU cross-check
-// One copy per host thread: every C-ABI call refreshes the calling thread's copy on entry (ilqr_capi.hip enter()) and the
-// launchers it then calls read that same copy, so handles driven from different host threads (one thread and one handle per
-// GPU, tests/cpp/cpp_multi_gpu_demo.cpp) never write to shared state.
-struct Variants { int scalar_dyn, rollout_split, ls_split, backward, fold, lin_one_knot; };
-static thread_local Variants g_var = {0, ROLLOUT_SPLIT_DEFAULT, LS_SPLIT_DEFAULT, -1, 1, 0};
+//   ILQR_BACKWARD=wave|wave-fold|wave-generic|wg|valu  one-wave MFMA on the operand layout (riccati_pack.hip, with analytic Jacobians) /
+//                     the folded one-wave kernel on the standard layout (riccati_wave.hip) / never a folded variant / four-wave MFMA
+//                     (riccati_mfma.hip) / LDS + VALU cross-check
+//   ILQR_LINT=1       the one-knot two-wave tangent kernel (cross-check of k_lin_tangent2)
+static thread_local Variants g_var = {0, ROLLOUT_SPLIT_DEFAULT, LS_SPLIT_DEFAULT, -1, 2, 0};
 static int env_split(const char* var, int dflt) { const char* e = getenv(var); return !e ? dflt : (e[0] == 's' ? 1 : 0); }
 #ifndef BACKWARD_DEFAULT
 #define BACKWARD_DEFAULT 2
 #endif
 static int backward_kind() { return g_var.backward < 0 ? BACKWARD_DEFAULT : g_var.backward; }
 static int use_scalar_dyn() { return g_var.scalar_dyn; }
-void refresh_variants() {
+Variants read_variants() {
+  Variants v;
   const char* e = getenv("ILQR_DYN");
-  g_var.scalar_dyn = (e && e[0] == 's') ? 1 : 0;
-  g_var.rollout_split = env_split("ILQR_ROLLOUT", ROLLOUT_SPLIT_DEFAULT);
-  g_var.ls_split = env_split("ILQR_LS", LS_SPLIT_DEFAULT);
+  v.scalar_dyn = (e && e[0] == 's') ? 1 : 0;
+  v.rollout_split = env_split("ILQR_ROLLOUT", ROLLOUT_SPLIT_DEFAULT);
+  v.ls_split = env_split("ILQR_LS", LS_SPLIT_DEFAULT);
   e = getenv("ILQR_BACKWARD");
-  g_var.backward = !e ? BACKWARD_DEFAULT : (e[0] == 'v') ? 1 : (e[0] == 'w' && e[1] == 'a') ? 2 : 0;
+  v.backward = !e ? BACKWARD_DEFAULT : (e[0] == 'v') ? 1 : (e[0] == 'w' && e[1] == 'a') ? 2 : 0;
   // fold: 0 never ("wave-generic"), 1 the folded kernel on the standard layout ("wave-fold": cross-check), 2 the operand-layout kernel
   // riccati_pack.hip (default)
-  g_var.fold = (e && strstr(e, "generic")) ? 0 : (e && strstr(e, "fold")) ? 1 : 2;
-  e = getenv("ILQR_LINT");                                // 1: the one-knot two-wave tangent kernel (cross-check of k_lin_tangent2)
-  g_var.lin_one_knot = (e && e[0] == '1') ? 1 : 0;
+  v.fold = (e && strstr(e, "generic")) ? 0 : (e && strstr(e, "fold")) ? 1 : 2;
+  e = getenv("ILQR_LINT");
+  v.lin_one_knot = (e && e[0] == '1') ? 1 : 0;
+  return v;
 }
+void set_variants(const Variants& v) { g_var = v; }
 int variant_ls_split() { return g_var.ls_split; }
 int variant_rollout_split() { return g_var.rollout_split; }
 int variant_backward() { return backward_kind(); }

@@ -12,6 +12,10 @@ try:
 except Exception:  # noqa: BLE001 -- the CPU-only suite does not need it
     torch = None
 
+# The library reads its diagnostic environment switches once per handle (ilqr_hip_create); many tests switch kernel families around
+# calls on ONE handle (the `env` blocks): this opt-in restores the re-read at the top of every C-ABI call for the test process.
+os.environ.setdefault("ILQR_ENV_PER_CALL", "1")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

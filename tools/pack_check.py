@@ -2,6 +2,7 @@
 """Operand-layout Riccati kernel (riccati_pack.hip) against the generic and the folded one-wave kernels on the same stage data:
    python tools/pack_check.py [B] [N]      (ILQR_CONTACT=1/2 for the stance-constrained Jacobians)"""
 import os, sys
+os.environ.setdefault("ILQR_ENV_PER_CALL", "1")   # these tools switch kernel families around calls on one handle
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Time one stage of the HIP path at the bench size (B=4096, N=25): python tools/time_stage.py backward [reps]"""
 import os, sys, time
+os.environ.setdefault("ILQR_ENV_PER_CALL", "1")   # this tool may switch kernel families around calls on one handle
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np
