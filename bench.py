@@ -67,7 +67,9 @@ def workload_label(args, B, N, iters, world, gravity):
     if getattr(args, "workload", "default") == "config4" and world == 1:
         return ("global batch of BASELINE.json configs[4] on ONE GPU: batch=%d windows of the H1 walking reference (data/h1_walking_pin.csv rows), N=%d, dt=0.02, per-rollout references and "
                 "contact schedule (contact-scheduled costs), unilateral rigid stance constraints on the scheduled feet (contact mode 2), analytic Jacobians of the constrained step, "
-                "%d fixed iterations per rollout, shipped config.yaml weights, gravity %s" % (B, N, iters, list(gravity)))
+                "%d fixed iterations per rollout, shipped config.yaml weights, gravity %s -- the reference's shipped config.yaml value, NOT physical gravity: the `contact` line of the "
+                "default workload (--contact) runs under [0, 0, -9.81] and is not comparable with this one; the reference rows come from the committed fixture tests/golden/refdata_golden.npz "
+                "(the reference repository does not travel to the GPU box)" % (B, N, iters, list(gravity)))
     if args.contact:
         return "custom (contact row f4: unilateral rigid stance on the scheduled feet): " + body
     if B == 4096 and N == 25 and iters == 10:
@@ -629,6 +631,15 @@ def main():
         roof["whole_iteration_frac"] = value * ITER_FLOPS_N25 * it_scale / (FP64_PEAK_TFLOPS * 1e12 * world)
         roof["whole_iteration_frac_hbm"] = value * ITER_BYTES_N25 * it_scale / (HBM_PEAK_GBS * 1e9 * world)
         roof["whole_iteration_frac_counted_flops"] = value * ITER_FLOPS_COUNTED_N25 * it_scale / (FP64_PEAK_TFLOPS * 1e12 * world)
+        # what a fixed-mode iteration EXECUTES: the reference's lambda retry (ilqr.cpp:619-644) repeats the backward pass and the line
+        # search for the rollouts whose first search failed -- late iterations, nearly all of them.  Its share is read off the profiled
+        # step: device time of the retry backward passes / of the first passes (the kernel's time is proportional to the rollouts it is given)
+        bw1, bw2 = stage_ms.get("iLQR_backwardPass", 0.0), stage_ms.get("iLQR_backwardPass_retry", 0.0)
+        retry_share = bw2 / bw1 if bw1 > 0 else 0.0
+        executed = (ITER_FLOPS_COUNTED_N25 + retry_share * 25.0 * (RICCATI_FLOPS_PER_KNOT + ALPHA_TRIAL_FLOPS_PER_KNOT)) * it_scale
+        roof["retry_share_of_first_pass"] = retry_share
+        roof["executed_flops_per_iteration"] = executed
+        roof["whole_iteration_frac_executed_flops"] = value * executed / (FP64_PEAK_TFLOPS * 1e12 * world)
         if dom_kernel in ("k_backward_wave", "k_backward_pack") and d["avg_launch_ms"] > 0:
             # `achieved` / `frac` are ALGORITHMIC-equivalent rates (914 786 flop per knot, the dense minimal-reuse count); the kernel
             # issues fewer, padded products: MFMA count x 2048 flops is what the hardware executes
@@ -646,7 +657,7 @@ def main():
                      "note": "achieved / frac = ALGORITHMIC flops (or bytes) of one launch / its average duration -- an algorithmic-equivalent rate, not a count of issued "
                              "instructions (executed_mfma_flops_per_launch / frac_executed_mfma give the issued MFMA flops of the Riccati kernel); "
                              "whole_iteration_frac = iterations/s x SURVEY 8(d)'s 27.8 MFLOP (2.43 MB) per rollout-iteration against the fp64 (HBM) roof, "
-                             "whole_iteration_frac_counted_flops the same with the op-counted per-stage figures (config.flop_source: 33.0 MFLOP at N = 25); "
+                             "whole_iteration_frac_counted_flops the same with the op-counted per-stage figures (config.flop_source: 33.0 MFLOP at N = 25), whole_iteration_frac_executed_flops with the lambda-retry passes a fixed-mode iteration really executes added (executed_flops_per_iteration = counted + retry_share_of_first_pass x (Riccati + line-search trial)); "
                              "full-batch launches of the timed steps only (HIP events on the launch stream; this kernel group was picked on an untimed probe "
                              "step with every stage timed, and is the only one that carries event pairs inside the timed region); traffic = 2 x FETCH_SIZE + WRITE_SIZE of a full-batch launch from "
                              "separate rocprofv3 --pmc passes of this command (see traffic_source), null when no record matches this run; "

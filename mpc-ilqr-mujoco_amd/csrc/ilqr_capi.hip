@@ -495,6 +495,10 @@ static int ensure_gate(ilqr_hip_ctx* c) {
 static int split_enabled(const ilqr_hip_ctx* c) { return c->knobs.split >= 0 ? c->knobs.split : c->early_exit; }
 static int alloc_twin(ilqr_hip_ctx* c);
 // (the side-by-side order is an optimisation: a handle that cannot get the memory keeps the sequential order instead of failing the solve)
+// Memory: the twin is indexed by rollout like everything else, so it is a full-batch copy of K, k, Vx, Vxx, the eight candidates and
+// their knot costs -- 0.33 MB per rollout at N = 25 (1.3 GB at B = 4096, 10.7 GB at B = 32 768), allocated by the first solve that can
+// take the side-by-side order: B <= ILQR_SPEC_MAX, or the convergence exit with its gate on (the late passes of any batch shrink below
+// the threshold).  ILQR_SPEC=0 keeps a handle from ever allocating it.
 static int ensure_twin(ilqr_hip_ctx* c) {
   if (c->twin || c->twin_failed) return ILQR_OK;
   if (alloc_twin(c) != ILQR_OK) {
@@ -502,6 +506,7 @@ static int ensure_twin(ilqr_hip_ctx* c) {
     for (void* p : tw) if (p) (void)hipFree(p);
     c->T = DevState{}; c->d_spec_gate = nullptr; c->twin = false; c->twin_failed = true;
     (void)hipGetLastError();
+    c->err.clear();      // (the failed allocation is not an error of the call: the sequential order runs instead)
   }
   return ILQR_OK;
 }

@@ -211,25 +211,22 @@ __global__ void __launch_bounds__(256, 3) k_lin_tangent2(DevState S, ProblemDev 
   }
   __syncthreads();
   LSTAMP(0)
+  // (one barrier for all four waves between the two halves: a __syncthreads() inside each wave's own branch happens to work --
+  // s_barrier counts waves -- but matching barriers across divergent code paths is not something to lean on)
+  MinvCarry Cm;
+  const int cm = lane & 31;
   if (wv == 0) {
     lin2_accumulate_forces_w(L2, lane);
     LSTAMP(1)
-    __syncthreads();
-    lin2_tangent_legs(L2, lane);
-  } else if (wv == 1) {
-    __syncthreads();
-    lin2_tangent_arms(L2, lane);
   } else if (wv == 2) {
-    MinvCarry C;
-    const int c = lane & 31;
-    LinShared& L = L2[lane >> 5];
-    if (c < H1_NV) lin2_minv_in(L, c, C);
-    __syncthreads();
-    if (c < H1_NV) lin2_minv_out(L, c, C);
-  } else {
-    if ((lane & 31) == 0) lin_prologue(L2[lane >> 5]);
-    __syncthreads();
+    if (cm < H1_NV) lin2_minv_in(L2[lane >> 5], cm, Cm);
+  } else if (wv == 3) {
+    if (cm == 0) lin_prologue(L2[lane >> 5]);
   }
+  __syncthreads();
+  if (wv == 0) lin2_tangent_legs(L2, lane);
+  else if (wv == 1) lin2_tangent_arms(L2, lane);
+  else if (wv == 2) { if (cm < H1_NV) lin2_minv_out(L2[lane >> 5], cm, Cm); }
   __syncthreads();
   LSTAMP(2)
   if (wv < 2) lin2_tangent_pelvis(L2[wv], lane);

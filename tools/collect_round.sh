@@ -1,9 +1,10 @@
 #!/bin/bash
-# Everything profiles/ keeps for a round, in one go on the GPU box (about ten minutes):  tools/collect_round.sh r04
+# Everything profiles/ keeps for a round, in one go on the GPU box (about ten minutes):  ILQR_GIT_HEAD=<sha> tools/collect_round.sh r05
+# (the repository's .git does not travel to the box: the build container passes `git rev-parse --short HEAD` in for the stamps)
 #   -> gpurun_out/profiles_<tag>/ : <tag>_kernel_stats.csv, traffic_latest.json, <tag>_pmc/*, <tag>_sq_issue_wait_summary.txt,
 #      <tag>_fp64_instruction_mix.txt, <tag>_iteration_timeline.txt, <tag>_iteration_spans_fixed_and_early_exit.txt, <tag>_bench_lines/*.json
 set -e
-tag=${1:-r04}
+tag=${1:-r05}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 out=gpurun_out/profiles_$tag
 bash tools/collect_profiles.sh "$tag" > /dev/null 2>&1 || true
@@ -75,5 +76,28 @@ python3 bench.py --batch 8192 --no-cpu-baseline --no-contact-line 2>/dev/null | 
 echo "[collect] small lines done"
 python3 bench.py --workload config3 --steps 3 --no-cpu-baseline 2>/dev/null | grep '^{' > "$L/bench_config3_global_batch_one_gpu.json"
 python3 bench.py --workload config4 --steps 3 2>/dev/null | grep '^{' > "$L/bench_config4_global_batch_one_gpu.json"
+# every stage kernel alone, full batch (stage API): what "alone ms" in the summary means
+rm -f "$out/${tag}_alone_kernel_stats.csv"
+for st in linearize quadratics backward line_search rollout; do
+  rocprofv3 --kernel-trace --stats --output-format csv -d "$out/alone_$st" -o a -- python3 tools/time_stage.py $st 5 > "$out/alone_$st.log" 2>&1 || true
+  f=$(find "$out/alone_$st" -name '*kernel_stats.csv' | head -1)
+  python3 - "$f" "$st" "$out/${tag}_alone_kernel_stats.csv" <<'PY'
+import csv, os, sys
+# keep the rows of the kernels the stage itself launches (the set-up before it launches other stages' kernels once)
+keep = {"linearize": ("k_lin_primal", "k_lin_tangent"), "quadratics": ("k_quad_kin", "k_cost_quadratics"), "backward": ("k_backward",),
+        "line_search": ("k_line_search", "k_traj_knot_cost"), "rollout": ("k_rollout", "k_traj_cost_sum")}[sys.argv[2]]
+rows = [r for r in csv.DictReader(open(sys.argv[1])) if any(k in r["Name"] for k in keep)]
+new = not os.path.exists(sys.argv[3])
+w = csv.DictWriter(open(sys.argv[3], "a", newline=""), fieldnames=["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev"], quoting=csv.QUOTE_NONNUMERIC)
+if new: w.writeheader()
+have = set()
+if not new: have = {r["Name"] for r in csv.DictReader(open(sys.argv[3]))}
+for r in rows:
+    if r["Name"] not in have: w.writerow({k: r[k] for k in w.fieldnames})
+PY
+  rm -rf "$out/alone_$st"
+done
+echo "[collect] stage kernels alone done"
+python3 tools/round_summary.py "$out" "$tag" "${ILQR_GIT_HEAD:-unknown}" > "$out/${tag}_summary.md"
 echo "[collect] all done"
 ls "$out" "$L"

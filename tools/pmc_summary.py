@@ -8,6 +8,7 @@
       rocprofv3 reports them.  bench.py turns them into bytes: 2 x FETCH_SIZE (gfx950 counts 64 B per 128-B request,
       MI355X_MICROARCH.md "HBM"; re-checked for 8-byte-per-lane accesses with tools/probes/pmc_calib.hip) + WRITE_SIZE.
 """
+import os
 import csv, sys, json, collections
 
 def load(paths):
@@ -34,10 +35,13 @@ if len(sys.argv) > 2 and sys.argv[1] == "--traffic-json":
     out = {k: v for k, v in out.items() if len(v) == 2}
     if stamp is not None:
         import subprocess, datetime
-        try:
-            stamp["head"] = subprocess.check_output(["git", "rev-parse", "--short", "HEAD"], text=True).strip()
-        except Exception:
-            stamp["head"] = "unknown"
+        # (the GPU box has no .git: the build container passes its HEAD in, tools/collect_round.sh)
+        stamp["head"] = os.environ.get("ILQR_GIT_HEAD", "")
+        if not stamp["head"]:
+            try:
+                stamp["head"] = subprocess.check_output(["git", "rev-parse", "--short", "HEAD"], text=True, stderr=subprocess.DEVNULL).strip()
+            except Exception:
+                stamp["head"] = "unknown"
         stamp["date"] = datetime.date.today().isoformat()
         out["_stamp"] = stamp
     json.dump(out, open(sys.argv[2], "w"), indent=1, sort_keys=True)
