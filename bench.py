@@ -567,6 +567,28 @@ def main():
         s.enable_profiling(False); s.set_profiled_stages(None)
         s.set_options(jacobian_mode=sv.JAC_ANALYTIC, early_exit=False)
 
+    # fifth number (not the headline): the default workload with ilqr_hip_set_dedup_saturated_retry -- lambda retries whose lambda is
+    # already at its cap repeat the failed pass bit for bit (ilqr.cpp:619-644 recomputes them) and are skipped; every observable of the
+    # solve is unchanged (-m gpu test).  What a user of MPC::stepOnce can have; the headline executes every pass the reference executes.
+    dedup_line = None
+    if not args.contact and not JAC_FD and world == 1 and args.workload == "default" and not args.no_fd_line:
+        s.set_problem(prob); s.set_contact_mode(0); s.set_options(jacobian_mode=sv.JAC_ANALYTIC, early_exit=False)
+        s.set_dedup_saturated_retry(True)
+
+        def dstep():
+            s.initialize_device(x0_d.data_ptr(), ui_d.data_ptr()); s.solve_async(); s.synchronize()
+        dstep()
+        torch.cuda.synchronize(); td0 = time.perf_counter()
+        dsteps = 2
+        for _ in range(dsteps):
+            dstep()
+        torch.cuda.synchronize(); td = time.perf_counter() - td0
+        assert np.all(s.iterations() == iters) and np.all(np.isfinite(s.cost()))
+        dedup_line = {"value": B * iters * dsteps / td, "unit": "iterations/s", "ms_per_step": 1e3 * td / dsteps,
+                      "note": "NOT the headline: same workload, same results bit for bit, with the lambda retries whose lambda is already saturated (min(10 lambda, 1e-3) == lambda: "
+                              "an exact repeat of the pass that has just failed) skipped -- ilqr_hip_set_dedup_saturated_retry, off by default"}
+        s.set_dedup_saturated_retry(False)
+
     if rank == 0:
         total_iters = float(world) * B * iters * args.steps
         value = total_iters / elapsed
@@ -698,6 +720,8 @@ def main():
             out["contact"] = contact_line
         if fd_line is not None:
             out["fd"] = fd_line
+        if dedup_line is not None:
+            out["dedup_saturated_retry"] = dedup_line
         if args.workload == "config4":
             out["cpu_baseline"] = None     # (the oracle's OpenMP batch shares ONE reference set; per-rollout windows are checked rollout by rollout in the -m gpu tests)
         elif not args.no_cpu_baseline and world == 1:   # the CPU baseline is timed on rank 0 of the one-GPU run only

@@ -52,6 +52,13 @@ int ilqr_hip_destroy(ilqr_hip_ctx* ctx);
    ilqr_hip_create, and kept in the handle: no getenv on the call path.  This call re-reads them for one handle (tests, profiling
    tools); ILQR_ENV_PER_CALL=1 at creation makes every call of the handle do so.  No reference counterpart. */
 int ilqr_hip_reload_environment(ilqr_hip_ctx* ctx);
+/* Off by default (the solve then executes every pass the reference executes).  On: a lambda retry (ilqr.cpp:619-644) whose lambda is
+   already saturated -- min(10 lambda, 1e-3) == lambda, the state a rollout reaches after a few failed searches -- is not executed:
+   it would repeat the backward pass and the line search that have just failed on identical inputs, bit for bit, and fail again.  Its
+   bookkeeping (trace entry, iteration count, convergence-exit rule of ilqr.cpp:640-655) is played at once.  Every observable of the solve
+   is unchanged (GPU test); bench.py reports the resulting rate as its own object, never as the headline.  No reference counterpart:
+   the reference recomputes. */
+int ilqr_hip_set_dedup_saturated_retry(ilqr_hip_ctx* ctx, int on);
 const char* ilqr_hip_last_error(const ilqr_hip_ctx* ctx);
 int ilqr_hip_batch(const ilqr_hip_ctx* ctx);
 int ilqr_hip_horizon(const ilqr_hip_ctx* ctx);

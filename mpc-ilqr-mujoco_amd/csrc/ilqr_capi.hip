@@ -26,6 +26,7 @@ using ilqr::DevState;
 // re-reads on demand.
 struct Knobs {
   ilqr::Variants var;
+  int dedup_retry;      // ILQR_DEDUP_RETRY (-1: the handle's own setting, ilqr_hip_set_dedup_saturated_retry)
   int slices, stagger, overlap_rollout, reuse_rollout, ee_gate /* -1: the handle's own setting */, split /* -1: on with the convergence exit */, spec, spec_dual, spec_max;
   bool per_call;
 };
@@ -38,6 +39,7 @@ static Knobs read_knobs() {
 #endif
   k.slices = geti("ILQR_SLICES", SLICES_DEFAULT);
   k.stagger = geti("ILQR_STAGGER", 1);
+  k.dedup_retry = geti("ILQR_DEDUP_RETRY", -1);
   k.overlap_rollout = geti("ILQR_OVERLAP_ROLLOUT", 1);
   { const char* e = getenv("ILQR_REUSE_ROLLOUT"); k.reuse_rollout = (e && e[0] == '1') ? 1 : 0; }
   k.ee_gate = geti("ILQR_EE_GATE", -1);
@@ -96,6 +98,7 @@ struct ilqr_hip_ctx {
   // standard layout over them).  The stage API and the getters convert on demand (in place, per knot region).
   int lxx_layout = 0;
   bool ab_packed = false, ab_pads_clean = false;
+  int dedup_retry = 0;          // ilqr_hip_set_dedup_saturated_retry
   Knobs knobs = read_knobs();   // (constructed in ilqr_hip_create)
   double lin_fold_h = 0.0;   // step size h while S.A / S.Bm hold the analytic Jacobians (folded backward kernel), else 0
   std::string err;
@@ -570,6 +573,9 @@ static int enqueue_solve(ilqr_hip_ctx* c, const DevState& S, const h1::ProblemDe
   //   caller-supplied trajectory is rolled out BEFORE the linearisation, as the reference does)
   // Sm: the view the mask-selected kernels (rollout, trajectory cost, adoption) get -- S, or S with a group's flags as `active`;
   // wl: the group's compacted list for the per-knot kernels (null: the iteration's own list / mask, as knot_mode and iter_l say).
+  // ilqr_hip_set_dedup_saturated_retry: bit 1 of k_control's early_exit argument (the sequential orders; the side-by-side order has
+  // both passes in flight before either outcome is known)
+  const int dedup_bit = (c->knobs.dedup_retry >= 0 ? c->knobs.dedup_retry : c->dedup_retry) ? 2 : 0;
   struct Rg { hipStream_t m, q, r; hipEvent_t fork, join, roll, lin, adopt; };
   const Rg G0{st, st2, st3, ev_fork, ev_join, ev_roll, ev_lin, ev_adopt};
   // (group A's cost quadratics and re-rollout share the second and third stream with group R -- idle while the retry runs, and R's
@@ -688,7 +694,7 @@ static int enqueue_solve(ilqr_hip_ctx* c, const DevState& S, const h1::ProblemDe
       HIPCHK(c, hipStreamWaitEvent(st, c->ev_spec_join, 0));
       { StageTimer T(c, 5, st);
         ilqr::launch_control_spec(S, Tw, iter, c->tol, c->early_exit, st, ilqr::ls_costs_per_knot(P), g);
-        ilqr::launch_control(S, 0, iter, c->tol, c->early_exit, st, ilqr::ls_costs_per_knot(P), g + 1); }
+        ilqr::launch_control(S, 0, iter, c->tol, c->early_exit | dedup_bit, st, ilqr::ls_costs_per_knot(P), g + 1); }
       { StageTimer T(c, 6, st); ilqr::launch_backward(S, ilqr::MASK_RETRY, st, fold_h, iter); }
       { StageTimer T(c, 7, st); ilqr::launch_line_search(S, P, ilqr::MASK_RETRY, st, iter, ls_bound); }
       { StageTimer T(c, 5, st); ilqr::launch_control(S, 1, iter, c->tol, c->early_exit, st, ilqr::ls_costs_per_knot(P)); }
@@ -701,7 +707,7 @@ static int enqueue_solve(ilqr_hip_ctx* c, const DevState& S, const h1::ProblemDe
     TRY(wait_adoption(st));
     if (iter == 0 && lead) HIPCHK(c, hipEventRecord(lead, st));
     { StageTimer T(c, 4, st); ilqr::launch_line_search(S, P, ilqr::MASK_ACTIVE, st, iter, ls_bound); }                  // :616
-    { StageTimer T(c, 5, st); ilqr::launch_control(S, 0, iter, c->tol, c->early_exit, st, ilqr::ls_costs_per_knot(P)); }                      // :619-620,645-655
+    { StageTimer T(c, 5, st); ilqr::launch_control(S, 0, iter, c->tol, c->early_exit | dedup_bit, st, ilqr::ls_costs_per_knot(P)); }          // :619-620,645-655
     const bool split_next = can_split && iter + 1 < c->max_iter && rolls_aside(iter + 1);
     if (split_next) {
       // group A of iteration iter + 1: the first entries of its list, as many as the first control pass has just put there
@@ -726,6 +732,7 @@ static int enqueue_solve(ilqr_hip_ctx* c, const DevState& S, const h1::ProblemDe
 }
 int ilqr_hip_get_split_iterations(const ilqr_hip_ctx* c) { return c ? c->split_iterations : -1; }
 int ilqr_hip_get_speculative_iterations(const ilqr_hip_ctx* c) { return c ? c->spec_iterations : -1; }
+int ilqr_hip_set_dedup_saturated_retry(ilqr_hip_ctx* c, int on) { if (!c) return ILQR_ERR_ARG; c->dedup_retry = on ? 1 : 0; return ILQR_OK; }
 int ilqr_hip_reload_environment(ilqr_hip_ctx* c) { if (!c) return ILQR_ERR_ARG; const bool pc = c->knobs.per_call; c->knobs = read_knobs(); c->knobs.per_call = c->knobs.per_call || pc; return ILQR_OK; }
 int ilqr_hip_num_slices(const ilqr_hip_ctx* c) { return c ? slices_wanted(c, c->B) : -1; }
 // The analytic Jacobians differentiate the constrained step with the active set held fixed (modes 1, 2); a sliding foot's

@@ -631,8 +631,13 @@ __device__ __forceinline__ void wave_copy(double* dst, const double* src, int le
   }
 }
 #define CTRL_WAVES 16
-__global__ void __launch_bounds__(64 * CTRL_WAVES) k_control(DevState S, int phase, int iter, double tol, int early_exit, int sum_knots, const int* gate) {
+__global__ void __launch_bounds__(64 * CTRL_WAVES) k_control(DevState S, int phase, int iter, double tol, int ee_flags, int sum_knots, const int* gate) {
   if (gate && *gate == 0) return;      // (device-side choice between two enqueued launch orders: launch_spec_gate)
+  // bit 0: the reference's convergence exit; bit 1 (phase 0 only, ilqr_hip_set_dedup_saturated_retry): a lambda retry whose lambda is
+  // already saturated -- min(10 lambda, 1e-3) == lambda -- would repeat the pass that has just failed bit for bit (same Jacobians,
+  // quadratics and lambda give the same gains, the same eight candidates and the same costs): its bookkeeping (ilqr.cpp:640-655, the
+  // failing branch) is played now and the rollout does not join the retry pass
+  const int early_exit = ee_flags & 1, dedup = (ee_flags >> 1) & 1;
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int b = blockIdx.x * CTRL_WAVES + wv;
   __shared__ int s_accept[CTRL_WAVES], s_slot[CTRL_WAVES], s_base[3];
@@ -684,7 +689,7 @@ __global__ void __launch_bounds__(64 * CTRL_WAVES) k_control(DevState S, int pha
         S.trace_alpha[(size_t)b * S.max_iter + tr] = ALPHAS[acc];
         S.trace_lambda[(size_t)b * S.max_iter + tr] = lam_used;
         if (early_exit && (fabs(Jn - Jprev) < tol || Jn > 1e6)) S.active[b] = 0;
-      } else if (phase == 0) {
+      } else if (phase == 0 && !(dedup && fmin(lam_used * 10.0, 1e-3) == lam_used)) {
         S.lambda[b] = fmin(lam_used * 10.0, 1e-3);
         S.need_retry[b] = 1;
       } else {

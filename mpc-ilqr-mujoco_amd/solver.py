@@ -22,7 +22,7 @@ JAC_ANALYTIC, JAC_FD_FORWARD = 0, 1
 
 # every symbol include/ilqr_hip.h declares (checked by the CPU test-suite against the built library)
 EXPORTS = [
-    "ilqr_hip_create", "ilqr_hip_destroy", "ilqr_hip_last_error", "ilqr_hip_batch", "ilqr_hip_horizon", "ilqr_hip_num_slices", "ilqr_hip_reload_environment",
+    "ilqr_hip_create", "ilqr_hip_destroy", "ilqr_hip_last_error", "ilqr_hip_batch", "ilqr_hip_horizon", "ilqr_hip_num_slices", "ilqr_hip_reload_environment", "ilqr_hip_set_dedup_saturated_retry",
     "ilqr_hip_set_cost_weights", "ilqr_hip_set_task_weights", "ilqr_hip_set_constraint_weights", "ilqr_hip_set_gravity",
     "ilqr_hip_set_contact_schedule", "ilqr_hip_set_ee_references", "ilqr_hip_set_references",
     "ilqr_hip_set_regularization", "ilqr_hip_set_max_iterations", "ilqr_hip_set_tolerance", "ilqr_hip_set_options", "ilqr_hip_set_early_exit_gate",
@@ -126,6 +126,10 @@ class BatchedILQR:
         if rc:
             msg = self.L.ilqr_hip_last_error(h).decode() if h else ""
             raise ILQRError("ilqr_hip_create failed: %s %s" % (STATUS.get(rc, rc), msg))
+
+    def set_dedup_saturated_retry(self, on=True):
+        """Skip lambda retries whose lambda is already saturated (bit-identical repeats of the pass that has just failed); off by default."""
+        self._chk(self.L.ilqr_hip_set_dedup_saturated_retry(self.h, int(bool(on))))
 
     def reload_environment(self):
         """Re-read the diagnostic environment switches (read once, at creation) for this handle."""

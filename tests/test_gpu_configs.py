@@ -366,6 +366,55 @@ def test_speculative_lambda_retry_is_the_sequential_retry_bit_for_bit(mode):
         assert np.allclose(tl[b, :n], olam[:n], rtol=1e-12) and rel(out["1"][5][b], o.get("K")) < 1e-5
 
 
+def test_forward_difference_jacobians_never_take_the_early_continuation():
+    """the forward-difference launchers select rollouts by S.active, not by a group's work list, and k_fd_finish
+    rewrites S.A / S.Bm in place -- a second group's pass would rewrite the Jacobians the retry's backward pass is reading.  The early
+    continuation is therefore analytic-only (ilqr_capi.hip can_split): with the reference's Jacobian scheme, the convergence exit,
+    ILQR_SPEC=0 and ILQR_SPLIT=1 no iteration is split, and the solve equals the ILQR_SPLIT=0 one and its own repetition bit for bit."""
+    B = 12
+    prob, x0, ui = standing(B, seed=53)
+    out = {}
+    for name, split in (("split", "1"), ("nosplit", "0"), ("again", "1")):
+        with env(ILQR_SPEC="0", ILQR_SPLIT=split):
+            s = _solver(B); s.set_problem(prob); s.set_options(jacobian_mode=1, fd_eps=1e-5, early_exit=True); s.set_max_iterations(10)
+            s.initialize(x0, ui); cost = s.solve(x0)
+            tc, ta, tl = s.trace()
+            out[name] = (cost, tc, ta, tl, s.iterations(), s.gains_K(), s.gains_kff(), s.xbar(), s.ubar(), s.split_iterations())
+            s.close()
+    assert out["split"][9] == 0 and out["nosplit"][9] == 0
+    for k in range(9):
+        assert np.array_equal(out["split"][k], out["nosplit"][k], equal_nan=True) and np.array_equal(out["split"][k], out["again"][k], equal_nan=True), k
+    o = ol.Oracle(prob["N"], prob["dt"]); o.set_problem(prob); o.set_options(max_iter=10, early_exit=1, jac_mode=1, fd_eps=1e-5)
+    o.initialize(x0[0], ui[0]); ok, c = o.solve(x0[0])
+    assert abs(out["split"][0][0] - c) <= 1e-5 * abs(c)
+
+
+@pytest.mark.parametrize("early_exit", [False, True])
+def test_skipping_saturated_lambda_retries_changes_no_observable(early_exit):
+    """ilqr_hip_set_dedup_saturated_retry: once lambda sits at its cap (min(10 lambda, 1e-3) == lambda) the retry of ilqr.cpp:619-644
+    repeats the failed pass on identical inputs; with the option on it is not executed and its bookkeeping is played at once.  Cost
+    trace, step sizes, lambda schedule, iteration counts, gains, value function, trajectories: bit for bit the default solve's, on a
+    batch where such retries do occur (ILQR_SPEC=0: the sequential orders are the ones that can skip)."""
+    B = 12
+    prob, x0, ui = standing(B, seed=53)
+    out = {}
+    for on in (0, 1):
+        with env(ILQR_SPEC="0"):
+            s = _solver(B); s.set_problem(prob); s.set_options(early_exit=early_exit); s.set_max_iterations(10)
+            s.set_dedup_saturated_retry(bool(on))
+            s.initialize(x0, ui); cost = s.solve(x0)
+            tc, ta, tl = s.trace()
+            Vx, Vxx = s.value_function()
+            out[on] = (cost, tc, ta, tl, s.iterations(), s.gains_K(), s.gains_kff(), Vx, Vxx, s.xbar(), s.ubar(), s.lambdas())
+            s.close()
+    for k in range(12):
+        assert np.array_equal(out[0][k], out[1][k], equal_nan=True), k
+    # the batch does contain failed iterations entered with a saturated lambda (the ones whose retry is skipped)
+    ta, tl, it = out[1][2], out[1][3], out[1][4]
+    skipped = sum(1 for b in range(B) for i in range(1, it[b]) if ta[b, i] == 0.0 and tl[b, i] == 1e-3 and ta[b, i - 1] == 0.0 and tl[b, i - 1] == 1e-3)
+    assert early_exit or skipped >= 3, skipped      # (with the convergence exit a failed iteration > 1 ends the rollout: ilqr.cpp:653-655)
+
+
 def test_profiled_stage_mask_times_only_the_chosen_stages():
     """bench.py keeps event pairs only around the roofline kernel group inside its timed region (ilqr_hip_set_profiled_stages)."""
     B = 4
