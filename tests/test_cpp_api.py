@@ -85,6 +85,40 @@ def test_cpp_mirror_matches_python_wrapper(tmp_path):
         assert fa[:3] == fb[:3] and fa[4:] == fb[4:] and float(fa[3]) > 0.0
 
 
+def test_exact_signature_eigen_adapter_compiles_against_a_robotutils_shaped_class():
+    """include/ilqr_hip_eigen.hpp (iLQR(RobotUtils&, int, double, const std::string&), solve(const Eigen::VectorXd&, ...),
+    MPC::stepOnce(const Eigen::VectorXd&, Eigen::VectorXd&): reference include/ilqr/ilqr.hpp:19-45, mpc.hpp:20-47) is built by
+    __graft_entry__.build() against the stand-in Eigen of tests/cpp/fake_eigen; without a GPU the demo fails loudly."""
+    import __graft_entry__ as ge
+    exe = ge.build_cpp_demos()["cpp_eigen_drop_in_demo"]
+    assert os.path.exists(exe)
+    src = open(os.path.join(ROOT, "include", "ilqr_hip_eigen.hpp")).read()
+    for sig in ("iLQR(Robot& robot, int N, double dt, const std::string&", "bool solve(const Eigen::VectorXd& x0, const std::vector<Eigen::VectorXd>& x_ref",
+                "bool stepOnce(const Eigen::VectorXd& x_measured, Eigen::VectorXd& u_apply)", "MPC(Robot& robot, int N, double dt, const std::string&"):
+        assert sig in src, sig
+
+
+@pytest.mark.gpu
+def test_exact_signature_eigen_adapter_equals_the_std_vector_mirror_bit_for_bit(tmp_path):
+    """The same two MPC steps through ilqr_hip_eigen::MPC<RobotUtils> (problem data pulled out of the robot's getters) and through
+    ilqr_hip::MPC (data pushed by the caller): identical costs, controls, nominal controls and gain rows; the adapter's iLQR on its
+    own reproduces the MPC's first step (checked inside the demo)."""
+    import __graft_entry__ as ge
+    from mpc_ilqr_mujoco_amd import solver as sv
+    exes = ge.build_cpp_demos()
+    stance = np.ones((26, 2), dtype=np.int32); stance[4:9, 0] = 0
+    prob = sc.make_problem(sv.reference_kinematics, stance=stance, gravity=(0.0, 0.0, -2.0))
+    x0 = sc.synthetic_batch(1, 25, 3, np.zeros(19))[0][0]
+    _inputs(str(tmp_path / "in.bin"), prob, x0)
+    outs = {}
+    for name in ("cpp_api_demo", "cpp_eigen_drop_in_demo"):
+        out = str(tmp_path / (name + ".bin"))
+        r = subprocess.run([exes[name], str(tmp_path / "in.bin"), out], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, (name, r.returncode, r.stderr)
+        outs[name] = np.fromfile(out)
+    assert outs["cpp_api_demo"].size == 2 * (2 + 19 + 19 + 51) and np.array_equal(outs["cpp_api_demo"], outs["cpp_eigen_drop_in_demo"])
+
+
 @pytest.mark.gpu
 def test_config0_as_shipped_walking_mpc_through_the_cpp_mirror_matches_oracle(tmp_path):
     """BASELINE.json configs[0] as config.yaml ships it: walking references q_ref2_mj / v_ref2 /
