@@ -26,6 +26,7 @@ __device__ __forceinline__ bool sel(const DevState& S, int b, int mode) {
   return S.active[b] != 0 && S.need_retry[b] != 0;
 }
 
+#ifdef ILQR_LEGACY_KERNELS
 __global__ void __launch_bounds__(64) k_rollout_r(DevState S, ProblemDev P, int mode, int do_roll, int count_iter, double* cost_out) {
   extern __shared__ double lds[];
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -60,6 +61,7 @@ __global__ void __launch_bounds__(64) k_rollout_r(DevState S, ProblemDev P, int 
   c += knot_cost_t(P, b, N, x, (const double*)nullptr, ComReg());
   cost_out[b] = c;
 }
+#endif
 
 __global__ void __launch_bounds__(64) k_step_r(int count, const double* x, const double* u, DynParams dyn, double* xn) {
   extern __shared__ double lds[];
@@ -112,6 +114,7 @@ __device__ __forceinline__ double shfl_xor_f64(double v, int mask) {
   const int lo = __shfl_xor(__double2loint(v), mask), hi = __shfl_xor(__double2hiint(v), mask);
   return __hiloint2double(hi, lo);
 }
+#ifdef ILQR_LEGACY_KERNELS
 __global__ void __launch_bounds__(64) k_line_search_r(DevState S, ProblemDev P, int mode) {
   extern __shared__ double lds[];
   const int gid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -191,6 +194,7 @@ __global__ void __launch_bounds__(64) k_line_search_r(DevState S, ProblemDev P, 
   if (gid == 0) for (int q = 0; q < 8; ++q) S.J[q] = (double)ph[q];
 #endif
 }
+#endif
 
 // computeTotalCost (ilqr.cpp:363-518) of the 8 line-search candidates of every rollout, taken off the serial rollout of
 // the two-lanes-per-candidate line search (k_line_search_s, where it cost 78 k of 194 k cycles per step):
@@ -281,6 +285,7 @@ struct DumpSink {
     blk[18] = U[6]; blk[19] = s; blk[20] = c; blk[21] = 0.0;
   }
 };
+#ifdef ILQR_LEGACY_KERNELS
 __global__ void __launch_bounds__(64) k_lin_primal_r(DevState S, ProblemDev P, int mode) {
   extern __shared__ double lds[];
   const long knot = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -316,19 +321,19 @@ __global__ void __launch_bounds__(64) k_lin_primal_r(DevState S, ProblemDev P, i
 #pragma unroll
   for (int k = 0; k < 36; ++k) g[LinDumpG_IA0inv + k] = inv36[k];
 }
+#endif
 
 static inline int cdiv2(long a, long b) { return (int)((a + b - 1) / b); }
 int dyn_kernels_set_attr() {
   int rc = 0;
-  rc |= hipFuncSetAttribute((const void*)k_rollout_r, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DYN_LDS_BYTES) != hipSuccess;
   rc |= hipFuncSetAttribute((const void*)k_step_r, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DYN_LDS_BYTES) != hipSuccess;
   rc |= hipFuncSetAttribute((const void*)k_last_step_r, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DYN_LDS_BYTES) != hipSuccess;
+#ifdef ILQR_LEGACY_KERNELS
+  rc |= hipFuncSetAttribute((const void*)k_rollout_r, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DYN_LDS_BYTES) != hipSuccess;
   rc |= hipFuncSetAttribute((const void*)k_line_search_r, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DYN_LDS_BYTES) != hipSuccess;
   rc |= hipFuncSetAttribute((const void*)k_lin_primal_r, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DYN_LDS_BYTES) != hipSuccess;
+#endif
   return rc;
-}
-void launch_rollout_r(const DevState& S, const ProblemDev& P, int mode, int do_roll, int count_iter, double* cost_out, hipStream_t st) {
-  hipLaunchKernelGGL(k_rollout_r, dim3(cdiv2(S.B, 64)), dim3(64), DYN_LDS_BYTES, st, S, P, mode, do_roll, count_iter, cost_out);
 }
 void launch_step_r(int count, const double* x, const double* u, const DynParams& dyn, double* xn, hipStream_t st) {
   hipLaunchKernelGGL(k_step_r, dim3(cdiv2(count, 64)), dim3(64), DYN_LDS_BYTES, st, count, x, u, dyn, xn);
@@ -336,11 +341,21 @@ void launch_step_r(int count, const double* x, const double* u, const DynParams&
 void launch_last_step_r(const DevState& S, const ProblemDev& P, hipStream_t st) {
   hipLaunchKernelGGL(k_last_step_r, dim3(cdiv2(S.B, 64)), dim3(64), DYN_LDS_BYTES, st, S, P);
 }
+// the one-lane cross-check family (ILQR_ROLLOUT=r / ILQR_LS=r): compiled into the test library only (-DILQR_LEGACY_KERNELS)
+#ifdef ILQR_LEGACY_KERNELS
+void launch_rollout_r(const DevState& S, const ProblemDev& P, int mode, int do_roll, int count_iter, double* cost_out, hipStream_t st) {
+  hipLaunchKernelGGL(k_rollout_r, dim3(cdiv2(S.B, 64)), dim3(64), DYN_LDS_BYTES, st, S, P, mode, do_roll, count_iter, cost_out);
+}
 void launch_line_search_r(const DevState& S, const ProblemDev& P, int mode, hipStream_t st) {
   hipLaunchKernelGGL(k_line_search_r, dim3(cdiv2((long)S.B * 8, 64)), dim3(64), DYN_LDS_BYTES, st, S, P, mode);
 }
 void launch_lin_primal_r(const DevState& S, const ProblemDev& P, int mode, hipStream_t st) {
   hipLaunchKernelGGL(k_lin_primal_r, dim3(cdiv2((long)S.B * S.N, 64)), dim3(64), DYN_LDS_BYTES, st, S, P, mode);
 }
+#else
+void launch_rollout_r(const DevState&, const ProblemDev&, int, int, int, double*, hipStream_t) {}
+void launch_line_search_r(const DevState&, const ProblemDev&, int, hipStream_t) {}
+void launch_lin_primal_r(const DevState&, const ProblemDev&, int, hipStream_t) {}
+#endif
 
 }  // namespace ilqr

@@ -161,7 +161,7 @@ struct StageTimer {
 
 static inline void enter(ilqr_hip_ctx* c) {
   hipSetDevice(c->device);
-  if (c->knobs.per_call) c->knobs = read_knobs();
+  if (c->knobs.per_call) { const Knobs k = read_knobs(); if (ilqr::variants_supported(k.var)) c->knobs = k; }     // (an unsupported selection keeps the previous one)
   ilqr::set_variants(c->knobs.var);
 }
 
@@ -174,6 +174,13 @@ int ilqr_hip_create(ilqr_hip_ctx** out, int device, int batch, int horizon, doub
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return ILQR_ERR_NO_DEVICE;
   ilqr_hip_ctx* c = new ilqr_hip_ctx();
   c->device = device; c->B = batch; c->N = horizon;
+  if (!ilqr::variants_supported(c->knobs.var)) {
+    // (the handle is returned so that ilqr_hip_last_error can say why; the caller destroys it)
+    c->err = "the environment selects a cross-check kernel family (ILQR_BACKWARD / ILQR_LS / ILQR_ROLLOUT / ILQR_DYN / ILQR_LINT) that this library does not hold: "
+             "they are compiled into the test library only (make ../lib/libilqr_hip_legacy.so, -DILQR_LEGACY_KERNELS)";
+    *out = c;
+    return ILQR_ERR_UNSUPPORTED;
+  }
   if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&c->stream) != hipSuccess || hipStreamCreate(&c->stream2) != hipSuccess || hipStreamCreate(&c->stream3) != hipSuccess || hipEventCreateWithFlags(&c->ev_roll, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_lin, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_adopt, hipEventDisableTiming) != hipSuccess) { delete c; return ILQR_ERR_NO_DEVICE; }
@@ -733,7 +740,13 @@ static int enqueue_solve(ilqr_hip_ctx* c, const DevState& S, const h1::ProblemDe
 int ilqr_hip_get_split_iterations(const ilqr_hip_ctx* c) { return c ? c->split_iterations : -1; }
 int ilqr_hip_get_speculative_iterations(const ilqr_hip_ctx* c) { return c ? c->spec_iterations : -1; }
 int ilqr_hip_set_dedup_saturated_retry(ilqr_hip_ctx* c, int on) { if (!c) return ILQR_ERR_ARG; c->dedup_retry = on ? 1 : 0; return ILQR_OK; }
-int ilqr_hip_reload_environment(ilqr_hip_ctx* c) { if (!c) return ILQR_ERR_ARG; const bool pc = c->knobs.per_call; c->knobs = read_knobs(); c->knobs.per_call = c->knobs.per_call || pc; return ILQR_OK; }
+int ilqr_hip_reload_environment(ilqr_hip_ctx* c) {
+  if (!c) return ILQR_ERR_ARG;
+  const Knobs k = read_knobs();
+  if (!ilqr::variants_supported(k.var)) { c->err = "the environment selects a kernel family this library does not hold (see ilqr_hip_create)"; return ILQR_ERR_UNSUPPORTED; }
+  const bool pc = c->knobs.per_call; c->knobs = k; c->knobs.per_call = k.per_call || pc;
+  return ILQR_OK;
+}
 int ilqr_hip_num_slices(const ilqr_hip_ctx* c) { return c ? slices_wanted(c, c->B) : -1; }
 // The analytic Jacobians differentiate the constrained step with the active set held fixed (modes 1, 2); a sliding foot's
 // constraint rows turn with the foot, which they do not carry: mode 3 linearises by the reference's forward differences.

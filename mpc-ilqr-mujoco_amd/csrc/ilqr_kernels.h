@@ -114,6 +114,7 @@ int backward_needs_lds_attr();
 struct Variants { int scalar_dyn, rollout_split, ls_split, backward, fold, lin_one_knot; };
 Variants read_variants();
 void set_variants(const Variants& v);
+int variants_supported(const Variants& v);      // 0: the environment selects a cross-check family this build does not hold (-DILQR_LEGACY_KERNELS)
 int variant_ls_split();
 int variant_rollout_split();
 int variant_backward();

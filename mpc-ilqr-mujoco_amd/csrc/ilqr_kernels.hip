@@ -39,6 +39,7 @@ __device__ __forceinline__ bool selected(const DevState& S, int b, int mode) {
 
 // ------------------------------------------------------------------ K1: nominal rollout + cost
 // thread per rollout. mode MASK_ALL also used by the stage API. do_roll = 0 -> cost only.
+#ifdef ILQR_LEGACY_KERNELS
 __global__ void __launch_bounds__(64) k_rollout(DevState S, ProblemDev P, int mode, int do_roll, int count_iter, double* cost_out) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= S.B || !selected(S, b, mode)) return;
@@ -63,8 +64,10 @@ __global__ void __launch_bounds__(64) k_rollout(DevState S, ProblemDev P, int mo
   c += knot_cost(P, b, N, x, nullptr);
   cost_out[b] = c;
 }
+#endif
 
 // plain batched step for the stage API
+#ifdef ILQR_LEGACY_KERNELS
 __global__ void __launch_bounds__(64) k_step(int count, const double* x, const double* u, DynParams dyn, double* xn, int stance_l, int stance_r) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= count) return;
@@ -75,6 +78,7 @@ __global__ void __launch_bounds__(64) k_step(int count, const double* x, const d
   step<double>(xl, ul, dyn, out, stance);
   for (int k = 0; k < H1_NX; ++k) xn[(size_t)i * H1_NX + k] = out[k];
 }
+#endif
 
 // ------------------------------------------------------------------ K2: dynamics Jacobians
 // Analytic mode = two kernels (h1_linearize_dev.h):
@@ -92,6 +96,7 @@ __global__ void __launch_bounds__(64) k_step(int count, const double* x, const d
 // workgroups per CU before, now 6 x 2 waves): wave 0 accumulates the inverse-dynamics forces and sweeps the legs, wave 1 runs
 // the Minv sweeps and sweeps torso + arms; the Minv product is split by row tile, the 51 columns of A go to wave 0 and the 19
 // of B to wave 1.  A knot's critical path drops from ~107 k to ~65 k cycles and twice as many waves hide each other's latencies.
+#ifdef ILQR_LEGACY_KERNELS
 __global__ void __launch_bounds__(128, 3) k_lin_tangent(DevState S, ProblemDev P, int mode, const int* list, const int* count) {
   const int t = blockIdx.x, tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
   int b = blockIdx.y;
@@ -137,6 +142,7 @@ __global__ void __launch_bounds__(128, 3) k_lin_tangent(DevState S, ProblemDev P
   if (wv == 1 && lane < H1_NU) lin_column(L, 1, lane, [&](int r, double v) { Bg[r * H1_NU + lane] = v; });
   LSTAMP(6)
 }
+#endif
 
 // Column stores of the two-knot tangent kernels.  PACK (inside a solve whose backward pass is the operand-layout Riccati kernel,
 // riccati_pack.hip): column c of A_t goes to column slot pk_state_slot(c) of the packed image A~, row r to row slot pk_state_slot(r)
@@ -249,6 +255,7 @@ __global__ void __launch_bounds__(256, 3) k_lin_tangent2(DevState S, ProblemDev 
 // primal dump is the free solve, the multipliers and the constrained accelerations are rebuilt here (twelve unit-wrench
 // lanes beside the 25 Minv lanes), the tangent sweeps carry the contact wrench as an external force and collect the
 // constraint-row tangents, and the final product is -Minv dT + G dlambda.
+#ifdef ILQR_LEGACY_KERNELS
 __global__ void __launch_bounds__(128, 2) k_lin_tangent_c(DevState S, ProblemDev P, int mode, const int* list, const int* count) {
   const int t = blockIdx.x, tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
   int b = blockIdx.y;
@@ -302,6 +309,7 @@ __global__ void __launch_bounds__(128, 2) k_lin_tangent_c(DevState S, ProblemDev
   if (wv == 1 && lane < H1_NU) lin_column(L, 1, lane, [&](int r, double v) { Bg[r * H1_NU + lane] = v; }, Cc.G, Cc.WU);
   LSTAMP(7)
 }
+#endif
 
 // Round 4: the stance-constrained tangent kernel with two knots per four-wave workgroup (h1_linearize_contact_dev.h "two knots per
 // four-wave workgroup"): the leg and arm sweeps of both knots on one wave each (64 lanes), the Minv columns of both knots on wave
@@ -384,6 +392,7 @@ __global__ void __launch_bounds__(256, 2) k_lin_tangent2c(DevState S, ProblemDev
 // thread per (rollout, knot, column); columns 0..50 = d/dx, 51..69 = d/du.
 // The unperturbed step f(x_t, u_t) is evaluated once per knot (k_fd_base, thread per knot, into the first 51 slots of the
 // knot's lin_dump record, unused in this mode) -- as the reference does (robot_utils.cpp:126) -- not once per column.
+#ifdef ILQR_LEGACY_KERNELS
 __global__ void __launch_bounds__(64) k_fd_base(DevState S, ProblemDev P, int mode) {
   const long item = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (item >= (long)S.B * S.N) return;
@@ -399,6 +408,8 @@ __global__ void __launch_bounds__(64) k_fd_base(DevState S, ProblemDev P, int mo
   double* out = S.lin_dump + (size_t)item * LinDumpG_SIZE;
   for (int i = 0; i < H1_NX; ++i) out[i] = base[i];
 }
+#endif
+#ifdef ILQR_LEGACY_KERNELS
 __global__ void __launch_bounds__(256) k_linearize_fd(DevState S, ProblemDev P, int mode, double eps) {
   const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const int NC = H1_NX + H1_NU;
@@ -423,6 +434,7 @@ __global__ void __launch_bounds__(256) k_linearize_fd(DevState S, ProblemDev P, 
   if (col < H1_NX) { for (int i = 0; i < H1_NX; ++i) Ag[i * H1_NX + col] = (pert[i] - base[i]) / eps; }
   else { const int c = col - H1_NX; for (int i = 0; i < H1_NX; ++i) Bg[i * H1_NU + c] = (pert[i] - base[i]) / eps; }
 }
+#endif
 
 // K3 (cost quadratics) lives in quad_kernels.hip
 
@@ -430,6 +442,7 @@ __global__ void __launch_bounds__(256) k_linearize_fd(DevState S, ProblemDev P, 
 // one 256-thread workgroup per rollout; Vxx, A_t, W, B_t, G, Qxu, K_t staged in LDS.
 #define LDN 52   // padded leading dimension of 51-wide LDS matrices
 #define LDM 20   // padded leading dimension of 19-wide LDS matrices
+#ifdef ILQR_LEGACY_KERNELS
 __global__ void __launch_bounds__(256) k_backward(DevState S, int mode) {
   const int b = blockIdx.x, tid = threadIdx.x;
   if (!selected(S, b, mode)) return;
@@ -575,6 +588,7 @@ __global__ void __launch_bounds__(256) k_backward(DevState S, int mode) {
   for (int e = tid; e < n * n; e += 256) S.Vxx[(size_t)b * n * n + e] = Vxx[(e / n) * LDN + (e % n)];
   if (tid < n) S.Vx[(size_t)b * n + tid] = Vx[tid];
 }
+#endif
 size_t backward_lds_bytes() {
   const int n = H1_NX, m = H1_NU;
   return sizeof(double) * (size_t)(3 * n * LDN + 3 * n * LDM + 2 * m * LDN + 2 * m * LDM + 2 * n + 3 * LDM);
@@ -583,6 +597,7 @@ size_t backward_lds_bytes() {
 // ------------------------------------------------------------------ K5: line search, all 8 alphas at once
 // thread per (rollout, alpha); candidates kept in HBM, k_control copies the accepted one.
 __constant__ double ALPHAS[8] = {1.0, 0.8, 0.6, 0.4, 0.2, 0.1, 0.05, 0.01};
+#ifdef ILQR_LEGACY_KERNELS
 __global__ void __launch_bounds__(64) k_line_search(DevState S, ProblemDev P, int mode) {
   const int gid = blockIdx.x * blockDim.x + threadIdx.x;
   const int b = gid >> 3, ai = gid & 7;
@@ -614,6 +629,7 @@ __global__ void __launch_bounds__(64) k_line_search(DevState S, ProblemDev P, in
   c += knot_cost(P, b, N, x, nullptr);
   S.cand_cost[(size_t)b * 8 + ai] = c;
 }
+#endif
 
 // ------------------------------------------------------------------ K6: iteration control
 // one wave per rollout, 16 rollouts per workgroup: lane 0 decides (ilqr.cpp:619-655), all lanes copy the accepted candidate.
@@ -914,6 +930,7 @@ __global__ void k_adopt_rollout(DevState S, const double* shadow, int mode, unsi
   if (bad) atomicAdd(mismatches, (unsigned long long)bad);
 }
 // last knot of the warm start: xbar[N] = f(xbar[N-1], ubar[N-1])
+#ifdef ILQR_LEGACY_KERNELS
 __global__ void k_last_step(DevState S, ProblemDev P) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= S.B) return;
@@ -924,6 +941,7 @@ __global__ void k_last_step(DevState S, ProblemDev P) {
   step<double>(x, u, P.dyn, xn, P.stance + b * P.stance_stride + 2 * (N - 1));
   for (int i = 0; i < H1_NX; ++i) S.xbar[((size_t)b * (N + 1) + N) * H1_NX + i] = xn[i];
 }
+#endif
 
 // u = ubar[0] + K[0] (x_meas - xbar[0]); also packs the first-knot results for the per-step gather
 __global__ void k_compute_control(DevState S, const double* x_meas, double* u_out) {
@@ -991,11 +1009,30 @@ static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 //                     the folded one-wave kernel on the standard layout (riccati_wave.hip) / never a folded variant / four-wave MFMA
 //                     (riccati_mfma.hip) / LDS + VALU cross-check
 //   ILQR_LINT=1       the one-knot two-wave tangent kernel (cross-check of k_lin_tangent2)
-static thread_local Variants g_var = {0, ROLLOUT_SPLIT_DEFAULT, LS_SPLIT_DEFAULT, -1, 2, 0};
-static int env_split(const char* var, int dflt) { const char* e = getenv(var); return !e ? dflt : (e[0] == 's' ? 1 : 0); }
 #ifndef BACKWARD_DEFAULT
 #define BACKWARD_DEFAULT 2
 #endif
+#define BACKWARD_DEFAULT_VALUE BACKWARD_DEFAULT
+static thread_local Variants g_var = {0, ROLLOUT_SPLIT_DEFAULT, LS_SPLIT_DEFAULT, -1, 2, 0};
+// The cross-check families -- scalar scratch-resident dynamics (ILQR_DYN=s), one-lane rollout / line search / primal dump
+// (ILQR_ROLLOUT=r, ILQR_LS=r), the VALU and four-wave Riccati kernels (ILQR_BACKWARD=valu / wg), the folded Riccati kernel on the
+// standard layout (wave-fold), the one-knot tangent kernels (ILQR_LINT=1) -- are compiled with -DILQR_LEGACY_KERNELS only: the test
+// library lib/libilqr_hip_legacy.so.  The product library holds the default family alone; ilqr_hip_create refuses a handle whose
+// environment selects anything else (variants_supported).
+#ifdef ILQR_LEGACY_KERNELS
+#define LEGACY_LAUNCH(...) __VA_ARGS__
+#else
+#define LEGACY_LAUNCH(...) (void)0
+#endif
+int variants_supported(const Variants& v) {
+#ifdef ILQR_LEGACY_KERNELS
+  (void)v; return 1;
+#else
+  const int bk = v.backward < 0 ? BACKWARD_DEFAULT_VALUE : v.backward;
+  return (!v.scalar_dyn && v.rollout_split && v.ls_split && bk == 2 && v.fold != 1 && !v.lin_one_knot) ? 1 : 0;
+#endif
+}
+static int env_split(const char* var, int dflt) { const char* e = getenv(var); return !e ? dflt : (e[0] == 's' ? 1 : 0); }
 static int backward_kind() { return g_var.backward < 0 ? BACKWARD_DEFAULT : g_var.backward; }
 static int use_scalar_dyn() { return g_var.scalar_dyn; }
 Variants read_variants() {
@@ -1022,16 +1059,16 @@ int variant_pack() { return (backward_kind() == 2 && g_var.fold == 2) ? 1 : 0; }
 void launch_rollout(const DevState& S, const ProblemDev& P, int mode, int do_roll, int count_iter, double* cost_out, hipStream_t st) {
   // contact mode (f4) runs on the two-lane kernels (the one-lane register kernels are constraint-free only)
   if (!use_scalar_dyn()) { if (g_var.rollout_split || P.dyn.contact) launch_rollout_s(S, P, mode, do_roll, count_iter, cost_out, st); else launch_rollout_r(S, P, mode, do_roll, count_iter, cost_out, st); return; }
-  hipLaunchKernelGGL(k_rollout, dim3(cdiv(S.B, 64)), dim3(64), 0, st, S, P, mode, do_roll, count_iter, cost_out);
+  LEGACY_LAUNCH(hipLaunchKernelGGL(k_rollout, dim3(cdiv(S.B, 64)), dim3(64), 0, st, S, P, mode, do_roll, count_iter, cost_out));
 }
 void launch_step(int count, const double* x, const double* u, const DynParams& dyn, double* xn, hipStream_t st, int stance_l, int stance_r) {
   if (!use_scalar_dyn()) { if (dyn.contact) launch_step_s(count, x, u, dyn, xn, st, stance_l, stance_r); else launch_step_r(count, x, u, dyn, xn, st); return; }
-  hipLaunchKernelGGL(k_step, dim3(cdiv(count, 64)), dim3(64), 0, st, count, x, u, dyn, xn, stance_l, stance_r);
+  LEGACY_LAUNCH(hipLaunchKernelGGL(k_step, dim3(cdiv(count, 64)), dim3(64), 0, st, count, x, u, dyn, xn, stance_l, stance_r));
 }
 // phases: 1 = primal dump only, 2 = tangent sweeps / FD only, 3 = both
 // constraint-free tangent kernel: two knots per four-wave workgroup (default) or, ILQR_LINT=1, the one-knot two-wave kernel
 static void launch_lin_tangent_free(const DevState& S, const ProblemDev& P, int mode, hipStream_t st, const WorkList& w, int pack) {
-  if (g_var.lin_one_knot) { hipLaunchKernelGGL(k_lin_tangent, dim3(S.N, S.B), dim3(128), 0, st, S, P, mode, w.list, w.count); if (pack) launch_pack_ab(S, st, mode, w.list, w.count); return; }
+  if (g_var.lin_one_knot) { LEGACY_LAUNCH(hipLaunchKernelGGL(k_lin_tangent, dim3(S.N, S.B), dim3(128), 0, st, S, P, mode, w.list, w.count)); if (pack) launch_pack_ab(S, st, mode, w.list, w.count); return; }
   const long items = (long)S.B * S.N;
   if (pack) hipLaunchKernelGGL(k_lin_tangent2<true>, dim3((unsigned)((items + 1) / 2)), dim3(256), 0, st, S, P, mode, w.list, w.count);
   else hipLaunchKernelGGL(k_lin_tangent2<false>, dim3((unsigned)((items + 1) / 2)), dim3(256), 0, st, S, P, mode, w.list, w.count);
@@ -1043,7 +1080,7 @@ void launch_linearize(const DevState& S, const ProblemDev& P, int mode, int jac_
     if (phases & 1) { if (g_var.rollout_split || P.dyn.contact) launch_lin_primal_s(S, P, mode, st, w.list, w.count); else launch_lin_primal_r(S, P, mode, st); }   // (contact mode: the dump is the free solve, see k_lin_tangent_c)
     if ((phases & 2) && P.dyn.contact) {
       const dim3 grid2((unsigned)(((long)S.B * S.N + 1) / 2));
-      if (g_var.lin_one_knot) { hipLaunchKernelGGL(k_lin_tangent_c, dim3(S.N, S.B), dim3(128), 0, st, S, P, mode, w.list, w.count); if (pack) launch_pack_ab(S, st, mode, w.list, w.count); }
+      if (g_var.lin_one_knot) { LEGACY_LAUNCH(hipLaunchKernelGGL(k_lin_tangent_c, dim3(S.N, S.B), dim3(128), 0, st, S, P, mode, w.list, w.count)); if (pack) launch_pack_ab(S, st, mode, w.list, w.count); }
       else if (pack) hipLaunchKernelGGL(k_lin_tangent2c<true>, grid2, dim3(256), 0, st, S, P, mode, w.list, w.count);
       else hipLaunchKernelGGL(k_lin_tangent2c<false>, grid2, dim3(256), 0, st, S, P, mode, w.list, w.count);
     }
@@ -1055,8 +1092,9 @@ void launch_linearize(const DevState& S, const ProblemDev& P, int mode, int jac_
     launch_linearize_fd_s(S, P, mode, eps, st);       // forward differences on the two-lane step (any contact mode)
   } else if (phases & 2) {
     const long total = (long)S.B * S.N * (H1_NX + H1_NU);
-    hipLaunchKernelGGL(k_fd_base, dim3(cdiv((long)S.B * S.N, 64)), dim3(64), 0, st, S, P, mode);
-    hipLaunchKernelGGL(k_linearize_fd, dim3(cdiv(total, 256)), dim3(256), 0, st, S, P, mode, eps);
+    LEGACY_LAUNCH(hipLaunchKernelGGL(k_fd_base, dim3(cdiv((long)S.B * S.N, 64)), dim3(64), 0, st, S, P, mode));
+    LEGACY_LAUNCH(hipLaunchKernelGGL(k_linearize_fd, dim3(cdiv(total, 256)), dim3(256), 0, st, S, P, mode, eps));
+    (void)total;
   }
 }
 size_t lin_dump_doubles() { return LinDumpG_SIZE; }
@@ -1070,7 +1108,7 @@ double linearize_fold_h(const ProblemDev& P, int jac_mode) {
 // kernel (riccati_mfma.hip), =wave the one-wave-per-rollout MFMA kernel (riccati_wave.hip)
 void launch_backward(const DevState& S, int mode, hipStream_t st, double fold_h, int iter) {
   const int kind = backward_kind();
-  if (kind == 1) hipLaunchKernelGGL(k_backward, dim3(S.B), dim3(256), backward_lds_bytes(), st, S, mode);
+  if (kind == 1) LEGACY_LAUNCH(hipLaunchKernelGGL(k_backward, dim3(S.B), dim3(256), backward_lds_bytes(), st, S, mode));
   else if (kind == 2) {
     // inside a solve (iter >= 0) the selected rollouts come from the compacted list of this pass
     const int slot = (S.order && iter >= 0 && mode != MASK_ALL) ? 2 * iter + (mode == MASK_RETRY ? 1 : 0) : -1;
@@ -1078,7 +1116,7 @@ void launch_backward(const DevState& S, int mode, hipStream_t st, double fold_h,
     if (g_var.fold == 2 && fold_h != 0.0) launch_backward_pack(S, mode, st, fold_h, list, count);      // (S.A, S.Bm, S.lxx in the operand layout: the caller's business)
     else launch_backward_wave(S, mode, st, g_var.fold == 1 ? fold_h : 0.0, list, count);
   }
-  else launch_backward_mfma(S, mode, st);
+  else LEGACY_LAUNCH(launch_backward_mfma(S, mode, st));
 }
 void launch_line_search(const DevState& S, const ProblemDev& P, int mode, hipStream_t st, int iter, int max_rollouts) {
   if (!use_scalar_dyn()) {
@@ -1090,7 +1128,7 @@ void launch_line_search(const DevState& S, const ProblemDev& P, int mode, hipStr
     else launch_line_search_r(S, P, mode, st);                                                  // (the one-lane kernel sums its own)
     return;
   }
-  hipLaunchKernelGGL(k_line_search, dim3(cdiv((long)S.B * 8, 64)), dim3(64), 0, st, S, P, mode);
+  LEGACY_LAUNCH(hipLaunchKernelGGL(k_line_search, dim3(cdiv((long)S.B * 8, 64)), dim3(64), 0, st, S, P, mode));
 }
 // inside a solve the two-lane line search leaves per-knot costs behind and k_control sums them itself (ls_costs_per_knot)
 bool ls_costs_per_knot(const ProblemDev& P) { return !use_scalar_dyn() && (g_var.ls_split || P.dyn.contact); }
@@ -1111,7 +1149,7 @@ void launch_line_search_list(const DevState& S, const ProblemDev& P, hipStream_t
 void launch_solve_begin(const DevState& S, hipStream_t st) { hipLaunchKernelGGL(k_solve_begin, dim3(cdiv(S.B, 64)), dim3(64), 0, st, S); }
 void launch_adopt_rollout(const DevState& S, const double* shadow, int mode, unsigned long long* mismatches, hipStream_t st) { hipLaunchKernelGGL(k_adopt_rollout, dim3(S.B), dim3(64), 0, st, S, shadow, mode, mismatches); }
 void launch_warm_shift(const DevState& S, const double* px, const double* pu, hipStream_t st) { hipLaunchKernelGGL(k_warm_shift, dim3(S.B), dim3(64), 0, st, S, px, pu); }
-void launch_last_step(const DevState& S, const ProblemDev& P, hipStream_t st) { if (!use_scalar_dyn()) { if (P.dyn.contact) launch_last_step_s(S, P, st); else launch_last_step_r(S, P, st); return; } hipLaunchKernelGGL(k_last_step, dim3(cdiv(S.B, 64)), dim3(64), 0, st, S, P); }
+void launch_last_step(const DevState& S, const ProblemDev& P, hipStream_t st) { if (!use_scalar_dyn()) { if (P.dyn.contact) launch_last_step_s(S, P, st); else launch_last_step_r(S, P, st); return; } LEGACY_LAUNCH(hipLaunchKernelGGL(k_last_step, dim3(cdiv(S.B, 64)), dim3(64), 0, st, S, P)); }
 void launch_compute_control(const DevState& S, const double* x_meas, double* u_out, hipStream_t st) { hipLaunchKernelGGL(k_compute_control, dim3(S.B), dim3(64), 0, st, S, x_meas, u_out); }
 void launch_pack_first_knot(const DevState& S, double* u0, double* K0, hipStream_t st) { hipLaunchKernelGGL(k_pack_first_knot, dim3(S.B), dim3(64), 0, st, S, u0, K0); }
 void launch_pack_payload(const DevState& S, int with_gains, double* out, hipStream_t st) { hipLaunchKernelGGL(k_pack_payload, dim3(S.B), dim3(64), 0, st, S, with_gains, out); }
@@ -1119,7 +1157,11 @@ int backward_needs_lds_attr() {
   if (backward_mfma_set_attr() != 0) return 1;
   if (dyn_kernels_set_attr() != 0) return 1;
   if (dyn_split_kernels_set_attr() != 0) return 1;
+#ifdef ILQR_LEGACY_KERNELS
   return hipFuncSetAttribute((const void*)k_backward, hipFuncAttributeMaxDynamicSharedMemorySize, (int)backward_lds_bytes()) == hipSuccess ? 0 : 1;
+#else
+  return 0;
+#endif
 }
 
 }  // namespace ilqr

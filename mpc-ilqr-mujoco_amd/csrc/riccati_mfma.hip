@@ -26,6 +26,16 @@
 // (ilqr.cpp:294-307), symmetric by construction (ilqr.cpp:307), differing only in rounding (parity tests).
 // LDS operands use leading dimensions chosen so that the MFMA operand reads are bank-conflict free:
 // 54 / 22 for [i][k]-pattern reads, 80 / 48 for [k][j]-pattern reads of 64 / 32 columns.
+// Compiled into the test library only (-DILQR_LEGACY_KERNELS, lib/libilqr_hip_legacy.so): ILQR_BACKWARD=wg, a cross-check family.
+#ifndef ILQR_LEGACY_KERNELS
+#include <hip/hip_runtime.h>
+#include "ilqr_kernels.h"
+namespace ilqr {
+void launch_backward_mfma(const DevState&, int, hipStream_t) {}
+int backward_mfma_set_attr() { return 0; }
+size_t backward_mfma_lds_bytes() { return 0; }
+}  // namespace ilqr
+#else
 #include <hip/hip_runtime.h>
 
 #include "h1_dynamics_dev.h"
@@ -416,3 +426,5 @@ void launch_backward_mfma(const DevState& S, int mode, hipStream_t st) {
 }
 
 }  // namespace ilqr
+
+#endif

@@ -791,8 +791,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
 // fold_h: the step size h when A_t, B_t come from the analytic linearisation kernels (their hinge-position rows are then
 // exactly e_k + h * the hinge-velocity rows, see fold_rows), 0 for Jacobians of any other origin (generic kernel)
 void launch_backward_wave(const DevState& S, int mode, hipStream_t st, double fold_h, const int* list, const int* count) {
-  if (fold_h != 0.0) hipLaunchKernelGGL(k_backward_wave<true>, dim3(S.B), dim3(64), 0, st, S, mode, fold_h, list, count);
-  else hipLaunchKernelGGL(k_backward_wave<false>, dim3(S.B), dim3(64), 0, st, S, mode, 0.0, list, count);
+#ifdef ILQR_LEGACY_KERNELS      // (the folded variant on the standard layout, ILQR_BACKWARD=wave-fold: cross-check of riccati_pack.hip, test library only)
+  if (fold_h != 0.0) { hipLaunchKernelGGL(k_backward_wave<true>, dim3(S.B), dim3(64), 0, st, S, mode, fold_h, list, count); return; }
+#endif
+  hipLaunchKernelGGL(k_backward_wave<false>, dim3(S.B), dim3(64), 0, st, S, mode, 0.0, list, count);
 }
 
 }  // namespace ilqr

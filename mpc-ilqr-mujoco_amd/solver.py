@@ -40,23 +40,30 @@ EXPORTS = [
     "ilqr_hip_reference_kinematics", "ilqr_hip_reference_com_velocity", "ilqr_hip_foot_clearance", "ilqr_hip_gravity_compensation", "ilqr_hip_stream",
 ]
 
-_lib = None
 
 
 class ILQRError(RuntimeError):
     pass
 
 
-def load_library(path=LIB_PATH):
-    """Load libilqr_hip.so; fails loudly when the HIP extension has not been built."""
-    global _lib
-    if _lib is None:
+_libs = {}
+# test library with every cross-check kernel family compiled in (csrc/Makefile, -DILQR_LEGACY_KERNELS); the product library
+# holds the default family only and refuses a handle whose environment selects another
+LEGACY_LIB_PATH = os.path.join(_HERE, "lib", "libilqr_hip_legacy.so")
+
+
+def load_library(path=None):
+    """Load libilqr_hip.so (or the library at `path`); fails loudly when the HIP extension has not been built."""
+    path = LIB_PATH if path is None else path
+    lib = _libs.get(path)
+    if lib is None:
         if not os.path.exists(path):
             raise ILQRError("HIP extension missing: %s (run __graft_entry__.build())" % path)
-        _lib = C.CDLL(path)
-        _lib.ilqr_hip_last_error.restype = C.c_char_p
-        _lib.ilqr_hip_stream.restype = C.c_void_p
-    return _lib
+        lib = C.CDLL(path)
+        lib.ilqr_hip_last_error.restype = C.c_char_p
+        lib.ilqr_hip_stream.restype = C.c_void_p
+        _libs[path] = lib
+    return lib
 
 
 def _c64(a):
@@ -116,8 +123,8 @@ def gravity_compensation(x, gravity):
 class BatchedILQR:
     """iLQR for B independent rollouts on one GPU (reference include/ilqr/ilqr.hpp:17-45)."""
 
-    def __init__(self, batch, N=25, dt=0.02, device=0):
-        self.L = load_library()
+    def __init__(self, batch, N=25, dt=0.02, device=0, lib_path=None):
+        self.L = load_library(lib_path)
         self.B, self.N, self.dt = int(batch), int(N), float(dt)
         self.max_iter = 10
         h = C.c_void_p()
@@ -125,6 +132,7 @@ class BatchedILQR:
         self.h = h
         if rc:
             msg = self.L.ilqr_hip_last_error(h).decode() if h else ""
+            self.close()
             raise ILQRError("ilqr_hip_create failed: %s %s" % (STATUS.get(rc, rc), msg))
 
     def set_dedup_saturated_retry(self, on=True):

@@ -19,8 +19,18 @@ pkg = load_package()
 sc = pkg.scenario
 
 
-def _solver(*a, **k):
+def _needs_legacy():
+    """does the environment select a cross-check kernel family?  (compiled into lib/libilqr_hip_legacy.so only)"""
+    e = os.environ
+    return (e.get("ILQR_BACKWARD", "wave") not in ("wave", "wave-generic") or e.get("ILQR_LS", "s")[:1] != "s" or e.get("ILQR_ROLLOUT", "s")[:1] != "s"
+            or e.get("ILQR_DYN", "")[:1] == "s" or e.get("ILQR_LINT", "0") == "1")
+
+
+def _solver(*a, legacy=False, **k):
+    """legacy=True: a handle of the test library, for tests that switch to a cross-check family around calls on ONE handle"""
     from mpc_ilqr_mujoco_amd import solver as sv
+    if legacy or _needs_legacy():
+        k["lib_path"] = sv.LEGACY_LIB_PATH
     return sv.BatchedILQR(*a, **k)
 
 
@@ -155,7 +165,7 @@ def test_folded_backward_pass_equals_generic_kernel_and_numpy(contact):
     (ILQR_BACKWARD=wave-generic) and NumPy; then with an indefinite Quu, where the folded products feed the Gauss-Jordan fallback."""
     B = 3
     prob, x0, ui = standing(B, seed=17, gravity=[0.0, 0.0, -9.81] if contact else None)
-    s = _solver(B); s.set_problem(prob); s.set_contact_mode(contact); s.set_options(jacobian_mode=0); s.set_regularization(1e-6)
+    s = _solver(B, legacy=True); s.set_problem(prob); s.set_contact_mode(contact); s.set_options(jacobian_mode=0); s.set_regularization(1e-6)
     s.initialize(x0, ui)
     s.stage_linearize(); s.stage_cost_quadratics()
     A, Bm = s.linearization()
@@ -208,7 +218,7 @@ def test_stage_backward_pass_on_another_kernel_family_after_a_solve_sees_the_who
     B = 3
     prob, x0, ui = standing(B, seed=29)
     with env(ILQR_BACKWARD=kind):
-        s = _solver(B); s.set_problem(prob); s.set_max_iterations(2); s.set_options(early_exit=False)
+        s = _solver(B, legacy=True); s.set_problem(prob); s.set_max_iterations(2); s.set_options(early_exit=False)      # (the VALU family below: test library)
         s.initialize(x0, ui); s.solve()
         Ksolve = s.gains_K()
         lx, lu, lxx, luu = s.quadratics()
@@ -796,6 +806,21 @@ def test_cpp_multi_gpu_demo_one_rank(tmp_path):
     s.initialize(x0, ui); c = s.solve(x0)
     assert rel(rows[:, 19], c) < 1e-9 and rel(rows[:, :19], s.ubar()[:, 0]) < 1e-8 and rel(rows[:, 20:].reshape(B, 19, 51), s.gains_K()[:, 0]) < 1e-7
     s.close()
+
+
+def test_product_library_holds_the_default_kernel_family_only():
+    """The cross-check families (scalar / one-lane dynamics, VALU and four-wave Riccati, the folded Riccati kernel on the standard layout,
+    one-knot tangent kernels) live in lib/libilqr_hip_legacy.so (-DILQR_LEGACY_KERNELS, tests only).  The product library refuses a
+    handle whose environment selects one of them -- loudly, with the reason -- instead of silently running something else."""
+    from mpc_ilqr_mujoco_amd import solver as sv
+    for var in (dict(ILQR_BACKWARD="valu"), dict(ILQR_BACKWARD="wg"), dict(ILQR_BACKWARD="wave-fold"), dict(ILQR_LS="r"), dict(ILQR_ROLLOUT="r"), dict(ILQR_DYN="s"), dict(ILQR_LINT="1")):
+        with env(**var):
+            with pytest.raises(sv.ILQRError, match="cross-check kernel family"):
+                sv.BatchedILQR(2)
+            s = sv.BatchedILQR(2, lib_path=sv.LEGACY_LIB_PATH); s.close()      # the test library takes it
+    with env(ILQR_BACKWARD="wave-generic"):
+        s = sv.BatchedILQR(2); s.close()                                       # (the generic one-wave kernel is product code: forward-difference Jacobians run on it)
+    assert os.path.getsize(sv.LIB_PATH) < 0.7 * os.path.getsize(sv.LEGACY_LIB_PATH)
 
 
 def _demo_and_fake_rccl():

@@ -16,8 +16,18 @@ pkg = load_package()
 sc = pkg.scenario
 
 
-def _solver(*a, **k):
+def _needs_legacy():
+    """does the environment select a cross-check kernel family?  (compiled into lib/libilqr_hip_legacy.so only)"""
+    e = os.environ
+    return (e.get("ILQR_BACKWARD", "wave") not in ("wave", "wave-generic") or e.get("ILQR_LS", "s")[:1] != "s" or e.get("ILQR_ROLLOUT", "s")[:1] != "s"
+            or e.get("ILQR_DYN", "")[:1] == "s" or e.get("ILQR_LINT", "0") == "1")
+
+
+def _solver(*a, legacy=False, **k):
+    """legacy=True: a handle of the test library, for tests that switch to a cross-check family around calls on ONE handle"""
     from mpc_ilqr_mujoco_amd import solver as sv
+    if legacy or _needs_legacy():
+        k["lib_path"] = sv.LEGACY_LIB_PATH
     return sv.BatchedILQR(*a, **k)
 
 

@@ -16,7 +16,7 @@ CONTACT = int(os.environ.get("ILQR_CONTACT", "0"))
 prob = sc.make_problem(sv.reference_kinematics, N=N, gravity=(0.0, 0.0, -9.81)) if CONTACT else sc.make_problem(sv.reference_kinematics, N=N)
 ug = sv.gravity_compensation(sc.standing_state(), prob["gravity"])
 x0, ui = sc.synthetic_batch(B, N, 0, ug)
-s = sv.BatchedILQR(B, N=N)
+s = sv.BatchedILQR(B, N=N, lib_path=sv.LEGACY_LIB_PATH)      # (wave-fold: a cross-check family of the test library)
 s.set_problem(prob)
 if CONTACT:
     s.set_contact_mode(CONTACT)
