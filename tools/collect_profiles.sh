@@ -8,10 +8,10 @@ tag=${1:-r03}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 out=gpurun_out/profiles_$tag
 rm -rf "$out"; mkdir -p "$out"
-BENCH="python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-contact-line"
+BENCH="python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-contact-line --no-fd-line"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats" -o k -- $BENCH > "$out/bench_stats.log" 2>&1
 cp "$(find "$out/stats" -name '*kernel_stats.csv' | head -1)" "$out/${tag}_kernel_stats.csv"
-BENCH1="python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-contact-line"
+BENCH1="python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-contact-line --no-fd-line"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$out/fetch" -o f -- $BENCH1 > "$out/bench_fetch.log" 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$out/write" -o w -- $BENCH1 > "$out/bench_write.log" 2>&1
 mkdir -p "$out/${tag}_pmc"

@@ -13,7 +13,7 @@ bash tools/sq_profile.sh "$tag" > /dev/null 2>&1 || true
 cp gpurun_out/sq_$tag/sq_summary.txt "$out/${tag}_sq_issue_wait_summary.txt"
 cp gpurun_out/sq_$tag/sq_counter_collection.csv "$out/${tag}_pmc/sq_counter_collection.csv"
 echo "[collect] sq done"
-BENCH1="python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-contact-line"
+BENCH1="python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-contact-line --no-fd-line"
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU SQ_INSTS_VALU_MFMA_MOPS_F64 \
   --output-format csv -d "$out/mix" -o x -- $BENCH1 > "$out/bench_mix.log" 2>&1
 cp "$(find "$out/mix" -name '*counter_collection.csv' | head -1)" "$out/${tag}_pmc/fp64_mix_counter_collection.csv"; rm -rf "$out/mix"
@@ -41,7 +41,7 @@ echo "[collect] fp64 mix done"
 # (one group per concurrent region for this trace: with the early continuation of the convergence-exit leg the regions of consecutive
 # iterations overlap and tools/timeline.py, which cuts at k_quad_kin, cannot attribute kernels to iterations)
 export ILQR_SPLIT=0
-rocprofv3 --kernel-trace --output-format csv -d "$out/tr" -o t -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-contact-line > "$out/bench_trace.log" 2>&1
+rocprofv3 --kernel-trace --output-format csv -d "$out/tr" -o t -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-contact-line --no-fd-line > "$out/bench_trace.log" 2>&1
 unset ILQR_SPLIT
 f=$(find "$out/tr" -name "*kernel_trace.csv" | head -1)
 python3 tools/timeline.py "$f" 16 > "$out/${tag}_iteration_timeline.txt"
