@@ -151,3 +151,13 @@ def test_bench_gpus_n_without_a_launcher_never_times_one_rank_silently():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--batch", "8", "--steps", "1", "--warmup", "0"],
                        capture_output=True, text=True, env=env1, timeout=600)
     assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr and not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
+def test_operand_layout_index_maps(tmp_path):
+    """csrc/riccati_pack.h: slot <-> state bijection, fold partners exactly 32 slots apart, contracted rows in tiles 2 / 3, image indices
+    distinct and inside their knot regions (tests/cpp/pack_layout_check.cpp, host compile of the same constexpr functions the kernels use)."""
+    exe = str(tmp_path / "pack_layout_check")
+    r = subprocess.run(["g++", "-O1", "-std=c++17", os.path.join(ROOT, "tests", "cpp", "pack_layout_check.cpp"), "-o", exe], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 0 and "pack layout ok" in r.stdout, r.stdout
