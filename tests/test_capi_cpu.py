@@ -3,6 +3,7 @@ declares; the GPU-free host helpers agree with the oracle; the product fails lou
 import ctypes as C
 import os
 import re
+import subprocess
 
 import numpy as np
 import pytest
