@@ -194,12 +194,13 @@ int ilqr_hip_step(ilqr_hip_ctx* ctx, int count, const double* x /*[count][51]*/,
    contacts do inside mj_step: a foot whose constraint force leaves the cone |f_t| <= mu f_n (f_n along the world up axis) slides --
    its two tangential translation rows are dropped (rotation and normal rows stay, no tangential force on a sliding foot) and
    the set is solved again, once.  mu: ilqr_hip_set_friction (default 1, MuJoCo's default sliding friction; the reference's
-   robots/h1_description/mjcf model sets none).  Jacobians in this mode: ILQR_JAC_FD_FORWARD only (the reference's own scheme);
-   a solve / stage_linearize with ILQR_JAC_ANALYTIC returns ILQR_ERR_UNSUPPORTED.
+   robots/h1_description/mjcf model sets none).  Jacobians in this mode: the reference's forward differences, or analytic
+   (decisions held fixed; a sliding foot's normal row and normal force turn with the foot: that term is carried).
    ILQR_CONTACT_KINETIC_FRICTION_STANCE: the same decision, but the sliding foot keeps kinetic friction: a tangential force mu f_n along
    the direction in which the sticking solution pulled (the one that opposes the slip); its normal multiplier then acts along
    up + mu t while the constraint row stays the normal one -- an unsymmetric 12 x 12 system, Gaussian elimination with partial
-   pivoting for the knots where a foot slides.  Forward-difference Jacobians only, as mode 3. */
+   pivoting for the knots where a foot slides.  Jacobians as mode 3; the analytic ones also carry the tangent of the sticking
+   solve, which the friction direction t follows. */
 enum ilqr_contact_mode { ILQR_CONTACT_NONE = 0, ILQR_CONTACT_RIGID_STANCE = 1, ILQR_CONTACT_UNILATERAL_STANCE = 2, ILQR_CONTACT_FRICTION_STANCE = 3,
                          ILQR_CONTACT_KINETIC_FRICTION_STANCE = 4 };
 int ilqr_hip_set_contact_mode(ilqr_hip_ctx* ctx, int mode, double softness);

@@ -32,6 +32,25 @@ struct LinContact {
   double WU[12][20];         // dlambda per control column
   int act[2];                // active stance feet after the unilateral check
 };
+// Sliding feet (contact modes 3 / 4, h1_aba_split.h stance_correct): what the multiplier tangents need beside LinContact.
+// Two more arrays live in LinContact storage that is dead by then: dZ[2][3][16] (tangent of the up axis in the feet's link coordinates
+// per chain-group slot) over Cc.da, and rho = (C lambda - b) on the translation rows of a sliding foot over Cc.b; in mode 4 the factor of
+// the STICKING system keeps the strict upper triangle of Cc.F (transposed) and its reciprocal pivots are Fsd.
+struct LinSlide {
+  double zlb[10][3];         // world up axis in the coordinates of the leg bodies 1..10
+  double n[2];               // normal multiplier of a sliding foot
+  double t[2][3];            // mode 4: unit direction of the sticking solution's tangential force
+  double fs[2][3];           // mode 4: force part of the sticking solution
+  double fn[2], nt[2];       // mode 4: its normal component, the norm of its tangential part
+  double Z[2][12];           // mode 4: K^-1 c_f (Woodbury)
+  double Mi[4];              // mode 4: (I + U^T Z)^-1, row-major 2 x 2
+  double Fsd[12];            // mode 4: reciprocal pivots of the sticking system's factor
+  double ls[12];             // mode 4: the sticking solution (first pass of the tangent sweeps, see k_lin_tangent2c)
+  int sl[2];                 // foot slides
+};
+DEVFN double (*slide_dZ(LinContact& Cc))[3][16] { return reinterpret_cast<double (*)[3][16]>(&Cc.da[0][0]); }
+DEVFN const double (*slide_dZ(const LinContact& Cc))[3][16] { return reinterpret_cast<const double (*)[3][16]>(&Cc.da[0][0]); }
+static_assert(sizeof(double) * 2 * 3 * 16 <= sizeof(double) * H1_NB * 6, "dZ must fit in LinContact::da");
 
 // columns of Minv (lanes 0..24, as lin_minv_lane) and of G = Mhat^-1 J^T (lanes 25..36: unit wrench component c on foot g);
 // the feet's accelerations of the wrench columns are the rows of C
@@ -179,7 +198,7 @@ DEVFN bool lin_load_dump2c(LinShared& L, LinContact& Cc, const double* g, int ti
 }
 
 // one lane per foot: gravity offset and world up axis rotated down the leg, right-hand side of the constraint
-DEVFN void lin_contact_rhs(LinShared& L, LinContact& Cc, const double* grav, int g) {
+DEVFN void lin_contact_rhs(LinShared& L, LinContact& Cc, const double* grav, int g, LinSlide* Zs = nullptr) {
   const LinDump& D = L.D;
   const double mg[3] = {-grav[0], -grav[1], -grav[2]};
   double off[3]; mtv3(D.R0, mg, off);
@@ -189,6 +208,7 @@ DEVFN void lin_contact_rhs(LinShared& L, LinContact& Cc, const double* grav, int
   for (int i = first; i < first + 5; ++i) {
     double o2[3], z2[3]; mtv3(D.Rj[i], off, o2); mtv3(D.Rj[i], zl, z2);
     for (int k = 0; k < 3; ++k) { off[k] = o2[k]; zl[k] = z2[k]; Cc.offb[i][k] = o2[k]; }
+    if (Zs) for (int k = 0; k < 3; ++k) Zs->zlb[i - 1][k] = z2[k];
   }
   const int fbody = first + 4;
   for (int k = 0; k < 3; ++k) {
@@ -291,14 +311,281 @@ DEVFN void lin_contact_solve_w(LinContact& Cc, const int* stance, double soft, i
   }
   if (lane == 0) { Cc.act[0] = actL; Cc.act[1] = actR; }
 }
+// ---- contact modes 3 / 4: the same solve with the Coulomb limit (h1_aba_split.h stance_correct, oracle forward_dynamics_mj_stance) -------
+// lane i = row i of a 12 x 12 SPD matrix in twelve registers -> its Cholesky factor (the factorisation of lin_contact_solve_w as a
+// routine): on exit F[j < i] = L_ij, F[k > i] = L_ki (column i of L), rinv = 1 / L_ii
+DEVFN void chol12_rows(double (&F)[12], double& rinv, int i) {
+  rinv = 1.0;
+#pragma unroll
+  for (int j = 0; j < 12; ++j) {
+    const double d = bcast_lane(F[j], j);
+    double ri = __builtin_amdgcn_rsq(d);
+    ri = ri * __builtin_fma(-0.5 * d * ri, ri, 1.5);
+    ri = ri * __builtin_fma(-0.5 * d * ri, ri, 1.5);
+    if (i == j) rinv = ri;
+    const double lij = F[j] * ri;
+#pragma unroll
+    for (int k = 0; k < 12; ++k) if (k > j) {
+      const double lkj = bcast_lane(lij, k);
+      if (i > j) F[k] -= lij * lkj;
+    }
+    if (i > j) F[j] = lij;
+    else if (i == j) {
+#pragma unroll
+      for (int k = 0; k < 12; ++k) if (k > j) F[k] *= ri;
+    }
+  }
+}
+// x_i of (L L^T) x = rhs, rhs_i in lane i
+DEVFN double solve12_rows(const double (&F)[12], double rinv, double rhs, int i) {
+  double y = rhs;
+#pragma unroll
+  for (int k = 0; k < 12; ++k) {
+    const double yk = bcast_lane(y * rinv, k);
+    if (i == k) y = yk;
+    else if (i > k) y -= F[k] * yk;
+  }
+  double x = y;
+#pragma unroll
+  for (int k = 11; k >= 0; --k) {
+    const double xk = bcast_lane(x * rinv, k);
+    if (i == k) x = xk;
+    else if (i < k) x -= F[k] * xk;
+  }
+  return x;
+}
+DEVFN double dot3_lanes(const double* u, double v, int o) { return u[0] * bcast_lane(v, o) + u[1] * bcast_lane(v, o + 1) + u[2] * bcast_lane(v, o + 2); }
+// One wave.  Rigid solve, unilateral release, then the cone check on the feet that still push; a foot outside the cone slides:
+//   mode 3:  (Pi (C + soft I) Pi + (I - Pi)) lambda = Pi b,  Pi = blockdiag(I3, u u^T) on a sliding foot (u: up axis in link coordinates)
+//   mode 4:  (K + sum_f c_f u_f^T) y = Pi b,  c_f = mu Pi C t_f,  lambda = y on the rotation rows, (u + mu t) (u . y) on the translation rows
+// Leaves lambda, the factor of K (Cc.F), the active set, and in Zs / the aliased arrays what the multiplier tangents need.
+template <bool KIN>
+DEVFN void lin_contact_solve_fr(LinContact& Cc, LinSlide& Zs, const int* stance, double soft, double mu, int lane) {
+  const int i = lane < 12 ? lane : 11;
+  int actL = stance[0] == 1, actR = stance[1] == 1;
+  double F[12], rinv = 1.0, x = 0.0;
+  auto masked_row = [&](double (&R)[12]) {
+    const bool ai = (i < 6) ? actL : actR;
+#pragma unroll
+    for (int j = 0; j < 12; ++j) {
+      const bool aj = (j < 6) ? actL : actR;
+      const double c = Cc.C[i > j ? i : j][i > j ? j : i];
+      R[j] = (ai && aj) ? c + (i == j ? soft : 0.0) : (i == j ? 1.0 : 0.0);
+    }
+  };
+#pragma unroll 1
+  for (int pass = 0; pass < 2; ++pass) {
+    masked_row(F);
+    chol12_rows(F, rinv, i);
+    x = solve12_rows(F, rinv, ((i < 6) ? actL : actR) ? Cc.b[i] : 0.0, i);
+    if (pass == 1) break;
+    const double fzL = dot3_lanes(Cc.zl[0], x, 3), fzR = dot3_lanes(Cc.zl[1], x, 9);
+    int again = 0;
+    if (actL && fzL < 0.0) { actL = 0; again = 1; }
+    if (actR && fzR < 0.0) { actR = 0; again = 1; }
+    if (!again) break;
+  }
+  const double uL[3] = {Cc.zl[0][0], Cc.zl[0][1], Cc.zl[0][2]}, uR[3] = {Cc.zl[1][0], Cc.zl[1][1], Cc.zl[1][2]};
+  double fL[3], fR[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { fL[k] = bcast_lane(x, 3 + k); fR[k] = bcast_lane(x, 9 + k); }
+  const double fnL = uL[0] * fL[0] + uL[1] * fL[1] + uL[2] * fL[2], fnR = uR[0] * fR[0] + uR[1] * fR[1] + uR[2] * fR[2];
+  const double ft2L = fL[0] * fL[0] + fL[1] * fL[1] + fL[2] * fL[2] - fnL * fnL, ft2R = fR[0] * fR[0] + fR[1] * fR[1] + fR[2] * fR[2] - fnR * fnR;
+  const bool slL = actL && ft2L > mu * mu * fnL * fnL, slR = actR && ft2R > mu * mu * fnR * fnR;
+  double nL = 0.0, nR = 0.0;
+  if (slL || slR) {
+    const bool ai = (i < 6) ? actL : actR;
+    const bool inL = slL && i >= 3 && i < 6, inR = slR && i >= 9;
+    const int a = inL ? i - 3 : (inR ? i - 9 : 0);
+    double tL[3] = {0.0, 0.0, 0.0}, tR[3] = {0.0, 0.0, 0.0};
+    if (KIN) {
+      const double ntL = sqrt(ft2L > 0.0 ? ft2L : 1.0), ntR = sqrt(ft2R > 0.0 ? ft2R : 1.0);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { tL[k] = slL ? (fL[k] - fnL * uL[k]) / ntL : 0.0; tR[k] = slR ? (fR[k] - fnR * uR[k]) / ntR : 0.0; }
+      if (lane < 12) {
+        // the sticking system's factor: transposed into the strict upper triangle of Cc.F
+#pragma unroll
+        for (int j = 0; j < 12; ++j) if (j < i) Cc.F[j][i] = F[j];
+        Zs.Fsd[i] = rinv; Zs.ls[i] = x;
+      }
+      if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { Zs.t[0][k] = tL[k]; Zs.t[1][k] = tR[k]; Zs.fs[0][k] = fL[k]; Zs.fs[1][k] = fR[k]; }
+        Zs.fn[0] = fnL; Zs.fn[1] = fnR; Zs.nt[0] = ntL; Zs.nt[1] = ntR;
+      }
+    }
+    double R[12]; masked_row(R);
+    double bi = ai ? Cc.b[i] : 0.0, cL = 0.0, cR = 0.0;
+    if (KIN) {
+      double sl_ = 0.0, sr_ = 0.0;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { sl_ += Cc.C[i > 3 + k ? i : 3 + k][i > 3 + k ? 3 + k : i] * tL[k]; sr_ += Cc.C[i > 9 + k ? i : 9 + k][i > 9 + k ? 9 + k : i] * tR[k]; }
+      cL = (ai && slL) ? mu * sl_ : 0.0; cR = (ai && slR) ? mu * sr_ : 0.0;
+    }
+    // Pi from the right (columns of the sliding translation blocks)
+    if (slL) { const double w = R[3] * uL[0] + R[4] * uL[1] + R[5] * uL[2]; R[3] = w * uL[0]; R[4] = w * uL[1]; R[5] = w * uL[2]; }
+    if (slR) { const double w = R[9] * uR[0] + R[10] * uR[1] + R[11] * uR[2]; R[9] = w * uR[0]; R[10] = w * uR[1]; R[11] = w * uR[2]; }
+    // Pi from the left (rows), the identity on the removed directions, Pi on the right-hand sides
+    if (slL) {
+#pragma unroll
+      for (int j = 0; j < 12; ++j) {
+        const double v = dot3_lanes(uL, R[j], 3);
+        if (inL) R[j] = uL[a] * v + (j == i ? 1.0 : 0.0) - ((j >= 3 && j < 6) ? uL[a] * uL[j - 3 < 0 ? 0 : (j - 3 > 2 ? 2 : j - 3)] : 0.0);
+      }
+      const double vb = dot3_lanes(uL, bi, 3), vl = dot3_lanes(uL, cL, 3), vr = dot3_lanes(uL, cR, 3);
+      if (inL) { bi = uL[a] * vb; cL = uL[a] * vl; cR = uL[a] * vr; }
+    }
+    if (slR) {
+#pragma unroll
+      for (int j = 0; j < 12; ++j) {
+        const double v = dot3_lanes(uR, R[j], 9);
+        if (inR) R[j] = uR[a] * v + (j == i ? 1.0 : 0.0) - ((j >= 9) ? uR[a] * uR[j - 9 < 0 ? 0 : j - 9] : 0.0);
+      }
+      const double vb = dot3_lanes(uR, bi, 9), vl = dot3_lanes(uR, cL, 9), vr = dot3_lanes(uR, cR, 9);
+      if (inR) { bi = uR[a] * vb; cL = uR[a] * vl; cR = uR[a] * vr; }
+    }
+    chol12_rows(R, rinv, i);
+    x = solve12_rows(R, rinv, bi, i);
+    if (!KIN) {
+      nL = dot3_lanes(uL, x, 3); nR = dot3_lanes(uR, x, 9);
+      if (inL) x = uL[a] * nL;        // (the removed directions carry zero up to rounding: exact, as the step does)
+      if (inR) x = uR[a] * nR;
+    } else {
+      const double zL = solve12_rows(R, rinv, cL, i), zR = solve12_rows(R, rinv, cR, i);
+      const double aLL = 1.0 + dot3_lanes(uL, zL, 3), aLR = dot3_lanes(uL, zR, 3), aRL = dot3_lanes(uR, zL, 9), aRR = 1.0 + dot3_lanes(uR, zR, 9);
+      const double rL = dot3_lanes(uL, x, 3), rR = dot3_lanes(uR, x, 9);
+      const double det = aLL * aRR - aLR * aRL;
+      const double alL = (rL * aRR - aLR * rR) / det, alR = (aLL * rR - aRL * rL) / det;
+      x = x - zL * alL - zR * alR;
+      nL = dot3_lanes(uL, x, 3); nR = dot3_lanes(uR, x, 9);
+      if (inL) x = (uL[a] + mu * tL[a]) * nL;
+      if (inR) x = (uR[a] + mu * tR[a]) * nR;
+      if (lane < 12) { Zs.Z[0][i] = zL; Zs.Z[1][i] = zR; }
+      if (lane == 0) { Zs.Mi[0] = aRR / det; Zs.Mi[1] = -aLR / det; Zs.Mi[2] = -aRL / det; Zs.Mi[3] = aLL / det; }
+    }
+#pragma unroll
+    for (int j = 0; j < 12; ++j) F[j] = R[j];
+    // rho = C lambda - b on the translation rows of the sliding feet (over b, which nobody reads any more)
+    double rho = -(ai ? Cc.b[i] : 0.0);
+#pragma unroll
+    for (int j = 0; j < 12; ++j) {
+      const bool aj = (j < 6) ? actL : actR;
+      const double xj = bcast_lane(x, j);
+      rho += (ai && aj) ? Cc.C[i > j ? i : j][i > j ? j : i] * xj : 0.0;
+    }
+    if (lane < 12 && (inL || inR)) Cc.b[i] = rho;
+  }
+  if (lane < 12) {
+    Cc.lam[i] = x;
+#pragma unroll
+    for (int j = 0; j < 12; ++j) if (j < i) Cc.F[i][j] = F[j];
+    Cc.F[i][i] = rinv;
+  }
+  if (lane == 0) { Cc.act[0] = actL; Cc.act[1] = actR; Zs.sl[0] = slL; Zs.sl[1] = slR; Zs.n[0] = nL; Zs.n[1] = nR; }
+}
+// x <- (sticking system)^-1 x: its factor is the strict upper triangle of Cc.F (transposed), reciprocal pivots Zs.Fsd
+DEVFN void lin_contact_backsolve_s(const LinContact& Cc, const LinSlide& Zs, double* x) {
+#pragma unroll
+  for (int i = 0; i < 12; ++i) { double t = x[i];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) if (k < i) t -= Cc.F[k][i] * x[k];
+    x[i] = t * Zs.Fsd[i];
+    __builtin_amdgcn_sched_barrier(0); }
+#pragma unroll
+  for (int i = 11; i >= 0; --i) { double t = x[i];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) if (k > i) t -= Cc.F[i][k] * x[k];
+    x[i] = t * Zs.Fsd[i];
+    __builtin_amdgcn_sched_barrier(0); }
+}
+// One multiplier tangent with sliding feet.  On entry w = G^T dT - dR on the active rows (zero elsewhere), dz[g] = tangent of foot g's up
+// axis in link coordinates for this direction (zero for a control column); on exit w = dlambda.  With lambda_lin = d n on a sliding foot
+// (d = u in mode 3, u + mu t in mode 4) and the constraint rows Pi r = 0, r = C lambda - b (+ soft terms along u):
+//   dlambda = Gm dy + e,  e = [0; n dd],   (K + sum_f c_f u_f^T) dy = Pi (w - C e) - [0; u (du . rho)]
+// and in mode 4  dt = (I - t t^T) (P_perp df - f_n du - u (du . f)) / |f_t|  from the tangent df of the STICKING solve.
+// (df_in: the force parts of the sticking solve's tangent for this direction, [foot][3] at stride df_stride, from the first pass; null
+// for a control column, whose right-hand side does not depend on the multipliers: solved here)
+template <bool KIN>
+DEVFN void lin_slide_tangent(const LinContact& Cc, const LinSlide& Zs, double mu, double* w, const double (*dz)[3], const double* df_in = nullptr, int df_stride = 0) {
+  double e[2][3] = {{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}};
+  if (KIN) {
+    double ws[12];
+    if (df_in) {
+#pragma unroll
+      for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) ws[6 * g + 3 + k] = df_in[(3 * g + k) * df_stride];
+    } else {
+#pragma unroll
+      for (int j = 0; j < 12; ++j) ws[j] = w[j];
+      lin_contact_backsolve_s(Cc, Zs, ws);
+    }
+#pragma unroll
+    for (int g = 0; g < 2; ++g) if (Zs.sl[g]) {
+      const double* df = ws + 6 * g + 3; const double* z = Cc.zl[g]; const double* t = Zs.t[g]; const double* f = Zs.fs[g];
+      const double zdf = z[0] * df[0] + z[1] * df[1] + z[2] * df[2], dzf = dz[g][0] * f[0] + dz[g][1] * f[1] + dz[g][2] * f[2];
+      double dtau[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) dtau[k] = df[k] - z[k] * zdf - Zs.fn[g] * dz[g][k] - z[k] * dzf;
+      const double tdt = t[0] * dtau[0] + t[1] * dtau[1] + t[2] * dtau[2];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) e[g][k] = Zs.n[g] * (dz[g][k] + mu * (dtau[k] - t[k] * tdt) / Zs.nt[g]);
+    }
+  } else {
+#pragma unroll
+    for (int g = 0; g < 2; ++g) if (Zs.sl[g]) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) e[g][k] = Zs.n[g] * dz[g][k];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 12; ++i) if (Cc.act[i / 6]) {
+    double t = w[i];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) if (Zs.sl[g]) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { const int j = 6 * g + 3 + k; t -= Cc.C[i > j ? i : j][i > j ? j : i] * e[g][k]; }
+    }
+    w[i] = t;
+  }
+#pragma unroll
+  for (int g = 0; g < 2; ++g) if (Zs.sl[g]) {
+    const double* z = Cc.zl[g]; double* wl = w + 6 * g + 3; const double* rho = Cc.b + 6 * g + 3;
+    const double s = z[0] * wl[0] + z[1] * wl[1] + z[2] * wl[2] - (dz[g][0] * rho[0] + dz[g][1] * rho[1] + dz[g][2] * rho[2]);
+    wl[0] = z[0] * s; wl[1] = z[1] * s; wl[2] = z[2] * s;
+  }
+  lin_contact_backsolve(Cc, w);
+  if (KIN) {
+    const double aL = Cc.zl[0][0] * w[3] + Cc.zl[0][1] * w[4] + Cc.zl[0][2] * w[5], aR = Cc.zl[1][0] * w[9] + Cc.zl[1][1] * w[10] + Cc.zl[1][2] * w[11];
+    const double alL = Zs.Mi[0] * aL + Zs.Mi[1] * aR, alR = Zs.Mi[2] * aL + Zs.Mi[3] * aR;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) w[i] -= Zs.Z[0][i] * alL + Zs.Z[1][i] * alR;
+  }
+#pragma unroll
+  for (int g = 0; g < 2; ++g) if (Zs.sl[g]) {
+    const double* z = Cc.zl[g]; double* wl = w + 6 * g + 3;
+    if (KIN) {
+      const double nn = z[0] * wl[0] + z[1] * wl[1] + z[2] * wl[2];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) wl[k] = (z[k] + mu * Zs.t[g][k]) * nn + e[g][k];
+    } else {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) wl[k] += e[g][k];
+    }
+  }
+}
 // wave 0: constrained accelerations.  dq = G lambda, qacc += dq, aL += R0^T dq_lin, body accelerations a += da (level by
 // level), then X a_parent and the body forces with the contact wrenches as external forces.  Wave-local ordering only.
-DEVFN void lin_contact_correct(LinShared& L, LinContact& Cc, int lane) {
+// (mode 4 runs the tangent sweeps twice on a knot with a sliding foot, first about the sticking solution: ldq - lsub = the multipliers
+// whose accelerations are added, lf = the contact wrench the body forces carry; defaults: Cc.lam)
+template <bool X = false>
+DEVFN void lin_contact_correct(LinShared& L, LinContact& Cc, int lane, const double* ldq = nullptr, const double* lsub = nullptr, const double* lf_ = nullptr) {
   LinDump& D = L.D;
+  const double* lf = X ? lf_ : Cc.lam;
   if (lane < H1_NV) {
     double s = 0.0;
 #pragma unroll
-    for (int j = 0; j < 12; ++j) s += Cc.G[lane][j] * Cc.lam[j];
+    for (int j = 0; j < 12; ++j) s += Cc.G[lane][j] * (X ? ldq[j] - (lsub ? lsub[j] : 0.0) : Cc.lam[j]);
     Cc.dq[lane] = s;
     D.qacc[lane] += s;
   }
@@ -329,7 +616,7 @@ DEVFN void lin_contact_correct(LinShared& L, LinContact& Cc, int lane) {
     for (int k = 0; k < 6; ++k) Iv[k] = L.Iv[i][k];
     inertia_mul(i, Cc.a[i], Ia); crf(D.v[i], Iv, vIv);
     const int g = (i == 5) ? 0 : ((i == 10) ? 1 : -1);
-    for (int k = 0; k < 6; ++k) D.F[i][k] = Ia[k] + vIv[k] - (g >= 0 ? Cc.lam[6 * (g < 0 ? 0 : g) + k] : 0.0);
+    for (int k = 0; k < 6; ++k) D.F[i][k] = Ia[k] + vIv[k] - (g >= 0 ? lf[6 * (g < 0 ? 0 : g) + k] : 0.0);
   }
 }
 
@@ -345,6 +632,17 @@ template <int K> DEVFN void tan_leg_gravity(const LinShared& L, const LinContact
   ng[0] += mt * t[0]; ng[1] += mt * t[1]; ng[2] += mt * t[2];
   if constexpr (K + 1 < 5) tan_leg_gravity<K + 1>(L, Cc, side, kind, idx, ng, dg_f);
   else { dg_f[0] = ng[0]; dg_f[1] = ng[1]; dg_f[2] = ng[2]; }
+}
+// the same recursion for the world up axis (sliding feet: the normal row and the normal force turn with the foot)
+template <int K> DEVFN void tan_leg_up(const LinShared& L, const LinSlide& Zs, bool side, int kind, int idx, const double* pz, double* dz_f) {
+  constexpr int IL = 1 + K, IR = 6 + K, ax = h1c::C_AXIS[IL];
+  const int i = side ? IR : IL;
+  double nz[3]; mtv3(L.D.Rj[i], pz, nz);
+  const double mt = (kind == DIR_THETA && idx == i) ? 1.0 : 0.0;
+  double t[3]; h1r::cross_axis<ax>(Zs.zlb[i - 1], t);
+  nz[0] += mt * t[0]; nz[1] += mt * t[1]; nz[2] += mt * t[2];
+  if constexpr (K + 1 < 5) tan_leg_up<K + 1>(L, Zs, side, kind, idx, nz, dz_f);
+  else { dz_f[0] = nz[0]; dz_f[1] = nz[1]; dz_f[2] = nz[2]; }
 }
 DEVFN void lin_tangent_legs_c(LinShared& L, LinContact& Cc, int lane) {
   const int grp = lane / 19, q = lane - 19 * grp;
@@ -380,8 +678,10 @@ DEVFN void lin_tangent_legs_c(LinShared& L, LinContact& Cc, int lane) {
 // constraint-row tangents and back-substitutes; wave 1: lane = control column (19)
 // (TWO: the 16-slot chain groups of the two-knot kernel, base-linear-velocity directions in the extra slots 16..18)
 DEVFN int slot_in_group2c(int c, int kind, int idx) { return kind == DIR_VLIN ? 16 + idx : slot_in_group2(c, kind, idx); }
-template <bool TWO = false>
-DEVFN void lin_contact_multipliers(const LinShared& L, LinContact& Cc, int wv, int lane) {
+// (FRIC = 2: `stash` = 6 x 48 doubles of global scratch per knot; sticking_pass: the sweeps ran about the sticking solution -- solve with
+// its factor and leave the force parts of dlambda_s there, nothing else)
+template <bool TWO = false, int FRIC = 0>
+DEVFN void lin_contact_multipliers(const LinShared& L, LinContact& Cc, int wv, int lane, const LinSlide* Zs = nullptr, double mu = 1.0, double* stash = nullptr, bool sticking_pass = false) {
   typedef double v4d_c __attribute__((ext_vector_type(4)));
   if (wv == 0) {
     const int lr = lane & 15, lk = lane >> 4;
@@ -417,6 +717,25 @@ DEVFN void lin_contact_multipliers(const LinShared& L, LinContact& Cc, int wv, i
           w[6 * g + k] = Cc.act[g] ? Cc.W[6 * g + k][lane] - dr : 0.0;
         }
       }
+      if (FRIC == 2 && sticking_pass) {
+        lin_contact_backsolve_s(Cc, *Zs, w);
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+          for (int k = 0; k < 3; ++k) stash[(3 * g + k) * LIN_LD + lane] = w[6 * g + 3 + k];
+      } else
+      if (FRIC != 0 && (Zs->sl[0] || Zs->sl[1])) {
+        double dz[2][3];
+        const double (*dZ)[3][16] = slide_dZ(Cc);
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+          const int sl = slot_in_group2c(g, kind, idx);
+          const bool on = Zs->sl[g] && sl >= 0 && sl < 16;
+#pragma unroll
+          for (int k = 0; k < 3; ++k) dz[g][k] = on ? dZ[g][k][on ? sl : 0] : 0.0;
+        }
+        lin_slide_tangent<FRIC == 2>(Cc, *Zs, mu, w, dz, FRIC == 2 ? stash + lane : nullptr, LIN_LD);
+      } else
       lin_contact_backsolve(Cc, w);
 #pragma unroll
       for (int j = 0; j < 12; ++j) Cc.W[j][lane] = w[j];
@@ -429,6 +748,10 @@ DEVFN void lin_contact_multipliers(const LinShared& L, LinContact& Cc, int wv, i
     double w[12];
 #pragma unroll
     for (int j = 0; j < 12; ++j) w[j] = Cc.act[j / 6] ? -Cc.G[6 + lane][j] : 0.0;
+    if (FRIC != 0 && (Zs->sl[0] || Zs->sl[1])) {
+      const double dz[2][3] = {{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}};
+      lin_slide_tangent<FRIC == 2>(Cc, *Zs, mu, w, dz);
+    } else
     lin_contact_backsolve(Cc, w);
 #pragma unroll
     for (int j = 0; j < 12; ++j) Cc.WU[j][lane] = w[j];
@@ -440,7 +763,7 @@ DEVFN void lin_contact_multipliers(const LinShared& L, LinContact& Cc, int wv, i
 // constraint row does -- through the foot's velocity v_f / h and the velocity-product part of its acceleration: pure kinematics.
 // The three v_lin directions therefore run a kinematics-only forward chain (lin2_leg_vlin_dR: dv, da down the leg, no inertia,
 // no forces, no backward pass) on 2 knots x 2 feet x 3 = 12 lanes of an otherwise idle wave, into the slots 16..18 of dR.
-DEVFN void lin2_tangent_legs_c(LinShared* L2, LinContact* C2, int lane) {
+DEVFN void lin2_tangent_legs_c(LinShared* L2, LinContact* C2, int lane, const LinSlide* Z2 = nullptr) {
   LinShared& L = L2[lane >> 5]; LinContact& Cc = C2[lane >> 5];
   const int grp = (lane >> 4) & 1, q = lane & 15;
   const bool side = grp == 1;
@@ -453,6 +776,15 @@ DEVFN void lin2_tangent_legs_c(LinShared* L2, LinContact* C2, int lane) {
     tan_leg_gravity<0>(L, Cc, side, kind, idx, dg0, dgf);
 #pragma unroll
     for (int k = 0; k < 3; ++k) Cc.dR[grp][3 + k][q] = -dgf[k];
+  }
+  if (Z2) {
+    const double zb[3] = {L.D.R0[6], L.D.R0[7], L.D.R0[8]};
+    double dz0[3] = {0.0, 0.0, 0.0}, dzf[3];
+    if (kind == DIR_PHI) cross_axis(zb, idx, dz0);
+    tan_leg_up<0>(L, Z2[lane >> 5], side, kind, idx, dz0, dzf);
+    double (*dZ)[3][16] = slide_dZ(Cc);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) dZ[grp][k][q] = dzf[k];
   }
   __builtin_amdgcn_sched_barrier(0);
   double df[5][6], dvf[6], daf[6];

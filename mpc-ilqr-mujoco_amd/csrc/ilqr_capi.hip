@@ -748,11 +748,13 @@ int ilqr_hip_reload_environment(ilqr_hip_ctx* c) {
   return ILQR_OK;
 }
 int ilqr_hip_num_slices(const ilqr_hip_ctx* c) { return c ? slices_wanted(c, c->B) : -1; }
-// The analytic Jacobians differentiate the constrained step with the active set held fixed (modes 1, 2); a sliding foot's
-// constraint rows turn with the foot, which they do not carry: mode 3 linearises by the reference's forward differences.
+// The analytic Jacobians differentiate the constrained step with the active set and the sliding decisions held fixed.  The sliding
+// branch (contact modes 3 / 4: the normal row and the normal force turn with the foot, kinetic friction follows the sticking
+// solution) is carried by the two-knot tangent kernel only (k_lin_tangent2c<., 1 / 2>): the one-knot and scalar cross-check families
+// refuse it.
 static int jacobians_available(ilqr_hip_ctx* c) {
-  if (c->P.dyn.contact >= ILQR_CONTACT_FRICTION_STANCE && c->jac_mode == ILQR_JAC_ANALYTIC) {
-    c->err = "contact modes 3 / 4 (Coulomb limit): analytic Jacobians are not available, select ILQR_JAC_FD_FORWARD with ilqr_hip_set_options";
+  if (c->P.dyn.contact >= ILQR_CONTACT_FRICTION_STANCE && c->jac_mode == ILQR_JAC_ANALYTIC && (ilqr::variant_lin_one_knot() || ilqr::variant_scalar_dyn())) {
+    c->err = "contact modes 3 / 4 (Coulomb limit): analytic Jacobians are not available in this kernel family (ILQR_LIN / ILQR_DYN), select ILQR_JAC_FD_FORWARD with ilqr_hip_set_options";
     return ILQR_ERR_UNSUPPORTED;
   }
   return ILQR_OK;

@@ -119,6 +119,7 @@ int variant_ls_split();
 int variant_rollout_split();
 int variant_backward();
 int variant_scalar_dyn();
+int variant_lin_one_knot();
 size_t backward_lds_bytes();
 size_t lin_dump_doubles();
 size_t quad_rec_doubles(size_t knots);

@@ -315,7 +315,12 @@ __global__ void __launch_bounds__(128, 2) k_lin_tangent_c(DevState S, ProblemDev
 // four-wave workgroup"): the leg and arm sweeps of both knots on one wave each (64 lanes), the Minv columns of both knots on wave
 // 2 and the twelve unit-wrench columns of both on wave 3, one constraint solve per wave, the three base-linear-velocity
 // directions as kinematics-only lanes.
-template <bool PACK>
+// FRIC: 0 contact modes 1 / 2; 1 mode 3 (Coulomb limit: a foot outside the cone slides), 2 mode 4 (kinetic friction on the sliding
+// foot) -- instantiations of their own (LinSlide, the cone check and the sliding branch of the multiplier tangents), modes 1 / 2 keep
+// their machine code.
+template <int FRIC> struct LinSlideOpt { LinSlide z[2]; DEVFN LinSlide* get() { return z; } };
+template <> struct LinSlideOpt<0> { DEVFN LinSlide* get() { return nullptr; } };
+template <bool PACK, int FRIC = 0>
 __global__ void __launch_bounds__(256, 2) k_lin_tangent2c(DevState S, ProblemDev P, int mode, const int* list, const int* count) {
   const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
   const int ks = tid >> 7, tid7 = tid & 127;
@@ -325,6 +330,8 @@ __global__ void __launch_bounds__(256, 2) k_lin_tangent2c(DevState S, ProblemDev
   if (it0 >= total) return;
   __shared__ LinShared L2[2];
   __shared__ LinContact C2[2];
+  __shared__ LinSlideOpt<FRIC> ZO;
+  LinSlide* Z2 = ZO.get();
 #ifdef LIN_STAMP
   long long qlast = clock64();
   const int t = (int)(it0 % N), b = (int)(it0 / N);
@@ -353,28 +360,67 @@ __global__ void __launch_bounds__(256, 2) k_lin_tangent2c(DevState S, ProblemDev
   LSTAMP(0)
   if (wv == 2) { const int c = lane & 31; if (c < H1_NV) lin_minv_lane_c(L2[lane >> 5], C2[lane >> 5], c); }          // Minv columns of both knots
   else if (wv == 3) { const int c = lane & 31; if (c < 12) lin_minv_lane_c(L2[lane >> 5], C2[lane >> 5], H1_NV + c); }   // unit-wrench columns (G, C) of both
-  else if (wv == 0 && (lane & 31) < 2) lin_contact_rhs(L2[lane >> 5], C2[lane >> 5], P.dyn.g, lane & 31);
+  else if (wv == 0 && (lane & 31) < 2) lin_contact_rhs(L2[lane >> 5], C2[lane >> 5], P.dyn.g, lane & 31, FRIC ? Z2 + (lane >> 5) : nullptr);
   __syncthreads();
   LSTAMP(1)
-  if (wv < 2) lin_contact_solve_w(C2[wv], stance[wv], P.dyn.soft, P.dyn.contact, lane);      // one constraint solve per wave
+  if (wv < 2) {                                                                              // one constraint solve per wave
+    if constexpr (FRIC != 0) lin_contact_solve_fr<FRIC == 2>(C2[wv], Z2[wv], stance[wv], P.dyn.soft, P.dyn.mu, lane);
+    else lin_contact_solve_w(C2[wv], stance[wv], P.dyn.soft, P.dyn.contact, lane);
+  }
   __syncthreads();
   LSTAMP(2)
-  if (wv < 2) lin_contact_correct(L2[wv], C2[wv], lane);
-  __syncthreads();
-  if (wv == 0) lin2_accumulate_forces_w(L2, lane);
-  else if (wv == 3 && (lane & 31) == 0) lin_prologue(L2[lane >> 5]);
-  __syncthreads();
-  LSTAMP(3)
-  if (wv == 0) lin2_tangent_legs_c(L2, C2, lane);
-  else if (wv == 1) lin2_tangent_arms(L2, lane);
-  else if (wv == 2) lin2_leg_vlin_dR(L2, C2, lane);
-  __syncthreads();
-  if (wv < 2) lin2_tangent_pelvis(L2[wv], lane);
-  __syncthreads();
-  LSTAMP(4)
-  if (wv < 2) lin_contact_multipliers<true>(L2[wv], C2[wv], 0, lane);                          // W = G^T dT, then dlambda per direction
-  else if (wv == 2) { const int c = lane & 31; lin_contact_multipliers<true>(L2[lane >> 5], C2[lane >> 5], 1, c < H1_NU ? c : 63); }   // dlambda per control column
-  __syncthreads();
+  // Mode 4 (FRIC = 2): the friction direction of a sliding foot follows the STICKING solution, whose tangent needs the sweeps about that
+  // solution (inverse-dynamics and constraint-row tangents are affine in the multipliers and the accelerations they cause): on a
+  // workgroup with a sliding foot the sweeps run twice -- first about the sticking solution, leaving the force parts of dlambda_s in
+  // the knot's dump record (consumed by now), then about the final one.
+  if constexpr (FRIC == 2) {
+  const bool two_pass = Z2[0].sl[0] || Z2[0].sl[1] || Z2[1].sl[0] || Z2[1].sl[1];
+  for (int pass = two_pass ? 0 : 1; pass < 2; ++pass) {
+    const bool sticking = pass == 0;
+    if (wv < 2) {
+      {
+        const bool slides = Z2[wv].sl[0] || Z2[wv].sl[1];
+        // (a knot without a sliding foot beside one with: corrected in the first pass, nothing to add in the second)
+        if (sticking) lin_contact_correct<true>(L2[wv], C2[wv], lane, slides ? Z2[wv].ls : C2[wv].lam, nullptr, slides ? Z2[wv].ls : C2[wv].lam);
+        else if (two_pass) lin_contact_correct<true>(L2[wv], C2[wv], lane, C2[wv].lam, slides ? Z2[wv].ls : C2[wv].lam, C2[wv].lam);
+        else lin_contact_correct(L2[wv], C2[wv], lane);
+      }
+    }
+    __syncthreads();
+    if (wv == 0) lin2_accumulate_forces_w(L2, lane);
+    else if (wv == 3 && (lane & 31) == 0 && !sticking) lin_prologue(L2[lane >> 5]);
+    __syncthreads();
+    LSTAMP(3)
+    if (wv == 0) lin2_tangent_legs_c(L2, C2, lane, Z2);
+    else if (wv == 1) lin2_tangent_arms(L2, lane);
+    else if (wv == 2) lin2_leg_vlin_dR(L2, C2, lane);
+    __syncthreads();
+    if (wv < 2) lin2_tangent_pelvis(L2[wv], lane);
+    __syncthreads();
+    LSTAMP(4)
+    double* stash = S.lin_dump + knot[wv < 2 ? wv : (lane >> 5)] * LinDumpG_SIZE;
+    if (wv < 2) lin_contact_multipliers<true, FRIC>(L2[wv], C2[wv], 0, lane, FRIC ? Z2 + wv : nullptr, P.dyn.mu, stash, sticking);      // W = G^T dT, then dlambda per direction
+    else if (wv == 2 && !sticking) { const int c = lane & 31; lin_contact_multipliers<true, FRIC>(L2[lane >> 5], C2[lane >> 5], 1, c < H1_NU ? c : 63, FRIC ? Z2 + (lane >> 5) : nullptr, P.dyn.mu); }   // dlambda per control column
+    __syncthreads();
+  }
+  } else {
+    if (wv < 2) lin_contact_correct(L2[wv], C2[wv], lane);
+    __syncthreads();
+    if (wv == 0) lin2_accumulate_forces_w(L2, lane);
+    else if (wv == 3 && (lane & 31) == 0) lin_prologue(L2[lane >> 5]);
+    __syncthreads();
+    LSTAMP(3)
+    if (wv == 0) lin2_tangent_legs_c(L2, C2, lane, Z2);
+    else if (wv == 1) lin2_tangent_arms(L2, lane);
+    else if (wv == 2) lin2_leg_vlin_dR(L2, C2, lane);
+    __syncthreads();
+    if (wv < 2) lin2_tangent_pelvis(L2[wv], lane);
+    __syncthreads();
+    LSTAMP(4)
+    if (wv < 2) lin_contact_multipliers<true, FRIC>(L2[wv], C2[wv], 0, lane, FRIC ? Z2 + wv : nullptr, P.dyn.mu);      // W = G^T dT, then dlambda per direction
+    else if (wv == 2) { const int c = lane & 31; lin_contact_multipliers<true, FRIC>(L2[lane >> 5], C2[lane >> 5], 1, c < H1_NU ? c : 63, FRIC ? Z2 + (lane >> 5) : nullptr, P.dyn.mu); }   // dlambda per control column
+    __syncthreads();
+  }
   LSTAMP(5)
   lin_apply_minv_2c(L2[ks], C2[ks], tid7);
   __syncthreads();
@@ -1055,6 +1101,7 @@ int variant_ls_split() { return g_var.ls_split; }
 int variant_rollout_split() { return g_var.rollout_split; }
 int variant_backward() { return backward_kind(); }
 int variant_scalar_dyn() { return g_var.scalar_dyn; }
+int variant_lin_one_knot() { return g_var.lin_one_knot; }
 int variant_pack() { return (backward_kind() == 2 && g_var.fold == 2) ? 1 : 0; }
 void launch_rollout(const DevState& S, const ProblemDev& P, int mode, int do_roll, int count_iter, double* cost_out, hipStream_t st) {
   // contact mode (f4) runs on the two-lane kernels (the one-lane register kernels are constraint-free only)
@@ -1081,8 +1128,10 @@ void launch_linearize(const DevState& S, const ProblemDev& P, int mode, int jac_
     if ((phases & 2) && P.dyn.contact) {
       const dim3 grid2((unsigned)(((long)S.B * S.N + 1) / 2));
       if (g_var.lin_one_knot) { LEGACY_LAUNCH(hipLaunchKernelGGL(k_lin_tangent_c, dim3(S.N, S.B), dim3(128), 0, st, S, P, mode, w.list, w.count)); if (pack) launch_pack_ab(S, st, mode, w.list, w.count); }
-      else if (pack) hipLaunchKernelGGL(k_lin_tangent2c<true>, grid2, dim3(256), 0, st, S, P, mode, w.list, w.count);
-      else hipLaunchKernelGGL(k_lin_tangent2c<false>, grid2, dim3(256), 0, st, S, P, mode, w.list, w.count);
+      else if (P.dyn.contact == 3) { if (pack) hipLaunchKernelGGL((k_lin_tangent2c<true, 1>), grid2, dim3(256), 0, st, S, P, mode, w.list, w.count); else hipLaunchKernelGGL((k_lin_tangent2c<false, 1>), grid2, dim3(256), 0, st, S, P, mode, w.list, w.count); }
+      else if (P.dyn.contact == 4) { if (pack) hipLaunchKernelGGL((k_lin_tangent2c<true, 2>), grid2, dim3(256), 0, st, S, P, mode, w.list, w.count); else hipLaunchKernelGGL((k_lin_tangent2c<false, 2>), grid2, dim3(256), 0, st, S, P, mode, w.list, w.count); }
+      else if (pack) hipLaunchKernelGGL((k_lin_tangent2c<true, 0>), grid2, dim3(256), 0, st, S, P, mode, w.list, w.count);
+      else hipLaunchKernelGGL((k_lin_tangent2c<false, 0>), grid2, dim3(256), 0, st, S, P, mode, w.list, w.count);
     }
     else if (phases & 2) launch_lin_tangent_free(S, P, mode, st, w, pack);
   } else if (jac_mode == 0 && !P.dyn.contact) {               // ILQR_DYN=s: the analytic kernels are constraint-free only

@@ -403,8 +403,7 @@ def test_unilateral_contact_mode_releases_pulled_feet_and_matches_oracle():
 def test_friction_limited_contact_mode_slides_feet_outside_the_cone_and_matches_oracle_and_golden():
     """Contact mode 3 (ILQR_CONTACT_FRICTION_STANCE): unilateral stance + Coulomb limit.  (i) the step on the two-lane kernels
     against the committed vectors of the independent NumPy KKT formulation (tests/golden/friction_golden.npz: no foot, one foot,
-    both feet sliding) and against the oracle, 1e-9; (ii) with the cone inactive the step IS mode 2, bit for bit; (iii) analytic
-    Jacobians are refused loudly in this mode; (iv) a full solve with the reference's forward-difference Jacobians on a walking
+    both feet sliding) and against the oracle, 1e-9; (ii) with the cone inactive the step IS mode 2, bit for bit; (iv) a full solve with the reference's forward-difference Jacobians on a walking
     schedule (mu = 0.7) reproduces the oracle's trace, and the nominal re-rollout reproduces the accepted
     candidates bit for bit."""
     g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "friction_golden.npz"))
@@ -441,12 +440,7 @@ def test_friction_limited_contact_mode_slides_feet_outside_the_cone_and_matches_
         else:
             assert np.array_equal(got3[0], got2[0]) and np.array_equal(got4[0], got2[0])
     assert slid >= 5
-    # (iii) loud refusal of the analytic Jacobians
-    s.set_contact_mode(3); s.set_friction(0.3)
-    s.set_options(jacobian_mode=0, early_exit=False); s.set_max_iterations(3)
-    s.initialize(x0, ui)
-    with pytest.raises(RuntimeError, match="analytic Jacobians are not available"):
-        s.solve(x0)
+    # (iii) analytic Jacobians in these modes: test_sliding_contact_analytic_jacobians_match_oracle_ad
     # (iv) the solve, forward differences on both sides
     Bs = 4
     s.close()
@@ -505,6 +499,57 @@ def test_contact_analytic_jacobians_match_oracle_ad(mode):
         n, oc, oa, ol_ = ob.trace()
         assert n == 3 and np.allclose(tc[b], oc, rtol=1e-5) and np.array_equal(ta[b], oa), (tc[b], oc, ta[b], oa)
         assert abs(cost[b] - c) <= 1e-5 * abs(c) and rel(s.gains_K()[b], ob.get("K")) < 1e-5 and rel(s.xbar()[b], ob.get("xbar")) < 1e-5
+    s.close()
+
+
+@pytest.mark.parametrize("mode", [3, 4])
+def test_sliding_contact_analytic_jacobians_match_oracle_ad(mode):
+    """Contact modes 3 / 4 (Coulomb limit, kinetic friction): analytic Jacobians of the step with sliding feet -- the normal row and
+    the normal force turn with the foot (tangent of the up axis in link coordinates down the leg), mode 4's friction direction follows
+    the tangent of the sticking solve -- against the oracle's forward-mode AD through the same branches, on the committed friction
+    states (tests/golden/friction_golden.npz: no foot, the left, the right, both feet sliding), each with its own mu.  Then a full
+    solve on a walking schedule against the oracle with AD Jacobians."""
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "friction_golden.npz"))
+    n, N = len(g["x"]), 25
+    prob, x0, ui = make(n, seed=28, gravity=list(g["gravity"]), walking=True)
+    prob["stance"] = np.ones_like(prob["stance"])
+    X = np.repeat(g["x"][:, None, :], N + 1, axis=1); U = np.repeat(g["u"][:, None, :], N, axis=1)
+    slid = 0
+    for mu in sorted(set(float(m) for m in g["mu"])):
+        s = _solver(n); s.set_problem(prob); s.set_contact_mode(mode, float(g["soft"])); s.set_friction(mu); s.set_options(jacobian_mode=0)
+        s.initialize(x0, ui); s.set_trajectory(X, U); s.stage_linearize()
+        A, Bm = s.linearization()
+        for i in [i for i in range(n) if float(g["mu"][i]) == mu]:
+            o = oracle_for(prob, jac_mode=0); o.set_contact_mode(mode, float(g["soft"])); o.set_friction(mu)
+            o.set_trajectory(X[i], U[i]); o.linearize()
+            Ao, Bo = o.get("A")[0], o.get("B")[0]
+            assert np.abs(A[i][0] - Ao).max() < 1e-8 * max(1.0, np.abs(Ao).max()), (mode, i, np.abs(A[i][0] - Ao).max(), np.unravel_index(np.abs(A[i][0] - Ao).argmax(), Ao.shape))
+            assert np.abs(Bm[i][0] - Bo).max() < 1e-8 * max(1.0, np.abs(Bo).max()), (mode, i, np.abs(Bm[i][0] - Bo).max())
+            if g["slide"][i].any():
+                # the sliding branch is a different derivative: the mode-2 Jacobians of the same state are far away
+                o2 = oracle_for(prob, jac_mode=0); o2.set_contact_mode(2, float(g["soft"])); o2.set_trajectory(X[i], U[i]); o2.linearize()
+                assert np.abs(o2.get("A")[0] - Ao).max() > 1e-3
+                slid += 1
+        s.close()
+    assert slid >= 5
+    Bs = 3
+    prob, x0, ui = make(Bs, seed=28, gravity=list(g["gravity"]), walking=True)
+    s = _solver(Bs); s.set_problem(prob); s.set_contact_mode(mode); s.set_friction(0.7)
+    s.set_options(jacobian_mode=0, early_exit=False); s.set_max_iterations(3)
+    s.initialize(x0, ui); cost = s.solve(x0)
+    tc, ta, tl = s.trace()
+    assert s.adopt_mismatches() == 0
+    differs = 0
+    for b in range(Bs):
+        ob = oracle_for(prob, jac_mode=0, early_exit=0, max_iter=3); ob.set_contact_mode(mode); ob.set_friction(0.7)
+        ob.initialize(x0[b], ui[b]); ok, c = ob.solve(x0[b])
+        nn, oc, oa, ol_ = ob.trace()
+        assert nn == 3 and np.allclose(tc[b], oc, rtol=1e-5) and np.array_equal(ta[b], oa), (mode, tc[b], oc, ta[b], oa)
+        assert abs(cost[b] - c) <= 1e-5 * abs(c) and rel(s.gains_K()[b], ob.get("K")) < 1e-5 and rel(s.xbar()[b], ob.get("xbar")) < 1e-5
+        o2 = oracle_for(prob, jac_mode=0, early_exit=0, max_iter=3); o2.set_contact_mode(2)
+        o2.initialize(x0[b], ui[b]); _, c2 = o2.solve(x0[b])
+        differs += int(abs(c2 - c) > 1e-6 * abs(c))
+    assert differs >= 1                              # the cone was active somewhere along these solves
     s.close()
 
 
