@@ -34,6 +34,8 @@ struct DynParams {
                          // 4: as 3, and the sliding foot keeps kinetic friction mu lambda_n along the direction the sticking force had
   double mu = 1.0;       // sliding friction coefficient of mode 3 (MuJoCo's default geom friction; the H1 model file sets none)
   double soft = 1e-5;    // diagonal softness of the stance constraint (1 / kg), keeps J Minv J^T invertible with straight knees
+  int limits = 0;        // 1: joint-limit rows (SURVEY Appendix C #7, h1.xml jnt_range enforced by mj_step): a hinge past its range that the
+                         //    step would still move outward is stopped (h1_step)
 };
 
 // ---------- small dense helpers (row-major) ----------
@@ -132,7 +134,9 @@ template <class T> inline void solve6_spd(const T* A, const T* b, T* y) {
 // Output: qacc (MuJoCo convention, 25)
 template <class T>
 inline void forward_dynamics_mj(const T* quat_hat, const T* theta, const T* v, const T* tau, double arm_eff,
-                                const double* grav, T* qacc) {
+                                const double* grav, T* qacc, const int* lock = nullptr, const T* lockacc = nullptr) {
+  // lock[i - 1] != 0: hinge i is acceleration-prescribed (Featherstone's hybrid dynamics): qacc_i = lockacc[i - 1], the body passes its
+  // whole articulated inertia to the parent (no reduction by U U^T / D), its bias carries IA S qacc_i
   double Isp[H1_NB][36];
   for (int i = 0; i < H1_NB; ++i) spatial_inertia(H1_MASS[i], H1_COM[i], H1_INERTIA[i], Isp[i]);
 
@@ -162,9 +166,10 @@ inline void forward_dynamics_mj(const T* quat_hat, const T* theta, const T* v, c
     D[i] = U[i][a] + arm_eff;
     uu[i] = tau[i - 1] - pA[i][a];
     T Ia[36], pa[6];
-    for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c) Ia[6 * r + c] = IA[i][6 * r + c] - U[i][r] * U[i][c] / D[i];
+    const bool lk = lock && lock[i - 1];
+    for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c) Ia[6 * r + c] = lk ? IA[i][6 * r + c] : IA[i][6 * r + c] - U[i][r] * U[i][c] / D[i];
     T Iac[6]; mat6_vec(Ia, cb[i], Iac);
-    for (int k = 0; k < 6; ++k) pa[k] = pA[i][k] + Iac[k] + U[i][k] * (uu[i] / D[i]);
+    for (int k = 0; k < 6; ++k) pa[k] = pA[i][k] + Iac[k] + U[i][k] * (lk ? lockacc[i - 1] : uu[i] / D[i]);
     // propagate to parent: IA_p += X^T Ia X ; pA_p += X^T pa
     T X[36]; plucker(Rj[i], H1_POS[i], X);
     T tmp[36];
@@ -186,7 +191,7 @@ inline void forward_dynamics_mj(const T* quat_hat, const T* theta, const T* v, c
     T ap[6]; xf_motion(Rj[i], H1_POS[i], acc[H1_PARENT[i]], ap);
     for (int k = 0; k < 6; ++k) ap[k] += cb[i][k];
     T s = uu[i]; for (int k = 0; k < 6; ++k) s -= U[i][k] * ap[k];
-    T qdd = s / D[i];
+    T qdd = (lock && lock[i - 1]) ? lockacc[i - 1] : s / D[i];
     for (int k = 0; k < 6; ++k) acc[i][k] = ap[k];
     acc[i][a] += qdd;
     qacc[6 + i - 1] = qdd;
@@ -273,7 +278,9 @@ constexpr int H1_FOOT_BODY[2] = {5, 10};   // left / right ankle link (leaf of e
 template <class T>
 inline void forward_dynamics_mj_stance(const T* quat_hat, const T* theta, const T* v, const T* tau, double arm_eff,
                                        const double* grav, double h, double soft, const int* stance, T* qacc, int contact_mode = 1,
-                                       double mu = 1.0) {
+                                       double mu = 1.0, const int* lock = nullptr, const T* lockacc = nullptr) {
+  // (lock / lockacc: as forward_dynamics_mj; the stance rows are then solved on the system with those hinges prescribed -- a locked
+  // hinge passes a unit wrench's share inward unreduced and does not accelerate in response)
   double Isp[H1_NB][36];
   for (int i = 0; i < H1_NB; ++i) spatial_inertia(H1_MASS[i], H1_COM[i], H1_INERTIA[i], Isp[i]);
   T R0[9]; quat_wxyz_to_R(quat_hat[0], quat_hat[1], quat_hat[2], quat_hat[3], R0);
@@ -301,9 +308,10 @@ inline void forward_dynamics_mj_stance(const T* quat_hat, const T* theta, const 
     D[i] = U[i][a] + arm_eff;
     uu[i] = tau[i - 1] - pA[i][a];
     T Ia[36], pa[6];
-    for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c) Ia[6 * r + c] = IA[i][6 * r + c] - U[i][r] * U[i][c] / D[i];
+    const bool lk = lock && lock[i - 1];
+    for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c) Ia[6 * r + c] = lk ? IA[i][6 * r + c] : IA[i][6 * r + c] - U[i][r] * U[i][c] / D[i];
     T Iac[6]; mat6_vec(Ia, cb[i], Iac);
-    for (int k = 0; k < 6; ++k) pa[k] = pA[i][k] + Iac[k] + U[i][k] * (uu[i] / D[i]);
+    for (int k = 0; k < 6; ++k) pa[k] = pA[i][k] + Iac[k] + U[i][k] * (lk ? lockacc[i - 1] : uu[i] / D[i]);
     T X[36]; plucker(Rj[i], H1_POS[i], X);
     T tmp[36];
     for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c) { T s = Ia[6 * r] * X[c]; for (int k = 1; k < 6; ++k) s += Ia[6 * r + k] * X[6 * k + c]; tmp[6 * r + c] = s; }
@@ -323,7 +331,7 @@ inline void forward_dynamics_mj_stance(const T* quat_hat, const T* theta, const 
     T ap[6]; xf_motion(Rj[i], H1_POS[i], acc[H1_PARENT[i]], ap);
     for (int k = 0; k < 6; ++k) ap[k] += cb[i][k];
     T s = uu[i]; for (int k = 0; k < 6; ++k) s -= U[i][k] * ap[k];
-    qdd[i] = s / D[i];
+    qdd[i] = (lock && lock[i - 1]) ? lockacc[i - 1] : s / D[i];
     for (int k = 0; k < 6; ++k) acc[i][k] = ap[k];
     acc[i][a] += qdd[i];
   }
@@ -341,7 +349,8 @@ inline void forward_dynamics_mj_stance(const T* quat_hat, const T* theta, const 
       for (int i = 10; i >= 1; --i) {                       // the two leg chains
         const int a = H1_AXIS[i];
         du[i] = -dpA[i][a];
-        T dpa[6]; for (int k = 0; k < 6; ++k) dpa[k] = dpA[i][k] + U[i][k] * (du[i] / D[i]);
+        const bool lk = lock && lock[i - 1];
+        T dpa[6]; for (int k = 0; k < 6; ++k) dpa[k] = lk ? dpA[i][k] : dpA[i][k] + U[i][k] * (du[i] / D[i]);
         xf_force_acc(Rj[i], H1_POS[i], dpa, dpA[H1_PARENT[i]]);
       }
       T r6[6]; for (int k = 0; k < 6; ++k) r6[k] = -dpA[0][k];
@@ -351,7 +360,7 @@ inline void forward_dynamics_mj_stance(const T* quat_hat, const T* theta, const 
         const int a = H1_AXIS[i];
         T ap[6]; xf_motion(Rj[i], H1_POS[i], da[H1_PARENT[i]], ap);
         T s = du[i]; for (int k = 0; k < 6; ++k) s -= U[i][k] * ap[k];
-        const T q = s / D[i];
+        const T q = (lock && lock[i - 1]) ? T(0.0) : s / D[i];
         for (int k = 0; k < 6; ++k) da[i][k] = ap[k];
         da[i][a] += q;
         if (full) dqdd[i] = q;
@@ -518,6 +527,24 @@ inline void h1_step(const T* x, const T* u, const DynParams& P, T* xn, const int
   T qacc[H1_NV];
   if (P.contact && stance) forward_dynamics_mj_stance(qh, x + 7, x + H1_NQ, tau, H1_ARMATURE + h * H1_DAMPING, P.g, h, P.soft, stance, qacc, P.contact, P.mu);
   else forward_dynamics_mj(qh, x + 7, x + H1_NQ, tau, H1_ARMATURE + h * H1_DAMPING, P.g, qacc);
+  if (P.limits) {
+    // Joint-limit rows (h1.xml jnt_range, enforced inside mj_step, robot_utils.cpp:113-114) restated as the rigid,
+    // velocity-level limit of that constraint, like the stance rows: a hinge past its range that the step above would still move
+    // outward (v_i + h qacc_i points out of the range) is stopped, v_i+ = 0, i.e. its acceleration is prescribed, qacc_i = -v_i / h,
+    //     Mhat qacc + bias - J^T lambda - E^T mu = tau,   E qacc = -v_L / h   (+ the stance rows, solved on the system with these hinges prescribed)
+    // -- Featherstone's hybrid dynamics through the same articulated-body recursion; the set is decided once, from the unlimited step.
+    int lock[H1_NJ], any = 0; T lockacc[H1_NJ];
+    for (int i = 0; i < H1_NJ; ++i) {
+      const double q = val(x[7 + i]), vnext = val(x[H1_NQ + 6 + i]) + h * val(qacc[6 + i]);
+      lock[i] = ((q > H1_JRANGE[i][1] && vnext > 0.0) || (q < H1_JRANGE[i][0] && vnext < 0.0)) ? 1 : 0;
+      lockacc[i] = -x[H1_NQ + 6 + i] / h;
+      any |= lock[i];
+    }
+    if (any) {
+      if (P.contact && stance) forward_dynamics_mj_stance(qh, x + 7, x + H1_NQ, tau, H1_ARMATURE + h * H1_DAMPING, P.g, h, P.soft, stance, qacc, P.contact, P.mu, lock, lockacc);
+      else forward_dynamics_mj(qh, x + 7, x + H1_NQ, tau, H1_ARMATURE + h * H1_DAMPING, P.g, qacc, lock, lockacc);
+    }
+  }
   T vn[H1_NV];
   for (int i = 0; i < H1_NV; ++i) { vn[i] = x[H1_NQ + i] + h * qacc[i]; xn[H1_NQ + i] = vn[i]; }
   for (int k = 0; k < 3; ++k) xn[k] = x[k] + h * vn[k];

@@ -307,6 +307,8 @@ void orc_step(void* s, const double* x, const double* u, double* xn) { Solver* S
 void orc_step_stance(void* s, const double* x, const double* u, const int* stance, double* xn) { Solver* S = (Solver*)s; orc::h1_step<double>(x, u, S->P.dyn, xn, stance); }
 void orc_set_contact_mode(void* s, int mode, double soft) { Solver* S = (Solver*)s; S->P.dyn.contact = mode; if (soft > 0.0) S->P.dyn.soft = soft; }
 void orc_set_friction(void* s, double mu) { ((Solver*)s)->P.dyn.mu = mu; }   // sliding friction coefficient of contact mode 3
+void orc_joint_ranges(double* out /*[19][2]*/) { for (int i = 0; i < H1_NJ; ++i) { out[2 * i] = H1_JRANGE[i][0]; out[2 * i + 1] = H1_JRANGE[i][1]; } }
+void orc_set_joint_limits(void* s, int on) { ((Solver*)s)->P.dyn.limits = on ? 1 : 0; }   // joint-limit rows of the plant (h1_step)
 void orc_rollout(void* s) { ((Solver*)s)->rollout_nominal(); }
 void orc_linearize(void* s) { ((Solver*)s)->linearize(); }
 void orc_cost_quadratics(void* s) { ((Solver*)s)->cost_quadratics(); }

@@ -235,7 +235,7 @@ def integrate_c(q, v, qacc, h):
     return np.concatenate([qn, vn])
 
 
-def kane_step_c(bodies, ctrlrange, x, u, h, grav, stance=(1, 1), contact=0, soft=1e-5, damping=1.0, armature=0.1, want=False, mu=1.0):
+def kane_step_c(bodies, ctrlrange, x, u, h, grav, stance=(1, 1), contact=0, soft=1e-5, damping=1.0, armature=0.1, want=False, mu=1.0, lock=()):
     """One MuJoCo-semantics step of the constraint-free plant (contact = 0) or with the feet the schedule
     marks as stance held by velocity-level rigid constraints over the step (contact = 1 bilateral, 2 unilateral: a foot whose
     normal force would pull is released and the rest solved again, once):
@@ -247,7 +247,9 @@ def kane_step_c(bodies, ctrlrange, x, u, h, grav, stance=(1, 1), contact=0, soft
     (`release` variant: a slipping foot receives no tangential force).
     contact = 4: the same decision, but the sliding foot keeps kinetic friction: a tangential force mu lambda_n along the unit direction in
     which the sticking solution pulled (the direction that opposes the slip), i.e. its normal multiplier acts along up + mu t while the
-    constraint row stays the normal one -- an unsymmetric system, solved once."""
+    constraint row stays the normal one -- an unsymmetric system, solved once.
+    lock: hinges (0..18) whose acceleration is prescribed, qacc_i = -v_i / h (joint-limit rows, kane_step_lim): rigid rows E qacc = -v_L / h
+    with multipliers of their own in every system solved here."""
     q, v = x[:26], x[26:]
     z25 = np.zeros(25)
     bias, feet0 = kane_eval_c(bodies, q, v, z25, grav, armature)
@@ -264,11 +266,19 @@ def kane_step_c(bodies, ctrlrange, x, u, h, grav, stance=(1, 1), contact=0, soft
     tdir = [None, None]
     lam = np.zeros(12, dtype=rhs.dtype)
     re_ = (lambda a: a.real) if np.iscomplexobj(rhs) else (lambda a: a)
+    nl = len(lock)
+    E = np.zeros((nl, 25)); bl = np.zeros(nl, dtype=rhs.dtype)
+    for r_, i_ in enumerate(lock):
+        E[r_, 6 + i_] = 1.0; bl[r_] = -v[6 + i_] / h
     stage = 0                      # 0: rigid set; 1: after the unilateral check; 2: after the Coulomb check
     while True:
         rows = [f for f in range(2) if act[f]]
         if not rows:
-            qacc = np.linalg.solve(Mh, rhs); lam[:] = 0
+            if nl:
+                qacc = np.linalg.solve(np.block([[Mh, -E.T], [E, np.zeros((nl, nl))]]), np.concatenate([rhs, bl]))[:25]
+            else:
+                qacc = np.linalg.solve(Mh, rhs)
+            lam[:] = 0
             break
         # row selection per foot: all six components of the link's spatial velocity, or -- sliding -- rotation + normal translation
         Ssel = []
@@ -291,8 +301,12 @@ def kane_step_c(bodies, ctrlrange, x, u, h, grav, stance=(1, 1), contact=0, soft
         JF = np.concatenate([Ff @ Jfull[f] for Ff, f in zip(Fsel, rows)], axis=0)
         b = np.concatenate([Sf @ (-feet0[f]["vel"] / h - feet0[f]["acc"]) for Sf, f in zip(Ssel, rows)])
         nc = J.shape[0]
-        KKT = np.block([[Mh, -JF.T], [J, soft * np.eye(nc)]])
-        sol = np.linalg.solve(KKT, np.concatenate([rhs, b]))
+        if nl:
+            KKT = np.block([[Mh, -JF.T, -E.T], [J, soft * np.eye(nc), np.zeros((nc, nl))], [E, np.zeros((nl, nc)), np.zeros((nl, nl))]])
+            sol = np.linalg.solve(KKT, np.concatenate([rhs, b, bl]))
+        else:
+            KKT = np.block([[Mh, -JF.T], [J, soft * np.eye(nc)]])
+            sol = np.linalg.solve(KKT, np.concatenate([rhs, b]))
         qacc = sol[:25]
         lam[:] = 0
         o = 25
@@ -325,6 +339,26 @@ def kane_step_c(bodies, ctrlrange, x, u, h, grav, stance=(1, 1), contact=0, soft
     if want:
         return xn, qacc, Mh, lam, act, slide
     return xn
+
+
+def kane_step_lim(bodies, ctrlrange, x, u, h, grav, **kw):
+    """The step with joint-limit rows (h1.xml jnt_range, enforced by mj_step; restated rigid and at velocity level like the stance rows):
+    a hinge past its range that the unlimited step would still move outward, (q_i > hi_i and v_i + h qacc_i > 0) or (q_i < lo_i and
+    v_i + h qacc_i < 0), is stopped over the step: E qacc = -v_L / h joins the KKT system, and the step (stance decisions included) is
+    taken again with that set.  Returns (x_next, lock set, x_next of the unlimited step, margins of the decisions)."""
+    kw = dict(kw); kw.pop("want", None)
+    xn0, qacc0, _, _, _, _ = kane_step_c(bodies, ctrlrange, x, u, h, grav, want=True, **kw)
+    rng = np.array([b["rng"] for b in bodies if b["rng"] is not None])
+    assert rng.shape == (19, 2)
+    th, qd = x[7:26], x[32:51]
+    vnext = qd + h * qacc0[6:]
+    lock = [i for i in range(19) if (th[i] > rng[i, 1] and vnext[i] > 0.0) or (th[i] < rng[i, 0] and vnext[i] < 0.0)]
+    viol = [i for i in range(19) if th[i] > rng[i, 1] or th[i] < rng[i, 0]]
+    margin = min([abs(vnext[i]) for i in viol], default=np.inf)
+    if not lock:
+        return xn0, lock, xn0, margin
+    xn = kane_step_c(bodies, ctrlrange, x, u, h, grav, lock=tuple(lock), **kw)
+    return xn, lock, xn0, margin
 
 
 def jacobians_complex_step(f, x, u, eps=1e-30):
@@ -918,8 +952,50 @@ def gen_friction():
     print("friction golden:", len(out["x"]), "cases; sliding patterns", sl.tolist(), "max |x_next - x_next_mode2|", [float(np.abs(a - b).max()) for a, b in zip(out["x_next"], out["x_next_mode2"])])
 
 
+def gen_limits():
+    """joint_limit_golden.npz: single steps with joint-limit rows (kane_step_lim): hinges past their range moving outward (stopped), moving
+    back in (left alone), several at once, on the constraint-free plant and with unilateral stance; decisions with |v_i+| < 0.05 rad/s
+    are rejected (the oracle / the kernels must take the same branch)."""
+    bodies, ctrl = load_mjcf()
+    rngj = np.array([b["rng"] for b in bodies if b["rng"] is not None])
+    rng = np.random.default_rng(2027)
+    h, grav = 0.02, np.array([0.0, 0.0, -9.81])
+    out = dict(x=[], u=[], stance=[], contact=[], x_next=[], x_next_unlimited=[], lock=[])
+    want = {(0, 0): 2, (0, 1): 3, (0, 2): 3, (2, 0): 1, (2, 1): 3, (2, 2): 2}       # (contact mode, min(#locked, 2))
+    tries = 0
+    while any(v > 0 for v in want.values()) and tries < 4000:
+        tries += 1
+        contact = [0, 2][tries % 2]
+        x = np.zeros(51); x[2] = 1.0432; x[3] = 1.0
+        aa = rng.uniform(-0.05, 0.05, 3); ang = np.linalg.norm(aa); x[3] = np.cos(ang / 2); x[4:7] = np.sin(ang / 2) / ang * aa
+        x[7:26] = rng.uniform(-0.15, 0.15, 19)
+        x[26:] = rng.uniform(-0.4, 0.4, 25)
+        nv = int(rng.integers(0, 4))
+        for i in rng.choice(19, size=nv, replace=False):
+            up = rng.random() < 0.5
+            x[7 + i] = rngj[i, 1] + rng.uniform(0.01, 0.08) if up else rngj[i, 0] - rng.uniform(0.01, 0.08)
+            x[32 + i] = rng.uniform(0.3, 2.0) * (1 if up else -1) * (1 if rng.random() < 0.75 else -1)     # mostly outward
+        u = rng.uniform(-20, 20, 19)
+        stance = (1, 1) if tries % 3 else (1, 0)
+        xn, lock, xn0, margin = kane_step_lim(bodies, ctrl, x, u, h, grav, stance=stance, contact=contact)
+        key = (contact, min(len(lock), 2))
+        if margin < 0.05 or want.get(key, 0) <= 0 or not np.all(np.isfinite(xn)):
+            continue
+        want[key] -= 1
+        lk = np.zeros(19, dtype=int); lk[lock] = 1
+        for k, val_ in (("x", x), ("u", u), ("stance", np.array(stance)), ("contact", contact), ("x_next", xn), ("x_next_unlimited", xn0), ("lock", lk)):
+            out[k].append(val_)
+    assert all(v == 0 for v in want.values()), want
+    np.savez(os.path.join(HERE, "joint_limit_golden.npz"), h=h, gravity=grav, soft=1e-5, jrange=rngj, **{k: np.array(v) for k, v in out.items()})
+    print("joint-limit golden:", len(out["x"]), "cases; locked hinges", [np.flatnonzero(l).tolist() for l in out["lock"]],
+          "max |x_next - unlimited|", [float(np.abs(a - b).max()) for a, b in zip(out["x_next"], out["x_next_unlimited"])])
+
+
 if __name__ == "__main__":
     import sys
+    if len(sys.argv) > 1 and sys.argv[1] == "limits":
+        gen_limits()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "friction":
         gen_friction()
         sys.exit(0)

@@ -138,6 +138,10 @@ class Oracle:
         """Sliding friction coefficient of contact mode 3 (unilateral + Coulomb release)."""
         self.L.orc_set_friction(self.h, C.c_double(mu))
 
+    def set_joint_limits(self, on):
+        """Joint-limit rows of the plant: a hinge past its range that the step would still move outward is stopped (h1_step)."""
+        self.L.orc_set_joint_limits(self.h, int(bool(on)))
+
     def step_stance(self, x, u, stance):
         x, u = c64(x), c64(u)
         st = np.ascontiguousarray(stance, dtype=np.int32)
@@ -251,6 +255,13 @@ class Oracle:
         K0 = np.zeros((B, NU, NX)) if want_gains else None
         total = self.L.orc_batch_solve(self.h, int(B), _p(x0), _p(ui), _p(cost), iters.ctypes.data_as(_ip), _p(u0), _p(K0), int(nthreads))
         return total, cost, iters, u0, K0
+
+
+def joint_ranges():
+    """The model table's hinge ranges (h1.xml jnt_range), [19][2]."""
+    out = np.zeros((19, 2))
+    lib().orc_joint_ranges(_p(out))
+    return out
 
 
 def reference_kinematics(x):

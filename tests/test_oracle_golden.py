@@ -393,6 +393,41 @@ def test_friction_limited_stance_step_against_the_independent_kkt_formulation():
     assert np.array_equal(a, b2)
 
 
+def test_joint_limit_rows_against_the_independent_kkt_formulation():
+    """Joint-limit rows of the plant.  The oracle treats a limited hinge as an
+    acceleration-prescribed joint of the articulated-body recursion (hybrid dynamics: no reduction of the articulated inertia, bias
+    carries IA S qacc_i; the stance rows are solved on that system); tests/golden/joint_limit_golden.npz is the dense NumPy KKT system
+    with the rows E qacc = -v_L / h and multipliers of their own (gen_golden.py kane_step_lim) -- two derivations of the same rule, on the
+    constraint-free plant and with unilateral stance, with none / one / several hinges stopped.  And the rule's defining properties."""
+    g = np.load(os.path.join(G, "joint_limit_golden.npz"))
+    prob = sc.make_problem(ol.reference_kinematics, N=5, gravity=list(g["gravity"]))
+    o = ol.Oracle(5, float(g["h"])); o.set_problem(prob)
+    seen = set()
+    for i in range(len(g["x"])):
+        cm = int(g["contact"][i])
+        o.set_contact_mode(cm, float(g["soft"]))
+        o.set_joint_limits(True)
+        xn = o.step_stance(g["x"][i], g["u"][i], g["stance"][i])
+        o.set_joint_limits(False)
+        x0 = o.step_stance(g["x"][i], g["u"][i], g["stance"][i])
+        assert np.abs(xn - g["x_next"][i]).max() < 1e-9 * max(1.0, np.abs(g["x_next"][i]).max()), (i, np.abs(xn - g["x_next"][i]).max())
+        assert np.abs(x0 - g["x_next_unlimited"][i]).max() < 1e-9 * max(1.0, np.abs(g["x_next_unlimited"][i]).max())
+        lock = np.flatnonzero(g["lock"][i])
+        if len(lock) == 0:
+            assert np.array_equal(xn, x0)               # no hinge stopped: the step IS the unlimited one
+        for j in lock:
+            assert abs(xn[32 + j]) < 1e-12 and abs(xn[7 + j] - g["x"][i][7 + j]) < 1e-12      # the hinge stops, where it is
+            assert abs(x0[32 + j]) > 0.05                                                       # ... and would not have
+        # a hinge past its range that moves back in is left alone: outside the range, not locked, velocity unchanged in sign
+        for j in range(19):
+            out_hi, out_lo = g["x"][i][7 + j] > g["jrange"][j, 1], g["x"][i][7 + j] < g["jrange"][j, 0]
+            if (out_hi or out_lo) and j not in lock:
+                assert (xn[32 + j] < 0) if out_hi else (xn[32 + j] > 0)
+        seen.add((cm, min(len(lock), 2)))
+    assert seen == {(0, 0), (0, 1), (0, 2), (2, 0), (2, 1), (2, 2)}
+    assert np.allclose(g["jrange"], ol.joint_ranges())
+
+
 def test_op_counter_pins_the_algorithmic_flop_figures_of_the_bench():
     """'flops of dynamics + analytic Jacobians + cost quadratics + one line-search alpha: to be taken from the CPU
     restatement's op counter'.  The counter (oracle/opcount.cpp) runs the oracle's own code on a counting scalar; bench.py's
