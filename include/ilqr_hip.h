@@ -205,6 +205,17 @@ enum ilqr_contact_mode { ILQR_CONTACT_NONE = 0, ILQR_CONTACT_RIGID_STANCE = 1, I
                          ILQR_CONTACT_KINETIC_FRICTION_STANCE = 4 };
 int ilqr_hip_set_contact_mode(ilqr_hip_ctx* ctx, int mode, double softness);
 int ilqr_hip_set_friction(ilqr_hip_ctx* ctx, double mu);
+/* Joint-limit rows of the plant: the reference's plant is mj_step (src/common/robot_utils.cpp:106-117), which
+   enforces the hinge ranges of robots/h1_description/mjcf/h1.xml (jnt_range, :55-151) as constraints that are active only when violated;
+   the cost side only carries the soft penalty (RobotUtils::constraintCost, robot_utils.cpp:615-672).  Restated here as the rigid,
+   velocity-level limit of that constraint, like the stance rows: a hinge past its range that the step would still move outward
+   (v_i + h qacc_i points out of the range, qacc of the step without these rows) is stopped over the step, v_i+ = 0 -- its acceleration
+   is prescribed, qacc_i = -v_i / h, in a second pass of the articulated-body recursion (Featherstone's hybrid dynamics; the stance
+   rows of the contact modes are solved on that system).  A hinge past its range that moves back in is left alone; nothing pushes a
+   hinge back (that is MuJoCo's soft constraint, solref / solimp: not modelled).  Default off (the constraint-free restatement).
+   Rollout, line search, plant step and the forward-difference Jacobians carry it (two-lane kernels); ILQR_JAC_ANALYTIC with the rows
+   switched on returns ILQR_ERR_UNSUPPORTED. */
+int ilqr_hip_set_joint_limits(ilqr_hip_ctx* ctx, int on);
 int ilqr_hip_step_stance(ilqr_hip_ctx* ctx, int count, const double* x, const double* u, int stance_left, int stance_right, double* x_next);
 
 /* per-stage device time of the last solve in milliseconds, keyed like the reference's profiler

@@ -65,6 +65,29 @@ __device__ __attribute__((noinline)) void step_stance_shared_kin(h1s::HalfX* hp,
   h1s::step_stance<true>(side, h, u, dt, grav, L, soft, 4, (side ? st_right : st_left) == 1, (side ? st_left : st_right) == 1, mu);
   *hp = h;
 }
+// the copies with joint-limit rows (DynParams::limits; h1s::step_stance<., true>): only reached when the option is on
+__device__ __attribute__((noinline)) void step_stance_shared_lim(h1s::HalfX* hp, const h1s::HalfU* up, double dt, double gx, double gy, double gz,
+                                                                 double soft, int mode, int st_left, int st_right, double mu) {
+  const int lane = threadIdx.x;
+  const bool side = (lane & 1) != 0;
+  const h1s::LaneLds L{dyn_lds_c, 64, lane};
+  const double grav[3] = {gx, gy, gz};
+  h1s::HalfX h = *hp;
+  const h1s::HalfU u = *up;
+  h1s::step_stance<false, true>(side, h, u, dt, grav, L, soft, mode, (side ? st_right : st_left) == 1, (side ? st_left : st_right) == 1, mu);
+  *hp = h;
+}
+__device__ __attribute__((noinline)) void step_stance_shared_kin_lim(h1s::HalfX* hp, const h1s::HalfU* up, double dt, double gx, double gy, double gz,
+                                                                     double soft, int st_left, int st_right, double mu) {
+  const int lane = threadIdx.x;
+  const bool side = (lane & 1) != 0;
+  const h1s::LaneLds L{dyn_lds_c, 64, lane};
+  const double grav[3] = {gx, gy, gz};
+  h1s::HalfX h = *hp;
+  const h1s::HalfU u = *up;
+  h1s::step_stance<true, true>(side, h, u, dt, grav, L, soft, 4, (side ? st_right : st_left) == 1, (side ? st_left : st_right) == 1, mu);
+  *hp = h;
+}
 // one step of either kind; `st` = stance flags (left, right) of the knot being stepped
 // (compile-time switch: the constraint-free instantiation of a kernel contains no call and no address-taken state -- with a
 // run-time branch the mere presence of the call cost the headline's line search 20 %)
@@ -89,12 +112,15 @@ DEVFN void pin_half_u(h1s::HalfU& u) {
 #pragma unroll
   for (int k = 0; k < 4; ++k) pin(u.uA[k]);
 }
-// CONTACT: 0 constraint-free, 1 stance constraints (contact modes 1-3), 2 stance constraints with kinetic friction on sliding feet (mode 4).
+// CONTACT: 0 constraint-free, 1 stance constraints (contact modes 1-3), 2 stance constraints with kinetic friction on sliding feet (mode 4),
+// 3 / 4: as 1 / 2 with joint-limit rows (DynParams::limits; 3 also serves the constraint-free plant with them: no stance rows in mode 0).
 // Mode 4 has kernels of its own: the private segment of a kernel is the largest frame it can reach, and the constrained kernels lose with
 // every kilobyte of it (1.4 -> 1.8 KB per lane: -0.7 % on the contact bench, -> 4 KB: -4 %, same machine code otherwise).
 template <int CONTACT>
 DEVFN void step_any(bool side, h1s::HalfX& h, const h1s::HalfU& u, const DynParams& dyn, const int* st, const h1s::LaneLds& L) {
-  if constexpr (CONTACT == 2) step_stance_shared_kin(&h, &u, dyn.h, dyn.g[0], dyn.g[1], dyn.g[2], dyn.soft, st[0], st[1], dyn.mu);
+  if constexpr (CONTACT == 4) step_stance_shared_kin_lim(&h, &u, dyn.h, dyn.g[0], dyn.g[1], dyn.g[2], dyn.soft, st[0], st[1], dyn.mu);
+  else if constexpr (CONTACT == 3) step_stance_shared_lim(&h, &u, dyn.h, dyn.g[0], dyn.g[1], dyn.g[2], dyn.soft, dyn.contact, st[0], st[1], dyn.mu);
+  else if constexpr (CONTACT == 2) step_stance_shared_kin(&h, &u, dyn.h, dyn.g[0], dyn.g[1], dyn.g[2], dyn.soft, st[0], st[1], dyn.mu);
   else if constexpr (CONTACT == 1) step_stance_shared(&h, &u, dyn.h, dyn.g[0], dyn.g[1], dyn.g[2], dyn.soft, dyn.contact, st[0], st[1], dyn.mu);
   else {
     // (the step size behind an opaque barrier as well: with h a loop invariant the articulated quantities of the chains' leaf
@@ -455,7 +481,7 @@ __global__ void __launch_bounds__(64) k_count_iter(DevState S, int mode) {
 }
 
 // two lanes per item: plain batched step with explicit stance flags (stage API / plant of the closed loop)
-template <bool KIN>
+template <int CK>     // CK: the CONTACT value of step_any the constrained plant takes (1..4)
 __global__ void __launch_bounds__(64) k_step_s(int count, const double* x, const double* u, DynParams dyn, double* xn, int st_l, int st_r) {
   extern __shared__ double lds[];
   const int gid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -466,11 +492,11 @@ __global__ void __launch_bounds__(64) k_step_s(int count, const double* x, const
   h1s::HalfX h; h1s::load_half(side, x + (size_t)i * H1_NX, h);
   h1s::HalfU uu; load_half_u(side, u + (size_t)i * H1_NU, uu);
   const int st[2] = {st_l, st_r};
-  if (dyn.contact) step_any<KIN ? 2 : 1>(side, h, uu, dyn, st, L); else step_any<0>(side, h, uu, dyn, st, L);
+  if (constrained(dyn)) step_any<CK>(side, h, uu, dyn, st, L); else step_any<0>(side, h, uu, dyn, st, L);
   h1s::store_half(side, h, xn + (size_t)i * H1_NX);
 }
 // last knot of the warm start: xbar[N] = f(xbar[N-1], ubar[N-1])  (ilqr.cpp:72-80)
-template <bool KIN>
+template <int CK>
 __global__ void __launch_bounds__(64) k_last_step_s(DevState S, ProblemDev P) {
   extern __shared__ double lds[];
   const int gid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -481,7 +507,7 @@ __global__ void __launch_bounds__(64) k_last_step_s(DevState S, ProblemDev P) {
   const int N = S.N;
   h1s::HalfX h; h1s::load_half(side, S.xbar + ((size_t)b * (N + 1) + N - 1) * H1_NX, h);
   h1s::HalfU uu; load_half_u(side, S.ubar + ((size_t)b * N + N - 1) * H1_NU, uu);
-  if (P.dyn.contact) step_any<KIN ? 2 : 1>(side, h, uu, P.dyn, P.stance + b * P.stance_stride + 2 * (N - 1), L); else step_any<0>(side, h, uu, P.dyn, P.stance + b * P.stance_stride + 2 * (N - 1), L);
+  if (constrained(P.dyn)) step_any<CK>(side, h, uu, P.dyn, P.stance + b * P.stance_stride + 2 * (N - 1), L); else step_any<0>(side, h, uu, P.dyn, P.stance + b * P.stance_stride + 2 * (N - 1), L);
   h1s::store_half(side, h, S.xbar + ((size_t)b * (N + 1) + N) * H1_NX);
 }
 // Reference-style forward differences (RobotUtils::linearizeDynamicsFD, robot_utils.cpp:120-160) on the two-lane step:
@@ -519,7 +545,7 @@ DEVFN void store_half_col(bool side, const h1s::HalfX& h, double* M, int ld, int
   for (int k = 0; k < 4; ++k) { M[(7 + h1s::jarm(side, k)) * ld + col] = h.q.thA[k]; M[(H1_NQ + 6 + h1s::jarm(side, k)) * ld + col] = h.q.qdA[k]; }
 }
 #define FD_NCOL (H1_NX + H1_NU + 1)
-template <bool KIN>
+template <int CK>
 __global__ void __launch_bounds__(64) k_fd_steps_s(DevState S, ProblemDev P, int mode, double eps, int dump_doubles) {
   extern __shared__ double lds[];
   const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -536,7 +562,7 @@ __global__ void __launch_bounds__(64) k_fd_steps_s(DevState S, ProblemDev P, int
   h1s::HalfX h; h1s::load_half(side, S.xbar + ((size_t)b * (S.N + 1) + t) * H1_NX, h);
   h1s::HalfU uu; load_half_u(side, S.ubar + ((size_t)b * S.N + t) * H1_NU, uu);
   perturb_half(side, h, uu, col, eps);
-  if (P.dyn.contact) step_any<KIN ? 2 : 1>(side, h, uu, P.dyn, P.stance + b * P.stance_stride + 2 * t, L); else step_any<0>(side, h, uu, P.dyn, P.stance + b * P.stance_stride + 2 * t, L);
+  if (constrained(P.dyn)) step_any<CK>(side, h, uu, P.dyn, P.stance + b * P.stance_stride + 2 * t, L); else step_any<0>(side, h, uu, P.dyn, P.stance + b * P.stance_stride + 2 * t, L);
   if (!act) return;
   if (col < H1_NX) store_half_col(side, h, S.A + (size_t)item * H1_NX * H1_NX, H1_NX, col);
   else if (col < H1_NX + H1_NU) store_half_col(side, h, S.Bm + (size_t)item * H1_NX * H1_NU, H1_NU, col - H1_NX);
@@ -562,21 +588,33 @@ int dyn_split_kernels_set_attr() {
   int rc = 0;
   const int lds = (int)DYN_LDS_BYTES_S;
   rc |= hipFuncSetAttribute((const void*)k_line_search_s<0, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess;
-  rc |= hipFuncSetAttribute((const void*)k_line_search_s<1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess;
-  rc |= hipFuncSetAttribute((const void*)k_line_search_s<2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess;
   rc |= hipFuncSetAttribute((const void*)k_line_search_s<0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess;
+  rc |= hipFuncSetAttribute((const void*)k_line_search_s<1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess;
   rc |= hipFuncSetAttribute((const void*)k_line_search_s<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess;
+  rc |= hipFuncSetAttribute((const void*)k_line_search_s<2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess;
   rc |= hipFuncSetAttribute((const void*)k_line_search_s<2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess;
+  rc |= hipFuncSetAttribute((const void*)k_line_search_s<3, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess;
+  rc |= hipFuncSetAttribute((const void*)k_line_search_s<3, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess;
+  rc |= hipFuncSetAttribute((const void*)k_line_search_s<4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess;
+  rc |= hipFuncSetAttribute((const void*)k_line_search_s<4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess;
   rc |= hipFuncSetAttribute((const void*)k_rollout_s<0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess;
   rc |= hipFuncSetAttribute((const void*)k_rollout_s<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess;
   rc |= hipFuncSetAttribute((const void*)k_rollout_s<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess;
-  rc |= hipFuncSetAttribute((const void*)k_step_s<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess;
-  rc |= hipFuncSetAttribute((const void*)k_step_s<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess;
+  rc |= hipFuncSetAttribute((const void*)k_rollout_s<3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess;
+  rc |= hipFuncSetAttribute((const void*)k_rollout_s<4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess;
+  rc |= hipFuncSetAttribute((const void*)k_step_s<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess;
+  rc |= hipFuncSetAttribute((const void*)k_step_s<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess;
+  rc |= hipFuncSetAttribute((const void*)k_step_s<3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess;
+  rc |= hipFuncSetAttribute((const void*)k_step_s<4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess;
+  rc |= hipFuncSetAttribute((const void*)k_last_step_s<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess;
+  rc |= hipFuncSetAttribute((const void*)k_last_step_s<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess;
+  rc |= hipFuncSetAttribute((const void*)k_last_step_s<3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess;
+  rc |= hipFuncSetAttribute((const void*)k_last_step_s<4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess;
+  rc |= hipFuncSetAttribute((const void*)k_fd_steps_s<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess;
+  rc |= hipFuncSetAttribute((const void*)k_fd_steps_s<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess;
+  rc |= hipFuncSetAttribute((const void*)k_fd_steps_s<3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess;
+  rc |= hipFuncSetAttribute((const void*)k_fd_steps_s<4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess;
   rc |= hipFuncSetAttribute((const void*)k_lin_primal_s, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(DYN_LDS_BYTES_S + DUMP_STG_BYTES)) != hipSuccess;
-  rc |= hipFuncSetAttribute((const void*)k_last_step_s<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess;
-  rc |= hipFuncSetAttribute((const void*)k_last_step_s<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess;
-  rc |= hipFuncSetAttribute((const void*)k_fd_steps_s<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess;
-  rc |= hipFuncSetAttribute((const void*)k_fd_steps_s<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess;
   return rc;
 }
 #ifndef LS_RPW1_MAX_BATCH
@@ -587,16 +625,22 @@ void launch_line_search_s(const DevState& S, const ProblemDev& P, int mode, hipS
   // host knows an upper bound of the compacted list's length (the selected rollouts are its first entries: blocks past the
   // list's true count leave at once); the results do not depend on the choice
   const int nsel = (list && max_rollouts >= 0 && max_rollouts < S.B) ? max_rollouts : S.B;
+  const int ck = constrained(P.dyn) ? (P.dyn.contact == 4 ? 2 : 1) + (P.dyn.limits ? 2 : 0) : 0;      // the CONTACT value of step_any
   if (nsel <= LS_RPW1_MAX_BATCH) {
     const int blocks = nsel > 0 ? nsel : 1;
-    if (P.dyn.contact == 4) hipLaunchKernelGGL((k_line_search_s<2, 1>), dim3(blocks), dim3(64), DYN_LDS_BYTES_S, st, S, P, mode, list, count);
-    else if (P.dyn.contact) hipLaunchKernelGGL((k_line_search_s<1, 1>), dim3(blocks), dim3(64), DYN_LDS_BYTES_S, st, S, P, mode, list, count);
+    if (ck == 4) hipLaunchKernelGGL((k_line_search_s<4, 1>), dim3(blocks), dim3(64), DYN_LDS_BYTES_S, st, S, P, mode, list, count);
+    else if (ck == 3) hipLaunchKernelGGL((k_line_search_s<3, 1>), dim3(blocks), dim3(64), DYN_LDS_BYTES_S, st, S, P, mode, list, count);
+    else if (ck == 2) hipLaunchKernelGGL((k_line_search_s<2, 1>), dim3(blocks), dim3(64), DYN_LDS_BYTES_S, st, S, P, mode, list, count);
+    else if (ck == 1) hipLaunchKernelGGL((k_line_search_s<1, 1>), dim3(blocks), dim3(64), DYN_LDS_BYTES_S, st, S, P, mode, list, count);
     else hipLaunchKernelGGL((k_line_search_s<0, 1>), dim3(blocks), dim3(64), DYN_LDS_BYTES_S, st, S, P, mode, list, count);
     return;
   }
-  if (P.dyn.contact == 4) hipLaunchKernelGGL((k_line_search_s<2, 4>), dim3(cdiv_s((long)S.B * 16, 64)), dim3(64), DYN_LDS_BYTES_S, st, S, P, mode, list, count);
-  else if (P.dyn.contact) hipLaunchKernelGGL((k_line_search_s<1, 4>), dim3(cdiv_s((long)S.B * 16, 64)), dim3(64), DYN_LDS_BYTES_S, st, S, P, mode, list, count);
-  else hipLaunchKernelGGL((k_line_search_s<0, 4>), dim3(cdiv_s((long)S.B * 16, 64)), dim3(64), DYN_LDS_BYTES_S, st, S, P, mode, list, count);
+  const dim3 grid(cdiv_s((long)S.B * 16, 64));
+  if (ck == 4) hipLaunchKernelGGL((k_line_search_s<4, 4>), grid, dim3(64), DYN_LDS_BYTES_S, st, S, P, mode, list, count);
+  else if (ck == 3) hipLaunchKernelGGL((k_line_search_s<3, 4>), grid, dim3(64), DYN_LDS_BYTES_S, st, S, P, mode, list, count);
+  else if (ck == 2) hipLaunchKernelGGL((k_line_search_s<2, 4>), grid, dim3(64), DYN_LDS_BYTES_S, st, S, P, mode, list, count);
+  else if (ck == 1) hipLaunchKernelGGL((k_line_search_s<1, 4>), grid, dim3(64), DYN_LDS_BYTES_S, st, S, P, mode, list, count);
+  else hipLaunchKernelGGL((k_line_search_s<0, 4>), grid, dim3(64), DYN_LDS_BYTES_S, st, S, P, mode, list, count);
 }
 void launch_lin_primal_s(const DevState& S, const ProblemDev& P, int mode, hipStream_t st, const int* list, const int* count) {
   // up to one wave per SIMD (32 knots per wave): the lanes store their blocks themselves, without the staging area (and its LDS: four waves per CU)
@@ -604,24 +648,44 @@ void launch_lin_primal_s(const DevState& S, const ProblemDev& P, int mode, hipSt
   const int direct = waves <= 1024 ? 1 : 0;
   hipLaunchKernelGGL(k_lin_primal_s, dim3(waves), dim3(64), DYN_LDS_BYTES_S + (direct ? 0 : DUMP_STG_BYTES), st, S, P, mode, list, count, direct);
 }
+static int step_kind(const DynParams& d) { return (d.contact == 4 ? 2 : 1) + (d.limits ? 2 : 0); }      // CK of the kernels below
 void launch_step_s(int count, const double* x, const double* u, const DynParams& dyn, double* xn, hipStream_t st, int stance_l, int stance_r) {
-  if (dyn.contact == 4) hipLaunchKernelGGL(k_step_s<true>, dim3(cdiv_s((long)count * 2, 64)), dim3(64), DYN_LDS_BYTES_S, st, count, x, u, dyn, xn, stance_l, stance_r);
-  else hipLaunchKernelGGL(k_step_s<false>, dim3(cdiv_s((long)count * 2, 64)), dim3(64), DYN_LDS_BYTES_S, st, count, x, u, dyn, xn, stance_l, stance_r);
+  const dim3 grid(cdiv_s((long)count * 2, 64));
+  switch (step_kind(dyn)) {
+    case 4: hipLaunchKernelGGL(k_step_s<4>, grid, dim3(64), DYN_LDS_BYTES_S, st, count, x, u, dyn, xn, stance_l, stance_r); break;
+    case 3: hipLaunchKernelGGL(k_step_s<3>, grid, dim3(64), DYN_LDS_BYTES_S, st, count, x, u, dyn, xn, stance_l, stance_r); break;
+    case 2: hipLaunchKernelGGL(k_step_s<2>, grid, dim3(64), DYN_LDS_BYTES_S, st, count, x, u, dyn, xn, stance_l, stance_r); break;
+    default: hipLaunchKernelGGL(k_step_s<1>, grid, dim3(64), DYN_LDS_BYTES_S, st, count, x, u, dyn, xn, stance_l, stance_r);
+  }
 }
 void launch_last_step_s(const DevState& S, const ProblemDev& P, hipStream_t st) {
-  if (P.dyn.contact == 4) hipLaunchKernelGGL(k_last_step_s<true>, dim3(cdiv_s((long)S.B * 2, 64)), dim3(64), DYN_LDS_BYTES_S, st, S, P);
-  else hipLaunchKernelGGL(k_last_step_s<false>, dim3(cdiv_s((long)S.B * 2, 64)), dim3(64), DYN_LDS_BYTES_S, st, S, P);
+  const dim3 grid(cdiv_s((long)S.B * 2, 64));
+  switch (step_kind(P.dyn)) {
+    case 4: hipLaunchKernelGGL(k_last_step_s<4>, grid, dim3(64), DYN_LDS_BYTES_S, st, S, P); break;
+    case 3: hipLaunchKernelGGL(k_last_step_s<3>, grid, dim3(64), DYN_LDS_BYTES_S, st, S, P); break;
+    case 2: hipLaunchKernelGGL(k_last_step_s<2>, grid, dim3(64), DYN_LDS_BYTES_S, st, S, P); break;
+    default: hipLaunchKernelGGL(k_last_step_s<1>, grid, dim3(64), DYN_LDS_BYTES_S, st, S, P);
+  }
 }
 void launch_linearize_fd_s(const DevState& S, const ProblemDev& P, int mode, double eps, hipStream_t st) {
   const int dd = (int)lin_dump_doubles();
-  if (P.dyn.contact == 4) hipLaunchKernelGGL(k_fd_steps_s<true>, dim3(cdiv_s((long)S.B * S.N * FD_NCOL * 2, 64)), dim3(64), DYN_LDS_BYTES_S, st, S, P, mode, eps, dd);
-  else hipLaunchKernelGGL(k_fd_steps_s<false>, dim3(cdiv_s((long)S.B * S.N * FD_NCOL * 2, 64)), dim3(64), DYN_LDS_BYTES_S, st, S, P, mode, eps, dd);
+  const dim3 grid(cdiv_s((long)S.B * S.N * FD_NCOL * 2, 64));
+  switch (step_kind(P.dyn)) {
+    case 4: hipLaunchKernelGGL(k_fd_steps_s<4>, grid, dim3(64), DYN_LDS_BYTES_S, st, S, P, mode, eps, dd); break;
+    case 3: hipLaunchKernelGGL(k_fd_steps_s<3>, grid, dim3(64), DYN_LDS_BYTES_S, st, S, P, mode, eps, dd); break;
+    case 2: hipLaunchKernelGGL(k_fd_steps_s<2>, grid, dim3(64), DYN_LDS_BYTES_S, st, S, P, mode, eps, dd); break;
+    default: hipLaunchKernelGGL(k_fd_steps_s<1>, grid, dim3(64), DYN_LDS_BYTES_S, st, S, P, mode, eps, dd);
+  }
   hipLaunchKernelGGL(k_fd_finish, dim3(cdiv_s((long)S.B * S.N * H1_NX * (H1_NX + H1_NU), 256)), dim3(256), 0, st, S, mode, eps, dd);
 }
 void launch_rollout_s(const DevState& S, const ProblemDev& P, int mode, int do_roll, int count_iter, double* cost_out, hipStream_t st) {
-  if (do_roll && P.dyn.contact == 4) hipLaunchKernelGGL(k_rollout_s<2>, dim3(cdiv_s((long)S.B * 2, 64)), dim3(64), DYN_LDS_BYTES_S, st, S, P, mode, count_iter);
-  else if (do_roll && P.dyn.contact) hipLaunchKernelGGL(k_rollout_s<1>, dim3(cdiv_s((long)S.B * 2, 64)), dim3(64), DYN_LDS_BYTES_S, st, S, P, mode, count_iter);
-  else if (do_roll) hipLaunchKernelGGL(k_rollout_s<0>, dim3(cdiv_s((long)S.B * 2, 64)), dim3(64), DYN_LDS_BYTES_S, st, S, P, mode, count_iter);
+  const dim3 grid(cdiv_s((long)S.B * 2, 64));
+  const int ck = constrained(P.dyn) ? step_kind(P.dyn) : 0;
+  if (do_roll && ck == 4) hipLaunchKernelGGL(k_rollout_s<4>, grid, dim3(64), DYN_LDS_BYTES_S, st, S, P, mode, count_iter);
+  else if (do_roll && ck == 3) hipLaunchKernelGGL(k_rollout_s<3>, grid, dim3(64), DYN_LDS_BYTES_S, st, S, P, mode, count_iter);
+  else if (do_roll && ck == 2) hipLaunchKernelGGL(k_rollout_s<2>, grid, dim3(64), DYN_LDS_BYTES_S, st, S, P, mode, count_iter);
+  else if (do_roll && ck == 1) hipLaunchKernelGGL(k_rollout_s<1>, grid, dim3(64), DYN_LDS_BYTES_S, st, S, P, mode, count_iter);
+  else if (do_roll) hipLaunchKernelGGL(k_rollout_s<0>, grid, dim3(64), DYN_LDS_BYTES_S, st, S, P, mode, count_iter);
   else if (count_iter) hipLaunchKernelGGL(k_count_iter, dim3(cdiv_s(S.B, 64)), dim3(64), 0, st, S, mode);
   launch_nominal_costs(S, P, mode, cost_out, st);
 }

@@ -312,13 +312,18 @@ template <int IL, int IR> DEVFN double body_acc(bool side, const double* vp, con
   return qdd;
 }
 
+struct ArmPer { double base; const double* add; };      // effective armature of hinge K of a chain: base + add[K]
+DEVFN double arm_at(double a, int) { return a; }
+DEVFN double arm_at(const ArmPer& a, int k) { return a.base + a.add[k]; }
 // ---- mirrored chains: bodies FL.. (even lane) / FR.. (odd lane), LEN hinges, LDS slot blocks from SLOT0 ------
 // Register-lean sweeps: the outward pass keeps only the running velocity and the joint sines / cosines; the inward
 // pass recovers each parent velocity with the inverse joint transform (v_parent = X^-1 (v - S qd)) and recomputes
 // the velocity-product force from it, instead of holding 12 numbers per body across the two passes.
 template <int FL, int FR, int LEN, int SLOT0> struct Chain {
   // th, qd, tau: this lane's LEN hinge values.  Yj / pAj accumulate this lane's chain only.
-  static DEVFN void in(bool side, const double* vj, const double* th, const double* qd, const double* tau, double arm_eff, const LaneLds& L,
+  // ARM: double (the same effective armature on every hinge) or ArmPer (joint-limit rows, step_stance<., true>: per-hinge armature on top)
+  template <class ARM>
+  static DEVFN void in(bool side, const double* vj, const double* th, const double* qd, const double* tau, ARM arm_eff, const LaneLds& L,
                        Art& Yj, double* pAj) {
     double sn[LEN], cs[LEN], v[6];
     step_out<0>(side, vj, th, qd, sn, cs, v);          // v = velocity of the chain's last body
@@ -337,7 +342,7 @@ template <int FL, int FR, int LEN, int SLOT0> struct Chain {
       for (int k = 0; k < 6; ++k) vlast[k] = v[k];
     }
   }
-  template <int K> static DEVFN void step_in(bool side, const double* qd, const double* tau, double arm_eff, const LaneLds& L,
+  template <int K, class ARM> static DEVFN void step_in(bool side, const double* qd, const double* tau, ARM arm_eff, const LaneLds& L,
                                              const double* sn, const double* cs, double* v, Art& carry, double* pc, Art& Yj, double* pAj) {
     constexpr int AX = C_AXIS[FL + K];
     BodyState S;
@@ -352,14 +357,14 @@ template <int FL, int FR, int LEN, int SLOT0> struct Chain {
       for (int k = 0; k < 6; ++k) S.pA[k] += pc[k];
     }
     if constexpr (K > 0) {
-      body_in<FL + K, FR + K, false>(side, Y, S, tau[K], qd[K], arm_eff, L, SLOT0 + 8 * K, carry, pc);     // carry, pc <- (assigned)
+      body_in<FL + K, FR + K, false>(side, Y, S, tau[K], qd[K], arm_at(arm_eff, K), L, SLOT0 + 8 * K, carry, pc);     // carry, pc <- (assigned)
       // parent's velocity for the next inward step
       double vc[6] = {v[0], v[1], v[2], v[3], v[4], v[5]};
       vc[AX] -= qd[K];
       xf_motion_inv<FL + K, FR + K>(side, vc, sn[K], cs[K], v);
       step_in<K - 1>(side, qd, tau, arm_eff, L, sn, cs, v, carry, pc, Yj, pAj);
     } else {
-      body_in<FL + K, FR + K>(side, Y, S, tau[K], qd[K], arm_eff, L, SLOT0 + 8 * K, Yj, pAj);
+      body_in<FL + K, FR + K>(side, Y, S, tau[K], qd[K], arm_at(arm_eff, K), L, SLOT0 + 8 * K, Yj, pAj);
     }
   }
   // the same sweep reporting every body: sink(body index of this lane's side, v, a, sin, cos)
@@ -426,8 +431,14 @@ typedef Chain<12, 16, 4, 48> ArmChain;   // bodies 12..15 / 16..19, LDS slots 48
 
 // Forward dynamics in MuJoCo coordinates.  R0: base rotation from the unit quaternion; vb = qvel[0..5];
 // qbase[6] (identical on both lanes) and this lane's hinge accelerations out.
+// arm_add: per-hinge armature on top of arm_eff (HalfTau-shaped), null for none.  A hinge with armature 2^1000 and torque c 2^1000 IS an
+// acceleration-prescribed joint, qacc = c, exactly: D = 2^1000, 1 / D = 2^-1000 and u / D = c to the last bit, the reduction of the
+// articulated inertia U U^T / D vanishes below rounding -- Featherstone's hybrid dynamics through the unmodified recursion, and every
+// later reader of U_i, 1 / D_i (the stance rows' unit-wrench responses, the linearisation's Minv columns) sees that hinge locked.
+template <bool PER = false>
 DEVFN void forward_dynamics(bool side, const double* R0, const double* vb, const HalfState& q, const HalfTau& tau, double arm_eff,
-                            const double* grav, const LaneLds& L, double* qbase, HalfAcc& qacc, Art* Y0_out = nullptr, double* a0_out = nullptr) {
+                            const double* grav, const LaneLds& L, double* qbase, HalfAcc& qacc, Art* Y0_out = nullptr, double* a0_out = nullptr,
+                            const HalfTau* arm_add = nullptr) {
   double v0[6] = {vb[3], vb[4], vb[5], 0, 0, 0};
   v0[3] = R0[0] * vb[0] + R0[3] * vb[1] + R0[6] * vb[2];
   v0[4] = R0[1] * vb[0] + R0[4] * vb[1] + R0[7] * vb[2];
@@ -437,7 +448,8 @@ DEVFN void forward_dynamics(bool side, const double* R0, const double* vb, const
   Art Y0; double p0[6];
   {
     Art Yt; art_zero(Yt); double pt[6] = {0, 0, 0, 0, 0, 0};
-    ArmChain::in(side, T11.v, q.thA, q.qdA, tau.tA, arm_eff, L, Yt, pt);
+    if constexpr (PER) ArmChain::in(side, T11.v, q.thA, q.qdA, tau.tA, ArmPer{arm_eff, arm_add->tA}, L, Yt, pt);
+    else ArmChain::in(side, T11.v, q.thA, q.qdA, tau.tA, arm_eff, L, Yt, pt);
     art_pair_sum(Yt);                         // left + right arm
 #pragma unroll
     for (int k = 0; k < 6; ++k) pt[k] = pair_sum(pt[k]);
@@ -447,14 +459,15 @@ DEVFN void forward_dynamics(bool side, const double* R0, const double* vb, const
     art_zero(Y0);
 #pragma unroll
     for (int k = 0; k < 6; ++k) p0[k] = 0.0;
-    body_in<11, 11>(side, Y, T11, tau.t11, q.qd11, arm_eff, L, 0, Y0, p0);   // torso's share of the pelvis (both lanes)
+    body_in<11, 11>(side, Y, T11, tau.t11, q.qd11, PER ? arm_eff + arm_add->t11 : arm_eff, L, 0, Y0, p0);   // torso's share of the pelvis (both lanes)
   }
 #ifdef ABA_FENCE   // scheduling fence between the independent sweeps (arms | legs | pelvis solve | outward passes): left free, the
   __builtin_amdgcn_sched_barrier(0);   // scheduler interleaves them and a third more temporaries live (and spill) at once
 #endif
   {
     Art Yl; art_zero(Yl); double pl[6] = {0, 0, 0, 0, 0, 0};
-    LegChain::in(side, v0, q.thL, q.qdL, tau.tL, arm_eff, L, Yl, pl);
+    if constexpr (PER) LegChain::in(side, v0, q.thL, q.qdL, tau.tL, ArmPer{arm_eff, arm_add->tL}, L, Yl, pl);
+    else LegChain::in(side, v0, q.thL, q.qdL, tau.tL, arm_eff, L, Yl, pl);
     art_pair_sum(Yl);                         // left + right leg
 #pragma unroll
     for (int k = 0; k < 6; ++k) pl[k] = pair_sum(pl[k]);
@@ -1055,7 +1068,11 @@ DEVFN void step(bool side, HalfX& h, const HalfU& u, double dt, const double* gr
 }
 
 // x <- f(x, u) with the stance constraints of the scheduled feet (contact mode 1 / 2 / 3)
-template <bool KIN = false>
+// LIM: joint-limit rows (h1.xml jnt_range, enforced inside mj_step; oracle h1_step): a hinge past its range that the
+// step would still move outward is stopped -- the dynamics run once more with those hinges acceleration-prescribed, qacc_i = -v_i / h
+// (forward_dynamics: armature 2^1000), the stance rows solved on that system.  mode 0: no stance rows (the constraint-free plant).
+constexpr double LOCK_ARM = 0x1p1000;
+template <bool KIN = false, bool LIM = false>
 DEVFN void step_stance(bool side, HalfX& h, const HalfU& u, double dt, const double* grav, const LaneLds& L, double soft, int mode, bool st_own, bool st_par, double mu = 1.0) {
   const double qn = sqrt(h.quat[0] * h.quat[0] + h.quat[1] * h.quat[1] + h.quat[2] * h.quat[2] + h.quat[3] * h.quat[3]);
   const double qh[4] = {h.quat[0] / qn, h.quat[1] / qn, h.quat[2] / qn, h.quat[3] / qn};
@@ -1076,7 +1093,28 @@ DEVFN void step_stance(bool side, HalfX& h, const HalfU& u, double dt, const dou
   }
   double qb[6]; HalfAcc qa; Art Y0; double a0[6];
   forward_dynamics(side, R0, h.vb, h.q, tau, ARMATURE + dt * DAMPING, grav, L, qb, qa, &Y0, a0);
+  if constexpr (LIM) { if (mode == 0) { st_own = false; st_par = false; } }
   if (st_own || st_par) stance_correct<KIN>(side, R0, h.vb, h.q, dt, soft, mode, st_own, st_par, grav, L, Y0, a0, qb, qa, mu);
+  if constexpr (LIM) {
+    HalfTau add; bool any = false;
+    auto lim = [&](double lo, double hi, double th, double qd, double qdd, double& tq, double& ad) {
+      const double vn = qd + dt * qdd;
+      const bool lk = (th > hi && vn > 0.0) || (th < lo && vn < 0.0);
+      ad = lk ? LOCK_ARM : 0.0;
+      tq = lk ? (-qd / dt) * LOCK_ARM : tq;
+      any = any || lk;
+    };
+    lim(C_JRANGE[10][0], C_JRANGE[10][1], h.q.th11, h.q.qd11, qa.q11, tau.t11, add.t11);
+#pragma unroll
+    for (int k = 0; k < 5; ++k) lim(side ? C_JRANGE[5 + k][0] : C_JRANGE[k][0], side ? C_JRANGE[5 + k][1] : C_JRANGE[k][1], h.q.thL[k], h.q.qdL[k], qa.qL[k], tau.tL[k], add.tL[k]);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) lim(side ? C_JRANGE[15 + k][0] : C_JRANGE[11 + k][0], side ? C_JRANGE[15 + k][1] : C_JRANGE[11 + k][1], h.q.thA[k], h.q.qdA[k], qa.qA[k], tau.tA[k], add.tA[k]);
+    const bool anyp = xch_flag(any) || any;          // the pair runs the recursion together
+    if (anyp) {
+      forward_dynamics<true>(side, R0, h.vb, h.q, tau, ARMATURE + dt * DAMPING, grav, L, qb, qa, &Y0, a0, &add);
+      if (st_own || st_par) stance_correct<KIN>(side, R0, h.vb, h.q, dt, soft, mode, st_own, st_par, grav, L, Y0, a0, qb, qa, mu);
+    }
+  }
 #pragma unroll
   for (int k = 0; k < 6; ++k) h.vb[k] += dt * qb[k];
 #pragma unroll

@@ -57,9 +57,13 @@ struct DynParams {
   int contact;      // 0: constraint-free step; 1: rigid stance constraints on the scheduled feet;
                     // 2: the same, unilateral (a stance foot the floor would have to pull on is released)
                     // 3: unilateral + Coulomb limit (a foot outside the cone |f_t| <= mu f_n slides: tangential rows dropped)
+  int limits;       // 1: joint-limit rows -- a hinge past its range that the step would still move outward is stopped (h1_aba_split.h
+                    // step_stance<., true>); sits in what was padding: the layout of the rest (kernel arguments) does not move
   double soft;      // diagonal softness of the stance constraint (1 / kg)
   double mu;        // sliding friction coefficient of mode 3
 };
+// the plant needs the constrained step (stance rows and / or joint-limit rows): the two-lane kernels with the shared constrained step
+__host__ __device__ inline bool constrained(const DynParams& d) { return d.contact != 0 || d.limits != 0; }
 
 // ---------- 3-vectors / 3x3 (row-major) ----------
 template <class T, class U> DEVFN void cross3(const T* a, const U* b, T* c) {

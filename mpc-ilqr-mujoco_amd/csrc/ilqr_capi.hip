@@ -214,7 +214,7 @@ int ilqr_hip_create(ilqr_hip_ctx** out, int device, int batch, int horizon, doub
   if (rc != ILQR_OK) { *out = c; return rc; }
   if (ilqr::backward_needs_lds_attr() != 0) { c->err = "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed"; *out = c; return ILQR_ERR_HIP; }
   h1::ProblemDev& P = c->P;
-  P.N = horizon; P.dyn.h = dt; P.dyn.g[0] = 0; P.dyn.g[1] = 0; P.dyn.g[2] = -9.81; P.dyn.contact = 0; P.dyn.soft = 1e-5; P.dyn.mu = 1.0;
+  P.N = horizon; P.dyn.h = dt; P.dyn.g[0] = 0; P.dyn.g[1] = 0; P.dyn.g[2] = -9.81; P.dyn.contact = 0; P.dyn.soft = 1e-5; P.dyn.mu = 1.0; P.dyn.limits = 0;
   for (int i = 0; i < ILQR_NX; ++i) { P.Q[i] = 1.0; P.Qf[i] = 1.0; }
   for (int i = 0; i < ILQR_NU; ++i) P.R[i] = 1.0;
   P.w_com = P.w_com_vel = P.w_ee_pos = P.w_ee_vel = P.w_upright = P.w_balance = 0.0;
@@ -364,10 +364,10 @@ int ilqr_hip_set_early_exit_gate(ilqr_hip_ctx* c, int on) { if (!c) return ILQR_
 // if it is this very kernel under these very dynamics parameters (bit-identical result); compared field by field, not by memcmp
 // (padding bytes).
 static int rollout_kernel_identity(const h1::ProblemDev& P) {
-  return ilqr::variant_scalar_dyn() ? 2 : ((ilqr::variant_rollout_split() || P.dyn.contact) ? 1 : 0);
+  return ilqr::variant_scalar_dyn() ? 2 : ((ilqr::variant_rollout_split() || h1::constrained(P.dyn)) ? 1 : 0);
 }
 static bool same_dyn(const h1::DynParams& a, const h1::DynParams& b) {
-  return a.h == b.h && a.g[0] == b.g[0] && a.g[1] == b.g[1] && a.g[2] == b.g[2] && a.contact == b.contact && a.soft == b.soft && a.mu == b.mu;
+  return a.h == b.h && a.g[0] == b.g[0] && a.g[1] == b.g[1] && a.g[2] == b.g[2] && a.contact == b.contact && a.soft == b.soft && a.mu == b.mu && a.limits == b.limits;
 }
 static int cold_start_device(ilqr_hip_ctx* c, const double* x0_dev, const double* uinit_dev) {
   const size_t B = c->B, N = c->N;
@@ -612,7 +612,7 @@ static int enqueue_solve(ilqr_hip_ctx* c, const DevState& S, const h1::ProblemDe
   };
   auto rolls_aside = [&](int iter) {
     const bool first_aside = iter == 0 && xbar_rolled && !ilqr::variant_scalar_dyn();
-    return (iter > 0 || first_aside) && !c->knobs.reuse_rollout && c->knobs.overlap_rollout && (P.dyn.contact || ilqr::variant_ls_split() == ilqr::variant_rollout_split());   // (contact mode: both on the two-lane kernels)
+    return (iter > 0 || first_aside) && !c->knobs.reuse_rollout && c->knobs.overlap_rollout && (h1::constrained(P.dyn) || ilqr::variant_ls_split() == ilqr::variant_rollout_split());   // (contact mode: both on the two-lane kernels)
   };
   // Early continuation: the rollouts whose first line search of iteration i accepted a step are done with iteration i; their share of
   // iteration i + 1's concurrent region (group A) starts right behind the first control pass, on streams of its own, while the
@@ -753,6 +753,10 @@ int ilqr_hip_num_slices(const ilqr_hip_ctx* c) { return c ? slices_wanted(c, c->
 // solution) is carried by the two-knot tangent kernel only (k_lin_tangent2c<., 1 / 2>): the one-knot and scalar cross-check families
 // refuse it.
 static int jacobians_available(ilqr_hip_ctx* c) {
+  if (c->P.dyn.limits && c->jac_mode == ILQR_JAC_ANALYTIC) {
+    c->err = "joint-limit rows (ilqr_hip_set_joint_limits): analytic Jacobians are not available, select ILQR_JAC_FD_FORWARD with ilqr_hip_set_options";
+    return ILQR_ERR_UNSUPPORTED;
+  }
   if (c->P.dyn.contact >= ILQR_CONTACT_FRICTION_STANCE && c->jac_mode == ILQR_JAC_ANALYTIC && (ilqr::variant_lin_one_knot() || ilqr::variant_scalar_dyn())) {
     c->err = "contact modes 3 / 4 (Coulomb limit): analytic Jacobians are not available in this kernel family (ILQR_LIN / ILQR_DYN), select ILQR_JAC_FD_FORWARD with ilqr_hip_set_options";
     return ILQR_ERR_UNSUPPORTED;
@@ -1002,6 +1006,12 @@ int ilqr_hip_set_contact_mode(ilqr_hip_ctx* c, int mode, double softness) {
   if (mode >= ILQR_CONTACT_FRICTION_STANCE && ilqr::variant_scalar_dyn()) { c->err = "contact modes 3 / 4 (Coulomb limit) exist on the two-lane kernels only; unset ILQR_DYN=s"; return ILQR_ERR_UNSUPPORTED; }
   c->P.dyn.contact = mode;
   if (softness > 0.0) c->P.dyn.soft = softness;
+  return ILQR_OK;
+}
+int ilqr_hip_set_joint_limits(ilqr_hip_ctx* c, int on) {
+  if (!c) return ILQR_ERR_ARG;
+  if (on && ilqr::variant_scalar_dyn()) { c->err = "joint-limit rows exist on the two-lane kernels only; unset ILQR_DYN=s"; return ILQR_ERR_UNSUPPORTED; }
+  c->P.dyn.limits = on ? 1 : 0;     // (a nominal rolled under the other setting is recognised by same_dyn)
   return ILQR_OK;
 }
 int ilqr_hip_set_friction(ilqr_hip_ctx* c, double mu) {

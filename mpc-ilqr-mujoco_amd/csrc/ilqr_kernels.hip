@@ -1105,11 +1105,11 @@ int variant_lin_one_knot() { return g_var.lin_one_knot; }
 int variant_pack() { return (backward_kind() == 2 && g_var.fold == 2) ? 1 : 0; }
 void launch_rollout(const DevState& S, const ProblemDev& P, int mode, int do_roll, int count_iter, double* cost_out, hipStream_t st) {
   // contact mode (f4) runs on the two-lane kernels (the one-lane register kernels are constraint-free only)
-  if (!use_scalar_dyn()) { if (g_var.rollout_split || P.dyn.contact) launch_rollout_s(S, P, mode, do_roll, count_iter, cost_out, st); else launch_rollout_r(S, P, mode, do_roll, count_iter, cost_out, st); return; }
+  if (!use_scalar_dyn()) { if (g_var.rollout_split || constrained(P.dyn)) launch_rollout_s(S, P, mode, do_roll, count_iter, cost_out, st); else launch_rollout_r(S, P, mode, do_roll, count_iter, cost_out, st); return; }
   LEGACY_LAUNCH(hipLaunchKernelGGL(k_rollout, dim3(cdiv(S.B, 64)), dim3(64), 0, st, S, P, mode, do_roll, count_iter, cost_out));
 }
 void launch_step(int count, const double* x, const double* u, const DynParams& dyn, double* xn, hipStream_t st, int stance_l, int stance_r) {
-  if (!use_scalar_dyn()) { if (dyn.contact) launch_step_s(count, x, u, dyn, xn, st, stance_l, stance_r); else launch_step_r(count, x, u, dyn, xn, st); return; }
+  if (!use_scalar_dyn()) { if (constrained(dyn)) launch_step_s(count, x, u, dyn, xn, st, stance_l, stance_r); else launch_step_r(count, x, u, dyn, xn, st); return; }
   LEGACY_LAUNCH(hipLaunchKernelGGL(k_step, dim3(cdiv(count, 64)), dim3(64), 0, st, count, x, u, dyn, xn, stance_l, stance_r));
 }
 // phases: 1 = primal dump only, 2 = tangent sweeps / FD only, 3 = both
@@ -1124,7 +1124,7 @@ void launch_linearize(const DevState& S, const ProblemDev& P, int mode, int jac_
   const WorkList w = wl ? *wl : work_list(S, mode, iter);
   if (jac_mode == 0 && !use_scalar_dyn()) {
     // primal dump: on two lanes per knot beside the two-lane rollout kernels, one lane per knot with ILQR_ROLLOUT=r
-    if (phases & 1) { if (g_var.rollout_split || P.dyn.contact) launch_lin_primal_s(S, P, mode, st, w.list, w.count); else launch_lin_primal_r(S, P, mode, st); }   // (contact mode: the dump is the free solve, see k_lin_tangent_c)
+    if (phases & 1) { if (g_var.rollout_split || constrained(P.dyn)) launch_lin_primal_s(S, P, mode, st, w.list, w.count); else launch_lin_primal_r(S, P, mode, st); }   // (contact mode: the dump is the free solve, see k_lin_tangent_c)
     if ((phases & 2) && P.dyn.contact) {
       const dim3 grid2((unsigned)(((long)S.B * S.N + 1) / 2));
       if (g_var.lin_one_knot) { LEGACY_LAUNCH(hipLaunchKernelGGL(k_lin_tangent_c, dim3(S.N, S.B), dim3(128), 0, st, S, P, mode, w.list, w.count)); if (pack) launch_pack_ab(S, st, mode, w.list, w.count); }
@@ -1169,7 +1169,7 @@ void launch_backward(const DevState& S, int mode, hipStream_t st, double fold_h,
 }
 void launch_line_search(const DevState& S, const ProblemDev& P, int mode, hipStream_t st, int iter, int max_rollouts) {
   if (!use_scalar_dyn()) {
-    if (g_var.ls_split || P.dyn.contact) {
+    if (g_var.ls_split || constrained(P.dyn)) {
       const int slot = (S.order && iter >= 0 && mode != MASK_ALL) ? 2 * iter + (mode == MASK_RETRY ? 1 : 0) : -1;      // as launch_backward
       launch_line_search_s(S, P, mode, st, slot >= 0 ? S.order + (size_t)slot * S.B : nullptr, slot >= 0 ? S.order_n + slot : nullptr, slot >= 0 ? max_rollouts : -1);
       launch_cand_costs(S, P, mode, st, iter < 0);      // (inside a solve k_control adds the knot costs up)
@@ -1180,7 +1180,7 @@ void launch_line_search(const DevState& S, const ProblemDev& P, int mode, hipStr
   LEGACY_LAUNCH(hipLaunchKernelGGL(k_line_search, dim3(cdiv((long)S.B * 8, 64)), dim3(64), 0, st, S, P, mode));
 }
 // inside a solve the two-lane line search leaves per-knot costs behind and k_control sums them itself (ls_costs_per_knot)
-bool ls_costs_per_knot(const ProblemDev& P) { return !use_scalar_dyn() && (g_var.ls_split || P.dyn.contact); }
+bool ls_costs_per_knot(const ProblemDev& P) { return !use_scalar_dyn() && (g_var.ls_split || constrained(P.dyn)); }
 void launch_control(const DevState& S, int phase, int iter, double tol, int early_exit, hipStream_t st, int sum_knots, const int* gate) {
   hipLaunchKernelGGL(k_control, dim3(cdiv(S.B, CTRL_WAVES)), dim3(64 * CTRL_WAVES), 0, st, S, phase, iter, tol, early_exit, sum_knots, gate);
 }
@@ -1189,7 +1189,7 @@ void launch_control_spec(const DevState& S, const DevState& T, int iter, double 
   hipLaunchKernelGGL(k_control_spec, dim3(cdiv(S.B, CTRL_WAVES)), dim3(64 * CTRL_WAVES), 0, st, S, T, iter, tol, early_exit, sum_knots, gate);
 }
 void launch_spec_gate(const DevState& S, int iter, int max, int* g, hipStream_t st) { hipLaunchKernelGGL(k_spec_gate, dim3(1), dim3(1), 0, st, (const int*)(S.order_n + 2 * iter), max, g); }
-bool spec_dual_available(const ProblemDev& P) { return !use_scalar_dyn() && backward_kind() == 2 && (g_var.ls_split || P.dyn.contact); }
+bool spec_dual_available(const ProblemDev& P) { return !use_scalar_dyn() && backward_kind() == 2 && (g_var.ls_split || constrained(P.dyn)); }
 void launch_backward_list(const DevState& S, hipStream_t st, double fold_h, const int* list, const int* count) {
   if (g_var.fold == 2 && fold_h != 0.0) launch_backward_pack(S, MASK_ACTIVE, st, fold_h, list, count);
   else launch_backward_wave(S, MASK_ACTIVE, st, g_var.fold == 1 ? fold_h : 0.0, list, count);
@@ -1198,7 +1198,7 @@ void launch_line_search_list(const DevState& S, const ProblemDev& P, hipStream_t
 void launch_solve_begin(const DevState& S, hipStream_t st) { hipLaunchKernelGGL(k_solve_begin, dim3(cdiv(S.B, 64)), dim3(64), 0, st, S); }
 void launch_adopt_rollout(const DevState& S, const double* shadow, int mode, unsigned long long* mismatches, hipStream_t st) { hipLaunchKernelGGL(k_adopt_rollout, dim3(S.B), dim3(64), 0, st, S, shadow, mode, mismatches); }
 void launch_warm_shift(const DevState& S, const double* px, const double* pu, hipStream_t st) { hipLaunchKernelGGL(k_warm_shift, dim3(S.B), dim3(64), 0, st, S, px, pu); }
-void launch_last_step(const DevState& S, const ProblemDev& P, hipStream_t st) { if (!use_scalar_dyn()) { if (P.dyn.contact) launch_last_step_s(S, P, st); else launch_last_step_r(S, P, st); return; } LEGACY_LAUNCH(hipLaunchKernelGGL(k_last_step, dim3(cdiv(S.B, 64)), dim3(64), 0, st, S, P)); }
+void launch_last_step(const DevState& S, const ProblemDev& P, hipStream_t st) { if (!use_scalar_dyn()) { if (constrained(P.dyn)) launch_last_step_s(S, P, st); else launch_last_step_r(S, P, st); return; } LEGACY_LAUNCH(hipLaunchKernelGGL(k_last_step, dim3(cdiv(S.B, 64)), dim3(64), 0, st, S, P)); }
 void launch_compute_control(const DevState& S, const double* x_meas, double* u_out, hipStream_t st) { hipLaunchKernelGGL(k_compute_control, dim3(S.B), dim3(64), 0, st, S, x_meas, u_out); }
 void launch_pack_first_knot(const DevState& S, double* u0, double* K0, hipStream_t st) { hipLaunchKernelGGL(k_pack_first_knot, dim3(S.B), dim3(64), 0, st, S, u0, K0); }
 void launch_pack_payload(const DevState& S, int with_gains, double* out, hipStream_t st) { hipLaunchKernelGGL(k_pack_payload, dim3(S.B), dim3(64), 0, st, S, with_gains, out); }

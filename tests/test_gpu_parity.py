@@ -553,6 +553,72 @@ def test_sliding_contact_analytic_jacobians_match_oracle_ad(mode):
     s.close()
 
 
+def test_joint_limit_rows_step_and_solve_match_golden_and_oracle():
+    """Joint-limit rows of the plant (include/ilqr_hip.h ilqr_hip_set_joint_limits): a hinge
+    past its range that the step would still move outward is stopped.  On the GPU a stopped hinge is a hinge with armature 2^1000 in a
+    second pass of the articulated-body recursion (exactly an acceleration-prescribed joint); the committed vectors come from the dense
+    NumPy KKT system with explicit rows (tests/golden/joint_limit_golden.npz), the oracle from its own hybrid recursion.  (i) the step,
+    1e-9, with and without unilateral stance, none / one / several hinges stopped; switched off it IS the unlimited step; (ii) a solve
+    with the reference's forward-difference Jacobians from a state with a knee and an elbow past their ranges, against the oracle;
+    (iii) the analytic Jacobians refuse loudly while the rows are on."""
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "joint_limit_golden.npz"))
+    n = len(g["x"])
+    prob, x0, ui = make(2, seed=31, gravity=list(g["gravity"]), walking=True)
+    s = _solver(2); s.set_problem(prob)
+    o = oracle_for(prob)
+    stopped = 0
+    for i in range(n):
+        cm = int(g["contact"][i])
+        xs = np.tile(g["x"][i], (2, 1)); us = np.tile(g["u"][i], (2, 1))
+        s.set_contact_mode(cm, float(g["soft"])); s.set_joint_limits(True)
+        got = s.step_stance(xs, us, int(g["stance"][i][0]), int(g["stance"][i][1]))
+        s.set_joint_limits(False)
+        got0 = s.step_stance(xs, us, int(g["stance"][i][0]), int(g["stance"][i][1]))
+        o.set_contact_mode(cm, float(g["soft"])); o.set_joint_limits(True)
+        want = o.step_stance(g["x"][i], g["u"][i], g["stance"][i])
+        assert np.array_equal(got[0], got[1])
+        assert np.abs(got[0] - g["x_next"][i]).max() < 1e-9 * max(1.0, np.abs(g["x_next"][i]).max()), (i, np.abs(got[0] - g["x_next"][i]).max())
+        assert np.abs(got[0] - want).max() < 1e-9 * max(1.0, np.abs(want).max())
+        assert np.abs(got0[0] - g["x_next_unlimited"][i]).max() < 1e-9 * max(1.0, np.abs(g["x_next_unlimited"][i]).max())
+        lock = np.flatnonzero(g["lock"][i])
+        for j in lock:
+            assert abs(got[0][32 + j]) < 1e-12
+        stopped += int(len(lock) > 0)
+        if len(lock) == 0:
+            assert np.abs(got[0] - got0[0]).max() < 1e-12
+    assert stopped >= 8
+    s.close()
+    # (ii) a solve: left knee (hinge 3: range -0.26 .. 2.05) and right elbow (hinge 18: -1.25 .. 2.61) past their ranges, moving outward
+    Bs = 3
+    for cm in (0, 2):
+        prob, x0, ui = make(Bs, seed=31, gravity=list(g["gravity"]) if cm else None, walking=True)
+        x0 = x0.copy()
+        x0[:, 7 + 3] = 2.09; x0[:, 32 + 3] = 1.5
+        x0[1:, 7 + 18] = -1.28; x0[1:, 32 + 18] = -2.0
+        s = _solver(Bs); s.set_problem(prob); s.set_contact_mode(cm); s.set_joint_limits(True)
+        s.set_options(jacobian_mode=1, fd_eps=1e-5, early_exit=False); s.set_max_iterations(3)
+        s.initialize(x0, ui); cost = s.solve(x0)
+        tc, ta, tl = s.trace()
+        assert s.adopt_mismatches() == 0
+        differs = 0
+        for b in range(Bs):
+            ob = oracle_for(prob, jac_mode=1, fd_eps=1e-5, early_exit=0, max_iter=3); ob.set_contact_mode(cm); ob.set_joint_limits(True)
+            ob.initialize(x0[b], ui[b]); ok, c = ob.solve(x0[b])
+            nn, oc, oa, ol_ = ob.trace()
+            assert nn == 3 and np.allclose(tc[b], oc, rtol=1e-5) and np.array_equal(ta[b], oa), (cm, tc[b], oc, ta[b], oa)
+            assert abs(cost[b] - c) <= 1e-5 * abs(c) and rel(s.gains_K()[b], ob.get("K")) < 1e-4 and rel(s.xbar()[b], ob.get("xbar")) < 1e-5
+            o2 = oracle_for(prob, jac_mode=1, fd_eps=1e-5, early_exit=0, max_iter=3); o2.set_contact_mode(cm)
+            o2.initialize(x0[b], ui[b]); _, c2 = o2.solve(x0[b])
+            differs += int(abs(c2 - c) > 1e-6 * abs(c))
+        assert differs >= 2                              # the rows mattered
+        # (iii)
+        s.set_options(jacobian_mode=0, early_exit=False)
+        s.initialize(x0, ui)
+        with pytest.raises(RuntimeError, match="joint-limit rows"):
+            s.solve(x0)
+        s.close()
+
+
 def test_forward_difference_jacobians_two_lane_vs_scalar_kernels():
     """The forward-difference Jacobians (the reference's scheme, robot_utils.cpp:120-160) on the two-lane step kernels equal the
     scalar kernels' (ILQR_DYN=s) to rounding / eps, with and without stance constraints."""
