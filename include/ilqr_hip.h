@@ -213,8 +213,9 @@ int ilqr_hip_set_friction(ilqr_hip_ctx* ctx, double mu);
    is prescribed, qacc_i = -v_i / h, in a second pass of the articulated-body recursion (Featherstone's hybrid dynamics; the stance
    rows of the contact modes are solved on that system).  A hinge past its range that moves back in is left alone; nothing pushes a
    hinge back (that is MuJoCo's soft constraint, solref / solimp: not modelled).  Default off (the constraint-free restatement).
-   Rollout, line search, plant step and the forward-difference Jacobians carry it (two-lane kernels); ILQR_JAC_ANALYTIC with the rows
-   switched on returns ILQR_ERR_UNSUPPORTED. */
+   Rollout, line search, plant step and both Jacobian schemes carry it (two-lane kernels, in instantiations of their own: with the
+   option off every kernel keeps its machine code).  Analytic Jacobians: the dumped recursion has the stopped hinges
+   acceleration-prescribed and d qacc_i = -1 / h rides the direction of a stopped hinge's own rate (decisions held fixed). */
 int ilqr_hip_set_joint_limits(ilqr_hip_ctx* ctx, int on);
 int ilqr_hip_step_stance(ilqr_hip_ctx* ctx, int count, const double* x, const double* u, int stance_left, int stance_right, double* x_next);
 

@@ -423,6 +423,9 @@ struct DumpSinkS {
     st->flush(blk, write ? rec + ldg_v(i) : -1L);
   }
 };
+// LIM (joint-limit rows): the set of hinges the step stops is decided as the step decides it -- on the accelerations of the step without
+// the rows, stance rows included --, then the recursion that is dumped runs with those hinges acceleration-prescribed.
+template <bool LIM>
 __global__ void __launch_bounds__(64) k_lin_primal_s(DevState S, ProblemDev P, int mode, const int* list, const int* count, int direct) {
   extern __shared__ double lds[];
   const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -456,6 +459,18 @@ __global__ void __launch_bounds__(64) k_lin_primal_s(DevState S, ProblemDev P, i
   const DumpStage stage{lds + h1s::LDS_SLOTS * 64, S.lin_dump, (int)threadIdx.x, direct != 0 || total <= 1024 * 32};
   const DumpSinkS sink{&stage, rec, &L, side, live};
   double qb[6], inv36[36], aL[3]; h1s::HalfAcc qa;
+  if constexpr (LIM) {
+    h1s::HalfTau add;
+    {
+      h1s::Art Y0; double a0[6];
+      h1s::forward_dynamics(side, R0, h.vb, h.q, tau, h1s::ARMATURE + dt * h1s::DAMPING, P.dyn.g, L, qb, qa, &Y0, a0);
+      const int* stn = P.stance + b * P.stance_stride + 2 * t;
+      const bool st_own = P.dyn.contact != 0 && (side ? stn[1] : stn[0]) == 1, st_par = P.dyn.contact != 0 && (side ? stn[0] : stn[1]) == 1;
+      if (st_own || st_par) h1s::stance_correct<true>(side, R0, h.vb, h.q, dt, P.dyn.soft, P.dyn.contact, st_own, st_par, P.dyn.g, L, Y0, a0, qb, qa, P.dyn.mu);
+      h1s::limit_locks(side, h.q, qa, dt, tau, add);
+    }
+    h1s::forward_dynamics_dump<const DumpSinkS, true>(side, R0, h.vb, h.q, tau, h1s::ARMATURE + dt * h1s::DAMPING, P.dyn.g, L, qb, qa, sink, inv36, aL, &add);
+  } else
   h1s::forward_dynamics_dump(side, R0, h.vb, h.q, tau, h1s::ARMATURE + dt * h1s::DAMPING, P.dyn.g, L, qb, qa, sink, inv36, aL);
   // the record's header, all of it from the left lane (the right lane's hinge accelerations cross over): four chunks of 22, the last
   // two overlapping (same values) so that nothing beyond the 76 doubles is touched
@@ -614,7 +629,8 @@ int dyn_split_kernels_set_attr() {
   rc |= hipFuncSetAttribute((const void*)k_fd_steps_s<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess;
   rc |= hipFuncSetAttribute((const void*)k_fd_steps_s<3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess;
   rc |= hipFuncSetAttribute((const void*)k_fd_steps_s<4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess;
-  rc |= hipFuncSetAttribute((const void*)k_lin_primal_s, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(DYN_LDS_BYTES_S + DUMP_STG_BYTES)) != hipSuccess;
+  rc |= hipFuncSetAttribute((const void*)k_lin_primal_s<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(DYN_LDS_BYTES_S + DUMP_STG_BYTES)) != hipSuccess;
+  rc |= hipFuncSetAttribute((const void*)k_lin_primal_s<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(DYN_LDS_BYTES_S + DUMP_STG_BYTES)) != hipSuccess;
   return rc;
 }
 #ifndef LS_RPW1_MAX_BATCH
@@ -646,7 +662,8 @@ void launch_lin_primal_s(const DevState& S, const ProblemDev& P, int mode, hipSt
   // up to one wave per SIMD (32 knots per wave): the lanes store their blocks themselves, without the staging area (and its LDS: four waves per CU)
   const long waves = cdiv_s((long)S.B * S.N * 2, 64);
   const int direct = waves <= 1024 ? 1 : 0;
-  hipLaunchKernelGGL(k_lin_primal_s, dim3(waves), dim3(64), DYN_LDS_BYTES_S + (direct ? 0 : DUMP_STG_BYTES), st, S, P, mode, list, count, direct);
+  if (P.dyn.limits) hipLaunchKernelGGL(k_lin_primal_s<true>, dim3(waves), dim3(64), DYN_LDS_BYTES_S + (direct ? 0 : DUMP_STG_BYTES), st, S, P, mode, list, count, direct);
+  else hipLaunchKernelGGL(k_lin_primal_s<false>, dim3(waves), dim3(64), DYN_LDS_BYTES_S + (direct ? 0 : DUMP_STG_BYTES), st, S, P, mode, list, count, direct);
 }
 static int step_kind(const DynParams& d) { return (d.contact == 4 ? 2 : 1) + (d.limits ? 2 : 0); }      // CK of the kernels below
 void launch_step_s(int count, const double* x, const double* u, const DynParams& dyn, double* xn, hipStream_t st, int stance_l, int stance_r) {

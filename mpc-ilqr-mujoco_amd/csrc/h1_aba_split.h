@@ -571,9 +571,9 @@ DEVFN void ldl6_solve(const Ldl6& F, const double* rhs, double* out) {
 // sink(body, v, a, sin, cos) for every body of this lane's side (pelvis and torso: both lanes report them), the explicit
 // inverse of the pelvis' articulated inertia and the pelvis' linear acceleration without the gravity term.  U, 1/D stay in
 // this lane's LDS slots (torso: slot block 0, leg hinge K: 8 + 8 K, arm hinge K: 48 + 8 K).
-template <class Sink>
+template <class Sink, bool PER = false>
 DEVFN void forward_dynamics_dump(bool side, const double* R0, const double* vb, const HalfState& q, const HalfTau& tau, double arm_eff, const double* grav,
-                                 const LaneLds& L, double* qbase, HalfAcc& qacc, Sink& sink, double* inv36, double* aL) {
+                                 const LaneLds& L, double* qbase, HalfAcc& qacc, Sink& sink, double* inv36, double* aL, const HalfTau* arm_add = nullptr) {
   double v0[6] = {vb[3], vb[4], vb[5], 0, 0, 0};
   v0[3] = R0[0] * vb[0] + R0[3] * vb[1] + R0[6] * vb[2];
   v0[4] = R0[1] * vb[0] + R0[4] * vb[1] + R0[7] * vb[2];
@@ -582,7 +582,8 @@ DEVFN void forward_dynamics_dump(bool side, const double* R0, const double* vb, 
   Art Y0; double p0[6];
   {
     Art Yt; art_zero(Yt); double pt[6] = {0, 0, 0, 0, 0, 0};
-    ArmChain::in(side, T11.v, q.thA, q.qdA, tau.tA, arm_eff, L, Yt, pt);
+    if constexpr (PER) ArmChain::in(side, T11.v, q.thA, q.qdA, tau.tA, ArmPer{arm_eff, arm_add->tA}, L, Yt, pt);
+    else ArmChain::in(side, T11.v, q.thA, q.qdA, tau.tA, arm_eff, L, Yt, pt);
     art_pair_sum(Yt);
 #pragma unroll
     for (int k = 0; k < 6; ++k) pt[k] = pair_sum(pt[k]);
@@ -592,12 +593,13 @@ DEVFN void forward_dynamics_dump(bool side, const double* R0, const double* vb, 
     art_zero(Y0);
 #pragma unroll
     for (int k = 0; k < 6; ++k) p0[k] = 0.0;
-    body_in<11, 11>(side, Y, T11, tau.t11, q.qd11, arm_eff, L, 0, Y0, p0);
+    body_in<11, 11>(side, Y, T11, tau.t11, q.qd11, PER ? arm_eff + arm_add->t11 : arm_eff, L, 0, Y0, p0);
   }
   __builtin_amdgcn_sched_barrier(0);
   {
     Art Yl; art_zero(Yl); double pl[6] = {0, 0, 0, 0, 0, 0};
-    LegChain::in(side, v0, q.thL, q.qdL, tau.tL, arm_eff, L, Yl, pl);
+    if constexpr (PER) LegChain::in(side, v0, q.thL, q.qdL, tau.tL, ArmPer{arm_eff, arm_add->tL}, L, Yl, pl);
+    else LegChain::in(side, v0, q.thL, q.qdL, tau.tL, arm_eff, L, Yl, pl);
     art_pair_sum(Yl);
 #pragma unroll
     for (int k = 0; k < 6; ++k) pl[k] = pair_sum(pl[k]);
@@ -1072,6 +1074,24 @@ DEVFN void step(bool side, HalfX& h, const HalfU& u, double dt, const double* gr
 // step would still move outward is stopped -- the dynamics run once more with those hinges acceleration-prescribed, qacc_i = -v_i / h
 // (forward_dynamics: armature 2^1000), the stance rows solved on that system.  mode 0: no stance rows (the constraint-free plant).
 constexpr double LOCK_ARM = 0x1p1000;
+// The hinges of this lane that the step stops, decided on the accelerations qa of the step without the rows: their torque and extra
+// armature for the second pass (tau, add); true if this lane has any.
+DEVFN bool limit_locks(bool side, const HalfState& q, const HalfAcc& qa, double dt, HalfTau& tau, HalfTau& add) {
+  bool any = false;
+  auto lim = [&](double lo, double hi, double th, double qd, double qdd, double& tq, double& ad) {
+    const double vn = qd + dt * qdd;
+    const bool lk = (th > hi && vn > 0.0) || (th < lo && vn < 0.0);
+    ad = lk ? LOCK_ARM : 0.0;
+    tq = lk ? (-qd / dt) * LOCK_ARM : tq;
+    any = any || lk;
+  };
+  lim(C_JRANGE[10][0], C_JRANGE[10][1], q.th11, q.qd11, qa.q11, tau.t11, add.t11);
+#pragma unroll
+  for (int k = 0; k < 5; ++k) lim(side ? C_JRANGE[5 + k][0] : C_JRANGE[k][0], side ? C_JRANGE[5 + k][1] : C_JRANGE[k][1], q.thL[k], q.qdL[k], qa.qL[k], tau.tL[k], add.tL[k]);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) lim(side ? C_JRANGE[15 + k][0] : C_JRANGE[11 + k][0], side ? C_JRANGE[15 + k][1] : C_JRANGE[11 + k][1], q.thA[k], q.qdA[k], qa.qA[k], tau.tA[k], add.tA[k]);
+  return any;
+}
 template <bool KIN = false, bool LIM = false>
 DEVFN void step_stance(bool side, HalfX& h, const HalfU& u, double dt, const double* grav, const LaneLds& L, double soft, int mode, bool st_own, bool st_par, double mu = 1.0) {
   const double qn = sqrt(h.quat[0] * h.quat[0] + h.quat[1] * h.quat[1] + h.quat[2] * h.quat[2] + h.quat[3] * h.quat[3]);
@@ -1096,19 +1116,8 @@ DEVFN void step_stance(bool side, HalfX& h, const HalfU& u, double dt, const dou
   if constexpr (LIM) { if (mode == 0) { st_own = false; st_par = false; } }
   if (st_own || st_par) stance_correct<KIN>(side, R0, h.vb, h.q, dt, soft, mode, st_own, st_par, grav, L, Y0, a0, qb, qa, mu);
   if constexpr (LIM) {
-    HalfTau add; bool any = false;
-    auto lim = [&](double lo, double hi, double th, double qd, double qdd, double& tq, double& ad) {
-      const double vn = qd + dt * qdd;
-      const bool lk = (th > hi && vn > 0.0) || (th < lo && vn < 0.0);
-      ad = lk ? LOCK_ARM : 0.0;
-      tq = lk ? (-qd / dt) * LOCK_ARM : tq;
-      any = any || lk;
-    };
-    lim(C_JRANGE[10][0], C_JRANGE[10][1], h.q.th11, h.q.qd11, qa.q11, tau.t11, add.t11);
-#pragma unroll
-    for (int k = 0; k < 5; ++k) lim(side ? C_JRANGE[5 + k][0] : C_JRANGE[k][0], side ? C_JRANGE[5 + k][1] : C_JRANGE[k][1], h.q.thL[k], h.q.qdL[k], qa.qL[k], tau.tL[k], add.tL[k]);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) lim(side ? C_JRANGE[15 + k][0] : C_JRANGE[11 + k][0], side ? C_JRANGE[15 + k][1] : C_JRANGE[11 + k][1], h.q.thA[k], h.q.qdA[k], qa.qA[k], tau.tA[k], add.tA[k]);
+    HalfTau add;
+    const bool any = limit_locks(side, h.q, qa, dt, tau, add);
     const bool anyp = xch_flag(any) || any;          // the pair runs the recursion together
     if (anyp) {
       forward_dynamics<true>(side, R0, h.vb, h.q, tau, ARMATURE + dt * DAMPING, grav, L, qb, qa, &Y0, a0, &add);

@@ -763,8 +763,10 @@ DEVFN void lin_contact_multipliers(const LinShared& L, LinContact& Cc, int wv, i
 // constraint row does -- through the foot's velocity v_f / h and the velocity-product part of its acceleration: pure kinematics.
 // The three v_lin directions therefore run a kinematics-only forward chain (lin2_leg_vlin_dR: dv, da down the leg, no inertia,
 // no forces, no backward pass) on 2 knots x 2 feet x 3 = 12 lanes of an otherwise idle wave, into the slots 16..18 of dR.
-DEVFN void lin2_tangent_legs_c(LinShared* L2, LinContact* C2, int lane, const LinSlide* Z2 = nullptr) {
+template <bool LIM = false>
+DEVFN void lin2_tangent_legs_c(LinShared* L2, LinContact* C2, int lane, const LinSlide* Z2 = nullptr, const double (*lockc2)[H1_NB] = nullptr) {
   LinShared& L = L2[lane >> 5]; LinContact& Cc = C2[lane >> 5];
+  const double* lockc = LIM ? lockc2[lane >> 5] : nullptr;
   const int grp = (lane >> 4) & 1, q = lane & 15;
   const bool side = grp == 1;
   int kind, idx; slot_direction2(false, side, q, kind, idx);
@@ -788,7 +790,7 @@ DEVFN void lin2_tangent_legs_c(LinShared* L2, LinContact* C2, int lane, const Li
   }
   __builtin_amdgcn_sched_barrier(0);
   double df[5][6], dvf[6], daf[6];
-  TanChain2<1, 6, 5>::fwd<0>(L, side, kind, idx, dv0, da0, df, dvf, daf);
+  TanChain2<1, 6, 5>::template fwd<0, LIM>(L, side, kind, idx, dv0, da0, df, dvf, daf, lockc);
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
     Cc.dR[grp][k][q] = daf[k] + dvf[k] / L.h;

@@ -88,9 +88,11 @@ DEVFN void lane_direction(int lane, int& kind, int& idx) {
 
 // tangent of (v_i, a_i, f_i) of body I given its parent's tangent (pv, pa).  The body index is a template parameter:
 // joint axis, offset and inertia are immediates (h1_model_constexpr.h) and no array is indexed at run time.
-template <int I>
+// (LIM, joint-limit rows: lockc[i] = -1 / h for a hinge the step stops -- its acceleration is prescribed, qacc_i = -v_i / h, so the
+// direction of its own rate carries d qacc_i = -1 / h through the inverse-dynamics tangent -- and 0 for the others)
+template <int I, bool LIM = false>
 DEVFN void tan_body_fwd(const LinShared& L, int kind, int idx, const double* pv, const double* pa,
-                        double* dv, double* da, double* df) {
+                        double* dv, double* da, double* df, const double* lockc = nullptr) {
   const LinDump& D = L.D;
   constexpr int ax = h1c::C_AXIS[I];
   const double* Rj = D.Rj[I];
@@ -113,6 +115,7 @@ DEVFN void tan_body_fwd(const LinShared& L, int kind, int idx, const double* pv,
     h1r::cross_axis<ax>(xa + 3, t);      da[3] += mt * t[0]; da[4] += mt * t[1]; da[5] += mt * t[2];
   }
   dv[ax] += md;
+  if constexpr (LIM) da[ax] += md * lockc[I];
   {  // + dv x (S qd)
     double t[3];
     h1r::cross_axis<ax>(dv, t);     da[0] += qd * t[0]; da[1] += qd * t[1]; da[2] += qd * t[2];
@@ -206,8 +209,8 @@ DEVFN void tan_base(const LinShared& L, int kind, int idx, double* dv0, double* 
   }
 }
 // mirrored-pair versions of tan_body_fwd / tan_body_bwd: body IL on the even group, IR on the odd one
-template <int IL, int IR>
-DEVFN void tan_body_fwd2(const LinShared& L, bool side, int kind, int idx, const double* pv, const double* pa, double* dv, double* da, double* df) {
+template <int IL, int IR, bool LIM = false>
+DEVFN void tan_body_fwd2(const LinShared& L, bool side, int kind, int idx, const double* pv, const double* pa, double* dv, double* da, double* df, const double* lockc = nullptr) {
   const LinDump& D = L.D;
   constexpr int ax = h1c::C_AXIS[IL];
   static_assert(h1c::C_AXIS[IL] == h1c::C_AXIS[IR], "mirror bodies");
@@ -229,6 +232,7 @@ DEVFN void tan_body_fwd2(const LinShared& L, bool side, int kind, int idx, const
     h1r::cross_axis<ax>(xa + 3, t);      da[3] += mt * t[0]; da[4] += mt * t[1]; da[5] += mt * t[2];
   }
   dv[ax] += md;
+  if constexpr (LIM) da[ax] += md * lockc[i];
   {
     double t[3];
     h1r::cross_axis<ax>(dv, t);     da[0] += qd * t[0]; da[1] += qd * t[1]; da[2] += qd * t[2];
@@ -265,12 +269,12 @@ DEVFN double tan_body_bwd2(const LinShared& L, bool side, int kind, int idx, con
 }
 template <int FL, int FR, int LEN> struct TanChain2 {
   // (dv_last / da_last: optional copy of the LAST body's velocity / acceleration tangents -- the foot's, for the contact row)
-  template <int K> static DEVFN void fwd(const LinShared& L, bool side, int kind, int idx, const double* pv, const double* pa, double (*df)[6],
-                                         double* dv_last = nullptr, double* da_last = nullptr) {
+  template <int K, bool LIM = false> static DEVFN void fwd(const LinShared& L, bool side, int kind, int idx, const double* pv, const double* pa, double (*df)[6],
+                                         double* dv_last = nullptr, double* da_last = nullptr, const double* lockc = nullptr) {
     double nv[6], na[6];
-    tan_body_fwd2<FL + K, FR + K>(L, side, kind, idx, pv, pa, nv, na, df[K]);
+    tan_body_fwd2<FL + K, FR + K, LIM>(L, side, kind, idx, pv, pa, nv, na, df[K], lockc);
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (K + 1 < LEN) fwd<K + 1>(L, side, kind, idx, nv, na, df, dv_last, da_last);
+    if constexpr (K + 1 < LEN) fwd<K + 1, LIM>(L, side, kind, idx, nv, na, df, dv_last, da_last, lockc);
     else if (dv_last) {
 #pragma unroll
       for (int k = 0; k < 6; ++k) { dv_last[k] = nv[k]; da_last[k] = na[k]; }
@@ -285,9 +289,10 @@ template <int FL, int FR, int LEN> struct TanChain2 {
     if constexpr (K > 0) bwd<K - 1>(L, side, kind, idx, df, acc, dFj, col);
   }
   // sweeps the chain for one direction; adds the chain's force tangent at its root to dFj; rows -> L.dT[.][col]
-  static DEVFN void run(LinShared& L, bool side, int kind, int idx, const double* jv, const double* ja, double* dFj, int col) {
+  template <bool LIM = false>
+  static DEVFN void run(LinShared& L, bool side, int kind, int idx, const double* jv, const double* ja, double* dFj, int col, const double* lockc = nullptr) {
     double df[LEN][6];
-    fwd<0>(L, side, kind, idx, jv, ja, df);
+    fwd<0, LIM>(L, side, kind, idx, jv, ja, df, nullptr, nullptr, lockc);
     double acc[6] = {0, 0, 0, 0, 0, 0};
     bwd<LEN - 1>(L, side, kind, idx, df, acc, dFj, col);
   }
@@ -726,32 +731,36 @@ DEVFN int slot_in_group2(int c, int kind, int idx) {
   return (idx >= first && idx < first + 4) ? 8 + 4 * off + (idx - first) : -1;
 }
 // lane = (knot slot, side, direction slot): all 64 lanes sweep
-DEVFN void lin2_tangent_legs(LinShared* L2, int lane) {
+template <bool LIM = false>
+DEVFN void lin2_tangent_legs(LinShared* L2, int lane, const double (*lockc2)[H1_NB] = nullptr) {
   LinShared& L = L2[lane >> 5];
+  const double* lockc = LIM ? lockc2[lane >> 5] : nullptr;
   const int grp = (lane >> 4) & 1, q = lane & 15;
   const bool side = grp == 1;
   int kind, idx; slot_direction2(false, side, q, kind, idx);
   const int col = dir_lane(kind, idx);
   double dv0[6], da0[6]; tan_base(L, kind, idx, dv0, da0);
   double dFj[6] = {0, 0, 0, 0, 0, 0};
-  TanChain2<1, 6, 5>::run(L, side, kind, idx, dv0, da0, dFj, col);
+  TanChain2<1, 6, 5>::template run<LIM>(L, side, kind, idx, dv0, da0, dFj, col, lockc);
 #pragma unroll
   for (int k = 0; k < 6; ++k) L.u.t.part[grp][k][q] = dFj[k];
 }
-DEVFN void lin2_tangent_arms(LinShared* L2, int lane) {
+template <bool LIM = false>
+DEVFN void lin2_tangent_arms(LinShared* L2, int lane, const double (*lockc2)[H1_NB] = nullptr) {
   LinShared& L = L2[lane >> 5];
+  const double* lockc = LIM ? lockc2[lane >> 5] : nullptr;
   const int grp = (lane >> 4) & 1, q = lane & 15;
   const bool side = grp == 1;
   int kind, idx; slot_direction2(true, side, q, kind, idx);
   const int col = dir_lane(kind, idx);
   double dv0[6], da0[6]; tan_base(L, kind, idx, dv0, da0);
   double tv[6], ta[6], dF11[6];
-  tan_body_fwd<11>(L, kind, idx, dv0, da0, tv, ta, dF11);     // the torso's own force tangent: counted by the left group only
+  tan_body_fwd<11, LIM>(L, kind, idx, dv0, da0, tv, ta, dF11, lockc);     // the torso's own force tangent: counted by the left group only
   if (side) {
 #pragma unroll
     for (int k = 0; k < 6; ++k) dF11[k] = 0.0;
   }
-  TanChain2<12, 16, 4>::run(L, side, kind, idx, tv, ta, dF11, col);
+  TanChain2<12, 16, 4>::template run<LIM>(L, side, kind, idx, tv, ta, dF11, col, lockc);
   double dFj[6] = {0, 0, 0, 0, 0, 0};
   L.u.t.part11[grp][q] = tan_body_bwd<11>(L, side ? DIR_NONE : kind, idx, dF11, dFj);
 #pragma unroll

@@ -753,8 +753,8 @@ int ilqr_hip_num_slices(const ilqr_hip_ctx* c) { return c ? slices_wanted(c, c->
 // solution) is carried by the two-knot tangent kernel only (k_lin_tangent2c<., 1 / 2>): the one-knot and scalar cross-check families
 // refuse it.
 static int jacobians_available(ilqr_hip_ctx* c) {
-  if (c->P.dyn.limits && c->jac_mode == ILQR_JAC_ANALYTIC) {
-    c->err = "joint-limit rows (ilqr_hip_set_joint_limits): analytic Jacobians are not available, select ILQR_JAC_FD_FORWARD with ilqr_hip_set_options";
+  if (c->P.dyn.limits && c->jac_mode == ILQR_JAC_ANALYTIC && (ilqr::variant_lin_one_knot() || ilqr::variant_scalar_dyn())) {
+    c->err = "joint-limit rows (ilqr_hip_set_joint_limits): analytic Jacobians are not available in this kernel family (ILQR_LIN / ILQR_DYN), select ILQR_JAC_FD_FORWARD with ilqr_hip_set_options";
     return ILQR_ERR_UNSUPPORTED;
   }
   if (c->P.dyn.contact >= ILQR_CONTACT_FRICTION_STANCE && c->jac_mode == ILQR_JAC_ANALYTIC && (ilqr::variant_lin_one_knot() || ilqr::variant_scalar_dyn())) {

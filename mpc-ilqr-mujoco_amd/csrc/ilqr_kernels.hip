@@ -182,7 +182,21 @@ DEVFN void lin2_store_B(const LinShared& L, int c, double* Ag, double* Bg, Cfn&&
 // A of knot 1 on wave 1, B of both knots on wave 2.  Work items are (selected rollout, knot) pairs in rollout-major order.
 // PACK: operand layout of riccati_pack.h (lin2_store_A / lin2_store_B above); getters and the other kernel families get the standard
 // layout back from k_unpack_ab.
-template <bool PACK>
+// LIM: joint-limit rows (DynParams::limits).  The dump then comes from the recursion with the stopped hinges acceleration-prescribed
+// (1 / D_i = 2^-1000: their Minv rows and columns vanish by themselves); what is left to carry is d qacc_i = -1 / h in the direction of
+// a stopped hinge's own rate -- seeded into the inverse-dynamics tangent (tan_body_fwd*) and written into its row of d qacc.  An
+// instantiation of its own: the default kernel keeps its machine code.
+template <bool LIM> struct LinLockOpt { double c[2][H1_NB]; DEVFN double (*get())[H1_NB] { return c; } };
+template <> struct LinLockOpt<false> { DEVFN double (*get())[H1_NB] { return nullptr; } };
+template <bool LIM>
+DEVFN void lin_lock_flags(LinShared& L, double* c, int tid7, double h) {
+  if constexpr (LIM) { if (tid7 < H1_NB) c[tid7] = (tid7 >= 1 && L.u.m.Dinv[tid7] < 1e-200) ? -1.0 / h : 0.0; }
+}
+template <bool LIM>
+DEVFN void lin_lock_rows(LinShared& L, const double* c, int tid7) {
+  if constexpr (LIM) { if (tid7 >= 1 && tid7 < H1_NB && c[tid7] != 0.0) L.dT[5 + tid7][dir_lane(DIR_THETADOT, tid7)] = c[tid7]; }
+}
+template <bool PACK, bool LIM = false>
 __global__ void __launch_bounds__(256, 3) k_lin_tangent2(DevState S, ProblemDev P, int mode, const int* list, const int* count) {
   const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
   const int ks = tid >> 7, tid7 = tid & 127;                   // knot slot of this thread in the 128-thread phases
@@ -191,6 +205,8 @@ __global__ void __launch_bounds__(256, 3) k_lin_tangent2(DevState S, ProblemDev 
   const unsigned it0 = 2u * blockIdx.x;
   if (it0 >= total) return;
   __shared__ LinShared L2[2];
+  __shared__ LinLockOpt<LIM> LKO;
+  double (*lockc2)[H1_NB] = LKO.get();
 #ifdef LIN_STAMP
   long long qlast = clock64();
   const int t = (int)(it0 % N), b = (int)(it0 / N);
@@ -217,6 +233,7 @@ __global__ void __launch_bounds__(256, 3) k_lin_tangent2(DevState S, ProblemDev 
   }
   __syncthreads();
   LSTAMP(0)
+  if constexpr (LIM) lin_lock_flags<LIM>(L2[ks], lockc2[ks], tid7, P.dyn.h);
   // (one barrier for all four waves between the two halves: a __syncthreads() inside each wave's own branch happens to work --
   // s_barrier counts waves -- but matching barriers across divergent code paths is not something to lean on)
   MinvCarry Cm;
@@ -230,8 +247,8 @@ __global__ void __launch_bounds__(256, 3) k_lin_tangent2(DevState S, ProblemDev 
     if (cm == 0) lin_prologue(L2[lane >> 5]);
   }
   __syncthreads();
-  if (wv == 0) lin2_tangent_legs(L2, lane);
-  else if (wv == 1) lin2_tangent_arms(L2, lane);
+  if (wv == 0) lin2_tangent_legs<LIM>(L2, lane, lockc2);
+  else if (wv == 1) lin2_tangent_arms<LIM>(L2, lane, lockc2);
   else if (wv == 2) { if (cm < H1_NV) lin2_minv_out(L2[lane >> 5], cm, Cm); }
   __syncthreads();
   LSTAMP(2)
@@ -240,6 +257,7 @@ __global__ void __launch_bounds__(256, 3) k_lin_tangent2(DevState S, ProblemDev 
   LSTAMP(3)
   lin_apply_minv_2(L2[ks], tid7);
   __syncthreads();
+  if constexpr (LIM) { lin_lock_rows<LIM>(L2[ks], lockc2[ks], tid7); __syncthreads(); }
   LSTAMP(4)
   // each lane streams one column; for a fixed row the lanes write consecutive addresses
   if (wv < 2) {
@@ -320,7 +338,7 @@ __global__ void __launch_bounds__(128, 2) k_lin_tangent_c(DevState S, ProblemDev
 // their machine code.
 template <int FRIC> struct LinSlideOpt { LinSlide z[2]; DEVFN LinSlide* get() { return z; } };
 template <> struct LinSlideOpt<0> { DEVFN LinSlide* get() { return nullptr; } };
-template <bool PACK, int FRIC = 0>
+template <bool PACK, int FRIC = 0, bool LIM = false>
 __global__ void __launch_bounds__(256, 2) k_lin_tangent2c(DevState S, ProblemDev P, int mode, const int* list, const int* count) {
   const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
   const int ks = tid >> 7, tid7 = tid & 127;
@@ -332,6 +350,8 @@ __global__ void __launch_bounds__(256, 2) k_lin_tangent2c(DevState S, ProblemDev
   __shared__ LinContact C2[2];
   __shared__ LinSlideOpt<FRIC> ZO;
   LinSlide* Z2 = ZO.get();
+  __shared__ LinLockOpt<LIM> LKO;
+  double (*lockc2)[H1_NB] = LKO.get();
 #ifdef LIN_STAMP
   long long qlast = clock64();
   const int t = (int)(it0 % N), b = (int)(it0 / N);
@@ -358,6 +378,7 @@ __global__ void __launch_bounds__(256, 2) k_lin_tangent2c(DevState S, ProblemDev
   }
   __syncthreads();
   LSTAMP(0)
+  if constexpr (LIM) lin_lock_flags<LIM>(L2[ks], lockc2[ks], tid7, P.dyn.h);
   if (wv == 2) { const int c = lane & 31; if (c < H1_NV) lin_minv_lane_c(L2[lane >> 5], C2[lane >> 5], c); }          // Minv columns of both knots
   else if (wv == 3) { const int c = lane & 31; if (c < 12) lin_minv_lane_c(L2[lane >> 5], C2[lane >> 5], H1_NV + c); }   // unit-wrench columns (G, C) of both
   else if (wv == 0 && (lane & 31) < 2) lin_contact_rhs(L2[lane >> 5], C2[lane >> 5], P.dyn.g, lane & 31, FRIC ? Z2 + (lane >> 5) : nullptr);
@@ -391,8 +412,8 @@ __global__ void __launch_bounds__(256, 2) k_lin_tangent2c(DevState S, ProblemDev
     else if (wv == 3 && (lane & 31) == 0 && !sticking) lin_prologue(L2[lane >> 5]);
     __syncthreads();
     LSTAMP(3)
-    if (wv == 0) lin2_tangent_legs_c(L2, C2, lane, Z2);
-    else if (wv == 1) lin2_tangent_arms(L2, lane);
+    if (wv == 0) lin2_tangent_legs_c<LIM>(L2, C2, lane, Z2, lockc2);
+    else if (wv == 1) lin2_tangent_arms<LIM>(L2, lane, lockc2);
     else if (wv == 2) lin2_leg_vlin_dR(L2, C2, lane);
     __syncthreads();
     if (wv < 2) lin2_tangent_pelvis(L2[wv], lane);
@@ -410,8 +431,8 @@ __global__ void __launch_bounds__(256, 2) k_lin_tangent2c(DevState S, ProblemDev
     else if (wv == 3 && (lane & 31) == 0) lin_prologue(L2[lane >> 5]);
     __syncthreads();
     LSTAMP(3)
-    if (wv == 0) lin2_tangent_legs_c(L2, C2, lane, Z2);
-    else if (wv == 1) lin2_tangent_arms(L2, lane);
+    if (wv == 0) lin2_tangent_legs_c<LIM>(L2, C2, lane, Z2, lockc2);
+    else if (wv == 1) lin2_tangent_arms<LIM>(L2, lane, lockc2);
     else if (wv == 2) lin2_leg_vlin_dR(L2, C2, lane);
     __syncthreads();
     if (wv < 2) lin2_tangent_pelvis(L2[wv], lane);
@@ -424,6 +445,7 @@ __global__ void __launch_bounds__(256, 2) k_lin_tangent2c(DevState S, ProblemDev
   LSTAMP(5)
   lin_apply_minv_2c(L2[ks], C2[ks], tid7);
   __syncthreads();
+  if constexpr (LIM) { lin_lock_rows<LIM>(L2[ks], lockc2[ks], tid7); __syncthreads(); }
   LSTAMP(6)
   if (wv < 2) {
     if (lane < H1_NX && valid[wv]) lin2_store_A<PACK>(L2[wv], lane, S.A + knot[wv] * H1_NX * H1_NX, [&](auto&& out) { lin_column(L2[wv], 0, lane, out); });
@@ -1117,8 +1139,10 @@ void launch_step(int count, const double* x, const double* u, const DynParams& d
 static void launch_lin_tangent_free(const DevState& S, const ProblemDev& P, int mode, hipStream_t st, const WorkList& w, int pack) {
   if (g_var.lin_one_knot) { LEGACY_LAUNCH(hipLaunchKernelGGL(k_lin_tangent, dim3(S.N, S.B), dim3(128), 0, st, S, P, mode, w.list, w.count)); if (pack) launch_pack_ab(S, st, mode, w.list, w.count); return; }
   const long items = (long)S.B * S.N;
-  if (pack) hipLaunchKernelGGL(k_lin_tangent2<true>, dim3((unsigned)((items + 1) / 2)), dim3(256), 0, st, S, P, mode, w.list, w.count);
-  else hipLaunchKernelGGL(k_lin_tangent2<false>, dim3((unsigned)((items + 1) / 2)), dim3(256), 0, st, S, P, mode, w.list, w.count);
+  const dim3 grid2((unsigned)((items + 1) / 2));
+  if (P.dyn.limits) { if (pack) hipLaunchKernelGGL((k_lin_tangent2<true, true>), grid2, dim3(256), 0, st, S, P, mode, w.list, w.count); else hipLaunchKernelGGL((k_lin_tangent2<false, true>), grid2, dim3(256), 0, st, S, P, mode, w.list, w.count); }
+  else if (pack) hipLaunchKernelGGL((k_lin_tangent2<true, false>), grid2, dim3(256), 0, st, S, P, mode, w.list, w.count);
+  else hipLaunchKernelGGL((k_lin_tangent2<false, false>), grid2, dim3(256), 0, st, S, P, mode, w.list, w.count);
 }
 void launch_linearize(const DevState& S, const ProblemDev& P, int mode, int jac_mode, double eps, hipStream_t st, int phases, int iter, int pack, const WorkList* wl) {
   const WorkList w = wl ? *wl : work_list(S, mode, iter);
@@ -1128,10 +1152,16 @@ void launch_linearize(const DevState& S, const ProblemDev& P, int mode, int jac_
     if ((phases & 2) && P.dyn.contact) {
       const dim3 grid2((unsigned)(((long)S.B * S.N + 1) / 2));
       if (g_var.lin_one_knot) { LEGACY_LAUNCH(hipLaunchKernelGGL(k_lin_tangent_c, dim3(S.N, S.B), dim3(128), 0, st, S, P, mode, w.list, w.count)); if (pack) launch_pack_ab(S, st, mode, w.list, w.count); }
-      else if (P.dyn.contact == 3) { if (pack) hipLaunchKernelGGL((k_lin_tangent2c<true, 1>), grid2, dim3(256), 0, st, S, P, mode, w.list, w.count); else hipLaunchKernelGGL((k_lin_tangent2c<false, 1>), grid2, dim3(256), 0, st, S, P, mode, w.list, w.count); }
-      else if (P.dyn.contact == 4) { if (pack) hipLaunchKernelGGL((k_lin_tangent2c<true, 2>), grid2, dim3(256), 0, st, S, P, mode, w.list, w.count); else hipLaunchKernelGGL((k_lin_tangent2c<false, 2>), grid2, dim3(256), 0, st, S, P, mode, w.list, w.count); }
-      else if (pack) hipLaunchKernelGGL((k_lin_tangent2c<true, 0>), grid2, dim3(256), 0, st, S, P, mode, w.list, w.count);
-      else hipLaunchKernelGGL((k_lin_tangent2c<false, 0>), grid2, dim3(256), 0, st, S, P, mode, w.list, w.count);
+      else {
+        // (template values: operand layout, Coulomb-limit branch of the contact mode, joint-limit rows)
+#define LAUNCH_T2C(PK, FR, LM) hipLaunchKernelGGL((k_lin_tangent2c<PK, FR, LM>), grid2, dim3(256), 0, st, S, P, mode, w.list, w.count)
+#define LAUNCH_T2C_L(PK, FR) do { if (P.dyn.limits) LAUNCH_T2C(PK, FR, true); else LAUNCH_T2C(PK, FR, false); } while (0)
+#define LAUNCH_T2C_F(PK) do { if (P.dyn.contact == 3) LAUNCH_T2C_L(PK, 1); else if (P.dyn.contact == 4) LAUNCH_T2C_L(PK, 2); else LAUNCH_T2C_L(PK, 0); } while (0)
+        if (pack) LAUNCH_T2C_F(true); else LAUNCH_T2C_F(false);
+#undef LAUNCH_T2C_F
+#undef LAUNCH_T2C_L
+#undef LAUNCH_T2C
+      }
     }
     else if (phases & 2) launch_lin_tangent_free(S, P, mode, st, w, pack);
   } else if (jac_mode == 0 && !P.dyn.contact) {               // ILQR_DYN=s: the analytic kernels are constraint-free only

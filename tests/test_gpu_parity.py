@@ -560,7 +560,7 @@ def test_joint_limit_rows_step_and_solve_match_golden_and_oracle():
     NumPy KKT system with explicit rows (tests/golden/joint_limit_golden.npz), the oracle from its own hybrid recursion.  (i) the step,
     1e-9, with and without unilateral stance, none / one / several hinges stopped; switched off it IS the unlimited step; (ii) a solve
     with the reference's forward-difference Jacobians from a state with a knee and an elbow past their ranges, against the oracle;
-    (iii) the analytic Jacobians refuse loudly while the rows are on."""
+    (iii) the same solve with analytic Jacobians; (iv) the analytic Jacobians against the oracle's forward-mode AD."""
     g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "joint_limit_golden.npz"))
     n = len(g["x"])
     prob, x0, ui = make(2, seed=31, gravity=list(g["gravity"]), walking=True)
@@ -611,12 +611,49 @@ def test_joint_limit_rows_step_and_solve_match_golden_and_oracle():
             o2.initialize(x0[b], ui[b]); _, c2 = o2.solve(x0[b])
             differs += int(abs(c2 - c) > 1e-6 * abs(c))
         assert differs >= 2                              # the rows mattered
-        # (iii)
-        s.set_options(jacobian_mode=0, early_exit=False)
-        s.initialize(x0, ui)
-        with pytest.raises(RuntimeError, match="joint-limit rows"):
-            s.solve(x0)
+        # (iii) the same solve with the analytic Jacobians (operand-layout Riccati kernel: the position rows of a stopped hinge still are
+        # e + h * its velocity row), against the oracle with AD Jacobians
+        s.set_options(jacobian_mode=0, early_exit=False); s.set_max_iterations(3)
+        s.set_regularization(1e-6)        # (lambda is a member that outlives a solve, ilqr.cpp:16,620,646: the fresh oracles below start from 1e-6)
+        s.initialize(x0, ui); cost = s.solve(x0)
+        tc, ta, tl = s.trace()
+        assert s.adopt_mismatches() == 0
+        for b in range(Bs):
+            ob = oracle_for(prob, jac_mode=0, early_exit=0, max_iter=3); ob.set_contact_mode(cm); ob.set_joint_limits(True)
+            ob.initialize(x0[b], ui[b]); ok, c = ob.solve(x0[b])
+            nn, oc, oa, ol_ = ob.trace()
+            assert nn == 3 and np.allclose(tc[b], oc, rtol=1e-5) and np.array_equal(ta[b], oa), (cm, tc[b], oc, ta[b], oa)
+            assert abs(cost[b] - c) <= 1e-5 * abs(c) and rel(s.gains_K()[b], ob.get("K")) < 1e-5 and rel(s.xbar()[b], ob.get("xbar")) < 1e-5
         s.close()
+    # (iv) analytic Jacobians on the committed states against the oracle's forward-mode AD through the same rows: a stopped hinge is an
+    # acceleration-prescribed joint of the dumped recursion, d qacc_i = -1 / h rides the direction of its own rate
+    N = 25
+    checked = 0
+    for cm in (0, 2):
+        for stance in ((1, 1), (1, 0)):
+            ids = [i for i in range(n) if int(g["contact"][i]) == cm and tuple(int(v) for v in g["stance"][i]) == stance]
+            if not ids:
+                continue
+            prob, x0, ui = make(len(ids), seed=28, gravity=list(g["gravity"]), walking=True)
+            prob["stance"] = np.ones_like(prob["stance"]) * np.array(stance, dtype=prob["stance"].dtype)
+            s = _solver(len(ids)); s.set_problem(prob); s.set_contact_mode(cm, float(g["soft"])); s.set_joint_limits(True); s.set_options(jacobian_mode=0)
+            s.initialize(x0, ui)
+            X = np.repeat(g["x"][ids][:, None, :], N + 1, axis=1); U = np.repeat(g["u"][ids][:, None, :], N, axis=1)
+            s.set_trajectory(X, U); s.stage_linearize()
+            A, Bm = s.linearization()
+            for k, i in enumerate(ids):
+                o = oracle_for(prob, jac_mode=0); o.set_contact_mode(cm, float(g["soft"])); o.set_joint_limits(True)
+                o.set_trajectory(X[k], U[k]); o.linearize()
+                Ao, Bo = o.get("A")[0], o.get("B")[0]
+                assert np.abs(A[k][0] - Ao).max() < 1e-8 * max(1.0, np.abs(Ao).max()), (cm, i, np.abs(A[k][0] - Ao).max())
+                assert np.abs(Bm[k][0] - Bo).max() < 1e-8 * max(1.0, np.abs(Bo).max())
+                for j in np.flatnonzero(g["lock"][i]):
+                    assert np.abs(A[k][0][32 + j]).max() < 1e-12 and np.abs(Bm[k][0][32 + j]).max() < 1e-12     # v_j+ = 0 whatever moves
+                    e = np.zeros(51); e[7 + j] = 1.0
+                    assert np.abs(A[k][0][7 + j] - e).max() < 1e-12                                                # q_j+ = q_j
+                checked += 1
+            s.close()
+    assert checked == n
 
 
 def test_forward_difference_jacobians_two_lane_vs_scalar_kernels():
