@@ -820,7 +820,7 @@ def test_product_library_holds_the_default_kernel_family_only():
             s = sv.BatchedILQR(2, lib_path=sv.LEGACY_LIB_PATH); s.close()      # the test library takes it
     with env(ILQR_BACKWARD="wave-generic"):
         s = sv.BatchedILQR(2); s.close()                                       # (the generic one-wave kernel is product code: forward-difference Jacobians run on it)
-    assert os.path.getsize(sv.LIB_PATH) < 0.7 * os.path.getsize(sv.LEGACY_LIB_PATH)
+    assert os.path.getsize(sv.LIB_PATH) < 0.8 * os.path.getsize(sv.LEGACY_LIB_PATH)      # (both carry the sliding-foot and joint-limit instantiations of round 5)
 
 
 def _demo_and_fake_rccl():
