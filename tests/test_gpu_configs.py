@@ -376,6 +376,46 @@ def test_speculative_lambda_retry_is_the_sequential_retry_bit_for_bit(mode):
         assert np.allclose(tl[b, :n], olam[:n], rtol=1e-12) and rel(out["1"][5][b], o.get("K")) < 1e-5
 
 
+@pytest.mark.parametrize("early_exit", [False, True])
+def test_joint_limit_rows_under_every_launch_order(early_exit):
+    """The joint-limit rows (ilqr_hip_set_joint_limits) run in kernels of their own (rollout, line search, dump, tangent):
+    with hinges past their ranges, unilateral stance and analytic Jacobians, every launch order of the solve -- speculative lambda retry,
+    sequential retry with and without the early continuation -- gives the same bits, the nominal re-rollout reproduces the accepted
+    candidates, and the solve is the oracle's; the plant step of the closed loop (ilqr_hip_step) carries the rows as well."""
+    B = 12
+    prob, x0, ui = standing(B, seed=57, gravity=[0.0, 0.0, -9.81])
+    x0 = x0.copy()
+    x0[:, 7 + 3] = 2.08; x0[:, 32 + 3] = 1.2                     # left knee past its range, opening
+    x0[B // 2:, 7 + 14] = 4.47; x0[B // 2:, 32 + 14] = 0.8       # left elbow past its range, opening
+    out = {}
+    for spec in ("1", "0", "0-nosplit"):
+        with env(ILQR_SPEC=spec[0], ILQR_SPLIT="0" if spec == "0-nosplit" else "1"):
+            s = _solver(B); s.set_problem(prob); s.set_contact_mode(2); s.set_joint_limits(True)
+            s.set_options(early_exit=early_exit); s.set_max_iterations(6)
+            s.initialize(x0, ui); cost = s.solve(x0)
+            tc, ta, tl = s.trace()
+            out[spec] = (cost, tc, ta, tl, s.iterations(), s.gains_K(), s.gains_kff(), s.xbar(), s.ubar(), s.lambdas(), s.adopt_mismatches())
+            if spec == "1":
+                x1 = s.step(x0, s.ubar()[:, 0])                   # the plant of the closed loop carries the rows too
+                warm = (s.xbar().copy(), s.ubar().copy(), x1)
+            s.close()
+    for v in out:
+        assert out[v][10] == 0
+        for k in range(10):
+            assert np.array_equal(out[v][k], out["0"][k], equal_nan=True), (v, k)
+    stopped = 0
+    for b in (0, B - 1):
+        o = ol.Oracle(prob["N"], prob["dt"]); o.set_problem(prob); o.set_options(max_iter=6, early_exit=int(early_exit)); o.set_contact_mode(2); o.set_joint_limits(True)
+        o.initialize(x0[b], ui[b]); ok, c = o.solve(x0[b])
+        n, oc, oa, olam = o.trace()
+        it = out["1"][4]
+        assert n == it[b] and np.allclose(out["1"][1][b, : n + 1], oc[: n + 1], rtol=1e-5) and np.array_equal(out["1"][2][b, :n], oa[:n])
+        assert rel(out["1"][5][b], o.get("K")) < 1e-5 and rel(out["1"][7][b], o.get("xbar")) < 1e-6
+        assert rel(warm[2][b], o.step_stance(x0[b], o.get("ubar")[0], [1, 1])) < 1e-9
+        stopped += int(abs(warm[2][b][32 + 3]) < 1e-12)
+    assert stopped >= 1                                            # the plant stopped the knee on its first step
+
+
 def test_forward_difference_jacobians_never_take_the_early_continuation():
     """the forward-difference launchers select rollouts by S.active, not by a group's work list, and k_fd_finish
     rewrites S.A / S.Bm in place -- a second group's pass would rewrite the Jacobians the retry's backward pass is reading.  The early
