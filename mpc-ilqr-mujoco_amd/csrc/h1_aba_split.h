@@ -817,25 +817,33 @@ DEVFN void stance_correct(bool side, const double* R0, const double* vb, const H
     double dp[6] = {0, 0, 0, 0, 0, 0}; dp[c] = -1.0;
     LegResp::in<4>(side, T.sn, T.cs, L, dp, du[c], p0[c]);
   }
-  // rows of C that belong to the own foot: columns 0..5 = left foot's wrench components, 6..11 = right foot's
-  double Crow[6][12];
+  // rows of C that belong to the own foot.  Own columns (wrench c on the own foot): the pelvis' response and the outward sweep with the
+  // joint-force increments.  The partner's columns reach this foot through the pelvis alone, a_f = T a0 with T the leg's acceleration
+  // transmission -- and the inward sweeps above have already computed it: force transmission is its transpose, p0[c] = -T^T e_c, so
+  // a_f[r] = -sum_k p0[r][k] a0[k] with the partner's pelvis response a0: a 6 x 6 product instead of an outward sweep per column.
+  double Cown[6][6], Ccross[6][6];
 #pragma unroll
-  for (int j = 0; j < 12; ++j) {
-    const bool own = (j >= 6) == side;              // column j is a wrench on this lane's own foot
-    const int c = j % 6;
+  for (int c = 0; c < 6; ++c) {
     double pj[6];
 #pragma unroll
-    for (int k = 0; k < 6; ++k) { const double mine = p0[c][k], theirs = xch(mine); pj[k] = -(own ? mine : theirs); }
-    double a0j[6]; ldl6_solve(F, pj, a0j);
-    double dz[5];
+    for (int k = 0; k < 6; ++k) pj[k] = -p0[c][k];
+    double a0m[6]; ldl6_solve(F, pj, a0m);
+    double afo[6];
+    LegResp::out<0>(side, T.sn, T.cs, L, a0m, du[c], nullptr, afo);
+    double a0t[6];
 #pragma unroll
-    for (int k = 0; k < 5; ++k) dz[k] = own ? du[c][k] : 0.0;
-    double afj[6];
-    LegResp::out<0>(side, T.sn, T.cs, L, a0j, dz, nullptr, afj);
+    for (int k = 0; k < 6; ++k) a0t[k] = xch(a0m[k]);
 #pragma unroll
-    for (int r = 0; r < 6; ++r) Crow[r][j] = afj[r];
+    for (int r = 0; r < 6; ++r) {
+      Cown[r][c] = afo[r];
+      double t = 0.0;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) t -= p0[r][k] * a0t[k];
+      Ccross[r][c] = t;
+    }
   }
   // both lanes assemble the same 12 x 12 system: rows 0..5 from the left lane, 6..11 from the right lane
+  // (columns 0..5 = left foot's wrench components: the left lane's own, the right lane's cross block; 6..11 the other way round)
   double C[78], b[12];
 #pragma unroll
   for (int r = 0; r < 6; ++r) {
@@ -843,7 +851,7 @@ DEVFN void stance_correct(bool side, const double* R0, const double* vb, const H
     b[r] = side ? bp : bo; b[6 + r] = side ? bo : bp;
 #pragma unroll
     for (int j = 0; j < 12; ++j) {
-      const double mine = Crow[r][j], theirs = xch(mine);
+      const double mine = (j < 6) ? (side ? Ccross[r][j % 6] : Cown[r][j % 6]) : (side ? Cown[r][j % 6] : Ccross[r][j % 6]), theirs = xch(mine);
       const double left = side ? theirs : mine, right = side ? mine : theirs;
       if (j <= r) C[pidx(r, j)] = left;             // lower triangle of the left foot's rows
       if (j <= 6 + r) C[pidx(6 + r, j)] = right;    // lower triangle of the right foot's rows
