@@ -416,6 +416,34 @@ def test_joint_limit_rows_under_every_launch_order(early_exit):
     assert stopped >= 1                                            # the plant stopped the knee on its first step
 
 
+@pytest.mark.parametrize("cm", [0, 4])
+def test_joint_limit_rows_are_batch_invariant_across_the_wide_kernels(cm):
+    """A batch above 1024 rollouts takes the four-rollouts-per-wave line search (k_line_search_s<3 | 4, 4>), a small one the
+    one-rollout-per-wave kernels: with the joint-limit rows on (constraint-free plant, and contact mode 4 with a low friction
+    coefficient) the same rollouts give the same bits in either, wherever they sit in the batch."""
+    Bs, B = 6, 1030
+    gravity = [0.0, 0.0, -9.81] if cm else None
+    prob, x0, ui = standing(Bs, seed=61, gravity=gravity)
+    x0 = x0.copy()
+    x0[:, 7 + 3] = 2.08; x0[:, 32 + 3] = 1.2
+    x0[Bs // 2:, 7 + 14] = 4.47; x0[Bs // 2:, 32 + 14] = 0.8
+    reps = (B + Bs - 1) // Bs
+    xb, ub = np.tile(x0, (reps, 1))[:B], np.tile(ui, (reps, 1, 1))[:B]
+    res = []
+    for xx, uu in ((x0, ui), (xb, ub)):
+        s = _solver(len(xx)); s.set_problem(prob); s.set_contact_mode(cm); s.set_friction(0.3); s.set_joint_limits(True)
+        s.set_options(early_exit=False); s.set_max_iterations(4)
+        s.initialize(xx, uu); cost = s.solve(xx)
+        res.append((cost, s.trace()[0], s.gains_K(), s.xbar(), s.adopt_mismatches())); s.close()
+    assert res[0][4] == 0 and res[1][4] == 0
+    for k in range(4):
+        assert np.array_equal(res[0][k], res[1][k][:Bs], equal_nan=True), k
+        assert np.array_equal(res[0][k], res[1][k][B - B % Bs - Bs: B - B % Bs] if B % Bs else res[1][k][-Bs:], equal_nan=True), k
+    o = ol.Oracle(prob["N"], prob["dt"]); o.set_problem(prob); o.set_options(max_iter=4, early_exit=0); o.set_contact_mode(cm); o.set_friction(0.3); o.set_joint_limits(True)
+    o.initialize(x0[Bs - 1], ui[Bs - 1]); ok, c = o.solve(x0[Bs - 1])
+    assert abs(res[0][0][Bs - 1] - c) <= 1e-5 * abs(c)
+
+
 def test_forward_difference_jacobians_never_take_the_early_continuation():
     """the forward-difference launchers select rollouts by S.active, not by a group's work list, and k_fd_finish
     rewrites S.A / S.Bm in place -- a second group's pass would rewrite the Jacobians the retry's backward pass is reading.  The early
