@@ -150,8 +150,9 @@ DEVFN void load_half_u(bool side, const double* u, h1s::HalfU& o) {
 }
 // RPW = rollouts per wave: 4 (the 64 lanes are four rollouts' 16) or 1 -- for batches of at most 1024 rollouts, where four per wave
 // would leave SIMDs empty: the wave's lanes 16..63 then mirror lanes 0..15 (same rollout, same candidates, no stores), a step
-// fetches one rollout's K_t and runs one feedback product instead of four, and every rollout has a SIMD to itself.  The per-rollout
-// arithmetic is the same instruction sequence in both: results are bit-identical (batch invariance, GPU tests).
+// fetches one rollout's K_t and the four blocks of the feedback product take four row groups of that rollout instead of four rollouts,
+// and every rollout has a SIMD to itself.  Every output accumulates the same thirteen k-steps in the same order in both: results are
+// bit-identical (batch invariance, GPU tests).
 template <int CONTACT, int RPW>
 __global__ void __launch_bounds__(64) k_line_search_s(DevState S, ProblemDev P, int mode, const int* list, const int* count) {
   extern __shared__ double lds[];
@@ -179,10 +180,6 @@ __global__ void __launch_bounds__(64) k_line_search_s(DevState S, ProblemDev P, 
   const double alpha = ALPHAS_S[ai];
   h1s::HalfX h; h1s::load_half(side, S.x0 + (size_t)b * n, h);
   if (live) h1s::store_half(side, h, S.xcand + ((size_t)b * 8 + ai) * (N + 1) * n);
-  // rollouts of the wave's four 16-lane groups (for the K_t operands every lane fetches for every group)
-  int bw[RPW];
-#pragma unroll
-  for (int r = 0; r < RPW; ++r) bw[r] = __shfl(b, 16 * r);
 #ifdef LS_STAMP
   long long ph[8] = {0}; long long tl = clock64();
 #endif
@@ -205,31 +202,34 @@ __global__ void __launch_bounds__(64) k_line_search_s(DevState S, ProblemDev P, 
     // rollouts (MFMA feedback below; left to itself the scheduler sinks these 52 loads down to their first use, behind the state
     // exchange and its barrier -- a second exposed HBM round trip per step), then this lane's half of the nominal state (for
     // x - xbar), nominal control and feedforward.  The scheduling fence keeps the order of issue.
-    typedef double v4d_s __attribute__((ext_vector_type(4)));
     typedef double v2d_s __attribute__((ext_vector_type(2), aligned(8)));      // rows of K_t have an odd pitch (51 doubles): the pairs are 8-byte aligned only
-    const int lk = lane >> 4, lr = lane & 15;
-    const int rowA1 = (16 + lr) < m ? (16 + lr) : (m - 1);
-    // K_t operands of the MFMA feedback, fetched sector by sector.  The 51 contraction indices can be dealt to the (k-step,
-    // lk) slots in any order as long as both operands agree: instruction j = 0..5 takes 16 bytes per lane at
-    // K_t[row][8 j + 2 lk], i.e. indices 8 j + 2 lk + h (h = 0, 1) for the k-steps 2 j + h, so the four lk lanes of a row
-    // fetch ONE contiguous 64-byte run (one or two sectors, the rows not being sector-aligned) and every byte of K_t is requested exactly once (with the plain mapping 4 sk + lk
-    // a lane fetched 8 bytes and every sector was requested by two to four instructions, out of an L1 the four waves of a
-    // CU thrash: the line search waited on its own re-fetches); k-step 12 takes the last three columns 48 + lk as before.
-    const unsigned offA0 = (unsigned)(lr * n + 2 * lk), offA1 = (unsigned)(rowA1 * n + 2 * lk);
-    const unsigned offT0 = (unsigned)(lr * n + 48 + lk), offT1 = (unsigned)(rowA1 * n + 48 + lk);
-    v2d_s ka[3][2][6];
-    double kt[3][2];
-    auto fetchK = [&](int slot, int r) {
-      const double* Kt = S.K + ((size_t)bw[r] * N + t) * m * n;
+    // ---- U_r = K_t,r dX_r on v_mfma_f64_4x4x4_4b_f64: FOUR independent 4 x 4 x 4 products per instruction (16 cycles).  Lane layout
+    // (tools/probes/mfma_f64_4x4x4_layout.hip): block = (lane >> 2) & 3;  A[i][k] at i = lane & 3, k = lane >> 4;  B[k][n] at k = lane >> 4,
+    // n = lane & 3;  D[i][n] at i = lane >> 4, n = lane & 3.
+    //   RPW = 4: block = rollout of the wave; per (row group g = 0..4, candidate half c, k-step s): A = K_t[4 g + i][kappa(s, k)],
+    //            B = dx_{kappa(s, k)} of candidate 4 c + n, D = U[4 g + i][4 c + n]: 5 x 2 x 13 = 130 products of which 93 % are real
+    //            work -- the 16 x 16 x 4 form ran 104 of four times the size, 29 % real (the 8 candidates and 19 rows fill a quarter of
+    //            its 16 x 32 tile).
+    //   RPW = 1: one rollout; block = row group (0..3, then 4 on block 0): 2 x 2 x 13 = 52 products.
+    // kappa: the dealing of the 51 contraction indices to the slots -- k-steps 2 j + h (j = 0..5, h = 0, 1) take 8 j + 2 k + h, so a
+    // lane's two operands of a step pair come as ONE 16-byte load and the four k lanes of a row fetch a contiguous 64-byte run; k-step
+    // 12 takes 48 + k, and column 51 does not exist: BOTH operands of that slot are zeroed (the A operand fetched there is the first
+    // entry of the next row of K -- of the NEXT rollout's gains for the last row of the last knot --, and 0 * NaN = NaN: a diverged
+    // neighbour would otherwise poison a healthy rollout, GPU test).  Every operand of the step is requested up front.
+    const int mb = (lane >> 2) & 3, mi = lane & 3, mk = lane >> 4;
+    constexpr int NG = RPW == 4 ? 5 : 2;                                     // row groups a lane works on
+    const int bk = RPW == 4 ? __shfl(bt, 16 * mb) : bt;                      // rollout of this lane's block
+    const double* Kt = S.K + ((size_t)bk * N + t) * m * n;
+    v2d_s ka[NG][6];
+    double kt[NG];
 #pragma unroll
-      for (int j = 0; j < 6; ++j) {
-        ka[slot][0][j] = *reinterpret_cast<const v2d_s*>(Kt + 8 * j + offA0);
-        ka[slot][1][j] = *reinterpret_cast<const v2d_s*>(Kt + 8 * j + offA1);
-      }
-      kt[slot][0] = Kt[offT0]; kt[slot][1] = Kt[offT1];
-    };
-    fetchK(0, 0);
-    if (RPW > 1) fetchK(1, 1);
+    for (int g = 0; g < NG; ++g) {
+      const int row = RPW == 4 ? 4 * g + mi : 4 * (mb + 4 * g) + mi;
+      const unsigned off = (unsigned)((row < m ? row : m - 1) * n);          // (rows past 18: a valid row, its product discarded)
+#pragma unroll
+      for (int j = 0; j < 6; ++j) ka[g][j] = *reinterpret_cast<const v2d_s*>(Kt + off + 8 * j + 2 * mk);
+      kt[g] = Kt[off + 48 + mk];
+    }
     h1s::HalfX xh; h1s::HalfU ubh, kfh;
     h1s::load_half(side, xbt, xh);
     load_half_u(side, ub + t * m, ubh);
@@ -260,41 +260,31 @@ __global__ void __launch_bounds__(64) k_line_search_s(DevState S, ProblemDev P, 
       lds[(H1_NQ + 6 + 11 + k) * 64 + sa + col] = h.q.qdA[k] - xh.q.qdA[k];
     }
     __syncthreads();
-    // ---- U_r = K_t,r dX_r on v_mfma_f64_16x16x4_f64, one product per rollout r of the wave (19 x 51 x 8, padded 32 x 52 x 16):
-    //   A (16 x 4 per k-step s, row tile I): lane l = K_t[16 I + (l & 15)][kappa(s, l >> 4)]  straight from HBM (rows past 18 clamped)
-    //   B (4 x 16):                          lane l = dx_{kappa(s, l >> 4)} of candidate l & 7   from the exchange rows in LDS
-    //   (kappa: the dealing of the contraction indices to the slots, see the fetch at the top of the step)
-    //   D lane l register q = U[16 I + 4 q + (l >> 4)][candidate l & 15]                       -> LDS rows 52.. -> the owning lanes
-    // 104 MFMA per step instead of ~1900 VALU instructions (a lone wave pays 8 cycles for each of those, 64 for an MFMA); the
-    // operands of rollout r + 2 are requested before the products of rollout r start.
     {
-      const int offB = 2 * lk * 64 + 2 * (lr & 7), offBt = (48 + lk) * 64 + 2 * (lr & 7);
       constexpr int UROW = 52;                        // LDS rows 52..70: the 19 feedback terms, column = the pair's
+      const int colB = (RPW == 4 ? 16 * mb : 0) + 2 * mi;                    // LDS column of candidate n of this lane's rollout (+ 8 for the second half)
+      double acc[NG][2];
 #pragma unroll
-      for (int r = 0; r < RPW; ++r) {
-        if (r + 2 < RPW) fetchK((r + 2) % 3, r + 2);
-        v4d_s d0 = {0.0, 0.0, 0.0, 0.0}, d1 = {0.0, 0.0, 0.0, 0.0};
+      for (int g = 0; g < NG; ++g) { acc[g][0] = 0.0; acc[g][1] = 0.0; }
 #pragma unroll
-        for (int j = 0; j < 6; ++j)
+      for (int s13 = 0; s13 < 13; ++s13) {
+        const int xrow = s13 < 12 ? 8 * (s13 >> 1) + 2 * mk + (s13 & 1) : 48 + mk;
+        double b0 = lds[xrow * 64 + colB], b1 = lds[xrow * 64 + colB + 8];
+        if (s13 == 12) { b0 = mk == 3 ? 0.0 : b0; b1 = mk == 3 ? 0.0 : b1; }
 #pragma unroll
-          for (int hh = 0; hh < 2; ++hh) {
-            const double bv = lds[(8 * j + hh) * 64 + 16 * r + offB];      // dx of index 8 j + 2 lk + hh
-            d0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ka[r % 3][0][j][hh], bv, d0, 0, 0, 0);
-            d1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ka[r % 3][1][j][hh], bv, d1, 0, 0, 0);
-          }
-        {
-          // k-step 12: indices 48 + lk; column 51 does not exist: BOTH operands of the phantom slot are zeroed.  The A operand
-          // fetched there is the first entry of the next row of K (row 18 of the last knot: of the NEXT rollout's gains), and
-          // 0 * NaN = NaN -- a diverged neighbour would otherwise poison u[18] of a healthy rollout (GPU test)
-          double bv = lds[16 * r + offBt], a0 = kt[r % 3][0], a1 = kt[r % 3][1];
-          bv = lk == 3 ? 0.0 : bv; a0 = lk == 3 ? 0.0 : a0; a1 = lk == 3 ? 0.0 : a1;
-          d0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, bv, d0, 0, 0, 0);
-          d1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, bv, d1, 0, 0, 0);
+        for (int g = 0; g < NG; ++g) {
+          double a = s13 < 12 ? ka[g][s13 >> 1][s13 & 1] : kt[g];
+          if (s13 == 12) a = mk == 3 ? 0.0 : a;
+          acc[g][0] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b0, acc[g][0], 0, 0, 0);
+          acc[g][1] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b1, acc[g][1], 0, 0, 0);
         }
-        if (lr < 8) {
+      }
 #pragma unroll
-          for (int q = 0; q < 4; ++q) lds[(UROW + 4 * q + lk) * 64 + 16 * r + 2 * lr] = d0[q];
-          if (lk < 3) lds[(UROW + 16 + lk) * 64 + 16 * r + 2 * lr] = d1[0];
+      for (int g = 0; g < NG; ++g) {
+        const int row = RPW == 4 ? 4 * g + mk : 4 * (mb + 4 * g) + mk;       // D: row index in the lane's upper field
+        if (row < m) {
+          lds[(UROW + row) * 64 + colB] = acc[g][0];
+          lds[(UROW + row) * 64 + colB + 8] = acc[g][1];
         }
       }
       __syncthreads();
