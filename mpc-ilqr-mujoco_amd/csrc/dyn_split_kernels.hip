@@ -486,7 +486,7 @@ __global__ void __launch_bounds__(64) k_count_iter(DevState S, int mode) {
 }
 
 // two lanes per item: plain batched step with explicit stance flags (stage API / plant of the closed loop)
-template <int CK>     // CK: the CONTACT value of step_any the constrained plant takes (1..4)
+template <int CK>     // CK: the CONTACT value of step_any (0: the constraint-free plant -- an instantiation that cannot reach the constrained step keeps its private segment small; 1..4)
 __global__ void __launch_bounds__(64) k_step_s(int count, const double* x, const double* u, DynParams dyn, double* xn, int st_l, int st_r) {
   extern __shared__ double lds[];
   const int gid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -497,7 +497,7 @@ __global__ void __launch_bounds__(64) k_step_s(int count, const double* x, const
   h1s::HalfX h; h1s::load_half(side, x + (size_t)i * H1_NX, h);
   h1s::HalfU uu; load_half_u(side, u + (size_t)i * H1_NU, uu);
   const int st[2] = {st_l, st_r};
-  if (constrained(dyn)) step_any<CK>(side, h, uu, dyn, st, L); else step_any<0>(side, h, uu, dyn, st, L);
+  step_any<CK>(side, h, uu, dyn, st, L);
   h1s::store_half(side, h, xn + (size_t)i * H1_NX);
 }
 // last knot of the warm start: xbar[N] = f(xbar[N-1], ubar[N-1])  (ilqr.cpp:72-80)
@@ -512,7 +512,7 @@ __global__ void __launch_bounds__(64) k_last_step_s(DevState S, ProblemDev P) {
   const int N = S.N;
   h1s::HalfX h; h1s::load_half(side, S.xbar + ((size_t)b * (N + 1) + N - 1) * H1_NX, h);
   h1s::HalfU uu; load_half_u(side, S.ubar + ((size_t)b * N + N - 1) * H1_NU, uu);
-  if (constrained(P.dyn)) step_any<CK>(side, h, uu, P.dyn, P.stance + b * P.stance_stride + 2 * (N - 1), L); else step_any<0>(side, h, uu, P.dyn, P.stance + b * P.stance_stride + 2 * (N - 1), L);
+  step_any<CK>(side, h, uu, P.dyn, P.stance + b * P.stance_stride + 2 * (N - 1), L);
   h1s::store_half(side, h, S.xbar + ((size_t)b * (N + 1) + N) * H1_NX);
 }
 // Reference-style forward differences (RobotUtils::linearizeDynamicsFD, robot_utils.cpp:120-160) on the two-lane step:
@@ -567,7 +567,7 @@ __global__ void __launch_bounds__(64) k_fd_steps_s(DevState S, ProblemDev P, int
   h1s::HalfX h; h1s::load_half(side, S.xbar + ((size_t)b * (S.N + 1) + t) * H1_NX, h);
   h1s::HalfU uu; load_half_u(side, S.ubar + ((size_t)b * S.N + t) * H1_NU, uu);
   perturb_half(side, h, uu, col, eps);
-  if (constrained(P.dyn)) step_any<CK>(side, h, uu, P.dyn, P.stance + b * P.stance_stride + 2 * t, L); else step_any<0>(side, h, uu, P.dyn, P.stance + b * P.stance_stride + 2 * t, L);
+  step_any<CK>(side, h, uu, P.dyn, P.stance + b * P.stance_stride + 2 * t, L);
   if (!act) return;
   if (col < H1_NX) store_half_col(side, h, S.A + (size_t)item * H1_NX * H1_NX, H1_NX, col);
   else if (col < H1_NX + H1_NU) store_half_col(side, h, S.Bm + (size_t)item * H1_NX * H1_NU, H1_NU, col - H1_NX);
@@ -607,14 +607,17 @@ int dyn_split_kernels_set_attr() {
   rc |= hipFuncSetAttribute((const void*)k_rollout_s<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess;
   rc |= hipFuncSetAttribute((const void*)k_rollout_s<3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess;
   rc |= hipFuncSetAttribute((const void*)k_rollout_s<4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess;
+  rc |= hipFuncSetAttribute((const void*)k_step_s<0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess;
   rc |= hipFuncSetAttribute((const void*)k_step_s<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess;
   rc |= hipFuncSetAttribute((const void*)k_step_s<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess;
   rc |= hipFuncSetAttribute((const void*)k_step_s<3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess;
   rc |= hipFuncSetAttribute((const void*)k_step_s<4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess;
+  rc |= hipFuncSetAttribute((const void*)k_last_step_s<0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess;
   rc |= hipFuncSetAttribute((const void*)k_last_step_s<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess;
   rc |= hipFuncSetAttribute((const void*)k_last_step_s<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess;
   rc |= hipFuncSetAttribute((const void*)k_last_step_s<3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess;
   rc |= hipFuncSetAttribute((const void*)k_last_step_s<4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess;
+  rc |= hipFuncSetAttribute((const void*)k_fd_steps_s<0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess;
   rc |= hipFuncSetAttribute((const void*)k_fd_steps_s<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess;
   rc |= hipFuncSetAttribute((const void*)k_fd_steps_s<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess;
   rc |= hipFuncSetAttribute((const void*)k_fd_steps_s<3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess;
@@ -655,14 +658,15 @@ void launch_lin_primal_s(const DevState& S, const ProblemDev& P, int mode, hipSt
   if (P.dyn.limits) hipLaunchKernelGGL(k_lin_primal_s<true>, dim3(waves), dim3(64), DYN_LDS_BYTES_S + (direct ? 0 : DUMP_STG_BYTES), st, S, P, mode, list, count, direct);
   else hipLaunchKernelGGL(k_lin_primal_s<false>, dim3(waves), dim3(64), DYN_LDS_BYTES_S + (direct ? 0 : DUMP_STG_BYTES), st, S, P, mode, list, count, direct);
 }
-static int step_kind(const DynParams& d) { return (d.contact == 4 ? 2 : 1) + (d.limits ? 2 : 0); }      // CK of the kernels below
+static int step_kind(const DynParams& d) { return constrained(d) ? (d.contact == 4 ? 2 : 1) + (d.limits ? 2 : 0) : 0; }      // CK of the kernels below
 void launch_step_s(int count, const double* x, const double* u, const DynParams& dyn, double* xn, hipStream_t st, int stance_l, int stance_r) {
   const dim3 grid(cdiv_s((long)count * 2, 64));
   switch (step_kind(dyn)) {
     case 4: hipLaunchKernelGGL(k_step_s<4>, grid, dim3(64), DYN_LDS_BYTES_S, st, count, x, u, dyn, xn, stance_l, stance_r); break;
     case 3: hipLaunchKernelGGL(k_step_s<3>, grid, dim3(64), DYN_LDS_BYTES_S, st, count, x, u, dyn, xn, stance_l, stance_r); break;
     case 2: hipLaunchKernelGGL(k_step_s<2>, grid, dim3(64), DYN_LDS_BYTES_S, st, count, x, u, dyn, xn, stance_l, stance_r); break;
-    default: hipLaunchKernelGGL(k_step_s<1>, grid, dim3(64), DYN_LDS_BYTES_S, st, count, x, u, dyn, xn, stance_l, stance_r);
+    case 1: hipLaunchKernelGGL(k_step_s<1>, grid, dim3(64), DYN_LDS_BYTES_S, st, count, x, u, dyn, xn, stance_l, stance_r); break;
+    default: hipLaunchKernelGGL(k_step_s<0>, grid, dim3(64), DYN_LDS_BYTES_S, st, count, x, u, dyn, xn, stance_l, stance_r);
   }
 }
 void launch_last_step_s(const DevState& S, const ProblemDev& P, hipStream_t st) {
@@ -671,7 +675,8 @@ void launch_last_step_s(const DevState& S, const ProblemDev& P, hipStream_t st) 
     case 4: hipLaunchKernelGGL(k_last_step_s<4>, grid, dim3(64), DYN_LDS_BYTES_S, st, S, P); break;
     case 3: hipLaunchKernelGGL(k_last_step_s<3>, grid, dim3(64), DYN_LDS_BYTES_S, st, S, P); break;
     case 2: hipLaunchKernelGGL(k_last_step_s<2>, grid, dim3(64), DYN_LDS_BYTES_S, st, S, P); break;
-    default: hipLaunchKernelGGL(k_last_step_s<1>, grid, dim3(64), DYN_LDS_BYTES_S, st, S, P);
+    case 1: hipLaunchKernelGGL(k_last_step_s<1>, grid, dim3(64), DYN_LDS_BYTES_S, st, S, P); break;
+    default: hipLaunchKernelGGL(k_last_step_s<0>, grid, dim3(64), DYN_LDS_BYTES_S, st, S, P);
   }
 }
 void launch_linearize_fd_s(const DevState& S, const ProblemDev& P, int mode, double eps, hipStream_t st) {
@@ -681,13 +686,14 @@ void launch_linearize_fd_s(const DevState& S, const ProblemDev& P, int mode, dou
     case 4: hipLaunchKernelGGL(k_fd_steps_s<4>, grid, dim3(64), DYN_LDS_BYTES_S, st, S, P, mode, eps, dd); break;
     case 3: hipLaunchKernelGGL(k_fd_steps_s<3>, grid, dim3(64), DYN_LDS_BYTES_S, st, S, P, mode, eps, dd); break;
     case 2: hipLaunchKernelGGL(k_fd_steps_s<2>, grid, dim3(64), DYN_LDS_BYTES_S, st, S, P, mode, eps, dd); break;
-    default: hipLaunchKernelGGL(k_fd_steps_s<1>, grid, dim3(64), DYN_LDS_BYTES_S, st, S, P, mode, eps, dd);
+    case 1: hipLaunchKernelGGL(k_fd_steps_s<1>, grid, dim3(64), DYN_LDS_BYTES_S, st, S, P, mode, eps, dd); break;
+    default: hipLaunchKernelGGL(k_fd_steps_s<0>, grid, dim3(64), DYN_LDS_BYTES_S, st, S, P, mode, eps, dd);
   }
   hipLaunchKernelGGL(k_fd_finish, dim3(cdiv_s((long)S.B * S.N * H1_NX * (H1_NX + H1_NU), 256)), dim3(256), 0, st, S, mode, eps, dd);
 }
 void launch_rollout_s(const DevState& S, const ProblemDev& P, int mode, int do_roll, int count_iter, double* cost_out, hipStream_t st) {
   const dim3 grid(cdiv_s((long)S.B * 2, 64));
-  const int ck = constrained(P.dyn) ? step_kind(P.dyn) : 0;
+  const int ck = step_kind(P.dyn);
   if (do_roll && ck == 4) hipLaunchKernelGGL(k_rollout_s<4>, grid, dim3(64), DYN_LDS_BYTES_S, st, S, P, mode, count_iter);
   else if (do_roll && ck == 3) hipLaunchKernelGGL(k_rollout_s<3>, grid, dim3(64), DYN_LDS_BYTES_S, st, S, P, mode, count_iter);
   else if (do_roll && ck == 2) hipLaunchKernelGGL(k_rollout_s<2>, grid, dim3(64), DYN_LDS_BYTES_S, st, S, P, mode, count_iter);
