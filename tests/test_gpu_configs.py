@@ -444,6 +444,33 @@ def test_joint_limit_rows_are_batch_invariant_across_the_wide_kernels(cm):
     assert abs(res[0][0][Bs - 1] - c) <= 1e-5 * abs(c)
 
 
+def test_cross_check_families_refuse_what_they_do_not_carry():
+    """The joint-limit rows and the sliding-foot Jacobians exist on the two-lane / two-knot kernels only: the scalar dynamics family
+    refuses the option, the one-knot tangent kernels refuse an analytic linearisation with it (and in contact modes 3 / 4) -- loudly,
+    with the reason -- while forward differences stay available there."""
+    from mpc_ilqr_mujoco_amd import solver as sv
+    B = 2
+    prob, x0, ui = standing(B, seed=3, gravity=[0.0, 0.0, -9.81])
+    with env(ILQR_DYN="s"):
+        s = sv.BatchedILQR(B, lib_path=sv.LEGACY_LIB_PATH); s.set_problem(prob)
+        with pytest.raises(sv.ILQRError, match="joint-limit rows exist on the two-lane kernels only"):
+            s.set_joint_limits(True)
+        s.close()
+    with env(ILQR_LINT="1"):
+        s = sv.BatchedILQR(B, lib_path=sv.LEGACY_LIB_PATH); s.set_problem(prob); s.set_contact_mode(2); s.set_joint_limits(True)
+        s.set_options(jacobian_mode=0); s.initialize(x0, ui)
+        with pytest.raises(sv.ILQRError, match="joint-limit rows"):
+            s.stage_linearize()
+        s.set_joint_limits(False); s.set_contact_mode(3)
+        with pytest.raises(sv.ILQRError, match="Coulomb limit"):
+            s.stage_linearize()
+        s.set_joint_limits(True)
+        s.set_options(jacobian_mode=1, fd_eps=1e-5); s.stage_linearize()          # the reference's scheme runs
+        A, Bm = s.linearization()
+        assert np.all(np.isfinite(A)) and np.all(np.isfinite(Bm))
+        s.close()
+
+
 def test_forward_difference_jacobians_never_take_the_early_continuation():
     """the forward-difference launchers select rollouts by S.active, not by a group's work list, and k_fd_finish
     rewrites S.A / S.Bm in place -- a second group's pass would rewrite the Jacobians the retry's backward pass is reading.  The early
