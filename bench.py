@@ -533,6 +533,17 @@ def main():
         contact_line = {"value": B * iters * csteps / tc, "unit": "iterations/s", "ms_per_step": 1e3 * tc / csteps,
                         "workload": "same batch, gravity [0, 0, -9.81], both feet scheduled in stance: unilateral rigid stance constraints in rollout / line search, "
                                     "analytic Jacobians of the constrained step, %d fixed iterations" % iters}
+        # ... and with the joint-limit rows of the plant switched on as well (no hinge of this batch leaves its range: what
+        # the option costs when nothing is stopped -- its kernels are instantiations of their own and decide the set every step)
+        s.set_joint_limits(True)
+        cstep()
+        torch.cuda.synchronize(); tl0 = time.perf_counter()
+        for _ in range(csteps):
+            cstep()
+        torch.cuda.synchronize(); tlim = time.perf_counter() - tl0
+        assert np.all(s.iterations() == iters) and np.all(np.isfinite(s.cost()))
+        contact_line["with_joint_limit_rows"] = {"value": B * iters * csteps / tlim, "unit": "iterations/s", "ms_per_step": 1e3 * tlim / csteps}
+        s.set_joint_limits(False)
         s.set_contact_mode(0)
 
     # fourth number (not the headline): the same batch with the REFERENCE'S OWN Jacobian scheme, forward differences

@@ -65,28 +65,47 @@ __device__ __attribute__((noinline)) void step_stance_shared_kin(h1s::HalfX* hp,
   h1s::step_stance<true>(side, h, u, dt, grav, L, soft, 4, (side ? st_right : st_left) == 1, (side ? st_left : st_right) == 1, mu);
   *hp = h;
 }
-// the copies with joint-limit rows (DynParams::limits; h1s::step_stance<., true>): only reached when the option is on
-__device__ __attribute__((noinline)) void step_stance_shared_lim(h1s::HalfX* hp, const h1s::HalfU* up, double dt, double gx, double gy, double gz,
-                                                                 double soft, int mode, int st_left, int st_right, double mu) {
+// the step with joint-limit rows (DynParams::limits; h1_aba_split.h "The step with the rows"): only reached when the option is on.
+// lim_accelerations is the ONE copy of the constrained accelerations, mask = the hinges it treats as acceleration-prescribed.
+struct LimAcc { double qb[6]; h1s::HalfAcc qa; };
+template <bool KIN>
+__device__ __attribute__((noinline)) void lim_accelerations(const h1s::HalfX* hp, const h1s::HalfU* up, unsigned mask, double dt, double gx, double gy, double gz,
+                                                            double soft, int mode, int st_left, int st_right, double mu, LimAcc* out) {
   const int lane = threadIdx.x;
   const bool side = (lane & 1) != 0;
   const h1s::LaneLds L{dyn_lds_c, 64, lane};
   const double grav[3] = {gx, gy, gz};
-  h1s::HalfX h = *hp;
+  const h1s::HalfX h = *hp;
   const h1s::HalfU u = *up;
-  h1s::step_stance<false, true>(side, h, u, dt, grav, L, soft, mode, (side ? st_right : st_left) == 1, (side ? st_left : st_right) == 1, mu);
+  double qh[4], R0[9]; h1s::HalfTau tau, add;
+  h1s::stance_prepare(side, h, u, qh, R0, tau);
+  h1s::apply_lock_mask(mask, h.q, dt, tau, add);
+  const bool st_own = mode != 0 && (side ? st_right : st_left) == 1, st_par = mode != 0 && (side ? st_left : st_right) == 1;      // (mode 0: no stance rows)
+  LimAcc o;
+  h1s::stance_accelerations<KIN, true>(side, R0, h, tau, dt, grav, L, soft, mode, st_own, st_par, mu, o.qb, o.qa, &add);
+  *out = o;
+}
+template <bool KIN>
+DEVFN void step_lim(h1s::HalfX* hp, const h1s::HalfU* up, double dt, double gx, double gy, double gz, double soft, int mode, int st_left, int st_right, double mu) {
+  const bool side = (threadIdx.x & 1) != 0;
+  LimAcc o;
+  lim_accelerations<KIN>(hp, up, 0u, dt, gx, gy, gz, soft, mode, st_left, st_right, mu, &o);
+  h1s::HalfX h = *hp;
+  const unsigned mask = h1s::limit_lock_mask(side, h.q, o.qa, dt);
+  const bool any = mask != 0u;
+  if (h1s::xch_flag(any) || any) lim_accelerations<KIN>(hp, up, mask, dt, gx, gy, gz, soft, mode, st_left, st_right, mu, &o);      // (the pair runs the recursion together)
+  const double qn = sqrt(h.quat[0] * h.quat[0] + h.quat[1] * h.quat[1] + h.quat[2] * h.quat[2] + h.quat[3] * h.quat[3]);
+  const double qh[4] = {h.quat[0] / qn, h.quat[1] / qn, h.quat[2] / qn, h.quat[3] / qn};
+  h1s::integrate_half(h, qh, o.qb, o.qa, dt);
   *hp = h;
+}
+__device__ __attribute__((noinline)) void step_stance_shared_lim(h1s::HalfX* hp, const h1s::HalfU* up, double dt, double gx, double gy, double gz,
+                                                                 double soft, int mode, int st_left, int st_right, double mu) {
+  step_lim<false>(hp, up, dt, gx, gy, gz, soft, mode, st_left, st_right, mu);
 }
 __device__ __attribute__((noinline)) void step_stance_shared_kin_lim(h1s::HalfX* hp, const h1s::HalfU* up, double dt, double gx, double gy, double gz,
                                                                      double soft, int st_left, int st_right, double mu) {
-  const int lane = threadIdx.x;
-  const bool side = (lane & 1) != 0;
-  const h1s::LaneLds L{dyn_lds_c, 64, lane};
-  const double grav[3] = {gx, gy, gz};
-  h1s::HalfX h = *hp;
-  const h1s::HalfU u = *up;
-  h1s::step_stance<true, true>(side, h, u, dt, grav, L, soft, 4, (side ? st_right : st_left) == 1, (side ? st_left : st_right) == 1, mu);
-  *hp = h;
+  step_lim<true>(hp, up, dt, gx, gy, gz, soft, 4, st_left, st_right, mu);
 }
 // one step of either kind; `st` = stance flags (left, right) of the knot being stepped
 // (compile-time switch: the constraint-free instantiation of a kernel contains no call and no address-taken state -- with a

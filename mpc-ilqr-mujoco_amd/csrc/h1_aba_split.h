@@ -1078,34 +1078,53 @@ DEVFN void step(bool side, HalfX& h, const HalfU& u, double dt, const double* gr
 }
 
 // x <- f(x, u) with the stance constraints of the scheduled feet (contact mode 1 / 2 / 3)
-// LIM: joint-limit rows (h1.xml jnt_range, enforced inside mj_step; oracle h1_step): a hinge past its range that the
+// joint-limit rows (h1.xml jnt_range, enforced inside mj_step; oracle h1_step): a hinge past its range that the
 // step would still move outward is stopped -- the dynamics run once more with those hinges acceleration-prescribed, qacc_i = -v_i / h
-// (forward_dynamics: armature 2^1000), the stance rows solved on that system.  mode 0: no stance rows (the constraint-free plant).
+// (forward_dynamics: armature 2^1000), the stance rows solved on that system.
 constexpr double LOCK_ARM = 0x1p1000;
-// The hinges of this lane that the step stops, decided on the accelerations qa of the step without the rows: their torque and extra
-// armature for the second pass (tau, add); true if this lane has any.
-DEVFN bool limit_locks(bool side, const HalfState& q, const HalfAcc& qa, double dt, HalfTau& tau, HalfTau& add) {
-  bool any = false;
-  auto lim = [&](double lo, double hi, double th, double qd, double qdd, double& tq, double& ad) {
+// The hinges of this lane that the step stops, decided on the accelerations qa of the step without the rows, as a bit mask (bit 0 the
+// torso hinge, 1..5 the leg's, 6..9 the arm's); and what the mask means for the second pass: torque c 2^1000 and armature 2^1000 there.
+DEVFN unsigned limit_lock_mask(bool side, const HalfState& q, const HalfAcc& qa, double dt) {
+  unsigned mask = 0u;
+  auto lim = [&](int bit, double lo, double hi, double th, double qd, double qdd) {
     const double vn = qd + dt * qdd;
-    const bool lk = (th > hi && vn > 0.0) || (th < lo && vn < 0.0);
+    if ((th > hi && vn > 0.0) || (th < lo && vn < 0.0)) mask |= 1u << bit;
+  };
+  lim(0, C_JRANGE[10][0], C_JRANGE[10][1], q.th11, q.qd11, qa.q11);
+#pragma unroll
+  for (int k = 0; k < 5; ++k) lim(1 + k, side ? C_JRANGE[5 + k][0] : C_JRANGE[k][0], side ? C_JRANGE[5 + k][1] : C_JRANGE[k][1], q.thL[k], q.qdL[k], qa.qL[k]);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) lim(6 + k, side ? C_JRANGE[15 + k][0] : C_JRANGE[11 + k][0], side ? C_JRANGE[15 + k][1] : C_JRANGE[11 + k][1], q.thA[k], q.qdA[k], qa.qA[k]);
+  return mask;
+}
+DEVFN void apply_lock_mask(unsigned mask, const HalfState& q, double dt, HalfTau& tau, HalfTau& add) {
+  auto ap = [&](int bit, double qd, double& tq, double& ad) {
+    const bool lk = ((mask >> bit) & 1u) != 0u;
     ad = lk ? LOCK_ARM : 0.0;
     tq = lk ? (-qd / dt) * LOCK_ARM : tq;
-    any = any || lk;
   };
-  lim(C_JRANGE[10][0], C_JRANGE[10][1], q.th11, q.qd11, qa.q11, tau.t11, add.t11);
+  ap(0, q.qd11, tau.t11, add.t11);
 #pragma unroll
-  for (int k = 0; k < 5; ++k) lim(side ? C_JRANGE[5 + k][0] : C_JRANGE[k][0], side ? C_JRANGE[5 + k][1] : C_JRANGE[k][1], q.thL[k], q.qdL[k], qa.qL[k], tau.tL[k], add.tL[k]);
+  for (int k = 0; k < 5; ++k) ap(1 + k, q.qdL[k], tau.tL[k], add.tL[k]);
 #pragma unroll
-  for (int k = 0; k < 4; ++k) lim(side ? C_JRANGE[15 + k][0] : C_JRANGE[11 + k][0], side ? C_JRANGE[15 + k][1] : C_JRANGE[11 + k][1], q.thA[k], q.qdA[k], qa.qA[k], tau.tA[k], add.tA[k]);
-  return any;
+  for (int k = 0; k < 4; ++k) ap(6 + k, q.qdA[k], tau.tA[k], add.tA[k]);
 }
-template <bool KIN = false, bool LIM = false>
-DEVFN void step_stance(bool side, HalfX& h, const HalfU& u, double dt, const double* grav, const LaneLds& L, double soft, int mode, bool st_own, bool st_par, double mu = 1.0) {
+DEVFN bool limit_locks(bool side, const HalfState& q, const HalfAcc& qa, double dt, HalfTau& tau, HalfTau& add) {
+  const unsigned mask = limit_lock_mask(side, q, qa, dt);
+  apply_lock_mask(mask, q, dt, tau, add);
+  return mask != 0u;
+}
+// The step with the rows: dyn_split_kernels.hip step_stance_shared_lim -- the accelerations are ONE function there, called once without
+// extra armature (x + 0.0 is x: the step without the rows, bit for bit) and, by the lane pairs that have a hinge to stop, once more with
+// it.  (Two inlined copies doubled the step's private segment, 1.3 -> 3.3 KB per lane, and with a wave per SIMD of these kernels in
+// flight that crosses the runtime's scratch budget: the launch is throttled and every step, stopped hinges or not, paid 2.4 x.)
+
+// the pieces of a constrained step: unit quaternion / base rotation / hinge torques; the accelerations (free recursion + stance rows; PER: with
+// the per-hinge extra armature of the joint-limit rows); the semi-implicit Euler update
+DEVFN void stance_prepare(bool side, const HalfX& h, const HalfU& u, double* qh, double* R0, HalfTau& tau) {
   const double qn = sqrt(h.quat[0] * h.quat[0] + h.quat[1] * h.quat[1] + h.quat[2] * h.quat[2] + h.quat[3] * h.quat[3]);
-  const double qh[4] = {h.quat[0] / qn, h.quat[1] / qn, h.quat[2] / qn, h.quat[3] / qn};
-  double R0[9]; quat_R(qh[0], qh[1], qh[2], qh[3], R0);
-  HalfTau tau;
+  qh[0] = h.quat[0] / qn; qh[1] = h.quat[1] / qn; qh[2] = h.quat[2] / qn; qh[3] = h.quat[3] / qn;
+  quat_R(qh[0], qh[1], qh[2], qh[3], R0);
   tau.t11 = clampu(u.u11, C_CTRLRANGE[10]) - DAMPING * h.q.qd11;
 #pragma unroll
   for (int k = 0; k < 5; ++k) {
@@ -1119,19 +1138,15 @@ DEVFN void step_stance(bool side, HalfX& h, const HalfU& u, double dt, const dou
     const double uc = u.uA[k] < lo ? lo : (u.uA[k] > hi ? hi : u.uA[k]);
     tau.tA[k] = uc - DAMPING * h.q.qdA[k];
   }
-  double qb[6]; HalfAcc qa; Art Y0; double a0[6];
-  forward_dynamics(side, R0, h.vb, h.q, tau, ARMATURE + dt * DAMPING, grav, L, qb, qa, &Y0, a0);
-  if constexpr (LIM) { if (mode == 0) { st_own = false; st_par = false; } }
+}
+template <bool KIN, bool PER>
+DEVFN void stance_accelerations(bool side, const double* R0, const HalfX& h, const HalfTau& tau, double dt, const double* grav, const LaneLds& L, double soft, int mode,
+                                bool st_own, bool st_par, double mu, double* qb, HalfAcc& qa, const HalfTau* add = nullptr) {
+  Art Y0; double a0[6];
+  forward_dynamics<PER>(side, R0, h.vb, h.q, tau, ARMATURE + dt * DAMPING, grav, L, qb, qa, &Y0, a0, add);
   if (st_own || st_par) stance_correct<KIN>(side, R0, h.vb, h.q, dt, soft, mode, st_own, st_par, grav, L, Y0, a0, qb, qa, mu);
-  if constexpr (LIM) {
-    HalfTau add;
-    const bool any = limit_locks(side, h.q, qa, dt, tau, add);
-    const bool anyp = xch_flag(any) || any;          // the pair runs the recursion together
-    if (anyp) {
-      forward_dynamics<true>(side, R0, h.vb, h.q, tau, ARMATURE + dt * DAMPING, grav, L, qb, qa, &Y0, a0, &add);
-      if (st_own || st_par) stance_correct<KIN>(side, R0, h.vb, h.q, dt, soft, mode, st_own, st_par, grav, L, Y0, a0, qb, qa, mu);
-    }
-  }
+}
+DEVFN void integrate_half(HalfX& h, const double* qh, const double* qb, const HalfAcc& qa, double dt) {
 #pragma unroll
   for (int k = 0; k < 6; ++k) h.vb[k] += dt * qb[k];
 #pragma unroll
@@ -1152,6 +1167,15 @@ DEVFN void step_stance(bool side, HalfX& h, const HalfU& u, double dt, const dou
   const double rz = qh[0] * ez + qh[1] * ey - qh[2] * ex + qh[3] * ew;
   const double rn = sqrt(rw * rw + rx * rx + ry * ry + rz * rz);
   h.quat[0] = rw / rn; h.quat[1] = rx / rn; h.quat[2] = ry / rn; h.quat[3] = rz / rn;
+}
+// x <- f(x, u) with the stance constraints of the scheduled feet (contact mode 1 / 2 / 3 / 4)
+template <bool KIN = false>
+DEVFN void step_stance(bool side, HalfX& h, const HalfU& u, double dt, const double* grav, const LaneLds& L, double soft, int mode, bool st_own, bool st_par, double mu = 1.0) {
+  double qh[4], R0[9]; HalfTau tau;
+  stance_prepare(side, h, u, qh, R0, tau);
+  double qb[6]; HalfAcc qa;
+  stance_accelerations<KIN, false>(side, R0, h, tau, dt, grav, L, soft, mode, st_own, st_par, mu, qb, qa);
+  integrate_half(h, qh, qb, qa, dt);
 }
 
 // ---- whole-body CoM with MuJoCo masses (RobotUtils::computeCoM, reference src/common/robot_utils.cpp:810-833):
