@@ -188,11 +188,16 @@ class MPC {
     if constexpr (detail::has_mj_model<Robot>::value) { const auto* m = robot_.model(); if (m) s.setGravity(m->opt.gravity[0], m->opt.gravity[1], m->opt.gravity[2]); }
     ilqr_hip::Vec ee((size_t)(N_ + 1) * 6, 0.0), cv((size_t)(N_ + 1) * 3, 0.0);
     std::vector<int> stance((size_t)(N_ + 1) * 2, 1);
-    for (int t = 0; t <= N_; ++t) {
-      for (int e = 0; e < 2; ++e) { const Eigen::Vector3d p = robot_.getEEReference(t, e); for (int k = 0; k < 3; ++k) ee[(size_t)t * 6 + 3 * e + k] = p(k); stance[(size_t)t * 2 + e] = robot_.isStance(e, t) ? 1 : 0; }
-      const Eigen::Vector3d c = robot_.getCoMVelReference(t); for (int k = 0; k < 3; ++k) cv[(size_t)t * 3 + k] = c(k);
+    // (a RobotUtils whose end-effector / CoM-velocity tables are not loaded throws from these getters; the reference catches that and
+    // carries on without the term, ilqr.cpp:401-434, 682-693, 703-720 -- so does this, like iLQR::pullProblem above)
+    bool have_refs = true;
+    for (int t = 0; t <= N_ && have_refs; ++t) {
+      try {
+        for (int e = 0; e < 2; ++e) { const Eigen::Vector3d p = robot_.getEEReference(t, e); for (int k = 0; k < 3; ++k) ee[(size_t)t * 6 + 3 * e + k] = p(k); stance[(size_t)t * 2 + e] = robot_.isStance(e, t) ? 1 : 0; }
+        const Eigen::Vector3d c = robot_.getCoMVelReference(t); for (int k = 0; k < 3; ++k) cv[(size_t)t * 3 + k] = c(k);
+      } catch (const std::exception&) { have_refs = false; }
     }
-    s.setEEReferences(ee, &cv); s.setContactSchedule(stance);
+    if (have_refs) { s.setEEReferences(ee, &cv); s.setContactSchedule(stance); }
   }
   Robot& robot_;
   ilqr_hip::MPC<Window> impl_;

@@ -247,7 +247,7 @@ __global__ void __launch_bounds__(64) k_line_search_s(DevState S, ProblemDev P, 
       const unsigned off = (unsigned)((row < m ? row : m - 1) * n);          // (rows past 18: a valid row, its product discarded)
 #pragma unroll
       for (int j = 0; j < 6; ++j) ka[g][j] = *reinterpret_cast<const v2d_s*>(Kt + off + 8 * j + 2 * mk);
-      kt[g] = Kt[off + 48 + mk];
+      kt[g] = Kt[off + 48 + (mk < 3 ? mk : 2)];                               // (column 51 does not exist: a valid load, zeroed below)
     }
     h1s::HalfX xh; h1s::HalfU ubh, kfh;
     h1s::load_half(side, xbt, xh);

@@ -99,6 +99,8 @@ struct ilqr_hip_ctx {
   int lxx_layout = 0;
   bool ab_packed = false, ab_pads_clean = false;
   int dedup_retry = 0;          // ilqr_hip_set_dedup_saturated_retry
+  bool env_refused = false;     // ILQR_ENV_PER_CALL: the last re-read selected a family this library does not hold (enter)
+  double packed_h = 0.0;        // step size h of the packed image while ab_packed (k_unpack_ab rebuilds the position rows from it)
   Knobs knobs = read_knobs();   // (constructed in ilqr_hip_create)
   double lin_fold_h = 0.0;   // step size h while S.A / S.Bm hold the analytic Jacobians (folded backward kernel), else 0
   std::string err;
@@ -161,9 +163,16 @@ struct StageTimer {
 
 static inline void enter(ilqr_hip_ctx* c) {
   hipSetDevice(c->device);
-  if (c->knobs.per_call) { const Knobs k = read_knobs(); if (ilqr::variants_supported(k.var)) c->knobs = k; }     // (an unsupported selection keeps the previous one)
+  if (c->knobs.per_call) {
+    // an unsupported selection keeps the previous one AND is recorded: the calls that launch kernels refuse (ENV_REFUSED) until the
+    // environment selects a family this library holds again -- a test that switches families on a product handle must not pass vacuously
+    const Knobs k = read_knobs();
+    if (ilqr::variants_supported(k.var)) { c->knobs = k; c->env_refused = false; }
+    else { c->env_refused = true; c->err = "ILQR_ENV_PER_CALL: the environment selects a kernel family this library does not hold (see ilqr_hip_create)"; }
+  }
   ilqr::set_variants(c->knobs.var);
 }
+#define ENV_REFUSED(c) do { if ((c)->env_refused) return ILQR_ERR_UNSUPPORTED; } while (0)
 
 extern "C" {
 
@@ -565,6 +574,8 @@ static int enqueue_solve(ilqr_hip_ctx* c, const DevState& S, const h1::ProblemDe
   // (iteration 0 rewrites A_t, B_t, lxx_t of every rollout: a solve leaves one layout behind; ilqr_hip_solve_async has prepared the padding)
   c->lxx_layout = lxx_lower;
   c->ab_packed = pack != 0;
+  c->lin_fold_h = fold_h;        // what S.A / S.Bm hold after this solve; assigned with the layout flags (an early return above leaves all of them alone)
+  if (pack) c->packed_h = fold_h;
   if (!pack) c->ab_pads_clean = false;
   if (gate) TRY(ensure_gate(c));
   c->iterations_enqueued = c->max_iter;
@@ -766,8 +777,9 @@ static int jacobians_available(ilqr_hip_ctx* c) {
 int ilqr_hip_solve_async(ilqr_hip_ctx* c) {
   if (!c) return ILQR_ERR_ARG;
   if (!c->initialized || !c->refs_set) { c->err = "solve before initialize/set_references"; return ILQR_ERR_STATE; }
+  enter(c);      // (first: the checks below read this handle's kernel family, not the last one entered on this thread)
+  ENV_REFUSED(c);
   if (int rc = jacobians_available(c)) return rc;
-  enter(c);
   hipStream_t st = c->stream;
   const DevState& S = c->S; const h1::ProblemDev& P = c->P;
   c->spans.clear(); c->pool_next = 0;
@@ -776,8 +788,7 @@ int ilqr_hip_solve_async(ilqr_hip_ctx* c) {
   c->n_slices = k;
   c->spec_iterations = 0; c->split_iterations = 0;
   if (c->knobs.spec && k <= 1 && !c->twin && (c->B <= c->knobs.spec_max || (c->early_exit && early_exit_gate(c)))) TRY(ensure_twin(c));
-  c->lin_fold_h = ilqr::linearize_fold_h(P, c->jac_mode);   // what S.A / S.Bm hold after this solve
-  if (c->lin_fold_h != 0.0 && ilqr::variant_pack() && !c->ab_pads_clean) { ilqr::launch_pack_zero_pads(S, st); c->ab_pads_clean = true; }
+  if (ilqr::linearize_fold_h(P, c->jac_mode) != 0.0 && ilqr::variant_pack() && !c->ab_pads_clean) { ilqr::launch_pack_zero_pads(S, st); c->ab_pads_clean = true; }
   c->first_aside = c->xbar_rolled && c->rolled_variant == rollout_kernel_identity(P) && same_dyn(c->rolled_dyn, P.dyn);
   c->xbar_rolled = false;                                   // after this solve xbar is an accepted line-search candidate
   if (k <= 1) {
@@ -892,14 +903,14 @@ int ilqr_hip_set_trajectory(ilqr_hip_ctx* c, const double* xbar, const double* u
   c->xbar_rolled = false;
   return ILQR_OK;
 }
-#define STAGE_PRE if (!c) return ILQR_ERR_ARG; if (!c->initialized) return ILQR_ERR_STATE; enter(c)
+#define STAGE_PRE if (!c) return ILQR_ERR_ARG; if (!c->initialized) return ILQR_ERR_STATE; enter(c); ENV_REFUSED(c)
 #define STAGE_POST HIPCHK(c, hipGetLastError()); HIPCHK(c, hipStreamSynchronize(c->stream)); return ILQR_OK
 int ilqr_hip_stage_rollout(ilqr_hip_ctx* c) { STAGE_PRE; ilqr::launch_rollout(c->S, c->P, ilqr::MASK_ALL, 1, 0, c->S.Jbase, c->stream); STAGE_POST; }
 int ilqr_hip_stage_linearize(ilqr_hip_ctx* c) { STAGE_PRE; if (int rc = jacobians_available(c)) return rc; ilqr::launch_linearize(c->S, c->P, ilqr::MASK_ALL, c->jac_mode, c->fd_eps, c->stream); c->lin_fold_h = ilqr::linearize_fold_h(c->P, c->jac_mode); c->ab_packed = false; c->ab_pads_clean = false; STAGE_POST; }
 int ilqr_hip_stage_cost_quadratics(ilqr_hip_ctx* c) { STAGE_PRE; if (!c->refs_set) return ILQR_ERR_STATE; ilqr::launch_cost_quadratics(c->S, c->P, ilqr::MASK_ALL, c->stream); c->lxx_layout = 0; STAGE_POST; }
 // layout conversions on demand (in place): what a consumer of the standard layout (getters, any kernel family but the operand-layout
 // one) or of the operand layout (stage API on riccati_pack.hip) calls first
-static void want_standard_ab(ilqr_hip_ctx* c) { if (c->ab_packed) { ilqr::launch_unpack_ab(c->S, c->lin_fold_h, c->stream); c->ab_packed = false; c->ab_pads_clean = false; } }
+static void want_standard_ab(ilqr_hip_ctx* c) { if (c->ab_packed) { ilqr::launch_unpack_ab(c->S, c->packed_h, c->stream); c->ab_packed = false; c->ab_pads_clean = false; } }
 static void want_standard_lxx(ilqr_hip_ctx* c, bool whole) {
   if (c->lxx_layout == 2) { ilqr::launch_unpack_lxx(c->S, c->stream); c->lxx_layout = 0; }
   if (c->lxx_layout == 1 && whole) { ilqr::launch_mirror_lxx(c->S, c->stream); c->lxx_layout = 0; }
@@ -908,7 +919,7 @@ int ilqr_hip_stage_backward_pass(ilqr_hip_ctx* c) {
   STAGE_PRE;
   if (c->lin_fold_h != 0.0 && ilqr::variant_pack()) {
     // analytic Jacobians and the operand-layout kernel (riccati_pack.hip): convert in place what is not yet in its layout
-    if (!c->ab_packed) { ilqr::launch_pack_ab(c->S, c->stream); c->ab_packed = true; c->ab_pads_clean = true; }
+    if (!c->ab_packed) { ilqr::launch_pack_ab(c->S, c->stream); c->ab_packed = true; c->packed_h = c->lin_fold_h; c->ab_pads_clean = true; }
     if (c->lxx_layout != 2) { want_standard_lxx(c, true); ilqr::launch_pack_lxx(c->S, c->stream); c->lxx_layout = 2; }
   } else {
     // any other family reads the standard layout (the one-wave kernel: the tiles I >= J of lxx_t, t < N, suffice)
@@ -1003,6 +1014,7 @@ int ilqr_hip_step(ilqr_hip_ctx* c, int count, const double* x, const double* u, 
 }
 int ilqr_hip_set_contact_mode(ilqr_hip_ctx* c, int mode, double softness) {
   if (!c || (mode != ILQR_CONTACT_NONE && mode != ILQR_CONTACT_RIGID_STANCE && mode != ILQR_CONTACT_UNILATERAL_STANCE && mode != ILQR_CONTACT_FRICTION_STANCE && mode != ILQR_CONTACT_KINETIC_FRICTION_STANCE)) return ILQR_ERR_ARG;
+  enter(c);
   if (mode >= ILQR_CONTACT_FRICTION_STANCE && ilqr::variant_scalar_dyn()) { c->err = "contact modes 3 / 4 (Coulomb limit) exist on the two-lane kernels only; unset ILQR_DYN=s"; return ILQR_ERR_UNSUPPORTED; }
   c->P.dyn.contact = mode;
   if (softness > 0.0) c->P.dyn.soft = softness;
@@ -1010,6 +1022,7 @@ int ilqr_hip_set_contact_mode(ilqr_hip_ctx* c, int mode, double softness) {
 }
 int ilqr_hip_set_joint_limits(ilqr_hip_ctx* c, int on) {
   if (!c) return ILQR_ERR_ARG;
+  enter(c);
   if (on && ilqr::variant_scalar_dyn()) { c->err = "joint-limit rows exist on the two-lane kernels only; unset ILQR_DYN=s"; return ILQR_ERR_UNSUPPORTED; }
   c->P.dyn.limits = on ? 1 : 0;     // (a nominal rolled under the other setting is recognised by same_dyn)
   return ILQR_OK;

@@ -949,6 +949,43 @@ def test_world_2_gather_branch_of_the_c_abi_runs_on_one_device_through_a_stand_i
     assert np.array_equal(np.fromfile(two).reshape(2 * B, 20), rows1[:, :20])
 
 
+@pytest.mark.parametrize("root,with_gains", [(0, 1), (5, 1), (5, 0)])
+def test_world_8_gather_on_one_device_at_the_width_of_the_node(tmp_path, root, with_gains):
+    """The machine has eight GPUs; code that has only run at world = 2 is not ready for 8.  Eight host threads, eight handles and eight
+    stand-in communicators on device 0 (ONE process: the GPU box admits six processes on its card, so eight bench ranks cannot be
+    rehearsed there): the root's receive offsets r * cnt for r = 0..7, a root in the middle of the ranks, with and without K0 -- the
+    gathered [8 B][width] rows equal the single-handle solve of the whole batch bit for bit.  Consumer: mpc.cpp:97-113."""
+    exe, fake = _demo_and_fake_rccl()
+    B, W = 3, (20 + 19 * 51) if with_gains else 20
+    eight, one = str(tmp_path / "eight.bin"), str(tmp_path / "one.bin")
+    r = subprocess.run([exe, "8", str(B), str(with_gains), eight, "0", str(root)], capture_output=True, text=True, timeout=900, env=dict(os.environ, ILQR_RCCL_LIB=fake))
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([exe, "1", str(8 * B), str(with_gains), one, "0"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    rows8, rows1 = np.fromfile(eight).reshape(8 * B, W), np.fromfile(one).reshape(8 * B, W)
+    assert np.all(np.isfinite(rows1)) and np.abs(rows1[:, :19]).max() > 0
+    assert np.array_equal(rows8, rows1)
+    # every shard is somebody else's rollouts: no two blocks of B rows coincide (a wrong receive offset would repeat or drop one)
+    assert len({rows8[k * B:(k + 1) * B].tobytes() for k in range(8)}) == 8
+
+
+def test_bench_four_ranks_without_a_launcher_on_one_gpu():
+    """bench.py's self-launcher and its world > 1 branch above world = 2: `python bench.py --gpus 4 --batch 64 --rehearse-single-gpu`
+    started plainly -- four ranks on device 0 over gloo (with this pytest process that is five processes on the card; the box admits
+    six, which is why the eight-rank case is not rehearsed here), shard_range for ranks 0..3, global batch 256 gathered in global
+    rollout order, one line labelled n_gpus: 4."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--batch", "64", "--steps", "1", "--warmup", "0", "--rehearse-single-gpu"],
+                       capture_output=True, text=True, timeout=1200, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 4 and d["config"]["global_batch"] == 256 and d["value"] > 0 and d["scaling"] == "weak"
+    assert d["config"]["gather_check"] == "rank 0 received 256 rows in global rollout order"
+    assert d["config"]["launcher"].startswith("self-launched")
+
+
 def test_an_rccl_error_inside_the_gather_group_closes_the_group_and_surfaces_through_last_error(tmp_path):
     """An ncclRecv that fails inside the group (injected by the stand-in library) still has the group closed (ncclGroupEnd is called,
     the peer's ncclGroupEnd returns instead of waiting forever) and comes back as ILQR_ERR_HIP with the RCCL error text in

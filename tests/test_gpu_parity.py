@@ -321,6 +321,21 @@ def test_fixed_iteration_mode_and_fd_mode_parity():
         n, oc, oa, ol_ = o.trace()
         assert n == 4 and np.allclose(tc[b], oc, rtol=1e-5) and np.array_equal(ta[b], oa)
         assert rel(s.gains_K()[b], o.get("K")) < 1e-4   # FD noise (1e-16/1e-5) amplified through the recursion
+    # The 1e-4 above is round-off / eps of two INDEPENDENT forward-difference evaluations carried through four iterations, not solver
+    # error.  north_star's 1e-5 on the gains, for the reference's own Jacobian scheme, is checked on the SAME forward-difference
+    # (A_t, B_t): the GPU's FD Jacobians about the solved trajectory go into the oracle (set_linearization), both run their own cost
+    # quadratics and backward pass with the rollout's own lambda.
+    xb, ub, lam = s.xbar(), s.ubar(), s.lambdas()
+    s.set_trajectory(xb, ub)
+    s.stage_linearize(); s.stage_cost_quadratics(); s.stage_backward_pass()
+    A, Bm = s.linearization(); K, kff = s.gains_K(), s.gains_kff()
+    for b in range(B):
+        o = oracle_for(prob, jac_mode=1, fd_eps=1e-5, early_exit=0, lam=float(lam[b]))
+        o.set_trajectory(xb[b], ub[b])
+        o.linearize()                                   # the oracle's own forward differences: the scheme itself, entry by entry
+        assert np.abs(A[b] - o.get("A")).max() < 1e-6 and np.abs(Bm[b] - o.get("B")).max() < 1e-6
+        o.set_linearization(A[b], Bm[b]); o.cost_quadratics(); o.backward_pass()
+        assert rel(K[b], o.get("K")) < 1e-5 and rel(kff[b], o.get("kff")) < 1e-5, (b, rel(K[b], o.get("K")), rel(kff[b], o.get("kff")))
     s.close()
 
 
