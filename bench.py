@@ -546,6 +546,29 @@ def main():
         s.set_joint_limits(False)
         s.set_contact_mode(0)
 
+    # (not the headline): the default workload -- the constraint-free plant -- with the joint-limit rows of the plant
+    # switched on (ilqr_hip_set_joint_limits): what the option costs on the headline's own batch, where no hinge leaves its
+    # range (its kernels are instantiations of their own -- k_rollout_s<3>, k_line_search_s<3, .>, k_lin_primal_s<true>, k_lin_tangent2<., true>
+    # -- and decide the set of stopped hinges every step)
+    limits_line = None
+    if not args.contact and not args.no_contact_line and not JAC_FD and world == 1 and args.workload == "default":
+        s.set_problem(prob); s.set_contact_mode(0); s.set_options(jacobian_mode=sv.JAC_ANALYTIC, early_exit=False)
+        s.set_joint_limits(True)
+
+        def lstep():
+            s.initialize_device(x0_d.data_ptr(), ui_d.data_ptr()); s.solve_async(); s.synchronize()
+        lstep()
+        torch.cuda.synchronize(); tl0 = time.perf_counter()
+        lsteps = 2
+        for _ in range(lsteps):
+            lstep()
+        torch.cuda.synchronize(); tlj = time.perf_counter() - tl0
+        assert np.all(s.iterations() == iters) and np.all(np.isfinite(s.cost())) and s.adopt_mismatches() == 0
+        limits_line = {"value": B * iters * lsteps / tlj, "unit": "iterations/s", "ms_per_step": 1e3 * tlj / lsteps,
+                       "workload": "the default batch and gravity (no contact rows) with the joint-limit rows of the plant on (hinge ranges of h1.xml as velocity-level "
+                                   "stops, robot_utils.cpp:113-114); no hinge of this batch leaves its range; analytic Jacobians, %d fixed iterations" % iters}
+        s.set_joint_limits(False)
+
     # fourth number (not the headline): the same batch with the REFERENCE'S OWN Jacobian scheme, forward differences
     # with eps 1e-5 (RobotUtils::linearizeDynamicsFD, robot_utils.cpp:120-160: one base step + 70 perturbed steps per knot), fixed
     # iterations -- the like-for-like line against cpu_baseline (the oracle is timed with the same scheme).  Its own roofline: the FD
@@ -729,6 +752,8 @@ def main():
         }
         if contact_line is not None:
             out["contact"] = contact_line
+        if limits_line is not None:
+            out["joint_limits"] = limits_line
         if fd_line is not None:
             out["fd"] = fd_line
         if dedup_line is not None:

@@ -469,14 +469,15 @@ __global__ void __launch_bounds__(64) k_lin_primal_s(DevState S, ProblemDev P, i
   const DumpSinkS sink{&stage, rec, &L, side, live};
   double qb[6], inv36[36], aL[3]; h1s::HalfAcc qa;
   if constexpr (LIM) {
+    // The decision pass is the step kernels' own non-inlined lim_accelerations (mask 0: the step without the rows, stance rows included):
+    // inlined here beside the reporting recursion it made a 3.4 KB private segment with 854 spilled registers -- past the scratch budget of
+    // a wave per SIMD, every launch throttled.  The kernel's frame is now the callee's.
     h1s::HalfTau add;
     {
-      h1s::Art Y0; double a0[6];
-      h1s::forward_dynamics(side, R0, h.vb, h.q, tau, h1s::ARMATURE + dt * h1s::DAMPING, P.dyn.g, L, qb, qa, &Y0, a0);
       const int* stn = P.stance + b * P.stance_stride + 2 * t;
-      const bool st_own = P.dyn.contact != 0 && (side ? stn[1] : stn[0]) == 1, st_par = P.dyn.contact != 0 && (side ? stn[0] : stn[1]) == 1;
-      if (st_own || st_par) h1s::stance_correct<true>(side, R0, h.vb, h.q, dt, P.dyn.soft, P.dyn.contact, st_own, st_par, P.dyn.g, L, Y0, a0, qb, qa, P.dyn.mu);
-      h1s::limit_locks(side, h.q, qa, dt, tau, add);
+      LimAcc o;
+      lim_accelerations<true>(&h, &u, 0u, dt, P.dyn.g[0], P.dyn.g[1], P.dyn.g[2], P.dyn.soft, P.dyn.contact, stn[0], stn[1], P.dyn.mu, &o);
+      h1s::limit_locks(side, h.q, o.qa, dt, tau, add);
     }
     h1s::forward_dynamics_dump<const DumpSinkS, true>(side, R0, h.vb, h.q, tau, h1s::ARMATURE + dt * h1s::DAMPING, P.dyn.g, L, qb, qa, sink, inv36, aL, &add);
   } else
