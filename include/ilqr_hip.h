@@ -212,11 +212,21 @@ int ilqr_hip_set_friction(ilqr_hip_ctx* ctx, double mu);
    (v_i + h qacc_i points out of the range, qacc of the step without these rows) is stopped over the step, v_i+ = 0 -- its acceleration
    is prescribed, qacc_i = -v_i / h, in a second pass of the articulated-body recursion (Featherstone's hybrid dynamics; the stance
    rows of the contact modes are solved on that system).  A hinge past its range that moves back in is left alone; nothing pushes a
-   hinge back (that is MuJoCo's soft constraint, solref / solimp: not modelled).  Default off (the constraint-free restatement).
+   hinge back unless ilqr_hip_set_joint_limit_stiffness gives the rows a restoring term.  Default off (the constraint-free restatement).
    Rollout, line search, plant step and both Jacobian schemes carry it (two-lane kernels, in instantiations of their own: with the
    option off every kernel keeps its machine code).  Analytic Jacobians: the dumped recursion has the stopped hinges
    acceleration-prescribed and d qacc_i = -1 / h rides the direction of a stopped hinge's own rate (decisions held fixed). */
 int ilqr_hip_set_joint_limits(ilqr_hip_ctx* ctx, int on);
+/* Restoring stiffness of the joint-limit rows (round 6; mj_step pushes a hinge back into its range, h1.xml:55-151 / robot_utils.cpp:113-114, the
+   pure stop above does not).  MuJoCo drives a violated constraint towards the reference acceleration a_ref = -b v - k r (solref: b = 2 /
+   (dmax timeconst), k = 1 / (dmax^2 timeconst^2 dampratio^2), timeconst clamped to 2 h); in the hard limit of its impedance the constrained
+   hinge takes exactly that acceleration.  With k = stiffness the row prescribes qacc_i = -v_i / h - k r_i (r_i = q_i - hi_i > 0 or q_i - lo_i < 0:
+   the violation; b = 1 / h is solref's damping at the clamped time constant), i.e. v_i+ = -h k r_i, and it is active when the step without the
+   rows falls short of that acceleration on the outward side -- a hinge that drifts back in too slowly is constrained too, one that returns
+   faster is left alone (the row only pushes).  k = 1 / (2 h)^2 (625 at h = 0.02) is solref's default time constant: a quarter of the violation
+   per step.  0 (default): the pure stop, bit for bit.  Needs ilqr_hip_set_joint_limits(ctx, 1); carried by the step, rollout, line search and
+   both Jacobian schemes (analytic: d qacc_i = -k rides the direction of the constrained hinge's own angle).  k < 0: ILQR_ERR_ARG. */
+int ilqr_hip_set_joint_limit_stiffness(ilqr_hip_ctx* ctx, double stiffness);
 int ilqr_hip_step_stance(ilqr_hip_ctx* ctx, int count, const double* x, const double* u, int stance_left, int stance_right, double* x_next);
 
 /* per-stage device time of the last solve in milliseconds, keyed like the reference's profiler

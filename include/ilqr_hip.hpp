@@ -97,6 +97,7 @@ class iLQR {
   // sliding friction coefficient of contact modes 3 / 4 (ilqr_hip.h: Coulomb limit on the stance feet; forward-difference Jacobians only)
   void setFriction(double mu) { chk(ilqr_hip_set_friction(ctx_, mu)); }
   void setJointLimits(bool on) { chk(ilqr_hip_set_joint_limits(ctx_, on ? 1 : 0)); }     // joint-limit rows of the plant (ilqr_hip.h)
+  void setJointLimitStiffness(double k) { chk(ilqr_hip_set_joint_limit_stiffness(ctx_, k)); }      // their restoring term (0: pure stop)
   void setEEReferences(const Vec& ee_ref /*[N+1][2][3]*/, const Vec* com_vel_ref = nullptr) { chk(ilqr_hip_set_ee_references(ctx_, ee_ref.data(), com_vel_ref ? com_vel_ref->data() : nullptr, 1)); }
 
   // include/ilqr/ilqr.hpp:22-24

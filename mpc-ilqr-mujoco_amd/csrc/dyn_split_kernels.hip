@@ -70,7 +70,7 @@ __device__ __attribute__((noinline)) void step_stance_shared_kin(h1s::HalfX* hp,
 struct LimAcc { double qb[6]; h1s::HalfAcc qa; };
 template <bool KIN>
 __device__ __attribute__((noinline)) void lim_accelerations(const h1s::HalfX* hp, const h1s::HalfU* up, unsigned mask, double dt, double gx, double gy, double gz,
-                                                            double soft, int mode, int st_left, int st_right, double mu, LimAcc* out) {
+                                                            double soft, int mode, int st_left, int st_right, double mu, double kr, LimAcc* out) {
   const int lane = threadIdx.x;
   const bool side = (lane & 1) != 0;
   const h1s::LaneLds L{dyn_lds_c, 64, lane};
@@ -79,33 +79,33 @@ __device__ __attribute__((noinline)) void lim_accelerations(const h1s::HalfX* hp
   const h1s::HalfU u = *up;
   double qh[4], R0[9]; h1s::HalfTau tau, add;
   h1s::stance_prepare(side, h, u, qh, R0, tau);
-  h1s::apply_lock_mask(mask, h.q, dt, tau, add);
+  h1s::apply_lock_mask(side, mask, h.q, dt, kr, tau, add);
   const bool st_own = mode != 0 && (side ? st_right : st_left) == 1, st_par = mode != 0 && (side ? st_left : st_right) == 1;      // (mode 0: no stance rows)
   LimAcc o;
   h1s::stance_accelerations<KIN, true>(side, R0, h, tau, dt, grav, L, soft, mode, st_own, st_par, mu, o.qb, o.qa, &add);
   *out = o;
 }
 template <bool KIN>
-DEVFN void step_lim(h1s::HalfX* hp, const h1s::HalfU* up, double dt, double gx, double gy, double gz, double soft, int mode, int st_left, int st_right, double mu) {
+DEVFN void step_lim(h1s::HalfX* hp, const h1s::HalfU* up, double dt, double gx, double gy, double gz, double soft, int mode, int st_left, int st_right, double mu, double kr) {
   const bool side = (threadIdx.x & 1) != 0;
   LimAcc o;
-  lim_accelerations<KIN>(hp, up, 0u, dt, gx, gy, gz, soft, mode, st_left, st_right, mu, &o);
+  lim_accelerations<KIN>(hp, up, 0u, dt, gx, gy, gz, soft, mode, st_left, st_right, mu, kr, &o);
   h1s::HalfX h = *hp;
-  const unsigned mask = h1s::limit_lock_mask(side, h.q, o.qa, dt);
+  const unsigned mask = h1s::limit_lock_mask(side, h.q, o.qa, dt, kr);
   const bool any = mask != 0u;
-  if (h1s::xch_flag(any) || any) lim_accelerations<KIN>(hp, up, mask, dt, gx, gy, gz, soft, mode, st_left, st_right, mu, &o);      // (the pair runs the recursion together)
+  if (h1s::xch_flag(any) || any) lim_accelerations<KIN>(hp, up, mask, dt, gx, gy, gz, soft, mode, st_left, st_right, mu, kr, &o);      // (the pair runs the recursion together)
   const double qn = sqrt(h.quat[0] * h.quat[0] + h.quat[1] * h.quat[1] + h.quat[2] * h.quat[2] + h.quat[3] * h.quat[3]);
   const double qh[4] = {h.quat[0] / qn, h.quat[1] / qn, h.quat[2] / qn, h.quat[3] / qn};
   h1s::integrate_half(h, qh, o.qb, o.qa, dt);
   *hp = h;
 }
 __device__ __attribute__((noinline)) void step_stance_shared_lim(h1s::HalfX* hp, const h1s::HalfU* up, double dt, double gx, double gy, double gz,
-                                                                 double soft, int mode, int st_left, int st_right, double mu) {
-  step_lim<false>(hp, up, dt, gx, gy, gz, soft, mode, st_left, st_right, mu);
+                                                                 double soft, int mode, int st_left, int st_right, double mu, double kr) {
+  step_lim<false>(hp, up, dt, gx, gy, gz, soft, mode, st_left, st_right, mu, kr);
 }
 __device__ __attribute__((noinline)) void step_stance_shared_kin_lim(h1s::HalfX* hp, const h1s::HalfU* up, double dt, double gx, double gy, double gz,
-                                                                     double soft, int st_left, int st_right, double mu) {
-  step_lim<true>(hp, up, dt, gx, gy, gz, soft, 4, st_left, st_right, mu);
+                                                                     double soft, int st_left, int st_right, double mu, double kr) {
+  step_lim<true>(hp, up, dt, gx, gy, gz, soft, 4, st_left, st_right, mu, kr);
 }
 // one step of either kind; `st` = stance flags (left, right) of the knot being stepped
 // (compile-time switch: the constraint-free instantiation of a kernel contains no call and no address-taken state -- with a
@@ -137,8 +137,8 @@ DEVFN void pin_half_u(h1s::HalfU& u) {
 // every kilobyte of it (1.4 -> 1.8 KB per lane: -0.7 % on the contact bench, -> 4 KB: -4 %, same machine code otherwise).
 template <int CONTACT>
 DEVFN void step_any(bool side, h1s::HalfX& h, const h1s::HalfU& u, const DynParams& dyn, const int* st, const h1s::LaneLds& L) {
-  if constexpr (CONTACT == 4) step_stance_shared_kin_lim(&h, &u, dyn.h, dyn.g[0], dyn.g[1], dyn.g[2], dyn.soft, st[0], st[1], dyn.mu);
-  else if constexpr (CONTACT == 3) step_stance_shared_lim(&h, &u, dyn.h, dyn.g[0], dyn.g[1], dyn.g[2], dyn.soft, dyn.contact, st[0], st[1], dyn.mu);
+  if constexpr (CONTACT == 4) step_stance_shared_kin_lim(&h, &u, dyn.h, dyn.g[0], dyn.g[1], dyn.g[2], dyn.soft, st[0], st[1], dyn.mu, dyn.lim_k);
+  else if constexpr (CONTACT == 3) step_stance_shared_lim(&h, &u, dyn.h, dyn.g[0], dyn.g[1], dyn.g[2], dyn.soft, dyn.contact, st[0], st[1], dyn.mu, dyn.lim_k);
   else if constexpr (CONTACT == 2) step_stance_shared_kin(&h, &u, dyn.h, dyn.g[0], dyn.g[1], dyn.g[2], dyn.soft, st[0], st[1], dyn.mu);
   else if constexpr (CONTACT == 1) step_stance_shared(&h, &u, dyn.h, dyn.g[0], dyn.g[1], dyn.g[2], dyn.soft, dyn.contact, st[0], st[1], dyn.mu);
   else {
@@ -476,8 +476,8 @@ __global__ void __launch_bounds__(64) k_lin_primal_s(DevState S, ProblemDev P, i
     {
       const int* stn = P.stance + b * P.stance_stride + 2 * t;
       LimAcc o;
-      lim_accelerations<true>(&h, &u, 0u, dt, P.dyn.g[0], P.dyn.g[1], P.dyn.g[2], P.dyn.soft, P.dyn.contact, stn[0], stn[1], P.dyn.mu, &o);
-      h1s::limit_locks(side, h.q, o.qa, dt, tau, add);
+      lim_accelerations<true>(&h, &u, 0u, dt, P.dyn.g[0], P.dyn.g[1], P.dyn.g[2], P.dyn.soft, P.dyn.contact, stn[0], stn[1], P.dyn.mu, P.dyn.lim_k, &o);
+      h1s::limit_locks(side, h.q, o.qa, dt, P.dyn.lim_k, tau, add);
     }
     h1s::forward_dynamics_dump<const DumpSinkS, true>(side, R0, h.vb, h.q, tau, h1s::ARMATURE + dt * h1s::DAMPING, P.dyn.g, L, qb, qa, sink, inv36, aL, &add);
   } else

@@ -1084,10 +1084,14 @@ DEVFN void step(bool side, HalfX& h, const HalfU& u, double dt, const double* gr
 constexpr double LOCK_ARM = 0x1p1000;
 // The hinges of this lane that the step stops, decided on the accelerations qa of the step without the rows, as a bit mask (bit 0 the
 // torso hinge, 1..5 the leg's, 6..9 the arm's); and what the mask means for the second pass: torque c 2^1000 and armature 2^1000 there.
-DEVFN unsigned limit_lock_mask(bool side, const HalfState& q, const HalfAcc& qa, double dt) {
+// kr: the restoring stiffness lim_k (DynParams; 0: the pure stop).  The row prescribes qacc_i = -v_i / h - kr r_i with r_i the violation, and is
+// active when the step without the rows falls short of that on the outward side: v_i + h (qacc_i + kr r_i) points out of the range
+// (kr = 0: v_i + h qacc_i, the round-5 expression bit for bit -- 0 * r is 0 and x + 0.0 is x).
+DEVFN unsigned limit_lock_mask(bool side, const HalfState& q, const HalfAcc& qa, double dt, double kr) {
   unsigned mask = 0u;
   auto lim = [&](int bit, double lo, double hi, double th, double qd, double qdd) {
-    const double vn = qd + dt * qdd;
+    const double r = th > hi ? th - hi : th - lo;
+    const double vn = qd + dt * (qdd + kr * r);
     if ((th > hi && vn > 0.0) || (th < lo && vn < 0.0)) mask |= 1u << bit;
   };
   lim(0, C_JRANGE[10][0], C_JRANGE[10][1], q.th11, q.qd11, qa.q11);
@@ -1097,21 +1101,22 @@ DEVFN unsigned limit_lock_mask(bool side, const HalfState& q, const HalfAcc& qa,
   for (int k = 0; k < 4; ++k) lim(6 + k, side ? C_JRANGE[15 + k][0] : C_JRANGE[11 + k][0], side ? C_JRANGE[15 + k][1] : C_JRANGE[11 + k][1], q.thA[k], q.qdA[k], qa.qA[k]);
   return mask;
 }
-DEVFN void apply_lock_mask(unsigned mask, const HalfState& q, double dt, HalfTau& tau, HalfTau& add) {
-  auto ap = [&](int bit, double qd, double& tq, double& ad) {
+DEVFN void apply_lock_mask(bool side, unsigned mask, const HalfState& q, double dt, double kr, HalfTau& tau, HalfTau& add) {
+  auto ap = [&](int bit, double lo, double hi, double th, double qd, double& tq, double& ad) {
     const bool lk = ((mask >> bit) & 1u) != 0u;
+    const double r = th > hi ? th - hi : th - lo;
     ad = lk ? LOCK_ARM : 0.0;
-    tq = lk ? (-qd / dt) * LOCK_ARM : tq;
+    tq = lk ? (-qd / dt - kr * r) * LOCK_ARM : tq;
   };
-  ap(0, q.qd11, tau.t11, add.t11);
+  ap(0, C_JRANGE[10][0], C_JRANGE[10][1], q.th11, q.qd11, tau.t11, add.t11);
 #pragma unroll
-  for (int k = 0; k < 5; ++k) ap(1 + k, q.qdL[k], tau.tL[k], add.tL[k]);
+  for (int k = 0; k < 5; ++k) ap(1 + k, side ? C_JRANGE[5 + k][0] : C_JRANGE[k][0], side ? C_JRANGE[5 + k][1] : C_JRANGE[k][1], q.thL[k], q.qdL[k], tau.tL[k], add.tL[k]);
 #pragma unroll
-  for (int k = 0; k < 4; ++k) ap(6 + k, q.qdA[k], tau.tA[k], add.tA[k]);
+  for (int k = 0; k < 4; ++k) ap(6 + k, side ? C_JRANGE[15 + k][0] : C_JRANGE[11 + k][0], side ? C_JRANGE[15 + k][1] : C_JRANGE[11 + k][1], q.thA[k], q.qdA[k], tau.tA[k], add.tA[k]);
 }
-DEVFN bool limit_locks(bool side, const HalfState& q, const HalfAcc& qa, double dt, HalfTau& tau, HalfTau& add) {
-  const unsigned mask = limit_lock_mask(side, q, qa, dt);
-  apply_lock_mask(mask, q, dt, tau, add);
+DEVFN bool limit_locks(bool side, const HalfState& q, const HalfAcc& qa, double dt, double kr, HalfTau& tau, HalfTau& add) {
+  const unsigned mask = limit_lock_mask(side, q, qa, dt, kr);
+  apply_lock_mask(side, mask, q, dt, kr, tau, add);
   return mask != 0u;
 }
 // The step with the rows: dyn_split_kernels.hip step_stance_shared_lim -- the accelerations are ONE function there, called once without

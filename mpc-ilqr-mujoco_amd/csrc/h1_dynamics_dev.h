@@ -61,6 +61,8 @@ struct DynParams {
                     // step_stance<., true>); sits in what was padding: the layout of the rest (kernel arguments) does not move
   double soft;      // diagonal softness of the stance constraint (1 / kg)
   double mu;        // sliding friction coefficient of mode 3
+  double lim_k;     // restoring stiffness of the joint-limit rows (1 / s^2): the row prescribes qacc_i = -v_i / h - lim_k r_i, r_i the violation
+                    // (MuJoCo's solref reference acceleration in its hard limit; 0: the pure stop)
 };
 // the plant needs the constrained step (stance rows and / or joint-limit rows): the two-lane kernels with the shared constrained step
 __host__ __device__ inline bool constrained(const DynParams& d) { return d.contact != 0 || d.limits != 0; }

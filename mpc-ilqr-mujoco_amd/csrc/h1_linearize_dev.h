@@ -88,8 +88,9 @@ DEVFN void lane_direction(int lane, int& kind, int& idx) {
 
 // tangent of (v_i, a_i, f_i) of body I given its parent's tangent (pv, pa).  The body index is a template parameter:
 // joint axis, offset and inertia are immediates (h1_model_constexpr.h) and no array is indexed at run time.
-// (LIM, joint-limit rows: lockc[i] = -1 / h for a hinge the step stops -- its acceleration is prescribed, qacc_i = -v_i / h, so the
-// direction of its own rate carries d qacc_i = -1 / h through the inverse-dynamics tangent -- and 0 for the others)
+// (LIM, joint-limit rows: lockc[i] = -1 / h for a hinge the step stops -- its acceleration is prescribed, qacc_i = -v_i / h - lim_k r_i, so the
+// direction of its own rate carries d qacc_i = -1 / h through the inverse-dynamics tangent, the direction of its own angle -lim_k = lockc[i] *
+// lockc[0] with lockc[0] = h lim_k riding in the pelvis' unused entry -- and 0 for the others)
 template <int I, bool LIM = false>
 DEVFN void tan_body_fwd(const LinShared& L, int kind, int idx, const double* pv, const double* pa,
                         double* dv, double* da, double* df, const double* lockc = nullptr) {
@@ -115,7 +116,7 @@ DEVFN void tan_body_fwd(const LinShared& L, int kind, int idx, const double* pv,
     h1r::cross_axis<ax>(xa + 3, t);      da[3] += mt * t[0]; da[4] += mt * t[1]; da[5] += mt * t[2];
   }
   dv[ax] += md;
-  if constexpr (LIM) da[ax] += md * lockc[I];
+  if constexpr (LIM) da[ax] += (md + mt * lockc[0]) * lockc[I];      // (lockc[0] = h * lim_k: the angle's direction carries d qacc_i = -lim_k)
   {  // + dv x (S qd)
     double t[3];
     h1r::cross_axis<ax>(dv, t);     da[0] += qd * t[0]; da[1] += qd * t[1]; da[2] += qd * t[2];
@@ -232,7 +233,7 @@ DEVFN void tan_body_fwd2(const LinShared& L, bool side, int kind, int idx, const
     h1r::cross_axis<ax>(xa + 3, t);      da[3] += mt * t[0]; da[4] += mt * t[1]; da[5] += mt * t[2];
   }
   dv[ax] += md;
-  if constexpr (LIM) da[ax] += md * lockc[i];
+  if constexpr (LIM) da[ax] += (md + mt * lockc[0]) * lockc[i];
   {
     double t[3];
     h1r::cross_axis<ax>(dv, t);     da[0] += qd * t[0]; da[1] += qd * t[1]; da[2] += qd * t[2];

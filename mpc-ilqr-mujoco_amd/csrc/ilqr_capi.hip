@@ -223,7 +223,7 @@ int ilqr_hip_create(ilqr_hip_ctx** out, int device, int batch, int horizon, doub
   if (rc != ILQR_OK) { *out = c; return rc; }
   if (ilqr::backward_needs_lds_attr() != 0) { c->err = "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed"; *out = c; return ILQR_ERR_HIP; }
   h1::ProblemDev& P = c->P;
-  P.N = horizon; P.dyn.h = dt; P.dyn.g[0] = 0; P.dyn.g[1] = 0; P.dyn.g[2] = -9.81; P.dyn.contact = 0; P.dyn.soft = 1e-5; P.dyn.mu = 1.0; P.dyn.limits = 0;
+  P.N = horizon; P.dyn.h = dt; P.dyn.g[0] = 0; P.dyn.g[1] = 0; P.dyn.g[2] = -9.81; P.dyn.contact = 0; P.dyn.soft = 1e-5; P.dyn.mu = 1.0; P.dyn.limits = 0; P.dyn.lim_k = 0.0;
   for (int i = 0; i < ILQR_NX; ++i) { P.Q[i] = 1.0; P.Qf[i] = 1.0; }
   for (int i = 0; i < ILQR_NU; ++i) P.R[i] = 1.0;
   P.w_com = P.w_com_vel = P.w_ee_pos = P.w_ee_vel = P.w_upright = P.w_balance = 0.0;
@@ -376,7 +376,7 @@ static int rollout_kernel_identity(const h1::ProblemDev& P) {
   return ilqr::variant_scalar_dyn() ? 2 : ((ilqr::variant_rollout_split() || h1::constrained(P.dyn)) ? 1 : 0);
 }
 static bool same_dyn(const h1::DynParams& a, const h1::DynParams& b) {
-  return a.h == b.h && a.g[0] == b.g[0] && a.g[1] == b.g[1] && a.g[2] == b.g[2] && a.contact == b.contact && a.soft == b.soft && a.mu == b.mu && a.limits == b.limits;
+  return a.h == b.h && a.g[0] == b.g[0] && a.g[1] == b.g[1] && a.g[2] == b.g[2] && a.contact == b.contact && a.soft == b.soft && a.mu == b.mu && a.limits == b.limits && a.lim_k == b.lim_k;
 }
 static int cold_start_device(ilqr_hip_ctx* c, const double* x0_dev, const double* uinit_dev) {
   const size_t B = c->B, N = c->N;
@@ -1025,6 +1025,11 @@ int ilqr_hip_set_joint_limits(ilqr_hip_ctx* c, int on) {
   enter(c);
   if (on && ilqr::variant_scalar_dyn()) { c->err = "joint-limit rows exist on the two-lane kernels only; unset ILQR_DYN=s"; return ILQR_ERR_UNSUPPORTED; }
   c->P.dyn.limits = on ? 1 : 0;     // (a nominal rolled under the other setting is recognised by same_dyn)
+  return ILQR_OK;
+}
+int ilqr_hip_set_joint_limit_stiffness(ilqr_hip_ctx* c, double k) {
+  if (!c || !(k >= 0.0) || !std::isfinite(k)) return ILQR_ERR_ARG;
+  c->P.dyn.lim_k = k;          // (a nominal rolled under another stiffness is recognised by same_dyn)
   return ILQR_OK;
 }
 int ilqr_hip_set_friction(ilqr_hip_ctx* c, double mu) {

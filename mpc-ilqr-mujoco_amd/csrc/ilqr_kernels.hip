@@ -188,13 +188,20 @@ DEVFN void lin2_store_B(const LinShared& L, int c, double* Ag, double* Bg, Cfn&&
 // instantiation of its own: the default kernel keeps its machine code.
 template <bool LIM> struct LinLockOpt { double c[2][H1_NB]; DEVFN double (*get())[H1_NB] { return c; } };
 template <> struct LinLockOpt<false> { DEVFN double (*get())[H1_NB] { return nullptr; } };
+// (lim_k, the restoring stiffness: qacc_i = -v_i / h - lim_k r_i on a constrained hinge, so its own angle carries d qacc_i = -lim_k as well;
+// c[0] -- the pelvis has no hinge -- carries h lim_k to the seeds of tan_body_fwd*)
 template <bool LIM>
-DEVFN void lin_lock_flags(LinShared& L, double* c, int tid7, double h) {
-  if constexpr (LIM) { if (tid7 < H1_NB) c[tid7] = (tid7 >= 1 && L.u.m.Dinv[tid7] < 1e-200) ? -1.0 / h : 0.0; }
+DEVFN void lin_lock_flags(LinShared& L, double* c, int tid7, double h, double lim_k) {
+  if constexpr (LIM) { if (tid7 < H1_NB) c[tid7] = tid7 == 0 ? h * lim_k : ((L.u.m.Dinv[tid7] < 1e-200) ? -1.0 / h : 0.0); }
 }
 template <bool LIM>
 DEVFN void lin_lock_rows(LinShared& L, const double* c, int tid7) {
-  if constexpr (LIM) { if (tid7 >= 1 && tid7 < H1_NB && c[tid7] != 0.0) L.dT[5 + tid7][dir_lane(DIR_THETADOT, tid7)] = c[tid7]; }
+  if constexpr (LIM) {
+    if (tid7 >= 1 && tid7 < H1_NB && c[tid7] != 0.0) {
+      L.dT[5 + tid7][dir_lane(DIR_THETADOT, tid7)] = c[tid7];
+      if (c[0] != 0.0) L.dT[5 + tid7][dir_lane(DIR_THETA, tid7)] = c[tid7] * c[0];
+    }
+  }
 }
 template <bool PACK, bool LIM = false>
 __global__ void __launch_bounds__(256, 3) k_lin_tangent2(DevState S, ProblemDev P, int mode, const int* list, const int* count) {
@@ -233,7 +240,7 @@ __global__ void __launch_bounds__(256, 3) k_lin_tangent2(DevState S, ProblemDev 
   }
   __syncthreads();
   LSTAMP(0)
-  if constexpr (LIM) lin_lock_flags<LIM>(L2[ks], lockc2[ks], tid7, P.dyn.h);
+  if constexpr (LIM) lin_lock_flags<LIM>(L2[ks], lockc2[ks], tid7, P.dyn.h, P.dyn.lim_k);
   // (one barrier for all four waves between the two halves: a __syncthreads() inside each wave's own branch happens to work --
   // s_barrier counts waves -- but matching barriers across divergent code paths is not something to lean on)
   MinvCarry Cm;
@@ -378,7 +385,7 @@ __global__ void __launch_bounds__(256, 2) k_lin_tangent2c(DevState S, ProblemDev
   }
   __syncthreads();
   LSTAMP(0)
-  if constexpr (LIM) lin_lock_flags<LIM>(L2[ks], lockc2[ks], tid7, P.dyn.h);
+  if constexpr (LIM) lin_lock_flags<LIM>(L2[ks], lockc2[ks], tid7, P.dyn.h, P.dyn.lim_k);
   if (wv == 2) { const int c = lane & 31; if (c < H1_NV) lin_minv_lane_c(L2[lane >> 5], C2[lane >> 5], c); }          // Minv columns of both knots
   else if (wv == 3) { const int c = lane & 31; if (c < 12) lin_minv_lane_c(L2[lane >> 5], C2[lane >> 5], H1_NV + c); }   // unit-wrench columns (G, C) of both
   else if (wv == 0 && (lane & 31) < 2) lin_contact_rhs(L2[lane >> 5], C2[lane >> 5], P.dyn.g, lane & 31, FRIC ? Z2 + (lane >> 5) : nullptr);

@@ -34,7 +34,7 @@ EXPORTS = [
     "ilqr_hip_set_trajectory", "ilqr_hip_stage_rollout", "ilqr_hip_stage_linearize", "ilqr_hip_stage_cost_quadratics",
     "ilqr_hip_stage_backward_pass", "ilqr_hip_stage_line_search", "ilqr_hip_stage_total_cost",
     "ilqr_hip_get_linearization", "ilqr_hip_set_linearization", "ilqr_hip_get_quadratics", "ilqr_hip_set_quadratics",
-    "ilqr_hip_get_value_function", "ilqr_hip_step", "ilqr_hip_step_stance", "ilqr_hip_set_contact_mode", "ilqr_hip_set_friction", "ilqr_hip_set_joint_limits", "ilqr_hip_enable_profiling", "ilqr_hip_get_stage_ms", "ilqr_hip_get_adopt_mismatches", "ilqr_hip_get_iterations_enqueued", "ilqr_hip_get_speculative_iterations", "ilqr_hip_get_split_iterations", "ilqr_hip_set_profiled_stages",
+    "ilqr_hip_get_value_function", "ilqr_hip_step", "ilqr_hip_step_stance", "ilqr_hip_set_contact_mode", "ilqr_hip_set_friction", "ilqr_hip_set_joint_limits", "ilqr_hip_set_joint_limit_stiffness", "ilqr_hip_enable_profiling", "ilqr_hip_get_stage_ms", "ilqr_hip_get_adopt_mismatches", "ilqr_hip_get_iterations_enqueued", "ilqr_hip_get_speculative_iterations", "ilqr_hip_get_split_iterations", "ilqr_hip_set_profiled_stages",
     "ilqr_hip_payload_width", "ilqr_hip_comm_available", "ilqr_hip_comm_get_unique_id", "ilqr_hip_comm_init", "ilqr_hip_comm_destroy", "ilqr_hip_comm_world", "ilqr_hip_comm_rank",
     "ilqr_hip_gather_first_knot",
     "ilqr_hip_reference_kinematics", "ilqr_hip_reference_com_velocity", "ilqr_hip_foot_clearance", "ilqr_hip_gravity_compensation", "ilqr_hip_stream",
@@ -372,6 +372,11 @@ class BatchedILQR:
     def set_joint_limits(self, on=True):
         """Joint-limit rows of the plant (include/ilqr_hip.h): a hinge past its range that the step would still move outward is stopped."""
         self._chk(self.L.ilqr_hip_set_joint_limits(self.h, int(bool(on))))
+
+    def set_joint_limit_stiffness(self, k):
+        """Restoring stiffness of the joint-limit rows (include/ilqr_hip.h): qacc_i = -v_i / h - k r_i on a constrained hinge; 0 = the pure stop,
+        1 / (2 h)^2 = MuJoCo's default solref time constant."""
+        self._chk(self.L.ilqr_hip_set_joint_limit_stiffness(self.h, C.c_double(float(k))))
 
     def enable_profiling(self, on=True):
         self._chk(self.L.ilqr_hip_enable_profiling(self.h, int(bool(on))))

@@ -36,6 +36,8 @@ struct DynParams {
   double soft = 1e-5;    // diagonal softness of the stance constraint (1 / kg), keeps J Minv J^T invertible with straight knees
   int limits = 0;        // 1: joint-limit rows (SURVEY Appendix C #7, h1.xml jnt_range enforced by mj_step): a hinge past its range that the
                          //    step would still move outward is stopped (h1_step)
+  double lim_k = 0.0;    // restoring stiffness of those rows (1 / s^2): the row prescribes qacc_i = -v_i / h - lim_k r_i, r_i the violation
+                         //    (MuJoCo's solref reference acceleration in its hard limit; 0: the pure stop of round 5)
 };
 
 // ---------- small dense helpers (row-major) ----------
@@ -534,10 +536,16 @@ inline void h1_step(const T* x, const T* u, const DynParams& P, T* xn, const int
     //     Mhat qacc + bias - J^T lambda - E^T mu = tau,   E qacc = -v_L / h   (+ the stance rows, solved on the system with these hinges prescribed)
     // -- Featherstone's hybrid dynamics through the same articulated-body recursion; the set is decided once, from the unlimited step.
     int lock[H1_NJ], any = 0; T lockacc[H1_NJ];
+    // lim_k > 0 (round 6): the restoring term of MuJoCo's constraint reference a_ref = -b v - k r in its hard limit (b = 1 / h for the
+    // clamped time constant 2 h, k = 1 / (2 h)^2 = 625 at h = 0.02): the row prescribes qacc_i = -v_i / h - k r_i, r_i = q_i - hi_i > 0 or
+    // q_i - lo_i < 0, and is active when the unlimited step falls short of that on the outward side (k = 0: exactly the stop above).
     for (int i = 0; i < H1_NJ; ++i) {
-      const double q = val(x[7 + i]), vnext = val(x[H1_NQ + 6 + i]) + h * val(qacc[6 + i]);
+      const double q = val(x[7 + i]);
+      const double r = q > H1_JRANGE[i][1] ? q - H1_JRANGE[i][1] : (q < H1_JRANGE[i][0] ? q - H1_JRANGE[i][0] : 0.0);
+      const double vnext = val(x[H1_NQ + 6 + i]) + h * (val(qacc[6 + i]) + P.lim_k * r);
       lock[i] = ((q > H1_JRANGE[i][1] && vnext > 0.0) || (q < H1_JRANGE[i][0] && vnext < 0.0)) ? 1 : 0;
-      lockacc[i] = -x[H1_NQ + 6 + i] / h;
+      const T rT = q > H1_JRANGE[i][1] ? x[7 + i] - H1_JRANGE[i][1] : (q < H1_JRANGE[i][0] ? x[7 + i] - H1_JRANGE[i][0] : x[7 + i] * 0.0);
+      lockacc[i] = -x[H1_NQ + 6 + i] / h - P.lim_k * rT;
       any |= lock[i];
     }
     if (any) {

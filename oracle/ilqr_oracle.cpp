@@ -309,6 +309,7 @@ void orc_set_contact_mode(void* s, int mode, double soft) { Solver* S = (Solver*
 void orc_set_friction(void* s, double mu) { ((Solver*)s)->P.dyn.mu = mu; }   // sliding friction coefficient of contact mode 3
 void orc_joint_ranges(double* out /*[19][2]*/) { for (int i = 0; i < H1_NJ; ++i) { out[2 * i] = H1_JRANGE[i][0]; out[2 * i + 1] = H1_JRANGE[i][1]; } }
 void orc_set_joint_limits(void* s, int on) { ((Solver*)s)->P.dyn.limits = on ? 1 : 0; }   // joint-limit rows of the plant (h1_step)
+void orc_set_joint_limit_stiffness(void* s, double k) { ((Solver*)s)->P.dyn.lim_k = k; }   // restoring stiffness of those rows (0: pure stop)
 void orc_rollout(void* s) { ((Solver*)s)->rollout_nominal(); }
 void orc_linearize(void* s) { ((Solver*)s)->linearize(); }
 void orc_cost_quadratics(void* s) { ((Solver*)s)->cost_quadratics(); }

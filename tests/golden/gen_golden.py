@@ -235,7 +235,7 @@ def integrate_c(q, v, qacc, h):
     return np.concatenate([qn, vn])
 
 
-def kane_step_c(bodies, ctrlrange, x, u, h, grav, stance=(1, 1), contact=0, soft=1e-5, damping=1.0, armature=0.1, want=False, mu=1.0, lock=()):
+def kane_step_c(bodies, ctrlrange, x, u, h, grav, stance=(1, 1), contact=0, soft=1e-5, damping=1.0, armature=0.1, want=False, mu=1.0, lock=(), lock_acc=None):
     """One MuJoCo-semantics step of the constraint-free plant (contact = 0) or with the feet the schedule
     marks as stance held by velocity-level rigid constraints over the step (contact = 1 bilateral, 2 unilateral: a foot whose
     normal force would pull is released and the rest solved again, once):
@@ -249,7 +249,8 @@ def kane_step_c(bodies, ctrlrange, x, u, h, grav, stance=(1, 1), contact=0, soft
     which the sticking solution pulled (the direction that opposes the slip), i.e. its normal multiplier acts along up + mu t while the
     constraint row stays the normal one -- an unsymmetric system, solved once.
     lock: hinges (0..18) whose acceleration is prescribed, qacc_i = -v_i / h (joint-limit rows, kane_step_lim): rigid rows E qacc = -v_L / h
-    with multipliers of their own in every system solved here."""
+    with multipliers of their own in every system solved here; lock_acc (optional, one value per locked hinge): the prescribed
+    accelerations instead (kane_step_lim with a restoring stiffness: -v_i / h - k r_i)."""
     q, v = x[:26], x[26:]
     z25 = np.zeros(25)
     bias, feet0 = kane_eval_c(bodies, q, v, z25, grav, armature)
@@ -269,7 +270,7 @@ def kane_step_c(bodies, ctrlrange, x, u, h, grav, stance=(1, 1), contact=0, soft
     nl = len(lock)
     E = np.zeros((nl, 25)); bl = np.zeros(nl, dtype=rhs.dtype)
     for r_, i_ in enumerate(lock):
-        E[r_, 6 + i_] = 1.0; bl[r_] = -v[6 + i_] / h
+        E[r_, 6 + i_] = 1.0; bl[r_] = -v[6 + i_] / h if lock_acc is None else lock_acc[r_]
     stage = 0                      # 0: rigid set; 1: after the unilateral check; 2: after the Coulomb check
     while True:
         rows = [f for f in range(2) if act[f]]
@@ -341,23 +342,29 @@ def kane_step_c(bodies, ctrlrange, x, u, h, grav, stance=(1, 1), contact=0, soft
     return xn
 
 
-def kane_step_lim(bodies, ctrlrange, x, u, h, grav, **kw):
+def kane_step_lim(bodies, ctrlrange, x, u, h, grav, stiffness=0.0, **kw):
     """The step with joint-limit rows (h1.xml jnt_range, enforced by mj_step; restated rigid and at velocity level like the stance rows):
     a hinge past its range that the unlimited step would still move outward, (q_i > hi_i and v_i + h qacc_i > 0) or (q_i < lo_i and
     v_i + h qacc_i < 0), is stopped over the step: E qacc = -v_L / h joins the KKT system, and the step (stance decisions included) is
-    taken again with that set.  Returns (x_next, lock set, x_next of the unlimited step, margins of the decisions)."""
+    taken again with that set.  Returns (x_next, lock set, x_next of the unlimited step, margins of the decisions).
+    stiffness k > 0 (round 6): the hard limit of MuJoCo's solref reference acceleration a_ref = -b v - k r (r_i = q_i - hi_i > 0 or
+    q_i - lo_i < 0 the violation; b = 1 / h is MuJoCo's damping for its clamped time constant 2 h, k = 1 / (2 h)^2 its stiffness): the
+    row prescribes qacc_i = -v_i / h - k r_i, i.e. v_i+ = -h k r_i pushes the hinge back, and the row is active when the unlimited
+    step falls short of that acceleration on the outward side: q_i > hi_i and qacc_i > -v_i / h - k r_i (mirrored below lo_i)."""
     kw = dict(kw); kw.pop("want", None)
     xn0, qacc0, _, _, _, _ = kane_step_c(bodies, ctrlrange, x, u, h, grav, want=True, **kw)
     rng = np.array([b["rng"] for b in bodies if b["rng"] is not None])
     assert rng.shape == (19, 2)
     th, qd = x[7:26], x[32:51]
-    vnext = qd + h * qacc0[6:]
+    r = np.where(th > rng[:, 1], th - rng[:, 1], np.where(th < rng[:, 0], th - rng[:, 0], 0.0))
+    vnext = qd + h * (qacc0[6:] + stiffness * r)          # (v_i + h qacc_i for k = 0)
     lock = [i for i in range(19) if (th[i] > rng[i, 1] and vnext[i] > 0.0) or (th[i] < rng[i, 0] and vnext[i] < 0.0)]
     viol = [i for i in range(19) if th[i] > rng[i, 1] or th[i] < rng[i, 0]]
     margin = min([abs(vnext[i]) for i in viol], default=np.inf)
     if not lock:
         return xn0, lock, xn0, margin
-    xn = kane_step_c(bodies, ctrlrange, x, u, h, grav, lock=tuple(lock), **kw)
+    acc = None if stiffness == 0.0 else [-qd[i] / h - stiffness * r[i] for i in lock]
+    xn = kane_step_c(bodies, ctrlrange, x, u, h, grav, lock=tuple(lock), lock_acc=acc, **kw)
     return xn, lock, xn0, margin
 
 
@@ -991,10 +998,63 @@ def gen_limits():
           "max |x_next - unlimited|", [float(np.abs(a - b).max()) for a, b in zip(out["x_next"], out["x_next_unlimited"])])
 
 
+def gen_limits_stiff():
+    """joint_limit_stiffness_golden.npz: the joint-limit rows with the restoring stiffness k = 1 / (2 h)^2 = 625 (kane_step_lim): hinges past
+    their range moving outward, standing still, and moving back in too slowly (all constrained: pushed back at v+ = -h k r) or fast enough
+    (left alone), on the constraint-free plant and with unilateral stance; decisions closer than 0.05 rad/s to the switch are rejected."""
+    bodies, ctrl = load_mjcf()
+    rngj = np.array([b["rng"] for b in bodies if b["rng"] is not None])
+    rng = np.random.default_rng(2031)
+    h, grav, k = 0.02, np.array([0.0, 0.0, -9.81]), 625.0
+    out = dict(x=[], u=[], stance=[], contact=[], x_next=[], x_next_unlimited=[], lock=[])
+    want = {(0, 0): 1, (0, 1): 3, (0, 2): 3, (2, 0): 1, (2, 1): 2, (2, 2): 2}
+    slow_in = 0
+    tries = 0
+    while any(v > 0 for v in want.values()) and tries < 4000:
+        tries += 1
+        contact = [0, 2][tries % 2]
+        x = np.zeros(51); x[2] = 1.0432; x[3] = 1.0
+        aa = rng.uniform(-0.05, 0.05, 3); ang = np.linalg.norm(aa); x[3] = np.cos(ang / 2); x[4:7] = np.sin(ang / 2) / ang * aa
+        x[7:26] = rng.uniform(-0.15, 0.15, 19)
+        x[26:] = rng.uniform(-0.4, 0.4, 25)
+        nv = int(rng.integers(0, 4))
+        inward = []
+        for i in rng.choice(19, size=nv, replace=False):
+            up = rng.random() < 0.5
+            x[7 + i] = rngj[i, 1] + rng.uniform(0.01, 0.08) if up else rngj[i, 0] - rng.uniform(0.01, 0.08)
+            sgn = 1 if rng.random() < 0.5 else -1          # half of them already move back in: slowly (still constrained) or fast (left alone)
+            x[32 + i] = rng.uniform(0.05, 2.5) * (1 if up else -1) * sgn
+            if sgn < 0:
+                inward.append(int(i))
+        u = rng.uniform(-20, 20, 19)
+        stance = (1, 1) if tries % 3 else (1, 0)
+        xn, lock, xn0, margin = kane_step_lim(bodies, ctrl, x, u, h, grav, stiffness=k, stance=stance, contact=contact)
+        key = (contact, min(len(lock), 2))
+        if margin < 0.05 or want.get(key, 0) <= 0 or not np.all(np.isfinite(xn)):
+            continue
+        want[key] -= 1
+        slow_in += len([i for i in inward if i in lock])
+        lk = np.zeros(19, dtype=int); lk[lock] = 1
+        for kk, val_ in (("x", x), ("u", u), ("stance", np.array(stance)), ("contact", contact), ("x_next", xn), ("x_next_unlimited", xn0), ("lock", lk)):
+            out[kk].append(val_)
+    assert all(v == 0 for v in want.values()), want
+    assert slow_in >= 1, "no case with a hinge that moves back in too slowly"
+    # what the row does: v_i+ = -h k r_i on every constrained hinge
+    for x, xn, lk in zip(out["x"], out["x_next"], out["lock"]):
+        for i in np.flatnonzero(lk):
+            r = x[7 + i] - rngj[i, 1] if x[7 + i] > rngj[i, 1] else x[7 + i] - rngj[i, 0]
+            assert abs(xn[32 + i] + h * k * r) < 1e-9, (i, xn[32 + i], -h * k * r)
+    np.savez(os.path.join(HERE, "joint_limit_stiffness_golden.npz"), h=h, gravity=grav, soft=1e-5, stiffness=k, jrange=rngj, **{kk: np.array(v) for kk, v in out.items()})
+    print("joint-limit stiffness golden:", len(out["x"]), "cases; constrained hinges", [np.flatnonzero(l).tolist() for l in out["lock"]], "of which moving back in:", slow_in)
+
+
 if __name__ == "__main__":
     import sys
     if len(sys.argv) > 1 and sys.argv[1] == "limits":
         gen_limits()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "limits_stiff":
+        gen_limits_stiff()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "friction":
         gen_friction()

@@ -138,6 +138,9 @@ class Oracle:
         """Sliding friction coefficient of contact mode 3 (unilateral + Coulomb release)."""
         self.L.orc_set_friction(self.h, C.c_double(mu))
 
+    def set_joint_limit_stiffness(self, k):
+        self.L.orc_set_joint_limit_stiffness(self.h, C.c_double(float(k)))
+
     def set_joint_limits(self, on):
         """Joint-limit rows of the plant: a hinge past its range that the step would still move outward is stopped (h1_step)."""
         self.L.orc_set_joint_limits(self.h, int(bool(on)))

@@ -671,6 +671,103 @@ def test_joint_limit_rows_step_and_solve_match_golden_and_oracle():
     assert checked == n
 
 
+def test_joint_limit_rows_with_restoring_stiffness_match_golden_and_oracle():
+    """Round 6: ilqr_hip_set_joint_limit_stiffness (include/ilqr_hip.h) -- the joint-limit rows prescribe MuJoCo's constraint reference
+    acceleration in its hard limit, qacc_i = -v_i / h - k r_i, so a hinge outside its range is pushed back (v_i+ = -h k r_i: mj_step pushes
+    it back too, robot_utils.cpp:113-114; the pure stop of round 5 does not).  (i) the step against the dense NumPy KKT system with explicit
+    rows (tests/golden/joint_limit_stiffness_golden.npz, k = 1 / (2 h)^2 = 625) and against the oracle, constraint-free plant and unilateral
+    stance, none / one / several hinges constrained, hinges that drift back in too slowly among them; k = 0 afterwards is the round-5 step
+    bit for bit; (ii) solves with forward-difference and with analytic Jacobians from states with a knee and an elbow past their ranges
+    against the oracle; the nominal re-rollout reproduces the accepted candidate (adopt_mismatches == 0); (iii) the analytic Jacobians
+    against the oracle's forward-mode AD: the constrained hinge's velocity row is -h k e_theta (its own angle) and nothing else."""
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "joint_limit_stiffness_golden.npz"))
+    g0 = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "joint_limit_golden.npz"))
+    n, k, h = len(g["x"]), float(g["stiffness"]), float(g["h"])
+    prob, x0, ui = make(2, seed=31, gravity=list(g["gravity"]), walking=True)
+    s = _solver(2); s.set_problem(prob)
+    o = oracle_for(prob)
+    constrained = 0
+    for i in range(n):
+        cm = int(g["contact"][i])
+        xs = np.tile(g["x"][i], (2, 1)); us = np.tile(g["u"][i], (2, 1))
+        s.set_contact_mode(cm, float(g["soft"])); s.set_joint_limits(True); s.set_joint_limit_stiffness(k)
+        got = s.step_stance(xs, us, int(g["stance"][i][0]), int(g["stance"][i][1]))
+        o.set_contact_mode(cm, float(g["soft"])); o.set_joint_limits(True); o.set_joint_limit_stiffness(k)
+        want = o.step_stance(g["x"][i], g["u"][i], g["stance"][i])
+        assert np.array_equal(got[0], got[1])
+        assert np.abs(got[0] - g["x_next"][i]).max() < 1e-9 * max(1.0, np.abs(g["x_next"][i]).max()), (i, np.abs(got[0] - g["x_next"][i]).max())
+        assert np.abs(got[0] - want).max() < 1e-9 * max(1.0, np.abs(want).max())
+        for j in np.flatnonzero(g["lock"][i]):
+            r = g["x"][i][7 + j] - (g["jrange"][j, 1] if g["x"][i][7 + j] > g["jrange"][j, 1] else g["jrange"][j, 0])
+            assert abs(got[0][32 + j] + h * k * r) < 1e-10
+        constrained += int(g["lock"][i].any())
+    assert constrained >= 8
+    # k = 0 again: the round-5 step, bit for bit, and its golden
+    for i in range(len(g0["x"])):
+        cm = int(g0["contact"][i])
+        xs = np.tile(g0["x"][i], (2, 1)); us = np.tile(g0["u"][i], (2, 1))
+        s.set_contact_mode(cm, float(g0["soft"])); s.set_joint_limits(True); s.set_joint_limit_stiffness(0.0)
+        got = s.step_stance(xs, us, int(g0["stance"][i][0]), int(g0["stance"][i][1]))
+        assert np.abs(got[0] - g0["x_next"][i]).max() < 1e-9 * max(1.0, np.abs(g0["x_next"][i]).max())
+        for j in np.flatnonzero(g0["lock"][i]):
+            assert abs(got[0][32 + j]) < 1e-12
+    s.close()
+    # (ii) solves: left knee (hinge 3) past its upper limit and moving out, right elbow (hinge 18) past its lower limit moving back in slowly
+    Bs = 3
+    for cm in (0, 2):
+        prob, x0, ui = make(Bs, seed=33, gravity=list(g["gravity"]) if cm else None, walking=True)
+        x0 = x0.copy()
+        x0[:, 7 + 3] = 2.09; x0[:, 32 + 3] = 1.5
+        x0[1:, 7 + 18] = -1.29; x0[1:, 32 + 18] = 0.1
+        for jm, ktol in ((1, 3e-4), (0, 1e-5)):      # (forward differences: round-off / eps of two independent FD evaluations through three iterations, see test_fixed_iteration_mode_and_fd_mode_parity)
+            s = _solver(Bs); s.set_problem(prob); s.set_contact_mode(cm); s.set_joint_limits(True); s.set_joint_limit_stiffness(k)
+            s.set_options(jacobian_mode=jm, fd_eps=1e-5, early_exit=False); s.set_max_iterations(3)
+            s.initialize(x0, ui); cost = s.solve(x0)
+            tc, ta, tl = s.trace()
+            assert s.adopt_mismatches() == 0
+            differs = 0
+            for b in range(Bs):
+                ob = oracle_for(prob, jac_mode=jm, fd_eps=1e-5, early_exit=0, max_iter=3); ob.set_contact_mode(cm); ob.set_joint_limits(True); ob.set_joint_limit_stiffness(k)
+                ob.initialize(x0[b], ui[b]); ok, c = ob.solve(x0[b])
+                nn, oc, oa, ol_ = ob.trace()
+                assert nn == 3 and np.allclose(tc[b], oc, rtol=1e-5) and np.array_equal(ta[b], oa), (cm, jm, tc[b], oc, ta[b], oa)
+                assert abs(cost[b] - c) <= 1e-5 * abs(c) and rel(s.gains_K()[b], ob.get("K")) < ktol and rel(s.xbar()[b], ob.get("xbar")) < 1e-5
+                o2 = oracle_for(prob, jac_mode=jm, fd_eps=1e-5, early_exit=0, max_iter=3); o2.set_contact_mode(cm); o2.set_joint_limits(True)
+                o2.initialize(x0[b], ui[b]); _, c2 = o2.solve(x0[b])
+                differs += int(abs(c2 - c) > 1e-6 * abs(c))
+            assert differs >= 2                              # the restoring term mattered (against the pure stop)
+            s.close()
+    # (iii) analytic Jacobians on the committed states against the oracle's forward-mode AD
+    N = 25
+    checked = 0
+    for cm in (0, 2):
+        for stance in ((1, 1), (1, 0)):
+            ids = [i for i in range(n) if int(g["contact"][i]) == cm and tuple(int(v) for v in g["stance"][i]) == stance]
+            if not ids:
+                continue
+            prob, x0, ui = make(len(ids), seed=28, gravity=list(g["gravity"]), walking=True)
+            prob["stance"] = np.ones_like(prob["stance"]) * np.array(stance, dtype=prob["stance"].dtype)
+            s = _solver(len(ids)); s.set_problem(prob); s.set_contact_mode(cm, float(g["soft"])); s.set_joint_limits(True); s.set_joint_limit_stiffness(k); s.set_options(jacobian_mode=0)
+            s.initialize(x0, ui)
+            X = np.repeat(g["x"][ids][:, None, :], N + 1, axis=1); U = np.repeat(g["u"][ids][:, None, :], N, axis=1)
+            s.set_trajectory(X, U); s.stage_linearize()
+            A, Bm = s.linearization()
+            for kk, i in enumerate(ids):
+                o = oracle_for(prob, jac_mode=0); o.set_contact_mode(cm, float(g["soft"])); o.set_joint_limits(True); o.set_joint_limit_stiffness(k)
+                o.set_trajectory(X[kk], U[kk]); o.linearize()
+                Ao, Bo = o.get("A")[0], o.get("B")[0]
+                assert np.abs(A[kk][0] - Ao).max() < 1e-8 * max(1.0, np.abs(Ao).max()), (cm, i, np.abs(A[kk][0] - Ao).max())
+                assert np.abs(Bm[kk][0] - Bo).max() < 1e-8 * max(1.0, np.abs(Bo).max())
+                for j in np.flatnonzero(g["lock"][i]):
+                    e = np.zeros(51); e[7 + j] = -h * k                 # v_j+ = -h k (theta_j - limit): its own angle and nothing else
+                    assert np.abs(A[kk][0][32 + j] - e).max() < 1e-10 and np.abs(Bm[kk][0][32 + j]).max() < 1e-12
+                    e2 = np.zeros(51); e2[7 + j] = 1.0 - h * h * k        # q_j+ = q_j + h v_j+
+                    assert np.abs(A[kk][0][7 + j] - e2).max() < 1e-10
+                checked += 1
+            s.close()
+    assert checked == n
+
+
 def test_forward_difference_jacobians_two_lane_vs_scalar_kernels():
     """The forward-difference Jacobians (the reference's scheme, robot_utils.cpp:120-160) on the two-lane step kernels equal the
     scalar kernels' (ILQR_DYN=s) to rounding / eps, with and without stance constraints."""
