@@ -11,7 +11,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PROF = os.path.join(ROOT, "profiles")
-TAG = "r05"
+TAG = "r06"
 
 
 def _summary_mod():
@@ -53,7 +53,7 @@ def test_kernel_figures_quoted_in_the_readme_for_this_round_match_the_kept_csvs(
     """README convention for the current round: a kernel figure is written  `k_name`: avg X ms  /  `k_name`: max X ms  /
     `k_name`: alone X ms  and nothing else counts as a quote of the CSVs (the prose cites rNN_summary.md for everything else)."""
     text = open(os.path.join(PROF, "README.md")).read()
-    start = text.index("## Round 5")
+    start = text.index("## Round 6")
     nxt = text.find("\n## Round ", start + 5)
     sec = text[start:nxt if nxt > 0 else len(text)]
     m = _summary_mod()

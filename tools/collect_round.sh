@@ -4,7 +4,7 @@
 #   -> gpurun_out/profiles_<tag>/ : <tag>_kernel_stats.csv, traffic_latest.json, <tag>_pmc/*, <tag>_sq_issue_wait_summary.txt,
 #      <tag>_fp64_instruction_mix.txt, <tag>_iteration_timeline.txt, <tag>_iteration_spans_fixed_and_early_exit.txt, <tag>_bench_lines/*.json
 set -e
-tag=${1:-r05}
+tag=${1:-r06}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 out=gpurun_out/profiles_$tag
 bash tools/collect_profiles.sh "$tag" > /dev/null 2>&1 || true
@@ -98,6 +98,8 @@ PY
   rm -rf "$out/alone_$st"
 done
 echo "[collect] stage kernels alone done"
+python3 tools/kernel_resources.py > "$out/${tag}_kernel_resources.txt" 2>/dev/null || true
+( cd mpc-ilqr-mujoco_amd/lib && ls -l libilqr_hip.so libilqr_hip_legacy.so | awk '{print $5, $9}' ) > "$out/${tag}_library_sizes.txt"
 python3 tools/round_summary.py "$out" "$tag" "${ILQR_GIT_HEAD:-unknown}" > "$out/${tag}_summary.md"
 echo "[collect] all done"
 ls "$out" "$L"
