@@ -107,6 +107,67 @@ __device__ __attribute__((noinline)) void step_stance_shared_kin_lim(h1s::HalfX*
                                                                      double soft, int st_left, int st_right, double mu, double kr) {
   step_lim<true>(hp, up, dt, gx, gy, gz, soft, 4, st_left, st_right, mu, kr);
 }
+// ---- joint-limit rows on the constraint-free plant (CONTACT == 5, round 6) ------------------------------------------------------
+// With no stance rows the first pass of the step with the rows IS the free step's recursion: it stays inlined, as in the constraint-free
+// kernels, and only a lane pair that has a hinge to constrain calls out -- state, controls and the mask cross that call through the
+// lane's own LDS column (the dynamics scratch is dead at that point; 44 of its 80 slots), the accelerations come back the same way, so
+// the caller keeps no address-taken state (by pointer, the mere presence of such a call cost the constraint-free line search 20 %, round 3).
+// Until round 6 this plant ran on CONTACT == 3 -- the shared constrained step, stance code and all: - 19 % on the headline's batch with
+// nothing to stop.
+DEVFN void lds_put_state(const h1s::LaneLds& L, const h1s::HalfX& h) {
+#pragma unroll
+  for (int k = 0; k < 3; ++k) L[k] = h.p[k];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) L[3 + k] = h.quat[k];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) L[7 + k] = h.vb[k];
+  L[13] = h.q.th11; L[14] = h.q.qd11;
+#pragma unroll
+  for (int k = 0; k < 5; ++k) { L[15 + k] = h.q.thL[k]; L[20 + k] = h.q.qdL[k]; }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { L[25 + k] = h.q.thA[k]; L[29 + k] = h.q.qdA[k]; }
+}
+DEVFN void lds_get_state(const h1s::LaneLds& L, h1s::HalfX& h) {
+#pragma unroll
+  for (int k = 0; k < 3; ++k) h.p[k] = L[k];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) h.quat[k] = L[3 + k];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) h.vb[k] = L[7 + k];
+  h.q.th11 = L[13]; h.q.qd11 = L[14];
+#pragma unroll
+  for (int k = 0; k < 5; ++k) { h.q.thL[k] = L[15 + k]; h.q.qdL[k] = L[20 + k]; }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { h.q.thA[k] = L[25 + k]; h.q.qdA[k] = L[29 + k]; }
+}
+// second pass: the recursion with the hinges of `mask` acceleration-prescribed (no stance rows); in: L[0..32] state, L[33..42] controls,
+// L[43] the mask; out: L[0..5] base accelerations, L[6] torso, L[7..11] leg, L[12..15] arm hinge accelerations
+__device__ __attribute__((noinline)) void lim_second_pass_lds(double dt, double gx, double gy, double gz, double kr) {
+  const int lane = threadIdx.x;
+  const bool side = (lane & 1) != 0;
+  const h1s::LaneLds L{dyn_lds_c, 64, lane};
+  const double grav[3] = {gx, gy, gz};
+  h1s::HalfX h; h1s::HalfU u;
+  lds_get_state(L, h);
+  u.u11 = L[33];
+#pragma unroll
+  for (int k = 0; k < 5; ++k) u.uL[k] = L[34 + k];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) u.uA[k] = L[39 + k];
+  const unsigned mask = (unsigned)__double_as_longlong(L[43]);
+  double qh[4], R0[9]; h1s::HalfTau tau, add;
+  h1s::stance_prepare(side, h, u, qh, R0, tau);
+  h1s::apply_lock_mask(side, mask, h.q, dt, kr, tau, add);
+  double qb[6]; h1s::HalfAcc qa;
+  h1s::forward_dynamics<true>(side, R0, h.vb, h.q, tau, h1s::ARMATURE + dt * h1s::DAMPING, grav, L, qb, qa, nullptr, nullptr, &add);
+#pragma unroll
+  for (int k = 0; k < 6; ++k) L[k] = qb[k];
+  L[6] = qa.q11;
+#pragma unroll
+  for (int k = 0; k < 5; ++k) L[7 + k] = qa.qL[k];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) L[12 + k] = qa.qA[k];
+}
 // one step of either kind; `st` = stance flags (left, right) of the knot being stepped
 // (compile-time switch: the constraint-free instantiation of a kernel contains no call and no address-taken state -- with a
 // run-time branch the mere presence of the call cost the headline's line search 20 %)
@@ -137,7 +198,38 @@ DEVFN void pin_half_u(h1s::HalfU& u) {
 // every kilobyte of it (1.4 -> 1.8 KB per lane: -0.7 % on the contact bench, -> 4 KB: -4 %, same machine code otherwise).
 template <int CONTACT>
 DEVFN void step_any(bool side, h1s::HalfX& h, const h1s::HalfU& u, const DynParams& dyn, const int* st, const h1s::LaneLds& L) {
-  if constexpr (CONTACT == 4) step_stance_shared_kin_lim(&h, &u, dyn.h, dyn.g[0], dyn.g[1], dyn.g[2], dyn.soft, st[0], st[1], dyn.mu, dyn.lim_k);
+  if constexpr (CONTACT == 5) {
+    double dt = dyn.h; asm volatile("" : "+s"(dt));
+    h1s::HalfU uo = u;
+    pin_half(h); pin_half_u(uo);
+    double qh[4], R0[9]; h1s::HalfTau tau;
+    h1s::stance_prepare(side, h, uo, qh, R0, tau);
+    double qb[6]; h1s::HalfAcc qa;
+    h1s::forward_dynamics(side, R0, h.vb, h.q, tau, h1s::ARMATURE + dt * h1s::DAMPING, dyn.g, L, qb, qa);
+    const unsigned mask = h1s::limit_lock_mask(side, h.q, qa, dt, dyn.lim_k);
+    const bool any = mask != 0u;
+    // (inlined in this branch instead, the second pass made a 1.7 KB private segment with 526 spilled registers: measured, dropped)
+    if (h1s::xch_flag(any) || any) {      // (the pair runs the recursion together)
+      lds_put_state(L, h);
+      L[33] = uo.u11;
+#pragma unroll
+      for (int k = 0; k < 5; ++k) L[34 + k] = uo.uL[k];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) L[39 + k] = uo.uA[k];
+      L[43] = __longlong_as_double((long long)mask);
+      lim_second_pass_lds(dt, dyn.g[0], dyn.g[1], dyn.g[2], dyn.lim_k);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) qb[k] = L[k];
+      qa.q11 = L[6];
+#pragma unroll
+      for (int k = 0; k < 5; ++k) qa.qL[k] = L[7 + k];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) qa.qA[k] = L[12 + k];
+    }
+    h1s::integrate_half(h, qh, qb, qa, dt);
+    pin_half(h);
+  }
+  else if constexpr (CONTACT == 4) step_stance_shared_kin_lim(&h, &u, dyn.h, dyn.g[0], dyn.g[1], dyn.g[2], dyn.soft, st[0], st[1], dyn.mu, dyn.lim_k);
   else if constexpr (CONTACT == 3) step_stance_shared_lim(&h, &u, dyn.h, dyn.g[0], dyn.g[1], dyn.g[2], dyn.soft, dyn.contact, st[0], st[1], dyn.mu, dyn.lim_k);
   else if constexpr (CONTACT == 2) step_stance_shared_kin(&h, &u, dyn.h, dyn.g[0], dyn.g[1], dyn.g[2], dyn.soft, st[0], st[1], dyn.mu);
   else if constexpr (CONTACT == 1) step_stance_shared(&h, &u, dyn.h, dyn.g[0], dyn.g[1], dyn.g[2], dyn.soft, dyn.contact, st[0], st[1], dyn.mu);
@@ -622,30 +714,39 @@ int dyn_split_kernels_set_attr() {
   rc |= hipFuncSetAttribute((const void*)k_line_search_s<3, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess;
   rc |= hipFuncSetAttribute((const void*)k_line_search_s<4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess;
   rc |= hipFuncSetAttribute((const void*)k_line_search_s<4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess;
+  rc |= hipFuncSetAttribute((const void*)k_line_search_s<5, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess;
+  rc |= hipFuncSetAttribute((const void*)k_line_search_s<5, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess;
   rc |= hipFuncSetAttribute((const void*)k_rollout_s<0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess;
   rc |= hipFuncSetAttribute((const void*)k_rollout_s<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess;
   rc |= hipFuncSetAttribute((const void*)k_rollout_s<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess;
   rc |= hipFuncSetAttribute((const void*)k_rollout_s<3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess;
   rc |= hipFuncSetAttribute((const void*)k_rollout_s<4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess;
+  rc |= hipFuncSetAttribute((const void*)k_rollout_s<5>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess;
   rc |= hipFuncSetAttribute((const void*)k_step_s<0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess;
   rc |= hipFuncSetAttribute((const void*)k_step_s<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess;
   rc |= hipFuncSetAttribute((const void*)k_step_s<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess;
   rc |= hipFuncSetAttribute((const void*)k_step_s<3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess;
   rc |= hipFuncSetAttribute((const void*)k_step_s<4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess;
+  rc |= hipFuncSetAttribute((const void*)k_step_s<5>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess;
   rc |= hipFuncSetAttribute((const void*)k_last_step_s<0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess;
   rc |= hipFuncSetAttribute((const void*)k_last_step_s<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess;
   rc |= hipFuncSetAttribute((const void*)k_last_step_s<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess;
   rc |= hipFuncSetAttribute((const void*)k_last_step_s<3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess;
   rc |= hipFuncSetAttribute((const void*)k_last_step_s<4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess;
+  rc |= hipFuncSetAttribute((const void*)k_last_step_s<5>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess;
   rc |= hipFuncSetAttribute((const void*)k_fd_steps_s<0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess;
   rc |= hipFuncSetAttribute((const void*)k_fd_steps_s<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess;
   rc |= hipFuncSetAttribute((const void*)k_fd_steps_s<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess;
   rc |= hipFuncSetAttribute((const void*)k_fd_steps_s<3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess;
   rc |= hipFuncSetAttribute((const void*)k_fd_steps_s<4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess;
+  rc |= hipFuncSetAttribute((const void*)k_fd_steps_s<5>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess;
   rc |= hipFuncSetAttribute((const void*)k_lin_primal_s<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(DYN_LDS_BYTES_S + DUMP_STG_BYTES)) != hipSuccess;
   rc |= hipFuncSetAttribute((const void*)k_lin_primal_s<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(DYN_LDS_BYTES_S + DUMP_STG_BYTES)) != hipSuccess;
   return rc;
 }
+// CONTACT / CK of the kernels: 0 constraint-free; 1 / 2 stance rows (2: kinetic friction, mode 4); 3 / 4 the same with joint-limit rows;
+// 5 joint-limit rows on the constraint-free plant
+static int step_kind(const DynParams& d) { return !constrained(d) ? 0 : (d.contact == 0 ? 5 : (d.contact == 4 ? 2 : 1) + (d.limits ? 2 : 0)); }
 #ifndef LS_RPW1_MAX_BATCH
 #define LS_RPW1_MAX_BATCH 1024      // one wave per SIMD on the 1024 SIMDs of an MI355X
 #endif
@@ -654,10 +755,11 @@ void launch_line_search_s(const DevState& S, const ProblemDev& P, int mode, hipS
   // host knows an upper bound of the compacted list's length (the selected rollouts are its first entries: blocks past the
   // list's true count leave at once); the results do not depend on the choice
   const int nsel = (list && max_rollouts >= 0 && max_rollouts < S.B) ? max_rollouts : S.B;
-  const int ck = constrained(P.dyn) ? (P.dyn.contact == 4 ? 2 : 1) + (P.dyn.limits ? 2 : 0) : 0;      // the CONTACT value of step_any
+  const int ck = step_kind(P.dyn);      // the CONTACT value of step_any
   if (nsel <= LS_RPW1_MAX_BATCH) {
     const int blocks = nsel > 0 ? nsel : 1;
-    if (ck == 4) hipLaunchKernelGGL((k_line_search_s<4, 1>), dim3(blocks), dim3(64), DYN_LDS_BYTES_S, st, S, P, mode, list, count);
+    if (ck == 5) hipLaunchKernelGGL((k_line_search_s<5, 1>), dim3(blocks), dim3(64), DYN_LDS_BYTES_S, st, S, P, mode, list, count);
+    else if (ck == 4) hipLaunchKernelGGL((k_line_search_s<4, 1>), dim3(blocks), dim3(64), DYN_LDS_BYTES_S, st, S, P, mode, list, count);
     else if (ck == 3) hipLaunchKernelGGL((k_line_search_s<3, 1>), dim3(blocks), dim3(64), DYN_LDS_BYTES_S, st, S, P, mode, list, count);
     else if (ck == 2) hipLaunchKernelGGL((k_line_search_s<2, 1>), dim3(blocks), dim3(64), DYN_LDS_BYTES_S, st, S, P, mode, list, count);
     else if (ck == 1) hipLaunchKernelGGL((k_line_search_s<1, 1>), dim3(blocks), dim3(64), DYN_LDS_BYTES_S, st, S, P, mode, list, count);
@@ -665,7 +767,8 @@ void launch_line_search_s(const DevState& S, const ProblemDev& P, int mode, hipS
     return;
   }
   const dim3 grid(cdiv_s((long)S.B * 16, 64));
-  if (ck == 4) hipLaunchKernelGGL((k_line_search_s<4, 4>), grid, dim3(64), DYN_LDS_BYTES_S, st, S, P, mode, list, count);
+  if (ck == 5) hipLaunchKernelGGL((k_line_search_s<5, 4>), grid, dim3(64), DYN_LDS_BYTES_S, st, S, P, mode, list, count);
+  else if (ck == 4) hipLaunchKernelGGL((k_line_search_s<4, 4>), grid, dim3(64), DYN_LDS_BYTES_S, st, S, P, mode, list, count);
   else if (ck == 3) hipLaunchKernelGGL((k_line_search_s<3, 4>), grid, dim3(64), DYN_LDS_BYTES_S, st, S, P, mode, list, count);
   else if (ck == 2) hipLaunchKernelGGL((k_line_search_s<2, 4>), grid, dim3(64), DYN_LDS_BYTES_S, st, S, P, mode, list, count);
   else if (ck == 1) hipLaunchKernelGGL((k_line_search_s<1, 4>), grid, dim3(64), DYN_LDS_BYTES_S, st, S, P, mode, list, count);
@@ -678,10 +781,10 @@ void launch_lin_primal_s(const DevState& S, const ProblemDev& P, int mode, hipSt
   if (P.dyn.limits) hipLaunchKernelGGL(k_lin_primal_s<true>, dim3(waves), dim3(64), DYN_LDS_BYTES_S + (direct ? 0 : DUMP_STG_BYTES), st, S, P, mode, list, count, direct);
   else hipLaunchKernelGGL(k_lin_primal_s<false>, dim3(waves), dim3(64), DYN_LDS_BYTES_S + (direct ? 0 : DUMP_STG_BYTES), st, S, P, mode, list, count, direct);
 }
-static int step_kind(const DynParams& d) { return constrained(d) ? (d.contact == 4 ? 2 : 1) + (d.limits ? 2 : 0) : 0; }      // CK of the kernels below
 void launch_step_s(int count, const double* x, const double* u, const DynParams& dyn, double* xn, hipStream_t st, int stance_l, int stance_r) {
   const dim3 grid(cdiv_s((long)count * 2, 64));
   switch (step_kind(dyn)) {
+    case 5: hipLaunchKernelGGL(k_step_s<5>, grid, dim3(64), DYN_LDS_BYTES_S, st, count, x, u, dyn, xn, stance_l, stance_r); break;
     case 4: hipLaunchKernelGGL(k_step_s<4>, grid, dim3(64), DYN_LDS_BYTES_S, st, count, x, u, dyn, xn, stance_l, stance_r); break;
     case 3: hipLaunchKernelGGL(k_step_s<3>, grid, dim3(64), DYN_LDS_BYTES_S, st, count, x, u, dyn, xn, stance_l, stance_r); break;
     case 2: hipLaunchKernelGGL(k_step_s<2>, grid, dim3(64), DYN_LDS_BYTES_S, st, count, x, u, dyn, xn, stance_l, stance_r); break;
@@ -692,6 +795,7 @@ void launch_step_s(int count, const double* x, const double* u, const DynParams&
 void launch_last_step_s(const DevState& S, const ProblemDev& P, hipStream_t st) {
   const dim3 grid(cdiv_s((long)S.B * 2, 64));
   switch (step_kind(P.dyn)) {
+    case 5: hipLaunchKernelGGL(k_last_step_s<5>, grid, dim3(64), DYN_LDS_BYTES_S, st, S, P); break;
     case 4: hipLaunchKernelGGL(k_last_step_s<4>, grid, dim3(64), DYN_LDS_BYTES_S, st, S, P); break;
     case 3: hipLaunchKernelGGL(k_last_step_s<3>, grid, dim3(64), DYN_LDS_BYTES_S, st, S, P); break;
     case 2: hipLaunchKernelGGL(k_last_step_s<2>, grid, dim3(64), DYN_LDS_BYTES_S, st, S, P); break;
@@ -703,6 +807,7 @@ void launch_linearize_fd_s(const DevState& S, const ProblemDev& P, int mode, dou
   const int dd = (int)lin_dump_doubles();
   const dim3 grid(cdiv_s((long)S.B * S.N * FD_NCOL * 2, 64));
   switch (step_kind(P.dyn)) {
+    case 5: hipLaunchKernelGGL(k_fd_steps_s<5>, grid, dim3(64), DYN_LDS_BYTES_S, st, S, P, mode, eps, dd); break;
     case 4: hipLaunchKernelGGL(k_fd_steps_s<4>, grid, dim3(64), DYN_LDS_BYTES_S, st, S, P, mode, eps, dd); break;
     case 3: hipLaunchKernelGGL(k_fd_steps_s<3>, grid, dim3(64), DYN_LDS_BYTES_S, st, S, P, mode, eps, dd); break;
     case 2: hipLaunchKernelGGL(k_fd_steps_s<2>, grid, dim3(64), DYN_LDS_BYTES_S, st, S, P, mode, eps, dd); break;
@@ -714,7 +819,8 @@ void launch_linearize_fd_s(const DevState& S, const ProblemDev& P, int mode, dou
 void launch_rollout_s(const DevState& S, const ProblemDev& P, int mode, int do_roll, int count_iter, double* cost_out, hipStream_t st) {
   const dim3 grid(cdiv_s((long)S.B * 2, 64));
   const int ck = step_kind(P.dyn);
-  if (do_roll && ck == 4) hipLaunchKernelGGL(k_rollout_s<4>, grid, dim3(64), DYN_LDS_BYTES_S, st, S, P, mode, count_iter);
+  if (do_roll && ck == 5) hipLaunchKernelGGL(k_rollout_s<5>, grid, dim3(64), DYN_LDS_BYTES_S, st, S, P, mode, count_iter);
+  else if (do_roll && ck == 4) hipLaunchKernelGGL(k_rollout_s<4>, grid, dim3(64), DYN_LDS_BYTES_S, st, S, P, mode, count_iter);
   else if (do_roll && ck == 3) hipLaunchKernelGGL(k_rollout_s<3>, grid, dim3(64), DYN_LDS_BYTES_S, st, S, P, mode, count_iter);
   else if (do_roll && ck == 2) hipLaunchKernelGGL(k_rollout_s<2>, grid, dim3(64), DYN_LDS_BYTES_S, st, S, P, mode, count_iter);
   else if (do_roll && ck == 1) hipLaunchKernelGGL(k_rollout_s<1>, grid, dim3(64), DYN_LDS_BYTES_S, st, S, P, mode, count_iter);

@@ -10,7 +10,7 @@ pkg = ge._load_package()
 from mpc_ilqr_mujoco_amd import solver as sv
 sc = pkg.scenario
 B, N = int(os.environ.get("ILQR_B", "4096")), 25
-prob = sc.make_problem(sv.reference_kinematics, N=N, gravity=(0.0, 0.0, -9.81))
+prob = sc.make_problem(sv.reference_kinematics, N=N, gravity=((0.0, 0.0, -9.81) if int(os.environ.get("CM", "2")) else None))
 ug = sv.gravity_compensation(sc.standing_state(), prob["gravity"])
 x0, ui = sc.synthetic_batch(B, N, 0, ug)
 s = sv.BatchedILQR(B, N=N); s.set_problem(prob); s.set_contact_mode(int(os.environ.get("CM", "2"))); s.set_joint_limits(os.environ.get("LIM", "0") == "1")
