@@ -20,6 +20,8 @@ s = sv.BatchedILQR(B, N=N)
 s.set_problem(prob)
 if CONTACT:
     s.set_contact_mode(CONTACT)
+if os.environ.get("ILQR_LIMITS"):        # joint-limit rows of the plant (the constraint-free plant then runs its CONTACT 5 kernels)
+    s.set_joint_limits(True)
 if os.environ.get("ILQR_LAMBDA"):
     s.set_regularization(float(os.environ["ILQR_LAMBDA"]))
 s.initialize(x0, ui)
