@@ -32,7 +32,7 @@ struct DevState {
   double* K;           // [B][N][19][51]
   double* kff;         // [B][N][19]
   double* lin_dump;    // [B][N][sizeof(KnotDump)/8] primal per-body quantities of every knot
-  double* quad_rec;    // per-knot records of the cost quadratics (k_quad_kin -> k_cost_quadratics; quad_rec_doubles(B (N + 1)), 16 knots interleaved per line)
+  double* quad_rec;    // per-knot records of the cost quadratics (k_quad_kin -> k_cost_quadratics; quad_rec_doubles(B (N + 1)), four knots per line in runs of four fields)
   long quad_knot0;     // index of this view's first knot in quad_rec (batch slices share the handle's buffer)
   double* Vx;          // [B][51]           value gradient at knot 0
   double* Vxx;         // [B][51][51]

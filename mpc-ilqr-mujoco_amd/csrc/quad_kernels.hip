@@ -8,9 +8,12 @@
 //                      the tree unrolled on compile-time body indices: ~50 wave instructions per knot instead of the ~2100 the
 //                      lane = body / lane = (set, body) / lane-0 phases of the one-kernel version issued (five tree levels with a
 //                      barrier each, 60 lanes looping over ancestor bitmasks, one lane pushing contexts while 127 wait: 37 k of
-//                      that kernel's 76 k cycles per knot).  It leaves a 468-double record per knot in HBM, 16 knots interleaved
-//                      per 128-byte line (field-major inside a group of 16 knots): every store instruction of a wave writes whole
-//                      lines.
+//                      that kernel's 76 k cycles per knot).  It leaves a 468-double record per knot in HBM, runs of FOUR
+//                      consecutive fields of a knot together and four knots per 128-byte line (QREC_RUN below): the reader's gather
+//                      is 117 line requests of 32 bytes per knot.  (Until round 6: one field per knot and 16 knots per line -- every
+//                      store instruction of the producer wrote whole lines, but the reader asked for 468 lines per knot, and that
+//                      work in the memory pipeline was 0.09 ms of its 1.1 per launch; runs of 8 or 16 lose it again on the
+//                      producer's side, whose store instructions then touch 32 / 64 lines each.)
 //   k_cost_quadratics  ONE TWO-WAVE WORKGROUP PER KNOT, the wide part: record -> LDS, then
 //                        1  wave 0, lane = coordinate: Jacobian columns of c and cdot of the three point sets, balance rows,
 //                           gradient lx (all per-column: no exchange);  wave 1, lane = (functional, joint): til x z_j, P'_j; lu, luu
@@ -20,7 +23,7 @@
 //                           in 8 of the 21 pairs of coordinate classes p | quat | theta | v_b | omega_b | thetadot only: those
 //                           entries are evaluated block by block into an LDS patch that the owner lanes of the accumulator tiles
 //                           add before they store lxx row by row (128-byte runs).
-//                      Workgroups are numbered so that the 16 knots sharing the lines of a record group run on one XCD (one L2).
+//                      Workgroups are numbered so that the knots sharing the lines of a record group run on one XCD (one L2).
 #include <hip/hip_runtime.h>
 
 #include "h1_cost_dev.h"
@@ -78,9 +81,16 @@ enum {
   QR_WF = 408,      // [2][5][3] w_j of the foot sets (their leg's five joints)
   QR_DGF = 438,     // [2][5][3]
   QREC_SIZE = 468,
-  QREC_GROUP = 16   // knots interleaved per group: field f of knot k at (k >> 4) * 468 * 16 + f * 16 + (k & 15)
+#ifndef QREC_G
+#define QREC_G 4
+#endif
+  QREC_RUN = QREC_G,                        // consecutive fields of one knot that lie together (a divisor of 16 and of 468)
+  QREC_KNOTS = 16 / QREC_RUN,               // knots sharing a 128-byte line
+  QREC_LINES = (QREC_SIZE + QREC_RUN - 1) / QREC_RUN    // lines of a group of QREC_KNOTS knots
+  // field f of knot k: double (k / QREC_KNOTS) * QREC_LINES * 16 + (f / QREC_RUN) * 16 + (k % QREC_KNOTS) * QREC_RUN + f % QREC_RUN
 };
-size_t quad_rec_doubles(size_t knots) { return ((knots + QREC_GROUP - 1) / QREC_GROUP) * (size_t)QREC_GROUP * QREC_SIZE; }
+static_assert(16 % QREC_RUN == 0 && QREC_RUN % 2 == 0, "record runs: whole lines, 16-byte pieces");
+size_t quad_rec_doubles(size_t knots) { return ((knots + QREC_KNOTS - 1) / QREC_KNOTS) * (size_t)QREC_LINES * 16; }
 
 // ---- k_quad_kin: compile-time model tables ------------------------------------------------------------------------------------
 struct QMassTab { double mu[H1_NB], msub[H1_NB], mtot; };
@@ -200,8 +210,8 @@ __global__ void __launch_bounds__(64) k_quad_kin(DevState S, ProblemDev P, const
   __syncthreads();
   const double* xg = xs + threadIdx.x * H1_NX;
   const long kn = knot0 + (long)b * N1 + t;
-  double* out = rec + (size_t)(kn >> 4) * ((size_t)QREC_SIZE * QREC_GROUP) + (kn & 15);
-  auto put = [&](int f, double v) { out[(size_t)f * QREC_GROUP] = v; };
+  double* out = rec + (size_t)(kn / QREC_KNOTS) * ((size_t)QREC_LINES * 16) + (kn % QREC_KNOTS) * QREC_RUN;
+  auto put = [&](int f, double v) { out[(f / QREC_RUN) * 16 + f % QREC_RUN] = v; };
   typedef decltype(put) PutT;
 
   // base: Pinocchio slot order of the quaternion (derivatives.cpp:12-24): xp[3..6] = (qx, qy, qz, qw)
@@ -389,7 +399,7 @@ __global__ void __launch_bounds__(64) k_quad_kin(DevState S, ProblemDev P, const
 enum { QJ_C = 0, QJ_V = 3, QJ_F0 = 6, QJ_F1 = 9, QJ_R0 = 12, QJ_R1 = 13, QJ_M = 14, QJ_ROWS = 15 };
 enum { QA_I9 = 0, QA_ZERO = 9, QA_UE = 12, QA_NBX = 39, QAUX_SIZE = 66 };   // LDS-only constants of phase 1a, right behind the record
 struct QuadLds {
-  double rec[QREC_SIZE];                     // the knot record
+  alignas(16) double rec[QREC_SIZE];         // the knot record
   double aux[QAUX_SIZE];                     // identity, zero vector, mfrac_s e_k, e_k x beta_s: operands of the uniform column formula
   union {
     struct { double J[QJ_ROWS][H1_NX]; };    // Jacobian rows: d c, d cdot of the CoM; the feet's; balance rows jr0, jr1, m
@@ -662,10 +672,11 @@ __global__ void __launch_bounds__(128, QUAD_WAVES) k_cost_quadratics(DevState S,
   {
     const int f1 = mode == MASK_ALL ? 1 : S.active[b], f2 = mode == MASK_RETRY ? S.need_retry[b] : 1;
     const long kn = knot0 + (long)b * N1 + t;
-    const double* rg = recg + (size_t)(kn >> 4) * ((size_t)QREC_SIZE * QREC_GROUP) + (kn & 15);
-    double rv[4];
+    const double* rg = recg + (size_t)(kn / QREC_KNOTS) * ((size_t)QREC_LINES * 16) + (kn % QREC_KNOTS) * QREC_RUN;
+    typedef double v2d_q __attribute__((ext_vector_type(2)));
+    v2d_q rv[2];                                                              // 16-byte pieces lane and lane + 128 of the record's 234
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { const int f = lane + 128 * k; rv[k] = rg[(size_t)(f < QREC_SIZE ? f : QREC_SIZE - 1) * QREC_GROUP]; }
+    for (int k = 0; k < 2; ++k) { int f = 2 * (lane + 128 * k); f = f < QREC_SIZE ? f : QREC_SIZE - 2; rv[k] = *reinterpret_cast<const v2d_q*>(rg + (f / QREC_RUN) * 16 + f % QREC_RUN); }
     const int a = lane < H1_NX ? lane : 0;
     xv = xg[a]; xrv = (P.x_ref + b * P.x_ref_stride + t * H1_NX)[a]; qdv = Qd[a];
     const int l1 = lane - 64, iu = (l1 >= 0 && l1 < H1_NU) ? l1 : 0, tu = term ? N - 1 : t;
@@ -689,18 +700,19 @@ __global__ void __launch_bounds__(128, QUAD_WAVES) k_cost_quadratics(DevState S,
     const unsigned pkw = QPK.w[lane & 63];
     if (!(f1 && f2)) return;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { const int f = lane + 128 * k; if (f < QREC_SIZE) L.rec[f] = rv[k]; }
+    for (int k = 0; k < 2; ++k) { const int f = 2 * (lane + 128 * k); if (f < QREC_SIZE) *reinterpret_cast<v2d_q*>(&L.rec[f]) = rv[k]; }
     if (lane < 64) L.pk[lane] = pkw;
     // constants of the uniform column formula (QColTable): identity and zero vector; mfrac_s e_k and e_k x beta_s from the lanes that
     // hold mfrac_s (field 60 + s: lane 60 + s, k = 0) and beta_s[j] (field 64 + 3 s + j: lane 64 + 3 s + j, k = 0)
     if (lane < QAUX_SIZE) L.aux[lane] = (lane < 9 && lane % 4 == 0) ? 1.0 : 0.0;     // (everything else starts as zero; the writes below land behind the wave barrier)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    if (lane >= QR_MFRAC && lane < QR_MFRAC + 3) { const int s_ = lane - QR_MFRAC; L.aux[QA_UE + 9 * s_] = rv[0]; L.aux[QA_UE + 9 * s_ + 4] = rv[0]; L.aux[QA_UE + 9 * s_ + 8] = rv[0]; }
+    if (lane >= QR_MFRAC && lane < QR_MFRAC + 3) { const int s_ = lane - QR_MFRAC; const double mf = L.rec[lane]; L.aux[QA_UE + 9 * s_] = mf; L.aux[QA_UE + 9 * s_ + 4] = mf; L.aux[QA_UE + 9 * s_ + 8] = mf; }
     if (lane >= QR_BETA && lane < QR_BETA + 9) {
       const int s_ = (lane - QR_BETA) / 3, j = (lane - QR_BETA) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
       // (e_k x beta)_i = eps_ikj beta_j: (i, k) = (j + 1, j + 2) -> +beta_j, (j + 2, j + 1) -> -beta_j
-      L.aux[QA_NBX + 9 * s_ + 3 * j2 + j1] = rv[0];
-      L.aux[QA_NBX + 9 * s_ + 3 * j1 + j2] = -rv[0];
+      const double bj = L.rec[lane];
+      L.aux[QA_NBX + 9 * s_ + 3 * j2 + j1] = bj;
+      L.aux[QA_NBX + 9 * s_ + 3 * j1 + j2] = -bj;
     }
   }
   __syncthreads();
