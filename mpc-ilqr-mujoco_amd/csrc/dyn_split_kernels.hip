@@ -290,7 +290,6 @@ __global__ void __launch_bounds__(64) k_line_search_s(DevState S, ProblemDev P, 
   const int N = S.N, n = H1_NX, m = H1_NU;
   const double alpha = ALPHAS_S[ai];
   h1s::HalfX h; h1s::load_half(side, S.x0 + (size_t)b * n, h);
-  if (live) h1s::store_half(side, h, S.xcand + ((size_t)b * 8 + ai) * (N + 1) * n);
 #ifdef LS_STAMP
   long long ph[8] = {0}; long long tl = clock64();
 #endif
@@ -418,14 +417,42 @@ __global__ void __launch_bounds__(64) k_line_search_s(DevState S, ProblemDev P, 
     __syncthreads();   // the dynamics step below reuses these LDS rows
     u.u11 = h1s::pair_sum(u.u11);     // torso control: from the left lane to both
     LSS(1)
+    // x_t leaves HERE, behind the step's loads and beside its controls -- not at the end of the step that produced it: vector-memory
+    // operations retire in order, so the next step's loads (requested a few instructions later) waited for these 33 scattered stores
+    // (each touches 32 lines) to be acknowledged: 0.11 of the kernel's 0.70 ms.  From here the dynamics step covers them.
+    if constexpr (RPW == 4) {
+      // ... and as whole rows: a lane's own stores put 8 bytes into each of 32 candidates' rows per instruction (33 instructions x 32
+      // lines through the CU's one address unit, for each of its four waves: 0.1 of the kernel's 0.70 ms).  The wave parks its 32 rows
+      // in LDS (free between the feedback and the dynamics step) and writes each out with lanes 0..50 on consecutive doubles; which
+      // rollout a row belongs to, and whether it is selected, are wave-uniform per row (scalar address arithmetic).
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      h1s::store_half(side, h, lds + (lane >> 1) * n);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      const int lv = live ? 1 : 0;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int br = __builtin_amdgcn_readlane(bt, 16 * r), lr = __builtin_amdgcn_readlane(lv, 16 * r);
+        if (lr) {
+          double* row0 = S.xcand + ((size_t)br * 8 * (N + 1) + t) * n;
+#pragma unroll
+          for (int a = 0; a < 8; ++a) {
+            const double v = lds[(8 * r + a) * n + (lane < n ? lane : 0)];
+            if (lane < n) (row0 + (size_t)a * (N + 1) * n)[lane] = v;
+          }
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    } else {
+      if (live) h1s::store_half(side, h, xc + t * n);
+    }
     LSS(2)
     int sd = side; asm volatile("" : "+v"(sd));          // (see k_rollout_s)
     const bool side_t = sd != 0;
     step_any<CONTACT>(side_t, h, u, P.dyn, P.stance + b * P.stance_stride + 2 * t, L);
     LSS(3)
-    if (live) h1s::store_half(side, h, xc + (t + 1) * n);
     LSS(4)
   }
+  if (live) h1s::store_half(side, h, S.xcand + (((size_t)b * 8 + ai) * (N + 1) + N) * n);
   // the candidates' costs are evaluated afterwards, all knots in parallel (launch_cand_costs, dyn_kernels.hip)
 #ifdef LS_STAMP
   if (gid == 0) for (int q = 0; q < 8; ++q) S.J[q] = (double)ph[q];
@@ -447,7 +474,7 @@ __global__ void __launch_bounds__(64) k_rollout_s(DevState S, ProblemDev P, int 
   const double* ub = S.ubar + (size_t)b * N * H1_NU;
   if (count_iter && !side) S.iters[b] += 1;
   h1s::HalfX h;
-  h1s::load_half(side, S.x0 + (size_t)b * H1_NX, h); h1s::store_half(side, h, xb);
+  h1s::load_half(side, S.x0 + (size_t)b * H1_NX, h);
   for (int t = 0; t < N; ++t) {
     h1s::HalfU u;
     u.u11 = ub[t * H1_NU + 10];
@@ -455,13 +482,14 @@ __global__ void __launch_bounds__(64) k_rollout_s(DevState S, ProblemDev P, int 
     for (int k = 0; k < 5; ++k) u.uL[k] = ub[t * H1_NU + h1s::jleg(side, k)];
 #pragma unroll
     for (int k = 0; k < 4; ++k) u.uA[k] = ub[t * H1_NU + h1s::jarm(side, k)];
+    h1s::store_half(side, h, xb + t * H1_NX);       // x_t: behind the step's loads (see k_line_search_s)
     // the side is re-derived behind an opaque barrier every step: otherwise the ~120 per-lane body constants `side ? right : left`
     // are hoisted out of the knot loop as loop invariants, spilled, and fetched back from scratch every step
     int sd = side; asm volatile("" : "+v"(sd));
     const bool side_t = sd != 0;
     step_any<CONTACT>(side_t, h, u, P.dyn, P.stance + b * P.stance_stride + 2 * t, L);
-    h1s::store_half(side, h, xb + (t + 1) * H1_NX);
   }
+  h1s::store_half(side, h, xb + (size_t)N * H1_NX);
 }
 // ---- primal dump of the analytic linearisation on two lanes per knot (replaces k_lin_primal_r, dyn_kernels.hip, wherever the
 // two-lane kernels run): forward dynamics of the nominal knot, every body's velocity / acceleration / sin, cos / U / 1/D, the base
