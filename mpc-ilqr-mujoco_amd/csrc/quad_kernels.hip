@@ -590,7 +590,9 @@ DEVFN void quad_tile_out_pk(const v4d_q& acc, const double* S2, const double* dg
     }
     out[r] = h;
   }
-  *reinterpret_cast<v4d_q*>(Hp + pk_l_tile(I, J) * 256 + lane64 * 4) = out;
+  typedef double v2d_t __attribute__((ext_vector_type(2)));
+  v2d_t* tp = reinterpret_cast<v2d_t*>(Hp + pk_l_tile(I, J) * 256) + lane64;        // (pk_l_elem: registers 0, 1 | registers 2, 3)
+  tp[0] = (v2d_t){out[0], out[1]}; tp[64] = (v2d_t){out[2], out[3]};
 }
 // low: 0 whole matrix, 1 the tiles I >= J in the standard layout, 2 the tiles I >= J in the operand layout
 template <int WV>

@@ -52,6 +52,11 @@ __host__ __device__ constexpr bool pk_row_slot(int s) { return s >= 32 && !(s >=
 __host__ __device__ constexpr int pk_a_index(int R, int C) { return (C >> 4) * 512 + (R - 32) * 16 + (C & 15); }
 __host__ __device__ constexpr int pk_b_index(int R, int u) { return (R - 32) * 16 + u; }
 __host__ __device__ constexpr int pk_l_tile(int I, int J) { return I * (I + 1) / 2 + J; }
-__host__ __device__ constexpr int pk_l_index(int R, int C) { return pk_l_tile(R >> 4, C >> 4) * 256 + ((R & 3) * 16 + (C & 15)) * 4 + ((R >> 2) & 3); }
+// element (row 4 r + lk, column lr) of a tile: register r of lane 16 lk + lr in the MFMA accumulator layout.  Registers 0, 1 of the 64 lanes
+// form the tile's first kilobyte, registers 2, 3 its second: a lane's 32 bytes leave (and arrive) as two 16-byte accesses, and with the four
+// registers of a lane side by side each of the two instructions touched every other 16-byte chunk of the tile -- every 64-byte segment
+// written twice, half at a time (twice the write requests of the cost-quadratics kernel, its address unit 40 % of the time waiting for L2)
+__host__ __device__ constexpr int pk_l_elem(int lane, int r) { return (r >> 1) * 128 + lane * 2 + (r & 1); }
+__host__ __device__ constexpr int pk_l_index(int R, int C) { return pk_l_tile(R >> 4, C >> 4) * 256 + pk_l_elem((R & 3) * 16 + (C & 15), (R >> 2) & 3); }
 
 }  // namespace ilqr

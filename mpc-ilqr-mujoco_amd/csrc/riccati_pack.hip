@@ -176,9 +176,10 @@ __device__ __forceinline__ void pload_b0(double (&b0)[8], const double* Bp, int 
   for (int s = 0; s < 8; ++s) b0[s] = Bp[64 * s + lane];
 }
 __device__ __forceinline__ void pload_q(v4d (&Q)[10], const double* Lp, int lane) {
-  const v4d* p = reinterpret_cast<const v4d*>(Lp) + lane;
+  typedef double v2d_t __attribute__((ext_vector_type(2)));
+  const v2d_t* p = reinterpret_cast<const v2d_t*>(Lp) + lane;                          // (pk_l_elem: registers 0, 1 | registers 2, 3)
 #pragma unroll
-  for (int t = 0; t < 10; ++t) Q[t] = p[64 * t];
+  for (int t = 0; t < 10; ++t) { const v2d_t a = p[128 * t], c = p[128 * t + 64]; Q[t] = (v4d){a.x, a.y, c.x, c.y}; }
 }
 __device__ __forceinline__ void put_tile(double* T, const v4d& q, int lk, int lr) {
 #pragma unroll
@@ -604,7 +605,7 @@ __global__ void __launch_bounds__(256) k_pack_lxx(DevState S) {
   for (int e = threadIdx.x; e < PN * PN; e += 256) sh[e] = Hg[e];
   __syncthreads();
   for (int e = threadIdx.x; e < PK_L_DOUBLES; e += 256) {
-    const int tile = e >> 8, lane = (e >> 2) & 63, r = e & 3;
+    const int tile = e >> 8, lane = (e >> 1) & 63, r = 2 * ((e >> 7) & 1) + (e & 1);       // (pk_l_elem)
     int I = 0; while (pk_l_tile(I + 1, 0) <= tile) ++I;
     const int J = tile - pk_l_tile(I, 0);
     const int sr = pk_slot_state(16 * I + 4 * r + (lane >> 4)), sc = pk_slot_state(16 * J + (lane & 15));

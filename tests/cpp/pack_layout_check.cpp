@@ -30,7 +30,14 @@ int main() {
   for (int R = 0; R < 64; ++R) for (int C = 0; C <= R; ++C) if ((C >> 4) <= (R >> 4)) { const int i = pk_l_index(R, C); chk(i >= 0 && i < PK_L_DOUBLES, "lxx~ index range"); il.insert(i); }
   chk(PK_L_DOUBLES + 7 <= 51 * 51 && PK_B_DOUBLES + 7 <= 51 * 19, "images fit their regions");
   // tile (I, J) register r lane (lk, lr) <-> element (16 I + 4 r + lk, 16 J + lr)
-  chk(pk_l_index(16 * 3 + 4 * 2 + 1, 16 * 1 + 5) == pk_l_tile(3, 1) * 256 + (1 * 16 + 5) * 4 + 2, "accumulator image order");
+  // (registers 0, 1 of the 64 lanes are the tile's first kilobyte, registers 2, 3 its second: pk_l_elem)
+  chk(pk_l_index(16 * 3 + 4 * 2 + 1, 16 * 1 + 5) == pk_l_tile(3, 1) * 256 + 128 + (1 * 16 + 5) * 2 + 0, "accumulator image order");
+  chk(pk_l_index(16 * 2 + 4 * 1 + 3, 16 * 2 + 9) == pk_l_tile(2, 2) * 256 + (3 * 16 + 9) * 2 + 1, "accumulator image order (first half)");
+  {
+    std::set<int> one;
+    for (int lane = 0; lane < 64; ++lane) for (int r = 0; r < 4; ++r) { const int i = pk_l_elem(lane, r); chk(i >= 0 && i < 256, "tile element range"); one.insert(i); }
+    chk(one.size() == 256, "tile elements distinct");
+  }
   std::printf(fails ? "pack layout: %d failures\n" : "pack layout ok\n", fails);
   return fails ? 1 : 0;
 }

@@ -1,12 +1,11 @@
 #!/bin/bash
-# PMC counters of one stage at the bench size: tools/pmc_stage.sh <stage> "<counters>" [outname]
-# (a counter set the hardware cannot collect in one pass -- e.g. more than two TA_* counters -- aborts rocprofv3 and leaves the child
-# hanging: the run is bounded by `timeout`)
+# PMC counters of every kernel of one bench step (the solve's own launches: operand layout, concurrent region):
+# tools/pmc_bench.sh "<counters>" [outname] [bench args...]   (at most two counters of one block per pass; bounded by `timeout`)
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-stage=$1; ctrs=$2; name=${3:-pmc_$stage}
+ctrs=$1; name=${2:-pmc_bench}; shift; shift
 out=gpurun_out/$name
 rm -rf "$out"; mkdir -p "$out"
-timeout -k 10 ${PMC_TIMEOUT:-150} rocprofv3 --pmc $ctrs --output-format csv -d "$out" -o c -- python3 tools/time_stage.py "$stage" 2 > "$out/run.log" 2>&1
+timeout -k 10 ${PMC_TIMEOUT:-200} rocprofv3 --pmc $ctrs --output-format csv -d "$out" -o c -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-contact-line --no-fd-line "$@" > "$out/run.log" 2>&1
 python3 - "$out" <<'PY'
 import csv, glob, sys, collections
 fs = glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True)
