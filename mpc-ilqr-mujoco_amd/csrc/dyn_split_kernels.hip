@@ -308,10 +308,10 @@ __global__ void __launch_bounds__(64) k_line_search_s(DevState S, ProblemDev P, 
     double* xc = S.xcand + ((size_t)bt * 8 + ai) * (N + 1) * n;
     double* uc = S.ucand + ((size_t)bt * 8 + ai) * N * m;
     const double* xbt = xb + t * n;
-    // ---- everything this step reads from HBM, requested in ONE batch at the very top: the K_t operands of the wave's first two
-    // rollouts (MFMA feedback below; left to itself the scheduler sinks these 52 loads down to their first use, behind the state
-    // exchange and its barrier -- a second exposed HBM round trip per step), then this lane's half of the nominal state (for
-    // x - xbar), nominal control and feedforward.  The scheduling fence keeps the order of issue.
+    // ---- everything this step reads from HBM, requested in ONE batch at the very top: this lane's half of the nominal state (for
+    // x - xbar), nominal control and feedforward, then the K_t operands of the wave's rollouts (MFMA feedback below; left to itself the
+    // scheduler sinks these loads down to their first use, behind the state exchange and its barrier -- a second exposed HBM round
+    // trip per step).  The scheduling fences keep the order of issue.
     typedef double v2d_s __attribute__((ext_vector_type(2), aligned(8)));      // rows of K_t have an odd pitch (51 doubles): the pairs are 8-byte aligned only
     // ---- U_r = K_t,r dX_r on v_mfma_f64_4x4x4_4b_f64: FOUR independent 4 x 4 x 4 products per instruction (16 cycles).  Lane layout
     // (tools/probes/mfma_f64_4x4x4_layout.hip): block = (lane >> 2) & 3;  A[i][k] at i = lane & 3, k = lane >> 4;  B[k][n] at k = lane >> 4,
@@ -330,6 +330,15 @@ __global__ void __launch_bounds__(64) k_line_search_s(DevState S, ProblemDev P, 
     constexpr int NG = RPW == 4 ? 5 : 2;                                     // row groups a lane works on
     const int bk = RPW == 4 ? __shfl(bt, 16 * mb) : bt;                      // rollout of this lane's block
     const double* Kt = S.K + ((size_t)bk * N + t) * m * n;
+    // (the nominal state / control / feedforward FIRST: vector-memory results return in issue order, and the state exchange below only
+    // needs these -- requested behind the 35 K_t loads it waited for all of them)
+    h1s::HalfX xh; h1s::HalfU ubh, kfh;
+    h1s::load_half(side, xbt, xh);
+    load_half_u(side, ub + t * m, ubh);
+    load_half_u(side, kg + t * m, kfh);
+#ifndef LS_NO_HOIST
+    __builtin_amdgcn_sched_barrier(0);
+#endif
     v2d_s ka[NG][6];
     double kt[NG];
 #pragma unroll
@@ -340,10 +349,6 @@ __global__ void __launch_bounds__(64) k_line_search_s(DevState S, ProblemDev P, 
       for (int j = 0; j < 6; ++j) ka[g][j] = *reinterpret_cast<const v2d_s*>(Kt + off + 8 * j + 2 * mk);
       kt[g] = Kt[off + 48 + (mk < 3 ? mk : 2)];                               // (column 51 does not exist: a valid load, zeroed below)
     }
-    h1s::HalfX xh; h1s::HalfU ubh, kfh;
-    h1s::load_half(side, xbt, xh);
-    load_half_u(side, ub + t * m, ubh);
-    load_half_u(side, kg + t * m, kfh);
 #ifndef LS_NO_HOIST
     __builtin_amdgcn_sched_barrier(0);
 #endif
