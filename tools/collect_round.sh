@@ -98,6 +98,11 @@ PY
   rm -rf "$out/alone_$st"
 done
 echo "[collect] stage kernels alone done"
+# address-unit counters of every kernel of a bench step (two passes: the TA block offers two counters at a time)
+bash tools/pmc_bench.sh "TA_TA_BUSY_sum TA_DATA_STALLED_BY_TC_CYCLES_sum GRBM_GUI_ACTIVE" ta1_$tag > /dev/null 2>&1 || true
+bash tools/pmc_bench.sh "TA_ADDR_STALLED_BY_TC_CYCLES_sum TCP_TCC_WRITE_REQ_sum TCP_TCC_READ_REQ_sum" ta2_$tag > /dev/null 2>&1 || true
+python3 tools/ta_table.py gpurun_out/ta1_$tag/c_counter_collection.csv gpurun_out/ta2_$tag/c_counter_collection.csv > "$out/${tag}_address_unit_counters.txt" 2>/dev/null || true
+echo "[collect] address-unit counters done"
 python3 tools/kernel_resources.py > "$out/${tag}_kernel_resources.txt" 2>/dev/null || true
 ( cd mpc-ilqr-mujoco_amd/lib && ls -l libilqr_hip.so libilqr_hip_legacy.so | awk '{print $5, $9}' ) > "$out/${tag}_library_sizes.txt"
 python3 tools/round_summary.py "$out" "$tag" "${ILQR_GIT_HEAD:-unknown}" > "$out/${tag}_summary.md"
